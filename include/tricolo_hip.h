@@ -1,0 +1,116 @@
+/* tricolo_hip.h - C ABI of libtricolo_hip.so: the MI355X (gfx950) kernels under the TriCoLo training step.
+ *
+ * The reference (3dlg-hcvc/tricolo) is pure Python and has no FFI; its hot path bottoms out in third-party native
+ * code (spconv, cuDNN via torchvision / torch.nn, cuBLAS).  This library is what sits under the reference's
+ * encoder / loss modules instead (last row).  Each entry point names the reference call site
+ * whose native work it replaces (paths relative to /root/reference).
+ *
+ * Conventions: plain pointers + sizes, all pointers are DEVICE pointers unless noted; `stream` is a hipStream_t
+ * passed as void*; every call is asynchronous on that stream, allocates nothing, keeps no global state and returns
+ * 0 on success, a hipError_t (>0) or a negative TRI_ERR_* code otherwise (text via tri_last_error()).  Activations
+ * are channels-last fp32: [B, D, H, W, C] (2D tensors use D = 1), C a multiple of 4.
+ */
+#ifndef TRICOLO_HIP_H
+#define TRICOLO_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int tri_version(void);
+const char* tri_last_error(void);
+
+/* Geometry of one convolution / dense layer.  Linear(in,out) is KD=KH=KW=1 on a 1x1x1 grid with B = rows. */
+typedef struct TriConvDesc {
+    int B, ID, IH, IW, Cin;   /* input grid, stored input channels (multiple of 4; 3-channel inputs are stored as 4) */
+    int OD, OH, OW, Cout;     /* output grid, output channels (multiple of 32) */
+    int KD, KH, KW, stride, pad_d, pad_h, pad_w;
+} TriConvDesc;
+
+/* ---- weight packing -----------------------------------------------------------------------------------------
+ * fp32 parameter in the reference's own layout (addressed by element strides) -> MFMA operand rows
+ * dst[row][tap * inner_pad + i], bf16, zero padded to tri_conv_kpad(ntaps, inner_pad).  w_lo != NULL additionally
+ * receives the residual x - bf16(x) (3-product split mode, fp32-grade accuracy).
+ *   forward operand : rows = Cout, inner = Cin     dgrad operand : rows = Cin, inner = Cout (swap the strides)
+ * Layouts: spconv SubMConv3d weight [Cout,kd,kh,kw,Cin] (sparse_cnn.py:12-32), torchvision conv [Cout,Cin,kh,kw]
+ * (mv_cnn.py:44), nn.Linear [out,in]. */
+int tri_conv_kpad(int ntaps, int cin_stored);
+int tri_weight_prep(const float* w, long s_row, long s_tap, long s_inner, int rows, int ntaps, int inner, int inner_pad,
+                    void* w_hi, void* w_lo, void* stream);
+
+/* ---- implicit-GEMM convolution on MFMA ------------------------------------------------------------------------
+ * tri_conv_fwd replaces spconv.SubMConv3d (sparse_cnn.py:12,17,22,27,32; row_mask = active-site mask gives the
+ * submanifold rule), every torchvision conv2d of net_1 (mv_cnn.py:29) and nn.Linear (sparse_cnn.py:39-44,
+ * mv_cnn.py:21-26, bigru.py:12, clip_text.py:9-14; bias + act 0 none / 1 relu / 2 tanh fused).
+ * stats (optional) receives [tri_conv_num_mtiles][2][Cout] per-tile column sums / sums of squares for BatchNorm.
+ * tri_conv_dgrad / tri_conv_wgrad replace the autograd backward of the same call sites; `d` is always the FORWARD
+ * descriptor.  wgrad writes dw through element strides, i.e. directly in the reference's parameter layout. */
+int tri_conv_num_mtiles(const TriConvDesc* d);
+int tri_conv_fwd(const TriConvDesc* d, const float* in, const void* w_hi, const void* w_lo, float* out, const uint8_t* row_mask,
+                 const float* bias, int act, int accumulate, float* stats, void* stream);
+int tri_conv_dgrad(const TriConvDesc* d, const float* dout, const void* wt_hi, const void* wt_lo, float* din,
+                   const uint8_t* row_mask, int accumulate, void* stream);
+size_t tri_conv_wgrad_workspace(const TriConvDesc* d);
+int tri_conv_wgrad(const TriConvDesc* d, const float* in, const float* dout, const uint8_t* row_mask, void* workspace,
+                   size_t workspace_bytes, float* dw, long s_co, long s_tap, long s_ci, int cin_real, int split3, void* stream);
+
+/* ---- BatchNorm (train-mode statistics, eps / momentum as torch.nn.BatchNorm1d/2d) ----------------------------------
+ * Replaces nn.BatchNorm1d over active voxels (sparse_cnn.py:13,18,23,28,33; count from a device counter) and the 20
+ * BatchNorm2d of ResNet-18 (mv_cnn.py:29; count_host = N*H*W). */
+int tri_bn_finalize(const float* partial, int ntiles, int C, const int* count_dev, int count_host, const float* gamma,
+                    const float* beta, float* running_mean, float* running_var, long long* num_batches_tracked, float momentum,
+                    float eps, float* mean, float* invstd, float* scale, float* shift, void* stream);
+int tri_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps, float* mean,
+                       float* invstd, float* scale, float* shift, void* stream);
+int tri_bn_act(const float* y, const float* scale, const float* shift, const float* res, const float* rscale, const float* rshift,
+               float* out, long M, int C, int relu, void* stream);
+int tri_relu_bwd(const float* dout, const float* out, float* g, long n, void* stream);
+int tri_bn_bwd_num_blocks(long M);
+int tri_bn_bwd_reduce(const float* y, const float* g, long M, int C, float* partial, void* stream);
+int tri_bn_bwd_finalize(const float* partial, int nblk, int C, const int* count_dev, int count_host, const float* gamma,
+                        const float* mean, const float* invstd, float* dgamma, float* dbeta, float* c1, float* c2, float* c3,
+                        void* stream);
+int tri_bn_bwd_apply(const float* y, const float* g, const float* c1, const float* c2, const float* c3, const uint8_t* row_mask,
+                     float* dy, long M, int C, void* stream);
+
+/* ---- pooling -------------------------------------------------------------------------------------------------
+ * BN + ReLU + mask + spconv.SparseMaxPool3d(2,2) fused (sparse_cnn.py:13-15 ...), its backward routing;
+ * nn.MaxPool2d(3,2,1) of the ResNet stem; AdaptiveAvgPool2d + torch.max over views (mv_cnn.py:29-31). */
+int tri_bn_relu_pool3d_fwd(const float* y, const float* scale, const float* shift, const uint8_t* mask, int B, int D, int C,
+                           float* pooled, uint8_t* mask_out, void* stream);
+int tri_pool3d_bwd_route(const float* y, const float* scale, const float* shift, const uint8_t* mask, const float* pooled,
+                         const float* dpooled, int B, int D, int C, float* g, void* stream);
+int tri_maxpool2d_fwd(const float* x, int N, int H, int W, int C, float* out, void* stream);
+int tri_maxpool2d_bwd(const float* x, const float* dout, int N, int H, int W, int C, float* dx, void* stream);
+int tri_avgpool_viewmax_fwd(const float* x, int B, int V, int HW, int C, float* out, int* arg, void* stream);
+int tri_avgpool_viewmax_bwd(const float* dout, const int* arg, int B, int V, int HW, int C, float* dx, void* stream);
+
+/* ---- layout converters (batch layout of tricolo/data/data_module.py:40-65) ---------------------------------------- */
+int tri_voxel_scatter(const int* locs, const float* feats, int n, int B, int V, float* dense, uint8_t* mask, void* stream);
+int tri_mask_count(const uint8_t* mask, long n, int* count, void* stream);
+int tri_nchw3_to_nhwc4(const float* x, int N, int H, int W, float* out, void* stream);
+
+/* ---- row ops ------------------------------------------------------------------------------------------------------
+ * F.normalize(dim=1) (sparse_cnn.py:51, mv_cnn.py:33, bigru.py:18), bias gradients, activation backward. */
+int tri_l2norm_fwd(const float* x, int rows, int D, float eps, float* z, float* norm, void* stream);
+int tri_l2norm_bwd(const float* z, const float* norm, const float* dz, int rows, int D, float eps, float* dx, void* stream);
+int tri_colsum(const float* g, long M, int C, float* out, void* stream);
+int tri_axpy(const float* x, float a, float* y, long n, void* stream);
+int tri_act_bwd(const float* dout, const float* out, float* g, long n, int act, void* stream);
+
+/* ---- NT-Xent loss, forward + backward fused (tricolo/loss/nt_xent.py:24-74) ------------------------------------------ */
+size_t tri_ntxent_workspace(int B, int D);
+int tri_ntxent_fwd_bwd(const float* za, const float* zb, int B, int D, float temperature, float alpha, int norm, float* loss,
+                       float* dza, float* dzb, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- Adam (torch.optim.Adam as instantiated by config/config.yaml:50-53, tricolo_net.py:43-44) ------------------------ */
+int tri_adam_tick(int* step, void* stream);
+int tri_adam_step(float* p, const float* g, float* m, float* v, long n, const int* step, float lr, float b1, float b2, float eps,
+                  float wd, float gscale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,245 @@
+"""GPU parity of the HIP-backed encoder / loss / container modules against the golden vectors produced by the REAL
+reference classes (tests/golden, oracle/make_golden.py) with identical recipe weights and identical synthetic inputs.
+
+Tolerances (fp32 reference vs bf16x3 split-MFMA path): embeddings 2e-4 abs on unit-norm rows, losses 1e-3 (the
+north-star bound), gradient norms 2e-3 relative.  The plain-bf16 mode is checked separately with its own stated bound."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from tricolo_amd import config as tcfg, ops
+    from tricolo_amd.loss.nt_xent import NTXentLoss
+    from tricolo_amd.model.module.img_encoder.mv_cnn import MVCNNEncoder
+    from tricolo_amd.model.module.text_encoder.bigru import BiGRUEncoder
+    from tricolo_amd.model.module.text_encoder.clip_text import CLIPTextEncoder
+    from tricolo_amd.model.module.voxel_encoder.sparse_cnn import SparseCNNEncoder
+    from tricolo_amd.model.tricolo_net import TriCoLoNet
+
+from oracle.recipe import fill_module, probe
+from tricolo_amd.data import synthetic as syn
+
+DEV = "cuda"
+EMB_TOL, LOSS_TOL, GRAD_RTOL = 2e-4, 1e-3, 2e-3
+
+
+def _sha(*ts):
+    h = hashlib.sha256()
+    for t in ts:
+        h.update(np.ascontiguousarray(t.cpu().numpy()).tobytes())
+    return h.hexdigest()
+
+
+def _check_grads(module, g, prefix, rtol=GRAD_RTOL):
+    bad = []
+    for name, p in module.named_parameters():
+        key = f"{prefix}gradnorm/{name}"
+        if key not in g:
+            continue
+        assert p.grad is not None, name
+        n, s = probe(p.grad.cpu())
+        ref_n, ref_s = float(g[key]), g[f"{prefix}gradsample/{name}"]
+        scale = max(ref_n / np.sqrt(p.numel()), 1e-8)
+        if abs(n - ref_n) > rtol * max(ref_n, 1e-6) or np.abs(s - ref_s).max() > 50 * rtol * scale + 1e-7:
+            bad.append((name, n, ref_n, float(np.abs(s - ref_s).max())))
+    assert not bad, bad
+
+
+@pytest.fixture(autouse=True)
+def _precision():
+    ops.set_default_precision("bf16x3")
+    yield
+    ops.set_default_precision("bf16x3")
+
+
+def test_bigru_matches_reference(golden):
+    g = golden("bigru")
+    m = BiGRUEncoder(syn.DEFAULT_VOCAB, 512)
+    fill_module(m, prefix="text_encoder.")
+    m = m.to(DEV)
+    batch = syn.make_batch(8, voxel_size=None, num_views=None, seed=syn.BASE_SEED + 6)
+    z = m(batch["tokens"].to(DEV), batch)
+    np.testing.assert_allclose(z.detach().cpu().numpy(), g["z"], atol=EMB_TOL)
+    (z * torch.from_numpy(g["upstream"]).to(DEV)).sum().backward()
+    _check_grads(m, g, "")
+    zp = m(torch.zeros((2, 96), dtype=torch.int32, device=DEV), {})
+    np.testing.assert_allclose(zp.detach().cpu().numpy(), g["z_allpad"], atol=EMB_TOL)
+
+
+def test_clip_text_matches_reference(golden):
+    g = golden("clip_text")
+    m = CLIPTextEncoder(out_dim=512)
+    fill_module(m, prefix="text_encoder.")
+    m = m.to(DEV).eval()
+    batch = syn.batch_to_device(syn.make_batch(8, voxel_size=None, num_views=None, clip_text=True, seed=syn.BASE_SEED + 5), DEV)
+    z = m(batch["tokens"], batch)
+    np.testing.assert_allclose(z.detach().cpu().numpy(), g["z"], atol=2e-4)
+    with pytest.raises(UnboundLocalError):
+        m(batch["tokens"], {})
+
+
+@pytest.mark.parametrize("tag,V,B,seed", [("v32", 32, 8, 1), ("v64", 64, 2, 8)])
+def test_voxel_encoder_matches_reference(golden, tag, V, B, seed):
+    g = golden("voxel")
+    m = SparseCNNEncoder(V, 32, 512, 512)
+    fill_module(m, prefix="voxel_encoder.")
+    m = m.to(DEV)
+    batch = syn.batch_to_device(syn.make_batch(B, voxel_size=V, num_views=None, seed=syn.BASE_SEED + seed), DEV)
+    assert _sha(batch["voxels"]["locs"], batch["voxels"]["feats"]) == str(g[f"{tag}/input_sha"])
+    z = m(batch["voxels"], B)
+    np.testing.assert_allclose(z.detach().cpu().numpy(), g[f"{tag}/z"], atol=EMB_TOL)
+    (z * torch.from_numpy(g[f"{tag}/upstream"]).to(DEV)).sum().backward()
+    _check_grads(m, g, f"{tag}/")
+    # running statistics after one train-mode forward
+    for name, v in m.state_dict().items():
+        if "running" in name:
+            n, s = probe(v.cpu())
+            np.testing.assert_allclose(s, g[f"{tag}/after/wsample/{name}"], rtol=1e-4, atol=1e-5, err_msg=name)
+
+
+def test_voxel_encoder_empty_sample_and_eval_mode(golden):
+    g = golden("voxel")
+    m = SparseCNNEncoder(32, 32, 512, 512)
+    fill_module(m, prefix="voxel_encoder.")
+    m = m.to(DEV)
+    batch = syn.make_batch(3, voxel_size=32, num_views=None, seed=syn.BASE_SEED + 9)
+    keep = batch["voxels"]["locs"][:, 0] != 1
+    vox = {"locs": batch["voxels"]["locs"][keep].to(DEV), "feats": batch["voxels"]["feats"][keep].to(DEV)}
+    with torch.no_grad():
+        z = m(vox, 3)
+    np.testing.assert_allclose(z.cpu().numpy(), g["empty1/z"], atol=EMB_TOL)
+    # eval mode: running statistics, no autograd node; compare with the oracle restatement in eval mode
+    from oracle.modules import SparseCNNRef
+    ref = SparseCNNRef(32, 32, 512, 512)
+    ref.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+    ref.eval(); m.eval()
+    zr = ref({"locs": vox["locs"].cpu(), "feats": vox["feats"].cpu()}, 3)
+    with torch.no_grad():
+        ze = m(vox, 3)
+    np.testing.assert_allclose(ze.cpu().numpy(), zr.detach().numpy(), atol=EMB_TOL)
+
+
+@pytest.mark.parametrize("tag,B,nv,S", [("v6s128", 8, 6, 128), ("v12s224", 2, 12, 224)])
+def test_mvcnn_encoder_matches_reference(golden, tag, B, nv, S):
+    g = golden("mvcnn")
+    m = MVCNNEncoder(512, 512, "resnet18", nv)
+    assert len(m.state_dict()) == 126
+    fill_module(m, prefix="image_encoder.")
+    m = m.to(DEV)
+    batch = syn.make_batch(B, voxel_size=None, num_views=nv, image_size=S, seed=syn.BASE_SEED + 3)
+    assert _sha(batch["images"]) == str(g[f"{tag}/input_sha"])
+    z = m(batch["images"].flatten(end_dim=1).to(DEV), batch)
+    np.testing.assert_allclose(z.detach().cpu().numpy(), g[f"{tag}/z"], atol=EMB_TOL)
+    (z * torch.from_numpy(g[f"{tag}/upstream"]).to(DEV)).sum().backward()
+    _check_grads(m, g, f"{tag}/", rtol=5e-3)
+    for name, v in m.state_dict().items():
+        if "running" in name:
+            n, s = probe(v.cpu())
+            np.testing.assert_allclose(s, g[f"{tag}/after/wsample/{name}"], rtol=1e-4, atol=1e-5, err_msg=name)
+
+
+def test_ntxent_module_autograd(golden):
+    g = golden("ntxent")
+    za = torch.from_numpy(g["b8/za"]).to(DEV).requires_grad_()
+    zb = torch.from_numpy(g["b8/zb"]).to(DEV).requires_grad_()
+    loss = NTXentLoss(0.1, 0.25)(za, zb)
+    (2.0 * loss).backward()
+    assert abs(loss.item() - float(g["b8/loss"])) < 2e-5
+    np.testing.assert_allclose(za.grad.cpu().numpy(), 2 * g["b8/dza"], atol=4e-6)
+    np.testing.assert_allclose(zb.grad.cpu().numpy(), 2 * g["b8/dzb"], atol=4e-6)
+
+
+STEP_CASES = [
+    ("cfg1_biV", "BiGRUEncoder", None, "SparseCNNEncoder", 32, None, 128, 8, 1, False),
+    ("cfg3_biI", "BiGRUEncoder", "MVCNNEncoder", None, 32, 6, 128, 8, 3, False),
+    ("cfg4_tri", "BiGRUEncoder", "MVCNNEncoder", "SparseCNNEncoder", 32, 6, 128, 8, 4, False),
+    ("cfg5_tri64", "CLIPTextEncoder", "MVCNNEncoder", "SparseCNNEncoder", 64, 12, 224, 2, 5, True),
+]
+
+
+def _build_net(text, image, voxel, V, nv, S, optimizer="tricolo_amd.optim.FusedAdam"):
+    ov = [f"model.text_encoder={text}", f"model.image_encoder={image or 'null'}", f"model.voxel_encoder={voxel or 'null'}",
+          "data=synthetic", f"data.voxel_size={V}", f"data.num_views={nv}", f"data.image_size={S}",
+          f"optimizer._target_={optimizer}", "experiment_name=test"]
+    cfg = tcfg.compose(overrides=ov)
+    net = TriCoLoNet(cfg)
+    fill_module(net)
+    if text == "CLIPTextEncoder":
+        net.text_encoder.mlp[2].eval()
+    return net.to(DEV), cfg
+
+
+@pytest.mark.parametrize("case", STEP_CASES, ids=[c[0] for c in STEP_CASES])
+def test_training_steps_match_reference(golden, case):
+    tag, text, image, voxel, V, nv, S, B, seed_off, clip_text = case
+    g = golden(f"step_{tag}")
+    net, cfg = _build_net(text, image, voxel, V, nv or 6, S)
+    batch = syn.make_batch(B, voxel_size=V if voxel else None, num_views=nv if image else None, image_size=S,
+                           clip_text=clip_text, seed=syn.BASE_SEED + seed_off)
+    batch = syn.batch_to_device(batch, DEV)
+    opt = net.configure_optimizers()
+    report = {}
+    for step in range(4):
+        opt.zero_grad(set_to_none=True)
+        emb = net(batch)
+        for k in emb:
+            emb[k].retain_grad()
+        losses = net._calculate_losses(emb, "train_loss")
+        total = losses["train_loss/total_loss"]
+        report[step] = (total.item(), float(g[f"step{step}/total_loss"]))
+        if step == 0:
+            for k, v in losses.items():
+                assert abs(v.item() - float(g[f"step0/{k}"])) < LOSS_TOL, (k, v.item(), float(g[f"step0/{k}"]))
+            for k, v in emb.items():
+                np.testing.assert_allclose(v.detach().cpu().numpy(), g[f"emb/{k}"], atol=EMB_TOL, err_msg=k)
+        if step == 3:
+            break
+        total.backward()
+        if step == 0:
+            for k, v in emb.items():
+                np.testing.assert_allclose(v.grad.cpu().numpy(), g[f"demb/{k}"], atol=2e-5, err_msg=k)
+            _check_grads(net, g, "", rtol=5e-3)
+        opt.step()
+    print(tag, report)
+    # after Adam updates (sign-like first steps amplify tiny gradient differences) the bound is looser and stated:
+    for step in (1, 2, 3):
+        assert abs(report[step][0] - report[step][1]) < 2e-2, report
+
+
+def test_fused_adam_equals_torch_adam_on_the_same_net(golden):
+    g = golden("step_cfg1_biV")
+    net, cfg = _build_net("BiGRUEncoder", None, "SparseCNNEncoder", 32, 6, 128, optimizer="torch.optim.Adam")
+    batch = syn.batch_to_device(syn.make_batch(8, voxel_size=32, num_views=None, seed=syn.BASE_SEED + 1), DEV)
+    opt = net.configure_optimizers()
+    assert isinstance(opt, torch.optim.Adam)
+    for step in range(2):
+        opt.zero_grad(set_to_none=True)
+        loss = net.training_step(batch, 0)
+        assert abs(loss.item() - float(g[f"step{step}/total_loss"])) < (LOSS_TOL if step == 0 else 2e-2)
+        loss.backward()
+        opt.step()
+
+
+def test_plain_bf16_mode_stated_tolerance(golden):
+    """bf16 operands (1 MFMA product): the documented bound is 1e-2 on the loss and 5e-3 on unit-norm embeddings."""
+    g = golden("step_cfg4_tri")
+    ops.set_default_precision("bf16")
+    net, cfg = _build_net("BiGRUEncoder", "MVCNNEncoder", "SparseCNNEncoder", 32, 6, 128)
+    batch = syn.batch_to_device(syn.make_batch(8, voxel_size=32, num_views=6, image_size=128, seed=syn.BASE_SEED + 4), DEV)
+    emb = net(batch)
+    losses = net._calculate_losses(emb, "train_loss")
+    diffs = {k: abs(v.item() - float(g[f"step0/{k}"])) for k, v in losses.items()}
+    edif = {k: float(np.abs(v.detach().cpu().numpy() - g[f"emb/{k}"]).max()) for k, v in emb.items()}
+    print("bf16 mode loss diffs", diffs, "embedding max diffs", edif)
+    assert max(diffs.values()) < 1e-2 and max(edif.values()) < 5e-3
+
+
+def test_cpu_input_fails_loudly():
+    m = SparseCNNEncoder(32, 32, 512, 512)
+    batch = syn.make_batch(2, voxel_size=32, num_views=None, seed=1)
+    with pytest.raises(RuntimeError, match="no CPU"):
+        m(batch["voxels"], 2)

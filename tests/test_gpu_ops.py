@@ -1,0 +1,364 @@
+"""GPU parity of every kernel family, called through the C ABI (tricolo_amd.ops -> libtricolo_hip.so), against
+plain PyTorch-CPU fp32 / float64 restatements of the same op.  Integer-valued inputs make the bf16 MFMA path exact,
+so layout / fragment-mapping mistakes show up as exact mismatches, not as tolerance noise."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from tricolo_amd import ops
+
+DEV = "cuda"
+
+
+def cl3(x):       # [B,C,D,H,W] -> channels-last [B,D,H,W,C]
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def cf3(x):       # channels-last -> [B,C,D,H,W]
+    return x.permute(0, 4, 1, 2, 3).contiguous()
+
+
+def ints(shape, lo, hi, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(lo, hi + 1, shape, generator=g).to(torch.float32)
+
+
+CONV_CASES = [
+    # name, B, grid(D,H,W), cin, cout, kernel, stride, pad, layout
+    ("vox_l0", 2, (8, 8, 8), 3, 32, (3, 3, 3), 1, (1, 1, 1), "spconv"),
+    ("vox_l1", 2, (8, 8, 8), 32, 64, (3, 3, 3), 1, (1, 1, 1), "spconv"),
+    ("vox_l3", 3, (4, 4, 4), 128, 256, (3, 3, 3), 1, (1, 1, 1), "spconv"),
+    ("stem7x7", 3, (1, 32, 32), 3, 64, (1, 7, 7), 2, (0, 3, 3), "torch"),
+    ("c3x3s1", 2, (1, 16, 16), 64, 64, (1, 3, 3), 1, (0, 1, 1), "torch"),
+    ("c3x3s2", 2, (1, 16, 16), 64, 128, (1, 3, 3), 2, (0, 1, 1), "torch"),
+    ("c1x1s2", 2, (1, 16, 16), 64, 128, (1, 1, 1), 2, (0, 0, 0), "torch"),
+    ("odd14", 2, (1, 14, 14), 128, 256, (1, 3, 3), 2, (0, 1, 1), "torch"),
+    ("linear", 8, (1, 1, 1), 512, 512, (1, 1, 1), 1, (0, 0, 0), "torch"),
+    ("clip768", 5, (1, 1, 1), 768, 512, (1, 1, 1), 1, (0, 0, 0), "torch"),
+]
+
+
+def make_case(case, integer, seed=0):
+    name, B, grid, cin, cout, k, s, p, layout = case
+    ntaps = k[0] * k[1] * k[2]
+    if integer:
+        x = ints((B, cin, *grid), -3, 3, seed)
+        w = ints((cout, cin, *k), -2, 2, seed + 1)
+    else:
+        g = torch.Generator().manual_seed(seed)
+        x = torch.randn((B, cin, *grid), generator=g)
+        w = torch.randn((cout, cin, *k), generator=g) / np.sqrt(cin * ntaps)
+    cs = 4 if cin == 3 else cin
+    if layout == "spconv":
+        wp = w.permute(0, 2, 3, 4, 1).contiguous()                 # [Cout,kd,kh,kw,Cin]
+        strides = (ntaps * cin, cin, 1)
+    else:
+        wp = w.contiguous()                                        # [Cout,Cin,kd,kh,kw]
+        strides = (cin * ntaps, 1, ntaps)
+    geom = ops.ConvGeom(B, grid, cin, cs, cout, k, s, p, strides)
+    xcl = cl3(x)
+    if cs != cin:
+        xcl = torch.cat([xcl, torch.zeros(*xcl.shape[:-1], cs - cin)], dim=-1).contiguous()
+    return x, w, wp, xcl, geom
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+def test_conv_fwd_integer_exact(case, precision):
+    x, w, wp, xcl, g = make_case(case, integer=True)
+    ref = cl3(F.conv3d(x, w, stride=case[6], padding=case[7]))
+    packed = ops.pack_weight(wp.to(DEV), g, precision)
+    out = ops.conv_fwd(xcl.to(DEV), g, packed).cpu()
+    assert out.shape == ref.shape
+    assert torch.equal(out, ref), f"max abs diff {(out - ref).abs().max().item()}"
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_fwd_float_split_precision(case):
+    x, w, wp, xcl, g = make_case(case, integer=False, seed=5)
+    ref = cl3(F.conv3d(x.double(), w.double(), stride=case[6], padding=case[7]))
+    scale = ref.abs().max().item()
+    out3 = ops.conv_fwd(xcl.to(DEV), g, ops.pack_weight(wp.to(DEV), g, "bf16x3")).cpu().double()
+    out1 = ops.conv_fwd(xcl.to(DEV), g, ops.pack_weight(wp.to(DEV), g, "bf16")).cpu().double()
+    assert (out3 - ref).abs().max().item() < 2e-5 * scale          # fp32-grade
+    assert (out1 - ref).abs().max().item() < 3e-2 * scale          # plain bf16 operands
+
+
+def test_conv_fwd_mask_bias_act_stats():
+    case = CONV_CASES[1]
+    x, w, wp, xcl, g = make_case(case, integer=True, seed=3)
+    B, grid = case[1], case[2]
+    M = B * grid[0] * grid[1] * grid[2]
+    gen = torch.Generator().manual_seed(9)
+    mask = (torch.rand(M, generator=gen) < 0.3).to(torch.uint8)
+    mask[:256] = 0                                                  # two fully inactive 128-row tiles
+    ref = cl3(F.conv3d(x, w, padding=1)).reshape(M, -1) * mask[:, None].float()
+    packed = ops.pack_weight(wp.to(DEV), g, "bf16")
+    out, stats = ops.conv_fwd(xcl.to(DEV), g, packed, row_mask=mask.to(DEV), want_stats=True)
+    out = out.cpu().reshape(M, -1)
+    assert torch.equal(out, ref)
+    st = stats.cpu().double().sum(0)
+    np.testing.assert_allclose(st[0].numpy(), ref.double().sum(0).numpy(), rtol=1e-6, atol=1e-3)
+    np.testing.assert_allclose(st[1].numpy(), (ref.double() ** 2).sum(0).numpy(), rtol=1e-6, atol=1e-3)
+    bias = ints((case[4],), -2, 2, 4)
+    out2 = ops.conv_fwd(xcl.to(DEV), g, packed, bias=bias.to(DEV), act=1).cpu().reshape(M, -1)
+    assert torch.equal(out2, F.relu(cl3(F.conv3d(x, w, padding=1)).reshape(M, -1) + bias))
+    out3 = ops.conv_fwd(xcl.to(DEV), g, packed, bias=bias.to(DEV), act=2).cpu().reshape(M, -1)
+    np.testing.assert_allclose(out3.numpy(), torch.tanh(cl3(F.conv3d(x, w, padding=1)).reshape(M, -1) + bias).numpy(), atol=2e-6)
+
+
+DGRAD_CASES = [c for c in CONV_CASES if c[3] != 3]
+
+
+@pytest.mark.parametrize("case", DGRAD_CASES, ids=[c[0] for c in DGRAD_CASES])
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+def test_conv_dgrad_integer_exact(case, precision):
+    x, w, wp, xcl, g = make_case(case, integer=True, seed=7)
+    xr = x.clone().requires_grad_()
+    y = F.conv3d(xr, w, stride=case[6], padding=case[7])
+    dy = ints(tuple(y.shape), -2, 2, 11)
+    y.backward(dy)
+    ref = cl3(xr.grad)
+    packed_t = ops.pack_weight(wp.to(DEV), g, precision, transposed=True)
+    dx = ops.conv_dgrad(cl3(dy).to(DEV), g, packed_t).cpu()
+    assert torch.equal(dx, ref), f"max abs diff {(dx - ref).abs().max().item()}"
+    base = ints(tuple(ref.shape), -5, 5, 13)
+    dx2 = ops.conv_dgrad(cl3(dy).to(DEV), g, packed_t, out=base.clone().to(DEV), accumulate=True).cpu()
+    assert torch.equal(dx2, ref + base)
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+def test_conv_wgrad_integer_exact(case, precision):
+    x, w, wp, xcl, g = make_case(case, integer=True, seed=17)
+    wr = w.clone().requires_grad_()
+    y = F.conv3d(x, wr, stride=case[6], padding=case[7])
+    dy = ints(tuple(y.shape), -2, 2, 19)
+    y.backward(dy)
+    ref = wr.grad
+    if case[8] == "spconv":
+        ref = ref.permute(0, 2, 3, 4, 1).contiguous()
+    dw = ops.conv_wgrad(xcl.to(DEV), cl3(dy).to(DEV), g, wp.to(DEV), precision).cpu()
+    assert dw.shape == ref.shape
+    assert torch.equal(dw, ref), f"max abs diff {(dw - ref).abs().max().item()}"
+
+
+def test_conv_wgrad_masked_steps_skipped():
+    case = CONV_CASES[1]
+    x, w, wp, xcl, g = make_case(case, integer=True, seed=23)
+    B, grid = case[1], case[2]
+    M = B * grid[0] * grid[1] * grid[2]
+    gen = torch.Generator().manual_seed(29)
+    mask = (torch.rand(M, generator=gen) < 0.2).to(torch.uint8)
+    mask[64:320] = 0
+    wr = w.clone().requires_grad_()
+    y = F.conv3d(x, wr, padding=1)
+    dy = ints(tuple(y.shape), -2, 2, 31) * mask.view(B, 1, *grid).float()
+    y.backward(dy)
+    ref = wr.grad.permute(0, 2, 3, 4, 1).contiguous()
+    dw = ops.conv_wgrad(xcl.to(DEV), cl3(dy).to(DEV), g, wp.to(DEV), "bf16", row_mask=mask.to(DEV)).cpu()
+    assert torch.equal(dw, ref)
+
+
+def test_linear_spatial_flatten_matches_channels_first():
+    """mlp[0] at 64^3: Linear(4096) over the channels-FIRST flatten of [B,512,2,2,2] (sparse_cnn.py:49)."""
+    from tricolo_amd.layers import linear_bwd, linear_fwd
+    B, C, e = 4, 512, 2
+    x = ints((B, C, e, e, e), -2, 2, 37)
+    w = ints((512, C * e ** 3), -1, 1, 41)
+    b = ints((512,), -3, 3, 43)
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    ref = F.relu(F.linear(xr.reshape(B, -1), wr, b))
+    xcl = cl3(x).reshape(B, -1).to(DEV)
+    out = linear_fwd(xcl, w.to(DEV), b.to(DEV), 1, "bf16", spatial=e ** 3)
+    assert torch.equal(out.cpu(), ref.detach())
+    dout = ints((B, 512), -2, 2, 47)
+    ref.backward(dout)
+    dx, dw, db = linear_bwd(xcl, w.to(DEV), out, dout.to(DEV), 1, "bf16", spatial=e ** 3)
+    assert torch.equal(dw.cpu(), wr.grad)
+    assert torch.equal(db.cpu(), (dout * (ref > 0)).sum(0))
+    assert torch.equal(dx.cpu().view(B, e, e, e, C), cl3(xr.grad))
+
+
+# ------------------------------------------------------------------------------------------------ BatchNorm
+def test_bn2d_forward_backward_matches_torch():
+    g = torch.Generator().manual_seed(3)
+    N, H, W, C = 4, 6, 6, 64
+    y = torch.randn(N, C, H, W, generator=g) * 2 + 0.5
+    res = torch.randn(N, C, H, W, generator=g)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+    rm, rv = torch.zeros(C), torch.ones(C)
+    yr, gr, br, rr = y.clone().requires_grad_(), gamma.clone().requires_grad_(), beta.clone().requires_grad_(), res.clone().requires_grad_()
+    ref = F.relu(F.batch_norm(yr, rm.clone(), rv.clone(), gr, br, True, 0.1, 1e-5) + rr)
+    dout = torch.randn(ref.shape, generator=g)
+    ref.backward(dout)
+    M = N * H * W
+    ycl = y.permute(0, 2, 3, 1).contiguous().view(M, C)
+    # statistics as the conv epilogue would deliver them: 128-row tiles of (sum, sumsq)
+    nt = (M + 127) // 128
+    stats = torch.zeros(nt, 2, C)
+    for t in range(nt):
+        blk = ycl[t * 128:(t + 1) * 128].double()
+        stats[t, 0], stats[t, 1] = blk.sum(0).float(), (blk * blk).sum(0).float()
+    rm_d, rv_d, nbt = rm.clone().to(DEV), rv.clone().to(DEV), torch.zeros((), dtype=torch.long, device=DEV)
+    co = ops.bn_finalize(stats.to(DEV), C, gamma.to(DEV), beta.to(DEV), rm_d, rv_d, nbt, count_host=M)
+    out = ops.bn_act(ycl.to(DEV), co, relu=True, res=res.permute(0, 2, 3, 1).contiguous().view(M, C).to(DEV))
+    np.testing.assert_allclose(out.cpu().numpy(), ref.detach().permute(0, 2, 3, 1).reshape(M, C).numpy(), atol=2e-5)
+    rm_ref, rv_ref = torch.zeros(C), torch.ones(C)
+    F.batch_norm(y, rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5)
+    np.testing.assert_allclose(rm_d.cpu().numpy(), rm_ref.numpy(), atol=1e-6)
+    np.testing.assert_allclose(rv_d.cpu().numpy(), rv_ref.numpy(), rtol=1e-5)
+    assert int(nbt.item()) == 1
+    gz = ops.relu_bwd(dout.permute(0, 2, 3, 1).contiguous().view(M, C).to(DEV), out, inplace=False)
+    dy, dgamma, dbeta = ops.bn_bwd(ycl.to(DEV), gz, co, gamma.to(DEV), count_host=M, inplace=False)
+    np.testing.assert_allclose(dy.cpu().numpy(), yr.grad.permute(0, 2, 3, 1).reshape(M, C).numpy(), atol=3e-5)
+    np.testing.assert_allclose(dgamma.cpu().numpy(), gr.grad.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(dbeta.cpu().numpy(), br.grad.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(gz.cpu().numpy(), rr.grad.permute(0, 2, 3, 1).reshape(M, C).numpy(), atol=1e-6)
+
+
+def test_voxel_bn_pool_forward_backward_matches_oracle():
+    from oracle import spconv_dense as sp
+    g = torch.Generator().manual_seed(5)
+    B, D, C = 2, 8, 32
+    mask = (torch.rand(B, 1, D, D, D, generator=g) < 0.3).float()
+    mask[1, :, 4:] = 0
+    y = torch.randn(B, C, D, D, D, generator=g) * mask
+    bn = torch.nn.BatchNorm1d(C)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=g) * 0.3)
+    yr = y.clone().requires_grad_()
+    t = sp.masked_batchnorm(bn, sp.SparseConvTensor.from_dense(yr, mask))
+    t = sp.SparseMaxPool3d(2, 2)(sp.SparseConvTensor.from_dense(F.relu(t.dense), t.mask))
+    dp = torch.randn(t.dense.shape, generator=g)
+    t.dense.backward(dp)
+    # HIP path
+    M = B * D ** 3
+    ycl = cl3(y).to(DEV)
+    m8 = torch.zeros((M + 31) // 32 * 32, dtype=torch.uint8)
+    m8[:M] = mask.reshape(-1).to(torch.uint8)
+    m8 = m8.to(DEV)
+    cnt = ops.mask_count(m8, M)
+    assert int(cnt.item()) == int(mask.sum().item())
+    y2 = ycl.view(M, C).cpu()
+    nt = (M + 127) // 128
+    stats = torch.zeros(nt, 2, C)
+    for i in range(nt):
+        blk = y2[i * 128:(i + 1) * 128].double()
+        stats[i, 0], stats[i, 1] = blk.sum(0).float(), (blk * blk).sum(0).float()
+    bn2 = torch.nn.BatchNorm1d(C)
+    bn2.load_state_dict({k: v.clone() for k, v in bn.state_dict().items()})
+    with torch.no_grad():
+        bn2.running_mean.zero_(); bn2.running_var.fill_(1.0)
+    bn2 = bn2.to(DEV)
+    co = ops.bn_finalize(stats.to(DEV), C, bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var, bn2.num_batches_tracked, count_dev=cnt)
+    pooled, mask_out = ops.bn_relu_pool3d_fwd(ycl, co, m8, B, D, C)
+    np.testing.assert_allclose(cf3(pooled.cpu()).numpy(), t.dense.detach().numpy(), atol=2e-5)
+    Mo = B * (D // 2) ** 3
+    assert torch.equal(mask_out[:Mo].cpu().float().view(B, 1, D // 2, D // 2, D // 2), t.mask)
+    np.testing.assert_allclose(bn2.running_mean.cpu().numpy(), bn.running_mean.numpy(), atol=1e-6)
+    np.testing.assert_allclose(bn2.running_var.cpu().numpy(), bn.running_var.numpy(), rtol=1e-5)
+    gz = ops.pool3d_bwd_route(ycl, co, m8, pooled, cl3(dp).to(DEV), B, D, C)
+    dy, dgamma, dbeta = ops.bn_bwd(ycl, gz, co, bn2.weight, count_dev=cnt, row_mask=m8)
+    np.testing.assert_allclose(cf3(dy.cpu()).numpy(), yr.grad.numpy(), atol=3e-5)
+    np.testing.assert_allclose(dgamma.cpu().numpy(), bn.weight.grad.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(dbeta.cpu().numpy(), bn.bias.grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_maxpool2d_and_viewmax():
+    g = torch.Generator().manual_seed(7)
+    N, H, W, C = 6, 10, 10, 64
+    x = torch.randint(0, 6, (N, C, H, W), generator=g).float()      # many ties: exercises the first-max rule
+    xr = x.clone().requires_grad_()
+    ref = F.max_pool2d(xr, 3, 2, 1)
+    dout = torch.randn(ref.shape, generator=g)
+    ref.backward(dout)
+    xcl = x.permute(0, 2, 3, 1).contiguous().view(N, 1, H, W, C).to(DEV)
+    out = ops.maxpool2d_fwd(xcl)
+    assert torch.equal(out.cpu().view(N, 5, 5, C).permute(0, 3, 1, 2), ref.detach())
+    dx = ops.maxpool2d_bwd(xcl, dout.permute(0, 2, 3, 1).contiguous().to(DEV))
+    np.testing.assert_allclose(dx.cpu().view(N, H, W, C).permute(0, 3, 1, 2).numpy(), xr.grad.numpy(), atol=1e-6)
+    # avg-pool + view max (mv_cnn.py:29-31)
+    B, V = 2, 3
+    f = torch.randn(B * V, 512, 4, 4, generator=g)
+    fr = f.clone().requires_grad_()
+    y = F.adaptive_avg_pool2d(fr, 1).view(B, V, 512)
+    refv = torch.max(y, 1)[0]
+    dp = torch.randn(B, 512, generator=g)
+    refv.backward(dp)
+    fcl = f.permute(0, 2, 3, 1).contiguous().view(B * V, 1, 4, 4, 512).to(DEV)
+    pooled, arg = ops.avgpool_viewmax_fwd(fcl, B, V)
+    np.testing.assert_allclose(pooled.cpu().numpy(), refv.detach().numpy(), atol=1e-6)
+    dxf = ops.avgpool_viewmax_bwd(dp.to(DEV), arg, tuple(fcl.shape), B, V)
+    np.testing.assert_allclose(dxf.cpu().view(B * V, 4, 4, 512).permute(0, 3, 1, 2).numpy(), fr.grad.numpy(), atol=1e-7)
+
+
+def test_layout_kernels_and_row_ops():
+    from tricolo_amd.data import synthetic as syn
+    batch = syn.make_batch(3, voxel_size=32, num_views=2, image_size=16, seed=77)
+    locs, feats = batch["voxels"]["locs"], batch["voxels"]["feats"]
+    dense, mask = ops.voxel_scatter(locs.to(DEV), feats.to(DEV), 3, 32)
+    ref = torch.zeros(3, 32, 32, 32, 4)
+    ref[locs[:, 0].long(), locs[:, 1].long(), locs[:, 2].long(), locs[:, 3].long(), :3] = feats
+    assert torch.equal(dense.cpu(), ref)
+    assert int(mask.sum().item()) == locs.shape[0]
+    img = batch["images"].flatten(end_dim=1)
+    out = ops.nchw3_to_nhwc4(img.to(DEV)).cpu()
+    assert torch.equal(out[:, 0, :, :, :3], img.permute(0, 2, 3, 1)) and float(out[..., 3].abs().sum()) == 0.0
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(9, 512, generator=g)
+    x[4] = 0
+    xr = x.clone().requires_grad_()
+    ref = F.normalize(xr, dim=1)
+    dz = torch.randn(9, 512, generator=g)
+    ref.backward(dz)
+    z, norm = ops.l2norm_fwd(x.to(DEV))
+    np.testing.assert_allclose(z.cpu().numpy(), ref.detach().numpy(), atol=1e-7)
+    dx = ops.l2norm_bwd(z, norm, dz.to(DEV))
+    np.testing.assert_allclose(dx.cpu()[[0, 1, 2, 3, 5, 6, 7, 8]].numpy(), xr.grad[[0, 1, 2, 3, 5, 6, 7, 8]].numpy(), rtol=1e-4, atol=1e-6)
+    m = torch.randn(37, 96, generator=g)
+    np.testing.assert_allclose(ops.colsum(m.to(DEV)).cpu().numpy(), m.sum(0).numpy(), atol=1e-5)
+
+
+def test_adam_matches_torch_optim():
+    from oracle.modules import adam_step_explicit
+    g = torch.Generator().manual_seed(2)
+    p = torch.randn(10007, generator=g)
+    pd, m, v = p.clone().to(DEV), torch.zeros(10007, device=DEV), torch.zeros(10007, device=DEV)
+    pr, mr, vr = p.clone(), torch.zeros(10007), torch.zeros(10007)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for s in range(1, 5):
+        gr = torch.randn(10007, generator=g)
+        ops.adam_tick(step)
+        ops.adam_step(pd, gr.to(DEV), m, v, step, 3.5e-4, 0.9, 0.999, 1e-8, 1e-6)
+        adam_step_explicit(pr, gr, mr, vr, s)
+        np.testing.assert_allclose(pd.cpu().numpy(), pr.numpy(), atol=2e-7)
+
+
+@pytest.mark.parametrize("tag", ["b8", "b5", "b16_sym", "b1"])
+def test_ntxent_kernel_matches_reference_golden(golden, tag):
+    gd = golden("ntxent")
+    za, zb = torch.from_numpy(gd[f"{tag}/za"]).to(DEV), torch.from_numpy(gd[f"{tag}/zb"]).to(DEV)
+    loss, dza, dzb = ops.ntxent_fwd_bwd(za, zb, float(gd[f"{tag}/T"]), float(gd[f"{tag}/alpha"]))
+    assert abs(loss.item() - float(gd[f"{tag}/loss"])) < 2e-5
+    np.testing.assert_allclose(dza.cpu().numpy(), gd[f"{tag}/dza"], atol=2e-6)
+    np.testing.assert_allclose(dzb.cpu().numpy(), gd[f"{tag}/dzb"], atol=2e-6)
+    sw, _, _ = ops.ntxent_fwd_bwd(zb, za, float(gd[f"{tag}/T"]), float(gd[f"{tag}/alpha"]), want_grad=False)
+    assert abs(sw.item() - float(gd[f"{tag}/loss_swapped"])) < 2e-5
+
+
+def test_ntxent_large_batch_against_float64():
+    from oracle.modules import nt_xent_numpy
+    g = torch.Generator().manual_seed(8)
+    za, zb = torch.randn(300, 512, generator=g), torch.randn(300, 512, generator=g)
+    zb[:150] += za[:150] * 2                                   # some strongly aligned pairs
+    loss, dza, dzb = ops.ntxent_fwd_bwd(za.to(DEV), zb.to(DEV), 0.1, 0.25)
+    l64, da, db = nt_xent_numpy(za.numpy(), zb.numpy(), 0.1, 0.25)
+    assert abs(loss.item() - l64) < 2e-5
+    np.testing.assert_allclose(dza.cpu().numpy(), da, atol=1e-6)
+    np.testing.assert_allclose(dzb.cpu().numpy(), db, atol=1e-6)

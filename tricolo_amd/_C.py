@@ -1,0 +1,103 @@
+"""ctypes binding of libtricolo_hip.so (C ABI declared in include/tricolo_hip.h).
+
+The product path has NO CPU fallback: if the library is missing, or a tensor is not on a GPU, the call raises.
+Build the library with ``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C tricolo_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtricolo_hip.so")
+
+
+class TriConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("B", "ID", "IH", "IW", "Cin", "OD", "OH", "OW", "Cout",
+                                       "KD", "KH", "KW", "stride", "pad_d", "pad_h", "pad_w")]
+
+
+P, I, L, F, Z = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
+DP = C.POINTER(TriConvDesc)
+
+# name -> (restype, argtypes); must list every symbol of include/tricolo_hip.h (checked by tests/test_abi.py)
+SIGNATURES = {
+    "tri_version": (I, []),
+    "tri_last_error": (C.c_char_p, []),
+    "tri_conv_kpad": (I, [I, I]),
+    "tri_weight_prep": (I, [P, L, L, L, I, I, I, I, P, P, P]),
+    "tri_conv_num_mtiles": (I, [DP]),
+    "tri_conv_fwd": (I, [DP, P, P, P, P, P, P, I, I, P, P]),
+    "tri_conv_dgrad": (I, [DP, P, P, P, P, P, I, P]),
+    "tri_conv_wgrad_workspace": (Z, [DP]),
+    "tri_conv_wgrad": (I, [DP, P, P, P, P, Z, P, L, L, L, I, I, P]),
+    "tri_bn_finalize": (I, [P, I, I, P, I, P, P, P, P, P, F, F, P, P, P, P, P]),
+    "tri_bn_eval_coeffs": (I, [I, P, P, P, P, F, P, P, P, P, P]),
+    "tri_bn_act": (I, [P, P, P, P, P, P, P, L, I, I, P]),
+    "tri_relu_bwd": (I, [P, P, P, L, P]),
+    "tri_bn_bwd_num_blocks": (I, [L]),
+    "tri_bn_bwd_reduce": (I, [P, P, L, I, P, P]),
+    "tri_bn_bwd_finalize": (I, [P, I, I, P, I, P, P, P, P, P, P, P, P, P]),
+    "tri_bn_bwd_apply": (I, [P, P, P, P, P, P, P, L, I, P]),
+    "tri_bn_relu_pool3d_fwd": (I, [P, P, P, P, I, I, I, P, P, P]),
+    "tri_pool3d_bwd_route": (I, [P, P, P, P, P, P, I, I, I, P, P]),
+    "tri_maxpool2d_fwd": (I, [P, I, I, I, I, P, P]),
+    "tri_maxpool2d_bwd": (I, [P, P, I, I, I, I, P, P]),
+    "tri_avgpool_viewmax_fwd": (I, [P, I, I, I, I, P, P, P]),
+    "tri_avgpool_viewmax_bwd": (I, [P, P, I, I, I, I, P, P]),
+    "tri_voxel_scatter": (I, [P, P, I, I, I, P, P, P]),
+    "tri_mask_count": (I, [P, L, P, P]),
+    "tri_nchw3_to_nhwc4": (I, [P, I, I, I, P, P]),
+    "tri_l2norm_fwd": (I, [P, I, I, F, P, P, P]),
+    "tri_l2norm_bwd": (I, [P, P, P, I, I, F, P, P]),
+    "tri_colsum": (I, [P, L, I, P, P]),
+    "tri_axpy": (I, [P, F, P, L, P]),
+    "tri_act_bwd": (I, [P, P, P, L, I, P]),
+    "tri_ntxent_workspace": (Z, [I, I]),
+    "tri_ntxent_fwd_bwd": (I, [P, P, I, I, F, F, I, P, P, P, P, Z, P]),
+    "tri_adam_tick": (I, [P, P]),
+    "tri_adam_step": (I, [P, P, P, P, L, P, F, F, F, F, F, F, P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: the HIP extension is not built.  Run `make -C tricolo_amd/csrc` "
+                "(or __graft_entry__.build()).  tricolo_amd has no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().tri_last_error().decode(errors="replace")
+        raise RuntimeError(f"libtricolo_hip {what} failed (code {rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Refuses host tensors: there is no CPU path."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("tricolo_amd: tensor is not on a GPU; the HIP path has no CPU fallback")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def make_desc(B, ID, IH, IW, Cin, OD, OH, OW, Cout, KD, KH, KW, stride, pad_d, pad_h, pad_w) -> TriConvDesc:
+    return TriConvDesc(B, ID, IH, IW, Cin, OD, OH, OW, Cout, KD, KH, KW, stride, pad_d, pad_h, pad_w)

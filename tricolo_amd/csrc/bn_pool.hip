@@ -1,0 +1,448 @@
+// HBM-bound passes of the TriCoLo towers on channels-last fp32 [M, C] tensors (gfx950): BatchNorm statistics /
+// apply / backward, ReLU, residual add, the submanifold 2^3 max-pool with mask propagation, the ResNet stem
+// 3x3/2 max-pool and the fused global-average-pool + per-shape view-max.
+//
+// Replaces: nn.BatchNorm1d + ReLU + spconv.SparseMaxPool3d (/root/reference/tricolo/model/module/voxel_encoder/
+// sparse_cnn.py:13-35), torchvision BatchNorm2d / ReLU / MaxPool2d / AdaptiveAvgPool2d inside net_1
+// (img_encoder/mv_cnn.py:20,29) and torch.max over views (mv_cnn.py:30-31).
+// Every thread moves float4 (4 channels of one position): 16 B per lane, coalesced along C.
+#include "common.h"
+#include "../../include/tricolo_hip.h"
+
+// ---------------------------------------------------------------------------------------------- BN statistics
+// partial: [ntiles][2][C] (sum, sum of squares) written by the conv epilogue.  count from host (count_host > 0) or
+// from a device counter (active voxel count).  Train-mode: biased variance for normalisation, unbiased for the
+// running estimate, momentum 0.1, eps 1e-5 (torch.nn.BatchNorm semantics).  All reductions in double.
+__global__ void bn_finalize_kernel(const float* __restrict__ partial, int ntiles, int C, const int* __restrict__ count_dev,
+                                   int count_host, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* running_mean, float* running_var, long long* num_batches_tracked, float momentum,
+                                   float eps, float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                   float* __restrict__ scale_out, float* __restrict__ shift_out) {
+    __shared__ double ssum[8][32], ssq[8][32];
+    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;        // 8 channels x 32 row lanes
+    const int c = blockIdx.x * 8 + cl;
+    double s = 0.0, q = 0.0;
+    if (c < C)
+        for (int tIdx = rl; tIdx < ntiles; tIdx += 32) {
+            s += (double)partial[((size_t)tIdx * 2 + 0) * C + c];
+            q += (double)partial[((size_t)tIdx * 2 + 1) * C + c];
+        }
+    ssum[cl][rl] = s;
+    ssq[cl][rl] = q;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        for (int i = 1; i < 32; ++i) { s += ssum[cl][i]; q += ssq[cl][i]; }
+        double n = count_dev ? (double)(*count_dev) : (double)count_host;
+        if (n < 1.0) {                       // SparseSequential skips BN when there is no active site
+            mean_out[c] = 0.f; invstd_out[c] = 0.f; scale_out[c] = 0.f; shift_out[c] = 0.f;
+            return;
+        }
+        double mean = s / n;
+        double var = q / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        double invstd = 1.0 / sqrt(var + (double)eps);
+        mean_out[c] = (float)mean;
+        invstd_out[c] = (float)invstd;
+        float sc = (float)((double)gamma[c] * invstd);
+        scale_out[c] = sc;
+        shift_out[c] = (float)((double)beta[c] - mean * (double)gamma[c] * invstd);
+        if (running_mean) {
+            double unb = n > 1.0 ? var * n / (n - 1.0) : var;
+            running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+            running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+        }
+        if (num_batches_tracked && c == 0) *num_batches_tracked += 1;
+    }
+}
+
+extern "C" int tri_bn_finalize(const float* partial, int ntiles, int C, const int* count_dev, int count_host, const float* gamma,
+                               const float* beta, float* running_mean, float* running_var, long long* num_batches_tracked,
+                               float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, void* stream) {
+    bn_finalize_kernel<<<(C + 7) / 8, 256, 0, (hipStream_t)stream>>>(partial, ntiles, C, count_dev, count_host, gamma, beta,
+                                                                      running_mean, running_var, num_batches_tracked, momentum,
+                                                                      eps, mean, invstd, scale, shift);
+    return tri_check_launch("tri_bn_finalize");
+}
+
+// Eval-mode scale/shift from running statistics.
+__global__ void bn_eval_coeffs_kernel(int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                                      float* mean, float* invstd, float* scale, float* shift) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float is = 1.0f / sqrtf(rv[c] + eps);
+    mean[c] = rm[c]; invstd[c] = is; scale[c] = gamma[c] * is; shift[c] = beta[c] - rm[c] * gamma[c] * is;
+}
+extern "C" int tri_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                                  float* mean, float* invstd, float* scale, float* shift, void* stream) {
+    bn_eval_coeffs_kernel<<<(C + 255) / 256, 256, 0, (hipStream_t)stream>>>(C, gamma, beta, rm, rv, eps, mean, invstd, scale, shift);
+    return tri_check_launch("tri_bn_eval_coeffs");
+}
+
+// ------------------------------------------------------------------------------------------ BN apply (+res, relu)
+// out = act(y*scale + shift + residual),  residual = res (identity) or res*rscale + rshift (down-sample BN branch)
+__global__ void bn_act_kernel(const float4* __restrict__ y, const float4* __restrict__ scale, const float4* __restrict__ shift,
+                              const float4* __restrict__ res, const float4* __restrict__ rscale, const float4* __restrict__ rshift,
+                              float4* __restrict__ out, long total4, int C4, int relu) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % C4);
+        float4 v = y[i], s = scale[c], b = shift[c];
+        v.x = __fmaf_rn(v.x, s.x, b.x); v.y = __fmaf_rn(v.y, s.y, b.y); v.z = __fmaf_rn(v.z, s.z, b.z); v.w = __fmaf_rn(v.w, s.w, b.w);
+        if (res) {
+            float4 r = res[i];
+            if (rscale) {
+                float4 rs = rscale[c], rb = rshift[c];
+                r.x = r.x * rs.x + rb.x; r.y = r.y * rs.y + rb.y; r.z = r.z * rs.z + rb.z; r.w = r.w * rs.w + rb.w;
+            }
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        out[i] = v;
+    }
+}
+static inline int ew_grid(long total) {
+    long b = (total + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+extern "C" int tri_bn_act(const float* y, const float* scale, const float* shift, const float* res, const float* rscale,
+                          const float* rshift, float* out, long M, int C, int relu, void* stream) {
+    if (C % 4) { tri_set_error("tri_bn_act: C must be a multiple of 4"); return TRI_ERR_ARG; }
+    long total4 = M * (C / 4);
+    bn_act_kernel<<<ew_grid(total4), 256, 0, (hipStream_t)stream>>>((const float4*)y, (const float4*)scale, (const float4*)shift,
+                                                                     (const float4*)res, (const float4*)rscale, (const float4*)rshift,
+                                                                     (float4*)out, total4, C / 4, relu);
+    return tri_check_launch("tri_bn_act");
+}
+
+// g = dout * (out > 0)   (ReLU backward from the saved output; may run in place on dout)
+__global__ void relu_bwd_kernel(const float4* dout, const float4* __restrict__ out, float4* g, long total4) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        float4 d = dout[i], o = out[i];
+        d.x = o.x > 0.f ? d.x : 0.f; d.y = o.y > 0.f ? d.y : 0.f; d.z = o.z > 0.f ? d.z : 0.f; d.w = o.w > 0.f ? d.w : 0.f;
+        g[i] = d;
+    }
+}
+extern "C" int tri_relu_bwd(const float* dout, const float* out, float* g, long n, void* stream) {
+    if (n % 4) { tri_set_error("tri_relu_bwd: n must be a multiple of 4"); return TRI_ERR_ARG; }
+    relu_bwd_kernel<<<ew_grid(n / 4), 256, 0, (hipStream_t)stream>>>((const float4*)dout, (const float4*)out, (float4*)g, n / 4);
+    return tri_check_launch("tri_relu_bwd");
+}
+
+// --------------------------------------------------------------------------------------------------- BN backward
+// Pass 1: per-block partial sums of g and g*y per channel ([nblk][2][C]); pass 2 (tri_bn_bwd_finalize): dgamma, dbeta
+// and the coefficients of dy = c1*g + c2 + c3*y; pass 3: apply (rows with row_mask == 0 stay zero).
+#define BNB_ROWS 256
+__global__ void bn_bwd_reduce_kernel(const float* __restrict__ y, const float* __restrict__ g, long M, int C, float* __restrict__ partial) {
+    extern __shared__ float sh[];                      // [rows_per_pass][C4*4][2]
+    const int C4 = C >> 2;
+    const int tpr = C4 < 256 ? C4 : 256;               // threads per row
+    const int rpp = 256 / tpr;                         // rows per pass
+    const int cpt = (C4 + tpr - 1) / tpr;              // float4 columns per thread
+    const int tc = threadIdx.x % tpr, tr = threadIdx.x / tpr;
+    const long r0 = (long)blockIdx.x * BNB_ROWS;
+    const long r1 = r0 + BNB_ROWS < M ? r0 + BNB_ROWS : M;
+    for (int cc = 0; cc < cpt; ++cc) {
+        int c4 = tc + cc * tpr;
+        float4 sg = make_float4(0, 0, 0, 0), sgy = make_float4(0, 0, 0, 0);
+        if (c4 < C4 && tr < rpp)
+            for (long r = r0 + tr; r < r1; r += rpp) {
+                float4 gv = *(const float4*)(g + r * C + c4 * 4), yv = *(const float4*)(y + r * C + c4 * 4);
+                sg.x += gv.x; sg.y += gv.y; sg.z += gv.z; sg.w += gv.w;
+                sgy.x += gv.x * yv.x; sgy.y += gv.y * yv.y; sgy.z += gv.z * yv.z; sgy.w += gv.w * yv.w;
+            }
+        __syncthreads();
+        if (c4 < C4 && tr < rpp) {
+            float* p = sh + ((size_t)tr * tpr + tc) * 8;
+            p[0] = sg.x; p[1] = sg.y; p[2] = sg.z; p[3] = sg.w; p[4] = sgy.x; p[5] = sgy.y; p[6] = sgy.z; p[7] = sgy.w;
+        }
+        __syncthreads();
+        if (tr == 0 && c4 < C4) {
+            float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int rr = 0; rr < rpp; ++rr) {
+                const float* p = sh + ((size_t)rr * tpr + tc) * 8;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a[k] += p[k];
+            }
+            float* o = partial + (size_t)blockIdx.x * 2 * C;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { o[c4 * 4 + k] = a[k]; o[C + c4 * 4 + k] = a[4 + k]; }
+        }
+    }
+}
+extern "C" int tri_bn_bwd_num_blocks(long M) { return (int)((M + BNB_ROWS - 1) / BNB_ROWS); }
+extern "C" int tri_bn_bwd_reduce(const float* y, const float* g, long M, int C, float* partial, void* stream) {
+    if (C % 4) { tri_set_error("tri_bn_bwd_reduce: C must be a multiple of 4"); return TRI_ERR_ARG; }
+    int nblk = (int)((M + BNB_ROWS - 1) / BNB_ROWS);
+    int C4 = C / 4, tpr = C4 < 256 ? C4 : 256, rpp = 256 / tpr;
+    size_t smem = (size_t)rpp * tpr * 8 * sizeof(float);
+    bn_bwd_reduce_kernel<<<nblk, 256, smem, (hipStream_t)stream>>>(y, g, M, C, partial);
+    return tri_check_launch("tri_bn_bwd_reduce");
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, const int* __restrict__ count_dev,
+                                       int count_host, const float* __restrict__ gamma, const float* __restrict__ mean,
+                                       const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                       float* __restrict__ c1, float* __restrict__ c2, float* __restrict__ c3) {
+    __shared__ double ssum[8][32], ssq[8][32];
+    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cl;
+    double s = 0.0, q = 0.0;
+    if (c < C)
+        for (int b = rl; b < nblk; b += 32) {
+            s += (double)partial[((size_t)b * 2 + 0) * C + c];
+            q += (double)partial[((size_t)b * 2 + 1) * C + c];
+        }
+    ssum[cl][rl] = s;
+    ssq[cl][rl] = q;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        for (int i = 1; i < 32; ++i) { s += ssum[cl][i]; q += ssq[cl][i]; }
+        double n = count_dev ? (double)(*count_dev) : (double)count_host;
+        if (n < 1.0) { dgamma[c] = 0.f; dbeta[c] = 0.f; c1[c] = 0.f; c2[c] = 0.f; c3[c] = 0.f; return; }
+        double mu = mean[c], is = invstd[c], ga = gamma[c];
+        double dbe = s;                                   // sum g
+        double dga = is * (q - mu * s);                   // sum g * xhat
+        dgamma[c] = (float)dga;
+        dbeta[c] = (float)dbe;
+        double k1 = ga * is;
+        double k3 = -ga * is * is * dga / n;
+        double k2 = -k1 * dbe / n - k3 * mu;
+        c1[c] = (float)k1; c2[c] = (float)k2; c3[c] = (float)k3;
+    }
+}
+extern "C" int tri_bn_bwd_finalize(const float* partial, int nblk, int C, const int* count_dev, int count_host, const float* gamma,
+                                   const float* mean, const float* invstd, float* dgamma, float* dbeta, float* c1, float* c2,
+                                   float* c3, void* stream) {
+    bn_bwd_finalize_kernel<<<(C + 7) / 8, 256, 0, (hipStream_t)stream>>>(partial, nblk, C, count_dev, count_host, gamma, mean,
+                                                                          invstd, dgamma, dbeta, c1, c2, c3);
+    return tri_check_launch("tri_bn_bwd_finalize");
+}
+
+__global__ void bn_bwd_apply_kernel(const float4* __restrict__ y, const float4* g, const float4* __restrict__ c1,
+                                    const float4* __restrict__ c2, const float4* __restrict__ c3,
+                                    const uint8_t* __restrict__ row_mask, float4* dy, long total4, int C4) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        long row = i / C4;
+        int c = (int)(i - row * C4);
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!row_mask || row_mask[row]) {
+            float4 yv = y[i], gv = g[i], a = c1[c], b = c2[c], d = c3[c];
+            o.x = a.x * gv.x + b.x + d.x * yv.x; o.y = a.y * gv.y + b.y + d.y * yv.y;
+            o.z = a.z * gv.z + b.z + d.z * yv.z; o.w = a.w * gv.w + b.w + d.w * yv.w;
+        }
+        dy[i] = o;
+    }
+}
+extern "C" int tri_bn_bwd_apply(const float* y, const float* g, const float* c1, const float* c2, const float* c3,
+                                const uint8_t* row_mask, float* dy, long M, int C, void* stream) {
+    long total4 = M * (C / 4);
+    bn_bwd_apply_kernel<<<ew_grid(total4), 256, 0, (hipStream_t)stream>>>((const float4*)y, (const float4*)g, (const float4*)c1,
+                                                                           (const float4*)c2, (const float4*)c3, row_mask,
+                                                                           (float4*)dy, total4, C / 4);
+    return tri_check_launch("tri_bn_bwd_apply");
+}
+
+// --------------------------------------------------------------------- voxel: BN + ReLU + mask + 2^3 max-pool
+// y [B,D,D,D,C] raw conv output, mask [B,D,D,D]; pooled [B,D/2,..,C], mask_out = OR of children
+__global__ void bn_relu_pool3d_fwd_kernel(const float* __restrict__ y, const float4* __restrict__ scale, const float4* __restrict__ shift,
+                                          const uint8_t* __restrict__ mask, int B, int D, int C4, float* __restrict__ pooled,
+                                          uint8_t* __restrict__ mask_out) {
+    const int Do = D >> 1;
+    const long total = (long)B * Do * Do * Do * C4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % C4);
+        long pos = i / C4;
+        int ox = (int)(pos % Do); long r = pos / Do;
+        int oy = (int)(r % Do); r /= Do;
+        int oz = (int)(r % Do); int b = (int)(r / Do);
+        float4 s = scale[c], t = shift[c];
+        float4 best = make_float4(0.f, 0.f, 0.f, 0.f);
+        int any = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            long ip = (((long)b * D + (oz * 2 + (k >> 2))) * D + (oy * 2 + ((k >> 1) & 1))) * D + (ox * 2 + (k & 1));
+            if (mask[ip]) {
+                any = 1;
+                float4 v = *(const float4*)(y + (ip * C4 + c) * 4);
+                best.x = fmaxf(best.x, __fmaf_rn(v.x, s.x, t.x)); best.y = fmaxf(best.y, __fmaf_rn(v.y, s.y, t.y));
+                best.z = fmaxf(best.z, __fmaf_rn(v.z, s.z, t.z)); best.w = fmaxf(best.w, __fmaf_rn(v.w, s.w, t.w));
+            }
+        }
+        *(float4*)(pooled + i * 4) = best;             // best >= 0: ReLU folded into the max with the zero init
+        if (c == 0) mask_out[pos] = (uint8_t)any;
+    }
+}
+extern "C" int tri_bn_relu_pool3d_fwd(const float* y, const float* scale, const float* shift, const uint8_t* mask, int B, int D, int C,
+                                      float* pooled, uint8_t* mask_out, void* stream) {
+    if (C % 4 || D % 2) { tri_set_error("tri_bn_relu_pool3d_fwd: C%4 or D%2"); return TRI_ERR_ARG; }
+    long total = (long)B * (D / 2) * (D / 2) * (D / 2) * (C / 4);
+    bn_relu_pool3d_fwd_kernel<<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(y, (const float4*)scale, (const float4*)shift, mask, B, D,
+                                                                                C / 4, pooled, mask_out);
+    return tri_check_launch("tri_bn_relu_pool3d_fwd");
+}
+
+// g[B,D,D,D,C] = gradient w.r.t. the BN output: dpooled routed to the FIRST child (d,h,w scan order, as
+// torch.max_pool3d) whose post-ReLU value equals the pooled maximum and is > 0; zero elsewhere / at inactive sites.
+__global__ void pool3d_bwd_route_kernel(const float* __restrict__ y, const float4* __restrict__ scale, const float4* __restrict__ shift,
+                                        const uint8_t* __restrict__ mask, const float* __restrict__ pooled,
+                                        const float* __restrict__ dpooled, int B, int D, int C4, float* __restrict__ g) {
+    const int Do = D >> 1;
+    const long total = (long)B * Do * Do * Do * C4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % C4);
+        long pos = i / C4;
+        int ox = (int)(pos % Do); long r = pos / Do;
+        int oy = (int)(r % Do); r /= Do;
+        int oz = (int)(r % Do); int b = (int)(r / Do);
+        float4 s = scale[c], t = shift[c];
+        float4 pm = *(const float4*)(pooled + i * 4), dp = *(const float4*)(dpooled + i * 4);
+        bool dx = false, dy = false, dz = false, dw = false;      // already routed
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            long ip = (((long)b * D + (oz * 2 + (k >> 2))) * D + (oy * 2 + ((k >> 1) & 1))) * D + (ox * 2 + (k & 1));
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (mask[ip]) {
+                float4 v = *(const float4*)(y + (ip * C4 + c) * 4);
+                float zx = fmaxf(__fmaf_rn(v.x, s.x, t.x), 0.f), zy = fmaxf(__fmaf_rn(v.y, s.y, t.y), 0.f);
+                float zz = fmaxf(__fmaf_rn(v.z, s.z, t.z), 0.f), zw = fmaxf(__fmaf_rn(v.w, s.w, t.w), 0.f);
+                if (!dx && zx == pm.x && zx > 0.f) { o.x = dp.x; dx = true; }
+                if (!dy && zy == pm.y && zy > 0.f) { o.y = dp.y; dy = true; }
+                if (!dz && zz == pm.z && zz > 0.f) { o.z = dp.z; dz = true; }
+                if (!dw && zw == pm.w && zw > 0.f) { o.w = dp.w; dw = true; }
+            }
+            *(float4*)(g + (ip * C4 + c) * 4) = o;
+        }
+    }
+}
+extern "C" int tri_pool3d_bwd_route(const float* y, const float* scale, const float* shift, const uint8_t* mask, const float* pooled,
+                                    const float* dpooled, int B, int D, int C, float* g, void* stream) {
+    long total = (long)B * (D / 2) * (D / 2) * (D / 2) * (C / 4);
+    pool3d_bwd_route_kernel<<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(y, (const float4*)scale, (const float4*)shift, mask, pooled,
+                                                                              dpooled, B, D, C / 4, g);
+    return tri_check_launch("tri_pool3d_bwd_route");
+}
+
+// ----------------------------------------------------------------------------- ResNet stem: 3x3 / stride 2 / pad 1
+__global__ void maxpool2d_fwd_kernel(const float* __restrict__ x, int N, int H, int W, int C4, float* __restrict__ out) {
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;          // floor((H + 2 - 3)/2) + 1
+    const long total = (long)N * Ho * Wo * C4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % C4);
+        long pos = i / C4;
+        int ow = (int)(pos % Wo); long r = pos / Wo;
+        int oh = (int)(r % Ho); int n = (int)(r / Ho);
+        float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            int ih = oh * 2 - 1 + kh;
+            if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                int iw = ow * 2 - 1 + kw;
+                if ((unsigned)iw >= (unsigned)W) continue;
+                float4 v = *(const float4*)(x + ((((long)n * H + ih) * W + iw) * C4 + c) * 4);
+                best.x = fmaxf(best.x, v.x); best.y = fmaxf(best.y, v.y); best.z = fmaxf(best.z, v.z); best.w = fmaxf(best.w, v.w);
+            }
+        }
+        *(float4*)(out + i * 4) = best;
+    }
+}
+extern "C" int tri_maxpool2d_fwd(const float* x, int N, int H, int W, int C, float* out, void* stream) {
+    long total = (long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
+    maxpool2d_fwd_kernel<<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(x, N, H, W, C / 4, out);
+    return tri_check_launch("tri_maxpool2d_fwd");
+}
+
+// dx[n,h,w,c] = sum over the (<= 4) windows covering (h,w) of dout where (h,w) is that window's FIRST maximum in
+// (kh,kw) scan order (torch.max_pool2d tie rule).  Gather form: deterministic, no atomics.
+__global__ void maxpool2d_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dout, int N, int H, int W, int C4,
+                                     float* __restrict__ dx) {
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const long total = (long)N * H * W * C4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % C4);
+        long pos = i / C4;
+        int w = (int)(pos % W); long r = pos / W;
+        int h = (int)(r % H); int n = (int)(r / H);
+        float4 me = *(const float4*)(x + i * 4);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int oh = h / 2; oh <= (h + 1) / 2; ++oh) {
+            if (oh >= Ho) continue;
+            for (int ow = w / 2; ow <= (w + 1) / 2; ++ow) {
+                if (ow >= Wo) continue;
+                // is (h,w) the first maximum of window (oh,ow)?
+                bool fx = true, fy = true, fz = true, fw = true;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    int ih = oh * 2 - 1 + kh;
+                    if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        int iw = ow * 2 - 1 + kw;
+                        if ((unsigned)iw >= (unsigned)W) continue;
+                        if (ih == h && iw == w) continue;
+                        float4 v = *(const float4*)(x + ((((long)n * H + ih) * W + iw) * C4 + c) * 4);
+                        bool before = (ih < h) || (ih == h && iw < w);
+                        // an earlier element wins ties; a later element must be strictly greater to win
+                        fx = fx && (before ? v.x < me.x : v.x <= me.x);
+                        fy = fy && (before ? v.y < me.y : v.y <= me.y);
+                        fz = fz && (before ? v.z < me.z : v.z <= me.z);
+                        fw = fw && (before ? v.w < me.w : v.w <= me.w);
+                    }
+                }
+                float4 d = *(const float4*)(dout + ((((long)n * Ho + oh) * Wo + ow) * C4 + c) * 4);
+                if (fx) acc.x += d.x;
+                if (fy) acc.y += d.y;
+                if (fz) acc.z += d.z;
+                if (fw) acc.w += d.w;
+            }
+        }
+        *(float4*)(dx + i * 4) = acc;
+    }
+}
+extern "C" int tri_maxpool2d_bwd(const float* x, const float* dout, int N, int H, int W, int C, float* dx, void* stream) {
+    long total = (long)N * H * W * (C / 4);
+    maxpool2d_bwd_kernel<<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(x, dout, N, H, W, C / 4, dx);
+    return tri_check_launch("tri_maxpool2d_bwd");
+}
+
+// ----------------------------------------------------- global average pool + max over the views of one shape
+// x [B*V, HW, C] -> out [B, C], argmax view index [B, C] (first maximum, as torch.max(dim=1))
+__global__ void avgpool_viewmax_fwd_kernel(const float* __restrict__ x, int B, int V, int HW, int C, float* __restrict__ out,
+                                           int* __restrict__ arg) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * C) return;
+    int c = (int)(i % C), b = (int)(i / C);
+    float best = -INFINITY;
+    int bi = 0;
+    float inv = 1.0f / (float)HW;
+    for (int v = 0; v < V; ++v) {
+        const float* p = x + ((long)(b * V + v) * HW) * C + c;
+        float s = 0.f;
+        for (int k = 0; k < HW; ++k) s += p[(long)k * C];
+        s *= inv;
+        if (s > best) { best = s; bi = v; }
+    }
+    out[i] = best;
+    arg[i] = bi;
+}
+extern "C" int tri_avgpool_viewmax_fwd(const float* x, int B, int V, int HW, int C, float* out, int* arg, void* stream) {
+    long total = (long)B * C;
+    avgpool_viewmax_fwd_kernel<<<(int)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, B, V, HW, C, out, arg);
+    return tri_check_launch("tri_avgpool_viewmax_fwd");
+}
+__global__ void avgpool_viewmax_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ arg, int B, int V, int HW, int C,
+                                           float* __restrict__ dx) {
+    const long total = (long)B * V * HW * C;
+    float inv = 1.0f / (float)HW;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % C);
+        long r = i / C / HW;
+        int v = (int)(r % V), b = (int)(r / V);
+        dx[i] = (arg[(long)b * C + c] == v) ? dout[(long)b * C + c] * inv : 0.f;
+    }
+}
+extern "C" int tri_avgpool_viewmax_bwd(const float* dout, const int* arg, int B, int V, int HW, int C, float* dx, void* stream) {
+    long total = (long)B * V * HW * C;
+    avgpool_viewmax_bwd_kernel<<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(dout, arg, B, V, HW, C, dx);
+    return tri_check_launch("tri_avgpool_viewmax_bwd");
+}

@@ -1,0 +1,187 @@
+// Small kernels of the TriCoLo step (gfx950): error plumbing, layout converters (COO voxels -> dense masked grid,
+// NCHW images -> NHWC4), row L2-normalise forward/backward, column sums (bias gradients), fused Adam.
+#include "common.h"
+#include "../../include/tricolo_hip.h"
+#include <stdio.h>
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+extern "C" void tri_set_error(const char* msg) { strncpy(g_err, msg, sizeof(g_err) - 1); g_err[sizeof(g_err) - 1] = 0; }
+extern "C" const char* tri_last_error() { return g_err; }
+int tri_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+        return (int)e;
+    }
+    return TRI_OK;
+}
+extern "C" int tri_version() { return 1; }
+
+static inline int ew_grid(long total) {
+    long b = (total + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+// ------------------------------------------------------------------------------------------------ voxel scatter
+// COO batch of data_module.py:52-64 (locs [n,4] = (b,i0,i1,i2), feats [n,3] in [0,1]) -> dense channels-last grid
+// [B,V,V,V,4] = (r,g,b,0) and site mask [B,V,V,V].  Both outputs must be zero-filled first (tri_fill_zero).
+__global__ void voxel_scatter_kernel(const int* __restrict__ locs, const float* __restrict__ feats, int n, int B, int V,
+                                     float4* __restrict__ dense, uint8_t* __restrict__ mask) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int b = locs[i * 4], z = locs[i * 4 + 1], y = locs[i * 4 + 2], x = locs[i * 4 + 3];
+    if ((unsigned)b >= (unsigned)B || (unsigned)z >= (unsigned)V || (unsigned)y >= (unsigned)V || (unsigned)x >= (unsigned)V) return;
+    long pos = (((long)b * V + z) * V + y) * V + x;
+    dense[pos] = make_float4(feats[i * 3], feats[i * 3 + 1], feats[i * 3 + 2], 0.f);
+    mask[pos] = 1;
+}
+extern "C" int tri_voxel_scatter(const int* locs, const float* feats, int n, int B, int V, float* dense, uint8_t* mask, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    size_t sites = (size_t)B * V * V * V;
+    hipMemsetAsync(dense, 0, sites * 4 * sizeof(float), s);
+    hipMemsetAsync(mask, 0, sites, s);
+    if (n > 0) voxel_scatter_kernel<<<(n + 255) / 256, 256, 0, s>>>(locs, feats, n, B, V, (float4*)dense, mask);
+    return tri_check_launch("tri_voxel_scatter");
+}
+
+// count of non-zero mask bytes -> *count (device int)
+__global__ void mask_count_kernel(const uint8_t* __restrict__ mask, long n, int* __restrict__ count) {
+    int local = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) local += mask[i] ? 1 : 0;
+    float f = wave_sum((float)local);
+    __shared__ float ws[4];
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = f;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(count, (int)(ws[0] + ws[1] + ws[2] + ws[3] + 0.5f));
+}
+extern "C" int tri_mask_count(const uint8_t* mask, long n, int* count, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    hipMemsetAsync(count, 0, sizeof(int), s);
+    long b = (n + 256 * 64 - 1) / (256 * 64);
+    mask_count_kernel<<<(int)(b < 1 ? 1 : (b > 256 ? 256 : b)), 256, 0, s>>>(mask, n, count);
+    return tri_check_launch("tri_mask_count");
+}
+
+// ------------------------------------------------------------------------------------------------ image layout
+// x [N,3,H,W] f32 (tricolo_net.py:51 flatten of data_dict["images"]) -> [N,H,W,4] with a zero 4th channel
+__global__ void nchw3_to_nhwc4_kernel(const float* __restrict__ x, long HW, long total, float4* __restrict__ out) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long n = i / HW, p = i - n * HW;
+        const float* b = x + n * 3 * HW + p;
+        out[i] = make_float4(b[0], b[HW], b[2 * HW], 0.f);
+    }
+}
+extern "C" int tri_nchw3_to_nhwc4(const float* x, int N, int H, int W, float* out, void* stream) {
+    long HW = (long)H * W, total = (long)N * HW;
+    nchw3_to_nhwc4_kernel<<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(x, HW, total, (float4*)out);
+    return tri_check_launch("tri_nchw3_to_nhwc4");
+}
+
+// ------------------------------------------------------------------------------------------------ row L2 normalise
+// z = x / max(||x||, eps)   (F.normalize(dim=1), sparse_cnn.py:51, mv_cnn.py:33, bigru.py:18);  one wave per row
+__global__ void l2norm_fwd_kernel(const float* __restrict__ x, int rows, int D, float eps, float* __restrict__ z, float* __restrict__ norm) {
+    int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* p = x + (long)row * D;
+    float s = 0.f;
+    for (int i = lane; i < D; i += 64) s += p[i] * p[i];
+    s = wave_sum(s);
+    float nrm = sqrtf(s);
+    float inv = 1.0f / fmaxf(nrm, eps);
+    for (int i = lane; i < D; i += 64) z[(long)row * D + i] = p[i] * inv;
+    if (lane == 0 && norm) norm[row] = nrm;
+}
+extern "C" int tri_l2norm_fwd(const float* x, int rows, int D, float eps, float* z, float* norm, void* stream) {
+    l2norm_fwd_kernel<<<(rows + 3) / 4, 256, 0, (hipStream_t)stream>>>(x, rows, D, eps, z, norm);
+    return tri_check_launch("tri_l2norm_fwd");
+}
+// dx = (dz - z * <dz, z>) / max(norm, eps)
+__global__ void l2norm_bwd_kernel(const float* __restrict__ z, const float* __restrict__ norm, const float* __restrict__ dz, int rows,
+                                  int D, float eps, float* __restrict__ dx) {
+    int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* zp = z + (long)row * D;
+    const float* dp = dz + (long)row * D;
+    float s = 0.f;
+    for (int i = lane; i < D; i += 64) s += zp[i] * dp[i];
+    s = wave_sum(s);
+    float inv = 1.0f / fmaxf(norm[row], eps);
+    for (int i = lane; i < D; i += 64) dx[(long)row * D + i] = (dp[i] - zp[i] * s) * inv;
+}
+extern "C" int tri_l2norm_bwd(const float* z, const float* norm, const float* dz, int rows, int D, float eps, float* dx, void* stream) {
+    l2norm_bwd_kernel<<<(rows + 3) / 4, 256, 0, (hipStream_t)stream>>>(z, norm, dz, rows, D, eps, dx);
+    return tri_check_launch("tri_l2norm_bwd");
+}
+
+// ------------------------------------------------------------------------------------------------ column sums
+// out[c] = sum_m g[m, c]   (bias gradients); one block per 64 columns, fixed summation order
+__global__ void colsum_kernel(const float* __restrict__ g, long M, int C, float* __restrict__ out) {
+    __shared__ float sh[4][64];
+    int c = blockIdx.x * 64 + (threadIdx.x & 63), r = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < C)
+        for (long m = r; m < M; m += 4) s += g[m * C + c];
+    sh[r][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (r == 0 && c < C) out[c] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+}
+extern "C" int tri_colsum(const float* g, long M, int C, float* out, void* stream) {
+    colsum_kernel<<<(C + 63) / 64, 256, 0, (hipStream_t)stream>>>(g, M, C, out);
+    return tri_check_launch("tri_colsum");
+}
+
+// elementwise helpers on flat fp32 buffers
+__global__ void axpy_kernel(const float* __restrict__ x, float a, float* y, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] += a * x[i];
+}
+extern "C" int tri_axpy(const float* x, float a, float* y, long n, void* stream) {
+    axpy_kernel<<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(x, a, y, n);
+    return tri_check_launch("tri_axpy");
+}
+__global__ void act_kernel(const float* __restrict__ x, float* __restrict__ y, long n, int act) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float v = x[i];
+        y[i] = act == 1 ? fmaxf(v, 0.f) : (act == 2 ? tanhf(v) : v);
+    }
+}
+// g = dout * act'(out):  relu: out > 0;  tanh: 1 - out^2
+__global__ void act_bwd_kernel(const float* dout, const float* __restrict__ out, float* g, long n, int act) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float o = out[i], d = dout[i];
+        g[i] = act == 1 ? (o > 0.f ? d : 0.f) : (act == 2 ? d * (1.f - o * o) : d);
+    }
+}
+extern "C" int tri_act_bwd(const float* dout, const float* out, float* g, long n, int act, void* stream) {
+    act_bwd_kernel<<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(dout, out, g, n, act);
+    return tri_check_launch("tri_act_bwd");
+}
+
+// ------------------------------------------------------------------------------------------------ fused Adam
+// torch.optim.Adam(lr, betas, eps, weight_decay) single-tensor update, L2-in-gradient (config.yaml:50-53,
+// tricolo_net.py:43-44).  `step` lives on the device (incremented by tri_adam_tick) so the launch is graph-replayable.
+__global__ void adam_tick_kernel(int* step) { *step += 1; }
+extern "C" int tri_adam_tick(int* step, void* stream) {
+    adam_tick_kernel<<<1, 1, 0, (hipStream_t)stream>>>(step);
+    return tri_check_launch("tri_adam_tick");
+}
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
+                            const int* __restrict__ step, float lr, float b1, float b2, float eps, float wd, float gscale) {
+    const int t = *step;
+    const float bc1 = 1.f - powf(b1, (float)t), bc2 = 1.f - powf(b2, (float)t);
+    const float step_size = lr / bc1, inv_sqrt_bc2 = 1.f / sqrtf(bc2);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float pi = p[i];
+        float gi = g[i] * gscale + wd * pi;
+        float mi = b1 * m[i] + (1.f - b1) * gi;
+        float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = pi - step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+    }
+}
+extern "C" int tri_adam_step(float* p, const float* g, float* m, float* v, long n, const int* step, float lr, float b1, float b2,
+                             float eps, float wd, float gscale, void* stream) {
+    adam_kernel<<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, step, lr, b1, b2, eps, wd, gscale);
+    return tri_check_launch("tri_adam_step");
+}

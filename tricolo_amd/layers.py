@@ -1,0 +1,113 @@
+"""Host-side building blocks shared by the encoder modules: module base class, dense layers on the MFMA conv
+kernel, and helpers for the hand-written backward passes."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+try:                                    # the reference's modules are pl.LightningModule (SURVEY 8b "Type / ownership")
+    import lightning.pytorch as _pl     # not installed on the build / GPU boxes; used when present
+    _Base = _pl.LightningModule
+except Exception:                       # noqa: BLE001
+    _Base = nn.Module
+
+
+class TriModule(_Base):
+    """nn.Module with the ``.device`` property the reference code relies on (bigru.py:16, nt_xent.py:62)."""
+
+    if _Base is nn.Module:
+        @property
+        def device(self):
+            for p in self.parameters():
+                return p.device
+            for b in self.buffers():
+                return b.device
+            return torch.device("cpu")
+
+
+def require_gpu(t: torch.Tensor, who: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"{who}: input is on {t.device}; tricolo_amd runs only on an MI355X (HIP extension, no CPU "
+                           f"fallback).  Use the oracle/ package for CPU reference arithmetic.")
+
+
+_linear_geoms: dict = {}
+
+
+def linear_geom(rows: int, K: int, N: int, spatial: int = 1) -> ops.ConvGeom:
+    """Linear(K*spatial -> N) as a conv over a `spatial`-site grid: x is channels-last [rows, spatial, K] and the
+    parameter is the reference's [N, K*spatial] with input index = c*spatial + s (channels-first flatten of
+    sparse_cnn.py:49), i.e. strides (s_co, s_tap, s_ci) = (K*spatial, 1, spatial)."""
+    key = (rows, K, N, spatial)
+    g = _linear_geoms.get(key)
+    if g is None:
+        if spatial == 1:
+            g = ops.ConvGeom(rows, (1, 1, 1), K, K, N, (1, 1, 1), 1, (0, 0, 0), (K, 1, 1))
+        else:
+            e = round(spatial ** (1 / 3))
+            assert e ** 3 == spatial
+            g = ops.ConvGeom(rows, (e, e, e), K, K, N, (e, e, e), e, (0, 0, 0), (K * spatial, 1, spatial))
+        _linear_geoms[key] = g
+    return g
+
+
+def linear_fwd(x, w, b, act: int, precision: str, spatial: int = 1):
+    """x [rows, spatial*K] channels-last -> act(x W^T + b) [rows, N] on the MFMA conv kernel (act 0/1 relu/2 tanh)."""
+    rows = x.shape[0]
+    N = w.shape[0]
+    K = w.shape[1] // spatial
+    g = linear_geom(rows, K, N, spatial)
+    packed = ops.pack_weight(w, g, precision)
+    out = ops.conv_fwd(x, g, packed, bias=b, act=act)
+    return out.view(rows, N)
+
+
+def linear_bwd(x, w, out, dout, act: int, precision: str, spatial: int = 1, need_dx: bool = True):
+    """Backward of linear_fwd.  Returns (dx | None, dw, db)."""
+    rows = x.shape[0]
+    N = w.shape[0]
+    K = w.shape[1] // spatial
+    g = linear_geom(rows, K, N, spatial)
+    dpre = ops.act_bwd(dout.contiguous().clone(), out, act) if act else dout.contiguous()
+    dw = ops.conv_wgrad(x, dpre, g, w, precision)
+    db = ops.colsum(dpre)
+    dx = None
+    if need_dx:
+        packed_t = ops.pack_weight(w, g, precision, transposed=True)
+        dx = ops.conv_dgrad(dpre, g, packed_t).view(x.shape)
+    return dx, dw, db
+
+
+class LinearFn(torch.autograd.Function):
+    """Autograd wrapper of one dense layer (used where a tower is not one fused Function: CLIP-text MLP, BiGRU fc)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act, precision):
+        x = x.contiguous()
+        out = linear_fwd(x, w, b, act, precision)
+        ctx.save_for_backward(x, w, out)
+        ctx.act, ctx.precision = act, precision
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w, out = ctx.saved_tensors
+        dx, dw, db = linear_bwd(x, w, out, dout, ctx.act, ctx.precision, need_dx=ctx.needs_input_grad[0])
+        return dx, dw, db, None, None
+
+
+class L2NormFn(torch.autograd.Function):
+    """F.normalize(x, dim=1) as one kernel each way."""
+
+    @staticmethod
+    def forward(ctx, x):
+        z, norm = ops.l2norm_fwd(x.contiguous())
+        ctx.save_for_backward(z, norm)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        z, norm = ctx.saved_tensors
+        return ops.l2norm_bwd(z, norm, dz)

@@ -1,0 +1,190 @@
+"""MVCNNEncoder (ResNet-18 trunk + per-shape view max-pool) on hand-written gfx950 kernels - drop-in for
+/root/reference/tricolo/model/module/img_encoder/mv_cnn.py:13-33 (resnet18 branch of SVCNN, :40-45).
+
+Same constructor kwargs (z_dim, out_dim, cnn_name, num_views, **kwargs; `clip_model` is accepted and ignored like
+the reference does), same forward(x=[B*Nv,3,S,S], data_dict) -> [B, out_dim] unit rows, and the same 126
+state-dict keys: net_1.{0,1,4,5,6,7}.* (Sequential over the torchvision children conv1, bn1, relu, maxpool,
+layer1..4, avgpool), net_2.{weight,bias}, mlp.{0,2}.{weight,bias}.  resnet34/50/efficientnet branches
+(mv_cnn.py:46-59) are out of scope (no BASELINE config uses them) and raise.  ImageNet weights cannot be downloaded
+offline: parameters start from torchvision's init rule; load a checkpoint through load_state_dict.
+
+MI355X design: images are converted once to channels-last [N,H,W,4]; all 20 convs run as implicit-GEMM on MFMA with
+BatchNorm statistics produced by the conv epilogue; BN(+residual)+ReLU is one pass; global-average-pool and the
+view max are fused.  The whole tower (forward and backward) is one autograd node.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .... import ops
+from ....layers import TriModule, linear_bwd, linear_fwd, require_gpu
+
+
+class _BasicBlockParams(nn.Module):
+    def __init__(self, inplanes, planes, stride):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = None
+        if stride != 1 or inplanes != planes:
+            self.downsample = nn.Sequential(nn.Conv2d(inplanes, planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
+        self.stride = stride
+
+
+def _resnet18_trunk_params():
+    layers = [nn.Conv2d(3, 64, 7, 2, 3, bias=False), nn.BatchNorm2d(64), nn.ReLU(inplace=True), nn.MaxPool2d(3, 2, 1)]
+    inpl = 64
+    for planes, stride in ((64, 1), (128, 2), (256, 2), (512, 2)):
+        layers.append(nn.Sequential(_BasicBlockParams(inpl, planes, stride), _BasicBlockParams(planes, planes, 1)))
+        inpl = planes
+    layers.append(nn.AdaptiveAvgPool2d((1, 1)))
+    net = nn.Sequential(*layers)
+    for m in net.modules():
+        if isinstance(m, nn.Conv2d):
+            nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+    return net
+
+
+class MVCNNEncoder(TriModule):
+    def __init__(self, z_dim, out_dim, cnn_name, num_views, precision=None, **kwargs):
+        super().__init__()
+        if cnn_name != "resnet18":
+            raise NotImplementedError(f"cnn_name={cnn_name!r}: only the resnet18 branch (mv_cnn.py:43-45) is built")
+        self.num_views = num_views
+        self.precision = precision
+        self.net_1 = _resnet18_trunk_params()
+        self.net_2 = nn.Linear(512, z_dim)
+        self.mlp = nn.Sequential(nn.Linear(z_dim, out_dim), nn.ReLU(inplace=True), nn.Linear(out_dim, out_dim))
+        self._geoms = {}
+
+    def _prec(self):
+        return self.precision or ops.default_precision()
+
+    # conv/bn units in execution order; each = (conv_module, bn_module)
+    def _blocks(self):
+        return [blk for li in (4, 5, 6, 7) for blk in self.net_1[li]]
+
+    def _param_list(self):
+        ps = [self.net_1[0].weight, self.net_1[1].weight, self.net_1[1].bias]
+        for blk in self._blocks():
+            ps += [blk.conv1.weight, blk.bn1.weight, blk.bn1.bias, blk.conv2.weight, blk.bn2.weight, blk.bn2.bias]
+            if blk.downsample is not None:
+                ps += [blk.downsample[0].weight, blk.downsample[1].weight, blk.downsample[1].bias]
+        ps += [self.net_2.weight, self.net_2.bias, self.mlp[0].weight, self.mlp[0].bias, self.mlp[2].weight, self.mlp[2].bias]
+        return ps
+
+    def _geom2d(self, N, H, W, conv: nn.Conv2d):
+        key = (N, H, W, id(conv))
+        g = self._geoms.get(key)
+        if g is None:
+            cin, cout = conv.in_channels, conv.out_channels
+            k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+            cs = 4 if cin == 3 else cin
+            g = ops.ConvGeom(N, (1, H, W), cin, cs, cout, (1, k, k), s, (0, p, p), (cin * k * k, 1, k * k))
+            self._geoms[key] = g
+        return g
+
+    def _conv_bn(self, x, conv, bn, prec, train):
+        N, _, H, W, _ = x.shape
+        g = self._geom2d(N, H, W, conv)
+        packed = ops.pack_weight(conv.weight, g, prec)
+        if train:
+            y, stats = ops.conv_fwd(x, g, packed, want_stats=True)
+            co = ops.bn_finalize(stats, g.cout, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                 count_host=g.M, momentum=bn.momentum, eps=bn.eps)
+        else:
+            y = ops.conv_fwd(x, g, packed)
+            co = ops.bn_eval_coeffs(g.cout, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+        return y, co, g
+
+    def _forward_impl(self, images, save: bool):
+        prec, train = self._prec(), self.training
+        N = images.shape[0]
+        if N % self.num_views:
+            raise RuntimeError("mat shape: number of images is not a multiple of num_views")
+        B = N // self.num_views
+        x0 = ops.nchw3_to_nhwc4(images)
+        y, co, g = self._conv_bn(x0, self.net_1[0], self.net_1[1], prec, train)
+        z = ops.bn_act(y, co, relu=True)
+        x = ops.maxpool2d_fwd(z)
+        saved = {"stem": (x0, y, co, g, z), "blocks": [], "B": B, "N": N}
+        for blk in self._blocks():
+            y1, co1, g1 = self._conv_bn(x, blk.conv1, blk.bn1, prec, train)
+            a1 = ops.bn_act(y1, co1, relu=True)
+            y2, co2, g2 = self._conv_bn(a1, blk.conv2, blk.bn2, prec, train)
+            if blk.downsample is not None:
+                yd, cod, gd = self._conv_bn(x, blk.downsample[0], blk.downsample[1], prec, train)
+                out = ops.bn_act(y2, co2, relu=True, res=yd, res_co=cod)
+            else:
+                yd = cod = gd = None
+                out = ops.bn_act(y2, co2, relu=True, res=x)
+            if save:
+                saved["blocks"].append((x, y1, co1, g1, a1, y2, co2, g2, yd, cod, gd, out))
+            x = out
+        pooled, arg = ops.avgpool_viewmax_fwd(x, B, self.num_views)
+        f = linear_fwd(pooled, self.net_2.weight, self.net_2.bias, 0, prec)
+        h = linear_fwd(f, self.mlp[0].weight, self.mlp[0].bias, 1, prec)
+        o = linear_fwd(h, self.mlp[2].weight, self.mlp[2].bias, 0, prec)
+        zz, norm = ops.l2norm_fwd(o)
+        if save:
+            saved.update(feat_shape=tuple(x.shape), pooled=pooled, arg=arg, f=f, h=h, o=o, z=zz, norm=norm)
+        return zz, saved
+
+    def _backward_impl(self, saved, dz):
+        prec, B, N = self._prec(), saved["B"], saved["N"]
+        gr = {}
+        do = ops.l2norm_bwd(saved["z"], saved["norm"], dz)
+        dh, gr[self.mlp[2].weight], gr[self.mlp[2].bias] = linear_bwd(saved["h"], self.mlp[2].weight, saved["o"], do, 0, prec)
+        df, gr[self.mlp[0].weight], gr[self.mlp[0].bias] = linear_bwd(saved["f"], self.mlp[0].weight, saved["h"], dh, 1, prec)
+        dp, gr[self.net_2.weight], gr[self.net_2.bias] = linear_bwd(saved["pooled"], self.net_2.weight, saved["f"], df, 0, prec)
+        dout = ops.avgpool_viewmax_bwd(dp, saved["arg"], saved["feat_shape"], B, self.num_views)
+        blocks = self._blocks()
+        for blk, sv in zip(reversed(blocks), reversed(saved["blocks"])):
+            x, y1, co1, g1, a1, y2, co2, g2, yd, cod, gd, out = sv
+            g = ops.relu_bwd(dout, out)                                       # grad of the block's pre-activation sum
+            dy2, gr[blk.bn2.weight], gr[blk.bn2.bias] = ops.bn_bwd(y2, g, co2, blk.bn2.weight, count_host=g2.M, inplace=False)
+            gr[blk.conv2.weight] = ops.conv_wgrad(a1, dy2, g2, blk.conv2.weight, prec)
+            da1 = ops.conv_dgrad(dy2, g2, ops.pack_weight(blk.conv2.weight, g2, prec, transposed=True))
+            g1z = ops.relu_bwd(da1, a1)
+            dy1, gr[blk.bn1.weight], gr[blk.bn1.bias] = ops.bn_bwd(y1, g1z, co1, blk.bn1.weight, count_host=g1.M)
+            gr[blk.conv1.weight] = ops.conv_wgrad(x, dy1, g1, blk.conv1.weight, prec)
+            if blk.downsample is not None:
+                dyd, gr[blk.downsample[1].weight], gr[blk.downsample[1].bias] = ops.bn_bwd(
+                    yd, g, cod, blk.downsample[1].weight, count_host=gd.M)
+                gr[blk.downsample[0].weight] = ops.conv_wgrad(x, dyd, gd, blk.downsample[0].weight, prec)
+                dx = ops.conv_dgrad(dyd, gd, ops.pack_weight(blk.downsample[0].weight, gd, prec, transposed=True))
+            else:
+                dx = g                                                         # identity branch
+            dx = ops.conv_dgrad(dy1, g1, ops.pack_weight(blk.conv1.weight, g1, prec, transposed=True), out=dx, accumulate=True)
+            dout = dx
+        x0, y, co, g0, z = saved["stem"]
+        dzs = ops.maxpool2d_bwd(z, dout)
+        gz = ops.relu_bwd(dzs, z)
+        dy, gr[self.net_1[1].weight], gr[self.net_1[1].bias] = ops.bn_bwd(y, gz, co, self.net_1[1].weight, count_host=g0.M)
+        gr[self.net_1[0].weight] = ops.conv_wgrad(x0, dy, g0, self.net_1[0].weight, prec)
+        return [gr[p] for p in self._param_list()]
+
+    def forward(self, x, data_dict=None):
+        require_gpu(x, "MVCNNEncoder")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return _MVCNNTowerFn.apply(self, x, *self._param_list())
+        z, _ = self._forward_impl(x, save=False)
+        return z
+
+
+class _MVCNNTowerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, images, *params):
+        z, saved = module._forward_impl(images, save=True)
+        ctx.module, ctx.saved = module, saved
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        grads = ctx.module._backward_impl(ctx.saved, dz.contiguous())
+        ctx.saved = None
+        return (None, None, *grads)

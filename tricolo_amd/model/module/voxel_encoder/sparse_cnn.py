@@ -1,0 +1,148 @@
+"""SparseCNNEncoder on hand-written gfx950 kernels - drop-in for
+/root/reference/tricolo/model/module/voxel_encoder/sparse_cnn.py:8-51.
+
+Same constructor kwargs (voxel_size, ef_dim, z_dim, out_dim, **kwargs), same forward(x={'locs','feats'}, batch_size)
+-> [B, out_dim] unit rows, same state-dict keys (sparseModel.{0,4,8,12,16}.weight in spconv's [Cout,kd,kh,kw,Cin]
+layout, sparseModel.{1,5,9,13,17}.{weight,bias,running_mean,running_var,num_batches_tracked}, mlp.{0,2}.*).
+One deliberate generalisation: mlp[0].in_features = z_dim * (voxel_size // 32)**3 instead of
+the hard-coded 4096 (identical at 64^3, and makes the 32^3 configs of BASELINE.json runnable).
+
+MI355X design: the COO batch is scattered once into a dense channels-last grid + site mask; every SubMConv3d is a
+masked implicit-GEMM on MFMA (inactive 128-site tiles are skipped, inactive rows written as zeros); BatchNorm
+statistics come out of the conv epilogue; BN + ReLU + mask + 2^3 max-pool is one HBM pass.  Forward and backward
+of the whole tower are ONE autograd node, so a step costs a handful of Python calls and is HIP-graph capturable.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from .... import ops
+from ....layers import TriModule, linear_bwd, linear_fwd, require_gpu
+
+
+class SubMConv3dParams(nn.Module):
+    """Parameter holder named like spconv.SubMConv3d(bias=False): weight [Cout, 3, 3, 3, Cin]."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, 3, 3, 3, cin))
+        bound = 1.0 / math.sqrt(cin * 27)
+        nn.init.uniform_(self.weight, -bound, bound)
+
+
+class SparseCNNEncoder(TriModule):
+    def __init__(self, voxel_size, ef_dim, z_dim, out_dim, precision=None, **kwargs):
+        super().__init__()
+        if voxel_size % 32 != 0:
+            raise ValueError("voxel_size must be a multiple of 32 (five stride-2 pools)")
+        self.voxel_size = voxel_size
+        self.precision = precision
+        self.chans = [3, ef_dim, ef_dim * 2, ef_dim * 4, ef_dim * 8, z_dim]
+        mods = {}
+        for i in range(5):                                  # sparse_cnn.py:12-35: conv at 4i, BN at 4i+1
+            mods[str(4 * i)] = SubMConv3dParams(self.chans[i], self.chans[i + 1])
+            mods[str(4 * i + 1)] = nn.BatchNorm1d(self.chans[i + 1])
+        self.sparseModel = nn.ModuleDict(mods)
+        self.spatial = (voxel_size // 32) ** 3
+        self.mlp = nn.Sequential(nn.Linear(z_dim * self.spatial, out_dim), nn.ReLU(inplace=True), nn.Linear(out_dim, out_dim))
+        self._geoms = {}
+
+    # ------------------------------------------------------------------ parameter plumbing
+    def _param_list(self):
+        ps = []
+        for i in range(5):
+            bn = self.sparseModel[str(4 * i + 1)]
+            ps += [self.sparseModel[str(4 * i)].weight, bn.weight, bn.bias]
+        ps += [self.mlp[0].weight, self.mlp[0].bias, self.mlp[2].weight, self.mlp[2].bias]
+        return ps
+
+    def _geom(self, B, level):
+        key = (B, level)
+        g = self._geoms.get(key)
+        if g is None:
+            D = self.voxel_size >> level
+            cin, cout = self.chans[level], self.chans[level + 1]
+            cs = 4 if cin == 3 else cin
+            g = ops.ConvGeom(B, (D, D, D), cin, cs, cout, (3, 3, 3), 1, (1, 1, 1), (27 * cin, cin, 1))
+            self._geoms[key] = g
+        return g
+
+    def _prec(self):
+        return self.precision or ops.default_precision()
+
+    # ------------------------------------------------------------------ forward / backward implementations
+    def _forward_impl(self, locs, feats, B, save: bool):
+        prec, V, train = self._prec(), self.voxel_size, self.training
+        x, mask = ops.voxel_scatter(locs, feats, B, V)
+        count = ops.mask_count(mask, B * V ** 3)
+        saved = {"levels": [], "B": B}
+        for l in range(5):
+            D, C = V >> l, self.chans[l + 1]
+            g = self._geom(B, l)
+            conv, bn = self.sparseModel[str(4 * l)], self.sparseModel[str(4 * l + 1)]
+            packed = ops.pack_weight(conv.weight, g, prec)
+            if train:
+                y, stats = ops.conv_fwd(x, g, packed, row_mask=mask, want_stats=True)
+                co = ops.bn_finalize(stats, C, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                     count_dev=count, momentum=bn.momentum, eps=bn.eps)
+            else:
+                y = ops.conv_fwd(x, g, packed, row_mask=mask)
+                co = ops.bn_eval_coeffs(C, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+            pooled, mask_out = ops.bn_relu_pool3d_fwd(y, co, mask, B, D, C)
+            count_out = ops.mask_count(mask_out, B * (D // 2) ** 3)
+            if save:
+                saved["levels"].append((x, y, mask, count, co, pooled))
+            x, mask, count = pooled, mask_out, count_out
+        flat = x.view(B, -1)                                   # channels-last [B, v, v, v, C]
+        h = linear_fwd(flat, self.mlp[0].weight, self.mlp[0].bias, 1, prec, spatial=self.spatial)
+        o = linear_fwd(h, self.mlp[2].weight, self.mlp[2].bias, 0, prec)
+        z, norm = ops.l2norm_fwd(o)
+        if save:
+            saved.update(flat=flat, h=h, o=o, z=z, norm=norm)
+        return z, saved
+
+    def _backward_impl(self, saved, dz):
+        prec, V, B = self._prec(), self.voxel_size, saved["B"]
+        grads = [None] * 19
+        do = ops.l2norm_bwd(saved["z"], saved["norm"], dz)
+        dh, grads[17], grads[18] = linear_bwd(saved["h"], self.mlp[2].weight, saved["o"], do, 0, prec)
+        dflat, grads[15], grads[16] = linear_bwd(saved["flat"], self.mlp[0].weight, saved["h"], dh, 1, prec, spatial=self.spatial)
+        dx = dflat
+        for l in range(4, -1, -1):
+            D, C = V >> l, self.chans[l + 1]
+            g = self._geom(B, l)
+            x, y, mask, count, co, pooled = saved["levels"][l]
+            conv, bn = self.sparseModel[str(4 * l)], self.sparseModel[str(4 * l + 1)]
+            gz = ops.pool3d_bwd_route(y, co, mask, pooled, dx.contiguous(), B, D, C)
+            dy, dgamma, dbeta = ops.bn_bwd(y, gz, co, bn.weight, count_dev=count, row_mask=mask)
+            grads[3 * l] = ops.conv_wgrad(x, dy, g, conv.weight, prec, row_mask=mask)
+            grads[3 * l + 1], grads[3 * l + 2] = dgamma, dbeta
+            if l > 0:
+                packed_t = ops.pack_weight(conv.weight, g, prec, transposed=True)
+                dx = ops.conv_dgrad(dy, g, packed_t, row_mask=mask)
+        return grads
+
+    def forward(self, x, batch_size):
+        locs, feats = x["locs"], x["feats"]
+        require_gpu(feats, "SparseCNNEncoder")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return _VoxelTowerFn.apply(self, locs, feats, int(batch_size), *self._param_list())
+        z, _ = self._forward_impl(locs, feats, int(batch_size), save=False)
+        return z
+
+
+class _VoxelTowerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, locs, feats, batch_size, *params):
+        z, saved = module._forward_impl(locs, feats, batch_size, save=True)
+        ctx.module, ctx.saved = module, saved
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        grads = ctx.module._backward_impl(ctx.saved, dz.contiguous())
+        ctx.saved = None
+        return (None, None, None, None, *grads)

@@ -1,0 +1,157 @@
+"""TriCoLoNet container - mirrors /root/reference/tricolo/model/tricolo_net.py:11-158 on the HIP-backed modules.
+
+Same construction from a Hydra-style cfg (encoders chosen by NAME in cfg.model.{text,image,voxel}_encoder and built
+from cfg.model.modules.<name> via `_target_`, loss from cfg.loss[cfg.loss.name], optimizer from cfg.optimizer),
+same forward / _calculate_losses / training_step / validation_step / test_step hooks and the same loss names
+(`train_loss/text_image_loss`, ... `total_loss`), so Lightning's Trainer can drive it when Lightning is installed;
+`tricolo_amd.trainer` drives it when it is not.  Modality order text, image, voxel matters: alpha_weight is
+asymmetric and the earlier modality is `zis` (tricolo_net.py:47-53,59-63).
+"""
+import os
+import pickle
+import types
+from itertools import combinations
+
+import numpy as np
+
+from .. import config as tcfg
+from ..evaluation.eval_retrieval import compute_metrics
+from ..layers import TriModule
+
+try:
+    import hydra as _hydra
+    _instantiate = _hydra.utils.instantiate
+except Exception:                                  # noqa: BLE001  Hydra is not installed on the build / GPU boxes
+    _instantiate = tcfg.instantiate
+
+
+def _load_clip(name, device):
+    """CLIP is only consulted for `.visual.output_dim` (clip_text.py:10); weights cannot be downloaded here."""
+    try:
+        import clip
+        model = clip.load(name, device=device)[0]
+        for p in model.parameters():
+            p.requires_grad = False               # tricolo_net.py:22-24
+        return model
+    except Exception:                              # noqa: BLE001
+        dim = {"ViT-L/14": 768, "ViT-B/32": 512, "ViT-B/16": 512}.get(name, 768)
+        return types.SimpleNamespace(visual=types.SimpleNamespace(output_dim=dim), parameters=lambda: [])
+
+
+class TriCoLoNet(TriModule):
+    def __init__(self, cfg):
+        super().__init__()
+        if hasattr(TriModule, "save_hyperparameters"):
+            self.save_hyperparameters()            # Lightning: stores cfg in the checkpoint (tricolo_net.py:14)
+        else:
+            self.__dict__["_hparams_ns"] = types.SimpleNamespace(cfg=cfg)
+        self._cfg = cfg
+        self.image_encoder = None
+        self.voxel_encoder = None
+        clip_model = None
+        if cfg.model.image_encoder == "CLIPImageEncoder" or cfg.model.text_encoder == "CLIPTextEncoder":
+            clip_model = _load_clip(cfg.model.modules.clip_model, self.device)
+        self.text_encoder = _instantiate(getattr(cfg.model.modules, cfg.model.text_encoder), clip_model=clip_model)
+        if cfg.model.image_encoder is not None:
+            self.image_encoder = _instantiate(getattr(cfg.model.modules, cfg.model.image_encoder), clip_model=clip_model)
+        if cfg.model.voxel_encoder is not None:
+            self.voxel_encoder = _instantiate(getattr(cfg.model.modules, cfg.model.voxel_encoder))
+        self.loss_fn = _instantiate(getattr(cfg.loss, cfg.loss.name))
+        self.val_test_step_outputs = []
+
+    # Lightning supplies .hparams / log_dict / log / print when present; minimal stand-ins otherwise
+    def __getattr__(self, name):
+        if name == "hparams" and "_hparams_ns" in self.__dict__:
+            return self.__dict__["_hparams_ns"]
+        return super().__getattr__(name)
+
+    def _log_dict(self, d, **kw):
+        fn = getattr(super(), "log_dict", None)
+        if fn is not None:
+            fn(d, **kw)
+
+    def _log(self, k, v):
+        fn = getattr(super(), "log", None)
+        if fn is not None:
+            fn(k, v)
+        else:
+            self.__dict__.setdefault("logged", {})[k] = v
+
+    def configure_optimizers(self):
+        return _instantiate(self._cfg.optimizer, params=self.parameters())
+
+    def forward(self, data_dict):
+        output_dict = {"text_features": self.text_encoder(data_dict["tokens"], data_dict)}
+        if self.image_encoder is not None:
+            output_dict["image_features"] = self.image_encoder(data_dict["images"].flatten(end_dim=1), data_dict)
+        if self.voxel_encoder is not None:
+            output_dict["voxel_features"] = self.voxel_encoder(data_dict["voxels"], len(data_dict["model_id"]))
+        return output_dict
+
+    def _calculate_losses(self, output_dict, loss_prefix):
+        loss_dict = {}
+        for a, b in combinations(output_dict.keys(), 2):
+            loss_dict[f"{loss_prefix}/{a[:-9]}_{b[:-9]}_loss"] = self.loss_fn(output_dict[a], output_dict[b])
+        loss_dict[f"{loss_prefix}/total_loss"] = sum(loss_dict.values())
+        return loss_dict
+
+    def training_step(self, data_dict, idx=0):
+        output_dict = self(data_dict)
+        loss_dict = self._calculate_losses(output_dict, "train_loss")
+        self._log_dict(loss_dict, on_step=True, on_epoch=False)
+        return loss_dict["train_loss/total_loss"]
+
+    def _stash(self, data_dict, output_dict):
+        out = {k: v.detach().cpu().numpy() for k, v in output_dict.items()}
+        reduced = {"model_id": data_dict["model_id"], "category": data_dict["category"],
+                   "tokens": data_dict["tokens"].cpu().numpy()}
+        self.val_test_step_outputs.append((reduced, out))
+
+    def validation_step(self, data_dict, idx=0):
+        output_dict = self(data_dict)
+        loss_dict = self._calculate_losses(output_dict, "val_loss")
+        self._log_dict(loss_dict, on_step=True, on_epoch=False)
+        self._stash(data_dict, output_dict)
+
+    def on_validation_epoch_end(self):
+        embeddings_dict = self._collate_output()
+        self.val_test_step_outputs.clear()
+        pr_at_k = compute_metrics(self._cfg.data.dataset, embeddings_dict)
+        self._log("val_eval/RR@1", pr_at_k["recall_rate"][0] * 100)
+        self._log("val_eval/RR@5", pr_at_k["recall_rate"][4] * 100)
+        self._log("val_eval/NDCG@5", pr_at_k["ndcg"][4] * 100)
+        self._log("val_eval/MRR", pr_at_k["mrr"] * 100)
+        return pr_at_k
+
+    def test_step(self, data_dict, idx=0):
+        self._stash(data_dict, self(data_dict))
+
+    def on_test_epoch_end(self):
+        embeddings_dict = self._collate_output()
+        self.val_test_step_outputs.clear()
+        pr = None
+        if self._cfg.inference.evaluate:
+            pr = compute_metrics(self._cfg.data.dataset, embeddings_dict, print_results=True)
+        if self._cfg.inference.save_predictions:
+            os.makedirs(self._cfg.inference.output_dir, exist_ok=True)
+            path = os.path.join(self._cfg.inference.output_dir, "output.p")
+            with open(path, "wb") as f:
+                pickle.dump(embeddings_dict, f)
+            print(f"\nPredictions saved at {path}")
+        return pr
+
+    def _collate_output(self):
+        """tricolo_net.py:125-158: shape embedding = image + voxel features, summed and NOT re-normalised."""
+        text, shape, model_ids, cats = [], [], [], []
+        for data_dict, output_dict in self.val_test_step_outputs:
+            text.append(output_dict["text_features"])
+            s = np.zeros_like(output_dict["text_features"])
+            if "image_features" in output_dict:
+                s += output_dict["image_features"]
+            if "voxel_features" in output_dict:
+                s += output_dict["voxel_features"]
+            shape.append(s)
+            model_ids.extend(data_dict["model_id"])
+            cats.extend(data_dict["category"])
+        text, shape = np.vstack(text), np.vstack(shape)
+        return {"caption_embedding_tuples": [(None, cats[i], model_ids[i], text[i], shape[i]) for i in range(text.shape[0])]}

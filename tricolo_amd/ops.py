@@ -1,0 +1,302 @@
+"""Tensor-level wrappers over the C ABI (one Python function per kernel family).
+
+All tensors are fp32, contiguous, channels-last ([B, D, H, W, C]; 2D tensors carry D = 1) and live on the GPU.
+Nothing here falls back to torch arithmetic: every function launches a kernel of libtricolo_hip.so on the
+current torch stream (so the calls can be captured into a HIP graph together with the rest of the step).
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+
+from . import _C
+from ._C import check, lib, make_desc, ptr, stream
+
+_PRECISIONS = ("bf16", "bf16x3")
+_default_precision = os.environ.get("TRICOLO_PRECISION", "bf16x3")
+
+
+def set_default_precision(p: str):
+    global _default_precision
+    if p not in _PRECISIONS:
+        raise ValueError(f"precision must be one of {_PRECISIONS}")
+    _default_precision = p
+
+
+def default_precision() -> str:
+    return _default_precision
+
+
+def _f32(t):
+    assert t.dtype == torch.float32 and t.is_contiguous(), "expected contiguous fp32"
+    return t
+
+
+class ConvGeom:
+    """Geometry + packed-weight buffers of one conv / linear layer.
+
+    weight_strides = (s_co, s_tap, s_ci) element strides of the fp32 parameter in the reference's layout."""
+
+    def __init__(self, B, in_grid, cin, cin_stored, cout, kernel, stride, pad, weight_strides):
+        ID, IH, IW = in_grid
+        KD, KH, KW = kernel
+        pd, ph, pw = pad
+        OD = (ID + 2 * pd - KD) // stride + 1
+        OH = (IH + 2 * ph - KH) // stride + 1
+        OW = (IW + 2 * pw - KW) // stride + 1
+        self.B, self.in_grid, self.out_grid = B, (ID, IH, IW), (OD, OH, OW)
+        self.cin, self.cin_stored, self.cout = cin, cin_stored, cout
+        self.kernel, self.stride, self.pad = kernel, stride, pad
+        self.ntaps = KD * KH * KW
+        self.strides = weight_strides
+        self.desc = make_desc(B, ID, IH, IW, cin_stored, OD, OH, OW, cout, KD, KH, KW, stride, pd, ph, pw)
+        self.kpad = lib().tri_conv_kpad(self.ntaps, cin_stored)
+        self.kpad_t = lib().tri_conv_kpad(self.ntaps, cout)
+        self.M = B * OD * OH * OW
+        self.M_in = B * ID * IH * IW
+        self.num_mtiles = lib().tri_conv_num_mtiles(_C.C.byref(self.desc))
+        self.wgrad_ws = lib().tri_conv_wgrad_workspace(_C.C.byref(self.desc))
+
+    @property
+    def flops(self):
+        return 2 * self.M * self.ntaps * self.cin * self.cout
+
+
+def pack_weight(w: torch.Tensor, g: ConvGeom, precision: str, transposed: bool = False):
+    """fp32 parameter -> (hi, lo|None) bf16 MFMA operand rows.  transposed=True packs the dgrad operand."""
+    s_co, s_tap, s_ci = g.strides
+    if not transposed:
+        rows, inner, inner_pad, kpad, s_row, s_inner = g.cout, g.cin, g.cin_stored, g.kpad, s_co, s_ci
+    else:
+        rows, inner, inner_pad, kpad, s_row, s_inner = g.cin_stored, g.cout, g.cout, g.kpad_t, s_ci, s_co
+        if g.cin != g.cin_stored:
+            raise RuntimeError("dgrad operand requested for a layer with padded input channels")
+    hi = torch.empty((rows, kpad), dtype=torch.bfloat16, device=w.device)
+    lo = torch.empty_like(hi) if precision == "bf16x3" else None
+    check(lib().tri_weight_prep(ptr(_f32(w)), s_row, s_tap, s_inner, rows, g.ntaps, inner, inner_pad, ptr(hi), ptr(lo), stream()),
+          "tri_weight_prep")
+    return hi, lo
+
+
+def conv_fwd(x, g: ConvGeom, packed, row_mask=None, bias=None, act=0, want_stats=False, out=None, accumulate=False):
+    hi, lo = packed
+    OD, OH, OW = g.out_grid
+    if out is None:
+        out = torch.empty((g.B, OD, OH, OW, g.cout), dtype=torch.float32, device=x.device)
+    stats = torch.empty((g.num_mtiles, 2, g.cout), dtype=torch.float32, device=x.device) if want_stats else None
+    check(lib().tri_conv_fwd(_C.C.byref(g.desc), ptr(_f32(x)), ptr(hi), ptr(lo), ptr(out), ptr(row_mask), ptr(bias), act,
+                             1 if accumulate else 0, ptr(stats), stream()), "tri_conv_fwd")
+    return (out, stats) if want_stats else out
+
+
+def conv_dgrad(dout, g: ConvGeom, packed_t, row_mask=None, out=None, accumulate=False):
+    hi, lo = packed_t
+    ID, IH, IW = g.in_grid
+    if out is None:
+        out = torch.empty((g.B, ID, IH, IW, g.cin_stored), dtype=torch.float32, device=dout.device)
+    check(lib().tri_conv_dgrad(_C.C.byref(g.desc), ptr(_f32(dout)), ptr(hi), ptr(lo), ptr(out), ptr(row_mask),
+                               1 if accumulate else 0, stream()), "tri_conv_dgrad")
+    return out
+
+
+_wgrad_ws = {}
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    ws = _wgrad_ws.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _wgrad_ws[key] = ws
+    return ws
+
+
+def conv_wgrad(x, dout, g: ConvGeom, like: torch.Tensor, precision: str, row_mask=None):
+    """Gradient of the layer's parameter, returned in the parameter's own layout (shape of ``like``)."""
+    dw = torch.empty_like(like)
+    ws = _workspace(g.wgrad_ws, x.device)
+    s_co, s_tap, s_ci = g.strides
+    check(lib().tri_conv_wgrad(_C.C.byref(g.desc), ptr(_f32(x)), ptr(_f32(dout)), ptr(row_mask), ptr(ws), ws.numel(), ptr(dw),
+                               s_co, s_tap, s_ci, g.cin, 1 if precision == "bf16x3" else 0, stream()), "tri_conv_wgrad")
+    return dw
+
+
+# ------------------------------------------------------------------------------------------------ BatchNorm
+class BNCoeffs:
+    __slots__ = ("mean", "invstd", "scale", "shift")
+
+    def __init__(self, C, device):
+        buf = torch.empty((4, C), dtype=torch.float32, device=device)
+        self.mean, self.invstd, self.scale, self.shift = buf[0], buf[1], buf[2], buf[3]
+
+
+def bn_finalize(stats, C, gamma, beta, running_mean, running_var, nbt, count_dev=None, count_host=0, momentum=0.1, eps=1e-5):
+    co = BNCoeffs(C, stats.device)
+    check(lib().tri_bn_finalize(ptr(stats), stats.shape[0], C, ptr(count_dev), int(count_host), ptr(gamma), ptr(beta),
+                                ptr(running_mean), ptr(running_var), ptr(nbt), momentum, eps, ptr(co.mean), ptr(co.invstd),
+                                ptr(co.scale), ptr(co.shift), stream()), "tri_bn_finalize")
+    return co
+
+
+def bn_eval_coeffs(C, gamma, beta, running_mean, running_var, eps=1e-5):
+    co = BNCoeffs(C, gamma.device)
+    check(lib().tri_bn_eval_coeffs(C, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), eps, ptr(co.mean),
+                                   ptr(co.invstd), ptr(co.scale), ptr(co.shift), stream()), "tri_bn_eval_coeffs")
+    return co
+
+
+def bn_act(y, co: BNCoeffs, relu=True, res=None, res_co: BNCoeffs | None = None):
+    C = y.shape[-1]
+    out = torch.empty_like(y)
+    check(lib().tri_bn_act(ptr(y), ptr(co.scale), ptr(co.shift), ptr(res), ptr(res_co.scale) if res_co else None,
+                           ptr(res_co.shift) if res_co else None, ptr(out), y.numel() // C, C, 1 if relu else 0, stream()),
+          "tri_bn_act")
+    return out
+
+
+def relu_bwd(dout, out, inplace=True):
+    g = dout if inplace else torch.empty_like(dout)
+    check(lib().tri_relu_bwd(ptr(dout), ptr(out), ptr(g), dout.numel(), stream()), "tri_relu_bwd")
+    return g
+
+
+def bn_bwd(y, g, co: BNCoeffs, gamma, count_dev=None, count_host=0, row_mask=None, inplace=True):
+    """Returns (dy, dgamma, dbeta).  g = gradient w.r.t. the BN output (already activation-masked)."""
+    C = y.shape[-1]
+    M = y.numel() // C
+    nblk = lib().tri_bn_bwd_num_blocks(M)
+    partial = torch.empty((nblk, 2, C), dtype=torch.float32, device=y.device)
+    check(lib().tri_bn_bwd_reduce(ptr(y), ptr(g), M, C, ptr(partial), stream()), "tri_bn_bwd_reduce")
+    buf = torch.empty((5, C), dtype=torch.float32, device=y.device)
+    check(lib().tri_bn_bwd_finalize(ptr(partial), nblk, C, ptr(count_dev), int(count_host), ptr(gamma), ptr(co.mean),
+                                    ptr(co.invstd), ptr(buf[0]), ptr(buf[1]), ptr(buf[2]), ptr(buf[3]), ptr(buf[4]), stream()),
+          "tri_bn_bwd_finalize")
+    dy = g if inplace else torch.empty_like(g)
+    check(lib().tri_bn_bwd_apply(ptr(y), ptr(g), ptr(buf[2]), ptr(buf[3]), ptr(buf[4]), ptr(row_mask), ptr(dy), M, C, stream()),
+          "tri_bn_bwd_apply")
+    return dy, buf[0], buf[1]
+
+
+# ------------------------------------------------------------------------------------------------ pooling
+def bn_relu_pool3d_fwd(y, co: BNCoeffs, mask, B, D, C):
+    Do = D // 2
+    pooled = torch.empty((B, Do, Do, Do, C), dtype=torch.float32, device=y.device)
+    mask_out = torch.zeros(((B * Do ** 3 + 31) // 32 * 32,), dtype=torch.uint8, device=y.device)
+    check(lib().tri_bn_relu_pool3d_fwd(ptr(y), ptr(co.scale), ptr(co.shift), ptr(mask), B, D, C, ptr(pooled), ptr(mask_out),
+                                       stream()), "tri_bn_relu_pool3d_fwd")
+    return pooled, mask_out
+
+
+def pool3d_bwd_route(y, co: BNCoeffs, mask, pooled, dpooled, B, D, C):
+    g = torch.empty_like(y)
+    check(lib().tri_pool3d_bwd_route(ptr(y), ptr(co.scale), ptr(co.shift), ptr(mask), ptr(pooled), ptr(_f32(dpooled)), B, D, C,
+                                     ptr(g), stream()), "tri_pool3d_bwd_route")
+    return g
+
+
+def maxpool2d_fwd(x):
+    N, _, H, W, C = x.shape
+    out = torch.empty((N, 1, (H + 1) // 2, (W + 1) // 2, C), dtype=torch.float32, device=x.device)
+    check(lib().tri_maxpool2d_fwd(ptr(x), N, H, W, C, ptr(out), stream()), "tri_maxpool2d_fwd")
+    return out
+
+
+def maxpool2d_bwd(x, dout):
+    N, _, H, W, C = x.shape
+    dx = torch.empty_like(x)
+    check(lib().tri_maxpool2d_bwd(ptr(x), ptr(_f32(dout)), N, H, W, C, ptr(dx), stream()), "tri_maxpool2d_bwd")
+    return dx
+
+
+def avgpool_viewmax_fwd(x, B, V):
+    N, _, H, W, C = x.shape
+    out = torch.empty((B, C), dtype=torch.float32, device=x.device)
+    arg = torch.empty((B, C), dtype=torch.int32, device=x.device)
+    check(lib().tri_avgpool_viewmax_fwd(ptr(x), B, V, H * W, C, ptr(out), ptr(arg), stream()), "tri_avgpool_viewmax_fwd")
+    return out, arg
+
+
+def avgpool_viewmax_bwd(dout, arg, shape, B, V):
+    N, _, H, W, C = shape
+    dx = torch.empty(shape, dtype=torch.float32, device=dout.device)
+    check(lib().tri_avgpool_viewmax_bwd(ptr(_f32(dout)), ptr(arg), B, V, H * W, C, ptr(dx), stream()), "tri_avgpool_viewmax_bwd")
+    return dx
+
+
+# ------------------------------------------------------------------------------------------------ layouts
+def voxel_scatter(locs, feats, B, V):
+    n = locs.shape[0]
+    dense = torch.empty((B, V, V, V, 4), dtype=torch.float32, device=feats.device)
+    sites = B * V ** 3
+    mask = torch.zeros(((sites + 31) // 32 * 32,), dtype=torch.uint8, device=feats.device)
+    locs = locs.to(torch.int32).contiguous()
+    check(lib().tri_voxel_scatter(ptr(locs), ptr(_f32(feats.contiguous())), n, B, V, ptr(dense), ptr(mask), stream()),
+          "tri_voxel_scatter")
+    return dense, mask
+
+
+def mask_count(mask, n):
+    cnt = torch.empty((1,), dtype=torch.int32, device=mask.device)
+    check(lib().tri_mask_count(ptr(mask), n, ptr(cnt), stream()), "tri_mask_count")
+    return cnt
+
+
+def nchw3_to_nhwc4(x):
+    N, C, H, W = x.shape
+    assert C == 3
+    out = torch.empty((N, 1, H, W, 4), dtype=torch.float32, device=x.device)
+    check(lib().tri_nchw3_to_nhwc4(ptr(_f32(x.contiguous())), N, H, W, ptr(out), stream()), "tri_nchw3_to_nhwc4")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ row ops
+def l2norm_fwd(x, eps=1e-12):
+    rows, D = x.shape
+    z = torch.empty_like(x)
+    norm = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    check(lib().tri_l2norm_fwd(ptr(_f32(x)), rows, D, eps, ptr(z), ptr(norm), stream()), "tri_l2norm_fwd")
+    return z, norm
+
+
+def l2norm_bwd(z, norm, dz, eps=1e-12):
+    rows, D = z.shape
+    dx = torch.empty_like(z)
+    check(lib().tri_l2norm_bwd(ptr(z), ptr(norm), ptr(_f32(dz.contiguous())), rows, D, eps, ptr(dx), stream()), "tri_l2norm_bwd")
+    return dx
+
+
+def colsum(g):
+    C = g.shape[-1]
+    out = torch.empty((C,), dtype=torch.float32, device=g.device)
+    check(lib().tri_colsum(ptr(_f32(g)), g.numel() // C, C, ptr(out), stream()), "tri_colsum")
+    return out
+
+
+def act_bwd(dout, out, act, inplace=True):
+    g = dout if inplace else torch.empty_like(dout)
+    check(lib().tri_act_bwd(ptr(dout), ptr(out), ptr(g), dout.numel(), act, stream()), "tri_act_bwd")
+    return g
+
+
+# ------------------------------------------------------------------------------------------------ NT-Xent
+def ntxent_fwd_bwd(za, zb, temperature, alpha, norm=True, want_grad=True):
+    B, D = za.shape
+    loss = torch.empty((), dtype=torch.float32, device=za.device)
+    dza = torch.empty_like(za) if want_grad else None
+    dzb = torch.empty_like(zb) if want_grad else None
+    nbytes = lib().tri_ntxent_workspace(B, D)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=za.device)
+    check(lib().tri_ntxent_fwd_bwd(ptr(_f32(za.contiguous())), ptr(_f32(zb.contiguous())), B, D, float(temperature), float(alpha),
+                                   1 if norm else 0, ptr(loss), ptr(dza), ptr(dzb), ptr(ws), nbytes, stream()), "tri_ntxent_fwd_bwd")
+    return loss, dza, dzb
+
+
+# ------------------------------------------------------------------------------------------------ Adam
+def adam_tick(step):
+    check(lib().tri_adam_tick(ptr(step), stream()), "tri_adam_tick")
+
+
+def adam_step(p, g, m, v, step, lr, b1, b2, eps, wd, gscale=1.0):
+    check(lib().tri_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(step), lr, b1, b2, eps, wd, gscale, stream()),
+          "tri_adam_step")
