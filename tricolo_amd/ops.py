@@ -28,6 +28,44 @@ def default_precision() -> str:
     return _default_precision
 
 
+class KernelTimer:
+    """Optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg).  Disabled by
+    default; when enabled every conv launch is bracketed by two events and tallied per kernel symbol."""
+
+    def __init__(self):
+        self.records = []          # (symbol, algorithmic_flops, start_event, end_event)
+
+    def run(self, symbol, flops, fn):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        r = fn()
+        b.record()
+        self.records.append((symbol, flops, a, b))
+        return r
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for sym, fl, a, b in self.records:
+            d = agg.setdefault(sym, {"launches": 0, "ms": 0.0, "flops": 0})
+            d["launches"] += 1
+            d["ms"] += a.elapsed_time(b)
+            d["flops"] += fl
+        return agg
+
+
+TIMER: KernelTimer | None = None
+
+
+def _timed(symbol, flops, fn):
+    return TIMER.run(symbol, flops, fn) if TIMER is not None else fn()
+
+
+def _igemm_symbol(cout, split):
+    bn = 128 if cout % 128 == 0 else (64 if cout % 64 == 0 else 32)
+    return f"conv_igemm_kernel<{bn},{2 if split else 1}>"
+
+
 def _f32(t):
     assert t.dtype == torch.float32 and t.is_contiguous(), "expected contiguous fp32"
     return t
@@ -85,8 +123,9 @@ def conv_fwd(x, g: ConvGeom, packed, row_mask=None, bias=None, act=0, want_stats
     if out is None:
         out = torch.empty((g.B, OD, OH, OW, g.cout), dtype=torch.float32, device=x.device)
     stats = torch.empty((g.num_mtiles, 2, g.cout), dtype=torch.float32, device=x.device) if want_stats else None
-    check(lib().tri_conv_fwd(_C.C.byref(g.desc), ptr(_f32(x)), ptr(hi), ptr(lo), ptr(out), ptr(row_mask), ptr(bias), act,
-                             1 if accumulate else 0, ptr(stats), stream()), "tri_conv_fwd")
+    check(_timed(_igemm_symbol(g.cout, lo is not None), g.flops,
+                 lambda: lib().tri_conv_fwd(_C.C.byref(g.desc), ptr(_f32(x)), ptr(hi), ptr(lo), ptr(out), ptr(row_mask), ptr(bias),
+                                            act, 1 if accumulate else 0, ptr(stats), stream())), "tri_conv_fwd")
     return (out, stats) if want_stats else out
 
 
@@ -95,8 +134,9 @@ def conv_dgrad(dout, g: ConvGeom, packed_t, row_mask=None, out=None, accumulate=
     ID, IH, IW = g.in_grid
     if out is None:
         out = torch.empty((g.B, ID, IH, IW, g.cin_stored), dtype=torch.float32, device=dout.device)
-    check(lib().tri_conv_dgrad(_C.C.byref(g.desc), ptr(_f32(dout)), ptr(hi), ptr(lo), ptr(out), ptr(row_mask),
-                               1 if accumulate else 0, stream()), "tri_conv_dgrad")
+    check(_timed(_igemm_symbol(g.cin_stored, lo is not None), g.flops,
+                 lambda: lib().tri_conv_dgrad(_C.C.byref(g.desc), ptr(_f32(dout)), ptr(hi), ptr(lo), ptr(out), ptr(row_mask),
+                                              1 if accumulate else 0, stream())), "tri_conv_dgrad")
     return out
 
 
@@ -117,8 +157,12 @@ def conv_wgrad(x, dout, g: ConvGeom, like: torch.Tensor, precision: str, row_mas
     dw = torch.empty_like(like)
     ws = _workspace(g.wgrad_ws, x.device)
     s_co, s_tap, s_ci = g.strides
-    check(lib().tri_conv_wgrad(_C.C.byref(g.desc), ptr(_f32(x)), ptr(_f32(dout)), ptr(row_mask), ptr(ws), ws.numel(), ptr(dw),
-                               s_co, s_tap, s_ci, g.cin, 1 if precision == "bf16x3" else 0, stream()), "tri_conv_wgrad")
+    bi = 128 if (g.cout % 128 == 0 and g.kpad >= 128) else 64
+    sym = f"conv_wgrad_kernel<{bi},{bi},{2 if precision == 'bf16x3' else 1}>"
+    check(_timed(sym, g.flops,
+                 lambda: lib().tri_conv_wgrad(_C.C.byref(g.desc), ptr(_f32(x)), ptr(_f32(dout)), ptr(row_mask), ptr(ws), ws.numel(),
+                                              ptr(dw), s_co, s_tap, s_ci, g.cin, 1 if precision == "bf16x3" else 0, stream())),
+          "tri_conv_wgrad")
     return dw
 
 

@@ -1,0 +1,82 @@
+"""Data-parallel pieces of the TriCoLo step: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI
+on MI355X, "gloo" in the CPU tests).
+
+The reference has no distributed code (Lightning's default DDP: local-batch negatives, un-synchronised BatchNorm,
+SURVEY.md section 2.3).  The north star adds ONE exchange step: an all-gather of the modality embeddings so every
+rank computes NT-Xent over the full global batch.  Design:
+  * forward: the 2-3 [B_local, 512] matrices are packed into one [B_local, 512*n_mod] buffer -> a single
+    all_gather_into_tensor (192 KB/rank at B_local=32: latency-bound, so one message instead of three);
+  * every rank evaluates the identical global loss; backward hands each rank the rows of d(loss)/d(z) that belong to
+    its own samples - no reduce-scatter is needed because all ranks hold the same dS;
+  * parameter gradients are SUM-all-reduced in one flat bucket per call (d L_global / d theta = sum over ranks of the
+    local-path gradients); BatchNorm keeps per-rank statistics like the reference's DDP default.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def is_dist() -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+class _AllGatherRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        world = dist.get_world_size()
+        out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, x.contiguous())
+        ctx.rows = x.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        r = dist.get_rank()
+        return dout[r * ctx.rows:(r + 1) * ctx.rows].contiguous()
+
+
+def gather_embeddings(output_dict: dict) -> dict:
+    """{name: [B_local, D]} -> {name: [B_global, D]} with one fused all-gather (rank-major row order)."""
+    if not is_dist():
+        return output_dict
+    keys = list(output_dict.keys())
+    packed = torch.cat([output_dict[k] for k in keys], dim=1)
+    full = _AllGatherRows.apply(packed)
+    out, off = {}, 0
+    for k in keys:
+        d = output_dict[k].shape[1]
+        out[k] = full[:, off:off + d].contiguous()
+        off += d
+    return out
+
+
+def allreduce_gradients(params, op=None) -> None:
+    """SUM-all-reduce every .grad in one flat bucket (bigger, fewer collectives: xGMI rings are per-link bound)."""
+    if not is_dist():
+        return
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=op or dist.ReduceOp.SUM)
+    off = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off:off + n].view_as(g))
+        off += n
+
+
+def dp_training_step(net, batch, optimizer=None):
+    """One data-parallel training step of TriCoLoNet: local towers -> gathered embeddings -> global losses ->
+    backward -> gradient all-reduce (-> optimizer step).  Returns the loss dict (identical on every rank)."""
+    out = net(batch)
+    out = gather_embeddings(out)
+    losses = net._calculate_losses(out, "train_loss")
+    if optimizer is not None:
+        optimizer.zero_grad(set_to_none=True)
+    losses["train_loss/total_loss"].backward()
+    allreduce_gradients(list(net.parameters()))
+    if optimizer is not None:
+        optimizer.step()
+    return losses
