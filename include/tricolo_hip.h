@@ -100,6 +100,17 @@ int tri_colsum(const float* g, long M, int C, float* out, void* stream);
 int tri_axpy(const float* x, float a, float* y, long n, void* stream);
 int tri_act_bwd(const float* dout, const float* out, float* g, long n, int act, void* stream);
 
+/* ---- persistent bidirectional GRU recurrence (nn.GRU(256,128,bidirectional) of text_encoder/bigru.py:11,17) -----------
+ * xproj [L][B][768] = x_t W_ih^T + b_ih for both directions (768 = dir*384 + gate*128 + unit, gate order r,z,n);
+ * w_hh [2][384][128], b_hh [2][384].  Outputs: hs [2][L][B][128], gates [2][L][B][4][128] (r,z,n,hn) saved for backward,
+ * hfinal [B][256] = cat(forward final state, reverse final state) (bigru.py:18).  tri_gru_bwd returns the gate
+ * pre-activation gradients dgi [L][B][768], dgh [2][L][B][384] and h_{t-1} rows hprev [2][L][B][128]; the weight
+ * gradients are then plain GEMMs (tri_conv_wgrad with 1x1 geometry). */
+int tri_gru_fwd(const float* xproj, const float* w_hh, const float* b_hh, int B, int L, float* hs, float* gates, float* hfinal,
+                int split3, void* stream);
+int tri_gru_bwd(const float* dhfinal, const float* w_hh, const float* hs, const float* gates, int B, int L, float* dgi, float* dgh,
+                float* hprev, int split3, void* stream);
+
 /* ---- NT-Xent loss, forward + backward fused (tricolo/loss/nt_xent.py:24-74) ------------------------------------------ */
 size_t tri_ntxent_workspace(int B, int D);
 int tri_ntxent_fwd_bwd(const float* za, const float* zb, int B, int D, float temperature, float alpha, int norm, float* loss,

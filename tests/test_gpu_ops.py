@@ -362,3 +362,39 @@ def test_ntxent_large_batch_against_float64():
     assert abs(loss.item() - l64) < 2e-5
     np.testing.assert_allclose(dza.cpu().numpy(), da, atol=1e-6)
     np.testing.assert_allclose(dzb.cpu().numpy(), db, atol=1e-6)
+
+
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 2e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("B,L", [(8, 96), (19, 7)])
+def test_gru_recurrence_matches_explicit_equations(precision, tol, B, L):
+    from oracle.modules import gru_explicit
+    g = torch.Generator().manual_seed(3)
+    xproj = torch.randn(L, B, 768, generator=g)
+    w_hh = torch.randn(2, 384, 128, generator=g) / np.sqrt(128)
+    b_hh = torch.randn(2, 384, generator=g) * 0.1
+    xr, wr, br = xproj.clone().requires_grad_(), w_hh.clone().requires_grad_(), b_hh.clone().requires_grad_()
+    # oracle: gi is given (x W_ih^T + b_ih already applied) -> use identity input weights
+    finals, prevs = [], []
+    for d in range(2):
+        gi = xr[:, :, d * 384:(d + 1) * 384]
+        h = torch.zeros(B, 128)
+        steps = range(L - 1, -1, -1) if d == 1 else range(L)
+        for t in steps:
+            gh = h @ wr[d].t() + br[d]
+            r = torch.sigmoid(gi[t, :, :128] + gh[:, :128])
+            z = torch.sigmoid(gi[t, :, 128:256] + gh[:, 128:256])
+            n = torch.tanh(gi[t, :, 256:] + r * gh[:, 256:])
+            h = (1 - z) * n + z * h
+        finals.append(h)
+    ref = torch.cat(finals, dim=1)
+    up = torch.randn(B, 256, generator=g)
+    (ref * up).sum().backward()
+    hfinal, hs, gates = ops.gru_fwd(xproj.to(DEV), w_hh.to(DEV), b_hh.to(DEV), B, L, precision)
+    np.testing.assert_allclose(hfinal.cpu().numpy(), ref.detach().numpy(), atol=tol)
+    dgi, dgh, hprev = ops.gru_bwd(up.to(DEV), w_hh.to(DEV), hs, gates, B, L, precision)
+    np.testing.assert_allclose(dgi.cpu().view(L, B, 768).numpy(), xr.grad.numpy(), atol=tol * 5)
+    # weight / bias gradients follow from the stored gate gradients: dW_hh = dgh^T hprev, db_hh = colsum(dgh)
+    for d in range(2):
+        dw = dgh[d].cpu().double().t() @ hprev[d].cpu().double()
+        np.testing.assert_allclose(dw.numpy(), wr.grad[d].double().numpy(), atol=tol * 50)
+        np.testing.assert_allclose(dgh[d].cpu().double().sum(0).numpy(), br.grad[d].double().numpy(), atol=tol * 50)

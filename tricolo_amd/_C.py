@@ -55,6 +55,8 @@ SIGNATURES = {
     "tri_colsum": (I, [P, L, I, P, P]),
     "tri_axpy": (I, [P, F, P, L, P]),
     "tri_act_bwd": (I, [P, P, P, L, I, P]),
+    "tri_gru_fwd": (I, [P, P, P, I, I, P, P, P, I, P]),
+    "tri_gru_bwd": (I, [P, P, P, P, I, I, P, P, P, I, P]),
     "tri_ntxent_workspace": (Z, [I, I]),
     "tri_ntxent_fwd_bwd": (I, [P, P, I, I, F, F, I, P, P, P, P, Z, P]),
     "tri_adam_tick": (I, [P, P]),

@@ -1,0 +1,238 @@
+// Persistent bidirectional GRU recurrence for gfx950 (hidden 128, any batch), forward and backward in time.
+//
+// Replaces the cuDNN/MIOpen RNN call behind nn.GRU in /root/reference/tricolo/model/module/text_encoder/bigru.py:11,17
+// (96 sequential steps x 2 directions; ~3,900 tiny launches per training step through MIOpen on ROCm).
+// The input projection x_t W_ih^T + b_ih for all steps is one MFMA GEMM outside (conv_igemm as a 1x1 layer); this
+// file is the sequential part:   r = s(xr + hr), z = s(xz + hz), n = tanh(xn + r * hn), h' = (1 - z) n + z h
+// with (hr, hz, hn) = h W_hh^T + b_hh, gate order (r, z, n) as torch.nn.GRU.  No packing: pads are stepped through.
+//
+// One workgroup = 16 batch rows of one direction, 8 waves; wave w owns hidden units [16w, 16w+16) of all three gates,
+// so the MFMA C layout (row = 4*(lane>>4)+reg, col = lane&15) gives every lane the r, z, n pre-activations of the SAME
+// (row, unit) and the cell update is lane-local.  W_hh never leaves registers (12 B-fragments per wave, +12 for the
+// lo half in split mode); h_{t-1} is re-published through LDS as bf16 (hi, lo) with an XOR-swizzled 256-B row image
+// (conflict-free ds_read_b128); the fp32 state stays in registers.  One barrier per time step.
+#include "common.h"
+#include "../../include/tricolo_hip.h"
+
+#define GRU_H 128
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// LDS image of a [16][ncols] bf16 matrix: 16-byte chunk c of row r stored at chunk (c ^ (r & 15))
+__device__ __forceinline__ int himg_off(int row, int chunk, int row_bytes) { return row * row_bytes + ((chunk ^ (row & 15)) << 4); }
+
+template <int NSPLIT>
+__global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ xproj,   // [L][B][768]
+                                                      const float* __restrict__ w_hh,    // [2][384][128]
+                                                      const float* __restrict__ b_hh,    // [2][384]
+                                                      int B, int L,
+                                                      float* __restrict__ hs,            // [2][L][B][128]  h after step t
+                                                      float* __restrict__ gates,         // [2][L][B][4][128] r, z, n, hn(+b)
+                                                      float* __restrict__ hfinal) {      // [B][256]
+    __shared__ __attribute__((aligned(16))) char lds[2 * NSPLIT * 16 * 256];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int dir = blockIdx.y, b0 = blockIdx.x * 16;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int unit = 16 * w + fr;
+    const float* W = w_hh + (size_t)dir * 384 * GRU_H;
+
+    // W_hh fragments: B operand of D[row][unit] += h[row][k] * W[g*128 + unit][k]
+    bf16x8 wh[3][4], wl[3][4];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const float* src = W + (size_t)(g * GRU_H + unit) * GRU_H + ks * 32 + fq * 8;
+            float4 a = *(const float4*)src, c = *(const float4*)(src + 4);
+            float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                bf16_t h = (bf16_t)v[j];
+                wh[g][ks][j] = h;
+                if (NSPLIT == 2) wl[g][ks][j] = (bf16_t)(v[j] - (float)h);
+            }
+        }
+    const float bhr = b_hh[dir * 384 + unit], bhz = b_hh[dir * 384 + 128 + unit], bhn = b_hh[dir * 384 + 256 + unit];
+
+    float h[4] = {0.f, 0.f, 0.f, 0.f};
+    // publish h_0 = 0
+    for (int i = t; i < 2 * NSPLIT * 16 * 256 / 4; i += 512) ((int*)lds)[i] = 0;
+    __syncthreads();
+
+    const size_t plane = (size_t)L * B * GRU_H;
+    int cur = 0;
+    for (int s = 0; s < L; ++s) {
+        const int tt = dir == 0 ? s : L - 1 - s;
+        // input projections of this step (issued first: latency hides under the MFMAs)
+        float xr[4], xz[4], xn[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int b = b0 + fq * 4 + r;
+            const float* xp = xproj + ((size_t)tt * B + (b < B ? b : 0)) * 768 + dir * 384 + unit;
+            xr[r] = xp[0]; xz[r] = xp[128]; xn[r] = xp[256];
+        }
+        const char* hb = lds + cur * (NSPLIT * 16 * 256);
+        f32x4 acc[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            int off = himg_off(fr, ks * 4 + fq, 256);
+            bf16x8 ah = *(const bf16x8*)(hb + off);
+            bf16x8 al;
+            if (NSPLIT == 2) al = *(const bf16x8*)(hb + 16 * 256 + off);
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                if (NSPLIT == 2) {
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wh[g][ks], acc[g], 0, 0, 0);
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wl[g][ks], acc[g], 0, 0, 0);
+                }
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wh[g][ks], acc[g], 0, 0, 0);
+            }
+        }
+        char* hn_buf = lds + (cur ^ 1) * (NSPLIT * 16 * 256);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int row = fq * 4 + r, b = b0 + row;
+            float rg = sigmoidf_(xr[r] + acc[0][r] + bhr);
+            float zg = sigmoidf_(xz[r] + acc[1][r] + bhz);
+            float ghn = acc[2][r] + bhn;
+            float ng = tanhf(xn[r] + rg * ghn);
+            float hnew = (1.f - zg) * ng + zg * h[r];
+            h[r] = hnew;
+            if (b < B) {
+                size_t o = ((size_t)dir * L + tt) * B + b;
+                hs[o * GRU_H + unit] = hnew;
+                float* gp = gates + o * 4 * GRU_H + unit;
+                gp[0] = rg; gp[GRU_H] = zg; gp[2 * GRU_H] = ng; gp[3 * GRU_H] = ghn;
+            }
+            // re-publish as bf16 (hi, lo): element (row, unit) -> chunk unit/8, byte (unit%8)*2
+            bf16_t hh = (bf16_t)hnew;
+            int off = himg_off(row, unit >> 3, 256) + (unit & 7) * 2;
+            *(bf16_t*)(hn_buf + off) = hh;
+            if (NSPLIT == 2) *(bf16_t*)(hn_buf + 16 * 256 + off) = (bf16_t)(hnew - (float)hh);
+        }
+        cur ^= 1;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        int b = b0 + fq * 4 + r;
+        if (b < B) hfinal[(size_t)b * 256 + dir * GRU_H + unit] = h[r];
+    }
+}
+
+// Backward through time.  dhfinal [B][256] seeds dh; per step the lane-local cell backward produces the gate
+// pre-activation gradients dgi (w.r.t. x W_ih^T + b_ih) and dgh (w.r.t. h W_hh^T + b_hh), stores both for the batched
+// weight-gradient GEMMs, and dh_{t-1} = dh * z + dgh @ W_hh through MFMA (W_hh column fragments resident in registers).
+template <int NSPLIT>
+__global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ dhfinal,  // [B][256]
+                                                      const float* __restrict__ w_hh,     // [2][384][128]
+                                                      const float* __restrict__ hs,       // [2][L][B][128]
+                                                      const float* __restrict__ gates,    // [2][L][B][4][128]
+                                                      int B, int L,
+                                                      float* __restrict__ dgi,            // [L][B][768]
+                                                      float* __restrict__ dgh,            // [2][L][B][384]
+                                                      float* __restrict__ hprev) {        // [2][L][B][128]
+    __shared__ __attribute__((aligned(16))) char lds[2 * NSPLIT * 16 * 768];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int dir = blockIdx.y, b0 = blockIdx.x * 16;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int unit = 16 * w + fr;
+    const float* W = w_hh + (size_t)dir * 384 * GRU_H;
+
+    // B operand of D[row][unit] += dgh[row][k] * W[k][unit],  k over the 384 gate units
+    bf16x8 wh[12], wl[12];
+#pragma unroll
+    for (int ks = 0; ks < 12; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = W[(size_t)(ks * 32 + fq * 8 + j) * GRU_H + unit];
+            bf16_t hgh = (bf16_t)v;
+            wh[ks][j] = hgh;
+            if (NSPLIT == 2) wl[ks][j] = (bf16_t)(v - (float)hgh);
+        }
+
+    float dh[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        int b = b0 + fq * 4 + r;
+        dh[r] = b < B ? dhfinal[(size_t)b * 256 + dir * GRU_H + unit] : 0.f;
+    }
+    int cur = 0;
+    for (int s = L - 1; s >= 0; --s) {
+        const int tt = dir == 0 ? s : L - 1 - s;              // time index processed at forward step s
+        const int tp = dir == 0 ? tt - 1 : tt + 1;            // time index of h_{prev}
+        const bool has_prev = s > 0;
+        char* gb = lds + cur * (NSPLIT * 16 * 768);
+        float dhz[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int row = fq * 4 + r, b = b0 + row;
+            float dr_pre = 0.f, dz_pre = 0.f, dn_pre = 0.f, dgn = 0.f, hp = 0.f;
+            dhz[r] = 0.f;
+            if (b < B) {
+                size_t o = ((size_t)dir * L + tt) * B + b;
+                const float* gp = gates + o * 4 * GRU_H + unit;
+                float rg = gp[0], zg = gp[GRU_H], ng = gp[2 * GRU_H], ghn = gp[3 * GRU_H];
+                if (has_prev) hp = hs[(((size_t)dir * L + tp) * B + b) * GRU_H + unit];
+                float d = dh[r];
+                float dn = d * (1.f - zg);
+                float dz = d * (hp - ng);
+                dhz[r] = d * zg;
+                dn_pre = dn * (1.f - ng * ng);
+                dz_pre = dz * zg * (1.f - zg);
+                dr_pre = dn_pre * ghn * rg * (1.f - rg);
+                dgn = dn_pre * rg;
+                float* gi = dgi + ((size_t)tt * B + b) * 768 + dir * 384 + unit;
+                gi[0] = dr_pre; gi[128] = dz_pre; gi[256] = dn_pre;
+                float* gh = dgh + o * 384 + unit;
+                gh[0] = dr_pre; gh[128] = dz_pre; gh[256] = dgn;
+                hprev[o * GRU_H + unit] = hp;
+            }
+            float vals[3] = {dr_pre, dz_pre, dgn};
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                int col = g * GRU_H + unit;
+                bf16_t hh = (bf16_t)vals[g];
+                int off = himg_off(row, col >> 3, 768) + (col & 7) * 2;
+                *(bf16_t*)(gb + off) = hh;
+                if (NSPLIT == 2) *(bf16_t*)(gb + 16 * 768 + off) = (bf16_t)(vals[g] - (float)hh);
+            }
+        }
+        __syncthreads();
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 12; ++ks) {
+            int off = himg_off(fr, ks * 4 + fq, 768);
+            bf16x8 ah = *(const bf16x8*)(gb + off);
+            if (NSPLIT == 2) {
+                bf16x8 al = *(const bf16x8*)(gb + 16 * 768 + off);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wh[ks], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wl[ks], acc, 0, 0, 0);
+            }
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wh[ks], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dh[r] = dhz[r] + acc[r];
+        cur ^= 1;                                             // next step writes the other image: one barrier per step
+    }
+}
+
+extern "C" int tri_gru_fwd(const float* xproj, const float* w_hh, const float* b_hh, int B, int L, float* hs, float* gates,
+                           float* hfinal, int split3, void* stream) {
+    if (B < 1 || L < 1) { tri_set_error("tri_gru_fwd: B, L must be positive"); return TRI_ERR_ARG; }
+    dim3 grid((B + 15) / 16, 2);
+    if (split3) gru_fwd_kernel<2><<<grid, 512, 0, (hipStream_t)stream>>>(xproj, w_hh, b_hh, B, L, hs, gates, hfinal);
+    else gru_fwd_kernel<1><<<grid, 512, 0, (hipStream_t)stream>>>(xproj, w_hh, b_hh, B, L, hs, gates, hfinal);
+    return tri_check_launch("tri_gru_fwd");
+}
+
+extern "C" int tri_gru_bwd(const float* dhfinal, const float* w_hh, const float* hs, const float* gates, int B, int L, float* dgi,
+                           float* dgh, float* hprev, int split3, void* stream) {
+    if (B < 1 || L < 1) { tri_set_error("tri_gru_bwd: B, L must be positive"); return TRI_ERR_ARG; }
+    dim3 grid((B + 15) / 16, 2);
+    if (split3) gru_bwd_kernel<2><<<grid, 512, 0, (hipStream_t)stream>>>(dhfinal, w_hh, hs, gates, B, L, dgi, dgh, hprev);
+    else gru_bwd_kernel<1><<<grid, 512, 0, (hipStream_t)stream>>>(dhfinal, w_hh, hs, gates, B, L, dgi, dgh, hprev);
+    return tri_check_launch("tri_gru_bwd");
+}

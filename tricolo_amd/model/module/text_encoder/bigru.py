@@ -1,19 +1,54 @@
-"""BiGRUEncoder - drop-in for /root/reference/tricolo/model/module/text_encoder/bigru.py:8-18.
+"""BiGRUEncoder on hand-written gfx950 kernels - drop-in for
+/root/reference/tricolo/model/module/text_encoder/bigru.py:8-18.
 
 Same constructor (vocab_size, out_dim, **kwargs - `clip_model` ignored), same forward(tokens [B,L] int, data_dict)
 -> [B, out_dim] unit rows, same state-dict keys (embedding_layer.weight, gru.{weight_ih,weight_hh,bias_ih,bias_hh}_l0
-[_reverse], fc.{weight,bias}).  As in the reference there is no packing: pad tokens (id 0, zero embedding row) are
-stepped through the GRU and the forward final state is taken after the trailing pads.
+[_reverse], fc.{weight,bias}; `gru` is a real nn.GRU used only as the parameter holder).  As in the reference there is
+no packing: pad tokens (id 0, zero embedding row) are stepped through the GRU and the forward final state is taken
+after the trailing pads.
 
-Round 1: embedding gather + the 96-step recurrence run through PyTorch-ROCm (nn.GRU -> MIOpen), which the task
-allows for this tower; the output projection + tanh is the MFMA dense kernel and the
-normalise is the row kernel.  The persistent fused recurrence kernel is the next row.
+MI355X design: the embedding gather stays a torch op (one launch each way); the input projection of all 96 steps and
+both directions is ONE MFMA GEMM ([L*B,256] x [256,768], bias fused); the recurrence is ONE persistent kernel per
+direction-batch-chunk with W_hh resident in registers as MFMA fragments (tricolo_amd/csrc/gru.hip) instead of the
+~3,900 MIOpen launches per training step measured for nn.GRU on ROCm (profiles/r1); the weight gradients are three
+GEMMs over the stored gate gradients; fc + tanh is the dense MFMA kernel and the normalise is the row kernel.
 """
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from .... import ops
-from ....layers import L2NormFn, LinearFn, TriModule, require_gpu
+from ....layers import L2NormFn, LinearFn, TriModule, linear_bwd, linear_fwd, linear_geom, require_gpu
+
+
+class _BiGRUFn(torch.autograd.Function):
+    """emb [L,B,256] + the eight nn.GRU parameters -> cat(h_fwd_final, h_rev_final) [B,256]."""
+
+    @staticmethod
+    def forward(ctx, emb, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r, precision):
+        L, B, I = emb.shape
+        x2d = emb.contiguous().view(L * B, I)
+        w_ih = torch.cat([w_ih_f, w_ih_r], dim=0)                       # [768, 256]
+        b_ih = torch.cat([b_ih_f, b_ih_r], dim=0)
+        w_hh = torch.stack([w_hh_f, w_hh_r]).contiguous()               # [2, 384, 128]
+        b_hh = torch.stack([b_hh_f, b_hh_r]).contiguous()
+        xproj = linear_fwd(x2d, w_ih, b_ih, 0, precision)               # [L*B, 768]
+        hfinal, hs, gates = ops.gru_fwd(xproj, w_hh, b_hh, B, L, precision)
+        ctx.save_for_backward(x2d, w_ih, w_hh, hs, gates)
+        ctx.dims, ctx.precision = (L, B, I), precision
+        return hfinal
+
+    @staticmethod
+    def backward(ctx, dhfinal):
+        x2d, w_ih, w_hh, hs, gates = ctx.saved_tensors
+        (L, B, I), prec = ctx.dims, ctx.precision
+        dgi, dgh, hprev = ops.gru_bwd(dhfinal, w_hh, hs, gates, B, L, prec)
+        dx, dw_ih, db_ih = linear_bwd(x2d, w_ih, None, dgi, 0, prec, need_dx=ctx.needs_input_grad[0])
+        g_hh = linear_geom(L * B, 128, 384)
+        dw_hh = [ops.conv_wgrad(hprev[d], dgh[d], g_hh, w_hh[d], prec) for d in range(2)]
+        db_hh = [ops.colsum(dgh[d]) for d in range(2)]
+        demb = dx.view(L, B, I) if dx is not None else None
+        return (demb, dw_ih[:384], dw_hh[0], db_ih[:384], db_hh[0], dw_ih[384:], dw_hh[1], db_ih[384:], db_hh[1], None)
 
 
 class BiGRUEncoder(TriModule):
@@ -26,9 +61,9 @@ class BiGRUEncoder(TriModule):
 
     def forward(self, x, data_dict=None):
         require_gpu(x, "BiGRUEncoder")
-        emb = torch.transpose(self.embedding_layer(x), 0, 1)                   # bigru.py:15
-        h0 = torch.zeros((2, emb.shape[1], 128), dtype=torch.float32, device=emb.device)
-        _, hidden = self.gru(emb, h0)                                          # bigru.py:17
-        feat = torch.cat((hidden[-2], hidden[-1]), dim=1)
         prec = self.precision or ops.default_precision()
-        return L2NormFn.apply(LinearFn.apply(feat, self.fc.weight, self.fc.bias, 2, prec))   # tanh fused, bigru.py:18
+        emb = F.embedding(x.t().contiguous().long(), self.embedding_layer.weight, padding_idx=0)    # [L,B,256], bigru.py:15
+        g = self.gru
+        feat = _BiGRUFn.apply(emb, g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0, g.weight_ih_l0_reverse,
+                              g.weight_hh_l0_reverse, g.bias_ih_l0_reverse, g.bias_hh_l0_reverse, prec)   # bigru.py:16-17
+        return L2NormFn.apply(LinearFn.apply(feat, self.fc.weight, self.fc.bias, 2, prec))              # bigru.py:18

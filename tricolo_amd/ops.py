@@ -323,6 +323,27 @@ def act_bwd(dout, out, act, inplace=True):
     return g
 
 
+# ------------------------------------------------------------------------------------------------ GRU recurrence
+def gru_fwd(xproj, w_hh, b_hh, B, L, precision):
+    dev = xproj.device
+    hs = torch.empty((2, L, B, 128), dtype=torch.float32, device=dev)
+    gates = torch.empty((2, L, B, 4, 128), dtype=torch.float32, device=dev)
+    hfinal = torch.empty((B, 256), dtype=torch.float32, device=dev)
+    check(lib().tri_gru_fwd(ptr(_f32(xproj)), ptr(_f32(w_hh)), ptr(_f32(b_hh)), B, L, ptr(hs), ptr(gates), ptr(hfinal),
+                            1 if precision == "bf16x3" else 0, stream()), "tri_gru_fwd")
+    return hfinal, hs, gates
+
+
+def gru_bwd(dhfinal, w_hh, hs, gates, B, L, precision):
+    dev = hs.device
+    dgi = torch.empty((L * B, 768), dtype=torch.float32, device=dev)
+    dgh = torch.empty((2, L * B, 384), dtype=torch.float32, device=dev)
+    hprev = torch.empty((2, L * B, 128), dtype=torch.float32, device=dev)
+    check(lib().tri_gru_bwd(ptr(_f32(dhfinal.contiguous())), ptr(_f32(w_hh)), ptr(hs), ptr(gates), B, L, ptr(dgi), ptr(dgh), ptr(hprev),
+                            1 if precision == "bf16x3" else 0, stream()), "tri_gru_bwd")
+    return dgi, dgh, hprev
+
+
 # ------------------------------------------------------------------------------------------------ NT-Xent
 def ntxent_fwd_bwd(za, zb, temperature, alpha, norm=True, want_grad=True):
     B, D = za.shape
