@@ -48,10 +48,12 @@ int tri_weight_prep(const float* w, long s_row, long s_tap, long s_inner, int ro
  * tri_conv_dgrad / tri_conv_wgrad replace the autograd backward of the same call sites; `d` is always the FORWARD
  * descriptor.  wgrad writes dw through element strides, i.e. directly in the reference's parameter layout. */
 int tri_conv_num_mtiles(const TriConvDesc* d);
+/* split-K scratch a small-M layer needs (0 = none): pass at least this many bytes to tri_conv_fwd / tri_conv_dgrad */
+size_t tri_conv_workspace(const TriConvDesc* d, int transposed);
 int tri_conv_fwd(const TriConvDesc* d, const float* in, const void* w_hi, const void* w_lo, float* out, const uint8_t* row_mask,
-                 const float* bias, int act, int accumulate, float* stats, void* stream);
+                 const float* bias, int act, int accumulate, float* stats, void* workspace, size_t workspace_bytes, void* stream);
 int tri_conv_dgrad(const TriConvDesc* d, const float* dout, const void* wt_hi, const void* wt_lo, float* din,
-                   const uint8_t* row_mask, int accumulate, void* stream);
+                   const uint8_t* row_mask, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 size_t tri_conv_wgrad_workspace(const TriConvDesc* d);
 int tri_conv_wgrad(const TriConvDesc* d, const float* in, const float* dout, const uint8_t* row_mask, void* workspace,
                    size_t workspace_bytes, float* dw, long s_co, long s_tap, long s_ci, int cin_real, int split3, void* stream);
@@ -82,8 +84,9 @@ int tri_bn_relu_pool3d_fwd(const float* y, const float* scale, const float* shif
                            float* pooled, uint8_t* mask_out, void* stream);
 int tri_pool3d_bwd_route(const float* y, const float* scale, const float* shift, const uint8_t* mask, const float* pooled,
                          const float* dpooled, int B, int D, int C, float* g, void* stream);
-int tri_maxpool2d_fwd(const float* x, int N, int H, int W, int C, float* out, void* stream);
-int tri_maxpool2d_bwd(const float* x, const float* dout, int N, int H, int W, int C, float* dx, void* stream);
+int tri_maxpool2d_fwd(const float* x, int N, int H, int W, int C, float* out, uint8_t* arg /* [N,Ho,Wo,C] winning tap, may be NULL */,
+                      void* stream);
+int tri_maxpool2d_bwd(const uint8_t* arg, const float* dout, int N, int H, int W, int C, float* dx, void* stream);
 int tri_avgpool_viewmax_fwd(const float* x, int B, int V, int HW, int C, float* out, int* arg, void* stream);
 int tri_avgpool_viewmax_bwd(const float* dout, const int* arg, int B, int V, int HW, int C, float* dx, void* stream);
 
@@ -109,7 +112,8 @@ int tri_act_bwd(const float* dout, const float* out, float* g, long n, int act, 
 int tri_gru_fwd(const float* xproj, const float* w_hh, const float* b_hh, int B, int L, float* hs, float* gates, float* hfinal,
                 int split3, void* stream);
 int tri_gru_bwd(const float* dhfinal, const float* w_hh, const float* hs, const float* gates, int B, int L, float* dgi, float* dgh,
-                float* hprev, int split3, void* stream);
+                float* hprev, float* dbias /* [ceil(B/16)][2][4][128] per-chunk sums of (dr, dz, dn_input, dn_hidden) */,
+                int split3, void* stream);
 
 /* ---- NT-Xent loss, forward + backward fused (tricolo/loss/nt_xent.py:24-74) ------------------------------------------ */
 size_t tri_ntxent_workspace(int B, int D);

@@ -279,9 +279,9 @@ def test_maxpool2d_and_viewmax():
     dout = torch.randn(ref.shape, generator=g)
     ref.backward(dout)
     xcl = x.permute(0, 2, 3, 1).contiguous().view(N, 1, H, W, C).to(DEV)
-    out = ops.maxpool2d_fwd(xcl)
+    out, parg = ops.maxpool2d_fwd(xcl)
     assert torch.equal(out.cpu().view(N, 5, 5, C).permute(0, 3, 1, 2), ref.detach())
-    dx = ops.maxpool2d_bwd(xcl, dout.permute(0, 2, 3, 1).contiguous().to(DEV))
+    dx = ops.maxpool2d_bwd(parg, dout.permute(0, 2, 3, 1).contiguous().to(DEV), tuple(xcl.shape))
     np.testing.assert_allclose(dx.cpu().view(N, H, W, C).permute(0, 3, 1, 2).numpy(), xr.grad.numpy(), atol=1e-6)
     # avg-pool + view max (mv_cnn.py:29-31)
     B, V = 2, 3
@@ -391,7 +391,11 @@ def test_gru_recurrence_matches_explicit_equations(precision, tol, B, L):
     (ref * up).sum().backward()
     hfinal, hs, gates = ops.gru_fwd(xproj.to(DEV), w_hh.to(DEV), b_hh.to(DEV), B, L, precision)
     np.testing.assert_allclose(hfinal.cpu().numpy(), ref.detach().numpy(), atol=tol)
-    dgi, dgh, hprev = ops.gru_bwd(up.to(DEV), w_hh.to(DEV), hs, gates, B, L, precision)
+    dgi, dgh, hprev, dbias = ops.gru_bwd(up.to(DEV), w_hh.to(DEV), hs, gates, B, L, precision)
+    db = dbias.sum(0).cpu()
+    np.testing.assert_allclose(db[:, 3].numpy(), br.grad[:, 256:].numpy(), atol=tol * 50)
+    np.testing.assert_allclose(db[:, :2].reshape(2, 256).numpy(), br.grad[:, :256].numpy(), atol=tol * 50)
+    np.testing.assert_allclose(db[:, :3].reshape(2, 384).numpy(), xr.grad.sum((0, 1)).view(2, 384).numpy(), atol=tol * 50)
     np.testing.assert_allclose(dgi.cpu().view(L, B, 768).numpy(), xr.grad.numpy(), atol=tol * 5)
     # weight / bias gradients follow from the stored gate gradients: dW_hh = dgh^T hprev, db_hh = colsum(dgh)
     for d in range(2):

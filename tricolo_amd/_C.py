@@ -29,8 +29,9 @@ SIGNATURES = {
     "tri_conv_kpad": (I, [I, I]),
     "tri_weight_prep": (I, [P, L, L, L, I, I, I, I, P, P, P]),
     "tri_conv_num_mtiles": (I, [DP]),
-    "tri_conv_fwd": (I, [DP, P, P, P, P, P, P, I, I, P, P]),
-    "tri_conv_dgrad": (I, [DP, P, P, P, P, P, I, P]),
+    "tri_conv_workspace": (Z, [DP, I]),
+    "tri_conv_fwd": (I, [DP, P, P, P, P, P, P, I, I, P, P, Z, P]),
+    "tri_conv_dgrad": (I, [DP, P, P, P, P, P, I, P, Z, P]),
     "tri_conv_wgrad_workspace": (Z, [DP]),
     "tri_conv_wgrad": (I, [DP, P, P, P, P, Z, P, L, L, L, I, I, P]),
     "tri_bn_finalize": (I, [P, I, I, P, I, P, P, P, P, P, F, F, P, P, P, P, P]),
@@ -43,7 +44,7 @@ SIGNATURES = {
     "tri_bn_bwd_apply": (I, [P, P, P, P, P, P, P, L, I, P]),
     "tri_bn_relu_pool3d_fwd": (I, [P, P, P, P, I, I, I, P, P, P]),
     "tri_pool3d_bwd_route": (I, [P, P, P, P, P, P, I, I, I, P, P]),
-    "tri_maxpool2d_fwd": (I, [P, I, I, I, I, P, P]),
+    "tri_maxpool2d_fwd": (I, [P, I, I, I, I, P, P, P]),
     "tri_maxpool2d_bwd": (I, [P, P, I, I, I, I, P, P]),
     "tri_avgpool_viewmax_fwd": (I, [P, I, I, I, I, P, P, P]),
     "tri_avgpool_viewmax_bwd": (I, [P, P, I, I, I, I, P, P]),
@@ -56,7 +57,7 @@ SIGNATURES = {
     "tri_axpy": (I, [P, F, P, L, P]),
     "tri_act_bwd": (I, [P, P, P, L, I, P]),
     "tri_gru_fwd": (I, [P, P, P, I, I, P, P, P, I, P]),
-    "tri_gru_bwd": (I, [P, P, P, P, I, I, P, P, P, I, P]),
+    "tri_gru_bwd": (I, [P, P, P, P, I, I, P, P, P, P, I, P]),
     "tri_ntxent_workspace": (Z, [I, I]),
     "tri_ntxent_fwd_bwd": (I, [P, P, I, I, F, F, I, P, P, P, P, Z, P]),
     "tri_adam_tick": (I, [P, P]),

@@ -322,7 +322,11 @@ extern "C" int tri_pool3d_bwd_route(const float* y, const float* scale, const fl
 }
 
 // ----------------------------------------------------------------------------- ResNet stem: 3x3 / stride 2 / pad 1
-__global__ void maxpool2d_fwd_kernel(const float* __restrict__ x, int N, int H, int W, int C4, float* __restrict__ out) {
+// Forward also records, per output element, WHICH of the 9 window taps won (first maximum in (kh,kw) scan order, the
+// torch.max_pool2d tie rule) as one byte; backward is then a gather over the <= 4 windows covering an input pixel:
+// 4 byte reads + 4 float4 reads instead of re-scanning 36 inputs.  Deterministic, no atomics.
+__global__ void maxpool2d_fwd_kernel(const float* __restrict__ x, int N, int H, int W, int C4, float* __restrict__ out,
+                                     uchar4* __restrict__ arg) {
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;          // floor((H + 2 - 3)/2) + 1
     const long total = (long)N * Ho * Wo * C4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -331,6 +335,7 @@ __global__ void maxpool2d_fwd_kernel(const float* __restrict__ x, int N, int H, 
         int ow = (int)(pos % Wo); long r = pos / Wo;
         int oh = (int)(r % Ho); int n = (int)(r / Ho);
         float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        uchar4 bi = make_uchar4(0, 0, 0, 0);
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
             int ih = oh * 2 - 1 + kh;
@@ -340,21 +345,24 @@ __global__ void maxpool2d_fwd_kernel(const float* __restrict__ x, int N, int H, 
                 int iw = ow * 2 - 1 + kw;
                 if ((unsigned)iw >= (unsigned)W) continue;
                 float4 v = *(const float4*)(x + ((((long)n * H + ih) * W + iw) * C4 + c) * 4);
-                best.x = fmaxf(best.x, v.x); best.y = fmaxf(best.y, v.y); best.z = fmaxf(best.z, v.z); best.w = fmaxf(best.w, v.w);
+                unsigned char k = (unsigned char)(kh * 3 + kw);
+                if (v.x > best.x) { best.x = v.x; bi.x = k; }
+                if (v.y > best.y) { best.y = v.y; bi.y = k; }
+                if (v.z > best.z) { best.z = v.z; bi.z = k; }
+                if (v.w > best.w) { best.w = v.w; bi.w = k; }
             }
         }
         *(float4*)(out + i * 4) = best;
+        if (arg) arg[i] = bi;
     }
 }
-extern "C" int tri_maxpool2d_fwd(const float* x, int N, int H, int W, int C, float* out, void* stream) {
+extern "C" int tri_maxpool2d_fwd(const float* x, int N, int H, int W, int C, float* out, uint8_t* arg, void* stream) {
     long total = (long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
-    maxpool2d_fwd_kernel<<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(x, N, H, W, C / 4, out);
+    maxpool2d_fwd_kernel<<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(x, N, H, W, C / 4, out, (uchar4*)arg);
     return tri_check_launch("tri_maxpool2d_fwd");
 }
 
-// dx[n,h,w,c] = sum over the (<= 4) windows covering (h,w) of dout where (h,w) is that window's FIRST maximum in
-// (kh,kw) scan order (torch.max_pool2d tie rule).  Gather form: deterministic, no atomics.
-__global__ void maxpool2d_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dout, int N, int H, int W, int C4,
+__global__ void maxpool2d_bwd_kernel(const uchar4* __restrict__ arg, const float* __restrict__ dout, int N, int H, int W, int C4,
                                      float* __restrict__ dx) {
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
     const long total = (long)N * H * W * C4;
@@ -363,45 +371,27 @@ __global__ void maxpool2d_bwd_kernel(const float* __restrict__ x, const float* _
         long pos = i / C4;
         int w = (int)(pos % W); long r = pos / W;
         int h = (int)(r % H); int n = (int)(r / H);
-        float4 me = *(const float4*)(x + i * 4);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int oh = h / 2; oh <= (h + 1) / 2; ++oh) {
             if (oh >= Ho) continue;
             for (int ow = w / 2; ow <= (w + 1) / 2; ++ow) {
                 if (ow >= Wo) continue;
-                // is (h,w) the first maximum of window (oh,ow)?
-                bool fx = true, fy = true, fz = true, fw = true;
-#pragma unroll
-                for (int kh = 0; kh < 3; ++kh) {
-                    int ih = oh * 2 - 1 + kh;
-                    if ((unsigned)ih >= (unsigned)H) continue;
-#pragma unroll
-                    for (int kw = 0; kw < 3; ++kw) {
-                        int iw = ow * 2 - 1 + kw;
-                        if ((unsigned)iw >= (unsigned)W) continue;
-                        if (ih == h && iw == w) continue;
-                        float4 v = *(const float4*)(x + ((((long)n * H + ih) * W + iw) * C4 + c) * 4);
-                        bool before = (ih < h) || (ih == h && iw < w);
-                        // an earlier element wins ties; a later element must be strictly greater to win
-                        fx = fx && (before ? v.x < me.x : v.x <= me.x);
-                        fy = fy && (before ? v.y < me.y : v.y <= me.y);
-                        fz = fz && (before ? v.z < me.z : v.z <= me.z);
-                        fw = fw && (before ? v.w < me.w : v.w <= me.w);
-                    }
-                }
-                float4 d = *(const float4*)(dout + ((((long)n * Ho + oh) * Wo + ow) * C4 + c) * 4);
-                if (fx) acc.x += d.x;
-                if (fy) acc.y += d.y;
-                if (fz) acc.z += d.z;
-                if (fw) acc.w += d.w;
+                unsigned char me = (unsigned char)((h - (oh * 2 - 1)) * 3 + (w - (ow * 2 - 1)));   // my tap index in that window
+                long o = (((long)n * Ho + oh) * Wo + ow) * C4 + c;
+                uchar4 a = arg[o];
+                float4 d = *(const float4*)(dout + o * 4);
+                if (a.x == me) acc.x += d.x;
+                if (a.y == me) acc.y += d.y;
+                if (a.z == me) acc.z += d.z;
+                if (a.w == me) acc.w += d.w;
             }
         }
         *(float4*)(dx + i * 4) = acc;
     }
 }
-extern "C" int tri_maxpool2d_bwd(const float* x, const float* dout, int N, int H, int W, int C, float* dx, void* stream) {
+extern "C" int tri_maxpool2d_bwd(const uint8_t* arg, const float* dout, int N, int H, int W, int C, float* dx, void* stream) {
     long total = (long)N * H * W * (C / 4);
-    maxpool2d_bwd_kernel<<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(x, dout, N, H, W, C / 4, dx);
+    maxpool2d_bwd_kernel<<<ew_grid(total), 256, 0, (hipStream_t)stream>>>((const uchar4*)arg, dout, N, H, W, C / 4, dx);
     return tri_check_launch("tri_maxpool2d_bwd");
 }
 

@@ -22,14 +22,21 @@ struct ConvArgs {
     const uint8_t* row_mask;   // per output position; 0 -> row forced to zero, all-zero tiles are skipped
     const float* bias;
     float* stats;              // [num_mtiles][2][Cout] per-tile column sum / sum of squares (BatchNorm statistics)
+    float* slab;               // split-K partial sums [ksplit][M][Cout] (ksplit > 1)
     int B, ID, IH, IW, Cin;
     int OD, OH, OW, Cout;
     int KD, KH, KW, stride, pd, ph, pw;
     int transposed, act, accumulate;
-    int Kpad, M, ntaps, cin_shift;
+    int Kpad, M, ntaps, cin_shift, ksplit, steps_per_split;
+    unsigned in_bytes;
     FastDiv dOW, dOH, dOD, dCin;
 };
 
+// im2col gather, per thread: 4 rows x one float4 of k per k-step.  Everything that depends only on the ROW is
+// computed once (element offset of the row's origin voxel + a packed per-axis validity mask, 8 bits per axis);
+// everything that depends only on the TAP comes from a 64-entry LDS table.  A load is then
+//   voffset = valid ? (rowoff + tapoff + c) * 4 : OUT_OF_RANGE   ->  raw buffer load (hardware returns 0 out of range)
+// i.e. ~5 VALU instructions instead of a full coordinate / bounds / address recomputation per load.
 template <int BN, int NSPLIT>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     constexpr int BM = 128;
@@ -39,14 +46,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     constexpr int STAGE = NSPLIT * (A_BYTES + B_BYTES);
     constexpr int BCH = (BN * 4 + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int* lut = (int*)(smem + 2 * STAGE);                 // [64] packed (kd | kh<<8 | kw<<16)
-    float* red = (float*)(smem + 2 * STAGE + 256);       // [WAVES_M][BN][2]
+    int* lut_off = (int*)(smem + 2 * STAGE);             // [64] element offset of the tap
+    int* lut_sh = lut_off + 64;                          // [64] packed shifts: kw | (8+kh)<<8 | (16+kd)<<16
+    float* red = (float*)(smem + 2 * STAGE + 512);       // [WAVES_M][BN][2]
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int NT = p.Cout / BN;
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const int mtile = wg / NT, ntile = wg - mtile * NT;
     const int m0 = mtile * BM, n0 = ntile * BN;
+    const int sshift = (p.stride == 2) ? 1 : 0;
 
     if (t < 64) {
         int kd = 0, kh = 0, kw = 0;
@@ -56,13 +65,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
             kh = r % p.KH;
             kd = r / p.KH;
         }
-        lut[t] = kd | (kh << 8) | (kw << 16);
+        lut_sh[t] = kw | ((8 + kh) << 8) | ((16 + kd) << 16);
+        int off = p.transposed ? -((((kd >> sshift) * p.IH + (kh >> sshift)) * p.IW + (kw >> sshift)) * p.Cin)
+                               : (((kd * p.IH + kh) * p.IW + kw) * p.Cin);
+        lut_off[t] = off;
     }
 
-    // ---- per-thread im2col rows: 4 rows (t>>3) + 32 i, one float4 (4 consecutive k) per row and k-step
     const int k4 = t & 7;
-    int rb[4], rz[4], ry[4], rx[4];
-    bool rv[4];
+    int rowoff[4];
+    unsigned rmask[4];
     int any_active = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -76,17 +87,28 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
         uint32_t b = fdiv(q2, p.dOD);
         int od = q2 - b * p.OD;
         if (p.row_mask) valid = valid && (p.row_mask[mm] != 0);
-        rv[i] = valid;
         any_active |= valid ? 1 : 0;
-        rb[i] = (int)b * p.ID * p.IH * p.IW;
+        unsigned mk = 0;
+        int z0, y0, x0;
         if (p.transposed) {
-            rz[i] = od + p.pd; ry[i] = oh + p.ph; rx[i] = ow + p.pw;
+            int rz = od + p.pd, ry = oh + p.ph, rx = ow + p.pw;
+            z0 = rz >> sshift; y0 = ry >> sshift; x0 = rx >> sshift;
+            for (int k = 0; k < p.KW; ++k) { int tt = rx - k; if (tt >= 0 && (tt & (p.stride - 1)) == 0 && (tt >> sshift) < p.IW) mk |= 1u << k; }
+            for (int k = 0; k < p.KH; ++k) { int tt = ry - k; if (tt >= 0 && (tt & (p.stride - 1)) == 0 && (tt >> sshift) < p.IH) mk |= 1u << (8 + k); }
+            for (int k = 0; k < p.KD; ++k) { int tt = rz - k; if (tt >= 0 && (tt & (p.stride - 1)) == 0 && (tt >> sshift) < p.ID) mk |= 1u << (16 + k); }
         } else {
-            rz[i] = od * p.stride - p.pd; ry[i] = oh * p.stride - p.ph; rx[i] = ow * p.stride - p.pw;
+            z0 = od * p.stride - p.pd; y0 = oh * p.stride - p.ph; x0 = ow * p.stride - p.pw;
+            for (int k = 0; k < p.KW; ++k) if ((unsigned)(x0 + k) < (unsigned)p.IW) mk |= 1u << k;
+            for (int k = 0; k < p.KH; ++k) if ((unsigned)(y0 + k) < (unsigned)p.IH) mk |= 1u << (8 + k);
+            for (int k = 0; k < p.KD; ++k) if ((unsigned)(z0 + k) < (unsigned)p.ID) mk |= 1u << (16 + k);
         }
+        rmask[i] = valid ? mk : 0u;
+        rowoff[i] = ((((int)b * p.ID + z0) * p.IH + y0) * p.IW + x0) * p.Cin;
     }
-    any_active = __syncthreads_or(any_active);       // also publishes lut[]
+    any_active = __syncthreads_or(any_active);       // also publishes the tap tables
 
+    // accumulators hold D^T tiles: acc[a][b][r] = out[m = a-tile row (lane&15)][n = b-tile col 4*(lane>>4) + r]
+    // (weights are the MFMA "A" operand, activations the "B" operand) so the epilogue stores 16 bytes per lane.
     f32x4 acc[TM][TN];
 #pragma unroll
     for (int a = 0; a < TM; ++a)
@@ -95,11 +117,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
 
     const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
     const int fr = lane & 15, fq = lane >> 4;
+    const int split = blockIdx.y;
 
     if (any_active) {
-        const int nk = p.Kpad >> 5;
-        const int sshift = (p.stride == 2) ? 1 : 0;
-        float4 av[4];
+        const int nk_total = p.Kpad >> 5;
+        const int ks0 = split * p.steps_per_split;
+        const int ks1 = min(nk_total, ks0 + p.steps_per_split);
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+        uint4 av[4];
         uint4 bh0, bh1, bl0, bl1;       // named, not an array: hipcc keeps conditionally-written arrays in scratch
         bh0 = bh1 = bl0 = bl1 = make_uint4(0, 0, 0, 0);
 
@@ -109,28 +134,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
             if (p.cin_shift >= 0) { tap = kb >> p.cin_shift; c = kb & ((1 << p.cin_shift) - 1); }
             else { tap = (int)fdiv((uint32_t)kb, p.dCin); c = kb - tap * p.Cin; }
             bool tv = tap < p.ntaps;
-            int code = lut[tv ? tap : 0];
-            int kd = code & 255, kh = (code >> 8) & 255, kw = (code >> 16) & 255;
+            int tsel = tv ? tap : 0;
+            int toff = lut_off[tsel] + c;
+            int sh = lut_sh[tsel];
+            int sx = sh & 255, sy = (sh >> 8) & 255, sz = (sh >> 16) & 255;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                int iz, iy, ix;
-                bool ok = rv[i] && tv;
-                if (p.transposed) {
-                    int tz = rz[i] - kd, ty = ry[i] - kh, tx = rx[i] - kw;
-                    ok = ok && ((tz | ty | tx) >= 0) && (((tz | ty | tx) & (p.stride - 1)) == 0);
-                    iz = tz >> sshift; iy = ty >> sshift; ix = tx >> sshift;
-                    ok = ok && iz < p.ID && iy < p.IH && ix < p.IW;
-                } else {
-                    iz = rz[i] + kd; iy = ry[i] + kh; ix = rx[i] + kw;
-                    ok = ok && (unsigned)iz < (unsigned)p.ID && (unsigned)iy < (unsigned)p.IH &&
-                         (unsigned)ix < (unsigned)p.IW;
-                }
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok) {
-                    size_t off = ((size_t)(rb[i] + (iz * p.IH + iy) * p.IW + ix)) * p.Cin + c;
-                    v = *(const float4*)(p.in + off);
-                }
-                av[i] = v;
+                unsigned mk = rmask[i];
+                bool ok = tv && (((mk >> sx) & (mk >> sy) & (mk >> sz)) & 1u);
+                unsigned voff = ok ? (unsigned)((rowoff[i] + toff) << 2) : 0x80000000u;
+                av[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
             }
             {
                 int idx = t;
@@ -153,13 +166,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
             for (int i = 0; i < 4; ++i) {
                 int row = (t >> 3) + 32 * i;
                 int off = tile_off(row, k4 >> 1) + (k4 & 1) * 8;
+                float4 v = __builtin_bit_cast(float4, av[i]);
                 if (NSPLIT == 2) {
                     bf16x4 h, l;
-                    split_bf16(av[i], h, l);
+                    split_bf16(v, h, l);
                     *(bf16x4*)(base + off) = h;
                     *(bf16x4*)(base + A_BYTES + off) = l;
                 } else {
-                    *(bf16x4*)(base + off) = to_bf16x4(av[i]);
+                    *(bf16x4*)(base + off) = to_bf16x4(v);
                 }
             }
             char* bb = base + NSPLIT * A_BYTES;
@@ -197,65 +211,90 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
                 for (int a = 0; a < TM; ++a) {
                     if (NSPLIT == 2) {
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[a], bhf, acc[a][b], 0, 0, 0);
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[a], blf, acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhf, al[a], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(blf, ah[a], acc[a][b], 0, 0, 0);
                     }
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[a], bhf, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhf, ah[a], acc[a][b], 0, 0, 0);
                 }
             }
         };
 
-        load_global(0);
-        store_lds(0);
-        __syncthreads();
-        for (int ks = 0; ks < nk; ++ks) {
-            if (ks + 1 < nk) load_global(ks + 1);      // issue early: latency hides under the MFMAs
-            compute(ks & 1);
-            if (ks + 1 < nk) store_lds((ks + 1) & 1);
+        if (ks0 < ks1) {
+            load_global(ks0);
+            store_lds(0);
             __syncthreads();
+            for (int ks = ks0; ks < ks1; ++ks) {
+                const int buf = (ks - ks0) & 1;
+                if (ks + 1 < ks1) load_global(ks + 1);      // issue early: latency hides under the MFMAs
+                compute(buf);
+                if (ks + 1 < ks1) store_lds(buf ^ 1);
+                __syncthreads();
+            }
         }
     }
 
-    // ---- epilogue: mask / bias / activation / accumulate / per-tile BatchNorm partial sums
-    float cs[TN], cq[TN];
+    if (p.ksplit > 1) {
+        // split-K: raw partial sums only; conv_splitk_finish_kernel applies mask / bias / activation / statistics
+        if (!any_active) return;
+        float* slab = p.slab + (size_t)split * p.M * p.Cout;
 #pragma unroll
-    for (int b = 0; b < TN; ++b) { cs[b] = 0.f; cq[b] = 0.f; }
-#pragma unroll
-    for (int a = 0; a < TM; ++a) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            int row = wm * WM + a * 16 + fq * 4 + r;
-            int m = m0 + row;
-            if (m < p.M) {
-                bool live = p.row_mask ? (p.row_mask[m] != 0) : true;
+        for (int a = 0; a < TM; ++a) {
+            int m = m0 + wm * WM + a * 16 + fr;
+            if (m < p.M)
 #pragma unroll
                 for (int b = 0; b < TN; ++b) {
-                    int n = n0 + wn * WN + b * 16 + fr;
-                    float v = live ? acc[a][b][r] : 0.f;
-                    if (p.bias) v += p.bias[n];
-                    if (p.act == 1) v = fmaxf(v, 0.f);
-                    else if (p.act == 2) v = tanhf(v);
-                    if (!live) v = 0.f;
-                    size_t o = (size_t)m * p.Cout + n;
-                    if (p.accumulate) v += p.out[o];
-                    p.out[o] = v;
-                    cs[b] += v;
-                    cq[b] += v * v;
+                    int n = n0 + wn * WN + b * 16 + fq * 4;
+                    *(f32x4*)(slab + (size_t)m * p.Cout + n) = acc[a][b];
                 }
+        }
+        return;
+    }
+
+    // ---- epilogue: mask / bias / activation / accumulate / per-tile BatchNorm partial sums; 16-byte stores
+    float cs[TN][4], cq[TN][4];
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { cs[b][r] = 0.f; cq[b][r] = 0.f; }
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+        int m = m0 + wm * WM + a * 16 + fr;
+        if (m < p.M) {
+            bool live = p.row_mask ? (p.row_mask[m] != 0) : true;
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                int n = n0 + wn * WN + b * 16 + fq * 4;
+                f32x4 v = acc[a][b];
+                if (p.bias) { f32x4 bv = *(const f32x4*)(p.bias + n); v += bv; }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = v[r];
+                    if (p.act == 1) x = fmaxf(x, 0.f);
+                    else if (p.act == 2) x = tanhf(x);
+                    v[r] = live ? x : 0.f;
+                }
+                float* o = p.out + (size_t)m * p.Cout + n;
+                if (p.accumulate) v += *(const f32x4*)o;
+                *(f32x4*)o = v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { cs[b][r] += v[r]; cq[b][r] += v[r] * v[r]; }
             }
         }
     }
     if (p.stats) {
 #pragma unroll
-        for (int b = 0; b < TN; ++b) {
-            cs[b] += __shfl_xor(cs[b], 16); cs[b] += __shfl_xor(cs[b], 32);
-            cq[b] += __shfl_xor(cq[b], 16); cq[b] += __shfl_xor(cq[b], 32);
-            if (fq == 0) {
-                int col = wn * WN + b * 16 + fr;
-                red[(wm * BN + col) * 2 + 0] = cs[b];
-                red[(wm * BN + col) * 2 + 1] = cq[b];
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s = cs[b][r], q = cq[b][r];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+                if (fr == 0) {
+                    int col = wn * WN + b * 16 + fq * 4 + r;
+                    red[(wm * BN + col) * 2 + 0] = s;
+                    red[(wm * BN + col) * 2 + 1] = q;
+                }
             }
-        }
         __syncthreads();
         if (t < BN) {
             float s = 0.f, q = 0.f;
@@ -263,6 +302,50 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
             for (int w = 0; w < WAVES_M; ++w) { s += red[(w * BN + t) * 2]; q += red[(w * BN + t) * 2 + 1]; }
             p.stats[((size_t)mtile * 2 + 0) * p.Cout + n0 + t] = s;
             p.stats[((size_t)mtile * 2 + 1) * p.Cout + n0 + t] = q;
+        }
+    }
+}
+
+// out = act(sum_split slab + bias) * mask (+ out), plus BatchNorm partial sums per 32-row chunk.
+// One block = 32 rows x 64 columns (16 row lanes x 16 float4 column groups), grid = (row chunks, column chunks), so even
+// a 256-row layer spreads its slab read over dozens of CUs.
+__global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const ConvArgs p) {
+    __shared__ float red[16][64][2];
+    const int t = threadIdx.x, tc = t & 15, rl = t >> 4;
+    const int chunk = blockIdx.x, m0 = chunk * 32, n = blockIdx.y * 64 + tc * 4;
+    float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f), q4 = s4;
+    const float4 bv = p.bias ? *(const float4*)(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        int m = m0 + rl * 2 + rr;
+        if (m >= p.M) continue;
+        bool live = p.row_mask ? (p.row_mask[m] != 0) : true;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live) {
+            for (int z = 0; z < p.ksplit; ++z) {
+                float4 x = *(const float4*)(p.slab + ((size_t)z * p.M + m) * p.Cout + n);
+                v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+            }
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            if (p.act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            else if (p.act == 2) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
+        }
+        float* o = p.out + (size_t)m * p.Cout + n;
+        if (p.accumulate) { float4 e = *(const float4*)o; v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w; }
+        *(float4*)o = v;
+        s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
+        q4.x += v.x * v.x; q4.y += v.y * v.y; q4.z += v.z * v.z; q4.w += v.w * v.w;
+    }
+    if (p.stats) {
+        float* d = &red[rl][tc * 4][0];
+        d[0] = s4.x; d[1] = q4.x; d[2] = s4.y; d[3] = q4.y; d[4] = s4.z; d[5] = q4.z; d[6] = s4.w; d[7] = q4.w;
+        __syncthreads();
+        if (t < 64) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) { s += red[w][t][0]; q += red[w][t][1]; }
+            p.stats[((size_t)chunk * 2 + 0) * p.Cout + blockIdx.y * 64 + t] = s;
+            p.stats[((size_t)chunk * 2 + 1) * p.Cout + blockIdx.y * 64 + t] = q;
         }
     }
 }
@@ -306,24 +389,57 @@ template <int BN, int NSPLIT>
 static int launch_conv(const ConvArgs& a, hipStream_t stream) {
     constexpr int STAGE = NSPLIT * (128 * 64 + BN * 64);
     constexpr int WAVES_M = (BN >= 64) ? 2 : 4;
-    size_t smem = 2 * STAGE + 256 + WAVES_M * BN * 2 * sizeof(float);
+    size_t smem = 2 * STAGE + 512 + WAVES_M * BN * 2 * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute((const void*)conv_igemm_kernel<BN, NSPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
     }
     int mt = (a.M + 127) / 128, nt = a.Cout / BN;
-    conv_igemm_kernel<BN, NSPLIT><<<mt * nt, 256, smem, stream>>>(a);
-    return tri_check_launch("tri_conv");
+    conv_igemm_kernel<BN, NSPLIT><<<dim3(mt * nt, a.ksplit), 256, smem, stream>>>(a);
+    int rc = tri_check_launch("tri_conv");
+    if (rc || a.ksplit == 1) return rc;
+    conv_splitk_finish_kernel<<<dim3((a.M + 31) / 32, a.Cout / 64), 256, 0, stream>>>(a);
+    return tri_check_launch("tri_conv_splitk_finish");
 }
 
-static int conv_dispatch(ConvArgs& a, hipStream_t stream) {
+static int conv_bn(int cout) { return cout % 128 == 0 ? 128 : (cout % 64 == 0 ? 64 : 32); }
+
+// split-K plan: layers whose M x N tiling gives fewer than ~1.5 workgroups per CU split the K loop over gridDim.y
+static void conv_split_plan(long M, int cout, int kpad, int* ksplit, int* steps_per_split) {
+    int blocks = (int)((M + 127) / 128) * (cout / conv_bn(cout));
+    int nk = kpad / 32;
+    int ks = 1;
+    if (blocks < 384 && nk >= 8 && cout % 64 == 0) {
+        ks = (768 + blocks - 1) / blocks;
+        if (ks > nk / 4) ks = nk / 4;
+        if (ks > 32) ks = 32;
+        if (ks < 1) ks = 1;
+    }
+    *steps_per_split = (nk + ks - 1) / ks;
+    *ksplit = (nk + *steps_per_split - 1) / *steps_per_split;
+}
+
+static int conv_dispatch(ConvArgs& a, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     if (a.Cin % 4 != 0) { tri_set_error("conv: stored input channels must be a multiple of 4"); return TRI_ERR_ARG; }
     if (a.Cout % 32 != 0) { tri_set_error("conv: output channels must be a multiple of 32"); return TRI_ERR_ARG; }
     if (a.ntaps > 64) { tri_set_error("conv: more than 64 taps unsupported"); return TRI_ERR_UNSUPPORTED; }
     if (a.stride != 1 && a.stride != 2) { tri_set_error("conv: stride must be 1 or 2"); return TRI_ERR_UNSUPPORTED; }
+    if (a.KD > 8 || a.KH > 8 || a.KW > 8) { tri_set_error("conv: kernel extent > 8 unsupported"); return TRI_ERR_UNSUPPORTED; }
     a.Kpad = (a.ntaps * a.Cin + 31) / 32 * 32;
     a.cin_shift = ilog2_exact(a.Cin);
+    size_t in_bytes = (size_t)a.B * a.ID * a.IH * a.IW * a.Cin * sizeof(float);
+    if (in_bytes >= ((size_t)1 << 31)) { tri_set_error("conv: input tensor >= 2 GiB (32-bit buffer offsets)"); return TRI_ERR_UNSUPPORTED; }
+    a.in_bytes = (unsigned)in_bytes;
+    conv_split_plan(a.M, a.Cout, a.Kpad, &a.ksplit, &a.steps_per_split);
+    if (a.ksplit > 1) {
+        size_t need = (size_t)a.ksplit * a.M * a.Cout * sizeof(float);
+        if (workspace == nullptr || workspace_bytes < need) {
+            tri_set_error("conv: this layer runs split-K; pass tri_conv_workspace() bytes of scratch");
+            return TRI_ERR_ARG;
+        }
+        a.slab = (float*)workspace;
+    }
     a.dOW = make_fastdiv(a.OW); a.dOH = make_fastdiv(a.OH); a.dOD = make_fastdiv(a.OD); a.dCin = make_fastdiv(a.Cin);
     bool split = a.w_lo != nullptr;
     if (a.Cout % 128 == 0) return split ? launch_conv<128, 2>(a, stream) : launch_conv<128, 1>(a, stream);
@@ -333,15 +449,32 @@ static int conv_dispatch(ConvArgs& a, hipStream_t stream) {
 
 extern "C" int tri_conv_kpad(int ntaps, int cin_stored) { return (ntaps * cin_stored + 31) / 32 * 32; }
 
+// number of [2][Cout] statistic records tri_conv_fwd writes for this layer: one per 128-row tile, or one per 32-row
+// chunk when the layer runs split-K (the finish kernel produces them).  tri_bn_finalize just sums all records.
 extern "C" int tri_conv_num_mtiles(const TriConvDesc* d) {
     long M = (long)d->B * d->OD * d->OH * d->OW;
-    return (int)((M + 127) / 128);
+    int kpad = (d->KD * d->KH * d->KW * d->Cin + 31) / 32 * 32;
+    int ks, sps;
+    conv_split_plan(M, d->Cout, kpad, &ks, &sps);
+    return ks > 1 ? (int)((M + 31) / 32) : (int)((M + 127) / 128);
 }
 
 // out[B,OD,OH,OW,Cout] = conv(in[B,ID,IH,IW,Cin], W) (+bias, act 0 none / 1 relu / 2 tanh); rows with row_mask==0 are
 // written as zeros (submanifold rule); stats != NULL receives per-128-row-tile column sums and sums of squares.
+// bytes of split-K scratch tri_conv_fwd (transposed = 0) / tri_conv_dgrad (transposed = 1) can use for this layer
+// (0 when the layer already fills the GPU) and therefore REQUIRES.
+extern "C" size_t tri_conv_workspace(const TriConvDesc* d, int transposed) {
+    long M = transposed ? (long)d->B * d->ID * d->IH * d->IW : (long)d->B * d->OD * d->OH * d->OW;
+    int cout = transposed ? d->Cin : d->Cout, cin = transposed ? d->Cout : d->Cin;
+    int kpad = (d->KD * d->KH * d->KW * cin + 31) / 32 * 32;
+    int ks, sps;
+    conv_split_plan(M, cout, kpad, &ks, &sps);
+    return ks > 1 ? (size_t)ks * M * cout * sizeof(float) : 0;
+}
+
 extern "C" int tri_conv_fwd(const TriConvDesc* d, const float* in, const void* w_hi, const void* w_lo, float* out,
-                            const uint8_t* row_mask, const float* bias, int act, int accumulate, float* stats, void* stream) {
+                            const uint8_t* row_mask, const float* bias, int act, int accumulate, float* stats, void* workspace,
+                            size_t workspace_bytes, void* stream) {
     ConvArgs a{};
     a.in = in; a.w_hi = (const bf16_t*)w_hi; a.w_lo = (const bf16_t*)w_lo; a.out = out;
     a.row_mask = row_mask; a.bias = bias; a.stats = stats;
@@ -351,13 +484,13 @@ extern "C" int tri_conv_fwd(const TriConvDesc* d, const float* in, const void* w
     a.transposed = 0; a.act = act; a.accumulate = accumulate;
     a.ntaps = d->KD * d->KH * d->KW;
     a.M = d->B * d->OD * d->OH * d->OW;
-    return conv_dispatch(a, (hipStream_t)stream);
+    return conv_dispatch(a, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 // din[B,ID,IH,IW,Cin] (+)= conv_transpose(dout[B,OD,OH,OW,Cout], Wt), Wt packed [Cin][taps*Cout] by tri_weight_prep
 // with swapped strides.  `d` is the FORWARD descriptor of the layer.
 extern "C" int tri_conv_dgrad(const TriConvDesc* d, const float* dout, const void* wt_hi, const void* wt_lo, float* din,
-                              const uint8_t* row_mask, int accumulate, void* stream) {
+                              const uint8_t* row_mask, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
     ConvArgs a{};
     a.in = dout; a.w_hi = (const bf16_t*)wt_hi; a.w_lo = (const bf16_t*)wt_lo; a.out = din;
     a.row_mask = row_mask; a.bias = nullptr; a.stats = nullptr;
@@ -367,5 +500,5 @@ extern "C" int tri_conv_dgrad(const TriConvDesc* d, const float* dout, const voi
     a.transposed = 1; a.act = 0; a.accumulate = accumulate;
     a.ntaps = d->KD * d->KH * d->KW;
     a.M = d->B * d->ID * d->IH * d->IW;
-    return conv_dispatch(a, (hipStream_t)stream);
+    return conv_dispatch(a, workspace, workspace_bytes, (hipStream_t)stream);
 }

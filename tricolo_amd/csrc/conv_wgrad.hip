@@ -251,7 +251,7 @@ static void wgrad_plan(const TriConvDesc* d, int* BI, int* tiles, int* splits, i
     *tiles = it * jt;
     long M = (long)d->B * d->OD * d->OH * d->OW;
     int steps = (int)((M + 31) / 32);
-    int want = (1024 + *tiles - 1) / *tiles;                    // aim at ~1024 workgroups (4 per CU)
+    int want = (768 + *tiles - 1) / *tiles;                     // aim at ~768 workgroups (3 per CU): slab traffic grows with splits
     int max_by_steps = steps / 4 > 0 ? steps / 4 : 1;           // at least 4 k-steps per split
     int s = want < max_by_steps ? want : max_by_steps;
     if (s < 1) s = 1;

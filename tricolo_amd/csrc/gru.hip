@@ -133,7 +133,8 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
                                                       int B, int L,
                                                       float* __restrict__ dgi,            // [L][B][768]
                                                       float* __restrict__ dgh,            // [2][L][B][384]
-                                                      float* __restrict__ hprev) {        // [2][L][B][128]
+                                                      float* __restrict__ hprev,          // [2][L][B][128]
+                                                      float* __restrict__ dbias) {        // [chunks][2][4][128]: sum_t,rows of (dr, dz, dn_i, dn_h)
     __shared__ __attribute__((aligned(16))) char lds[2 * NSPLIT * 16 * 768];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int dir = blockIdx.y, b0 = blockIdx.x * 16;
@@ -159,6 +160,7 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
         int b = b0 + fq * 4 + r;
         dh[r] = b < B ? dhfinal[(size_t)b * 256 + dir * GRU_H + unit] : 0.f;
     }
+    float sb[4] = {0.f, 0.f, 0.f, 0.f};                      // bias-gradient partial sums of this lane's (rows, unit)
     int cur = 0;
     for (int s = L - 1; s >= 0; --s) {
         const int tt = dir == 0 ? s : L - 1 - s;              // time index processed at forward step s
@@ -189,6 +191,7 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
                 float* gh = dgh + o * 384 + unit;
                 gh[0] = dr_pre; gh[128] = dz_pre; gh[256] = dgn;
                 hprev[o * GRU_H + unit] = hp;
+                sb[0] += dr_pre; sb[1] += dz_pre; sb[2] += dn_pre; sb[3] += dgn;
             }
             float vals[3] = {dr_pre, dz_pre, dgn};
 #pragma unroll
@@ -217,6 +220,13 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
         for (int r = 0; r < 4; ++r) dh[r] = dhz[r] + acc[r];
         cur ^= 1;                                             // next step writes the other image: one barrier per step
     }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float v = sb[k];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (fq == 0) dbias[(((size_t)blockIdx.x * 2 + dir) * 4 + k) * GRU_H + unit] = v;
+    }
 }
 
 extern "C" int tri_gru_fwd(const float* xproj, const float* w_hh, const float* b_hh, int B, int L, float* hs, float* gates,
@@ -229,10 +239,10 @@ extern "C" int tri_gru_fwd(const float* xproj, const float* w_hh, const float* b
 }
 
 extern "C" int tri_gru_bwd(const float* dhfinal, const float* w_hh, const float* hs, const float* gates, int B, int L, float* dgi,
-                           float* dgh, float* hprev, int split3, void* stream) {
+                           float* dgh, float* hprev, float* dbias, int split3, void* stream) {
     if (B < 1 || L < 1) { tri_set_error("tri_gru_bwd: B, L must be positive"); return TRI_ERR_ARG; }
     dim3 grid((B + 15) / 16, 2);
-    if (split3) gru_bwd_kernel<2><<<grid, 512, 0, (hipStream_t)stream>>>(dhfinal, w_hh, hs, gates, B, L, dgi, dgh, hprev);
-    else gru_bwd_kernel<1><<<grid, 512, 0, (hipStream_t)stream>>>(dhfinal, w_hh, hs, gates, B, L, dgi, dgh, hprev);
+    if (split3) gru_bwd_kernel<2><<<grid, 512, 0, (hipStream_t)stream>>>(dhfinal, w_hh, hs, gates, B, L, dgi, dgh, hprev, dbias);
+    else gru_bwd_kernel<1><<<grid, 512, 0, (hipStream_t)stream>>>(dhfinal, w_hh, hs, gates, B, L, dgi, dgh, hprev, dbias);
     return tri_check_launch("tri_gru_bwd");
 }

@@ -64,7 +64,7 @@ def linear_fwd(x, w, b, act: int, precision: str, spatial: int = 1):
     return out.view(rows, N)
 
 
-def linear_bwd(x, w, out, dout, act: int, precision: str, spatial: int = 1, need_dx: bool = True):
+def linear_bwd(x, w, out, dout, act: int, precision: str, spatial: int = 1, need_dx: bool = True, need_db: bool = True):
     """Backward of linear_fwd.  Returns (dx | None, dw, db)."""
     rows = x.shape[0]
     N = w.shape[0]
@@ -72,7 +72,7 @@ def linear_bwd(x, w, out, dout, act: int, precision: str, spatial: int = 1, need
     g = linear_geom(rows, K, N, spatial)
     dpre = ops.act_bwd(dout.contiguous().clone(), out, act) if act else dout.contiguous()
     dw = ops.conv_wgrad(x, dpre, g, w, precision)
-    db = ops.colsum(dpre)
+    db = ops.colsum(dpre) if need_db else None
     dx = None
     if need_dx:
         packed_t = ops.pack_weight(w, g, precision, transposed=True)

@@ -110,8 +110,8 @@ class MVCNNEncoder(TriModule):
         x0 = ops.nchw3_to_nhwc4(images)
         y, co, g = self._conv_bn(x0, self.net_1[0], self.net_1[1], prec, train)
         z = ops.bn_act(y, co, relu=True)
-        x = ops.maxpool2d_fwd(z)
-        saved = {"stem": (x0, y, co, g, z), "blocks": [], "B": B, "N": N}
+        x, parg = ops.maxpool2d_fwd(z, want_arg=save)
+        saved = {"stem": (x0, y, co, g, z, parg), "blocks": [], "B": B, "N": N}
         for blk in self._blocks():
             y1, co1, g1 = self._conv_bn(x, blk.conv1, blk.bn1, prec, train)
             a1 = ops.bn_act(y1, co1, relu=True)
@@ -161,8 +161,8 @@ class MVCNNEncoder(TriModule):
                 dx = g                                                         # identity branch
             dx = ops.conv_dgrad(dy1, g1, ops.pack_weight(blk.conv1.weight, g1, prec, transposed=True), out=dx, accumulate=True)
             dout = dx
-        x0, y, co, g0, z = saved["stem"]
-        dzs = ops.maxpool2d_bwd(z, dout)
+        x0, y, co, g0, z, parg = saved["stem"]
+        dzs = ops.maxpool2d_bwd(parg, dout, tuple(z.shape))
         gz = ops.relu_bwd(dzs, z)
         dy, gr[self.net_1[1].weight], gr[self.net_1[1].bias] = ops.bn_bwd(y, gz, co, self.net_1[1].weight, count_host=g0.M)
         gr[self.net_1[0].weight] = ops.conv_wgrad(x0, dy, g0, self.net_1[0].weight, prec)

@@ -42,13 +42,15 @@ class _BiGRUFn(torch.autograd.Function):
     def backward(ctx, dhfinal):
         x2d, w_ih, w_hh, hs, gates = ctx.saved_tensors
         (L, B, I), prec = ctx.dims, ctx.precision
-        dgi, dgh, hprev = ops.gru_bwd(dhfinal, w_hh, hs, gates, B, L, prec)
-        dx, dw_ih, db_ih = linear_bwd(x2d, w_ih, None, dgi, 0, prec, need_dx=ctx.needs_input_grad[0])
+        dgi, dgh, hprev, dbias = ops.gru_bwd(dhfinal, w_hh, hs, gates, B, L, prec)
+        dx, dw_ih, _ = linear_bwd(x2d, w_ih, None, dgi, 0, prec, need_dx=ctx.needs_input_grad[0], need_db=False)
         g_hh = linear_geom(L * B, 128, 384)
         dw_hh = [ops.conv_wgrad(hprev[d], dgh[d], g_hh, w_hh[d], prec) for d in range(2)]
-        db_hh = [ops.colsum(dgh[d]) for d in range(2)]
+        db = dbias.sum(0)                                   # [2, 4, 128]: (dr, dz, dn_input, dn_hidden) summed in-kernel over t, rows
+        db_ih = [db[d, :3].reshape(384) for d in range(2)]
+        db_hh = [torch.cat([db[d, :2].reshape(256), db[d, 3]]) for d in range(2)]
         demb = dx.view(L, B, I) if dx is not None else None
-        return (demb, dw_ih[:384], dw_hh[0], db_ih[:384], db_hh[0], dw_ih[384:], dw_hh[1], db_ih[384:], db_hh[1], None)
+        return (demb, dw_ih[:384], dw_hh[0], db_ih[0], db_hh[0], dw_ih[384:], dw_hh[1], db_ih[1], db_hh[1], None)
 
 
 class BiGRUEncoder(TriModule):

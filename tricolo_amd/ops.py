@@ -95,6 +95,8 @@ class ConvGeom:
         self.M_in = B * ID * IH * IW
         self.num_mtiles = lib().tri_conv_num_mtiles(_C.C.byref(self.desc))
         self.wgrad_ws = lib().tri_conv_wgrad_workspace(_C.C.byref(self.desc))
+        self.fwd_ws = lib().tri_conv_workspace(_C.C.byref(self.desc), 0)
+        self.dgrad_ws = lib().tri_conv_workspace(_C.C.byref(self.desc), 1) if cin == cin_stored and cin % 32 == 0 else 0
 
     @property
     def flops(self):
@@ -123,9 +125,11 @@ def conv_fwd(x, g: ConvGeom, packed, row_mask=None, bias=None, act=0, want_stats
     if out is None:
         out = torch.empty((g.B, OD, OH, OW, g.cout), dtype=torch.float32, device=x.device)
     stats = torch.empty((g.num_mtiles, 2, g.cout), dtype=torch.float32, device=x.device) if want_stats else None
+    ws = _workspace(g.fwd_ws, x.device) if g.fwd_ws else None
     check(_timed(_igemm_symbol(g.cout, lo is not None), g.flops,
                  lambda: lib().tri_conv_fwd(_C.C.byref(g.desc), ptr(_f32(x)), ptr(hi), ptr(lo), ptr(out), ptr(row_mask), ptr(bias),
-                                            act, 1 if accumulate else 0, ptr(stats), stream())), "tri_conv_fwd")
+                                            act, 1 if accumulate else 0, ptr(stats), ptr(ws), ws.numel() if ws is not None else 0,
+                                            stream())), "tri_conv_fwd")
     return (out, stats) if want_stats else out
 
 
@@ -134,9 +138,11 @@ def conv_dgrad(dout, g: ConvGeom, packed_t, row_mask=None, out=None, accumulate=
     ID, IH, IW = g.in_grid
     if out is None:
         out = torch.empty((g.B, ID, IH, IW, g.cin_stored), dtype=torch.float32, device=dout.device)
+    ws = _workspace(g.dgrad_ws, dout.device) if g.dgrad_ws else None
     check(_timed(_igemm_symbol(g.cin_stored, lo is not None), g.flops,
                  lambda: lib().tri_conv_dgrad(_C.C.byref(g.desc), ptr(_f32(dout)), ptr(hi), ptr(lo), ptr(out), ptr(row_mask),
-                                              1 if accumulate else 0, stream())), "tri_conv_dgrad")
+                                              1 if accumulate else 0, ptr(ws), ws.numel() if ws is not None else 0, stream())),
+          "tri_conv_dgrad")
     return out
 
 
@@ -239,17 +245,19 @@ def pool3d_bwd_route(y, co: BNCoeffs, mask, pooled, dpooled, B, D, C):
     return g
 
 
-def maxpool2d_fwd(x):
+def maxpool2d_fwd(x, want_arg=True):
+    """3x3/2/pad-1 max-pool; also returns the winning-tap byte map used by maxpool2d_bwd."""
     N, _, H, W, C = x.shape
     out = torch.empty((N, 1, (H + 1) // 2, (W + 1) // 2, C), dtype=torch.float32, device=x.device)
-    check(lib().tri_maxpool2d_fwd(ptr(x), N, H, W, C, ptr(out), stream()), "tri_maxpool2d_fwd")
-    return out
+    arg = torch.empty(out.shape, dtype=torch.uint8, device=x.device) if want_arg else None
+    check(lib().tri_maxpool2d_fwd(ptr(x), N, H, W, C, ptr(out), ptr(arg), stream()), "tri_maxpool2d_fwd")
+    return out, arg
 
 
-def maxpool2d_bwd(x, dout):
-    N, _, H, W, C = x.shape
-    dx = torch.empty_like(x)
-    check(lib().tri_maxpool2d_bwd(ptr(x), ptr(_f32(dout)), N, H, W, C, ptr(dx), stream()), "tri_maxpool2d_bwd")
+def maxpool2d_bwd(arg, dout, in_shape):
+    N, _, H, W, C = in_shape
+    dx = torch.empty(in_shape, dtype=torch.float32, device=dout.device)
+    check(lib().tri_maxpool2d_bwd(ptr(arg), ptr(_f32(dout)), N, H, W, C, ptr(dx), stream()), "tri_maxpool2d_bwd")
     return dx
 
 
@@ -339,9 +347,10 @@ def gru_bwd(dhfinal, w_hh, hs, gates, B, L, precision):
     dgi = torch.empty((L * B, 768), dtype=torch.float32, device=dev)
     dgh = torch.empty((2, L * B, 384), dtype=torch.float32, device=dev)
     hprev = torch.empty((2, L * B, 128), dtype=torch.float32, device=dev)
+    dbias = torch.empty(((B + 15) // 16, 2, 4, 128), dtype=torch.float32, device=dev)
     check(lib().tri_gru_bwd(ptr(_f32(dhfinal.contiguous())), ptr(_f32(w_hh)), ptr(hs), ptr(gates), B, L, ptr(dgi), ptr(dgh), ptr(hprev),
-                            1 if precision == "bf16x3" else 0, stream()), "tri_gru_bwd")
-    return dgi, dgh, hprev
+                            ptr(dbias), 1 if precision == "bf16x3" else 0, stream()), "tri_gru_bwd")
+    return dgi, dgh, hprev, dbias
 
 
 # ------------------------------------------------------------------------------------------------ NT-Xent

@@ -1,8 +1,12 @@
 """Fused Adam on the gfx950 kernel: torch.optim.Adam semantics (L2 weight decay folded into the gradient, bias
 correction, eps added after the sqrt) as instantiated by /root/reference/config/config.yaml:50-53 through
-tricolo_net.py:43-44.  The step counter lives on the device, so the whole optimizer step is HIP-graph capturable.
-Select it with ``optimizer._target_: tricolo_amd.optim.FusedAdam`` (the default of tricolo_amd/config/config.yaml);
-``torch.optim.Adam`` keeps working on the same parameters.
+tricolo_net.py:43-44.  Select it with ``optimizer._target_: tricolo_amd.optim.FusedAdam`` (the default of
+tricolo_amd/config/config.yaml); ``torch.optim.Adam`` keeps working on the same parameters.
+
+MI355X design: all parameters are re-bound (once) to views of ONE flat fp32 buffer; each step concatenates the
+gradients into one flat buffer (a single copy kernel), optionally hands that buffer to the data-parallel all-reduce
+(one collective for the whole model: xGMI rings are per-link bound, so fewer and bigger), and updates everything with
+ONE kernel launch.  The step counter lives on the device, so the optimizer step is HIP-graph capturable.
 """
 import torch
 
@@ -10,17 +14,77 @@ from . import ops
 
 
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, flatten=True):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
-        self._step_dev = None
+        self._flatten = flatten and len(self.param_groups) == 1
+        self._flat_p = self._flat_m = self._flat_v = self._step_dev = None
+        self._params = None
+
+    # ------------------------------------------------------------------ state
+    def prepare(self):
+        """Allocate state (and flatten the parameters) ahead of the first step / HIP-graph capture."""
+        if self._step_dev is not None:
+            return
+        params = [p for g in self.param_groups for p in g["params"] if p.requires_grad]
+        if not params:
+            return
+        for p in params:
+            if not p.is_cuda:
+                raise RuntimeError("FusedAdam: parameter is not on a GPU (no CPU fallback)")
+            if p.dtype != torch.float32:
+                raise RuntimeError("FusedAdam: fp32 master parameters expected")
+        dev = params[0].device
+        self._params = params
+        self._step_dev = torch.zeros((1,), dtype=torch.int32, device=dev)
+        if self._flatten:
+            sizes = [p.numel() for p in params]
+            flat = torch.empty((sum(sizes),), dtype=torch.float32, device=dev)
+            off = 0
+            with torch.no_grad():
+                for p, n in zip(params, sizes):
+                    flat[off:off + n].copy_(p.detach().reshape(-1))
+                    p.data = flat[off:off + n].view(p.shape)         # same Parameter object, storage now inside `flat`
+                    off += n
+            self._flat_p = flat
+            self._flat_m = torch.zeros_like(flat)
+            self._flat_v = torch.zeros_like(flat)
+            off = 0
+            for p, n in zip(params, sizes):                          # torch-compatible per-parameter state views
+                self.state[p]["exp_avg"] = self._flat_m[off:off + n].view(p.shape)
+                self.state[p]["exp_avg_sq"] = self._flat_v[off:off + n].view(p.shape)
+                off += n
+        else:
+            for p in params:
+                self.state[p]["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                self.state[p]["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+
+    def flat_grad(self):
+        """All gradients as one contiguous fp32 buffer in parameter order (zeros for parameters without a gradient)."""
+        parts = []
+        for p in self._params:
+            g = p.grad
+            parts.append(g.reshape(-1) if g is not None else torch.zeros(p.numel(), dtype=torch.float32, device=p.device))
+        return torch.cat(parts)
 
     @torch.no_grad()
-    def step(self, closure=None, grad_scale: float = 1.0):
+    def step(self, closure=None, grad_scale: float = 1.0, reduce_fn=None):
+        """reduce_fn(flat_grad) (optional) runs between gradient packing and the update - the data-parallel hook."""
         loss = closure() if closure is not None else None
         self.prepare()
         if self._step_dev is None:
             return loss
+        group = self.param_groups[0]
+        b1, b2 = group["betas"]
         ops.adam_tick(self._step_dev)                       # step += 1 on the device, once per optimizer step
+        if self._flatten:
+            g = self.flat_grad()
+            if reduce_fn is not None:
+                reduce_fn(g)
+            ops.adam_step(self._flat_p, g, self._flat_m, self._flat_v, self._step_dev, group["lr"], b1, b2, group["eps"],
+                          group["weight_decay"], grad_scale)
+            return loss
+        if reduce_fn is not None:
+            raise RuntimeError("reduce_fn needs flatten=True")
         for group in self.param_groups:
             b1, b2 = group["betas"]
             for p in group["params"]:
@@ -31,16 +95,3 @@ class FusedAdam(torch.optim.Optimizer):
                 ops.adam_step(p, g, st["exp_avg"], st["exp_avg_sq"], self._step_dev, group["lr"], b1, b2, group["eps"],
                               group["weight_decay"], grad_scale)
         return loss
-
-    def prepare(self):
-        """Allocate state ahead of HIP-graph capture (capture must not see first-use allocations of the counter)."""
-        for group in self.param_groups:
-            for p in group["params"]:
-                if not p.is_cuda:
-                    raise RuntimeError("FusedAdam: parameter is not on a GPU (no CPU fallback)")
-                st = self.state[p]
-                if not st:
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                if self._step_dev is None:
-                    self._step_dev = torch.zeros((1,), dtype=torch.int32, device=p.device)

@@ -67,6 +67,12 @@ def allreduce_gradients(params, op=None) -> None:
         off += n
 
 
+def allreduce_flat(flat: torch.Tensor) -> None:
+    """In-place SUM all-reduce of one flat gradient bucket (hook for FusedAdam.step(reduce_fn=...))."""
+    if is_dist():
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+
+
 def dp_training_step(net, batch, optimizer=None):
     """One data-parallel training step of TriCoLoNet: local towers -> gathered embeddings -> global losses ->
     backward -> gradient all-reduce (-> optimizer step).  Returns the loss dict (identical on every rank)."""
@@ -76,6 +82,9 @@ def dp_training_step(net, batch, optimizer=None):
     if optimizer is not None:
         optimizer.zero_grad(set_to_none=True)
     losses["train_loss/total_loss"].backward()
+    if optimizer is not None and getattr(optimizer, "_flatten", False):
+        optimizer.step(reduce_fn=allreduce_flat if is_dist() else None)    # one bucket: pack -> all-reduce -> fused update
+        return losses
     allreduce_gradients(list(net.parameters()))
     if optimizer is not None:
         optimizer.step()
