@@ -130,8 +130,10 @@ extern "C" int tri_relu_bwd(const float* dout, const float* out, float* g, long 
 // --------------------------------------------------------------------------------------------------- BN backward
 // Pass 1: per-block partial sums of g and g*y per channel ([nblk][2][C]); pass 2 (tri_bn_bwd_finalize): dgamma, dbeta
 // and the coefficients of dy = c1*g + c2 + c3*y; pass 3: apply (rows with row_mask == 0 stay zero).
-#define BNB_ROWS 256
-__global__ void bn_bwd_reduce_kernel(const float* __restrict__ y, const float* __restrict__ g, long M, int C, float* __restrict__ partial) {
+// rows per block: 256 for large tensors, 64 for small ones (so that a 3,072-row layer still fills 48 CUs)
+static inline int bnb_rows(long M) { return M >= 65536 ? 256 : 64; }
+__global__ void bn_bwd_reduce_kernel(const float* __restrict__ y, const float* __restrict__ g, long M, int C, float* __restrict__ partial,
+                                     int BNB_ROWS) {
     extern __shared__ float sh[];                      // [rows_per_pass][C4*4][2]
     const int C4 = C >> 2;
     const int tpr = C4 < 256 ? C4 : 256;               // threads per row
@@ -144,6 +146,7 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ y, const float* _
         int c4 = tc + cc * tpr;
         float4 sg = make_float4(0, 0, 0, 0), sgy = make_float4(0, 0, 0, 0);
         if (c4 < C4 && tr < rpp)
+#pragma unroll 4
             for (long r = r0 + tr; r < r1; r += rpp) {
                 float4 gv = *(const float4*)(g + r * C + c4 * 4), yv = *(const float4*)(y + r * C + c4 * 4);
                 sg.x += gv.x; sg.y += gv.y; sg.z += gv.z; sg.w += gv.w;
@@ -168,13 +171,14 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ y, const float* _
         }
     }
 }
-extern "C" int tri_bn_bwd_num_blocks(long M) { return (int)((M + BNB_ROWS - 1) / BNB_ROWS); }
+extern "C" int tri_bn_bwd_num_blocks(long M) { return (int)((M + bnb_rows(M) - 1) / bnb_rows(M)); }
 extern "C" int tri_bn_bwd_reduce(const float* y, const float* g, long M, int C, float* partial, void* stream) {
     if (C % 4) { tri_set_error("tri_bn_bwd_reduce: C must be a multiple of 4"); return TRI_ERR_ARG; }
-    int nblk = (int)((M + BNB_ROWS - 1) / BNB_ROWS);
+    int rows = bnb_rows(M);
+    int nblk = (int)((M + rows - 1) / rows);
     int C4 = C / 4, tpr = C4 < 256 ? C4 : 256, rpp = 256 / tpr;
     size_t smem = (size_t)rpp * tpr * 8 * sizeof(float);
-    bn_bwd_reduce_kernel<<<nblk, 256, smem, (hipStream_t)stream>>>(y, g, M, C, partial);
+    bn_bwd_reduce_kernel<<<nblk, 256, smem, (hipStream_t)stream>>>(y, g, M, C, partial, rows);
     return tri_check_launch("tri_bn_bwd_reduce");
 }
 

@@ -13,6 +13,7 @@ import types
 from itertools import combinations
 
 import numpy as np
+import torch
 
 from .. import config as tcfg
 from ..evaluation.eval_retrieval import compute_metrics
@@ -58,6 +59,8 @@ class TriCoLoNet(TriModule):
             self.voxel_encoder = _instantiate(getattr(cfg.model.modules, cfg.model.voxel_encoder))
         self.loss_fn = _instantiate(getattr(cfg.loss, cfg.loss.name))
         self.val_test_step_outputs = []
+        self.overlap_towers = os.environ.get("TRICOLO_OVERLAP", "1") != "0"
+        self.__dict__["_side_streams"] = None
 
     # Lightning supplies .hparams / log_dict / log / print when present; minimal stand-ins otherwise
     def __getattr__(self, name):
@@ -81,11 +84,39 @@ class TriCoLoNet(TriModule):
         return _instantiate(self._cfg.optimizer, params=self.parameters())
 
     def forward(self, data_dict):
-        output_dict = {"text_features": self.text_encoder(data_dict["tokens"], data_dict)}
-        if self.image_encoder is not None:
-            output_dict["image_features"] = self.image_encoder(data_dict["images"].flatten(end_dim=1), data_dict)
+        """Towers are independent until the loss (tricolo_net.py:46-54 runs them serially on one stream).  On a GPU the
+        text and voxel towers - latency-bound, few workgroups - run on side HIP streams next to the ResNet tower; autograd
+        replays each tower's backward on the stream its forward ran on, so the overlap holds both ways and is captured as
+        parallel branches of the HIP graph.  Key order (text, image, voxel) is preserved: it fixes which side gets alpha."""
+        tokens = data_dict["tokens"]
+        overlap = tokens.is_cuda and self.overlap_towers and (self.image_encoder is not None) and torch.is_grad_enabled()
+        if not overlap:
+            output_dict = {"text_features": self.text_encoder(tokens, data_dict)}
+            if self.image_encoder is not None:
+                output_dict["image_features"] = self.image_encoder(data_dict["images"].flatten(end_dim=1), data_dict)
+            if self.voxel_encoder is not None:
+                output_dict["voxel_features"] = self.voxel_encoder(data_dict["voxels"], len(data_dict["model_id"]))
+            return output_dict
+        main = torch.cuda.current_stream()
+        if self._side_streams is None:
+            self._side_streams = (torch.cuda.Stream(), torch.cuda.Stream())
+        s_text, s_vox = self._side_streams
+        s_text.wait_stream(main)
+        with torch.cuda.stream(s_text):
+            text = self.text_encoder(tokens, data_dict)
+        vox = None
         if self.voxel_encoder is not None:
-            output_dict["voxel_features"] = self.voxel_encoder(data_dict["voxels"], len(data_dict["model_id"]))
+            s_vox.wait_stream(main)
+            with torch.cuda.stream(s_vox):
+                vox = self.voxel_encoder(data_dict["voxels"], len(data_dict["model_id"]))
+        img = self.image_encoder(data_dict["images"].flatten(end_dim=1), data_dict)
+        main.wait_stream(s_text)
+        text.record_stream(main)
+        output_dict = {"text_features": text, "image_features": img}
+        if vox is not None:
+            main.wait_stream(s_vox)
+            vox.record_stream(main)
+            output_dict["voxel_features"] = vox
         return output_dict
 
     def _calculate_losses(self, output_dict, loss_prefix):
