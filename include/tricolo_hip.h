@@ -55,8 +55,12 @@ int tri_conv_fwd(const TriConvDesc* d, const float* in, const void* w_hi, const 
 int tri_conv_dgrad(const TriConvDesc* d, const float* dout, const void* wt_hi, const void* wt_lo, float* din,
                    const uint8_t* row_mask, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 size_t tri_conv_wgrad_workspace(const TriConvDesc* d);
-int tri_conv_wgrad(const TriConvDesc* d, const float* in, const float* dout, const uint8_t* row_mask, void* workspace,
-                   size_t workspace_bytes, float* dw, long s_co, long s_tap, long s_ci, int cin_real, int split3, void* stream);
+/* gather plan of a layer geometry (origin offset + tap validity bits per output position): build once, reuse every step */
+size_t tri_conv_plan_bytes(const TriConvDesc* d);
+int tri_conv_plan_build(const TriConvDesc* d, void* plan, void* stream);
+int tri_conv_wgrad(const TriConvDesc* d, const float* in, const float* dout, const uint8_t* row_mask, const void* plan /* required */,
+                   void* workspace, size_t workspace_bytes, float* dw, long s_co, long s_tap, long s_ci, int cin_real, int split3,
+                   void* stream);
 
 /* ---- BatchNorm (train-mode statistics, eps / momentum as torch.nn.BatchNorm1d/2d) ----------------------------------
  * Replaces nn.BatchNorm1d over active voxels (sparse_cnn.py:13,18,23,28,33; count from a device counter) and the 20

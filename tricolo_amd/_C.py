@@ -33,7 +33,9 @@ SIGNATURES = {
     "tri_conv_fwd": (I, [DP, P, P, P, P, P, P, I, I, P, P, Z, P]),
     "tri_conv_dgrad": (I, [DP, P, P, P, P, P, I, P, Z, P]),
     "tri_conv_wgrad_workspace": (Z, [DP]),
-    "tri_conv_wgrad": (I, [DP, P, P, P, P, Z, P, L, L, L, I, I, P]),
+    "tri_conv_plan_bytes": (Z, [DP]),
+    "tri_conv_plan_build": (I, [DP, P, P]),
+    "tri_conv_wgrad": (I, [DP, P, P, P, P, P, Z, P, L, L, L, I, I, P]),
     "tri_bn_finalize": (I, [P, I, I, P, I, P, P, P, P, P, F, F, P, P, P, P, P]),
     "tri_bn_eval_coeffs": (I, [I, P, P, P, P, F, P, P, P, P, P]),
     "tri_bn_act": (I, [P, P, P, P, P, P, P, L, I, I, P]),

@@ -12,6 +12,7 @@
 // Precision modes: NSPLIT=1  bf16 operands;  NSPLIT=2  x = hi + lo split, acc += a_lo*b_hi + a_hi*b_lo + a_hi*b_hi
 // (three bf16 MFMAs, ~2^-17 relative operand error: fp32-grade parity at 3/16 of the f32-MFMA cost).
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/tricolo_hip.h"
 
 struct ConvArgs {
@@ -37,6 +38,20 @@ struct ConvArgs {
 // everything that depends only on the TAP comes from a 64-entry LDS table.  A load is then
 //   voffset = valid ? (rowoff + tapoff + c) * 4 : OUT_OF_RANGE   ->  raw buffer load (hardware returns 0 out of range)
 // i.e. ~5 VALU instructions instead of a full coordinate / bounds / address recomputation per load.
+// taps k in [0,K) with 0 <= x0 + k < I
+__device__ __forceinline__ unsigned axis_mask(int x0, int K, int I) {
+    int lo = max(0, -x0), hi = min(K, I - x0);
+    return hi > lo ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
+}
+// taps k with t = r - k >= 0, t % stride == 0, t / stride < I
+__device__ __forceinline__ unsigned axis_mask_t(int r, int K, int I, int stride) {
+    int hi = min(K, r + 1);                                   // k <= r
+    int lo = max(0, r - (I - 1) * stride);                    // (r - k) / stride <= I - 1
+    unsigned m = hi > lo ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
+    if (stride == 2) m &= (r & 1) ? 0xAAu : 0x55u;            // k must have the parity of r
+    return m;
+}
+
 template <int BN, int NSPLIT>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     constexpr int BM = 128;
@@ -88,19 +103,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
         int od = q2 - b * p.OD;
         if (p.row_mask) valid = valid && (p.row_mask[mm] != 0);
         any_active |= valid ? 1 : 0;
-        unsigned mk = 0;
+        // per-axis validity bits in closed form: the valid taps of an axis form an interval (AND a parity class when
+        // the transposed gather has stride 2), so no per-tap loop is needed
+        unsigned mk;
         int z0, y0, x0;
         if (p.transposed) {
             int rz = od + p.pd, ry = oh + p.ph, rx = ow + p.pw;
             z0 = rz >> sshift; y0 = ry >> sshift; x0 = rx >> sshift;
-            for (int k = 0; k < p.KW; ++k) { int tt = rx - k; if (tt >= 0 && (tt & (p.stride - 1)) == 0 && (tt >> sshift) < p.IW) mk |= 1u << k; }
-            for (int k = 0; k < p.KH; ++k) { int tt = ry - k; if (tt >= 0 && (tt & (p.stride - 1)) == 0 && (tt >> sshift) < p.IH) mk |= 1u << (8 + k); }
-            for (int k = 0; k < p.KD; ++k) { int tt = rz - k; if (tt >= 0 && (tt & (p.stride - 1)) == 0 && (tt >> sshift) < p.ID) mk |= 1u << (16 + k); }
+            mk = axis_mask_t(rx, p.KW, p.IW, p.stride) | (axis_mask_t(ry, p.KH, p.IH, p.stride) << 8) |
+                 (axis_mask_t(rz, p.KD, p.ID, p.stride) << 16);
         } else {
             z0 = od * p.stride - p.pd; y0 = oh * p.stride - p.ph; x0 = ow * p.stride - p.pw;
-            for (int k = 0; k < p.KW; ++k) if ((unsigned)(x0 + k) < (unsigned)p.IW) mk |= 1u << k;
-            for (int k = 0; k < p.KH; ++k) if ((unsigned)(y0 + k) < (unsigned)p.IH) mk |= 1u << (8 + k);
-            for (int k = 0; k < p.KD; ++k) if ((unsigned)(z0 + k) < (unsigned)p.ID) mk |= 1u << (16 + k);
+            mk = axis_mask(x0, p.KW, p.IW) | (axis_mask(y0, p.KH, p.IH) << 8) | (axis_mask(z0, p.KD, p.ID) << 16);
         }
         rmask[i] = valid ? mk : 0u;
         rowoff[i] = ((((int)b * p.ID + z0) * p.IH + y0) * p.IW + x0) * p.Cin;
@@ -250,34 +264,34 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
         return;
     }
 
-    // ---- epilogue: mask / bias / activation / accumulate / per-tile BatchNorm partial sums; 16-byte stores
-    float cs[TN][4], cq[TN][4];
+    // ---- epilogue: mask / bias / activation / accumulate / per-tile BatchNorm partial sums; 16-byte stores.
+    // The conv+BN case (no bias, no activation, no accumulate) takes a branch-free path.
+    const bool plain = (p.bias == nullptr) && (p.act == 0) && (p.accumulate == 0);
+    f32x4 cs[TN], cq[TN];
 #pragma unroll
-    for (int b = 0; b < TN; ++b)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { cs[b][r] = 0.f; cq[b][r] = 0.f; }
+    for (int b = 0; b < TN; ++b) { cs[b] = (f32x4){0.f, 0.f, 0.f, 0.f}; cq[b] = cs[b]; }
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
-        int m = m0 + wm * WM + a * 16 + fr;
+        const int m = m0 + wm * WM + a * 16 + fr;
         if (m < p.M) {
-            bool live = p.row_mask ? (p.row_mask[m] != 0) : true;
+            const float live = (p.row_mask && p.row_mask[m] == 0) ? 0.f : 1.f;
 #pragma unroll
             for (int b = 0; b < TN; ++b) {
-                int n = n0 + wn * WN + b * 16 + fq * 4;
+                const int n = n0 + wn * WN + b * 16 + fq * 4;
                 f32x4 v = acc[a][b];
-                if (p.bias) { f32x4 bv = *(const f32x4*)(p.bias + n); v += bv; }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float x = v[r];
-                    if (p.act == 1) x = fmaxf(x, 0.f);
-                    else if (p.act == 2) x = tanhf(x);
-                    v[r] = live ? x : 0.f;
-                }
                 float* o = p.out + (size_t)m * p.Cout + n;
-                if (p.accumulate) v += *(const f32x4*)o;
+                if (!plain) {
+                    if (p.bias) v += *(const f32x4*)(p.bias + n);
+                    if (p.act == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                    else if (p.act == 2) { v[0] = tanhf(v[0]); v[1] = tanhf(v[1]); v[2] = tanhf(v[2]); v[3] = tanhf(v[3]); }
+                    v *= live;
+                    if (p.accumulate) v += *(const f32x4*)o;
+                } else {
+                    v *= live;
+                }
                 *(f32x4*)o = v;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { cs[b][r] += v[r]; cq[b][r] += v[r] * v[r]; }
+                cs[b] += v;
+                cq[b] += v * v;
             }
         }
     }

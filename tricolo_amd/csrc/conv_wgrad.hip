@@ -10,6 +10,7 @@
 // reproducible, no float atomics) straight into the reference's parameter layout.
 // Submanifold layers pass the output-site mask: 32-position steps with no active site are skipped.
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/tricolo_hip.h"
 
 struct WgradArgs {
@@ -17,6 +18,9 @@ struct WgradArgs {
     const float* dout;
     const uint8_t* row_mask;
     float* slab;                 // [splits][Cout][Kpad]
+    const int* plan_off;         // optional gather plan: element offset of each output position's origin voxel
+    const unsigned* plan_mask;   //                       packed per-axis tap validity bits (8 per axis)
+    unsigned in_bytes;
     int B, ID, IH, IW, Cin;
     int OD, OH, OW, Cout;
     int KD, KH, KW, stride, pd, ph, pw;
@@ -24,15 +28,43 @@ struct WgradArgs {
     FastDiv dOW, dOH, dOD, dCin;
 };
 
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// LDS operand images are NATURAL layout [32 positions][C channels] bf16 (what the global loads deliver: 8-byte writes,
+// consecutive lanes -> consecutive addresses, conflict-free).  The position-major -> channel-major transpose both MFMA
+// operands need is done by the LDS itself: ds_read_b64_tr_b16 hands lane i of each 16-lane group column i of a
+// 4-row x 16-column block (rows = 4 consecutive positions = 4 consecutive k), two reads = one 8-k operand fragment.
+// 32-byte chunk c of row r is stored at chunk c ^ sw(r) so the 8 rows one half-wave touches hit distinct banks.
+template <int ROWB>
+__device__ __forceinline__ int nat_off(int row, int byte) {
+    constexpr int NCH = ROWB / 32;
+    int sw = NCH >= 8 ? ((row & 3) | (((row >> 3) & 1) << 2)) : (((row >> 1) & 1) | (((row >> 3) & 1) << 1));
+    return row * ROWB + ((((byte >> 5) ^ sw) & (NCH - 1)) << 5) + (byte & 31);
+}
+template <int ROWB>
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int col0, int g, int q, int pq) {
+    // rows 8g+q and 8g+4+q, columns col0 + 4*pq .. +3 (bf16)
+    const int byte = (col0 + 4 * pq) * 2;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(tile + nat_off<ROWB>(8 * g + q, byte)));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(tile + nat_off<ROWB>(8 * g + 4 + q, byte)));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, r);
+}
+
 template <int BI, int BJ, int NSPLIT>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
     constexpr int WI = BI / 2, WJ = BJ / 2, TM = WI / 16, TN = WJ / 16;
-    constexpr int X_BYTES = BI * 64, Y_BYTES = BJ * 64;
+    constexpr int XROW = BI * 2, YROW = BJ * 2;                  // bytes per position row
+    constexpr int X_BYTES = 32 * XROW, Y_BYTES = 32 * YROW;
     constexpr int STAGE = NSPLIT * (X_BYTES + Y_BYTES);
-    constexpr int XB = 8 * (BI / 4), YB = 8 * (BJ / 4);          // 4x4 register-transpose units per k-step
-    constexpr int UNITS = (XB + YB + 255) / 256;
+    constexpr int XL = 8 * BI, YL = 8 * BJ;                      // float4 loads per k-step (32 positions x C/4 quads)
+    constexpr int LOADS = (XL + YL) / 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* lut = (int*)(smem + 2 * STAGE);
+    int* lut_off = lut + 64;
+    int* lplan_off = lut + 128;                                  // [steps_per_split * 32] origin offsets of this block's positions
+    unsigned* lplan_mask = (unsigned*)lplan_off + p.steps_per_split * 32;
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int JT = (p.Kpad + BJ - 1) / BJ;
@@ -53,6 +85,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
             kd = r / p.KH;
         }
         lut[t] = kd | (kh << 8) | (kw << 16);
+        lut_off[t] = ((kd * p.IH + kh) * p.IW + kw) * p.Cin;
+    }
+    // the gather plan of this block's position range goes to LDS once: per-load plan reads then cost no VMEM issue
+    {
+        const int n4 = (ks_end - ks_begin) * 8;                 // int4 chunks
+        const int4* so = (const int4*)(p.plan_off + ks_begin * 32);
+        const int4* sm = (const int4*)(p.plan_mask + ks_begin * 32);
+        for (int i = t; i < n4; i += 256) { ((int4*)lplan_off)[i] = so[i]; ((int4*)lplan_mask)[i] = sm[i]; }
     }
     __syncthreads();
 
@@ -63,15 +103,38 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
         for (int b = 0; b < TN; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int wi = wave >> 1, wj = wave & 1;
-    const int fr = lane & 15, fq = lane >> 4;
+    const int fr = lane & 15, fg = lane >> 4, fqq = fr >> 2, fp = fr & 3;
 
-    float4 v[UNITS][4];
+    // per-thread constants of the Y (input) gather: the (tap, channel quad) a thread fetches never changes
+    int y_toff[LOADS], y_sh[LOADS];
+    bool y_tv[LOADS];
+#pragma unroll
+    for (int u = 0; u < LOADS; ++u) {
+        int e = t + u * 256;
+        y_toff[u] = 0; y_sh[u] = 0; y_tv[u] = false;
+        if (e >= XL) {
+            int quad = (e - XL) % (BJ / 4);
+            int j = j0 + quad * 4;
+            int tap, c;
+            if (p.cin_shift >= 0) { tap = j >> p.cin_shift; c = j & ((1 << p.cin_shift) - 1); }
+            else { tap = (int)fdiv((uint32_t)j, p.dCin); c = j - tap * p.Cin; }
+            bool tv = tap < p.ntaps;
+            int code = lut[tv ? tap : 0];
+            int kd = code & 255, kh = (code >> 8) & 255, kw = (code >> 16) & 255;
+            y_tv[u] = tv;
+            y_toff[u] = lut_off[tv ? tap : 0] + c;
+            y_sh[u] = kw | ((8 + kh) << 8) | ((16 + kd) << 16);
+        }
+    }
+
+    float4 v[LOADS];
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
 
     // a 32-position step is live when any of its output sites is active (dense layers: always)
     auto step_live = [&](int ks) -> bool {
         if (!p.row_mask) return true;
         int m = ks * 32;
-        const uint32_t* mp = (const uint32_t*)(p.row_mask + m);          // M is padded to 32 by the caller's mask buffer
+        const uint32_t* mp = (const uint32_t*)(p.row_mask + m);          // mask buffers are padded to 32 bytes
         uint32_t any = 0;
 #pragma unroll
         for (int q = 0; q < 8; ++q) any |= (m + q * 4 < p.M) ? mp[q] : 0u;
@@ -85,80 +148,50 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
     auto load_global = [&](int ks) {
         const int mbase = ks * 32;
 #pragma unroll
-        for (int u = 0; u < UNITS; ++u) {
-            int unit = t + u * 256;
-            if (unit < XB) {
-                int cg = unit % (BI / 4), mg = unit / (BI / 4);
-                int co = i0 + cg * 4;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    int m = mbase + mg * 4 + i;
-                    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (m < p.M && co < p.Cout) x = *(const float4*)(p.dout + (size_t)m * p.Cout + co);
-                    v[u][i] = x;
-                }
-            } else if (unit < XB + YB) {
-                int uy = unit - XB;
-                int jg = uy % (BJ / 4), mg = uy / (BJ / 4);
-                int j = j0 + jg * 4;
-                int tap, c;
-                if (p.cin_shift >= 0) { tap = j >> p.cin_shift; c = j & ((1 << p.cin_shift) - 1); }
-                else { tap = (int)fdiv((uint32_t)j, p.dCin); c = j - tap * p.Cin; }
-                bool tv = tap < p.ntaps;
-                int code = lut[tv ? tap : 0];
-                int kd = code & 255, kh = (code >> 8) & 255, kw = (code >> 16) & 255;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    int m = mbase + mg * 4 + i;
-                    bool ok = tv && m < p.M;
-                    uint32_t mm = ok ? (uint32_t)m : 0u;
-                    uint32_t q1 = fdiv(mm, p.dOW);
-                    int ow = mm - q1 * p.OW;
-                    uint32_t q2 = fdiv(q1, p.dOH);
-                    int oh = q1 - q2 * p.OH;
-                    uint32_t b = fdiv(q2, p.dOD);
-                    int od = q2 - b * p.OD;
-                    int iz = od * p.stride - p.pd + kd, iy = oh * p.stride - p.ph + kh, ix = ow * p.stride - p.pw + kw;
-                    ok = ok && (unsigned)iz < (unsigned)p.ID && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
-                    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (ok) {
-                        size_t off = ((size_t)(((int)b * p.ID + iz) * p.IH + iy) * p.IW + ix) * p.Cin + c;
-                        x = *(const float4*)(p.in + off);
-                    }
-                    v[u][i] = x;
-                }
+        for (int u = 0; u < LOADS; ++u) {
+            int e = t + u * 256;
+            if (e < XL) {
+                int quad = e % (BI / 4), pos = e / (BI / 4);
+                int m = mbase + pos, co = i0 + quad * 4;
+                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (m < p.M && co < p.Cout) x = *(const float4*)(p.dout + (size_t)m * p.Cout + co);
+                v[u] = x;
+            } else {
+                int pos = (e - XL) / (BJ / 4);
+                int m = mbase + pos;
+                int ro = lplan_off[m - ks_begin * 32];
+                unsigned rm = lplan_mask[m - ks_begin * 32];
+                int sh = y_sh[u];
+                bool ok = y_tv[u] && (((rm >> (sh & 255)) & (rm >> ((sh >> 8) & 255)) & (rm >> ((sh >> 16) & 255))) & 1u);
+                unsigned voff = ok ? (unsigned)((ro + y_toff[u]) << 2) : 0x80000000u;
+                v[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
             }
         }
     };
     auto store_lds = [&](int buf) {
-        char* base = smem + buf * STAGE;
+        char* xb = smem + buf * STAGE;
+        char* yb = xb + NSPLIT * X_BYTES;
 #pragma unroll
-        for (int u = 0; u < UNITS; ++u) {
-            int unit = t + u * 256;
-            if (unit >= XB + YB) continue;
-            bool isx = unit < XB;
-            int uu = isx ? unit : unit - XB;
-            int per = isx ? (BI / 4) : (BJ / 4);
-            int cg = uu % per, mg = uu / per;
-            char* tb = isx ? base : base + NSPLIT * X_BYTES;
-            int lo_off = isx ? X_BYTES : Y_BYTES;
-            // register transpose: channel c of the 4 consecutive positions -> one 8-byte LDS write
-            float4 tr[4];
-            tr[0] = make_float4(v[u][0].x, v[u][1].x, v[u][2].x, v[u][3].x);
-            tr[1] = make_float4(v[u][0].y, v[u][1].y, v[u][2].y, v[u][3].y);
-            tr[2] = make_float4(v[u][0].z, v[u][1].z, v[u][2].z, v[u][3].z);
-            tr[3] = make_float4(v[u][0].w, v[u][1].w, v[u][2].w, v[u][3].w);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                int off = tile_off(cg * 4 + c, mg >> 1) + (mg & 1) * 8;
-                if (NSPLIT == 2) {
-                    bf16x4 h, l;
-                    split_bf16(tr[c], h, l);
-                    *(bf16x4*)(tb + off) = h;
-                    *(bf16x4*)(tb + lo_off + off) = l;
-                } else {
-                    *(bf16x4*)(tb + off) = to_bf16x4(tr[c]);
-                }
+        for (int u = 0; u < LOADS; ++u) {
+            int e = t + u * 256;
+            char* dst;
+            int lo_off;
+            if (e < XL) {
+                int quad = e % (BI / 4), pos = e / (BI / 4);
+                dst = xb + nat_off<XROW>(pos, quad * 8);
+                lo_off = X_BYTES;
+            } else {
+                int quad = (e - XL) % (BJ / 4), pos = (e - XL) / (BJ / 4);
+                dst = yb + nat_off<YROW>(pos, quad * 8);
+                lo_off = Y_BYTES;
+            }
+            if (NSPLIT == 2) {
+                bf16x4 h, l;
+                split_bf16(v[u], h, l);
+                *(bf16x4*)dst = h;
+                *(bf16x4*)(dst + lo_off) = l;
+            } else {
+                *(bf16x4*)dst = to_bf16x4(v[u]);
             }
         }
     };
@@ -168,16 +201,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
         bf16x8 ah[TM], al[TM];
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
-            int off = tile_off(wi * WI + a * 16 + fr, fq);
-            ah[a] = *(const bf16x8*)(xb + off);
-            if (NSPLIT == 2) al[a] = *(const bf16x8*)(xb + X_BYTES + off);
+            ah[a] = tr_frag<XROW>(xb, wi * WI + a * 16, fg, fqq, fp);
+            if (NSPLIT == 2) al[a] = tr_frag<XROW>(xb + X_BYTES, wi * WI + a * 16, fg, fqq, fp);
         }
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
-            int off = tile_off(wj * WJ + b * 16 + fr, fq);
-            bf16x8 bhf = *(const bf16x8*)(yb + off);
+            bf16x8 bhf = tr_frag<YROW>(yb, wj * WJ + b * 16, fg, fqq, fp);
             bf16x8 blf;
-            if (NSPLIT == 2) blf = *(const bf16x8*)(yb + Y_BYTES + off);
+            if (NSPLIT == 2) blf = tr_frag<YROW>(yb + Y_BYTES, wj * WJ + b * 16, fg, fqq, fp);
 #pragma unroll
             for (int a = 0; a < TM; ++a) {
                 if (NSPLIT == 2) {
@@ -211,7 +242,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
     for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            int co = i0 + wi * WI + a * 16 + fq * 4 + r;
+            int co = i0 + wi * WI + a * 16 + fg * 4 + r;
             if (co >= p.Cout) continue;
 #pragma unroll
             for (int b = 0; b < TN; ++b) {
@@ -222,72 +253,128 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
 }
 
 // dw[co*s_co + tap*s_tap + ci*s_ci] = sum_split slab[split][co][tap*cin_stored + ci]   (ci < cin_real)
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, int Cout, int Kpad, int ntaps, int cin_stored,
-                                    int cin_real, float* __restrict__ dw, long s_co, long s_tap, long s_ci) {
-    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    long total = (long)Cout * ntaps * cin_stored;
-    if (idx >= total) return;
-    int co = (int)(idx / (ntaps * cin_stored));
-    int k = (int)(idx - (long)co * ntaps * cin_stored);
-    int tap = k / cin_stored, ci = k - tap * cin_stored;
-    if (ci >= cin_real) return;
+// block = (256 / zlanes) consecutive k of one co x zlanes split lanes; lane z sums splits z, z+zlanes, ... and the partials are
+// added in a fixed order (bitwise reproducible).  Layers with hundreds of splits (stem, voxel level 0) no longer serialise.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, int Cout, int Kpad, int ntaps,
+                                                           int cin_stored, int cin_real, float* __restrict__ dw, long s_co, long s_tap,
+                                                           long s_ci, int zlanes) {
+    __shared__ float part[256];
+    const int kper = 256 / zlanes;                               // consecutive k handled per block (zlanes in {1,2,4,8})
+    const int kl = threadIdx.x % kper, zl = threadIdx.x / kper;
+    const int K = ntaps * cin_stored;
+    const int kchunks = (K + kper - 1) / kper;
+    const int co = blockIdx.x / kchunks, k = (blockIdx.x - co * kchunks) * kper + kl;
     float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += slab[((size_t)z * Cout + co) * Kpad + k];
-    dw[co * s_co + tap * s_tap + ci * s_ci] = s;
+    if (k < K)
+        for (int z = zl; z < splits; z += zlanes) s += slab[((size_t)z * Cout + co) * Kpad + k];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (zl == 0 && k < K) {
+        float tot = s;
+        for (int z = 1; z < zlanes; ++z) tot += part[z * kper + kl];
+        int tap = k / cin_stored, ci = k - tap * cin_stored;
+        if (ci < cin_real) dw[co * s_co + tap * s_tap + ci * s_ci] = tot;
+    }
 }
-
 
 static int ilog2_exact(int v) {
     for (int s = 0; s < 31; ++s) if ((1 << s) == v) return s;
     return -1;
 }
 
-static void wgrad_plan(const TriConvDesc* d, int* BI, int* tiles, int* splits, int* steps_per_split, int* Kpad) {
+
+// ---------------------------------------------------------------------------------------------------- gather plan
+// Per output position: element offset of the origin input voxel (o*stride - pad) and per-axis tap validity bits
+// (bit k of byte 0 / 1 / 2 = tap k along W / H / D reads inside the grid).  Depends only on the layer geometry, so it is
+// built once per layer shape and reused by every step's wgrad (and can serve the forward gather as well).
+__global__ void conv_plan_kernel(int M, int Mpad, int ID, int IH, int IW, int Cin, int OD, int OH, int OW, int KD, int KH, int KW,
+                                 int stride, int pd, int ph, int pw, int* __restrict__ plan_off, unsigned* __restrict__ plan_mask) {
+    int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= Mpad) return;
+    if (m >= M) { plan_off[m] = 0; plan_mask[m] = 0u; return; }
+    int ow = m % OW; int r = m / OW;
+    int oh = r % OH; r /= OH;
+    int od = r % OD; int b = r / OD;
+    int z0 = od * stride - pd, y0 = oh * stride - ph, x0 = ow * stride - pw;
+    unsigned mk = 0;
+    for (int k = 0; k < KW; ++k) if ((unsigned)(x0 + k) < (unsigned)IW) mk |= 1u << k;
+    for (int k = 0; k < KH; ++k) if ((unsigned)(y0 + k) < (unsigned)IH) mk |= 1u << (8 + k);
+    for (int k = 0; k < KD; ++k) if ((unsigned)(z0 + k) < (unsigned)ID) mk |= 1u << (16 + k);
+    plan_off[m] = (((b * ID + z0) * IH + y0) * IW + x0) * Cin;
+    plan_mask[m] = mk;
+}
+
+extern "C" size_t tri_conv_plan_bytes(const TriConvDesc* d) {
+    long M = (long)d->B * d->OD * d->OH * d->OW;
+    long Mpad = (M + 31) / 32 * 32;
+    return (size_t)Mpad * 8;
+}
+
+extern "C" int tri_conv_plan_build(const TriConvDesc* d, void* plan, void* stream) {
+    long M = (long)d->B * d->OD * d->OH * d->OW;
+    long Mpad = (M + 31) / 32 * 32;
+    if (d->KD > 8 || d->KH > 8 || d->KW > 8) { tri_set_error("conv plan: kernel extent > 8 unsupported"); return TRI_ERR_UNSUPPORTED; }
+    conv_plan_kernel<<<(int)((Mpad + 255) / 256), 256, 0, (hipStream_t)stream>>>((int)M, (int)Mpad, d->ID, d->IH, d->IW, d->Cin, d->OD,
+                                                                                 d->OH, d->OW, d->KD, d->KH, d->KW, d->stride, d->pad_d,
+                                                                                 d->pad_h, d->pad_w, (int*)plan, (unsigned*)plan + Mpad);
+    return tri_check_launch("tri_conv_plan_build");
+}
+
+#ifndef WGRAD_TARGET_BLOCKS
+#define WGRAD_TARGET_BLOCKS 768
+#endif
+// tile shapes: 128x128 for wide layers; 64-row tiles take the whole K in one 256-column tile when it fits (the dOut
+// operand is then read once, not once per j-tile: stem 7x7, voxel level 0, 1x1 down-samples), else 128 columns.
+static void wgrad_plan(const TriConvDesc* d, int* BI, int* BJ_out, int* tiles, int* splits, int* steps_per_split, int* Kpad) {
     int ntaps = d->KD * d->KH * d->KW;
     *Kpad = (ntaps * d->Cin + 31) / 32 * 32;
     *BI = (d->Cout % 128 == 0 && *Kpad >= 128) ? 128 : 64;
-    int BJ = *BI;
+    int BJ = *BI == 128 ? 128 : (*Kpad <= 256 ? 256 : 128);
+    *BJ_out = BJ;
     int it = (d->Cout + *BI - 1) / *BI, jt = (*Kpad + BJ - 1) / BJ;
     *tiles = it * jt;
     long M = (long)d->B * d->OD * d->OH * d->OW;
     int steps = (int)((M + 31) / 32);
-    int want = (768 + *tiles - 1) / *tiles;                     // aim at ~768 workgroups (3 per CU): slab traffic grows with splits
+    int want = (WGRAD_TARGET_BLOCKS + *tiles - 1) / *tiles;     // workgroups to aim for: the k-loop is latency-bound, so occupancy matters
     int max_by_steps = steps / 4 > 0 ? steps / 4 : 1;           // at least 4 k-steps per split
     int s = want < max_by_steps ? want : max_by_steps;
     if (s < 1) s = 1;
     if (s > 256) s = 256;
     *steps_per_split = (steps + s - 1) / s;
+    if (*steps_per_split > 96) *steps_per_split = 96;          // the block's gather plan (256 B / step) must fit in LDS
     *splits = (steps + *steps_per_split - 1) / *steps_per_split;
 }
 
 extern "C" size_t tri_conv_wgrad_workspace(const TriConvDesc* d) {
-    int BI, tiles, splits, sps, Kpad;
-    wgrad_plan(d, &BI, &tiles, &splits, &sps, &Kpad);
+    int BI, BJ, tiles, splits, sps, Kpad;
+    wgrad_plan(d, &BI, &BJ, &tiles, &splits, &sps, &Kpad);
     return (size_t)splits * d->Cout * Kpad * sizeof(float);
 }
 
-template <int BI, int NSPLIT>
+#define WGRAD_MAX_STEPS 96
+template <int BI, int BJ, int NSPLIT>
 static int launch_wgrad(const WgradArgs& a, int tiles, int splits, hipStream_t stream) {
-    constexpr int STAGE = NSPLIT * (BI * 64 + BI * 64);
-    size_t smem = 2 * STAGE + 256;
+    constexpr int STAGE = NSPLIT * (32 * BI * 2 + 32 * BJ * 2);
+    size_t smem = 2 * STAGE + 512 + (size_t)a.steps_per_split * 256;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)conv_wgrad_kernel<BI, BI, NSPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipFuncSetAttribute((const void*)conv_wgrad_kernel<BI, BJ, NSPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            2 * STAGE + 512 + WGRAD_MAX_STEPS * 256);
         attr_set = true;
     }
-    conv_wgrad_kernel<BI, BI, NSPLIT><<<dim3(tiles, splits), 256, smem, stream>>>(a);
+    conv_wgrad_kernel<BI, BJ, NSPLIT><<<dim3(tiles, splits), 256, smem, stream>>>(a);
     return tri_check_launch("tri_conv_wgrad");
 }
 
 // dw (addressed by element strides s_co / s_tap / s_ci, i.e. directly in the reference's parameter layout)
 //   = sum over positions of dout x im2col(in).  row_mask (optional, per output position, buffer padded to a
 // multiple of 32 bytes) marks live positions; split3 != 0 selects the 3-product bf16 split mode.
-extern "C" int tri_conv_wgrad(const TriConvDesc* d, const float* in, const float* dout, const uint8_t* row_mask, void* workspace,
-                              size_t workspace_bytes, float* dw, long s_co, long s_tap, long s_ci, int cin_real, int split3,
-                              void* stream) {
+extern "C" int tri_conv_wgrad(const TriConvDesc* d, const float* in, const float* dout, const uint8_t* row_mask, const void* plan,
+                              void* workspace, size_t workspace_bytes, float* dw, long s_co, long s_tap, long s_ci, int cin_real,
+                              int split3, void* stream) {
     if (d->Cin % 4 != 0 || d->Cout % 4 != 0) { tri_set_error("wgrad: channels must be multiples of 4"); return TRI_ERR_ARG; }
-    int BI, tiles, splits, sps, Kpad;
-    wgrad_plan(d, &BI, &tiles, &splits, &sps, &Kpad);
+    int BI, BJ, tiles, splits, sps, Kpad;
+    wgrad_plan(d, &BI, &BJ, &tiles, &splits, &sps, &Kpad);
     if (workspace_bytes < (size_t)splits * d->Cout * Kpad * sizeof(float)) { tri_set_error("wgrad: workspace too small"); return TRI_ERR_ARG; }
     WgradArgs a{};
     a.in = in; a.dout = dout; a.row_mask = row_mask; a.slab = (float*)workspace;
@@ -300,14 +387,26 @@ extern "C" int tri_conv_wgrad(const TriConvDesc* d, const float* in, const float
     a.M = d->B * d->OD * d->OH * d->OW;
     a.cin_shift = ilog2_exact(a.Cin);
     a.steps_per_split = sps;
+    size_t in_bytes = (size_t)a.B * a.ID * a.IH * a.IW * a.Cin * sizeof(float);
+    if (!plan) { tri_set_error("wgrad: a gather plan from tri_conv_plan_build is required"); return TRI_ERR_ARG; }
+    if (in_bytes >= ((size_t)1 << 31)) { tri_set_error("wgrad: input tensor >= 2 GiB (32-bit buffer offsets)"); return TRI_ERR_UNSUPPORTED; }
+    {
+        long Mpad = ((long)a.M + 31) / 32 * 32;
+        a.plan_off = (const int*)plan;
+        a.plan_mask = (const unsigned*)plan + Mpad;
+        a.in_bytes = (unsigned)in_bytes;
+    }
     a.dOW = make_fastdiv(a.OW); a.dOH = make_fastdiv(a.OH); a.dOD = make_fastdiv(a.OD); a.dCin = make_fastdiv(a.Cin);
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    if (BI == 128) rc = split3 ? launch_wgrad<128, 2>(a, tiles, splits, s) : launch_wgrad<128, 1>(a, tiles, splits, s);
-    else rc = split3 ? launch_wgrad<64, 2>(a, tiles, splits, s) : launch_wgrad<64, 1>(a, tiles, splits, s);
+    if (BI == 128) rc = split3 ? launch_wgrad<128, 128, 2>(a, tiles, splits, s) : launch_wgrad<128, 128, 1>(a, tiles, splits, s);
+    else if (BJ == 256) rc = split3 ? launch_wgrad<64, 256, 2>(a, tiles, splits, s) : launch_wgrad<64, 256, 1>(a, tiles, splits, s);
+    else rc = split3 ? launch_wgrad<64, 128, 2>(a, tiles, splits, s) : launch_wgrad<64, 128, 1>(a, tiles, splits, s);
     if (rc) return rc;
-    long total = (long)d->Cout * a.ntaps * d->Cin;
-    wgrad_reduce_kernel<<<(int)((total + 255) / 256), 256, 0, s>>>((const float*)workspace, splits, d->Cout, Kpad, a.ntaps, d->Cin,
-                                                                    cin_real, dw, s_co, s_tap, s_ci);
+    int zlanes = splits >= 8 ? 8 : (splits >= 4 ? 4 : (splits >= 2 ? 2 : 1));
+    int kper = 256 / zlanes;
+    int kchunks = (a.ntaps * d->Cin + kper - 1) / kper;
+    wgrad_reduce_kernel<<<d->Cout * kchunks, 256, 0, s>>>((const float*)workspace, splits, d->Cout, Kpad, a.ntaps, d->Cin, cin_real, dw,
+                                                           s_co, s_tap, s_ci, zlanes);
     return tri_check_launch("tri_wgrad_reduce");
 }

@@ -2,6 +2,8 @@
 kernel, and helpers for the hand-written backward passes."""
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -111,3 +113,36 @@ class L2NormFn(torch.autograd.Function):
     def backward(ctx, dz):
         z, norm = ctx.saved_tensors
         return ops.l2norm_bwd(z, norm, dz)
+
+
+class SideStream:
+    """Weight-gradient side stream of a tower.  wgrad(layer) and dgrad(layer) both consume the same dy and are
+    independent, and each leaves most CUs idle (latency-bound k-loops, few workgroups), so the tower's wgrad launches
+    run on a second HIP stream next to the dgrad / BatchNorm-backward chain and are joined at the end of the backward.
+    The fork/join is captured into the HIP graph as parallel branches."""
+
+    def __init__(self, tag=""):
+        self.stream = None
+        self.enabled = tag not in os.environ.get("TRICOLO_NO_SIDE", "").split(",")
+
+    def fork(self, *tensors):
+        """Make the side stream wait for everything issued so far on the current stream; returns the side stream."""
+        if not self.enabled:
+            return torch.cuda.current_stream()
+        if self.stream is None:
+            self.stream = torch.cuda.Stream()
+        self.stream.wait_stream(torch.cuda.current_stream())
+        if not torch.cuda.is_current_stream_capturing():   # (under capture the graph's private pool defers every free)
+            for t in tensors:
+                if t is not None:
+                    t.record_stream(self.stream)      # allocator: do not recycle these while the side stream reads them
+        return self.stream
+
+    def join(self, *tensors):
+        if self.stream is not None:
+            cur = torch.cuda.current_stream()
+            cur.wait_stream(self.stream)
+            if not torch.cuda.is_current_stream_capturing():
+                for t in tensors:
+                    if t is not None:
+                        t.record_stream(cur)

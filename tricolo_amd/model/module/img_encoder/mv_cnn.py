@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from .... import ops
-from ....layers import TriModule, linear_bwd, linear_fwd, require_gpu
+from ....layers import SideStream, TriModule, linear_bwd, linear_fwd, require_gpu
 
 
 class _BasicBlockParams(nn.Module):
@@ -60,6 +60,7 @@ class MVCNNEncoder(TriModule):
         self.net_2 = nn.Linear(512, z_dim)
         self.mlp = nn.Sequential(nn.Linear(z_dim, out_dim), nn.ReLU(inplace=True), nn.Linear(out_dim, out_dim))
         self._geoms = {}
+        self.__dict__["_side"] = SideStream("img")
 
     def _prec(self):
         return self.precision or ops.default_precision()
@@ -143,19 +144,26 @@ class MVCNNEncoder(TriModule):
         dp, gr[self.net_2.weight], gr[self.net_2.bias] = linear_bwd(saved["pooled"], self.net_2.weight, saved["f"], df, 0, prec)
         dout = ops.avgpool_viewmax_bwd(dp, saved["arg"], saved["feat_shape"], B, self.num_views)
         blocks = self._blocks()
+        side = self._side
+
+        def wgrad_async(x, dy, g, w):
+            """dW on the side stream (needs only x and dy, both final at this point)."""
+            with torch.cuda.stream(side.fork(x, dy)):
+                gr[w] = ops.conv_wgrad(x, dy, g, w, prec)
+
         for blk, sv in zip(reversed(blocks), reversed(saved["blocks"])):
             x, y1, co1, g1, a1, y2, co2, g2, yd, cod, gd, out = sv
             g = ops.relu_bwd(dout, out)                                       # grad of the block's pre-activation sum
             dy2, gr[blk.bn2.weight], gr[blk.bn2.bias] = ops.bn_bwd(y2, g, co2, blk.bn2.weight, count_host=g2.M, inplace=False)
-            gr[blk.conv2.weight] = ops.conv_wgrad(a1, dy2, g2, blk.conv2.weight, prec)
+            wgrad_async(a1, dy2, g2, blk.conv2.weight)
             da1 = ops.conv_dgrad(dy2, g2, ops.pack_weight(blk.conv2.weight, g2, prec, transposed=True))
             g1z = ops.relu_bwd(da1, a1)
             dy1, gr[blk.bn1.weight], gr[blk.bn1.bias] = ops.bn_bwd(y1, g1z, co1, blk.bn1.weight, count_host=g1.M)
-            gr[blk.conv1.weight] = ops.conv_wgrad(x, dy1, g1, blk.conv1.weight, prec)
+            wgrad_async(x, dy1, g1, blk.conv1.weight)
             if blk.downsample is not None:
                 dyd, gr[blk.downsample[1].weight], gr[blk.downsample[1].bias] = ops.bn_bwd(
                     yd, g, cod, blk.downsample[1].weight, count_host=gd.M)
-                gr[blk.downsample[0].weight] = ops.conv_wgrad(x, dyd, gd, blk.downsample[0].weight, prec)
+                wgrad_async(x, dyd, gd, blk.downsample[0].weight)
                 dx = ops.conv_dgrad(dyd, gd, ops.pack_weight(blk.downsample[0].weight, gd, prec, transposed=True))
             else:
                 dx = g                                                         # identity branch
@@ -165,7 +173,8 @@ class MVCNNEncoder(TriModule):
         dzs = ops.maxpool2d_bwd(parg, dout, tuple(z.shape))
         gz = ops.relu_bwd(dzs, z)
         dy, gr[self.net_1[1].weight], gr[self.net_1[1].bias] = ops.bn_bwd(y, gz, co, self.net_1[1].weight, count_host=g0.M)
-        gr[self.net_1[0].weight] = ops.conv_wgrad(x0, dy, g0, self.net_1[0].weight, prec)
+        wgrad_async(x0, dy, g0, self.net_1[0].weight)
+        side.join(*[gr[p] for p in self._param_list() if p.dim() == 4])
         return [gr[p] for p in self._param_list()]
 
     def forward(self, x, data_dict=None):

@@ -95,8 +95,18 @@ class ConvGeom:
         self.M_in = B * ID * IH * IW
         self.num_mtiles = lib().tri_conv_num_mtiles(_C.C.byref(self.desc))
         self.wgrad_ws = lib().tri_conv_wgrad_workspace(_C.C.byref(self.desc))
+        self._plans = {}
         self.fwd_ws = lib().tri_conv_workspace(_C.C.byref(self.desc), 0)
         self.dgrad_ws = lib().tri_conv_workspace(_C.C.byref(self.desc), 1) if cin == cin_stored and cin % 32 == 0 else 0
+
+    def plan(self, device):
+        """Gather plan (built once per geometry and device, reused by every step's wgrad)."""
+        pl = self._plans.get(device)
+        if pl is None:
+            pl = torch.empty((lib().tri_conv_plan_bytes(_C.C.byref(self.desc)),), dtype=torch.uint8, device=device)
+            check(lib().tri_conv_plan_build(_C.C.byref(self.desc), ptr(pl), stream()), "tri_conv_plan_build")
+            self._plans[device] = pl
+        return pl
 
     @property
     def flops(self):
@@ -162,12 +172,15 @@ def conv_wgrad(x, dout, g: ConvGeom, like: torch.Tensor, precision: str, row_mas
     """Gradient of the layer's parameter, returned in the parameter's own layout (shape of ``like``)."""
     dw = torch.empty_like(like)
     ws = _workspace(g.wgrad_ws, x.device)
+    plan = g.plan(x.device)
     s_co, s_tap, s_ci = g.strides
     bi = 128 if (g.cout % 128 == 0 and g.kpad >= 128) else 64
-    sym = f"conv_wgrad_kernel<{bi},{bi},{2 if precision == 'bf16x3' else 1}>"
+    bj = 128 if bi == 128 else (256 if g.kpad <= 256 else 128)
+    sym = f"conv_wgrad_kernel<{bi},{bj},{2 if precision == 'bf16x3' else 1}>"
     check(_timed(sym, g.flops,
-                 lambda: lib().tri_conv_wgrad(_C.C.byref(g.desc), ptr(_f32(x)), ptr(_f32(dout)), ptr(row_mask), ptr(ws), ws.numel(),
-                                              ptr(dw), s_co, s_tap, s_ci, g.cin, 1 if precision == "bf16x3" else 0, stream())),
+                 lambda: lib().tri_conv_wgrad(_C.C.byref(g.desc), ptr(_f32(x)), ptr(_f32(dout)), ptr(row_mask), ptr(plan), ptr(ws),
+                                              ws.numel(), ptr(dw), s_co, s_tap, s_ci, g.cin, 1 if precision == "bf16x3" else 0,
+                                              stream())),
           "tri_conv_wgrad")
     return dw
 
