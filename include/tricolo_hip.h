@@ -47,7 +47,7 @@ int tri_weight_prep(const float* w, long s_row, long s_tap, long s_inner, int ro
  * stats (optional) receives [tri_conv_num_mtiles][2][Cout] per-tile column sums / sums of squares for BatchNorm.
  * tri_conv_dgrad / tri_conv_wgrad replace the autograd backward of the same call sites; `d` is always the FORWARD
  * descriptor.  wgrad writes dw through element strides, i.e. directly in the reference's parameter layout. */
-int tri_conv_num_mtiles(const TriConvDesc* d);
+int tri_conv_num_mtiles(const TriConvDesc* d, int split3);
 /* split-K scratch a small-M layer needs (0 = none): pass at least this many bytes to tri_conv_fwd / tri_conv_dgrad */
 size_t tri_conv_workspace(const TriConvDesc* d, int transposed);
 int tri_conv_fwd(const TriConvDesc* d, const float* in, const void* w_hi, const void* w_lo, float* out, const uint8_t* row_mask,

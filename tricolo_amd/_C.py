@@ -28,7 +28,7 @@ SIGNATURES = {
     "tri_last_error": (C.c_char_p, []),
     "tri_conv_kpad": (I, [I, I]),
     "tri_weight_prep": (I, [P, L, L, L, I, I, I, I, P, P, P]),
-    "tri_conv_num_mtiles": (I, [DP]),
+    "tri_conv_num_mtiles": (I, [DP, I]),
     "tri_conv_workspace": (Z, [DP, I]),
     "tri_conv_fwd": (I, [DP, P, P, P, P, P, P, I, I, P, P, Z, P]),
     "tri_conv_dgrad": (I, [DP, P, P, P, P, P, I, P, Z, P]),

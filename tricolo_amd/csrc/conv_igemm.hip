@@ -30,8 +30,86 @@ struct ConvArgs {
     int transposed, act, accumulate;
     int Kpad, M, ntaps, cin_shift, ksplit, steps_per_split;
     unsigned in_bytes;
+    int R, brick_rows, nunits, units_per_split;      // brick kernel: halo reach (positions), LDS rows, (chunk, tap) units
     FastDiv dOW, dOH, dOD, dCin;
 };
+
+// Shared epilogue: acc[a][b][r] = out[m = a-tile row (lane & 15)][n = b-tile col 4 * (lane >> 4) + r].
+template <int BN, int TM, int TN, int WAVES_M, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[TM][TN], int m0, int n0, int mtile, int wm, int wn, int fr,
+                                              int fq, int t, int split, int any_active, float* red) {
+    if (p.ksplit > 1) {
+        // split-K: raw partial sums only; conv_splitk_finish_kernel applies mask / bias / activation / statistics
+        if (!any_active) return;
+        float* slab = p.slab + (size_t)split * p.M * p.Cout;
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            int m = m0 + wm * WM + a * 16 + fr;
+            if (m < p.M)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    int n = n0 + wn * WN + b * 16 + fq * 4;
+                    *(f32x4*)(slab + (size_t)m * p.Cout + n) = acc[a][b];
+                }
+        }
+        return;
+    }
+
+    // ---- epilogue: mask / bias / activation / accumulate / per-tile BatchNorm partial sums; 16-byte stores.
+    // The conv+BN case (no bias, no activation, no accumulate) takes a branch-free path.
+    const bool plain = (p.bias == nullptr) && (p.act == 0) && (p.accumulate == 0);
+    f32x4 cs[TN], cq[TN];
+#pragma unroll
+    for (int b = 0; b < TN; ++b) { cs[b] = (f32x4){0.f, 0.f, 0.f, 0.f}; cq[b] = cs[b]; }
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+        const int m = m0 + wm * WM + a * 16 + fr;
+        if (m < p.M) {
+            const float live = (p.row_mask && p.row_mask[m] == 0) ? 0.f : 1.f;
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const int n = n0 + wn * WN + b * 16 + fq * 4;
+                f32x4 v = acc[a][b];
+                float* o = p.out + (size_t)m * p.Cout + n;
+                if (!plain) {
+                    if (p.bias) v += *(const f32x4*)(p.bias + n);
+                    if (p.act == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                    else if (p.act == 2) { v[0] = tanhf(v[0]); v[1] = tanhf(v[1]); v[2] = tanhf(v[2]); v[3] = tanhf(v[3]); }
+                    v *= live;
+                    if (p.accumulate) v += *(const f32x4*)o;
+                } else {
+                    v *= live;
+                }
+                *(f32x4*)o = v;
+                cs[b] += v;
+                cq[b] += v * v;
+            }
+        }
+    }
+    if (p.stats) {
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s = cs[b][r], q = cq[b][r];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+                if (fr == 0) {
+                    int col = wn * WN + b * 16 + fq * 4 + r;
+                    red[(wm * BN + col) * 2 + 0] = s;
+                    red[(wm * BN + col) * 2 + 1] = q;
+                }
+            }
+        __syncthreads();
+        if (t < BN) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES_M; ++w) { s += red[(w * BN + t) * 2]; q += red[(w * BN + t) * 2 + 1]; }
+            p.stats[((size_t)mtile * 2 + 0) * p.Cout + n0 + t] = s;
+            p.stats[((size_t)mtile * 2 + 1) * p.Cout + n0 + t] = q;
+        }
+    }
+}
 
 // im2col gather, per thread: 4 rows x one float4 of k per k-step.  Everything that depends only on the ROW is
 // computed once (element offset of the row's origin voxel + a packed per-axis validity mask, 8 bits per axis);
@@ -247,77 +325,231 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
         }
     }
 
-    if (p.ksplit > 1) {
-        // split-K: raw partial sums only; conv_splitk_finish_kernel applies mask / bias / activation / statistics
-        if (!any_active) return;
-        float* slab = p.slab + (size_t)split * p.M * p.Cout;
-#pragma unroll
-        for (int a = 0; a < TM; ++a) {
-            int m = m0 + wm * WM + a * 16 + fr;
-            if (m < p.M)
-#pragma unroll
-                for (int b = 0; b < TN; ++b) {
-                    int n = n0 + wn * WN + b * 16 + fq * 4;
-                    *(f32x4*)(slab + (size_t)m * p.Cout + n) = acc[a][b];
-                }
+    conv_epilogue<BN, TM, TN, WAVES_M, WM, WN>(p, acc, m0, n0, mtile, wm, wn, fr, fq, t, split, any_active, red);
+}
+
+// ================================================================================================ brick kernel
+// Stride-1 "same" convolutions (3x3, 3x3x3 and their data gradients): the generic kernel above re-gathers the input
+// once per tap (9x / 27x), and the per-workgroup footprint overflows the 32 KiB L1, so those layers run at the L2
+// bandwidth limit (~15 TB/s measured) instead of the MFMA rate.  Here a workgroup reads the input it needs ONCE:
+// the 128 output positions of a tile are consecutive in memory, so every tap reads the same linear range shifted by a
+// constant delta(tap); the range [m0 - R, m0 + 128 + R) x CB channels is staged in LDS as bf16 (the "brick", coalesced
+// whole-row loads, all of a thread's loads in flight together), and the A fragment of tap t is a plain ds_read_b128
+// at row (m - m0 + R + delta(t)).  Image borders (and the wrap of the linear range across rows / planes / samples) are
+// handled by redirecting invalid (row, tap) pairs to a zero row using the same per-axis validity bits.  Only the
+// BN x CB weight slice of each (channel chunk, tap) unit is fetched inside the loop (double-buffered, one barrier).
+template <int CB>
+__device__ __forceinline__ int brick_off(int row, int chunk) {                 // byte offset of 16-byte chunk `chunk` of row `row`
+    if (CB == 64) return row * 128 + (((chunk ^ (row >> 1)) & 7) << 4);        // 128-B rows: 8 chunks, XOR with (row / 2) % 8
+    return tile_off(row, chunk);                                                // 64-B rows: same image as the GEMM tiles
+}
+
+template <int BN, int CB, int NSPLIT>
+__global__ __launch_bounds__(256) void conv_brick_kernel(const ConvArgs p) {
+    constexpr int BM = 128;
+    constexpr int WAVES_N = (BN >= 64) ? 2 : 1, WAVES_M = 4 / WAVES_N;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 16, TN = WN / 16;
+    constexpr int ROWB = CB * 2, KK = CB / 32;
+    constexpr int W_BYTES = BN * ROWB;                           // one weight slice (hi)
+    constexpr int WLOADS = (BN * CB * 2 / 16 + 255) / 256;      // 16-byte weight loads per thread per unit
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int brick_bytes = (p.brick_rows + 1) * ROWB;          // + the zero row
+    char* brick = smem;                                          // [NSPLIT][brick_rows + 1][CB]
+    char* wbuf = smem + NSPLIT * brick_bytes;                    // [2][NSPLIT][BN][CB]
+    int* lut_delta = (int*)(wbuf + 2 * NSPLIT * W_BYTES);
+    int* lut_sh = lut_delta + 32;
+    float* red = (float*)(lut_sh + 32);
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int NT = p.Cout / BN;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int mtile = wg / NT, ntile = wg - mtile * NT;
+    const int m0 = mtile * BM, n0 = ntile * BN;
+    const int split = blockIdx.y;
+    const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    if (t < 32) {
+        int kd = 0, kh = 0, kw = 0;
+        if (t < p.ntaps) {
+            kw = t % p.KW;
+            int r = t / p.KW;
+            kh = r % p.KH;
+            kd = r / p.KH;
         }
-        return;
+        lut_sh[t] = kw | ((8 + kh) << 8) | ((16 + kd) << 16);
+        int d = ((kd - p.pd) * p.IH + (kh - p.ph)) * p.IW + (kw - p.pw);
+        lut_delta[t] = p.transposed ? -d : d;
+    }
+    // zero row (index brick_rows) of every plane
+    if (t < ROWB / 8) {
+        *(uint2*)(brick + p.brick_rows * ROWB + t * 8) = make_uint2(0, 0);
+        if (NSPLIT == 2) *(uint2*)(brick + brick_bytes + p.brick_rows * ROWB + t * 8) = make_uint2(0, 0);
     }
 
-    // ---- epilogue: mask / bias / activation / accumulate / per-tile BatchNorm partial sums; 16-byte stores.
-    // The conv+BN case (no bias, no activation, no accumulate) takes a branch-free path.
-    const bool plain = (p.bias == nullptr) && (p.act == 0) && (p.accumulate == 0);
-    f32x4 cs[TN], cq[TN];
-#pragma unroll
-    for (int b = 0; b < TN; ++b) { cs[b] = (f32x4){0.f, 0.f, 0.f, 0.f}; cq[b] = cs[b]; }
+    // per-lane fragment rows: brick row of the centre tap and the per-axis validity bits
+    int arow[TM];
+    unsigned amask[TM];
+    int any_active = 0;
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
-        const int m = m0 + wm * WM + a * 16 + fr;
-        if (m < p.M) {
-            const float live = (p.row_mask && p.row_mask[m] == 0) ? 0.f : 1.f;
+        int ml = wm * WM + a * 16 + fr;
+        int m = m0 + ml;
+        bool valid = m < p.M;
+        uint32_t mm = valid ? (uint32_t)m : 0u;
+        uint32_t q1 = fdiv(mm, p.dOW);
+        int ow = mm - q1 * p.OW;
+        uint32_t q2 = fdiv(q1, p.dOH);
+        int oh = q1 - q2 * p.OH;
+        uint32_t b = fdiv(q2, p.dOD);
+        int od = q2 - b * p.OD;
+        if (p.row_mask) valid = valid && (p.row_mask[mm] != 0);
+        any_active |= valid ? 1 : 0;
+        unsigned mk;
+        if (p.transposed)
+            mk = axis_mask_t(ow + p.pw, p.KW, p.IW, 1) | (axis_mask_t(oh + p.ph, p.KH, p.IH, 1) << 8) |
+                 (axis_mask_t(od + p.pd, p.KD, p.ID, 1) << 16);
+        else
+            mk = axis_mask(ow - p.pw, p.KW, p.IW) | (axis_mask(oh - p.ph, p.KH, p.IH) << 8) | (axis_mask(od - p.pd, p.KD, p.ID) << 16);
+        amask[a] = valid ? mk : 0u;
+        arow[a] = ml + p.R;
+    }
+    any_active = __syncthreads_or(any_active);       // also publishes the tap tables and the zero row
+
+    f32x4 acc[TM][TN];
 #pragma unroll
-            for (int b = 0; b < TN; ++b) {
-                const int n = n0 + wn * WN + b * 16 + fq * 4;
-                f32x4 v = acc[a][b];
-                float* o = p.out + (size_t)m * p.Cout + n;
-                if (!plain) {
-                    if (p.bias) v += *(const f32x4*)(p.bias + n);
-                    if (p.act == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-                    else if (p.act == 2) { v[0] = tanhf(v[0]); v[1] = tanhf(v[1]); v[2] = tanhf(v[2]); v[3] = tanhf(v[3]); }
-                    v *= live;
-                    if (p.accumulate) v += *(const f32x4*)o;
-                } else {
-                    v *= live;
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (any_active) {
+        const int u0 = split * p.units_per_split;
+        const int u1 = min(p.nunits, u0 + p.units_per_split);
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+        const long mtot = (long)p.B * p.ID * p.IH * p.IW;
+        uint4 wh[WLOADS], wl[WLOADS];
+
+        auto load_brick = [&](int cb) {
+            // rows x (CB / 4) float4, row-major: consecutive lanes -> consecutive 16 bytes; 8 loads in flight per batch
+            const int total = p.brick_rows * (CB / 4);
+            for (int base = 0; base < total; base += 256 * 8) {
+                uint4 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    int idx = base + j * 256 + t;
+                    int r = idx / (CB / 4), q = idx - r * (CB / 4);
+                    long pos = (long)m0 - p.R + r;
+                    bool ok = idx < total && pos >= 0 && pos < mtot;
+                    unsigned voff = ok ? (unsigned)(((int)pos * p.Cin + cb * CB + q * 4) << 2) : 0x80000000u;
+                    v[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
                 }
-                *(f32x4*)o = v;
-                cs[b] += v;
-                cq[b] += v * v;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    int idx = base + j * 256 + t;
+                    if (idx < total) {
+                        int r = idx / (CB / 4), q = idx - r * (CB / 4);
+                        int off = brick_off<CB>(r, q >> 1) + (q & 1) * 8;
+                        float4 f = __builtin_bit_cast(float4, v[j]);
+                        if (NSPLIT == 2) {
+                            bf16x4 h, l;
+                            split_bf16(f, h, l);
+                            *(bf16x4*)(brick + off) = h;
+                            *(bf16x4*)(brick + brick_bytes + off) = l;
+                        } else {
+                            *(bf16x4*)(brick + off) = to_bf16x4(f);
+                        }
+                    }
+                }
+            }
+        };
+        auto load_w = [&](int u) {
+            int cb = u / p.ntaps, tap = u - cb * p.ntaps;
+#pragma unroll
+            for (int j = 0; j < WLOADS; ++j) {
+                int idx = t + j * 256;
+                if (BN * CB / 8 >= 256 * (j + 1) || idx < BN * CB / 8) {
+                    int n = idx / (CB / 8), ch = idx - n * (CB / 8);
+                    size_t off = (size_t)(n0 + n) * p.Kpad + tap * p.Cin + cb * CB + ch * 8;
+                    wh[j] = *(const uint4*)(p.w_hi + off);
+                    if (NSPLIT == 2) wl[j] = *(const uint4*)(p.w_lo + off);
+                }
+            }
+        };
+        auto store_w = [&](int buf) {
+            char* wb = wbuf + buf * NSPLIT * W_BYTES;
+#pragma unroll
+            for (int j = 0; j < WLOADS; ++j) {
+                int idx = t + j * 256;
+                if (BN * CB / 8 >= 256 * (j + 1) || idx < BN * CB / 8) {
+                    int n = idx / (CB / 8), ch = idx - n * (CB / 8);
+                    int off = brick_off<CB>(n, ch);
+                    *(uint4*)(wb + off) = wh[j];
+                    if (NSPLIT == 2) *(uint4*)(wb + W_BYTES + off) = wl[j];
+                }
+            }
+        };
+        auto compute = [&](int u, int buf) {
+            const int cb = u / p.ntaps, tap = u - cb * p.ntaps;
+            const int delta = lut_delta[tap], sh = lut_sh[tap];
+            const int sx = sh & 255, sy = (sh >> 8) & 255, sz = (sh >> 16) & 255;
+            const char* wb = wbuf + buf * NSPLIT * W_BYTES;
+            int rows[TM];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                unsigned mk = amask[a];
+                bool ok = ((mk >> sx) & (mk >> sy) & (mk >> sz)) & 1u;
+                rows[a] = ok ? arow[a] + delta : p.brick_rows;          // invalid (row, tap) -> zero row
+            }
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                bf16x8 ah[TM], al[TM];
+#pragma unroll
+                for (int a = 0; a < TM; ++a) {
+                    int off = brick_off<CB>(rows[a], kk * 4 + fq);
+                    ah[a] = *(const bf16x8*)(brick + off);
+                    if (NSPLIT == 2) al[a] = *(const bf16x8*)(brick + brick_bytes + off);
+                }
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    int off = brick_off<CB>(wn * WN + b * 16 + fr, kk * 4 + fq);
+                    bf16x8 bhf = *(const bf16x8*)(wb + off);
+                    bf16x8 blf;
+                    if (NSPLIT == 2) blf = *(const bf16x8*)(wb + W_BYTES + off);
+#pragma unroll
+                    for (int a = 0; a < TM; ++a) {
+                        if (NSPLIT == 2) {
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhf, al[a], acc[a][b], 0, 0, 0);
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(blf, ah[a], acc[a][b], 0, 0, 0);
+                        }
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhf, ah[a], acc[a][b], 0, 0, 0);
+                    }
+                }
+            }
+        };
+
+        if (u0 < u1) {
+            load_w(u0);
+            load_brick(u0 / p.ntaps);
+            store_w(0);
+            __syncthreads();
+            for (int u = u0; u < u1; ++u) {
+                const int buf = (u - u0) & 1;
+                const bool more = u + 1 < u1;
+                if (more) load_w(u + 1);                         // weight slice of the next unit: in flight under the MFMAs
+                compute(u, buf);
+                if (more) {
+                    int cbn = (u + 1) / p.ntaps;
+                    if (cbn != u / p.ntaps) {                    // next unit starts a new channel chunk: restage the brick
+                        __syncthreads();
+                        load_brick(cbn);
+                    }
+                    store_w(buf ^ 1);
+                }
+                __syncthreads();
             }
         }
     }
-    if (p.stats) {
-#pragma unroll
-        for (int b = 0; b < TN; ++b)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float s = cs[b][r], q = cq[b][r];
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
-                if (fr == 0) {
-                    int col = wn * WN + b * 16 + fq * 4 + r;
-                    red[(wm * BN + col) * 2 + 0] = s;
-                    red[(wm * BN + col) * 2 + 1] = q;
-                }
-            }
-        __syncthreads();
-        if (t < BN) {
-            float s = 0.f, q = 0.f;
-#pragma unroll
-            for (int w = 0; w < WAVES_M; ++w) { s += red[(w * BN + t) * 2]; q += red[(w * BN + t) * 2 + 1]; }
-            p.stats[((size_t)mtile * 2 + 0) * p.Cout + n0 + t] = s;
-            p.stats[((size_t)mtile * 2 + 1) * p.Cout + n0 + t] = q;
-        }
-    }
+    conv_epilogue<BN, TM, TN, WAVES_M, WM, WN>(p, acc, m0, n0, mtile, wm, wn, fr, fq, t, split, any_active, red);
 }
 
 // out = act(sum_split slab + bias) * mask (+ out), plus BatchNorm partial sums per 32-row chunk.
@@ -419,19 +651,73 @@ static int launch_conv(const ConvArgs& a, hipStream_t stream) {
 
 static int conv_bn(int cout) { return cout % 128 == 0 ? 128 : (cout % 64 == 0 ? 64 : 32); }
 
-// split-K plan: layers whose M x N tiling gives fewer than ~1.5 workgroups per CU split the K loop over gridDim.y
-static void conv_split_plan(long M, int cout, int kpad, int* ksplit, int* steps_per_split) {
-    int blocks = (int)((M + 127) / 128) * (cout / conv_bn(cout));
-    int nk = kpad / 32;
+// One plan per (geometry, direction), used by the launchers AND by the workspace / statistics-size queries.
+struct ConvPlan {
+    int brick;            // 0 generic im2col kernel, else channel chunk CB (32 / 64) of the brick kernel
+    int R, brick_rows;    // brick: halo reach and staged rows
+    int nunits;           // brick: (channel chunk, tap) units;  generic: 32-wide k-steps
+    int ksplit, per_split;
+    size_t smem;          // brick: dynamic LDS bytes for NSPLIT = 1 (x2 planes for the split mode is added by the launcher)
+};
+
+// The brick kernel is correct (bit-exact in tests/test_gpu_ops.py with TRICOLO_BRICK=1) but measured 5-25 % SLOWER than
+// the generic kernel on MI355X in round 1 (un-overlapped brick staging, one barrier per tap), so it is opt-in until tuned.
+static bool brick_disabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("TRICOLO_BRICK"); v = (e && e[0] == '1') ? 0 : 1; }
+    return v == 1;
+}
+
+// dims: grid of the rows (M side) == grid of the gathered tensor for brick-eligible layers
+static ConvPlan conv_make_plan(int B, int ID, int IH, int IW, int cin, int OD, int OH, int OW, int cout, int KD, int KH, int KW, int stride,
+                               int pd, int ph, int pw, int split_mode) {
+    ConvPlan pl{};
+    long M = (long)B * OD * OH * OW;
+    int ntaps = KD * KH * KW;
+    int kpad = (ntaps * cin + 31) / 32 * 32;
+    int bn = conv_bn(cout);
+    int blocks = (int)((M + 127) / 128) * (cout / bn);
+    bool same = stride == 1 && ID == OD && IH == OH && IW == OW && (KD == 1 || KD == 3) && (KH == 1 || KH == 3) && (KW == 1 || KW == 3) &&
+                pd == KD / 2 && ph == KH / 2 && pw == KW / 2;
+    if (same && ntaps >= 9 && cin % 32 == 0 && !brick_disabled()) {
+        int cb = cin % 64 == 0 ? 64 : 32;
+        int R = (pd * IH + ph) * IW + pw;
+        int rows = 128 + 2 * R;
+        int planes = split_mode ? 2 : 1;
+        size_t smem = (size_t)planes * ((size_t)(rows + 1) * cb * 2 + 2 * (size_t)bn * cb * 2) + 256 + (size_t)4 * bn * 2 * sizeof(float);
+        if (smem <= 150 * 1024) {
+            pl.brick = cb; pl.R = R; pl.brick_rows = rows; pl.smem = smem;
+            pl.nunits = (cin / cb) * ntaps;
+        }
+    }
+    if (!pl.brick) pl.nunits = kpad / 32;
     int ks = 1;
-    if (blocks < 384 && nk >= 8 && cout % 64 == 0) {
+    int min_per = pl.brick ? 3 : 4;                              // at least this many units per split
+    if (blocks < 384 && pl.nunits >= 2 * min_per && cout % 64 == 0) {
         ks = (768 + blocks - 1) / blocks;
-        if (ks > nk / 4) ks = nk / 4;
+        if (ks > pl.nunits / min_per) ks = pl.nunits / min_per;
         if (ks > 32) ks = 32;
         if (ks < 1) ks = 1;
     }
-    *steps_per_split = (nk + ks - 1) / ks;
-    *ksplit = (nk + *steps_per_split - 1) / *steps_per_split;
+    pl.per_split = (pl.nunits + ks - 1) / ks;
+    pl.ksplit = (pl.nunits + pl.per_split - 1) / pl.per_split;
+    return pl;
+}
+
+template <int BN, int CB, int NSPLIT>
+static int launch_brick(const ConvArgs& a, const ConvPlan& pl, hipStream_t stream) {
+    size_t smem = pl.smem;
+    static size_t attr = 0;
+    if (smem > attr) {
+        hipFuncSetAttribute((const void*)conv_brick_kernel<BN, CB, NSPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr = smem;
+    }
+    int mt = (a.M + 127) / 128, nt = a.Cout / BN;
+    conv_brick_kernel<BN, CB, NSPLIT><<<dim3(mt * nt, a.ksplit), 256, smem, stream>>>(a);
+    int rc = tri_check_launch("tri_conv(brick)");
+    if (rc || a.ksplit == 1) return rc;
+    conv_splitk_finish_kernel<<<dim3((a.M + 31) / 32, a.Cout / 64), 256, 0, stream>>>(a);
+    return tri_check_launch("tri_conv_splitk_finish");
 }
 
 static int conv_dispatch(ConvArgs& a, void* workspace, size_t workspace_bytes, hipStream_t stream) {
@@ -445,7 +731,14 @@ static int conv_dispatch(ConvArgs& a, void* workspace, size_t workspace_bytes, h
     size_t in_bytes = (size_t)a.B * a.ID * a.IH * a.IW * a.Cin * sizeof(float);
     if (in_bytes >= ((size_t)1 << 31)) { tri_set_error("conv: input tensor >= 2 GiB (32-bit buffer offsets)"); return TRI_ERR_UNSUPPORTED; }
     a.in_bytes = (unsigned)in_bytes;
-    conv_split_plan(a.M, a.Cout, a.Kpad, &a.ksplit, &a.steps_per_split);
+    const bool split = a.w_lo != nullptr;
+    ConvPlan pl = conv_make_plan(a.B, a.ID, a.IH, a.IW, a.Cin, a.OD, a.OH, a.OW, a.Cout, a.KD, a.KH, a.KW, a.stride, a.pd, a.ph, a.pw, split);
+    a.ksplit = pl.ksplit;
+    a.steps_per_split = pl.per_split;
+    a.units_per_split = pl.per_split;
+    a.nunits = pl.nunits;
+    a.R = pl.R;
+    a.brick_rows = pl.brick_rows;
     if (a.ksplit > 1) {
         size_t need = (size_t)a.ksplit * a.M * a.Cout * sizeof(float);
         if (workspace == nullptr || workspace_bytes < need) {
@@ -455,7 +748,13 @@ static int conv_dispatch(ConvArgs& a, void* workspace, size_t workspace_bytes, h
         a.slab = (float*)workspace;
     }
     a.dOW = make_fastdiv(a.OW); a.dOH = make_fastdiv(a.OH); a.dOD = make_fastdiv(a.OD); a.dCin = make_fastdiv(a.Cin);
-    bool split = a.w_lo != nullptr;
+    if (pl.brick) {
+        const int bn = conv_bn(a.Cout);
+#define TRI_BRICK(BN_, CB_) (split ? launch_brick<BN_, CB_, 2>(a, pl, stream) : launch_brick<BN_, CB_, 1>(a, pl, stream))
+        if (pl.brick == 64) return bn == 128 ? TRI_BRICK(128, 64) : (bn == 64 ? TRI_BRICK(64, 64) : TRI_BRICK(32, 64));
+        return bn == 128 ? TRI_BRICK(128, 32) : (bn == 64 ? TRI_BRICK(64, 32) : TRI_BRICK(32, 32));
+#undef TRI_BRICK
+    }
     if (a.Cout % 128 == 0) return split ? launch_conv<128, 2>(a, stream) : launch_conv<128, 1>(a, stream);
     if (a.Cout % 64 == 0) return split ? launch_conv<64, 2>(a, stream) : launch_conv<64, 1>(a, stream);
     return split ? launch_conv<32, 2>(a, stream) : launch_conv<32, 1>(a, stream);
@@ -465,12 +764,11 @@ extern "C" int tri_conv_kpad(int ntaps, int cin_stored) { return (ntaps * cin_st
 
 // number of [2][Cout] statistic records tri_conv_fwd writes for this layer: one per 128-row tile, or one per 32-row
 // chunk when the layer runs split-K (the finish kernel produces them).  tri_bn_finalize just sums all records.
-extern "C" int tri_conv_num_mtiles(const TriConvDesc* d) {
+extern "C" int tri_conv_num_mtiles(const TriConvDesc* d, int split3) {
     long M = (long)d->B * d->OD * d->OH * d->OW;
-    int kpad = (d->KD * d->KH * d->KW * d->Cin + 31) / 32 * 32;
-    int ks, sps;
-    conv_split_plan(M, d->Cout, kpad, &ks, &sps);
-    return ks > 1 ? (int)((M + 31) / 32) : (int)((M + 127) / 128);
+    ConvPlan pl = conv_make_plan(d->B, d->ID, d->IH, d->IW, d->Cin, d->OD, d->OH, d->OW, d->Cout, d->KD, d->KH, d->KW, d->stride, d->pad_d,
+                                 d->pad_h, d->pad_w, split3);
+    return pl.ksplit > 1 ? (int)((M + 31) / 32) : (int)((M + 127) / 128);
 }
 
 // out[B,OD,OH,OW,Cout] = conv(in[B,ID,IH,IW,Cin], W) (+bias, act 0 none / 1 relu / 2 tanh); rows with row_mask==0 are
@@ -478,12 +776,24 @@ extern "C" int tri_conv_num_mtiles(const TriConvDesc* d) {
 // bytes of split-K scratch tri_conv_fwd (transposed = 0) / tri_conv_dgrad (transposed = 1) can use for this layer
 // (0 when the layer already fills the GPU) and therefore REQUIRES.
 extern "C" size_t tri_conv_workspace(const TriConvDesc* d, int transposed) {
-    long M = transposed ? (long)d->B * d->ID * d->IH * d->IW : (long)d->B * d->OD * d->OH * d->OW;
-    int cout = transposed ? d->Cin : d->Cout, cin = transposed ? d->Cout : d->Cin;
-    int kpad = (d->KD * d->KH * d->KW * cin + 31) / 32 * 32;
-    int ks, sps;
-    conv_split_plan(M, cout, kpad, &ks, &sps);
-    return ks > 1 ? (size_t)ks * M * cout * sizeof(float) : 0;
+    size_t need = 0;
+    for (int mode = 0; mode < 2; ++mode) {
+        ConvPlan pl;
+        long M;
+        int cout;
+        if (transposed) {
+            M = (long)d->B * d->ID * d->IH * d->IW; cout = d->Cin;
+            pl = conv_make_plan(d->B, d->OD, d->OH, d->OW, d->Cout, d->ID, d->IH, d->IW, d->Cin, d->KD, d->KH, d->KW, d->stride, d->pad_d,
+                                d->pad_h, d->pad_w, mode);
+        } else {
+            M = (long)d->B * d->OD * d->OH * d->OW; cout = d->Cout;
+            pl = conv_make_plan(d->B, d->ID, d->IH, d->IW, d->Cin, d->OD, d->OH, d->OW, d->Cout, d->KD, d->KH, d->KW, d->stride, d->pad_d,
+                                d->pad_h, d->pad_w, mode);
+        }
+        size_t n = pl.ksplit > 1 ? (size_t)pl.ksplit * M * cout * sizeof(float) : 0;
+        if (n > need) need = n;
+    }
+    return need;
 }
 
 extern "C" int tri_conv_fwd(const TriConvDesc* d, const float* in, const void* w_hi, const void* w_lo, float* out,
