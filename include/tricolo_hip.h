@@ -8,7 +8,8 @@
  * Conventions: plain pointers + sizes, all pointers are DEVICE pointers unless noted; `stream` is a hipStream_t
  * passed as void*; every call is asynchronous on that stream, allocates nothing, keeps no global state and returns
  * 0 on success, a hipError_t (>0) or a negative TRI_ERR_* code otherwise (text via tri_last_error()).  Activations
- * are channels-last fp32: [B, D, H, W, C] (2D tensors use D = 1), C a multiple of 4.
+ * are channels-last [B, D, H, W, C] (2D tensors use D = 1), C a multiple of 4, stored fp32 (act_bf16 = 0: parity /
+ * bf16x3 mode) or bf16 (act_bf16 = 1: plain bf16 mode, half the bytes of every pass); arithmetic is fp32 either way.
  */
 #ifndef TRICOLO_HIP_H
 #define TRICOLO_HIP_H
@@ -50,17 +51,18 @@ int tri_weight_prep(const float* w, long s_row, long s_tap, long s_inner, int ro
 int tri_conv_num_mtiles(const TriConvDesc* d, int split3);
 /* split-K scratch a small-M layer needs (0 = none): pass at least this many bytes to tri_conv_fwd / tri_conv_dgrad */
 size_t tri_conv_workspace(const TriConvDesc* d, int transposed);
-int tri_conv_fwd(const TriConvDesc* d, const float* in, const void* w_hi, const void* w_lo, float* out, const uint8_t* row_mask,
-                 const float* bias, int act, int accumulate, float* stats, void* workspace, size_t workspace_bytes, void* stream);
-int tri_conv_dgrad(const TriConvDesc* d, const float* dout, const void* wt_hi, const void* wt_lo, float* din,
-                   const uint8_t* row_mask, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+int tri_conv_fwd(const TriConvDesc* d, const void* in, const void* w_hi, const void* w_lo, void* out, const uint8_t* row_mask,
+                 const float* bias, int act, int accumulate, float* stats, int act_bf16, void* workspace, size_t workspace_bytes,
+                 void* stream);
+int tri_conv_dgrad(const TriConvDesc* d, const void* dout, const void* wt_hi, const void* wt_lo, void* din,
+                   const uint8_t* row_mask, int accumulate, int act_bf16, void* workspace, size_t workspace_bytes, void* stream);
 size_t tri_conv_wgrad_workspace(const TriConvDesc* d);
 /* gather plan of a layer geometry (origin offset + tap validity bits per output position): build once, reuse every step */
 size_t tri_conv_plan_bytes(const TriConvDesc* d);
 int tri_conv_plan_build(const TriConvDesc* d, void* plan, void* stream);
-int tri_conv_wgrad(const TriConvDesc* d, const float* in, const float* dout, const uint8_t* row_mask, const void* plan /* required */,
+int tri_conv_wgrad(const TriConvDesc* d, const void* in, const void* dout, const uint8_t* row_mask, const void* plan /* required */,
                    void* workspace, size_t workspace_bytes, float* dw, long s_co, long s_tap, long s_ci, int cin_real, int split3,
-                   void* stream);
+                   int act_bf16, void* stream);
 
 /* ---- BatchNorm (train-mode statistics, eps / momentum as torch.nn.BatchNorm1d/2d) ----------------------------------
  * Replaces nn.BatchNorm1d over active voxels (sparse_cnn.py:13,18,23,28,33; count from a device counter) and the 20
@@ -70,34 +72,34 @@ int tri_bn_finalize(const float* partial, int ntiles, int C, const int* count_de
                     float eps, float* mean, float* invstd, float* scale, float* shift, void* stream);
 int tri_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps, float* mean,
                        float* invstd, float* scale, float* shift, void* stream);
-int tri_bn_act(const float* y, const float* scale, const float* shift, const float* res, const float* rscale, const float* rshift,
-               float* out, long M, int C, int relu, void* stream);
-int tri_relu_bwd(const float* dout, const float* out, float* g, long n, void* stream);
+int tri_bn_act(const void* y, const float* scale, const float* shift, const void* res, const float* rscale, const float* rshift,
+               void* out, long M, int C, int relu, int act_bf16, void* stream);
+int tri_relu_bwd(const void* dout, const void* out, void* g, long n, int act_bf16, void* stream);
 int tri_bn_bwd_num_blocks(long M);
-int tri_bn_bwd_reduce(const float* y, const float* g, long M, int C, float* partial, void* stream);
+int tri_bn_bwd_reduce(const void* y, const void* g, long M, int C, float* partial, int act_bf16, void* stream);
 int tri_bn_bwd_finalize(const float* partial, int nblk, int C, const int* count_dev, int count_host, const float* gamma,
                         const float* mean, const float* invstd, float* dgamma, float* dbeta, float* c1, float* c2, float* c3,
                         void* stream);
-int tri_bn_bwd_apply(const float* y, const float* g, const float* c1, const float* c2, const float* c3, const uint8_t* row_mask,
-                     float* dy, long M, int C, void* stream);
+int tri_bn_bwd_apply(const void* y, const void* g, const float* c1, const float* c2, const float* c3, const uint8_t* row_mask,
+                     void* dy, long M, int C, int act_bf16, void* stream);
 
 /* ---- pooling -------------------------------------------------------------------------------------------------
  * BN + ReLU + mask + spconv.SparseMaxPool3d(2,2) fused (sparse_cnn.py:13-15 ...), its backward routing;
  * nn.MaxPool2d(3,2,1) of the ResNet stem; AdaptiveAvgPool2d + torch.max over views (mv_cnn.py:29-31). */
-int tri_bn_relu_pool3d_fwd(const float* y, const float* scale, const float* shift, const uint8_t* mask, int B, int D, int C,
-                           float* pooled, uint8_t* mask_out, void* stream);
-int tri_pool3d_bwd_route(const float* y, const float* scale, const float* shift, const uint8_t* mask, const float* pooled,
-                         const float* dpooled, int B, int D, int C, float* g, void* stream);
-int tri_maxpool2d_fwd(const float* x, int N, int H, int W, int C, float* out, uint8_t* arg /* [N,Ho,Wo,C] winning tap, may be NULL */,
-                      void* stream);
-int tri_maxpool2d_bwd(const uint8_t* arg, const float* dout, int N, int H, int W, int C, float* dx, void* stream);
-int tri_avgpool_viewmax_fwd(const float* x, int B, int V, int HW, int C, float* out, int* arg, void* stream);
-int tri_avgpool_viewmax_bwd(const float* dout, const int* arg, int B, int V, int HW, int C, float* dx, void* stream);
+int tri_bn_relu_pool3d_fwd(const void* y, const float* scale, const float* shift, const uint8_t* mask, int B, int D, int C,
+                           void* pooled, uint8_t* mask_out, int act_bf16, void* stream);
+int tri_pool3d_bwd_route(const void* y, const float* scale, const float* shift, const uint8_t* mask, const void* pooled,
+                         const void* dpooled, int B, int D, int C, void* g, int act_bf16, void* stream);
+int tri_maxpool2d_fwd(const void* x, int N, int H, int W, int C, void* out, uint8_t* arg /* [N,Ho,Wo,C] winning tap, may be NULL */,
+                      int act_bf16, void* stream);
+int tri_maxpool2d_bwd(const uint8_t* arg, const void* dout, int N, int H, int W, int C, void* dx, int act_bf16, void* stream);
+int tri_avgpool_viewmax_fwd(const void* x, int B, int V, int HW, int C, float* out, int* arg, int act_bf16, void* stream);
+int tri_avgpool_viewmax_bwd(const float* dout, const int* arg, int B, int V, int HW, int C, void* dx, int act_bf16, void* stream);
 
 /* ---- layout converters (batch layout of tricolo/data/data_module.py:40-65) ---------------------------------------- */
-int tri_voxel_scatter(const int* locs, const float* feats, int n, int B, int V, float* dense, uint8_t* mask, void* stream);
+int tri_voxel_scatter(const int* locs, const float* feats, int n, int B, int V, void* dense, uint8_t* mask, int act_bf16, void* stream);
 int tri_mask_count(const uint8_t* mask, long n, int* count, void* stream);
-int tri_nchw3_to_nhwc4(const float* x, int N, int H, int W, float* out, void* stream);
+int tri_nchw3_to_nhwc4(const float* x, int N, int H, int W, void* out, int act_bf16, void* stream);
 
 /* ---- row ops ------------------------------------------------------------------------------------------------------
  * F.normalize(dim=1) (sparse_cnn.py:51, mv_cnn.py:33, bigru.py:18), bias gradients, activation backward. */

@@ -402,3 +402,69 @@ def test_gru_recurrence_matches_explicit_equations(precision, tol, B, L):
         dw = dgh[d].cpu().double().t() @ hprev[d].cpu().double()
         np.testing.assert_allclose(dw.numpy(), wr.grad[d].double().numpy(), atol=tol * 50)
         np.testing.assert_allclose(dgh[d].cpu().double().sum(0).numpy(), br.grad[d].double().numpy(), atol=tol * 50)
+
+
+# ------------------------------------------------------------------------------------------- bf16 activation storage
+BF16_CASES = [c for c in CONV_CASES if c[0] in ("vox_l0", "vox_l1", "stem7x7", "c3x3s1", "c3x3s2", "c1x1s2", "odd14")]
+
+
+@pytest.mark.parametrize("case", BF16_CASES, ids=[c[0] for c in BF16_CASES])
+def test_conv_bf16_storage_integer_exact(case):
+    """bf16 mode stores activations as bf16: operands are exact, the fp32 accumulator is rounded once on store."""
+    x, w, wp, xcl, g = make_case(case, integer=True, seed=51)
+    ref = cl3(F.conv3d(x, w, stride=case[6], padding=case[7]))
+    packed = ops.pack_weight(wp.to(DEV), g, "bf16")
+    out = ops.conv_fwd(xcl.to(DEV).to(torch.bfloat16), g, packed)
+    assert out.dtype == torch.bfloat16
+    assert torch.equal(out.cpu(), ref.to(torch.bfloat16))
+    # wgrad (fp32 result, exact) and dgrad (bf16 result, rounded once)
+    wr = w.clone().requires_grad_()
+    xr = x.clone().requires_grad_()
+    y = F.conv3d(xr, wr, stride=case[6], padding=case[7])
+    dy = ints(tuple(y.shape), -2, 2, 53)
+    y.backward(dy)
+    refw = wr.grad.permute(0, 2, 3, 4, 1).contiguous() if case[8] == "spconv" else wr.grad
+    dw = ops.conv_wgrad(xcl.to(DEV).to(torch.bfloat16), cl3(dy).to(DEV).to(torch.bfloat16), g, wp.to(DEV), "bf16")
+    assert torch.equal(dw.cpu(), refw)
+    if case[3] != 3:
+        dx = ops.conv_dgrad(cl3(dy).to(DEV).to(torch.bfloat16), g, ops.pack_weight(wp.to(DEV), g, "bf16", transposed=True))
+        assert torch.equal(dx.cpu(), cl3(xr.grad).to(torch.bfloat16))
+
+
+def test_elementwise_kernels_bf16_storage():
+    g = torch.Generator().manual_seed(61)
+    N, H, W, C = 4, 8, 8, 64
+    M = N * H * W
+    bf = torch.bfloat16
+    y = (torch.randn(M, C, generator=g) * 2).to(bf)
+    res = torch.randn(M, C, generator=g).to(bf)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+    yf, rf = y.float(), res.float()
+    stats = torch.stack([yf.double().sum(0).float(), (yf.double() ** 2).sum(0).float()]).view(1, 2, C)
+    rm, rv, nbt = torch.zeros(C, device=DEV), torch.ones(C, device=DEV), torch.zeros((), dtype=torch.long, device=DEV)
+    co = ops.bn_finalize(stats.to(DEV), C, gamma.to(DEV), beta.to(DEV), rm, rv, nbt, count_host=M)
+    out = ops.bn_act(y.to(DEV), co, relu=True, res=res.to(DEV))
+    assert out.dtype == bf
+    mean, var = yf.mean(0), yf.var(0, unbiased=False)
+    ref = F.relu((yf - mean) / torch.sqrt(var + 1e-5) * gamma + beta + rf)
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), rtol=1e-2, atol=1e-2)       # one bf16 rounding of the result
+    dout = torch.randn(M, C, generator=g).to(bf)
+    gz = ops.relu_bwd(dout.to(DEV), out, inplace=False)
+    assert torch.equal(gz.cpu(), (dout.float() * (out.float().cpu() > 0)).to(bf))
+    dy, dgamma, dbeta = ops.bn_bwd(y.to(DEV), gz, co, gamma.to(DEV), count_host=M, inplace=False)
+    yr, gr, br = yf.clone().requires_grad_(), gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    F.batch_norm(yr, None, None, gr, br, True, 0.1, 1e-5).backward(gz.float().cpu())
+    np.testing.assert_allclose(dy.float().cpu().numpy(), yr.grad.numpy(), rtol=2e-2, atol=2e-2)
+    np.testing.assert_allclose(dgamma.cpu().numpy(), gr.grad.numpy(), rtol=1e-3, atol=1e-2)
+    np.testing.assert_allclose(dbeta.cpu().numpy(), br.grad.numpy(), rtol=1e-3, atol=1e-2)
+    # max-pool 3x3/2 with ties, bf16 storage
+    x = torch.randint(0, 6, (N, C, 10, 10), generator=g).float()
+    xr = x.clone().requires_grad_()
+    refp = F.max_pool2d(xr, 3, 2, 1)
+    dp = torch.randint(-3, 4, refp.shape, generator=g).float()
+    refp.backward(dp)
+    xcl = x.permute(0, 2, 3, 1).contiguous().view(N, 1, 10, 10, C).to(DEV).to(bf)
+    po, parg = ops.maxpool2d_fwd(xcl)
+    assert torch.equal(po.float().cpu().view(N, 5, 5, C).permute(0, 3, 1, 2), refp.detach())
+    dxp = ops.maxpool2d_bwd(parg, dp.permute(0, 2, 3, 1).contiguous().to(DEV).to(bf), tuple(xcl.shape))
+    assert torch.equal(dxp.float().cpu().view(N, 10, 10, C).permute(0, 3, 1, 2), xr.grad)

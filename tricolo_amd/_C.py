@@ -30,29 +30,29 @@ SIGNATURES = {
     "tri_weight_prep": (I, [P, L, L, L, I, I, I, I, P, P, P]),
     "tri_conv_num_mtiles": (I, [DP, I]),
     "tri_conv_workspace": (Z, [DP, I]),
-    "tri_conv_fwd": (I, [DP, P, P, P, P, P, P, I, I, P, P, Z, P]),
-    "tri_conv_dgrad": (I, [DP, P, P, P, P, P, I, P, Z, P]),
+    "tri_conv_fwd": (I, [DP, P, P, P, P, P, P, I, I, P, I, P, Z, P]),
+    "tri_conv_dgrad": (I, [DP, P, P, P, P, P, I, I, P, Z, P]),
     "tri_conv_wgrad_workspace": (Z, [DP]),
     "tri_conv_plan_bytes": (Z, [DP]),
     "tri_conv_plan_build": (I, [DP, P, P]),
-    "tri_conv_wgrad": (I, [DP, P, P, P, P, P, Z, P, L, L, L, I, I, P]),
+    "tri_conv_wgrad": (I, [DP, P, P, P, P, P, Z, P, L, L, L, I, I, I, P]),
     "tri_bn_finalize": (I, [P, I, I, P, I, P, P, P, P, P, F, F, P, P, P, P, P]),
     "tri_bn_eval_coeffs": (I, [I, P, P, P, P, F, P, P, P, P, P]),
-    "tri_bn_act": (I, [P, P, P, P, P, P, P, L, I, I, P]),
-    "tri_relu_bwd": (I, [P, P, P, L, P]),
+    "tri_bn_act": (I, [P, P, P, P, P, P, P, L, I, I, I, P]),
+    "tri_relu_bwd": (I, [P, P, P, L, I, P]),
     "tri_bn_bwd_num_blocks": (I, [L]),
-    "tri_bn_bwd_reduce": (I, [P, P, L, I, P, P]),
+    "tri_bn_bwd_reduce": (I, [P, P, L, I, P, I, P]),
     "tri_bn_bwd_finalize": (I, [P, I, I, P, I, P, P, P, P, P, P, P, P, P]),
-    "tri_bn_bwd_apply": (I, [P, P, P, P, P, P, P, L, I, P]),
-    "tri_bn_relu_pool3d_fwd": (I, [P, P, P, P, I, I, I, P, P, P]),
-    "tri_pool3d_bwd_route": (I, [P, P, P, P, P, P, I, I, I, P, P]),
-    "tri_maxpool2d_fwd": (I, [P, I, I, I, I, P, P, P]),
-    "tri_maxpool2d_bwd": (I, [P, P, I, I, I, I, P, P]),
-    "tri_avgpool_viewmax_fwd": (I, [P, I, I, I, I, P, P, P]),
-    "tri_avgpool_viewmax_bwd": (I, [P, P, I, I, I, I, P, P]),
-    "tri_voxel_scatter": (I, [P, P, I, I, I, P, P, P]),
+    "tri_bn_bwd_apply": (I, [P, P, P, P, P, P, P, L, I, I, P]),
+    "tri_bn_relu_pool3d_fwd": (I, [P, P, P, P, I, I, I, P, P, I, P]),
+    "tri_pool3d_bwd_route": (I, [P, P, P, P, P, P, I, I, I, P, I, P]),
+    "tri_maxpool2d_fwd": (I, [P, I, I, I, I, P, P, I, P]),
+    "tri_maxpool2d_bwd": (I, [P, P, I, I, I, I, P, I, P]),
+    "tri_avgpool_viewmax_fwd": (I, [P, I, I, I, I, P, P, I, P]),
+    "tri_avgpool_viewmax_bwd": (I, [P, P, I, I, I, I, P, I, P]),
+    "tri_voxel_scatter": (I, [P, P, I, I, I, P, P, I, P]),
     "tri_mask_count": (I, [P, L, P, P]),
-    "tri_nchw3_to_nhwc4": (I, [P, I, I, I, P, P]),
+    "tri_nchw3_to_nhwc4": (I, [P, I, I, I, P, I, P]),
     "tri_l2norm_fwd": (I, [P, I, I, F, P, P, P]),
     "tri_l2norm_bwd": (I, [P, P, P, I, I, F, P, P]),
     "tri_colsum": (I, [P, L, I, P, P]),

@@ -80,15 +80,16 @@ extern "C" int tri_bn_eval_coeffs(int C, const float* gamma, const float* beta, 
 
 // ------------------------------------------------------------------------------------------ BN apply (+res, relu)
 // out = act(y*scale + shift + residual),  residual = res (identity) or res*rscale + rshift (down-sample BN branch)
-__global__ void bn_act_kernel(const float4* __restrict__ y, const float4* __restrict__ scale, const float4* __restrict__ shift,
-                              const float4* __restrict__ res, const float4* __restrict__ rscale, const float4* __restrict__ rshift,
-                              float4* __restrict__ out, long total4, int C4, int relu) {
+template <typename T>
+__global__ void bn_act_kernel(const T* __restrict__ y, const float4* __restrict__ scale, const float4* __restrict__ shift,
+                              const T* __restrict__ res, const float4* __restrict__ rscale, const float4* __restrict__ rshift,
+                              T* __restrict__ out, long total4, int C4, int relu) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
         int c = (int)(i % C4);
-        float4 v = y[i], s = scale[c], b = shift[c];
+        float4 v = Act<T>::ld4(y + i * 4), s = scale[c], b = shift[c];
         v.x = __fmaf_rn(v.x, s.x, b.x); v.y = __fmaf_rn(v.y, s.y, b.y); v.z = __fmaf_rn(v.z, s.z, b.z); v.w = __fmaf_rn(v.w, s.w, b.w);
         if (res) {
-            float4 r = res[i];
+            float4 r = Act<T>::ld4(res + i * 4);
             if (rscale) {
                 float4 rs = rscale[c], rb = rshift[c];
                 r.x = r.x * rs.x + rb.x; r.y = r.y * rs.y + rb.y; r.z = r.z * rs.z + rb.z; r.w = r.w * rs.w + rb.w;
@@ -96,34 +97,40 @@ __global__ void bn_act_kernel(const float4* __restrict__ y, const float4* __rest
             v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
         }
         if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        out[i] = v;
+        Act<T>::st4(out + i * 4, v);
     }
 }
+#define TRI_ACT_DISPATCH(flag, ...)                  \
+    do {                                             \
+        if (flag) { using T = bf16_t; __VA_ARGS__; } \
+        else { using T = float; __VA_ARGS__; }       \
+    } while (0)
 static inline int ew_grid(long total) {
     long b = (total + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
 }
-extern "C" int tri_bn_act(const float* y, const float* scale, const float* shift, const float* res, const float* rscale,
-                          const float* rshift, float* out, long M, int C, int relu, void* stream) {
+extern "C" int tri_bn_act(const void* y, const float* scale, const float* shift, const void* res, const float* rscale,
+                          const float* rshift, void* out, long M, int C, int relu, int act_bf16, void* stream) {
     if (C % 4) { tri_set_error("tri_bn_act: C must be a multiple of 4"); return TRI_ERR_ARG; }
     long total4 = M * (C / 4);
-    bn_act_kernel<<<ew_grid(total4), 256, 0, (hipStream_t)stream>>>((const float4*)y, (const float4*)scale, (const float4*)shift,
-                                                                     (const float4*)res, (const float4*)rscale, (const float4*)rshift,
-                                                                     (float4*)out, total4, C / 4, relu);
+    TRI_ACT_DISPATCH(act_bf16, bn_act_kernel<T><<<ew_grid(total4), 256, 0, (hipStream_t)stream>>>(
+        (const T*)y, (const float4*)scale, (const float4*)shift, (const T*)res, (const float4*)rscale, (const float4*)rshift, (T*)out,
+        total4, C / 4, relu));
     return tri_check_launch("tri_bn_act");
 }
 
 // g = dout * (out > 0)   (ReLU backward from the saved output; may run in place on dout)
-__global__ void relu_bwd_kernel(const float4* dout, const float4* __restrict__ out, float4* g, long total4) {
+template <typename T>
+__global__ void relu_bwd_kernel(const T* dout, const T* __restrict__ out, T* g, long total4) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
-        float4 d = dout[i], o = out[i];
+        float4 d = Act<T>::ld4(dout + i * 4), o = Act<T>::ld4(out + i * 4);
         d.x = o.x > 0.f ? d.x : 0.f; d.y = o.y > 0.f ? d.y : 0.f; d.z = o.z > 0.f ? d.z : 0.f; d.w = o.w > 0.f ? d.w : 0.f;
-        g[i] = d;
+        Act<T>::st4(g + i * 4, d);
     }
 }
-extern "C" int tri_relu_bwd(const float* dout, const float* out, float* g, long n, void* stream) {
+extern "C" int tri_relu_bwd(const void* dout, const void* out, void* g, long n, int act_bf16, void* stream) {
     if (n % 4) { tri_set_error("tri_relu_bwd: n must be a multiple of 4"); return TRI_ERR_ARG; }
-    relu_bwd_kernel<<<ew_grid(n / 4), 256, 0, (hipStream_t)stream>>>((const float4*)dout, (const float4*)out, (float4*)g, n / 4);
+    TRI_ACT_DISPATCH(act_bf16, relu_bwd_kernel<T><<<ew_grid(n / 4), 256, 0, (hipStream_t)stream>>>((const T*)dout, (const T*)out, (T*)g, n / 4));
     return tri_check_launch("tri_relu_bwd");
 }
 
@@ -132,7 +139,8 @@ extern "C" int tri_relu_bwd(const float* dout, const float* out, float* g, long 
 // and the coefficients of dy = c1*g + c2 + c3*y; pass 3: apply (rows with row_mask == 0 stay zero).
 // rows per block: 256 for large tensors, 64 for small ones (so that a 3,072-row layer still fills 48 CUs)
 static inline int bnb_rows(long M) { return M >= 65536 ? 256 : 64; }
-__global__ void bn_bwd_reduce_kernel(const float* __restrict__ y, const float* __restrict__ g, long M, int C, float* __restrict__ partial,
+template <typename T>
+__global__ void bn_bwd_reduce_kernel(const T* __restrict__ y, const T* __restrict__ g, long M, int C, float* __restrict__ partial,
                                      int BNB_ROWS) {
     extern __shared__ float sh[];                      // [rows_per_pass][C4*4][2]
     const int C4 = C >> 2;
@@ -148,7 +156,7 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ y, const float* _
         if (c4 < C4 && tr < rpp)
 #pragma unroll 4
             for (long r = r0 + tr; r < r1; r += rpp) {
-                float4 gv = *(const float4*)(g + r * C + c4 * 4), yv = *(const float4*)(y + r * C + c4 * 4);
+                float4 gv = Act<T>::ld4(g + r * C + c4 * 4), yv = Act<T>::ld4(y + r * C + c4 * 4);
                 sg.x += gv.x; sg.y += gv.y; sg.z += gv.z; sg.w += gv.w;
                 sgy.x += gv.x * yv.x; sgy.y += gv.y * yv.y; sgy.z += gv.z * yv.z; sgy.w += gv.w * yv.w;
             }
@@ -172,13 +180,13 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ y, const float* _
     }
 }
 extern "C" int tri_bn_bwd_num_blocks(long M) { return (int)((M + bnb_rows(M) - 1) / bnb_rows(M)); }
-extern "C" int tri_bn_bwd_reduce(const float* y, const float* g, long M, int C, float* partial, void* stream) {
+extern "C" int tri_bn_bwd_reduce(const void* y, const void* g, long M, int C, float* partial, int act_bf16, void* stream) {
     if (C % 4) { tri_set_error("tri_bn_bwd_reduce: C must be a multiple of 4"); return TRI_ERR_ARG; }
     int rows = bnb_rows(M);
     int nblk = (int)((M + rows - 1) / rows);
     int C4 = C / 4, tpr = C4 < 256 ? C4 : 256, rpp = 256 / tpr;
     size_t smem = (size_t)rpp * tpr * 8 * sizeof(float);
-    bn_bwd_reduce_kernel<<<nblk, 256, smem, (hipStream_t)stream>>>(y, g, M, C, partial, rows);
+    TRI_ACT_DISPATCH(act_bf16, bn_bwd_reduce_kernel<T><<<nblk, 256, smem, (hipStream_t)stream>>>((const T*)y, (const T*)g, M, C, partial, rows));
     return tri_check_launch("tri_bn_bwd_reduce");
 }
 
@@ -221,34 +229,35 @@ extern "C" int tri_bn_bwd_finalize(const float* partial, int nblk, int C, const 
     return tri_check_launch("tri_bn_bwd_finalize");
 }
 
-__global__ void bn_bwd_apply_kernel(const float4* __restrict__ y, const float4* g, const float4* __restrict__ c1,
+template <typename T>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ y, const T* g, const float4* __restrict__ c1,
                                     const float4* __restrict__ c2, const float4* __restrict__ c3,
-                                    const uint8_t* __restrict__ row_mask, float4* dy, long total4, int C4) {
+                                    const uint8_t* __restrict__ row_mask, T* dy, long total4, int C4) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
         long row = i / C4;
         int c = (int)(i - row * C4);
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
         if (!row_mask || row_mask[row]) {
-            float4 yv = y[i], gv = g[i], a = c1[c], b = c2[c], d = c3[c];
+            float4 yv = Act<T>::ld4(y + i * 4), gv = Act<T>::ld4(g + i * 4), a = c1[c], b = c2[c], d = c3[c];
             o.x = a.x * gv.x + b.x + d.x * yv.x; o.y = a.y * gv.y + b.y + d.y * yv.y;
             o.z = a.z * gv.z + b.z + d.z * yv.z; o.w = a.w * gv.w + b.w + d.w * yv.w;
         }
-        dy[i] = o;
+        Act<T>::st4(dy + i * 4, o);
     }
 }
-extern "C" int tri_bn_bwd_apply(const float* y, const float* g, const float* c1, const float* c2, const float* c3,
-                                const uint8_t* row_mask, float* dy, long M, int C, void* stream) {
+extern "C" int tri_bn_bwd_apply(const void* y, const void* g, const float* c1, const float* c2, const float* c3,
+                                const uint8_t* row_mask, void* dy, long M, int C, int act_bf16, void* stream) {
     long total4 = M * (C / 4);
-    bn_bwd_apply_kernel<<<ew_grid(total4), 256, 0, (hipStream_t)stream>>>((const float4*)y, (const float4*)g, (const float4*)c1,
-                                                                           (const float4*)c2, (const float4*)c3, row_mask,
-                                                                           (float4*)dy, total4, C / 4);
+    TRI_ACT_DISPATCH(act_bf16, bn_bwd_apply_kernel<T><<<ew_grid(total4), 256, 0, (hipStream_t)stream>>>(
+        (const T*)y, (const T*)g, (const float4*)c1, (const float4*)c2, (const float4*)c3, row_mask, (T*)dy, total4, C / 4));
     return tri_check_launch("tri_bn_bwd_apply");
 }
 
 // --------------------------------------------------------------------- voxel: BN + ReLU + mask + 2^3 max-pool
 // y [B,D,D,D,C] raw conv output, mask [B,D,D,D]; pooled [B,D/2,..,C], mask_out = OR of children
-__global__ void bn_relu_pool3d_fwd_kernel(const float* __restrict__ y, const float4* __restrict__ scale, const float4* __restrict__ shift,
-                                          const uint8_t* __restrict__ mask, int B, int D, int C4, float* __restrict__ pooled,
+template <typename T>
+__global__ void bn_relu_pool3d_fwd_kernel(const T* __restrict__ y, const float4* __restrict__ scale, const float4* __restrict__ shift,
+                                          const uint8_t* __restrict__ mask, int B, int D, int C4, T* __restrict__ pooled,
                                           uint8_t* __restrict__ mask_out) {
     const int Do = D >> 1;
     const long total = (long)B * Do * Do * Do * C4;
@@ -266,29 +275,31 @@ __global__ void bn_relu_pool3d_fwd_kernel(const float* __restrict__ y, const flo
             long ip = (((long)b * D + (oz * 2 + (k >> 2))) * D + (oy * 2 + ((k >> 1) & 1))) * D + (ox * 2 + (k & 1));
             if (mask[ip]) {
                 any = 1;
-                float4 v = *(const float4*)(y + (ip * C4 + c) * 4);
+                float4 v = Act<T>::ld4(y + (ip * C4 + c) * 4);
                 best.x = fmaxf(best.x, __fmaf_rn(v.x, s.x, t.x)); best.y = fmaxf(best.y, __fmaf_rn(v.y, s.y, t.y));
                 best.z = fmaxf(best.z, __fmaf_rn(v.z, s.z, t.z)); best.w = fmaxf(best.w, __fmaf_rn(v.w, s.w, t.w));
             }
         }
-        *(float4*)(pooled + i * 4) = best;             // best >= 0: ReLU folded into the max with the zero init
+        Act<T>::st4(pooled + i * 4, best);             // best >= 0: ReLU folded into the max with the zero init
         if (c == 0) mask_out[pos] = (uint8_t)any;
     }
 }
-extern "C" int tri_bn_relu_pool3d_fwd(const float* y, const float* scale, const float* shift, const uint8_t* mask, int B, int D, int C,
-                                      float* pooled, uint8_t* mask_out, void* stream) {
+extern "C" int tri_bn_relu_pool3d_fwd(const void* y, const float* scale, const float* shift, const uint8_t* mask, int B, int D, int C,
+                                      void* pooled, uint8_t* mask_out, int act_bf16, void* stream) {
     if (C % 4 || D % 2) { tri_set_error("tri_bn_relu_pool3d_fwd: C%4 or D%2"); return TRI_ERR_ARG; }
     long total = (long)B * (D / 2) * (D / 2) * (D / 2) * (C / 4);
-    bn_relu_pool3d_fwd_kernel<<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(y, (const float4*)scale, (const float4*)shift, mask, B, D,
-                                                                                C / 4, pooled, mask_out);
+    TRI_ACT_DISPATCH(act_bf16, bn_relu_pool3d_fwd_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(
+        (const T*)y, (const float4*)scale, (const float4*)shift, mask, B, D, C / 4, (T*)pooled, mask_out));
     return tri_check_launch("tri_bn_relu_pool3d_fwd");
 }
 
 // g[B,D,D,D,C] = gradient w.r.t. the BN output: dpooled routed to the FIRST child (d,h,w scan order, as
 // torch.max_pool3d) whose post-ReLU value equals the pooled maximum and is > 0; zero elsewhere / at inactive sites.
-__global__ void pool3d_bwd_route_kernel(const float* __restrict__ y, const float4* __restrict__ scale, const float4* __restrict__ shift,
-                                        const uint8_t* __restrict__ mask, const float* __restrict__ pooled,
-                                        const float* __restrict__ dpooled, int B, int D, int C4, float* __restrict__ g) {
+// (with bf16 storage the recomputed value is rounded like the stored maximum before the comparison)
+template <typename T>
+__global__ void pool3d_bwd_route_kernel(const T* __restrict__ y, const float4* __restrict__ scale, const float4* __restrict__ shift,
+                                        const uint8_t* __restrict__ mask, const T* __restrict__ pooled,
+                                        const T* __restrict__ dpooled, int B, int D, int C4, T* __restrict__ g) {
     const int Do = D >> 1;
     const long total = (long)B * Do * Do * Do * C4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -298,30 +309,31 @@ __global__ void pool3d_bwd_route_kernel(const float* __restrict__ y, const float
         int oy = (int)(r % Do); r /= Do;
         int oz = (int)(r % Do); int b = (int)(r / Do);
         float4 s = scale[c], t = shift[c];
-        float4 pm = *(const float4*)(pooled + i * 4), dp = *(const float4*)(dpooled + i * 4);
+        float4 pm = Act<T>::ld4(pooled + i * 4), dp = Act<T>::ld4(dpooled + i * 4);
         bool dx = false, dy = false, dz = false, dw = false;      // already routed
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             long ip = (((long)b * D + (oz * 2 + (k >> 2))) * D + (oy * 2 + ((k >> 1) & 1))) * D + (ox * 2 + (k & 1));
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
             if (mask[ip]) {
-                float4 v = *(const float4*)(y + (ip * C4 + c) * 4);
+                float4 v = Act<T>::ld4(y + (ip * C4 + c) * 4);
                 float zx = fmaxf(__fmaf_rn(v.x, s.x, t.x), 0.f), zy = fmaxf(__fmaf_rn(v.y, s.y, t.y), 0.f);
                 float zz = fmaxf(__fmaf_rn(v.z, s.z, t.z), 0.f), zw = fmaxf(__fmaf_rn(v.w, s.w, t.w), 0.f);
+                if (sizeof(T) == 2) { zx = (float)(bf16_t)zx; zy = (float)(bf16_t)zy; zz = (float)(bf16_t)zz; zw = (float)(bf16_t)zw; }
                 if (!dx && zx == pm.x && zx > 0.f) { o.x = dp.x; dx = true; }
                 if (!dy && zy == pm.y && zy > 0.f) { o.y = dp.y; dy = true; }
                 if (!dz && zz == pm.z && zz > 0.f) { o.z = dp.z; dz = true; }
                 if (!dw && zw == pm.w && zw > 0.f) { o.w = dp.w; dw = true; }
             }
-            *(float4*)(g + (ip * C4 + c) * 4) = o;
+            Act<T>::st4(g + (ip * C4 + c) * 4, o);
         }
     }
 }
-extern "C" int tri_pool3d_bwd_route(const float* y, const float* scale, const float* shift, const uint8_t* mask, const float* pooled,
-                                    const float* dpooled, int B, int D, int C, float* g, void* stream) {
+extern "C" int tri_pool3d_bwd_route(const void* y, const float* scale, const float* shift, const uint8_t* mask, const void* pooled,
+                                    const void* dpooled, int B, int D, int C, void* g, int act_bf16, void* stream) {
     long total = (long)B * (D / 2) * (D / 2) * (D / 2) * (C / 4);
-    pool3d_bwd_route_kernel<<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(y, (const float4*)scale, (const float4*)shift, mask, pooled,
-                                                                              dpooled, B, D, C / 4, g);
+    TRI_ACT_DISPATCH(act_bf16, pool3d_bwd_route_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(
+        (const T*)y, (const float4*)scale, (const float4*)shift, mask, (const T*)pooled, (const T*)dpooled, B, D, C / 4, (T*)g));
     return tri_check_launch("tri_pool3d_bwd_route");
 }
 
@@ -329,7 +341,8 @@ extern "C" int tri_pool3d_bwd_route(const float* y, const float* scale, const fl
 // Forward also records, per output element, WHICH of the 9 window taps won (first maximum in (kh,kw) scan order, the
 // torch.max_pool2d tie rule) as one byte; backward is then a gather over the <= 4 windows covering an input pixel:
 // 4 byte reads + 4 float4 reads instead of re-scanning 36 inputs.  Deterministic, no atomics.
-__global__ void maxpool2d_fwd_kernel(const float* __restrict__ x, int N, int H, int W, int C4, float* __restrict__ out,
+template <typename T>
+__global__ void maxpool2d_fwd_kernel(const T* __restrict__ x, int N, int H, int W, int C4, T* __restrict__ out,
                                      uchar4* __restrict__ arg) {
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;          // floor((H + 2 - 3)/2) + 1
     const long total = (long)N * Ho * Wo * C4;
@@ -348,7 +361,7 @@ __global__ void maxpool2d_fwd_kernel(const float* __restrict__ x, int N, int H, 
             for (int kw = 0; kw < 3; ++kw) {
                 int iw = ow * 2 - 1 + kw;
                 if ((unsigned)iw >= (unsigned)W) continue;
-                float4 v = *(const float4*)(x + ((((long)n * H + ih) * W + iw) * C4 + c) * 4);
+                float4 v = Act<T>::ld4(x + ((((long)n * H + ih) * W + iw) * C4 + c) * 4);
                 unsigned char k = (unsigned char)(kh * 3 + kw);
                 if (v.x > best.x) { best.x = v.x; bi.x = k; }
                 if (v.y > best.y) { best.y = v.y; bi.y = k; }
@@ -356,18 +369,19 @@ __global__ void maxpool2d_fwd_kernel(const float* __restrict__ x, int N, int H, 
                 if (v.w > best.w) { best.w = v.w; bi.w = k; }
             }
         }
-        *(float4*)(out + i * 4) = best;
+        Act<T>::st4(out + i * 4, best);
         if (arg) arg[i] = bi;
     }
 }
-extern "C" int tri_maxpool2d_fwd(const float* x, int N, int H, int W, int C, float* out, uint8_t* arg, void* stream) {
+extern "C" int tri_maxpool2d_fwd(const void* x, int N, int H, int W, int C, void* out, uint8_t* arg, int act_bf16, void* stream) {
     long total = (long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
-    maxpool2d_fwd_kernel<<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(x, N, H, W, C / 4, out, (uchar4*)arg);
+    TRI_ACT_DISPATCH(act_bf16, maxpool2d_fwd_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)stream>>>((const T*)x, N, H, W, C / 4, (T*)out, (uchar4*)arg));
     return tri_check_launch("tri_maxpool2d_fwd");
 }
 
-__global__ void maxpool2d_bwd_kernel(const uchar4* __restrict__ arg, const float* __restrict__ dout, int N, int H, int W, int C4,
-                                     float* __restrict__ dx) {
+template <typename T>
+__global__ void maxpool2d_bwd_kernel(const uchar4* __restrict__ arg, const T* __restrict__ dout, int N, int H, int W, int C4,
+                                     T* __restrict__ dx) {
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
     const long total = (long)N * H * W * C4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -383,25 +397,26 @@ __global__ void maxpool2d_bwd_kernel(const uchar4* __restrict__ arg, const float
                 unsigned char me = (unsigned char)((h - (oh * 2 - 1)) * 3 + (w - (ow * 2 - 1)));   // my tap index in that window
                 long o = (((long)n * Ho + oh) * Wo + ow) * C4 + c;
                 uchar4 a = arg[o];
-                float4 d = *(const float4*)(dout + o * 4);
+                float4 d = Act<T>::ld4(dout + o * 4);
                 if (a.x == me) acc.x += d.x;
                 if (a.y == me) acc.y += d.y;
                 if (a.z == me) acc.z += d.z;
                 if (a.w == me) acc.w += d.w;
             }
         }
-        *(float4*)(dx + i * 4) = acc;
+        Act<T>::st4(dx + i * 4, acc);
     }
 }
-extern "C" int tri_maxpool2d_bwd(const uint8_t* arg, const float* dout, int N, int H, int W, int C, float* dx, void* stream) {
+extern "C" int tri_maxpool2d_bwd(const uint8_t* arg, const void* dout, int N, int H, int W, int C, void* dx, int act_bf16, void* stream) {
     long total = (long)N * H * W * (C / 4);
-    maxpool2d_bwd_kernel<<<ew_grid(total), 256, 0, (hipStream_t)stream>>>((const uchar4*)arg, dout, N, H, W, C / 4, dx);
+    TRI_ACT_DISPATCH(act_bf16, maxpool2d_bwd_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)stream>>>((const uchar4*)arg, (const T*)dout, N, H, W, C / 4, (T*)dx));
     return tri_check_launch("tri_maxpool2d_bwd");
 }
 
 // ----------------------------------------------------- global average pool + max over the views of one shape
 // x [B*V, HW, C] -> out [B, C], argmax view index [B, C] (first maximum, as torch.max(dim=1))
-__global__ void avgpool_viewmax_fwd_kernel(const float* __restrict__ x, int B, int V, int HW, int C, float* __restrict__ out,
+template <typename T>
+__global__ void avgpool_viewmax_fwd_kernel(const T* __restrict__ x, int B, int V, int HW, int C, float* __restrict__ out,
                                            int* __restrict__ arg) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)B * C) return;
@@ -410,33 +425,34 @@ __global__ void avgpool_viewmax_fwd_kernel(const float* __restrict__ x, int B, i
     int bi = 0;
     float inv = 1.0f / (float)HW;
     for (int v = 0; v < V; ++v) {
-        const float* p = x + ((long)(b * V + v) * HW) * C + c;
+        const T* p = x + ((long)(b * V + v) * HW) * C + c;
         float s = 0.f;
-        for (int k = 0; k < HW; ++k) s += p[(long)k * C];
+        for (int k = 0; k < HW; ++k) s += (float)p[(long)k * C];
         s *= inv;
         if (s > best) { best = s; bi = v; }
     }
     out[i] = best;
     arg[i] = bi;
 }
-extern "C" int tri_avgpool_viewmax_fwd(const float* x, int B, int V, int HW, int C, float* out, int* arg, void* stream) {
+extern "C" int tri_avgpool_viewmax_fwd(const void* x, int B, int V, int HW, int C, float* out, int* arg, int act_bf16, void* stream) {
     long total = (long)B * C;
-    avgpool_viewmax_fwd_kernel<<<(int)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, B, V, HW, C, out, arg);
+    TRI_ACT_DISPATCH(act_bf16, avgpool_viewmax_fwd_kernel<T><<<(int)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>((const T*)x, B, V, HW, C, out, arg));
     return tri_check_launch("tri_avgpool_viewmax_fwd");
 }
+template <typename T>
 __global__ void avgpool_viewmax_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ arg, int B, int V, int HW, int C,
-                                           float* __restrict__ dx) {
+                                           T* __restrict__ dx) {
     const long total = (long)B * V * HW * C;
     float inv = 1.0f / (float)HW;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         int c = (int)(i % C);
         long r = i / C / HW;
         int v = (int)(r % V), b = (int)(r / V);
-        dx[i] = (arg[(long)b * C + c] == v) ? dout[(long)b * C + c] * inv : 0.f;
+        dx[i] = (T)((arg[(long)b * C + c] == v) ? dout[(long)b * C + c] * inv : 0.f);
     }
 }
-extern "C" int tri_avgpool_viewmax_bwd(const float* dout, const int* arg, int B, int V, int HW, int C, float* dx, void* stream) {
+extern "C" int tri_avgpool_viewmax_bwd(const float* dout, const int* arg, int B, int V, int HW, int C, void* dx, int act_bf16, void* stream) {
     long total = (long)B * V * HW * C;
-    avgpool_viewmax_bwd_kernel<<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(dout, arg, B, V, HW, C, dx);
+    TRI_ACT_DISPATCH(act_bf16, avgpool_viewmax_bwd_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(dout, arg, B, V, HW, C, (T*)dx));
     return tri_check_launch("tri_avgpool_viewmax_bwd");
 }

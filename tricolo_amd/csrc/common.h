@@ -55,6 +55,24 @@ __device__ __forceinline__ bf16x4 to_bf16x4(const float4& v) {
     return h;
 }
 
+// ---- activation storage ---------------------------------------------------------------------------------------
+// Big activation tensors are fp32 (parity / bf16x3 mode) or bf16 (bf16 mode: half the HBM and L2 bytes of every pass).
+// All arithmetic is fp32 either way; these helpers move 4 consecutive channels.
+template <typename T> struct Act;
+template <> struct Act<float> {
+    static constexpr int BYTES = 4;
+    static __device__ __forceinline__ float4 ld4(const float* p) { return *(const float4*)p; }
+    static __device__ __forceinline__ void st4(float* p, const float4& v) { *(float4*)p = v; }
+};
+template <> struct Act<bf16_t> {
+    static constexpr int BYTES = 2;
+    static __device__ __forceinline__ float4 ld4(const bf16_t* p) {
+        bf16x4 r = *(const bf16x4*)p;
+        return make_float4((float)r[0], (float)r[1], (float)r[2], (float)r[3]);
+    }
+    static __device__ __forceinline__ void st4(bf16_t* p, const float4& v) { *(bf16x4*)p = to_bf16x4(v); }
+};
+
 // XCD-aware bijective remap (cdna_hip_programming.md T1): blocks that share operand panels get consecutive
 // logical ids on one XCD, so the panel is fetched into that XCD's L2 once.
 __device__ __forceinline__ int xcd_remap(int orig, int nwg) {

@@ -16,10 +16,10 @@
 #include "../../include/tricolo_hip.h"
 
 struct ConvArgs {
-    const float* in;
+    const void* in;            // activations: fp32 or bf16 (kernel template parameter AT)
     const bf16_t* w_hi;
     const bf16_t* w_lo;
-    float* out;
+    void* out;
     const uint8_t* row_mask;   // per output position; 0 -> row forced to zero, all-zero tiles are skipped
     const float* bias;
     float* stats;              // [num_mtiles][2][Cout] per-tile column sum / sum of squares (BatchNorm statistics)
@@ -35,7 +35,7 @@ struct ConvArgs {
 };
 
 // Shared epilogue: acc[a][b][r] = out[m = a-tile row (lane & 15)][n = b-tile col 4 * (lane >> 4) + r].
-template <int BN, int TM, int TN, int WAVES_M, int WM, int WN>
+template <typename AT, int BN, int TM, int TN, int WAVES_M, int WM, int WN>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[TM][TN], int m0, int n0, int mtile, int wm, int wn, int fr,
                                               int fq, int t, int split, int any_active, float* red) {
     if (p.ksplit > 1) {
@@ -70,17 +70,20 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[TM
             for (int b = 0; b < TN; ++b) {
                 const int n = n0 + wn * WN + b * 16 + fq * 4;
                 f32x4 v = acc[a][b];
-                float* o = p.out + (size_t)m * p.Cout + n;
+                AT* o = (AT*)p.out + (size_t)m * p.Cout + n;
                 if (!plain) {
                     if (p.bias) v += *(const f32x4*)(p.bias + n);
                     if (p.act == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
                     else if (p.act == 2) { v[0] = tanhf(v[0]); v[1] = tanhf(v[1]); v[2] = tanhf(v[2]); v[3] = tanhf(v[3]); }
                     v *= live;
-                    if (p.accumulate) v += *(const f32x4*)o;
+                    if (p.accumulate) { float4 e = Act<AT>::ld4(o); v[0] += e.x; v[1] += e.y; v[2] += e.z; v[3] += e.w; }
                 } else {
                     v *= live;
                 }
-                *(f32x4*)o = v;
+                Act<AT>::st4(o, make_float4(v[0], v[1], v[2], v[3]));
+                if (sizeof(AT) == 2) {                            // statistics of what BatchNorm will actually read back
+                    v[0] = (float)(bf16_t)v[0]; v[1] = (float)(bf16_t)v[1]; v[2] = (float)(bf16_t)v[2]; v[3] = (float)(bf16_t)v[3];
+                }
                 cs[b] += v;
                 cq[b] += v * v;
             }
@@ -130,7 +133,7 @@ __device__ __forceinline__ unsigned axis_mask_t(int r, int K, int I, int stride)
     return m;
 }
 
-template <int BN, int NSPLIT>
+template <int BN, int NSPLIT, typename AT>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     constexpr int BM = 128;
     constexpr int WAVES_N = (BN >= 64) ? 2 : 1, WAVES_M = 4 / WAVES_N;
@@ -234,8 +237,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
             for (int i = 0; i < 4; ++i) {
                 unsigned mk = rmask[i];
                 bool ok = tv && (((mk >> sx) & (mk >> sy) & (mk >> sz)) & 1u);
-                unsigned voff = ok ? (unsigned)((rowoff[i] + toff) << 2) : 0x80000000u;
-                av[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
+                if (sizeof(AT) == 4) {
+                    unsigned voff = ok ? (unsigned)((rowoff[i] + toff) << 2) : 0x80000000u;
+                    av[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
+                } else {                                          // bf16 activations: 4 channels = 8 bytes, already MFMA operands
+                    unsigned voff = ok ? (unsigned)((rowoff[i] + toff) << 1) : 0x80000000u;
+                    uint2 h = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, 0, 0));
+                    av[i] = make_uint4(h.x, h.y, 0, 0);
+                }
             }
             {
                 int idx = t;
@@ -258,14 +267,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
             for (int i = 0; i < 4; ++i) {
                 int row = (t >> 3) + 32 * i;
                 int off = tile_off(row, k4 >> 1) + (k4 & 1) * 8;
-                float4 v = __builtin_bit_cast(float4, av[i]);
-                if (NSPLIT == 2) {
-                    bf16x4 h, l;
-                    split_bf16(v, h, l);
-                    *(bf16x4*)(base + off) = h;
-                    *(bf16x4*)(base + A_BYTES + off) = l;
+                if (sizeof(AT) == 2) {
+                    *(uint2*)(base + off) = make_uint2(av[i].x, av[i].y);
+                    if (NSPLIT == 2) *(uint2*)(base + A_BYTES + off) = make_uint2(0, 0);
                 } else {
-                    *(bf16x4*)(base + off) = to_bf16x4(v);
+                    float4 v = __builtin_bit_cast(float4, av[i]);
+                    if (NSPLIT == 2) {
+                        bf16x4 h, l;
+                        split_bf16(v, h, l);
+                        *(bf16x4*)(base + off) = h;
+                        *(bf16x4*)(base + A_BYTES + off) = l;
+                    } else {
+                        *(bf16x4*)(base + off) = to_bf16x4(v);
+                    }
                 }
             }
             char* bb = base + NSPLIT * A_BYTES;
@@ -325,7 +339,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
         }
     }
 
-    conv_epilogue<BN, TM, TN, WAVES_M, WM, WN>(p, acc, m0, n0, mtile, wm, wn, fr, fq, t, split, any_active, red);
+    conv_epilogue<AT, BN, TM, TN, WAVES_M, WM, WN>(p, acc, m0, n0, mtile, wm, wn, fr, fq, t, split, any_active, red);
 }
 
 // ================================================================================================ brick kernel
@@ -344,7 +358,7 @@ __device__ __forceinline__ int brick_off(int row, int chunk) {                 /
     return tile_off(row, chunk);                                                // 64-B rows: same image as the GEMM tiles
 }
 
-template <int BN, int CB, int NSPLIT>
+template <int BN, int CB, int NSPLIT, typename AT>
 __global__ __launch_bounds__(256) void conv_brick_kernel(const ConvArgs p) {
     constexpr int BM = 128;
     constexpr int WAVES_N = (BN >= 64) ? 2 : 1, WAVES_M = 4 / WAVES_N;
@@ -440,8 +454,14 @@ __global__ __launch_bounds__(256) void conv_brick_kernel(const ConvArgs p) {
                     int r = idx / (CB / 4), q = idx - r * (CB / 4);
                     long pos = (long)m0 - p.R + r;
                     bool ok = idx < total && pos >= 0 && pos < mtot;
-                    unsigned voff = ok ? (unsigned)(((int)pos * p.Cin + cb * CB + q * 4) << 2) : 0x80000000u;
-                    v[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
+                    if (sizeof(AT) == 4) {
+                        unsigned voff = ok ? (unsigned)(((int)pos * p.Cin + cb * CB + q * 4) << 2) : 0x80000000u;
+                        v[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
+                    } else {
+                        unsigned voff = ok ? (unsigned)(((int)pos * p.Cin + cb * CB + q * 4) << 1) : 0x80000000u;
+                        uint2 h = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, 0, 0));
+                        v[j] = make_uint4(h.x, h.y, 0, 0);
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -449,14 +469,19 @@ __global__ __launch_bounds__(256) void conv_brick_kernel(const ConvArgs p) {
                     if (idx < total) {
                         int r = idx / (CB / 4), q = idx - r * (CB / 4);
                         int off = brick_off<CB>(r, q >> 1) + (q & 1) * 8;
-                        float4 f = __builtin_bit_cast(float4, v[j]);
-                        if (NSPLIT == 2) {
-                            bf16x4 h, l;
-                            split_bf16(f, h, l);
-                            *(bf16x4*)(brick + off) = h;
-                            *(bf16x4*)(brick + brick_bytes + off) = l;
+                        if (sizeof(AT) == 2) {
+                            *(uint2*)(brick + off) = make_uint2(v[j].x, v[j].y);
+                            if (NSPLIT == 2) *(uint2*)(brick + brick_bytes + off) = make_uint2(0, 0);
                         } else {
-                            *(bf16x4*)(brick + off) = to_bf16x4(f);
+                            float4 f = __builtin_bit_cast(float4, v[j]);
+                            if (NSPLIT == 2) {
+                                bf16x4 h, l;
+                                split_bf16(f, h, l);
+                                *(bf16x4*)(brick + off) = h;
+                                *(bf16x4*)(brick + brick_bytes + off) = l;
+                            } else {
+                                *(bf16x4*)(brick + off) = to_bf16x4(f);
+                            }
                         }
                     }
                 }
@@ -549,12 +574,13 @@ __global__ __launch_bounds__(256) void conv_brick_kernel(const ConvArgs p) {
             }
         }
     }
-    conv_epilogue<BN, TM, TN, WAVES_M, WM, WN>(p, acc, m0, n0, mtile, wm, wn, fr, fq, t, split, any_active, red);
+    conv_epilogue<AT, BN, TM, TN, WAVES_M, WM, WN>(p, acc, m0, n0, mtile, wm, wn, fr, fq, t, split, any_active, red);
 }
 
 // out = act(sum_split slab + bias) * mask (+ out), plus BatchNorm partial sums per 32-row chunk.
 // One block = 32 rows x 64 columns (16 row lanes x 16 float4 column groups), grid = (row chunks, column chunks), so even
 // a 256-row layer spreads its slab read over dozens of CUs.
+template <typename AT>
 __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const ConvArgs p) {
     __shared__ float red[16][64][2];
     const int t = threadIdx.x, tc = t & 15, rl = t >> 4;
@@ -576,9 +602,10 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const ConvArgs 
             if (p.act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             else if (p.act == 2) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
         }
-        float* o = p.out + (size_t)m * p.Cout + n;
-        if (p.accumulate) { float4 e = *(const float4*)o; v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w; }
-        *(float4*)o = v;
+        AT* o = (AT*)p.out + (size_t)m * p.Cout + n;
+        if (p.accumulate) { float4 e = Act<AT>::ld4(o); v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w; }
+        Act<AT>::st4(o, v);
+        if (sizeof(AT) == 2) { bf16x4 rb = to_bf16x4(v); v = make_float4((float)rb[0], (float)rb[1], (float)rb[2], (float)rb[3]); }
         s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
         q4.x += v.x * v.x; q4.y += v.y * v.y; q4.z += v.z * v.z; q4.w += v.w * v.w;
     }
@@ -631,21 +658,21 @@ static int ilog2_exact(int v) {
     return -1;
 }
 
-template <int BN, int NSPLIT>
+template <int BN, int NSPLIT, typename AT>
 static int launch_conv(const ConvArgs& a, hipStream_t stream) {
     constexpr int STAGE = NSPLIT * (128 * 64 + BN * 64);
     constexpr int WAVES_M = (BN >= 64) ? 2 : 4;
     size_t smem = 2 * STAGE + 512 + WAVES_M * BN * 2 * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)conv_igemm_kernel<BN, NSPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipFuncSetAttribute((const void*)conv_igemm_kernel<BN, NSPLIT, AT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
     }
     int mt = (a.M + 127) / 128, nt = a.Cout / BN;
-    conv_igemm_kernel<BN, NSPLIT><<<dim3(mt * nt, a.ksplit), 256, smem, stream>>>(a);
+    conv_igemm_kernel<BN, NSPLIT, AT><<<dim3(mt * nt, a.ksplit), 256, smem, stream>>>(a);
     int rc = tri_check_launch("tri_conv");
     if (rc || a.ksplit == 1) return rc;
-    conv_splitk_finish_kernel<<<dim3((a.M + 31) / 32, a.Cout / 64), 256, 0, stream>>>(a);
+    conv_splitk_finish_kernel<AT><<<dim3((a.M + 31) / 32, a.Cout / 64), 256, 0, stream>>>(a);
     return tri_check_launch("tri_conv_splitk_finish");
 }
 
@@ -704,23 +731,23 @@ static ConvPlan conv_make_plan(int B, int ID, int IH, int IW, int cin, int OD, i
     return pl;
 }
 
-template <int BN, int CB, int NSPLIT>
+template <int BN, int CB, int NSPLIT, typename AT>
 static int launch_brick(const ConvArgs& a, const ConvPlan& pl, hipStream_t stream) {
     size_t smem = pl.smem;
     static size_t attr = 0;
     if (smem > attr) {
-        hipFuncSetAttribute((const void*)conv_brick_kernel<BN, CB, NSPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipFuncSetAttribute((const void*)conv_brick_kernel<BN, CB, NSPLIT, AT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr = smem;
     }
     int mt = (a.M + 127) / 128, nt = a.Cout / BN;
-    conv_brick_kernel<BN, CB, NSPLIT><<<dim3(mt * nt, a.ksplit), 256, smem, stream>>>(a);
+    conv_brick_kernel<BN, CB, NSPLIT, AT><<<dim3(mt * nt, a.ksplit), 256, smem, stream>>>(a);
     int rc = tri_check_launch("tri_conv(brick)");
     if (rc || a.ksplit == 1) return rc;
-    conv_splitk_finish_kernel<<<dim3((a.M + 31) / 32, a.Cout / 64), 256, 0, stream>>>(a);
+    conv_splitk_finish_kernel<AT><<<dim3((a.M + 31) / 32, a.Cout / 64), 256, 0, stream>>>(a);
     return tri_check_launch("tri_conv_splitk_finish");
 }
 
-static int conv_dispatch(ConvArgs& a, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+static int conv_dispatch(ConvArgs& a, int act_bf16, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     if (a.Cin % 4 != 0) { tri_set_error("conv: stored input channels must be a multiple of 4"); return TRI_ERR_ARG; }
     if (a.Cout % 32 != 0) { tri_set_error("conv: output channels must be a multiple of 32"); return TRI_ERR_ARG; }
     if (a.ntaps > 64) { tri_set_error("conv: more than 64 taps unsupported"); return TRI_ERR_UNSUPPORTED; }
@@ -728,10 +755,11 @@ static int conv_dispatch(ConvArgs& a, void* workspace, size_t workspace_bytes, h
     if (a.KD > 8 || a.KH > 8 || a.KW > 8) { tri_set_error("conv: kernel extent > 8 unsupported"); return TRI_ERR_UNSUPPORTED; }
     a.Kpad = (a.ntaps * a.Cin + 31) / 32 * 32;
     a.cin_shift = ilog2_exact(a.Cin);
-    size_t in_bytes = (size_t)a.B * a.ID * a.IH * a.IW * a.Cin * sizeof(float);
+    size_t in_bytes = (size_t)a.B * a.ID * a.IH * a.IW * a.Cin * (act_bf16 ? 2 : 4);
     if (in_bytes >= ((size_t)1 << 31)) { tri_set_error("conv: input tensor >= 2 GiB (32-bit buffer offsets)"); return TRI_ERR_UNSUPPORTED; }
     a.in_bytes = (unsigned)in_bytes;
     const bool split = a.w_lo != nullptr;
+    if (act_bf16 && split) { tri_set_error("conv: bf16 activation storage is for the plain bf16 mode (no lo operand)"); return TRI_ERR_ARG; }
     ConvPlan pl = conv_make_plan(a.B, a.ID, a.IH, a.IW, a.Cin, a.OD, a.OH, a.OW, a.Cout, a.KD, a.KH, a.KW, a.stride, a.pd, a.ph, a.pw, split);
     a.ksplit = pl.ksplit;
     a.steps_per_split = pl.per_split;
@@ -750,14 +778,20 @@ static int conv_dispatch(ConvArgs& a, void* workspace, size_t workspace_bytes, h
     a.dOW = make_fastdiv(a.OW); a.dOH = make_fastdiv(a.OH); a.dOD = make_fastdiv(a.OD); a.dCin = make_fastdiv(a.Cin);
     if (pl.brick) {
         const int bn = conv_bn(a.Cout);
-#define TRI_BRICK(BN_, CB_) (split ? launch_brick<BN_, CB_, 2>(a, pl, stream) : launch_brick<BN_, CB_, 1>(a, pl, stream))
+#define TRI_BRICK(BN_, CB_)                                                                               \
+    (act_bf16 ? launch_brick<BN_, CB_, 1, bf16_t>(a, pl, stream)                                          \
+              : (split ? launch_brick<BN_, CB_, 2, float>(a, pl, stream) : launch_brick<BN_, CB_, 1, float>(a, pl, stream)))
         if (pl.brick == 64) return bn == 128 ? TRI_BRICK(128, 64) : (bn == 64 ? TRI_BRICK(64, 64) : TRI_BRICK(32, 64));
         return bn == 128 ? TRI_BRICK(128, 32) : (bn == 64 ? TRI_BRICK(64, 32) : TRI_BRICK(32, 32));
 #undef TRI_BRICK
     }
-    if (a.Cout % 128 == 0) return split ? launch_conv<128, 2>(a, stream) : launch_conv<128, 1>(a, stream);
-    if (a.Cout % 64 == 0) return split ? launch_conv<64, 2>(a, stream) : launch_conv<64, 1>(a, stream);
-    return split ? launch_conv<32, 2>(a, stream) : launch_conv<32, 1>(a, stream);
+#define TRI_CONV(BN_)                                                                                     \
+    (act_bf16 ? launch_conv<BN_, 1, bf16_t>(a, stream)                                                    \
+              : (split ? launch_conv<BN_, 2, float>(a, stream) : launch_conv<BN_, 1, float>(a, stream)))
+    if (a.Cout % 128 == 0) return TRI_CONV(128);
+    if (a.Cout % 64 == 0) return TRI_CONV(64);
+    return TRI_CONV(32);
+#undef TRI_CONV
 }
 
 extern "C" int tri_conv_kpad(int ntaps, int cin_stored) { return (ntaps * cin_stored + 31) / 32 * 32; }
@@ -796,9 +830,9 @@ extern "C" size_t tri_conv_workspace(const TriConvDesc* d, int transposed) {
     return need;
 }
 
-extern "C" int tri_conv_fwd(const TriConvDesc* d, const float* in, const void* w_hi, const void* w_lo, float* out,
-                            const uint8_t* row_mask, const float* bias, int act, int accumulate, float* stats, void* workspace,
-                            size_t workspace_bytes, void* stream) {
+extern "C" int tri_conv_fwd(const TriConvDesc* d, const void* in, const void* w_hi, const void* w_lo, void* out,
+                            const uint8_t* row_mask, const float* bias, int act, int accumulate, float* stats, int act_bf16,
+                            void* workspace, size_t workspace_bytes, void* stream) {
     ConvArgs a{};
     a.in = in; a.w_hi = (const bf16_t*)w_hi; a.w_lo = (const bf16_t*)w_lo; a.out = out;
     a.row_mask = row_mask; a.bias = bias; a.stats = stats;
@@ -808,13 +842,14 @@ extern "C" int tri_conv_fwd(const TriConvDesc* d, const float* in, const void* w
     a.transposed = 0; a.act = act; a.accumulate = accumulate;
     a.ntaps = d->KD * d->KH * d->KW;
     a.M = d->B * d->OD * d->OH * d->OW;
-    return conv_dispatch(a, workspace, workspace_bytes, (hipStream_t)stream);
+    return conv_dispatch(a, act_bf16, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 // din[B,ID,IH,IW,Cin] (+)= conv_transpose(dout[B,OD,OH,OW,Cout], Wt), Wt packed [Cin][taps*Cout] by tri_weight_prep
 // with swapped strides.  `d` is the FORWARD descriptor of the layer.
-extern "C" int tri_conv_dgrad(const TriConvDesc* d, const float* dout, const void* wt_hi, const void* wt_lo, float* din,
-                              const uint8_t* row_mask, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int tri_conv_dgrad(const TriConvDesc* d, const void* dout, const void* wt_hi, const void* wt_lo, void* din,
+                              const uint8_t* row_mask, int accumulate, int act_bf16, void* workspace, size_t workspace_bytes,
+                              void* stream) {
     ConvArgs a{};
     a.in = dout; a.w_hi = (const bf16_t*)wt_hi; a.w_lo = (const bf16_t*)wt_lo; a.out = din;
     a.row_mask = row_mask; a.bias = nullptr; a.stats = nullptr;
@@ -824,5 +859,5 @@ extern "C" int tri_conv_dgrad(const TriConvDesc* d, const float* dout, const voi
     a.transposed = 1; a.act = 0; a.accumulate = accumulate;
     a.ntaps = d->KD * d->KH * d->KW;
     a.M = d->B * d->ID * d->IH * d->IW;
-    return conv_dispatch(a, workspace, workspace_bytes, (hipStream_t)stream);
+    return conv_dispatch(a, act_bf16, workspace, workspace_bytes, (hipStream_t)stream);
 }

@@ -14,8 +14,8 @@
 #include "../../include/tricolo_hip.h"
 
 struct WgradArgs {
-    const float* in;
-    const float* dout;
+    const void* in;              // activations / gradients: fp32 or bf16 (kernel template parameter AT)
+    const void* dout;
     const uint8_t* row_mask;
     float* slab;                 // [splits][Cout][Kpad]
     const int* plan_off;         // optional gather plan: element offset of each output position's origin voxel
@@ -52,7 +52,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int col0, int g, int
     return __builtin_bit_cast(bf16x8, r);
 }
 
-template <int BI, int BJ, int NSPLIT>
+template <int BI, int BJ, int NSPLIT, typename AT>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
     constexpr int WI = BI / 2, WJ = BJ / 2, TM = WI / 16, TN = WJ / 16;
     constexpr int XROW = BI * 2, YROW = BJ * 2;                  // bytes per position row
@@ -154,7 +154,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
                 int quad = e % (BI / 4), pos = e / (BI / 4);
                 int m = mbase + pos, co = i0 + quad * 4;
                 float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (m < p.M && co < p.Cout) x = *(const float4*)(p.dout + (size_t)m * p.Cout + co);
+                if (m < p.M && co < p.Cout) {
+                    if (sizeof(AT) == 4) x = *(const float4*)((const float*)p.dout + (size_t)m * p.Cout + co);
+                    else { uint2 h = *(const uint2*)((const bf16_t*)p.dout + (size_t)m * p.Cout + co); x.x = __builtin_bit_cast(float, h.x); x.y = __builtin_bit_cast(float, h.y); }
+                }
                 v[u] = x;
             } else {
                 int pos = (e - XL) / (BJ / 4);
@@ -163,8 +166,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
                 unsigned rm = lplan_mask[m - ks_begin * 32];
                 int sh = y_sh[u];
                 bool ok = y_tv[u] && (((rm >> (sh & 255)) & (rm >> ((sh >> 8) & 255)) & (rm >> ((sh >> 16) & 255))) & 1u);
-                unsigned voff = ok ? (unsigned)((ro + y_toff[u]) << 2) : 0x80000000u;
-                v[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
+                if (sizeof(AT) == 4) {
+                    unsigned voff = ok ? (unsigned)((ro + y_toff[u]) << 2) : 0x80000000u;
+                    v[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
+                } else {                                          // bf16: the 8 loaded bytes ARE the LDS payload (kept in .x/.y)
+                    unsigned voff = ok ? (unsigned)((ro + y_toff[u]) << 1) : 0x80000000u;
+                    uint2 h = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, 0, 0));
+                    v[u] = make_float4(__builtin_bit_cast(float, h.x), __builtin_bit_cast(float, h.y), 0.f, 0.f);
+                }
             }
         }
     };
@@ -185,7 +194,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
                 dst = yb + nat_off<YROW>(pos, quad * 8);
                 lo_off = Y_BYTES;
             }
-            if (NSPLIT == 2) {
+            if (sizeof(AT) == 2) {
+                *(uint2*)dst = make_uint2(__builtin_bit_cast(unsigned, v[u].x), __builtin_bit_cast(unsigned, v[u].y));
+                if (NSPLIT == 2) *(uint2*)(dst + lo_off) = make_uint2(0, 0);
+            } else if (NSPLIT == 2) {
                 bf16x4 h, l;
                 split_bf16(v[u], h, l);
                 *(bf16x4*)dst = h;
@@ -352,26 +364,26 @@ extern "C" size_t tri_conv_wgrad_workspace(const TriConvDesc* d) {
 }
 
 #define WGRAD_MAX_STEPS 96
-template <int BI, int BJ, int NSPLIT>
+template <int BI, int BJ, int NSPLIT, typename AT>
 static int launch_wgrad(const WgradArgs& a, int tiles, int splits, hipStream_t stream) {
     constexpr int STAGE = NSPLIT * (32 * BI * 2 + 32 * BJ * 2);
     size_t smem = 2 * STAGE + 512 + (size_t)a.steps_per_split * 256;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)conv_wgrad_kernel<BI, BJ, NSPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute((const void*)conv_wgrad_kernel<BI, BJ, NSPLIT, AT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             2 * STAGE + 512 + WGRAD_MAX_STEPS * 256);
         attr_set = true;
     }
-    conv_wgrad_kernel<BI, BJ, NSPLIT><<<dim3(tiles, splits), 256, smem, stream>>>(a);
+    conv_wgrad_kernel<BI, BJ, NSPLIT, AT><<<dim3(tiles, splits), 256, smem, stream>>>(a);
     return tri_check_launch("tri_conv_wgrad");
 }
 
 // dw (addressed by element strides s_co / s_tap / s_ci, i.e. directly in the reference's parameter layout)
 //   = sum over positions of dout x im2col(in).  row_mask (optional, per output position, buffer padded to a
 // multiple of 32 bytes) marks live positions; split3 != 0 selects the 3-product bf16 split mode.
-extern "C" int tri_conv_wgrad(const TriConvDesc* d, const float* in, const float* dout, const uint8_t* row_mask, const void* plan,
+extern "C" int tri_conv_wgrad(const TriConvDesc* d, const void* in, const void* dout, const uint8_t* row_mask, const void* plan,
                               void* workspace, size_t workspace_bytes, float* dw, long s_co, long s_tap, long s_ci, int cin_real,
-                              int split3, void* stream) {
+                              int split3, int act_bf16, void* stream) {
     if (d->Cin % 4 != 0 || d->Cout % 4 != 0) { tri_set_error("wgrad: channels must be multiples of 4"); return TRI_ERR_ARG; }
     int BI, BJ, tiles, splits, sps, Kpad;
     wgrad_plan(d, &BI, &BJ, &tiles, &splits, &sps, &Kpad);
@@ -387,7 +399,8 @@ extern "C" int tri_conv_wgrad(const TriConvDesc* d, const float* in, const float
     a.M = d->B * d->OD * d->OH * d->OW;
     a.cin_shift = ilog2_exact(a.Cin);
     a.steps_per_split = sps;
-    size_t in_bytes = (size_t)a.B * a.ID * a.IH * a.IW * a.Cin * sizeof(float);
+    size_t in_bytes = (size_t)a.B * a.ID * a.IH * a.IW * a.Cin * (act_bf16 ? 2 : 4);
+    if (act_bf16 && split3) { tri_set_error("wgrad: bf16 activation storage is for the plain bf16 mode"); return TRI_ERR_ARG; }
     if (!plan) { tri_set_error("wgrad: a gather plan from tri_conv_plan_build is required"); return TRI_ERR_ARG; }
     if (in_bytes >= ((size_t)1 << 31)) { tri_set_error("wgrad: input tensor >= 2 GiB (32-bit buffer offsets)"); return TRI_ERR_UNSUPPORTED; }
     {
@@ -399,9 +412,13 @@ extern "C" int tri_conv_wgrad(const TriConvDesc* d, const float* in, const float
     a.dOW = make_fastdiv(a.OW); a.dOH = make_fastdiv(a.OH); a.dOD = make_fastdiv(a.OD); a.dCin = make_fastdiv(a.Cin);
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    if (BI == 128) rc = split3 ? launch_wgrad<128, 128, 2>(a, tiles, splits, s) : launch_wgrad<128, 128, 1>(a, tiles, splits, s);
-    else if (BJ == 256) rc = split3 ? launch_wgrad<64, 256, 2>(a, tiles, splits, s) : launch_wgrad<64, 256, 1>(a, tiles, splits, s);
-    else rc = split3 ? launch_wgrad<64, 128, 2>(a, tiles, splits, s) : launch_wgrad<64, 128, 1>(a, tiles, splits, s);
+#define TRI_WG(BI_, BJ_)                                                                                   \
+    (act_bf16 ? launch_wgrad<BI_, BJ_, 1, bf16_t>(a, tiles, splits, s)                                     \
+              : (split3 ? launch_wgrad<BI_, BJ_, 2, float>(a, tiles, splits, s) : launch_wgrad<BI_, BJ_, 1, float>(a, tiles, splits, s)))
+    if (BI == 128) rc = TRI_WG(128, 128);
+    else if (BJ == 256) rc = TRI_WG(64, 256);
+    else rc = TRI_WG(64, 128);
+#undef TRI_WG
     if (rc) return rc;
     int zlanes = splits >= 8 ? 8 : (splits >= 4 ? 4 : (splits >= 2 ? 2 : 1));
     int kper = 256 / zlanes;

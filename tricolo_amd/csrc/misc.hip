@@ -26,22 +26,27 @@ static inline int ew_grid(long total) {
 // ------------------------------------------------------------------------------------------------ voxel scatter
 // COO batch of data_module.py:52-64 (locs [n,4] = (b,i0,i1,i2), feats [n,3] in [0,1]) -> dense channels-last grid
 // [B,V,V,V,4] = (r,g,b,0) and site mask [B,V,V,V].  Both outputs must be zero-filled first (tri_fill_zero).
+template <typename T>
 __global__ void voxel_scatter_kernel(const int* __restrict__ locs, const float* __restrict__ feats, int n, int B, int V,
-                                     float4* __restrict__ dense, uint8_t* __restrict__ mask) {
+                                     T* __restrict__ dense, uint8_t* __restrict__ mask) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int b = locs[i * 4], z = locs[i * 4 + 1], y = locs[i * 4 + 2], x = locs[i * 4 + 3];
     if ((unsigned)b >= (unsigned)B || (unsigned)z >= (unsigned)V || (unsigned)y >= (unsigned)V || (unsigned)x >= (unsigned)V) return;
     long pos = (((long)b * V + z) * V + y) * V + x;
-    dense[pos] = make_float4(feats[i * 3], feats[i * 3 + 1], feats[i * 3 + 2], 0.f);
+    Act<T>::st4(dense + pos * 4, make_float4(feats[i * 3], feats[i * 3 + 1], feats[i * 3 + 2], 0.f));
     mask[pos] = 1;
 }
-extern "C" int tri_voxel_scatter(const int* locs, const float* feats, int n, int B, int V, float* dense, uint8_t* mask, void* stream) {
+extern "C" int tri_voxel_scatter(const int* locs, const float* feats, int n, int B, int V, void* dense, uint8_t* mask, int act_bf16,
+                                 void* stream) {
     hipStream_t s = (hipStream_t)stream;
     size_t sites = (size_t)B * V * V * V;
-    hipMemsetAsync(dense, 0, sites * 4 * sizeof(float), s);
+    hipMemsetAsync(dense, 0, sites * 4 * (act_bf16 ? 2 : 4), s);
     hipMemsetAsync(mask, 0, sites, s);
-    if (n > 0) voxel_scatter_kernel<<<(n + 255) / 256, 256, 0, s>>>(locs, feats, n, B, V, (float4*)dense, mask);
+    if (n > 0) {
+        if (act_bf16) voxel_scatter_kernel<bf16_t><<<(n + 255) / 256, 256, 0, s>>>(locs, feats, n, B, V, (bf16_t*)dense, mask);
+        else voxel_scatter_kernel<float><<<(n + 255) / 256, 256, 0, s>>>(locs, feats, n, B, V, (float*)dense, mask);
+    }
     return tri_check_launch("tri_voxel_scatter");
 }
 
@@ -65,16 +70,18 @@ extern "C" int tri_mask_count(const uint8_t* mask, long n, int* count, void* str
 
 // ------------------------------------------------------------------------------------------------ image layout
 // x [N,3,H,W] f32 (tricolo_net.py:51 flatten of data_dict["images"]) -> [N,H,W,4] with a zero 4th channel
-__global__ void nchw3_to_nhwc4_kernel(const float* __restrict__ x, long HW, long total, float4* __restrict__ out) {
+template <typename T>
+__global__ void nchw3_to_nhwc4_kernel(const float* __restrict__ x, long HW, long total, T* __restrict__ out) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         long n = i / HW, p = i - n * HW;
         const float* b = x + n * 3 * HW + p;
-        out[i] = make_float4(b[0], b[HW], b[2 * HW], 0.f);
+        Act<T>::st4(out + i * 4, make_float4(b[0], b[HW], b[2 * HW], 0.f));
     }
 }
-extern "C" int tri_nchw3_to_nhwc4(const float* x, int N, int H, int W, float* out, void* stream) {
+extern "C" int tri_nchw3_to_nhwc4(const float* x, int N, int H, int W, void* out, int act_bf16, void* stream) {
     long HW = (long)H * W, total = (long)N * HW;
-    nchw3_to_nhwc4_kernel<<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(x, HW, total, (float4*)out);
+    if (act_bf16) nchw3_to_nhwc4_kernel<bf16_t><<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(x, HW, total, (bf16_t*)out);
+    else nchw3_to_nhwc4_kernel<float><<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(x, HW, total, (float*)out);
     return tri_check_launch("tri_nchw3_to_nhwc4");
 }
 

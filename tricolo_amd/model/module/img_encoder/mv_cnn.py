@@ -108,7 +108,7 @@ class MVCNNEncoder(TriModule):
         if N % self.num_views:
             raise RuntimeError("mat shape: number of images is not a multiple of num_views")
         B = N // self.num_views
-        x0 = ops.nchw3_to_nhwc4(images)
+        x0 = ops.nchw3_to_nhwc4(images, dtype=ops.act_dtype(prec))
         y, co, g = self._conv_bn(x0, self.net_1[0], self.net_1[1], prec, train)
         z = ops.bn_act(y, co, relu=True)
         x, parg = ops.maxpool2d_fwd(z, want_arg=save)
@@ -142,7 +142,7 @@ class MVCNNEncoder(TriModule):
         dh, gr[self.mlp[2].weight], gr[self.mlp[2].bias] = linear_bwd(saved["h"], self.mlp[2].weight, saved["o"], do, 0, prec)
         df, gr[self.mlp[0].weight], gr[self.mlp[0].bias] = linear_bwd(saved["f"], self.mlp[0].weight, saved["h"], dh, 1, prec)
         dp, gr[self.net_2.weight], gr[self.net_2.bias] = linear_bwd(saved["pooled"], self.net_2.weight, saved["f"], df, 0, prec)
-        dout = ops.avgpool_viewmax_bwd(dp, saved["arg"], saved["feat_shape"], B, self.num_views)
+        dout = ops.avgpool_viewmax_bwd(dp, saved["arg"], saved["feat_shape"], B, self.num_views, dtype=ops.act_dtype(prec))
         blocks = self._blocks()
         side = self._side
 

@@ -76,7 +76,7 @@ class SparseCNNEncoder(TriModule):
     # ------------------------------------------------------------------ forward / backward implementations
     def _forward_impl(self, locs, feats, B, save: bool):
         prec, V, train = self._prec(), self.voxel_size, self.training
-        x, mask = ops.voxel_scatter(locs, feats, B, V)
+        x, mask = ops.voxel_scatter(locs, feats, B, V, dtype=ops.act_dtype(prec))
         count = ops.mask_count(mask, B * V ** 3)
         saved = {"levels": [], "B": B}
         for l in range(5):
@@ -96,7 +96,7 @@ class SparseCNNEncoder(TriModule):
             if save:
                 saved["levels"].append((x, y, mask, count, co, pooled))
             x, mask, count = pooled, mask_out, count_out
-        flat = x.view(B, -1)                                   # channels-last [B, v, v, v, C]
+        flat = x.view(B, -1).float()                           # channels-last [B, v, v, v, C]; the head runs in fp32
         h = linear_fwd(flat, self.mlp[0].weight, self.mlp[0].bias, 1, prec, spatial=self.spatial)
         o = linear_fwd(h, self.mlp[2].weight, self.mlp[2].bias, 0, prec)
         z, norm = ops.l2norm_fwd(o)
@@ -110,7 +110,7 @@ class SparseCNNEncoder(TriModule):
         do = ops.l2norm_bwd(saved["z"], saved["norm"], dz)
         dh, grads[17], grads[18] = linear_bwd(saved["h"], self.mlp[2].weight, saved["o"], do, 0, prec)
         dflat, grads[15], grads[16] = linear_bwd(saved["flat"], self.mlp[0].weight, saved["h"], dh, 1, prec, spatial=self.spatial)
-        dx = dflat
+        dx = dflat.to(ops.act_dtype(prec))
         for l in range(4, -1, -1):
             D, C = V >> l, self.chans[l + 1]
             g = self._geom(B, l)

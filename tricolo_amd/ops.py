@@ -71,6 +71,23 @@ def _f32(t):
     return t
 
 
+def _act(t):
+    """Activation tensor: contiguous fp32 (parity / bf16x3 mode) or bf16 (bf16 mode storage)."""
+    assert t.dtype in (torch.float32, torch.bfloat16) and t.is_contiguous(), "expected contiguous fp32 / bf16 activations"
+    return t
+
+
+def _abf(t) -> int:
+    return 1 if t.dtype == torch.bfloat16 else 0
+
+
+def act_dtype(precision: str):
+    """Storage type of the big activation tensors for a precision mode (TRICOLO_ACT_FP32=1 forces fp32 storage)."""
+    if precision == "bf16" and os.environ.get("TRICOLO_ACT_FP32", "0") != "1":
+        return torch.bfloat16
+    return torch.float32
+
+
 class ConvGeom:
     """Geometry + packed-weight buffers of one conv / linear layer.
 
@@ -133,14 +150,15 @@ def conv_fwd(x, g: ConvGeom, packed, row_mask=None, bias=None, act=0, want_stats
     hi, lo = packed
     OD, OH, OW = g.out_grid
     if out is None:
-        out = torch.empty((g.B, OD, OH, OW, g.cout), dtype=torch.float32, device=x.device)
+        out = torch.empty((g.B, OD, OH, OW, g.cout), dtype=x.dtype, device=x.device)
+    assert out.dtype == x.dtype
     stats = (torch.empty((g.num_mtiles["bf16x3" if lo is not None else "bf16"], 2, g.cout), dtype=torch.float32, device=x.device)
              if want_stats else None)
     ws = _workspace(g.fwd_ws, x.device) if g.fwd_ws else None
     check(_timed(_igemm_symbol(g.cout, lo is not None), g.flops,
-                 lambda: lib().tri_conv_fwd(_C.C.byref(g.desc), ptr(_f32(x)), ptr(hi), ptr(lo), ptr(out), ptr(row_mask), ptr(bias),
-                                            act, 1 if accumulate else 0, ptr(stats), ptr(ws), ws.numel() if ws is not None else 0,
-                                            stream())), "tri_conv_fwd")
+                 lambda: lib().tri_conv_fwd(_C.C.byref(g.desc), ptr(_act(x)), ptr(hi), ptr(lo), ptr(out), ptr(row_mask), ptr(bias),
+                                            act, 1 if accumulate else 0, ptr(stats), _abf(x), ptr(ws),
+                                            ws.numel() if ws is not None else 0, stream())), "tri_conv_fwd")
     return (out, stats) if want_stats else out
 
 
@@ -148,12 +166,13 @@ def conv_dgrad(dout, g: ConvGeom, packed_t, row_mask=None, out=None, accumulate=
     hi, lo = packed_t
     ID, IH, IW = g.in_grid
     if out is None:
-        out = torch.empty((g.B, ID, IH, IW, g.cin_stored), dtype=torch.float32, device=dout.device)
+        out = torch.empty((g.B, ID, IH, IW, g.cin_stored), dtype=dout.dtype, device=dout.device)
+    assert out.dtype == dout.dtype
     ws = _workspace(g.dgrad_ws, dout.device) if g.dgrad_ws else None
     check(_timed(_igemm_symbol(g.cin_stored, lo is not None), g.flops,
-                 lambda: lib().tri_conv_dgrad(_C.C.byref(g.desc), ptr(_f32(dout)), ptr(hi), ptr(lo), ptr(out), ptr(row_mask),
-                                              1 if accumulate else 0, ptr(ws), ws.numel() if ws is not None else 0, stream())),
-          "tri_conv_dgrad")
+                 lambda: lib().tri_conv_dgrad(_C.C.byref(g.desc), ptr(_act(dout)), ptr(hi), ptr(lo), ptr(out), ptr(row_mask),
+                                              1 if accumulate else 0, _abf(dout), ptr(ws), ws.numel() if ws is not None else 0,
+                                              stream())), "tri_conv_dgrad")
     return out
 
 
@@ -171,6 +190,7 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
 
 def conv_wgrad(x, dout, g: ConvGeom, like: torch.Tensor, precision: str, row_mask=None):
     """Gradient of the layer's parameter, returned in the parameter's own layout (shape of ``like``)."""
+    assert x.dtype == dout.dtype
     dw = torch.empty_like(like)
     ws = _workspace(g.wgrad_ws, x.device)
     plan = g.plan(x.device)
@@ -179,9 +199,9 @@ def conv_wgrad(x, dout, g: ConvGeom, like: torch.Tensor, precision: str, row_mas
     bj = 128 if bi == 128 else (256 if g.kpad <= 256 else 128)
     sym = f"conv_wgrad_kernel<{bi},{bj},{2 if precision == 'bf16x3' else 1}>"
     check(_timed(sym, g.flops,
-                 lambda: lib().tri_conv_wgrad(_C.C.byref(g.desc), ptr(_f32(x)), ptr(_f32(dout)), ptr(row_mask), ptr(plan), ptr(ws),
+                 lambda: lib().tri_conv_wgrad(_C.C.byref(g.desc), ptr(_act(x)), ptr(_act(dout)), ptr(row_mask), ptr(plan), ptr(ws),
                                               ws.numel(), ptr(dw), s_co, s_tap, s_ci, g.cin, 1 if precision == "bf16x3" else 0,
-                                              stream())),
+                                              _abf(x), stream())),
           "tri_conv_wgrad")
     return dw
 
@@ -213,15 +233,15 @@ def bn_eval_coeffs(C, gamma, beta, running_mean, running_var, eps=1e-5):
 def bn_act(y, co: BNCoeffs, relu=True, res=None, res_co: BNCoeffs | None = None):
     C = y.shape[-1]
     out = torch.empty_like(y)
-    check(lib().tri_bn_act(ptr(y), ptr(co.scale), ptr(co.shift), ptr(res), ptr(res_co.scale) if res_co else None,
-                           ptr(res_co.shift) if res_co else None, ptr(out), y.numel() // C, C, 1 if relu else 0, stream()),
+    check(lib().tri_bn_act(ptr(_act(y)), ptr(co.scale), ptr(co.shift), ptr(res), ptr(res_co.scale) if res_co else None,
+                           ptr(res_co.shift) if res_co else None, ptr(out), y.numel() // C, C, 1 if relu else 0, _abf(y), stream()),
           "tri_bn_act")
     return out
 
 
 def relu_bwd(dout, out, inplace=True):
     g = dout if inplace else torch.empty_like(dout)
-    check(lib().tri_relu_bwd(ptr(dout), ptr(out), ptr(g), dout.numel(), stream()), "tri_relu_bwd")
+    check(lib().tri_relu_bwd(ptr(_act(dout)), ptr(out), ptr(g), dout.numel(), _abf(dout), stream()), "tri_relu_bwd")
     return g
 
 
@@ -231,13 +251,14 @@ def bn_bwd(y, g, co: BNCoeffs, gamma, count_dev=None, count_host=0, row_mask=Non
     M = y.numel() // C
     nblk = lib().tri_bn_bwd_num_blocks(M)
     partial = torch.empty((nblk, 2, C), dtype=torch.float32, device=y.device)
-    check(lib().tri_bn_bwd_reduce(ptr(y), ptr(g), M, C, ptr(partial), stream()), "tri_bn_bwd_reduce")
+    assert y.dtype == g.dtype
+    check(lib().tri_bn_bwd_reduce(ptr(_act(y)), ptr(_act(g)), M, C, ptr(partial), _abf(y), stream()), "tri_bn_bwd_reduce")
     buf = torch.empty((5, C), dtype=torch.float32, device=y.device)
     check(lib().tri_bn_bwd_finalize(ptr(partial), nblk, C, ptr(count_dev), int(count_host), ptr(gamma), ptr(co.mean),
                                     ptr(co.invstd), ptr(buf[0]), ptr(buf[1]), ptr(buf[2]), ptr(buf[3]), ptr(buf[4]), stream()),
           "tri_bn_bwd_finalize")
     dy = g if inplace else torch.empty_like(g)
-    check(lib().tri_bn_bwd_apply(ptr(y), ptr(g), ptr(buf[2]), ptr(buf[3]), ptr(buf[4]), ptr(row_mask), ptr(dy), M, C, stream()),
+    check(lib().tri_bn_bwd_apply(ptr(y), ptr(g), ptr(buf[2]), ptr(buf[3]), ptr(buf[4]), ptr(row_mask), ptr(dy), M, C, _abf(y), stream()),
           "tri_bn_bwd_apply")
     return dy, buf[0], buf[1]
 
@@ -245,33 +266,34 @@ def bn_bwd(y, g, co: BNCoeffs, gamma, count_dev=None, count_host=0, row_mask=Non
 # ------------------------------------------------------------------------------------------------ pooling
 def bn_relu_pool3d_fwd(y, co: BNCoeffs, mask, B, D, C):
     Do = D // 2
-    pooled = torch.empty((B, Do, Do, Do, C), dtype=torch.float32, device=y.device)
+    pooled = torch.empty((B, Do, Do, Do, C), dtype=y.dtype, device=y.device)
     mask_out = torch.zeros(((B * Do ** 3 + 31) // 32 * 32,), dtype=torch.uint8, device=y.device)
-    check(lib().tri_bn_relu_pool3d_fwd(ptr(y), ptr(co.scale), ptr(co.shift), ptr(mask), B, D, C, ptr(pooled), ptr(mask_out),
-                                       stream()), "tri_bn_relu_pool3d_fwd")
+    check(lib().tri_bn_relu_pool3d_fwd(ptr(_act(y)), ptr(co.scale), ptr(co.shift), ptr(mask), B, D, C, ptr(pooled), ptr(mask_out),
+                                       _abf(y), stream()), "tri_bn_relu_pool3d_fwd")
     return pooled, mask_out
 
 
 def pool3d_bwd_route(y, co: BNCoeffs, mask, pooled, dpooled, B, D, C):
     g = torch.empty_like(y)
-    check(lib().tri_pool3d_bwd_route(ptr(y), ptr(co.scale), ptr(co.shift), ptr(mask), ptr(pooled), ptr(_f32(dpooled)), B, D, C,
-                                     ptr(g), stream()), "tri_pool3d_bwd_route")
+    assert dpooled.dtype == y.dtype and pooled.dtype == y.dtype
+    check(lib().tri_pool3d_bwd_route(ptr(_act(y)), ptr(co.scale), ptr(co.shift), ptr(mask), ptr(pooled), ptr(_act(dpooled)), B, D, C,
+                                     ptr(g), _abf(y), stream()), "tri_pool3d_bwd_route")
     return g
 
 
 def maxpool2d_fwd(x, want_arg=True):
     """3x3/2/pad-1 max-pool; also returns the winning-tap byte map used by maxpool2d_bwd."""
     N, _, H, W, C = x.shape
-    out = torch.empty((N, 1, (H + 1) // 2, (W + 1) // 2, C), dtype=torch.float32, device=x.device)
+    out = torch.empty((N, 1, (H + 1) // 2, (W + 1) // 2, C), dtype=x.dtype, device=x.device)
     arg = torch.empty(out.shape, dtype=torch.uint8, device=x.device) if want_arg else None
-    check(lib().tri_maxpool2d_fwd(ptr(x), N, H, W, C, ptr(out), ptr(arg), stream()), "tri_maxpool2d_fwd")
+    check(lib().tri_maxpool2d_fwd(ptr(_act(x)), N, H, W, C, ptr(out), ptr(arg), _abf(x), stream()), "tri_maxpool2d_fwd")
     return out, arg
 
 
 def maxpool2d_bwd(arg, dout, in_shape):
     N, _, H, W, C = in_shape
-    dx = torch.empty(in_shape, dtype=torch.float32, device=dout.device)
-    check(lib().tri_maxpool2d_bwd(ptr(arg), ptr(_f32(dout)), N, H, W, C, ptr(dx), stream()), "tri_maxpool2d_bwd")
+    dx = torch.empty(in_shape, dtype=dout.dtype, device=dout.device)
+    check(lib().tri_maxpool2d_bwd(ptr(arg), ptr(_act(dout)), N, H, W, C, ptr(dx), _abf(dout), stream()), "tri_maxpool2d_bwd")
     return dx
 
 
@@ -279,25 +301,25 @@ def avgpool_viewmax_fwd(x, B, V):
     N, _, H, W, C = x.shape
     out = torch.empty((B, C), dtype=torch.float32, device=x.device)
     arg = torch.empty((B, C), dtype=torch.int32, device=x.device)
-    check(lib().tri_avgpool_viewmax_fwd(ptr(x), B, V, H * W, C, ptr(out), ptr(arg), stream()), "tri_avgpool_viewmax_fwd")
+    check(lib().tri_avgpool_viewmax_fwd(ptr(_act(x)), B, V, H * W, C, ptr(out), ptr(arg), _abf(x), stream()), "tri_avgpool_viewmax_fwd")
     return out, arg
 
 
-def avgpool_viewmax_bwd(dout, arg, shape, B, V):
+def avgpool_viewmax_bwd(dout, arg, shape, B, V, dtype=torch.float32):
     N, _, H, W, C = shape
-    dx = torch.empty(shape, dtype=torch.float32, device=dout.device)
-    check(lib().tri_avgpool_viewmax_bwd(ptr(_f32(dout)), ptr(arg), B, V, H * W, C, ptr(dx), stream()), "tri_avgpool_viewmax_bwd")
+    dx = torch.empty(shape, dtype=dtype, device=dout.device)
+    check(lib().tri_avgpool_viewmax_bwd(ptr(_f32(dout)), ptr(arg), B, V, H * W, C, ptr(dx), _abf(dx), stream()), "tri_avgpool_viewmax_bwd")
     return dx
 
 
 # ------------------------------------------------------------------------------------------------ layouts
-def voxel_scatter(locs, feats, B, V):
+def voxel_scatter(locs, feats, B, V, dtype=torch.float32):
     n = locs.shape[0]
-    dense = torch.empty((B, V, V, V, 4), dtype=torch.float32, device=feats.device)
+    dense = torch.empty((B, V, V, V, 4), dtype=dtype, device=feats.device)
     sites = B * V ** 3
     mask = torch.zeros(((sites + 31) // 32 * 32,), dtype=torch.uint8, device=feats.device)
     locs = locs.to(torch.int32).contiguous()
-    check(lib().tri_voxel_scatter(ptr(locs), ptr(_f32(feats.contiguous())), n, B, V, ptr(dense), ptr(mask), stream()),
+    check(lib().tri_voxel_scatter(ptr(locs), ptr(_f32(feats.contiguous())), n, B, V, ptr(dense), ptr(mask), _abf(dense), stream()),
           "tri_voxel_scatter")
     return dense, mask
 
@@ -308,11 +330,11 @@ def mask_count(mask, n):
     return cnt
 
 
-def nchw3_to_nhwc4(x):
+def nchw3_to_nhwc4(x, dtype=torch.float32):
     N, C, H, W = x.shape
     assert C == 3
-    out = torch.empty((N, 1, H, W, 4), dtype=torch.float32, device=x.device)
-    check(lib().tri_nchw3_to_nhwc4(ptr(_f32(x.contiguous())), N, H, W, ptr(out), stream()), "tri_nchw3_to_nhwc4")
+    out = torch.empty((N, 1, H, W, 4), dtype=dtype, device=x.device)
+    check(lib().tri_nchw3_to_nhwc4(ptr(_f32(x.contiguous())), N, H, W, ptr(out), _abf(out), stream()), "tri_nchw3_to_nhwc4")
     return out
 
 
