@@ -38,6 +38,15 @@ typedef struct TriConvDesc {
  * Layouts: spconv SubMConv3d weight [Cout,kd,kh,kw,Cin] (sparse_cnn.py:12-32), torchvision conv [Cout,Cin,kh,kw]
  * (mv_cnn.py:44), nn.Linear [out,in]. */
 int tri_conv_kpad(int ntaps, int cin_stored);
+/* one packing job; tri_weight_prep_multi runs an array of them (DEVICE memory) in a single launch - one per tower and step */
+typedef struct TriPrepDesc {
+    const float* w;
+    void* hi;
+    void* lo;            /* NULL in plain bf16 mode */
+    long s_row, s_tap, s_inner;
+    int rows, ntaps, inner, inner_pad, kpad, reserved;
+} TriPrepDesc;
+int tri_weight_prep_multi(const TriPrepDesc* descs_dev, int n, void* stream);
 int tri_weight_prep(const float* w, long s_row, long s_tap, long s_inner, int rows, int ntaps, int inner, int inner_pad,
                     void* w_hi, void* w_lo, void* stream);
 

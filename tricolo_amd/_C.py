@@ -19,6 +19,12 @@ class TriConvDesc(C.Structure):
                                        "KD", "KH", "KW", "stride", "pad_d", "pad_h", "pad_w")]
 
 
+class TriPrepDesc(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("hi", C.c_void_p), ("lo", C.c_void_p), ("s_row", C.c_long), ("s_tap", C.c_long),
+                ("s_inner", C.c_long), ("rows", C.c_int), ("ntaps", C.c_int), ("inner", C.c_int), ("inner_pad", C.c_int),
+                ("kpad", C.c_int), ("reserved", C.c_int)]
+
+
 P, I, L, F, Z = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
 DP = C.POINTER(TriConvDesc)
 
@@ -28,6 +34,7 @@ SIGNATURES = {
     "tri_last_error": (C.c_char_p, []),
     "tri_conv_kpad": (I, [I, I]),
     "tri_weight_prep": (I, [P, L, L, L, I, I, I, I, P, P, P]),
+    "tri_weight_prep_multi": (I, [P, I, P]),
     "tri_conv_num_mtiles": (I, [DP, I]),
     "tri_conv_workspace": (Z, [DP, I]),
     "tri_conv_fwd": (I, [DP, P, P, P, P, P, P, I, I, P, I, P, Z, P]),

@@ -640,6 +640,29 @@ __global__ void weight_prep_kernel(const float* __restrict__ w, long s_row, long
     if (lo) lo[idx] = (bf16_t)(v - (float)h);
 }
 
+// All layers of a tower in ONE launch: blockIdx.y selects the descriptor, blockIdx.x grid-strides over its elements.
+__global__ void weight_prep_multi_kernel(const TriPrepDesc* __restrict__ descs) {
+    const TriPrepDesc d = descs[blockIdx.y];
+    const long total = (long)d.rows * d.kpad;
+    bf16_t* hi = (bf16_t*)d.hi;
+    bf16_t* lo = (bf16_t*)d.lo;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        int row = (int)(idx / d.kpad), k = (int)(idx - (long)row * d.kpad);
+        int tap = k / d.inner_pad, i = k - tap * d.inner_pad;
+        float v = 0.f;
+        if (tap < d.ntaps && i < d.inner) v = d.w[row * d.s_row + tap * d.s_tap + i * d.s_inner];
+        bf16_t h = (bf16_t)v;
+        hi[idx] = h;
+        if (lo) lo[idx] = (bf16_t)(v - (float)h);
+    }
+}
+
+extern "C" int tri_weight_prep_multi(const TriPrepDesc* descs_dev, int n, void* stream) {
+    if (n <= 0) return TRI_OK;
+    weight_prep_multi_kernel<<<dim3(256, n), 256, 0, (hipStream_t)stream>>>(descs_dev);
+    return tri_check_launch("tri_weight_prep_multi");
+}
+
 extern "C" int tri_weight_prep(const float* w, long s_row, long s_tap, long s_inner, int rows, int ntaps, int inner,
                                int inner_pad, void* w_hi, void* w_lo, void* stream) {
     if (inner_pad % 4 != 0 || inner > inner_pad) { tri_set_error("tri_weight_prep: inner_pad must be a multiple of 4 >= inner"); return TRI_ERR_ARG; }

@@ -60,6 +60,8 @@ class MVCNNEncoder(TriModule):
         self.net_2 = nn.Linear(512, z_dim)
         self.mlp = nn.Sequential(nn.Linear(z_dim, out_dim), nn.ReLU(inplace=True), nn.Linear(out_dim, out_dim))
         self._geoms = {}
+        self.__dict__["_packers"] = {}
+        self.__dict__["_packed"] = {}
         self.__dict__["_side"] = SideStream("img")
 
     def _prec(self):
@@ -89,10 +91,34 @@ class MVCNNEncoder(TriModule):
             self._geoms[key] = g
         return g
 
+    def _pack_all(self, N, H, W, prec, train, device):
+        """One packing launch for every conv of the trunk (forward operands, plus data-gradient operands when training)."""
+        key = (N, H, W, train)
+        packer = self._packers.get(key)
+        if packer is None:
+            packer = ops.WeightPacker()
+            convs = [(self.net_1[0], H, W)]
+            h, w = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+            h, w = (h + 1) // 2, (w + 1) // 2
+            for blk in self._blocks():
+                s = blk.conv1.stride[0]
+                convs.append((blk.conv1, h, w))
+                if blk.downsample is not None:
+                    convs.append((blk.downsample[0], h, w))
+                h, w = (h + 2 - 3) // s + 1, (w + 2 - 3) // s + 1
+                convs.append((blk.conv2, h, w))
+            for conv, ch, cw in convs:
+                g = self._geom2d(N, ch, cw, conv)
+                packer.add((id(conv), False), conv.weight, g)
+                if train and conv is not self.net_1[0]:
+                    packer.add((id(conv), True), conv.weight, g, transposed=True)
+            self._packers[key] = packer
+        return packer.run(prec, device)
+
     def _conv_bn(self, x, conv, bn, prec, train):
         N, _, H, W, _ = x.shape
         g = self._geom2d(N, H, W, conv)
-        packed = ops.pack_weight(conv.weight, g, prec)
+        packed = self._packed[(id(conv), False)]
         if train:
             y, stats = ops.conv_fwd(x, g, packed, want_stats=True)
             co = ops.bn_finalize(stats, g.cout, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
@@ -108,6 +134,7 @@ class MVCNNEncoder(TriModule):
         if N % self.num_views:
             raise RuntimeError("mat shape: number of images is not a multiple of num_views")
         B = N // self.num_views
+        self._packed = self._pack_all(N, images.shape[2], images.shape[3], prec, train and save, images.device)
         x0 = ops.nchw3_to_nhwc4(images, dtype=ops.act_dtype(prec))
         y, co, g = self._conv_bn(x0, self.net_1[0], self.net_1[1], prec, train)
         z = ops.bn_act(y, co, relu=True)
@@ -156,7 +183,7 @@ class MVCNNEncoder(TriModule):
             g = ops.relu_bwd(dout, out)                                       # grad of the block's pre-activation sum
             dy2, gr[blk.bn2.weight], gr[blk.bn2.bias] = ops.bn_bwd(y2, g, co2, blk.bn2.weight, count_host=g2.M, inplace=False)
             wgrad_async(a1, dy2, g2, blk.conv2.weight)
-            da1 = ops.conv_dgrad(dy2, g2, ops.pack_weight(blk.conv2.weight, g2, prec, transposed=True))
+            da1 = ops.conv_dgrad(dy2, g2, self._packed[(id(blk.conv2), True)])
             g1z = ops.relu_bwd(da1, a1)
             dy1, gr[blk.bn1.weight], gr[blk.bn1.bias] = ops.bn_bwd(y1, g1z, co1, blk.bn1.weight, count_host=g1.M)
             wgrad_async(x, dy1, g1, blk.conv1.weight)
@@ -164,10 +191,10 @@ class MVCNNEncoder(TriModule):
                 dyd, gr[blk.downsample[1].weight], gr[blk.downsample[1].bias] = ops.bn_bwd(
                     yd, g, cod, blk.downsample[1].weight, count_host=gd.M)
                 wgrad_async(x, dyd, gd, blk.downsample[0].weight)
-                dx = ops.conv_dgrad(dyd, gd, ops.pack_weight(blk.downsample[0].weight, gd, prec, transposed=True))
+                dx = ops.conv_dgrad(dyd, gd, self._packed[(id(blk.downsample[0]), True)])
             else:
                 dx = g                                                         # identity branch
-            dx = ops.conv_dgrad(dy1, g1, ops.pack_weight(blk.conv1.weight, g1, prec, transposed=True), out=dx, accumulate=True)
+            dx = ops.conv_dgrad(dy1, g1, self._packed[(id(blk.conv1), True)], out=dx, accumulate=True)
             dout = dx
         x0, y, co, g0, z, parg = saved["stem"]
         dzs = ops.maxpool2d_bwd(parg, dout, tuple(z.shape))

@@ -49,6 +49,8 @@ class SparseCNNEncoder(TriModule):
         self.spatial = (voxel_size // 32) ** 3
         self.mlp = nn.Sequential(nn.Linear(z_dim * self.spatial, out_dim), nn.ReLU(inplace=True), nn.Linear(out_dim, out_dim))
         self._geoms = {}
+        self.__dict__["_packers"] = {}
+        self.__dict__["_packed"] = {}
 
     # ------------------------------------------------------------------ parameter plumbing
     def _param_list(self):
@@ -73,9 +75,24 @@ class SparseCNNEncoder(TriModule):
     def _prec(self):
         return self.precision or ops.default_precision()
 
+    def _pack_all(self, B, prec, train, device):
+        """One packing launch for the five conv layers (forward operands + data-gradient operands of levels 1-4)."""
+        key = (B, train)
+        packer = self._packers.get(key)
+        if packer is None:
+            packer = ops.WeightPacker()
+            for l in range(5):
+                w, g = self.sparseModel[str(4 * l)].weight, self._geom(B, l)
+                packer.add((l, False), w, g)
+                if train and l > 0:
+                    packer.add((l, True), w, g, transposed=True)
+            self._packers[key] = packer
+        return packer.run(prec, device)
+
     # ------------------------------------------------------------------ forward / backward implementations
     def _forward_impl(self, locs, feats, B, save: bool):
         prec, V, train = self._prec(), self.voxel_size, self.training
+        self._packed = self._pack_all(B, prec, train and save, feats.device)
         x, mask = ops.voxel_scatter(locs, feats, B, V, dtype=ops.act_dtype(prec))
         count = ops.mask_count(mask, B * V ** 3)
         saved = {"levels": [], "B": B}
@@ -83,7 +100,7 @@ class SparseCNNEncoder(TriModule):
             D, C = V >> l, self.chans[l + 1]
             g = self._geom(B, l)
             conv, bn = self.sparseModel[str(4 * l)], self.sparseModel[str(4 * l + 1)]
-            packed = ops.pack_weight(conv.weight, g, prec)
+            packed = self._packed[(l, False)]
             if train:
                 y, stats = ops.conv_fwd(x, g, packed, row_mask=mask, want_stats=True)
                 co = ops.bn_finalize(stats, C, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
@@ -121,8 +138,7 @@ class SparseCNNEncoder(TriModule):
             grads[3 * l] = ops.conv_wgrad(x, dy, g, conv.weight, prec, row_mask=mask)
             grads[3 * l + 1], grads[3 * l + 2] = dgamma, dbeta
             if l > 0:
-                packed_t = ops.pack_weight(conv.weight, g, prec, transposed=True)
-                dx = ops.conv_dgrad(dy, g, packed_t, row_mask=mask)
+                dx = ops.conv_dgrad(dy, g, self._packed[(l, True)], row_mask=mask)
         return grads
 
     def forward(self, x, batch_size):

@@ -146,6 +146,53 @@ def pack_weight(w: torch.Tensor, g: ConvGeom, precision: str, transposed: bool =
     return hi, lo
 
 
+class WeightPacker:
+    """Packs the MFMA operand rows of every layer of a tower in ONE launch per step (forward + data-gradient operands).
+
+    Entries are registered once (parameter, geometry, direction); the packed buffers and the device-side descriptor
+    table are persistent, so a step costs one kernel instead of one per layer.  The table is rebuilt if a parameter's
+    storage moved (e.g. after FusedAdam re-bound the parameters to its flat buffer)."""
+
+    def __init__(self):
+        self.entries = {}            # key -> (param, geom, transposed)
+        self._tables = {}            # precision -> (desc tensor, n, {key: (hi, lo)}, ptr snapshot)
+
+    def add(self, key, param, g: "ConvGeom", transposed: bool = False):
+        if key not in self.entries:
+            self.entries[key] = (param, g, transposed)
+            self._tables.clear()
+
+    def _build(self, precision, device):
+        descs = (_C.TriPrepDesc * len(self.entries))()
+        bufs = {}
+        for i, (key, (w, g, tr)) in enumerate(self.entries.items()):
+            s_co, s_tap, s_ci = g.strides
+            if not tr:
+                rows, inner, inner_pad, kpad, s_row, s_inner = g.cout, g.cin, g.cin_stored, g.kpad, s_co, s_ci
+            else:
+                rows, inner, inner_pad, kpad, s_row, s_inner = g.cin_stored, g.cout, g.cout, g.kpad_t, s_ci, s_co
+            hi = torch.empty((rows, kpad), dtype=torch.bfloat16, device=device)
+            lo = torch.empty_like(hi) if precision == "bf16x3" else None
+            bufs[key] = (hi, lo)
+            d = descs[i]
+            d.w, d.hi, d.lo = w.data_ptr(), hi.data_ptr(), (lo.data_ptr() if lo is not None else None)
+            d.s_row, d.s_tap, d.s_inner = s_row, s_tap, s_inner
+            d.rows, d.ntaps, d.inner, d.inner_pad, d.kpad = rows, g.ntaps, inner, inner_pad, kpad
+        raw = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(device)
+        snap = tuple(w.data_ptr() for (w, _, _) in self.entries.values())
+        return raw, len(self.entries), bufs, snap
+
+    def run(self, precision, device):
+        """Launch the packing of all registered layers; returns {key: (hi, lo)}."""
+        tab = self._tables.get(precision)
+        if tab is None or tab[3] != tuple(w.data_ptr() for (w, _, _) in self.entries.values()):
+            tab = self._build(precision, device)
+            self._tables[precision] = tab
+        raw, n, bufs, _ = tab
+        check(lib().tri_weight_prep_multi(ptr(raw), n, stream()), "tri_weight_prep_multi")
+        return bufs
+
+
 def conv_fwd(x, g: ConvGeom, packed, row_mask=None, bias=None, act=0, want_stats=False, out=None, accumulate=False):
     hi, lo = packed
     OD, OH, OW = g.out_grid
