@@ -172,6 +172,11 @@ def main():
     if rank == 0:
         ops.TIMER = ops.KernelTimer()
         nprof = 3
+        # serialise the streams for this leg: a kernel's HIP-event duration must not include the other towers' kernels
+        # sharing the GPU with it (the timed region above keeps towers / weight gradients on parallel streams)
+        net.overlap_towers = False
+        if getattr(net.image_encoder, "_side", None) is not None:
+            net.image_encoder._side.enabled = False
         for i in range(nprof):
             # park the GPU on a spin kernel first so the host enqueues the whole step ahead of it: the HIP events then
             # bracket back-to-back kernel execution instead of host launch gaps (eager launches cost ~10 us each)

@@ -61,9 +61,10 @@ def _timed(symbol, flops, fn):
     return TIMER.run(symbol, flops, fn) if TIMER is not None else fn()
 
 
-def _igemm_symbol(cout, split):
+def _igemm_symbol(cout, split, t=None):
     bn = 128 if cout % 128 == 0 else (64 if cout % 64 == 0 else 32)
-    return f"conv_igemm_kernel<{bn},{2 if split else 1}>"
+    at = "bf16" if (t is not None and t.dtype == torch.bfloat16) else "float"
+    return f"conv_igemm_kernel<{bn},{2 if split else 1},{at}>"
 
 
 def _f32(t):
@@ -202,7 +203,7 @@ def conv_fwd(x, g: ConvGeom, packed, row_mask=None, bias=None, act=0, want_stats
     stats = (torch.empty((g.num_mtiles["bf16x3" if lo is not None else "bf16"], 2, g.cout), dtype=torch.float32, device=x.device)
              if want_stats else None)
     ws = _workspace(g.fwd_ws, x.device) if g.fwd_ws else None
-    check(_timed(_igemm_symbol(g.cout, lo is not None), g.flops,
+    check(_timed(_igemm_symbol(g.cout, lo is not None, x), g.flops,
                  lambda: lib().tri_conv_fwd(_C.C.byref(g.desc), ptr(_act(x)), ptr(hi), ptr(lo), ptr(out), ptr(row_mask), ptr(bias),
                                             act, 1 if accumulate else 0, ptr(stats), _abf(x), ptr(ws),
                                             ws.numel() if ws is not None else 0, stream())), "tri_conv_fwd")
@@ -216,7 +217,7 @@ def conv_dgrad(dout, g: ConvGeom, packed_t, row_mask=None, out=None, accumulate=
         out = torch.empty((g.B, ID, IH, IW, g.cin_stored), dtype=dout.dtype, device=dout.device)
     assert out.dtype == dout.dtype
     ws = _workspace(g.dgrad_ws, dout.device) if g.dgrad_ws else None
-    check(_timed(_igemm_symbol(g.cin_stored, lo is not None), g.flops,
+    check(_timed(_igemm_symbol(g.cin_stored, lo is not None, dout), g.flops,
                  lambda: lib().tri_conv_dgrad(_C.C.byref(g.desc), ptr(_act(dout)), ptr(hi), ptr(lo), ptr(out), ptr(row_mask),
                                               1 if accumulate else 0, _abf(dout), ptr(ws), ws.numel() if ws is not None else 0,
                                               stream())), "tri_conv_dgrad")
@@ -244,7 +245,7 @@ def conv_wgrad(x, dout, g: ConvGeom, like: torch.Tensor, precision: str, row_mas
     s_co, s_tap, s_ci = g.strides
     bi = 128 if (g.cout % 128 == 0 and g.kpad >= 128) else 64
     bj = 128 if bi == 128 else (256 if g.kpad <= 256 else 128)
-    sym = f"conv_wgrad_kernel<{bi},{bj},{2 if precision == 'bf16x3' else 1}>"
+    sym = f"conv_wgrad_kernel<{bi},{bj},{2 if precision == 'bf16x3' else 1},{'bf16' if x.dtype == torch.bfloat16 else 'float'}>"
     check(_timed(sym, g.flops,
                  lambda: lib().tri_conv_wgrad(_C.C.byref(g.desc), ptr(_act(x)), ptr(_act(dout)), ptr(row_mask), ptr(plan), ptr(ws),
                                               ws.numel(), ptr(dw), s_co, s_tap, s_ci, g.cin, 1 if precision == "bf16x3" else 0,
