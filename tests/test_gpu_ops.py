@@ -405,7 +405,11 @@ def test_gru_recurrence_matches_explicit_equations(precision, tol, B, L):
 
 
 # ------------------------------------------------------------------------------------------- bf16 activation storage
-BF16_CASES = [c for c in CONV_CASES if c[0] in ("vox_l0", "vox_l1", "stem7x7", "c3x3s1", "c3x3s2", "c1x1s2", "odd14")]
+BF16_CASES = [c for c in CONV_CASES if c[0] in ("vox_l0", "vox_l1", "vox_l3", "stem7x7", "c3x3s1", "c3x3s2", "c1x1s2", "odd14", "linear", "clip768")] + [
+    # Cin % 64 == 0 layers run the LDS-DMA kernel in this mode; these two fill the GPU (no split-K) / use Cout % 128 != 0
+    ("big_nosplit", 12, (1, 64, 64), 64, 64, (1, 3, 3), 1, (0, 1, 1), "torch"),
+    ("cout192", 2, (1, 12, 12), 128, 192, (1, 3, 3), 1, (0, 1, 1), "torch"),
+]
 
 
 @pytest.mark.parametrize("case", BF16_CASES, ids=[c[0] for c in BF16_CASES])
@@ -429,6 +433,31 @@ def test_conv_bf16_storage_integer_exact(case):
     if case[3] != 3:
         dx = ops.conv_dgrad(cl3(dy).to(DEV).to(torch.bfloat16), g, ops.pack_weight(wp.to(DEV), g, "bf16", transposed=True))
         assert torch.equal(dx.cpu(), cl3(xr.grad).to(torch.bfloat16))
+
+
+def test_conv_bf16_storage_masked_stats():
+    """Submanifold rule + BatchNorm partial sums through the LDS-DMA kernel (Cin = 64) and its split-K finish."""
+    case = ("vox_m", 2, (8, 8, 8), 64, 128, (3, 3, 3), 1, (1, 1, 1), "spconv")
+    x, w, wp, xcl, g = make_case(case, integer=True, seed=61)
+    M = 2 * 512
+    gen = torch.Generator().manual_seed(9)
+    mask = (torch.rand(M, generator=gen) < 0.3).to(torch.uint8)
+    mask[:256] = 0                                                  # two fully inactive 128-row tiles
+    full = cl3(F.conv3d(x, w, padding=1)).reshape(M, -1)
+    ref = (full * mask[:, None].float()).to(torch.bfloat16)
+    packed = ops.pack_weight(wp.to(DEV), g, "bf16")
+    out, stats = ops.conv_fwd(xcl.to(DEV).to(torch.bfloat16), g, packed, row_mask=mask.to(DEV), want_stats=True)
+    assert torch.equal(out.cpu().reshape(M, -1), ref)
+    st = stats.cpu().double().sum(0)
+    exact = ref.double()                                            # statistics of what BatchNorm reads back (the stored bf16)
+    np.testing.assert_allclose(st[0].numpy(), exact.sum(0).numpy(), rtol=1e-6, atol=1e-3)
+    np.testing.assert_allclose(st[1].numpy(), (exact ** 2).sum(0).numpy(), rtol=1e-6, atol=1e-3)
+    dy = ints((M, 128), -2, 2, 63) * mask[:, None].float()
+    xr = x.clone().requires_grad_()
+    F.conv3d(xr, w, padding=1).backward(cf3(dy.view(2, 8, 8, 8, 128)))
+    dx = ops.conv_dgrad(dy.view(2, 8, 8, 8, 128).to(DEV).to(torch.bfloat16), g, ops.pack_weight(wp.to(DEV), g, "bf16", transposed=True),
+                        row_mask=mask.to(DEV))
+    assert torch.equal(dx.cpu().reshape(M, -1), (cl3(xr.grad).reshape(M, -1) * mask[:, None].float()).to(torch.bfloat16))
 
 
 def test_elementwise_kernels_bf16_storage():

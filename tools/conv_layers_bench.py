@@ -93,6 +93,7 @@ def main():
         if mask is not None:
             x = x * mask[:g.M_in].view(g.B, ID, IH, IW, 1).float()
             dy = dy * mask[:g.M].view(g.B, OD, OH, OW, 1).float()
+        x, dy = x.to(ops.act_dtype(prec)), dy.to(ops.act_dtype(prec))     # bf16 mode stores activations as bf16
         w = torch.randn(g.cout * g.ntaps * g.cin, device=dev) * 0.05
         packed = ops.pack_weight(w, g, prec)
         t_f = time_it(lambda: ops.conv_fwd(x, g, packed, row_mask=mask, want_stats=True))

@@ -577,6 +577,172 @@ __global__ __launch_bounds__(256) void conv_brick_kernel(const ConvArgs p) {
     conv_epilogue<AT, BN, TM, TN, WAVES_M, WM, WN>(p, acc, m0, n0, mtile, wm, wn, fr, fq, t, split, any_active, red);
 }
 
+// ================================================================================================ LDS-DMA kernel
+// bf16 activation storage + Cin % 64 == 0 (every 3x3 / 1x1 layer of ResNet-18 past the stem, voxel levels 2-4 and all
+// their data gradients): the operands in HBM already ARE the MFMA operand bytes, so both tiles go global -> LDS with
+// buffer_load_dwordx4 ... lds (no VGPR round trip, no cvt, no ds_write), BK = 64 (half the barriers / address work per
+// MFMA, 16-32 MFMAs per wave-iteration) and the DMA of step k+1 in flight under the MFMAs of step k.
+// One wave-instruction writes 1 KiB = 8 tile rows x 128 B contiguously (LDS address = wave base + lane * 16), so the
+// bank swizzle is applied on the SOURCE side: lane (row, slot) fetches chunk slot ^ ((row >> 1) & 7) and the
+// fragment reads apply the same XOR (cdna_hip_programming.md rule 21).  Invalid (row, tap) pairs use an out-of-range
+// buffer offset, for which the buffer unit returns - and writes to LDS - zeros.
+// 16 bytes per lane, global -> LDS at (wave-uniform dst) + lane * 16.  The LDS address space only exists in the device
+// pass, so the builtin is hidden from the host pass (which only needs the kernel's launch stub).
+__device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t rsrc, char* dst, int voff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)dst, 16, voff, 0, 0, 0);
+#endif
+}
+
+template <int BN>
+__global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs p) {
+    typedef bf16_t AT;
+    constexpr int BM = 128, BK = 64;
+    constexpr int WAVES_N = 2, WAVES_M = 2;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 16, TN = WN / 16;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* lut_off = (int*)(smem + 2 * STAGE);
+    int* lut_sh = lut_off + 64;
+    float* red = (float*)(smem + 2 * STAGE + 512);
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int NT = p.Cout / BN;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int mtile = wg / NT, ntile = wg - mtile * NT;
+    const int m0 = mtile * BM, n0 = ntile * BN;
+    const int sshift = (p.stride == 2) ? 1 : 0;
+
+    if (t < 64) {
+        int kd = 0, kh = 0, kw = 0;
+        if (t < p.ntaps) {
+            kw = t % p.KW;
+            int r = t / p.KW;
+            kh = r % p.KH;
+            kd = r / p.KH;
+        }
+        lut_sh[t] = kw | ((8 + kh) << 8) | ((16 + kd) << 16);
+        lut_off[t] = p.transposed ? -((((kd >> sshift) * p.IH + (kh >> sshift)) * p.IW + (kw >> sshift)) * p.Cin)
+                                  : (((kd * p.IH + kh) * p.IW + kw) * p.Cin);
+    }
+
+    // DMA rows of this lane: row = (t >> 3) + 32 i, slot = t & 7 (16-byte chunk position inside the 128-B LDS row)
+    const int slot = t & 7;
+    int rowoff[4];
+    unsigned rmask[4];
+    int any_active = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int row = (t >> 3) + 32 * i;
+        int m = m0 + row;
+        bool valid = m < p.M;
+        uint32_t mm = valid ? (uint32_t)m : 0u;
+        uint32_t q1 = fdiv(mm, p.dOW);
+        int ow = mm - q1 * p.OW;
+        uint32_t q2 = fdiv(q1, p.dOH);
+        int oh = q1 - q2 * p.OH;
+        uint32_t b = fdiv(q2, p.dOD);
+        int od = q2 - b * p.OD;
+        if (p.row_mask) valid = valid && (p.row_mask[mm] != 0);
+        any_active |= valid ? 1 : 0;
+        unsigned mk;
+        int z0, y0, x0;
+        if (p.transposed) {
+            int rz = od + p.pd, ry = oh + p.ph, rx = ow + p.pw;
+            z0 = rz >> sshift; y0 = ry >> sshift; x0 = rx >> sshift;
+            mk = axis_mask_t(rx, p.KW, p.IW, p.stride) | (axis_mask_t(ry, p.KH, p.IH, p.stride) << 8) |
+                 (axis_mask_t(rz, p.KD, p.ID, p.stride) << 16);
+        } else {
+            z0 = od * p.stride - p.pd; y0 = oh * p.stride - p.ph; x0 = ow * p.stride - p.pw;
+            mk = axis_mask(x0, p.KW, p.IW) | (axis_mask(y0, p.KH, p.IH) << 8) | (axis_mask(z0, p.KD, p.ID) << 16);
+        }
+        rmask[i] = valid ? mk : 0u;
+        // byte offset of the chunk this lane fetches for that row (tap / channel-step offsets are added per k-step)
+        rowoff[i] = (((((int)b * p.ID + z0) * p.IH + y0) * p.IW + x0) * p.Cin + (slot ^ ((row >> 1) & 7)) * 8) * 2;
+    }
+    any_active = __syncthreads_or(any_active);
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int split = blockIdx.y;
+
+    if (any_active) {
+        const int nk_total = p.Kpad >> 6;
+        const int ks0 = split * p.steps_per_split;
+        const int ks1 = min(nk_total, ks0 + p.steps_per_split);
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t wrsrc =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(p.w_hi + (size_t)n0 * p.Kpad), 0, (unsigned)(BN * p.Kpad * 2), 0x00020000);
+        int woff[BN / 32];
+#pragma unroll
+        for (int i = 0; i < BN / 32; ++i) {
+            int n = (t >> 3) + 32 * i;
+            woff[i] = (n * p.Kpad + (slot ^ ((n >> 1) & 7)) * 8) * 2;
+        }
+
+        auto issue = [&](int ks, int buf) {
+            char* base = smem + buf * STAGE;
+            const int kb = ks * BK;
+            int tap, c0;
+            if (p.cin_shift >= 0) { tap = kb >> p.cin_shift; c0 = kb & ((1 << p.cin_shift) - 1); }
+            else { tap = (int)fdiv((uint32_t)kb, p.dCin); c0 = kb - tap * p.Cin; }
+            const bool tv = tap < p.ntaps;
+            const int toff = (lut_off[tv ? tap : 0] + c0) * 2;
+            const int sh = lut_sh[tv ? tap : 0];
+            const int sx = sh & 255, sy = (sh >> 8) & 255, sz = (sh >> 16) & 255;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                unsigned mk = rmask[i];
+                bool ok = tv && (((mk >> sx) & (mk >> sy) & (mk >> sz)) & 1u);
+                int voff = ok ? rowoff[i] + toff : (int)0x80000000;         // out of range -> zeros land in LDS, branch-free
+                char* dst = base + (wave * 8 + 32 * i) * 128;              // wave-uniform; the hardware adds lane * 16
+                dma16(rsrc, dst, voff);
+            }
+#pragma unroll
+            for (int i = 0; i < BN / 32; ++i) {
+                char* dst = base + A_BYTES + (wave * 8 + 32 * i) * 128;
+                dma16(wrsrc, dst, woff[i] + kb * 2);
+            }
+        };
+        auto compute = [&](int buf) {
+            const char* base = smem + buf * STAGE;
+            const char* bb = base + A_BYTES;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 ah[TM];
+#pragma unroll
+                for (int a = 0; a < TM; ++a) ah[a] = *(const bf16x8*)(base + brick_off<64>(wm * WM + a * 16 + fr, kk * 4 + fq));
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    bf16x8 bhf = *(const bf16x8*)(bb + brick_off<64>(wn * WN + b * 16 + fr, kk * 4 + fq));
+#pragma unroll
+                    for (int a = 0; a < TM; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhf, ah[a], acc[a][b], 0, 0, 0);
+                }
+            }
+        };
+
+        if (ks0 < ks1) {
+            issue(ks0, 0);
+            for (int ks = ks0; ks < ks1; ++ks) {
+                const int buf = (ks - ks0) & 1;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's DMAs of stage `buf` have landed
+                __builtin_amdgcn_s_barrier();                            // ... and everybody else's; all reads of buf^1 are done
+                asm volatile("" ::: "memory");
+                if (ks + 1 < ks1) issue(ks + 1, buf ^ 1);                // next stage streams in under the MFMAs below
+                compute(buf);
+            }
+        }
+        __syncthreads();
+    }
+    conv_epilogue<AT, BN, TM, TN, WAVES_M, WM, WN>(p, acc, m0, n0, mtile, wm, wn, fr, fq, t, split, any_active, red);
+}
+
 // out = act(sum_split slab + bias) * mask (+ out), plus BatchNorm partial sums per 32-row chunk.
 // One block = 32 rows x 64 columns (16 row lanes x 16 float4 column groups), grid = (row chunks, column chunks), so even
 // a 256-row layer spreads its slab read over dozens of CUs.
@@ -703,6 +869,7 @@ static int conv_bn(int cout) { return cout % 128 == 0 ? 128 : (cout % 64 == 0 ? 
 
 // One plan per (geometry, direction), used by the launchers AND by the workspace / statistics-size queries.
 struct ConvPlan {
+    int dma;              // 1: LDS-DMA kernel (bf16 activation storage, Cin % 64 == 0), 64-wide k-steps
     int brick;            // 0 generic im2col kernel, else channel chunk CB (32 / 64) of the brick kernel
     int R, brick_rows;    // brick: halo reach and staged rows
     int nunits;           // brick: (channel chunk, tap) units;  generic: 32-wide k-steps
@@ -719,6 +886,13 @@ static bool brick_disabled() {
 }
 
 // dims: grid of the rows (M side) == grid of the gathered tensor for brick-eligible layers
+static bool dma_disabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("TRICOLO_NO_DMA"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+
+// split_mode: 0 bf16 operands / fp32 activations, 1 bf16x3 (hi + lo operands), 2 bf16 operands / bf16 activation storage
 static ConvPlan conv_make_plan(int B, int ID, int IH, int IW, int cin, int OD, int OH, int OW, int cout, int KD, int KH, int KW, int stride,
                                int pd, int ph, int pw, int split_mode) {
     ConvPlan pl{};
@@ -733,16 +907,17 @@ static ConvPlan conv_make_plan(int B, int ID, int IH, int IW, int cin, int OD, i
         int cb = cin % 64 == 0 ? 64 : 32;
         int R = (pd * IH + ph) * IW + pw;
         int rows = 128 + 2 * R;
-        int planes = split_mode ? 2 : 1;
+        int planes = split_mode == 1 ? 2 : 1;
         size_t smem = (size_t)planes * ((size_t)(rows + 1) * cb * 2 + 2 * (size_t)bn * cb * 2) + 256 + (size_t)4 * bn * 2 * sizeof(float);
         if (smem <= 150 * 1024) {
             pl.brick = cb; pl.R = R; pl.brick_rows = rows; pl.smem = smem;
             pl.nunits = (cin / cb) * ntaps;
         }
     }
-    if (!pl.brick) pl.nunits = kpad / 32;
+    if (!pl.brick && split_mode == 2 && cin % 64 == 0 && cout % 64 == 0 && !dma_disabled()) pl.dma = 1;
+    if (!pl.brick) pl.nunits = pl.dma ? kpad / 64 : kpad / 32;
     int ks = 1;
-    int min_per = pl.brick ? 3 : 4;                              // at least this many units per split
+    int min_per = pl.brick ? 3 : (pl.dma ? 2 : 4);                              // at least this many units per split
     if (blocks < 384 && pl.nunits >= 2 * min_per && cout % 64 == 0) {
         ks = (768 + blocks - 1) / blocks;
         if (ks > pl.nunits / min_per) ks = pl.nunits / min_per;
@@ -770,6 +945,22 @@ static int launch_brick(const ConvArgs& a, const ConvPlan& pl, hipStream_t strea
     return tri_check_launch("tri_conv_splitk_finish");
 }
 
+template <int BN>
+static int launch_dma(const ConvArgs& a, hipStream_t stream) {
+    constexpr size_t smem = 2 * (128 * 128 + BN * 128) + 512 + (size_t)4 * BN * 2 * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute((const void*)conv_dma_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr = true;
+    }
+    int mt = (a.M + 127) / 128, nt = a.Cout / BN;
+    conv_dma_kernel<BN><<<dim3(mt * nt, a.ksplit), 256, smem, stream>>>(a);
+    int rc = tri_check_launch("tri_conv(dma)");
+    if (rc || a.ksplit == 1) return rc;
+    conv_splitk_finish_kernel<bf16_t><<<dim3((a.M + 31) / 32, a.Cout / 64), 256, 0, stream>>>(a);
+    return tri_check_launch("tri_conv_splitk_finish");
+}
+
 static int conv_dispatch(ConvArgs& a, int act_bf16, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     if (a.Cin % 4 != 0) { tri_set_error("conv: stored input channels must be a multiple of 4"); return TRI_ERR_ARG; }
     if (a.Cout % 32 != 0) { tri_set_error("conv: output channels must be a multiple of 32"); return TRI_ERR_ARG; }
@@ -783,7 +974,7 @@ static int conv_dispatch(ConvArgs& a, int act_bf16, void* workspace, size_t work
     a.in_bytes = (unsigned)in_bytes;
     const bool split = a.w_lo != nullptr;
     if (act_bf16 && split) { tri_set_error("conv: bf16 activation storage is for the plain bf16 mode (no lo operand)"); return TRI_ERR_ARG; }
-    ConvPlan pl = conv_make_plan(a.B, a.ID, a.IH, a.IW, a.Cin, a.OD, a.OH, a.OW, a.Cout, a.KD, a.KH, a.KW, a.stride, a.pd, a.ph, a.pw, split);
+    ConvPlan pl = conv_make_plan(a.B, a.ID, a.IH, a.IW, a.Cin, a.OD, a.OH, a.OW, a.Cout, a.KD, a.KH, a.KW, a.stride, a.pd, a.ph, a.pw, act_bf16 ? 2 : (split ? 1 : 0));
     a.ksplit = pl.ksplit;
     a.steps_per_split = pl.per_split;
     a.units_per_split = pl.per_split;
@@ -799,6 +990,7 @@ static int conv_dispatch(ConvArgs& a, int act_bf16, void* workspace, size_t work
         a.slab = (float*)workspace;
     }
     a.dOW = make_fastdiv(a.OW); a.dOH = make_fastdiv(a.OH); a.dOD = make_fastdiv(a.OD); a.dCin = make_fastdiv(a.Cin);
+    if (pl.dma) return a.Cout % 128 == 0 ? launch_dma<128>(a, stream) : launch_dma<64>(a, stream);
     if (pl.brick) {
         const int bn = conv_bn(a.Cout);
 #define TRI_BRICK(BN_, CB_)                                                                               \
@@ -821,6 +1013,7 @@ extern "C" int tri_conv_kpad(int ntaps, int cin_stored) { return (ntaps * cin_st
 
 // number of [2][Cout] statistic records tri_conv_fwd writes for this layer: one per 128-row tile, or one per 32-row
 // chunk when the layer runs split-K (the finish kernel produces them).  tri_bn_finalize just sums all records.
+// split3: 0 bf16 operands / fp32 activations, 1 bf16x3 (hi + lo operands), 2 bf16 operands / bf16 activation storage.
 extern "C" int tri_conv_num_mtiles(const TriConvDesc* d, int split3) {
     long M = (long)d->B * d->OD * d->OH * d->OW;
     ConvPlan pl = conv_make_plan(d->B, d->ID, d->IH, d->IW, d->Cin, d->OD, d->OH, d->OW, d->Cout, d->KD, d->KH, d->KW, d->stride, d->pad_d,
@@ -834,7 +1027,7 @@ extern "C" int tri_conv_num_mtiles(const TriConvDesc* d, int split3) {
 // (0 when the layer already fills the GPU) and therefore REQUIRES.
 extern "C" size_t tri_conv_workspace(const TriConvDesc* d, int transposed) {
     size_t need = 0;
-    for (int mode = 0; mode < 2; ++mode) {
+    for (int mode = 0; mode < 3; ++mode) {
         ConvPlan pl;
         long M;
         int cout;

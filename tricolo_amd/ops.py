@@ -111,7 +111,8 @@ class ConvGeom:
         self.kpad_t = lib().tri_conv_kpad(self.ntaps, cout)
         self.M = B * OD * OH * OW
         self.M_in = B * ID * IH * IW
-        self.num_mtiles = {m: lib().tri_conv_num_mtiles(_C.C.byref(self.desc), 1 if m == "bf16x3" else 0) for m in _PRECISIONS}
+        self.num_mtiles = {m: lib().tri_conv_num_mtiles(_C.C.byref(self.desc), {"bf16x3": 1, "bf16": 0, "bf16s": 2}[m])
+                           for m in (*_PRECISIONS, "bf16s")}          # bf16s: bf16 operands AND bf16 activation storage
         self.wgrad_ws = lib().tri_conv_wgrad_workspace(_C.C.byref(self.desc))
         self._plans = {}
         self.fwd_ws = lib().tri_conv_workspace(_C.C.byref(self.desc), 0)
@@ -200,7 +201,7 @@ def conv_fwd(x, g: ConvGeom, packed, row_mask=None, bias=None, act=0, want_stats
     if out is None:
         out = torch.empty((g.B, OD, OH, OW, g.cout), dtype=x.dtype, device=x.device)
     assert out.dtype == x.dtype
-    stats = (torch.empty((g.num_mtiles["bf16x3" if lo is not None else "bf16"], 2, g.cout), dtype=torch.float32, device=x.device)
+    stats = (torch.empty((g.num_mtiles["bf16x3" if lo is not None else ("bf16s" if x.dtype == torch.bfloat16 else "bf16")], 2, g.cout), dtype=torch.float32, device=x.device)
              if want_stats else None)
     ws = _workspace(g.fwd_ws, x.device) if g.fwd_ws else None
     check(_timed(_igemm_symbol(g.cout, lo is not None, x), g.flops,
