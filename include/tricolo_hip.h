@@ -57,7 +57,13 @@ int tri_weight_prep(const float* w, long s_row, long s_tap, long s_inner, int ro
  * stats (optional) receives [tri_conv_num_mtiles][2][Cout] per-tile column sums / sums of squares for BatchNorm.
  * tri_conv_dgrad / tri_conv_wgrad replace the autograd backward of the same call sites; `d` is always the FORWARD
  * descriptor.  wgrad writes dw through element strides, i.e. directly in the reference's parameter layout. */
+/* split3: 0 = bf16 operands / fp32 activations, 1 = bf16x3 (hi + lo operands), 2 = bf16 operands / bf16 activation storage */
 int tri_conv_num_mtiles(const TriConvDesc* d, int split3);
+/* kernel family tri_conv_fwd (transposed = 0) / tri_conv_dgrad (transposed = 1) dispatches for this layer and mode:
+ * 0 conv_igemm_kernel (register-staged im2col), 1 conv_brick_kernel, 2 conv_dma_kernel (LDS-DMA staging).  For profilers. */
+int tri_conv_kernel_family(const TriConvDesc* d, int transposed, int split3);
+/* same for tri_conv_wgrad: 0 conv_wgrad_kernel, 2 conv_wgrad_dma_kernel (taken when act_bf16 != 0 and the layer qualifies) */
+int tri_conv_wgrad_kernel_family(const TriConvDesc* d, int act_bf16);
 /* split-K scratch a small-M layer needs (0 = none): pass at least this many bytes to tri_conv_fwd / tri_conv_dgrad */
 size_t tri_conv_workspace(const TriConvDesc* d, int transposed);
 int tri_conv_fwd(const TriConvDesc* d, const void* in, const void* w_hi, const void* w_lo, void* out, const uint8_t* row_mask,

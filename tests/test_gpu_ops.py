@@ -454,7 +454,11 @@ def test_conv_bf16_storage_masked_stats():
     np.testing.assert_allclose(st[1].numpy(), (exact ** 2).sum(0).numpy(), rtol=1e-6, atol=1e-3)
     dy = ints((M, 128), -2, 2, 63) * mask[:, None].float()
     xr = x.clone().requires_grad_()
-    F.conv3d(xr, w, padding=1).backward(cf3(dy.view(2, 8, 8, 8, 128)))
+    wr = w.clone().requires_grad_()
+    F.conv3d(xr, wr, padding=1).backward(cf3(dy.view(2, 8, 8, 8, 128)))
+    dw = ops.conv_wgrad(xcl.to(DEV).to(torch.bfloat16), dy.view(2, 8, 8, 8, 128).to(DEV).to(torch.bfloat16), g, wp.to(DEV), "bf16",
+                        row_mask=mask.to(DEV))                      # 64-position steps without an active site are skipped
+    assert torch.equal(dw.cpu(), wr.grad.permute(0, 2, 3, 4, 1).contiguous())
     dx = ops.conv_dgrad(dy.view(2, 8, 8, 8, 128).to(DEV).to(torch.bfloat16), g, ops.pack_weight(wp.to(DEV), g, "bf16", transposed=True),
                         row_mask=mask.to(DEV))
     assert torch.equal(dx.cpu().reshape(M, -1), (cl3(xr.grad).reshape(M, -1) * mask[:, None].float()).to(torch.bfloat16))

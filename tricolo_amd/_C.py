@@ -37,6 +37,8 @@ SIGNATURES = {
     "tri_weight_prep_multi": (I, [P, I, P]),
     "tri_conv_num_mtiles": (I, [DP, I]),
     "tri_conv_workspace": (Z, [DP, I]),
+    "tri_conv_kernel_family": (I, [DP, I, I]),
+    "tri_conv_wgrad_kernel_family": (I, [DP, I]),
     "tri_conv_fwd": (I, [DP, P, P, P, P, P, P, I, I, P, I, P, Z, P]),
     "tri_conv_dgrad": (I, [DP, P, P, P, P, P, I, I, P, Z, P]),
     "tri_conv_wgrad_workspace": (Z, [DP]),

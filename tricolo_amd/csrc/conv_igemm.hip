@@ -1021,6 +1021,14 @@ extern "C" int tri_conv_num_mtiles(const TriConvDesc* d, int split3) {
     return pl.ksplit > 1 ? (int)((M + 31) / 32) : (int)((M + 127) / 128);
 }
 
+extern "C" int tri_conv_kernel_family(const TriConvDesc* d, int transposed, int split3) {
+    ConvPlan pl = transposed ? conv_make_plan(d->B, d->OD, d->OH, d->OW, d->Cout, d->ID, d->IH, d->IW, d->Cin, d->KD, d->KH, d->KW, d->stride,
+                                              d->pad_d, d->pad_h, d->pad_w, split3)
+                             : conv_make_plan(d->B, d->ID, d->IH, d->IW, d->Cin, d->OD, d->OH, d->OW, d->Cout, d->KD, d->KH, d->KW, d->stride,
+                                              d->pad_d, d->pad_h, d->pad_w, split3);
+    return pl.dma ? 2 : (pl.brick ? 1 : 0);
+}
+
 // out[B,OD,OH,OW,Cout] = conv(in[B,ID,IH,IW,Cin], W) (+bias, act 0 none / 1 relu / 2 tanh); rows with row_mask==0 are
 // written as zeros (submanifold rule); stats != NULL receives per-128-row-tile column sums and sums of squares.
 // bytes of split-K scratch tri_conv_fwd (transposed = 0) / tri_conv_dgrad (transposed = 1) can use for this layer

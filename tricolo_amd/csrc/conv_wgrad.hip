@@ -278,6 +278,192 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
         }
 }
 
+// ================================================================================================ LDS-DMA variant
+// bf16 activation storage: dOut rows and input rows in HBM already are the bf16 LDS image, so both operand tiles go
+// global -> LDS with buffer_load_dwordx4 ... lds (16 B per lane, no VGPR staging / ds_write), 64 positions per step
+// (32 MFMAs per wave per barrier instead of 16) and the DMA of the next live step in flight under the MFMAs.
+// One wave-instruction fills 1 KiB = 1024 / ROWB consecutive tile rows; the nat_off bank swizzle is applied on the
+// SOURCE side (the lane that owns LDS slot s of row r fetches the chunk nat_off would have stored there).  The slot ->
+// chunk map of a lane is the same for every instruction and step, so (tap, channel, validity shifts) are per-lane constants.
+__device__ __forceinline__ void wdma16(const __amdgpu_buffer_rsrc_t rsrc, char* dst, unsigned voff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)dst, 16, (int)voff, 0, 0, 0);
+#endif
+}
+template <int ROWB>
+__device__ __forceinline__ int nat_sw(int row) {
+    constexpr int NCH = ROWB / 32;
+    return NCH >= 8 ? ((row & 3) | (((row >> 3) & 1) << 2)) : (((row >> 1) & 1) | (((row >> 3) & 1) << 1));
+}
+
+template <int BI, int BJ>
+__global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs p) {
+    constexpr int KB = 64;
+    constexpr int WI = BI / 2, WJ = BJ / 2, TM = WI / 16, TN = WJ / 16;
+    constexpr int XROW = BI * 2, YROW = BJ * 2;
+    static_assert((XROW == 128 || XROW == 256) && (YROW == 128 || YROW == 256), "lane -> chunk map must not depend on the instruction");
+    constexpr int X_BYTES = KB * XROW, Y_BYTES = KB * YROW, STAGE = X_BYTES + Y_BYTES;
+    constexpr int XRPI = 1024 / XROW, YRPI = 1024 / YROW;        // tile rows per wave-instruction
+    constexpr int XNI = KB / (4 * XRPI), YNI = KB / (4 * YRPI);  // instructions per wave per step
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* lut = (int*)(smem + 2 * STAGE);
+    int* lut_off = lut + 64;
+    int* lplan_off = lut + 128;                                  // [steps_per_split * 64]
+    unsigned* lplan_mask = (unsigned*)lplan_off + p.steps_per_split * KB;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int JT = (p.Kpad + BJ - 1) / BJ;
+    const int ntiles = p.ntiles;
+    int split, tile;
+    if (p.nsplits >= 16) {                                       // XCD pinning, see conv_wgrad_kernel
+        const int grp = blockIdx.x / (8 * ntiles), rem = blockIdx.x - grp * 8 * ntiles;
+        split = grp * 8 + (rem & 7);
+        tile = rem >> 3;
+    } else {
+        split = blockIdx.x / ntiles;
+        tile = blockIdx.x - split * ntiles;
+    }
+    if (split >= p.nsplits) return;
+    const int it = tile / JT, jt = tile - it * JT;
+    const int i0 = it * BI, j0 = jt * BJ;
+    const int ks_begin = split * p.steps_per_split;
+    const int nsteps_total = (p.M + KB - 1) / KB;
+    const int ks_end = min(nsteps_total, ks_begin + p.steps_per_split);
+
+    if (t < 64) {
+        int kd = 0, kh = 0, kw = 0;
+        if (t < p.ntaps) {
+            kw = t % p.KW;
+            int r = t / p.KW;
+            kh = r % p.KH;
+            kd = r / p.KH;
+        }
+        lut[t] = kd | (kh << 8) | (kw << 16);
+        lut_off[t] = ((kd * p.IH + kh) * p.IW + kw) * p.Cin;
+    }
+    {
+        const int n = (ks_end - ks_begin) * KB, mpad = (p.M + 31) & ~31;
+        for (int i = t; i < n; i += 256) {
+            int m = ks_begin * KB + i;
+            lplan_off[i] = m < mpad ? p.plan_off[m] : 0;
+            lplan_mask[i] = m < mpad ? p.plan_mask[m] : 0u;
+        }
+    }
+    __syncthreads();
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int wi = wave >> 1, wj = wave & 1;
+    const int fr = lane & 15, fg = lane >> 4, fqq = fr >> 2, fp = fr & 3;
+
+    // X (dOut) lane constants: row inside the instruction, 16-byte source chunk, byte offset of (row, chunk)
+    const int xrow0 = wave * XRPI + lane / (XROW / 16), xs = lane % (XROW / 16);
+    const int xchunk = ((((xs >> 1) ^ nat_sw<XROW>(xrow0)) & (XROW / 32 - 1)) << 1) | (xs & 1);
+    const unsigned xoff = (unsigned)((xrow0 * p.Cout + i0 + xchunk * 8) * 2);
+    const unsigned xstep = (unsigned)(4 * XRPI * p.Cout * 2);   // bytes between the rows of consecutive instructions
+    // Y (input gather) lane constants
+    const int yrow0 = wave * YRPI + lane / (YROW / 16), ys = lane % (YROW / 16);
+    const int ychunk = ((((ys >> 1) ^ nat_sw<YROW>(yrow0)) & (YROW / 32 - 1)) << 1) | (ys & 1);
+    int y_toff, y_sh;
+    bool y_tv;
+    {
+        int j = j0 + ychunk * 8;
+        int tap, c;
+        if (p.cin_shift >= 0) { tap = j >> p.cin_shift; c = j & ((1 << p.cin_shift) - 1); }
+        else { tap = (int)fdiv((uint32_t)j, p.dCin); c = j - tap * p.Cin; }
+        y_tv = tap < p.ntaps;
+        int code = lut[y_tv ? tap : 0];
+        int kd = code & 255, kh = (code >> 8) & 255, kw = (code >> 16) & 255;
+        y_toff = (lut_off[y_tv ? tap : 0] + c) * 2;
+        y_sh = kw | ((8 + kh) << 8) | ((16 + kd) << 16);
+    }
+    const int sx = y_sh & 255, sy = (y_sh >> 8) & 255, sz = (y_sh >> 16) & 255;
+
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    // rows m >= M of dOut fall outside this descriptor and arrive as zeros
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.dout, 0, (unsigned)p.M * p.Cout * 2, 0x00020000);
+
+    auto step_live = [&](int ks) -> bool {
+        if (!p.row_mask) return true;
+        int m = ks * KB;
+        const uint32_t* mp = (const uint32_t*)(p.row_mask + m);          // mask buffers are padded to 32 bytes
+        uint32_t any = 0;
+#pragma unroll
+        for (int q = 0; q < KB / 4; ++q) any |= (m + q * 4 < p.M) ? mp[q] : 0u;
+        return any != 0;
+    };
+    auto next_live = [&](int ks) -> int {
+        while (ks < ks_end && !step_live(ks)) ++ks;
+        return ks;
+    };
+    auto issue = [&](int ks, int buf) {
+        char* xb = smem + buf * STAGE;
+        char* yb = xb + X_BYTES;
+        const unsigned xbase = xoff + (unsigned)(ks * KB) * (unsigned)(p.Cout * 2);
+#pragma unroll
+        for (int i = 0; i < XNI; ++i) wdma16(xrsrc, xb + (4 * i + wave) * 1024, xbase + i * xstep);
+        const int* po = lplan_off + (ks - ks_begin) * KB + yrow0;
+        const unsigned* pm = lplan_mask + (ks - ks_begin) * KB + yrow0;
+#pragma unroll
+        for (int i = 0; i < YNI; ++i) {
+            int ro = po[4 * YRPI * i];
+            unsigned rm = pm[4 * YRPI * i];
+            bool ok = y_tv && (((rm >> sx) & (rm >> sy) & (rm >> sz)) & 1u);
+            unsigned voff = ok ? (unsigned)(ro * 2 + y_toff) : 0x80000000u;
+            wdma16(rsrc, yb + (4 * i + wave) * 1024, voff);
+        }
+    };
+    auto compute = [&](int buf) {
+        const char* xb = smem + buf * STAGE;
+        const char* yb = xb + X_BYTES;
+#pragma unroll
+        for (int h = 0; h < KB / 32; ++h) {
+            bf16x8 ah[TM];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) ah[a] = tr_frag<XROW>(xb + h * 32 * XROW, wi * WI + a * 16, fg, fqq, fp);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                bf16x8 bhf = tr_frag<YROW>(yb + h * 32 * YROW, wj * WJ + b * 16, fg, fqq, fp);
+#pragma unroll
+                for (int a = 0; a < TM; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[a], bhf, acc[a][b], 0, 0, 0);
+            }
+        }
+    };
+
+    int ks = next_live(ks_begin);
+    int buf = 0;
+    if (ks < ks_end) {
+        issue(ks, 0);
+        while (ks < ks_end) {
+            int nxt = next_live(ks + 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's DMAs of stage `buf` have landed
+            __builtin_amdgcn_s_barrier();                                // ... everyone's have, and all reads of buf ^ 1 are done
+            asm volatile("" ::: "memory");
+            if (nxt < ks_end) issue(nxt, buf ^ 1);
+            compute(buf);
+            buf ^= 1;
+            ks = nxt;
+        }
+    }
+
+    float* slab = p.slab + (size_t)split * p.Cout * p.Kpad;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int co = i0 + wi * WI + a * 16 + fg * 4 + r;
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                int j = j0 + wj * WJ + b * 16 + fr;
+                if (j < p.Kpad) slab[(size_t)co * p.Kpad + j] = acc[a][b][r];
+            }
+        }
+}
+
 // dw[co*s_co + tap*s_tap + ci*s_ci] = sum_split slab[split][co][tap*cin_stored + ci]   (ci < cin_real)
 // block = (256 / zlanes) consecutive k of one co x zlanes split lanes; lane z sums splits z, z+zlanes, ... and the partials are
 // added in a fixed order (bitwise reproducible).  Layers with hundreds of splits (stem, voxel level 0) no longer serialise.
@@ -351,7 +537,22 @@ extern "C" int tri_conv_plan_build(const TriConvDesc* d, void* plan, void* strea
 #endif
 // tile shapes: 128x128 for wide layers; 64-row tiles take the whole K in one 256-column tile when it fits (the dOut
 // operand is then read once, not once per j-tile: stem 7x7, voxel level 0, 1x1 down-samples), else 128 columns.
-static void wgrad_plan(const TriConvDesc* d, int* BI, int* BJ_out, int* tiles, int* splits, int* steps_per_split, int* Kpad) {
+static int wgrad_target_blocks() {                             // tuning aid: TRICOLO_WGRAD_BLOCKS overrides the default
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("TRICOLO_WGRAD_BLOCKS"); v = (e && atoi(e) > 0) ? atoi(e) : WGRAD_TARGET_BLOCKS; }
+    return v;
+}
+
+static bool wgrad_dma_disabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("TRICOLO_NO_DMA"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+
+// act_bf16 != 0 asks for the plan of the bf16-storage call; *dma is set when that call runs the LDS-DMA kernel
+// (64-position steps), and steps_per_split is then in 64-position units.
+static void wgrad_plan(const TriConvDesc* d, int act_bf16, int* BI, int* BJ_out, int* tiles, int* splits, int* steps_per_split, int* Kpad,
+                       int* dma) {
     int ntaps = d->KD * d->KH * d->KW;
     *Kpad = (ntaps * d->Cin + 31) / 32 * 32;
     *BI = (d->Cout % 128 == 0 && *Kpad >= 128) ? 128 : 64;
@@ -360,21 +561,60 @@ static void wgrad_plan(const TriConvDesc* d, int* BI, int* BJ_out, int* tiles, i
     int it = (d->Cout + *BI - 1) / *BI, jt = (*Kpad + BJ - 1) / BJ;
     *tiles = it * jt;
     long M = (long)d->B * d->OD * d->OH * d->OW;
-    int steps = (int)((M + 31) / 32);
-    int want = (WGRAD_TARGET_BLOCKS + *tiles - 1) / *tiles;     // workgroups to aim for: the k-loop is latency-bound, so occupancy matters
+    *dma = (act_bf16 && BJ == 128 && d->Cin % 8 == 0 && d->Cout % *BI == 0 && !wgrad_dma_disabled()) ? 1 : 0;
+    const int unit = *dma ? 64 : 32;
+    int steps = (int)((M + unit - 1) / unit);
     int max_by_steps = steps / 4 > 0 ? steps / 4 : 1;           // at least 4 k-steps per split
-    int s = want < max_by_steps ? want : max_by_steps;
+    int s, cap;
+    if (act_bf16 && *BI == 128 && wgrad_target_blocks() == WGRAD_TARGET_BLOCKS) {
+        // 128x128 bf16-storage tiles (64 KiB of operand stages -> 2 workgroups per CU): at most ONE resident round of
+        // workgroups, and not quite full (7/8 of the 512 slots).  More splits only add slab traffic (splits x Cout x K
+        // fp32 written + re-read by the reduce) and a second, partly empty round; measured sweep in profiles/r1/README.md.
+        const int fixed = (*dma ? 2 * 64 * (*BI * 2 + BJ * 2) : 2 * (32 * *BI * 2 + 32 * BJ * 2)) + 512;
+        cap = (163840 / 2 - fixed) / (*dma ? 512 : 256);        // gather plan: 8 B per position of the split
+        if (cap > 96) cap = 96;
+        s = 448 / *tiles;
+    } else {
+        cap = *dma ? 60 : 96;
+        s = (wgrad_target_blocks() + *tiles - 1) / *tiles;      // narrow tiles / fp32 storage: ~3 workgroups per CU
+    }
+    if (s > max_by_steps) s = max_by_steps;
     if (s < 1) s = 1;
-    if (s > 256) s = 256;
+    if (s > 1024) s = 1024;
     *steps_per_split = (steps + s - 1) / s;
-    if (*steps_per_split > 96) *steps_per_split = 96;          // the block's gather plan (256 B / step) must fit in LDS
+    if (*steps_per_split > cap) *steps_per_split = cap;
     *splits = (steps + *steps_per_split - 1) / *steps_per_split;
 }
 
 extern "C" size_t tri_conv_wgrad_workspace(const TriConvDesc* d) {
-    int BI, BJ, tiles, splits, sps, Kpad;
-    wgrad_plan(d, &BI, &BJ, &tiles, &splits, &sps, &Kpad);
-    return (size_t)splits * d->Cout * Kpad * sizeof(float);
+    size_t need = 0;
+    for (int mode = 0; mode < 2; ++mode) {
+        int BI, BJ, tiles, splits, sps, Kpad, dma;
+        wgrad_plan(d, mode, &BI, &BJ, &tiles, &splits, &sps, &Kpad, &dma);
+        size_t n = (size_t)splits * d->Cout * Kpad * sizeof(float);
+        if (n > need) need = n;
+    }
+    return need;
+}
+
+// 0: conv_wgrad_kernel (register-staged), 2: conv_wgrad_dma_kernel (bf16 activation storage, LDS-DMA).  For profilers.
+extern "C" int tri_conv_wgrad_kernel_family(const TriConvDesc* d, int act_bf16) {
+    int BI, BJ, tiles, splits, sps, Kpad, dma;
+    wgrad_plan(d, act_bf16, &BI, &BJ, &tiles, &splits, &sps, &Kpad, &dma);
+    return dma ? 2 : 0;
+}
+
+template <int BI, int BJ>
+static int launch_wgrad_dma(const WgradArgs& a, int tiles, int splits, hipStream_t stream) {
+    constexpr int STAGE = 64 * (BI * 2 + BJ * 2);
+    size_t smem = 2 * STAGE + 512 + (size_t)a.steps_per_split * 512;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel<BI, BJ>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE + 512 + 96 * 512);
+        attr_set = true;
+    }
+    conv_wgrad_dma_kernel<BI, BJ><<<dim3(((splits + 7) / 8) * 8 * tiles), 256, smem, stream>>>(a);
+    return tri_check_launch("tri_conv_wgrad(dma)");
 }
 
 #define WGRAD_MAX_STEPS 96
@@ -399,8 +639,8 @@ extern "C" int tri_conv_wgrad(const TriConvDesc* d, const void* in, const void* 
                               void* workspace, size_t workspace_bytes, float* dw, long s_co, long s_tap, long s_ci, int cin_real,
                               int split3, int act_bf16, void* stream) {
     if (d->Cin % 4 != 0 || d->Cout % 4 != 0) { tri_set_error("wgrad: channels must be multiples of 4"); return TRI_ERR_ARG; }
-    int BI, BJ, tiles, splits, sps, Kpad;
-    wgrad_plan(d, &BI, &BJ, &tiles, &splits, &sps, &Kpad);
+    int BI, BJ, tiles, splits, sps, Kpad, dma;
+    wgrad_plan(d, act_bf16, &BI, &BJ, &tiles, &splits, &sps, &Kpad, &dma);
     if (workspace_bytes < (size_t)splits * d->Cout * Kpad * sizeof(float)) { tri_set_error("wgrad: workspace too small"); return TRI_ERR_ARG; }
     WgradArgs a{};
     a.in = in; a.dout = dout; a.row_mask = row_mask; a.slab = (float*)workspace;
@@ -431,7 +671,10 @@ extern "C" int tri_conv_wgrad(const TriConvDesc* d, const void* in, const void* 
 #define TRI_WG(BI_, BJ_)                                                                                   \
     (act_bf16 ? launch_wgrad<BI_, BJ_, 1, bf16_t>(a, tiles, splits, s)                                     \
               : (split3 ? launch_wgrad<BI_, BJ_, 2, float>(a, tiles, splits, s) : launch_wgrad<BI_, BJ_, 1, float>(a, tiles, splits, s)))
-    if (BI == 128) rc = TRI_WG(128, 128);
+    if (dma) {
+        if ((size_t)a.M * a.Cout * 2 >= ((size_t)1 << 31)) { tri_set_error("wgrad: dOut tensor >= 2 GiB (32-bit buffer offsets)"); return TRI_ERR_UNSUPPORTED; }
+        rc = BI == 128 ? launch_wgrad_dma<128, 128>(a, tiles, splits, s) : launch_wgrad_dma<64, 128>(a, tiles, splits, s);
+    } else if (BI == 128) rc = TRI_WG(128, 128);
     else if (BJ == 256) rc = TRI_WG(64, 256);
     else rc = TRI_WG(64, 128);
 #undef TRI_WG

@@ -61,10 +61,15 @@ def _timed(symbol, flops, fn):
     return TIMER.run(symbol, flops, fn) if TIMER is not None else fn()
 
 
-def _igemm_symbol(cout, split, t=None):
+def _igemm_symbol(g, transposed, split, t):
+    """Name of the kernel the C dispatch picks for this layer (what rocprofv3 reports), for the KernelTimer."""
+    cout = g.cin_stored if transposed else g.cout
     bn = 128 if cout % 128 == 0 else (64 if cout % 64 == 0 else 32)
-    at = "bf16" if (t is not None and t.dtype == torch.bfloat16) else "float"
-    return f"conv_igemm_kernel<{bn},{2 if split else 1},{at}>"
+    bf = t.dtype == torch.bfloat16
+    fam = g.kernel_family[(transposed, 1 if split else (2 if bf else 0))]
+    if fam == 2:
+        return f"conv_dma_kernel<{bn}>"
+    return f"{'conv_brick_kernel' if fam == 1 else 'conv_igemm_kernel'}<{bn},{2 if split else 1},{'bf16' if bf else 'float'}>"
 
 
 def _f32(t):
@@ -113,7 +118,10 @@ class ConvGeom:
         self.M_in = B * ID * IH * IW
         self.num_mtiles = {m: lib().tri_conv_num_mtiles(_C.C.byref(self.desc), {"bf16x3": 1, "bf16": 0, "bf16s": 2}[m])
                            for m in (*_PRECISIONS, "bf16s")}          # bf16s: bf16 operands AND bf16 activation storage
+        self.kernel_family = {(tr, m): lib().tri_conv_kernel_family(_C.C.byref(self.desc), 1 if tr else 0, m)
+                              for tr in (False, True) for m in (0, 1, 2)}
         self.wgrad_ws = lib().tri_conv_wgrad_workspace(_C.C.byref(self.desc))
+        self.wgrad_dma = lib().tri_conv_wgrad_kernel_family(_C.C.byref(self.desc), 1) == 2
         self._plans = {}
         self.fwd_ws = lib().tri_conv_workspace(_C.C.byref(self.desc), 0)
         self.dgrad_ws = lib().tri_conv_workspace(_C.C.byref(self.desc), 1) if cin == cin_stored and cin % 32 == 0 else 0
@@ -204,7 +212,7 @@ def conv_fwd(x, g: ConvGeom, packed, row_mask=None, bias=None, act=0, want_stats
     stats = (torch.empty((g.num_mtiles["bf16x3" if lo is not None else ("bf16s" if x.dtype == torch.bfloat16 else "bf16")], 2, g.cout), dtype=torch.float32, device=x.device)
              if want_stats else None)
     ws = _workspace(g.fwd_ws, x.device) if g.fwd_ws else None
-    check(_timed(_igemm_symbol(g.cout, lo is not None, x), g.flops,
+    check(_timed(_igemm_symbol(g, False, lo is not None, x), g.flops,
                  lambda: lib().tri_conv_fwd(_C.C.byref(g.desc), ptr(_act(x)), ptr(hi), ptr(lo), ptr(out), ptr(row_mask), ptr(bias),
                                             act, 1 if accumulate else 0, ptr(stats), _abf(x), ptr(ws),
                                             ws.numel() if ws is not None else 0, stream())), "tri_conv_fwd")
@@ -218,7 +226,7 @@ def conv_dgrad(dout, g: ConvGeom, packed_t, row_mask=None, out=None, accumulate=
         out = torch.empty((g.B, ID, IH, IW, g.cin_stored), dtype=dout.dtype, device=dout.device)
     assert out.dtype == dout.dtype
     ws = _workspace(g.dgrad_ws, dout.device) if g.dgrad_ws else None
-    check(_timed(_igemm_symbol(g.cin_stored, lo is not None, dout), g.flops,
+    check(_timed(_igemm_symbol(g, True, lo is not None, dout), g.flops,
                  lambda: lib().tri_conv_dgrad(_C.C.byref(g.desc), ptr(_act(dout)), ptr(hi), ptr(lo), ptr(out), ptr(row_mask),
                                               1 if accumulate else 0, _abf(dout), ptr(ws), ws.numel() if ws is not None else 0,
                                               stream())), "tri_conv_dgrad")
@@ -246,7 +254,11 @@ def conv_wgrad(x, dout, g: ConvGeom, like: torch.Tensor, precision: str, row_mas
     s_co, s_tap, s_ci = g.strides
     bi = 128 if (g.cout % 128 == 0 and g.kpad >= 128) else 64
     bj = 128 if bi == 128 else (256 if g.kpad <= 256 else 128)
-    sym = f"conv_wgrad_kernel<{bi},{bj},{2 if precision == 'bf16x3' else 1},{'bf16' if x.dtype == torch.bfloat16 else 'float'}>"
+    bf = x.dtype == torch.bfloat16
+    if bf and g.wgrad_dma:
+        sym = f"conv_wgrad_dma_kernel<{bi},{bj}>"
+    else:
+        sym = f"conv_wgrad_kernel<{bi},{bj},{2 if precision == 'bf16x3' else 1},{'bf16' if bf else 'float'}>"
     check(_timed(sym, g.flops,
                  lambda: lib().tri_conv_wgrad(_C.C.byref(g.desc), ptr(_act(x)), ptr(_act(dout)), ptr(row_mask), ptr(plan), ptr(ws),
                                               ws.numel(), ptr(dw), s_co, s_tap, s_ci, g.cin, 1 if precision == "bf16x3" else 0,
