@@ -18,22 +18,23 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int ntiles
                                    float* running_mean, float* running_var, long long* num_batches_tracked, float momentum,
                                    float eps, float* __restrict__ mean_out, float* __restrict__ invstd_out,
                                    float* __restrict__ scale_out, float* __restrict__ shift_out) {
-    __shared__ double ssum[4][64], ssq[4][64];
-    const int cl = threadIdx.x & 3, rl = threadIdx.x >> 2;        // 4 channels x 64 row lanes; loads unrolled for MLP
-    const int c = blockIdx.x * 4 + cl;
+    // one channel per block, 256 record lanes: every load of the [ntiles][2][C] table is independent and in flight at
+    // once (the 4-channel x 64-lane version spent 12-30 us in a dependent-load chain on the 1,536 - 6,144 record layers)
+    __shared__ double ssum[4], ssq[4];
+    const int c = blockIdx.x;
     double s = 0.0, q = 0.0;
-    if (c < C) {
 #pragma unroll 8
-        for (int tIdx = rl; tIdx < ntiles; tIdx += 64) {
-            s += (double)partial[((size_t)tIdx * 2 + 0) * C + c];
-            q += (double)partial[((size_t)tIdx * 2 + 1) * C + c];
-        }
+    for (int tIdx = threadIdx.x; tIdx < ntiles; tIdx += 256) {
+        s += (double)partial[((size_t)tIdx * 2 + 0) * C + c];
+        q += (double)partial[((size_t)tIdx * 2 + 1) * C + c];
     }
-    ssum[cl][rl] = s;
-    ssq[cl][rl] = q;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+    if ((threadIdx.x & 63) == 0) { ssum[threadIdx.x >> 6] = s; ssq[threadIdx.x >> 6] = q; }
     __syncthreads();
-    if (rl == 0 && c < C) {
-        for (int i = 1; i < 64; ++i) { s += ssum[cl][i]; q += ssq[cl][i]; }
+    if (threadIdx.x == 0) {
+        s = (ssum[0] + ssum[1]) + (ssum[2] + ssum[3]);
+        q = (ssq[0] + ssq[1]) + (ssq[2] + ssq[3]);
         double n = count_dev ? (double)(*count_dev) : (double)count_host;
         if (n < 1.0) {                       // SparseSequential skips BN when there is no active site
             mean_out[c] = 0.f; invstd_out[c] = 0.f; scale_out[c] = 0.f; shift_out[c] = 0.f;
@@ -60,7 +61,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int ntiles
 extern "C" int tri_bn_finalize(const float* partial, int ntiles, int C, const int* count_dev, int count_host, const float* gamma,
                                const float* beta, float* running_mean, float* running_var, long long* num_batches_tracked,
                                float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, void* stream) {
-    bn_finalize_kernel<<<(C + 3) / 4, 256, 0, (hipStream_t)stream>>>(partial, ntiles, C, count_dev, count_host, gamma, beta,
+    bn_finalize_kernel<<<C, 256, 0, (hipStream_t)stream>>>(partial, ntiles, C, count_dev, count_host, gamma, beta,
                                                                       running_mean, running_var, num_batches_tracked, momentum,
                                                                       eps, mean, invstd, scale, shift);
     return tri_check_launch("tri_bn_finalize");
@@ -196,22 +197,21 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nb
                                        int count_host, const float* __restrict__ gamma, const float* __restrict__ mean,
                                        const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                        float* __restrict__ c1, float* __restrict__ c2, float* __restrict__ c3) {
-    __shared__ double ssum[4][64], ssq[4][64];
-    const int cl = threadIdx.x & 3, rl = threadIdx.x >> 2;
-    const int c = blockIdx.x * 4 + cl;
+    __shared__ double ssum[4], ssq[4];                              // one channel per block, see bn_finalize_kernel
+    const int c = blockIdx.x;
     double s = 0.0, q = 0.0;
-    if (c < C) {
 #pragma unroll 8
-        for (int b = rl; b < nblk; b += 64) {
-            s += (double)partial[((size_t)b * 2 + 0) * C + c];
-            q += (double)partial[((size_t)b * 2 + 1) * C + c];
-        }
+    for (int b = threadIdx.x; b < nblk; b += 256) {
+        s += (double)partial[((size_t)b * 2 + 0) * C + c];
+        q += (double)partial[((size_t)b * 2 + 1) * C + c];
     }
-    ssum[cl][rl] = s;
-    ssq[cl][rl] = q;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+    if ((threadIdx.x & 63) == 0) { ssum[threadIdx.x >> 6] = s; ssq[threadIdx.x >> 6] = q; }
     __syncthreads();
-    if (rl == 0 && c < C) {
-        for (int i = 1; i < 64; ++i) { s += ssum[cl][i]; q += ssq[cl][i]; }
+    if (threadIdx.x == 0) {
+        s = (ssum[0] + ssum[1]) + (ssum[2] + ssum[3]);
+        q = (ssq[0] + ssq[1]) + (ssq[2] + ssq[3]);
         double n = count_dev ? (double)(*count_dev) : (double)count_host;
         if (n < 1.0) { dgamma[c] = 0.f; dbeta[c] = 0.f; c1[c] = 0.f; c2[c] = 0.f; c3[c] = 0.f; return; }
         double mu = mean[c], is = invstd[c], ga = gamma[c];
@@ -228,7 +228,7 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nb
 extern "C" int tri_bn_bwd_finalize(const float* partial, int nblk, int C, const int* count_dev, int count_host, const float* gamma,
                                    const float* mean, const float* invstd, float* dgamma, float* dbeta, float* c1, float* c2,
                                    float* c3, void* stream) {
-    bn_bwd_finalize_kernel<<<(C + 3) / 4, 256, 0, (hipStream_t)stream>>>(partial, nblk, C, count_dev, count_host, gamma, mean,
+    bn_bwd_finalize_kernel<<<C, 256, 0, (hipStream_t)stream>>>(partial, nblk, C, count_dev, count_host, gamma, mean,
                                                                           invstd, dgamma, dbeta, c1, c2, c3);
     return tri_check_launch("tri_bn_bwd_finalize");
 }

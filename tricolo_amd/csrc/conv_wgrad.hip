@@ -465,27 +465,46 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs p) 
 }
 
 // dw[co*s_co + tap*s_tap + ci*s_ci] = sum_split slab[split][co][tap*cin_stored + ci]   (ci < cin_real)
-// block = (256 / zlanes) consecutive k of one co x zlanes split lanes; lane z sums splits z, z+zlanes, ... and the partials are
-// added in a fixed order (bitwise reproducible).  Layers with hundreds of splits (stem, voxel level 0) no longer serialise.
+// Each thread owns 4 consecutive k (one 16-byte load per split) of one co; a block is (256 / zlanes) such quads x zlanes
+// split lanes: lane z sums splits z, z + zlanes, ... and lane 0 adds the partials in a fixed order (bitwise
+// reproducible for a given layer shape).  zlanes grows with splits / outputs so that the layers with hundreds of splits
+// and a tiny dW (stem, voxel level 0) still put a few hundred thousand loads in flight.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, int Cout, int Kpad, int ntaps,
                                                            int cin_stored, int cin_real, float* __restrict__ dw, long s_co, long s_tap,
                                                            long s_ci, int zlanes) {
-    __shared__ float part[256];
-    const int kper = 256 / zlanes;                               // consecutive k handled per block (zlanes in {1,2,4,8})
-    const int kl = threadIdx.x % kper, zl = threadIdx.x / kper;
-    const int K = ntaps * cin_stored;
-    const int kchunks = (K + kper - 1) / kper;
-    const int co = blockIdx.x / kchunks, k = (blockIdx.x - co * kchunks) * kper + kl;
-    float s = 0.f;
-    if (k < K)
-        for (int z = zl; z < splits; z += zlanes) s += slab[((size_t)z * Cout + co) * Kpad + k];
+    __shared__ float4 part[256];
+    const int kq = 256 / zlanes;                                 // quads per block
+    const int ql = threadIdx.x % kq, zl = threadIdx.x / kq;
+    const int K4 = (ntaps * cin_stored) >> 2;
+    const long quad = (long)blockIdx.x * kq + ql;
+    const bool live = quad < (long)Cout * K4;
+    const int co = live ? (int)(quad / K4) : 0, k = live ? (int)(quad - (long)co * K4) * 4 : 0;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+        const float* src = slab + (size_t)co * Kpad + k;
+        const size_t zs = (size_t)Cout * Kpad;
+#pragma unroll 4
+        for (int z = zl; z < splits; z += zlanes) {
+            float4 v = *(const float4*)(src + z * zs);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
     part[threadIdx.x] = s;
     __syncthreads();
-    if (zl == 0 && k < K) {
-        float tot = s;
-        for (int z = 1; z < zlanes; ++z) tot += part[z * kper + kl];
-        int tap = k / cin_stored, ci = k - tap * cin_stored;
-        if (ci < cin_real) dw[co * s_co + tap * s_tap + ci * s_ci] = tot;
+    if (zl == 0 && live) {
+        for (int z = 1; z < zlanes; ++z) {
+            float4 v = part[z * kq + ql];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        const int tap = k / cin_stored, ci = k - tap * cin_stored;   // cin_stored % 4 == 0: the quad stays inside one tap
+        float* d = dw + co * s_co + tap * s_tap + ci * s_ci;
+        if (s_ci == 1 && cin_real == cin_stored && (((uintptr_t)d) & 15) == 0) *(float4*)d = s;
+        else {
+            if (ci + 0 < cin_real) d[0] = s.x;
+            if (ci + 1 < cin_real) d[s_ci] = s.y;
+            if (ci + 2 < cin_real) d[2 * s_ci] = s.z;
+            if (ci + 3 < cin_real) d[3 * s_ci] = s.w;
+        }
     }
 }
 
@@ -679,10 +698,11 @@ extern "C" int tri_conv_wgrad(const TriConvDesc* d, const void* in, const void* 
     else rc = TRI_WG(64, 128);
 #undef TRI_WG
     if (rc) return rc;
-    int zlanes = splits >= 8 ? 8 : (splits >= 4 ? 4 : (splits >= 2 ? 2 : 1));
-    int kper = 256 / zlanes;
-    int kchunks = (a.ntaps * d->Cin + kper - 1) / kper;
-    wgrad_reduce_kernel<<<d->Cout * kchunks, 256, 0, s>>>((const float*)workspace, splits, d->Cout, Kpad, a.ntaps, d->Cin, cin_real, dw,
-                                                           s_co, s_tap, s_ci, zlanes);
+    const long quads = (long)d->Cout * ((a.ntaps * d->Cin) >> 2);
+    int zlanes = 1;
+    while (zlanes < 64 && zlanes * 2 <= splits && quads * zlanes < 262144) zlanes *= 2;
+    const int kq = 256 / zlanes;
+    wgrad_reduce_kernel<<<(unsigned)((quads + kq - 1) / kq), 256, 0, s>>>((const float*)workspace, splits, d->Cout, Kpad, a.ntaps, d->Cin,
+                                                                          cin_real, dw, s_co, s_tap, s_ci, zlanes);
     return tri_check_launch("tri_wgrad_reduce");
 }

@@ -44,6 +44,34 @@ __global__ __launch_bounds__(256) void ntx_sim_kernel(const float* __restrict__ 
         }
 }
 
+// Small batches (the per-GPU batch of the training step): the 64x64 tiling above would run on one or a handful of CUs.
+// One block per row i keeps a_i in LDS; each wave takes columns j = wave, wave + 4, ... four at a time (16-byte loads of
+// b_j along D, 8 independent loads in flight), reduces with wave shuffles.  D % 4 == 0.
+__global__ __launch_bounds__(256) void ntx_sim_rows_kernel(const float* __restrict__ a, const float* __restrict__ b, int B, int D,
+                                                           float inv_T, float* __restrict__ S) {
+    extern __shared__ float sa[];
+    const int i = blockIdx.x, t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    for (int k = t * 4; k < D; k += 1024) *(float4*)(sa + k) = *(const float4*)(a + (long)i * D + k);
+    __syncthreads();
+    for (int jb = wave * 4; jb < B; jb += 16) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = lane * 4; k < D; k += 256) {
+            const float4 av = *(const float4*)(sa + k);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = jb + u < B ? jb + u : B - 1;
+                const float4 bv = *(const float4*)(b + (long)j * D + k);
+                acc[u] = fmaf(av.x, bv.x, fmaf(av.y, bv.y, fmaf(av.z, bv.z, fmaf(av.w, bv.w, acc[u]))));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float v = wave_sum(acc[u]);
+            if (lane == 0 && jb + u < B) S[(long)i * B + jb + u] = v * inv_T;
+        }
+    }
+}
+
 __device__ __forceinline__ float block_max(float v, float* sh) {
     v = wave_max(v);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
@@ -181,7 +209,8 @@ extern "C" int tri_ntxent_fwd_bwd(const float* za, const float* zb, int B, int D
         a = ahat; b = bhat;
     }
     float inv_T = 1.0f / temperature;
-    ntx_sim_kernel<<<dim3((B + 63) / 64, (B + 63) / 64), 256, 0, s>>>(a, b, B, D, inv_T, S);
+    if (B <= 512 && D % 4 == 0 && D <= 8192) ntx_sim_rows_kernel<<<B, 256, (size_t)D * sizeof(float), s>>>(a, b, B, D, inv_T, S);
+    else ntx_sim_kernel<<<dim3((B + 63) / 64, (B + 63) / 64), 256, 0, s>>>(a, b, B, D, inv_T, S);
     ntx_lse_kernel<<<B, 256, 0, s>>>(S, B, alpha, lse_row, lse_col, rowloss);
     ntx_loss_sum_kernel<<<1, 64, 0, s>>>(rowloss, B, loss);
     if (dza && dzb)
