@@ -91,12 +91,14 @@ int tri_bn_act(const void* y, const float* scale, const float* shift, const void
                void* out, long M, int C, int relu, int act_bf16, void* stream);
 int tri_relu_bwd(const void* dout, const void* out, void* g, long n, int act_bf16, void* stream);
 int tri_bn_bwd_num_blocks(long M);
-int tri_bn_bwd_reduce(const void* y, const void* g, long M, int C, float* partial, int act_bf16, void* stream);
+/* relu_scale / relu_shift (optional): g is the gradient w.r.t. relu(bn(y)); the mask y*scale+shift > 0 is recomputed */
+int tri_bn_bwd_reduce(const void* y, const void* g, long M, int C, float* partial, const float* relu_scale, const float* relu_shift,
+                      int act_bf16, void* stream);
 int tri_bn_bwd_finalize(const float* partial, int nblk, int C, const int* count_dev, int count_host, const float* gamma,
                         const float* mean, const float* invstd, float* dgamma, float* dbeta, float* c1, float* c2, float* c3,
                         void* stream);
 int tri_bn_bwd_apply(const void* y, const void* g, const float* c1, const float* c2, const float* c3, const uint8_t* row_mask,
-                     void* dy, long M, int C, int act_bf16, void* stream);
+                     void* dy, long M, int C, const float* relu_scale, const float* relu_shift, int act_bf16, void* stream);
 
 /* ---- pooling -------------------------------------------------------------------------------------------------
  * BN + ReLU + mask + spconv.SparseMaxPool3d(2,2) fused (sparse_cnn.py:13-15 ...), its backward routing;

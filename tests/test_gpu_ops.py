@@ -221,6 +221,29 @@ def test_bn2d_forward_backward_matches_torch():
     np.testing.assert_allclose(gz.cpu().numpy(), rr.grad.permute(0, 2, 3, 1).reshape(M, C).numpy(), atol=1e-6)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_bn_bwd_recomputed_relu_mask(dtype):
+    """relu(bn(y)) backward with the mask recomputed from y inside the BN passes == relu_bwd followed by bn_bwd."""
+    g = torch.Generator().manual_seed(13)
+    M, C = 700, 64
+    y = (torch.randn(M, C, generator=g) * 2 + 0.3).to(dtype)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    yf = y.float()
+    stats = torch.stack([yf.double().sum(0).float(), (yf.double() ** 2).sum(0).float()]).view(1, 2, C)
+    co = ops.bn_finalize(stats.to(DEV), C, gamma.to(DEV), beta.to(DEV), None, None, None, count_host=M)
+    out = ops.bn_act(y.to(DEV), co, relu=True)
+    dout = torch.randn(M, C, generator=g).to(dtype).to(DEV)
+    gz = ops.relu_bwd(dout, out, inplace=False)
+    dy_a, dg_a, db_a = ops.bn_bwd(y.to(DEV), gz, co, gamma.to(DEV), count_host=M, inplace=False)
+    dy_b, dg_b, db_b = ops.bn_bwd(y.to(DEV), dout, co, gamma.to(DEV), count_host=M, inplace=False, relu=True)
+    assert torch.equal(dy_a, dy_b) and torch.equal(dg_a, dg_b) and torch.equal(db_a, db_b)
+    yr, gr, br = yf.clone().requires_grad_(), gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    F.relu(F.batch_norm(yr, None, None, gr, br, True, 0.1, 1e-5)).backward(dout.float().cpu())
+    tol = 3e-5 if dtype == torch.float32 else 3e-2
+    np.testing.assert_allclose(dy_b.float().cpu().numpy(), yr.grad.numpy(), atol=tol, rtol=tol)
+    np.testing.assert_allclose(dg_b.cpu().numpy(), gr.grad.numpy(), rtol=2e-3 if dtype == torch.bfloat16 else 1e-4, atol=tol * 10)
+
+
 def test_voxel_bn_pool_forward_backward_matches_oracle():
     from oracle import spconv_dense as sp
     g = torch.Generator().manual_seed(5)

@@ -144,7 +144,7 @@ extern "C" int tri_relu_bwd(const void* dout, const void* out, void* g, long n, 
 static inline int bnb_rows(long M) { return M >= 65536 ? 256 : 64; }
 template <typename T>
 __global__ void bn_bwd_reduce_kernel(const T* __restrict__ y, const T* __restrict__ g, long M, int C, float* __restrict__ partial,
-                                     int BNB_ROWS) {
+                                     int BNB_ROWS, const float4* __restrict__ rs, const float4* __restrict__ rb) {
     extern __shared__ float sh[];                      // [rows_per_pass][C4*4][2]
     const int C4 = C >> 2;
     const int tpr = C4 < 256 ? C4 : 256;               // threads per row
@@ -156,10 +156,14 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ y, const T* __restric
     for (int cc = 0; cc < cpt; ++cc) {
         int c4 = tc + cc * tpr;
         float4 sg = make_float4(0, 0, 0, 0), sgy = make_float4(0, 0, 0, 0);
+        float4 s4 = make_float4(0, 0, 0, 0), b4 = make_float4(1, 1, 1, 1);      // no ReLU: y*0 + 1 > 0 always
+        if (rs && c4 < C4) { s4 = rs[c4]; b4 = rb[c4]; }
         if (c4 < C4 && tr < rpp)
 #pragma unroll 4
             for (long r = r0 + tr; r < r1; r += rpp) {
                 float4 gv = Act<T>::ld4(g + r * C + c4 * 4), yv = Act<T>::ld4(y + r * C + c4 * 4);
+                gv.x = __fmaf_rn(yv.x, s4.x, b4.x) > 0.f ? gv.x : 0.f; gv.y = __fmaf_rn(yv.y, s4.y, b4.y) > 0.f ? gv.y : 0.f;
+                gv.z = __fmaf_rn(yv.z, s4.z, b4.z) > 0.f ? gv.z : 0.f; gv.w = __fmaf_rn(yv.w, s4.w, b4.w) > 0.f ? gv.w : 0.f;
                 sg.x += gv.x; sg.y += gv.y; sg.z += gv.z; sg.w += gv.w;
                 sgy.x += gv.x * yv.x; sgy.y += gv.y * yv.y; sgy.z += gv.z * yv.z; sgy.w += gv.w * yv.w;
             }
@@ -183,13 +187,17 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ y, const T* __restric
     }
 }
 extern "C" int tri_bn_bwd_num_blocks(long M) { return (int)((M + bnb_rows(M) - 1) / bnb_rows(M)); }
-extern "C" int tri_bn_bwd_reduce(const void* y, const void* g, long M, int C, float* partial, int act_bf16, void* stream) {
+// relu_scale / relu_shift (optional, [C]): the BN output went through ReLU and `g` is the gradient w.r.t. the ReLU OUTPUT;
+// the mask (y*scale + shift > 0, the forward's own expression) is recomputed instead of materialising relu_bwd's result.
+extern "C" int tri_bn_bwd_reduce(const void* y, const void* g, long M, int C, float* partial, const float* relu_scale,
+                                 const float* relu_shift, int act_bf16, void* stream) {
     if (C % 4) { tri_set_error("tri_bn_bwd_reduce: C must be a multiple of 4"); return TRI_ERR_ARG; }
     int rows = bnb_rows(M);
     int nblk = (int)((M + rows - 1) / rows);
     int C4 = C / 4, tpr = C4 < 256 ? C4 : 256, rpp = 256 / tpr;
     size_t smem = (size_t)rpp * tpr * 8 * sizeof(float);
-    TRI_ACT_DISPATCH(act_bf16, bn_bwd_reduce_kernel<T><<<nblk, 256, smem, (hipStream_t)stream>>>((const T*)y, (const T*)g, M, C, partial, rows));
+    TRI_ACT_DISPATCH(act_bf16, bn_bwd_reduce_kernel<T><<<nblk, 256, smem, (hipStream_t)stream>>>((const T*)y, (const T*)g, M, C, partial, rows,
+                                                                                                  (const float4*)relu_scale, (const float4*)relu_shift));
     return tri_check_launch("tri_bn_bwd_reduce");
 }
 
@@ -236,13 +244,19 @@ extern "C" int tri_bn_bwd_finalize(const float* partial, int nblk, int C, const 
 template <typename T>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ y, const T* g, const float4* __restrict__ c1,
                                     const float4* __restrict__ c2, const float4* __restrict__ c3,
-                                    const uint8_t* __restrict__ row_mask, T* dy, long total4, int C4) {
+                                    const uint8_t* __restrict__ row_mask, T* dy, long total4, int C4,
+                                    const float4* __restrict__ rs, const float4* __restrict__ rb) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
         long row = i / C4;
         int c = (int)(i - row * C4);
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
         if (!row_mask || row_mask[row]) {
             float4 yv = Act<T>::ld4(y + i * 4), gv = Act<T>::ld4(g + i * 4), a = c1[c], b = c2[c], d = c3[c];
+            if (rs) {                                               // ReLU mask recomputed from y (see tri_bn_bwd_reduce)
+                const float4 s4 = rs[c], b4 = rb[c];
+                gv.x = __fmaf_rn(yv.x, s4.x, b4.x) > 0.f ? gv.x : 0.f; gv.y = __fmaf_rn(yv.y, s4.y, b4.y) > 0.f ? gv.y : 0.f;
+                gv.z = __fmaf_rn(yv.z, s4.z, b4.z) > 0.f ? gv.z : 0.f; gv.w = __fmaf_rn(yv.w, s4.w, b4.w) > 0.f ? gv.w : 0.f;
+            }
             o.x = a.x * gv.x + b.x + d.x * yv.x; o.y = a.y * gv.y + b.y + d.y * yv.y;
             o.z = a.z * gv.z + b.z + d.z * yv.z; o.w = a.w * gv.w + b.w + d.w * yv.w;
         }
@@ -250,10 +264,12 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ y, const T* g, const f
     }
 }
 extern "C" int tri_bn_bwd_apply(const void* y, const void* g, const float* c1, const float* c2, const float* c3,
-                                const uint8_t* row_mask, void* dy, long M, int C, int act_bf16, void* stream) {
+                                const uint8_t* row_mask, void* dy, long M, int C, const float* relu_scale, const float* relu_shift,
+                                int act_bf16, void* stream) {
     long total4 = M * (C / 4);
     TRI_ACT_DISPATCH(act_bf16, bn_bwd_apply_kernel<T><<<ew_grid(total4), 256, 0, (hipStream_t)stream>>>(
-        (const T*)y, (const T*)g, (const float4*)c1, (const float4*)c2, (const float4*)c3, row_mask, (T*)dy, total4, C / 4));
+        (const T*)y, (const T*)g, (const float4*)c1, (const float4*)c2, (const float4*)c3, row_mask, (T*)dy, total4, C / 4,
+        (const float4*)relu_scale, (const float4*)relu_shift));
     return tri_check_launch("tri_bn_bwd_apply");
 }
 

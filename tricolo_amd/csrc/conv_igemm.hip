@@ -886,6 +886,14 @@ static bool brick_disabled() {
 }
 
 // dims: grid of the rows (M side) == grid of the gathered tensor for brick-eligible layers
+// Split-K target: workgroups a small-M layer is split up to.  Every split costs M x Cout fp32 of slab write + re-read,
+// so the sweep (profiles/r1/README.md) favours ~one workgroup per CU over the 3 per CU the fp32-staging kernel liked.
+static int conv_target_blocks() {                               // tuning aid: TRICOLO_CONV_BLOCKS overrides it
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("TRICOLO_CONV_BLOCKS"); v = (e && atoi(e) > 0) ? atoi(e) : 0; }
+    return v;
+}
+
 static bool dma_disabled() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("TRICOLO_NO_DMA"); v = (e && e[0] == '1') ? 1 : 0; }
@@ -919,7 +927,8 @@ static ConvPlan conv_make_plan(int B, int ID, int IH, int IW, int cin, int OD, i
     int ks = 1;
     int min_per = pl.brick ? 3 : (pl.dma ? 2 : 4);                              // at least this many units per split
     if (blocks < 384 && pl.nunits >= 2 * min_per && cout % 64 == 0) {
-        ks = (768 + blocks - 1) / blocks;
+        const int target = conv_target_blocks() ? conv_target_blocks() : (split_mode == 2 ? 256 : 768);
+        ks = (target + blocks - 1) / blocks;
         if (ks > pl.nunits / min_per) ks = pl.nunits / min_per;
         if (ks > 32) ks = 32;
         if (ks < 1) ks = 1;

@@ -184,8 +184,8 @@ class MVCNNEncoder(TriModule):
             dy2, gr[blk.bn2.weight], gr[blk.bn2.bias] = ops.bn_bwd(y2, g, co2, blk.bn2.weight, count_host=g2.M, inplace=False)
             wgrad_async(a1, dy2, g2, blk.conv2.weight)
             da1 = ops.conv_dgrad(dy2, g2, self._packed[(id(blk.conv2), True)])
-            g1z = ops.relu_bwd(da1, a1)
-            dy1, gr[blk.bn1.weight], gr[blk.bn1.bias] = ops.bn_bwd(y1, g1z, co1, blk.bn1.weight, count_host=g1.M)
+            # relu(bn1(y1)) backward: the ReLU mask is recomputed from y1 inside the BN passes (no relu_bwd pass over a1)
+            dy1, gr[blk.bn1.weight], gr[blk.bn1.bias] = ops.bn_bwd(y1, da1, co1, blk.bn1.weight, count_host=g1.M, relu=True)
             wgrad_async(x, dy1, g1, blk.conv1.weight)
             if blk.downsample is not None:
                 dyd, gr[blk.downsample[1].weight], gr[blk.downsample[1].bias] = ops.bn_bwd(
@@ -198,8 +198,7 @@ class MVCNNEncoder(TriModule):
             dout = dx
         x0, y, co, g0, z, parg = saved["stem"]
         dzs = ops.maxpool2d_bwd(parg, dout, tuple(z.shape))
-        gz = ops.relu_bwd(dzs, z)
-        dy, gr[self.net_1[1].weight], gr[self.net_1[1].bias] = ops.bn_bwd(y, gz, co, self.net_1[1].weight, count_host=g0.M)
+        dy, gr[self.net_1[1].weight], gr[self.net_1[1].bias] = ops.bn_bwd(y, dzs, co, self.net_1[1].weight, count_host=g0.M, relu=True)
         wgrad_async(x0, dy, g0, self.net_1[0].weight)
         side.join(*[gr[p] for p in self._param_list() if p.dim() == 4])
         return [gr[p] for p in self._param_list()]
