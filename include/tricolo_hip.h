@@ -107,8 +107,9 @@ int tri_bn_relu_pool3d_fwd(const void* y, const float* scale, const float* shift
                            void* pooled, uint8_t* mask_out, int act_bf16, void* stream);
 int tri_pool3d_bwd_route(const void* y, const float* scale, const float* shift, const uint8_t* mask, const void* pooled,
                          const void* dpooled, int B, int D, int C, void* g, int act_bf16, void* stream);
+/* bn_scale / bn_shift (optional, [C]): pools relu(x * scale + shift), i.e. BatchNorm + ReLU + MaxPool2d of the ResNet stem in one pass */
 int tri_maxpool2d_fwd(const void* x, int N, int H, int W, int C, void* out, uint8_t* arg /* [N,Ho,Wo,C] winning tap, may be NULL */,
-                      int act_bf16, void* stream);
+                      const float* bn_scale, const float* bn_shift, int act_bf16, void* stream);
 int tri_maxpool2d_bwd(const uint8_t* arg, const void* dout, int N, int H, int W, int C, void* dx, int act_bf16, void* stream);
 int tri_avgpool_viewmax_fwd(const void* x, int B, int V, int HW, int C, float* out, int* arg, int act_bf16, void* stream);
 int tri_avgpool_viewmax_bwd(const float* dout, const int* arg, int B, int V, int HW, int C, void* dx, int act_bf16, void* stream);

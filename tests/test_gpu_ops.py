@@ -306,6 +306,13 @@ def test_maxpool2d_and_viewmax():
     assert torch.equal(out.cpu().view(N, 5, 5, C).permute(0, 3, 1, 2), ref.detach())
     dx = ops.maxpool2d_bwd(parg, dout.permute(0, 2, 3, 1).contiguous().to(DEV), tuple(xcl.shape))
     np.testing.assert_allclose(dx.cpu().view(N, H, W, C).permute(0, 3, 1, 2).numpy(), xr.grad.numpy(), atol=1e-6)
+    # BN + ReLU + max-pool in one pass == bn_act followed by the plain pool (values and winning taps)
+    co = ops.bn_eval_coeffs(C, (torch.rand(C, generator=g) + 0.5).to(DEV), torch.randn(C, generator=g).to(DEV),
+                            torch.full((C,), 2.5).to(DEV), torch.ones(C).to(DEV))
+    z = ops.bn_act(xcl, co, relu=True)
+    o1, a1 = ops.maxpool2d_fwd(z)
+    o2, a2 = ops.maxpool2d_fwd(xcl, bn=co)
+    assert torch.equal(o1, o2) and torch.equal(a1, a2)
     # avg-pool + view max (mv_cnn.py:29-31)
     B, V = 2, 3
     f = torch.randn(B * V, 512, 4, 4, generator=g)

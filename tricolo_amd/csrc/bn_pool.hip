@@ -363,7 +363,7 @@ extern "C" int tri_pool3d_bwd_route(const void* y, const float* scale, const flo
 // 4 byte reads + 4 float4 reads instead of re-scanning 36 inputs.  Deterministic, no atomics.
 template <typename T>
 __global__ void maxpool2d_fwd_kernel(const T* __restrict__ x, int N, int H, int W, int C4, T* __restrict__ out,
-                                     uchar4* __restrict__ arg) {
+                                     uchar4* __restrict__ arg, const float4* __restrict__ scale, const float4* __restrict__ shift) {
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;          // floor((H + 2 - 3)/2) + 1
     const long total = (long)N * Ho * Wo * C4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -373,6 +373,8 @@ __global__ void maxpool2d_fwd_kernel(const T* __restrict__ x, int N, int H, int 
         int oh = (int)(r % Ho); int n = (int)(r / Ho);
         float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
         uchar4 bi = make_uchar4(0, 0, 0, 0);
+        float4 s4 = make_float4(1.f, 1.f, 1.f, 1.f), b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (scale) { s4 = scale[c]; b4 = shift[c]; }
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
             int ih = oh * 2 - 1 + kh;
@@ -382,6 +384,10 @@ __global__ void maxpool2d_fwd_kernel(const T* __restrict__ x, int N, int H, int 
                 int iw = ow * 2 - 1 + kw;
                 if ((unsigned)iw >= (unsigned)W) continue;
                 float4 v = Act<T>::ld4(x + ((((long)n * H + ih) * W + iw) * C4 + c) * 4);
+                if (scale) {                                       // pooling relu(bn(x)) without materialising it
+                    v.x = fmaxf(__fmaf_rn(v.x, s4.x, b4.x), 0.f); v.y = fmaxf(__fmaf_rn(v.y, s4.y, b4.y), 0.f);
+                    v.z = fmaxf(__fmaf_rn(v.z, s4.z, b4.z), 0.f); v.w = fmaxf(__fmaf_rn(v.w, s4.w, b4.w), 0.f);
+                }
                 unsigned char k = (unsigned char)(kh * 3 + kw);
                 if (v.x > best.x) { best.x = v.x; bi.x = k; }
                 if (v.y > best.y) { best.y = v.y; bi.y = k; }
@@ -393,9 +399,12 @@ __global__ void maxpool2d_fwd_kernel(const T* __restrict__ x, int N, int H, int 
         if (arg) arg[i] = bi;
     }
 }
-extern "C" int tri_maxpool2d_fwd(const void* x, int N, int H, int W, int C, void* out, uint8_t* arg, int act_bf16, void* stream) {
+// bn_scale / bn_shift (optional, [C]): pool relu(x * scale + shift) - the ResNet stem's BN + ReLU + max-pool in one pass
+extern "C" int tri_maxpool2d_fwd(const void* x, int N, int H, int W, int C, void* out, uint8_t* arg, const float* bn_scale,
+                                 const float* bn_shift, int act_bf16, void* stream) {
     long total = (long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
-    TRI_ACT_DISPATCH(act_bf16, maxpool2d_fwd_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)stream>>>((const T*)x, N, H, W, C / 4, (T*)out, (uchar4*)arg));
+    TRI_ACT_DISPATCH(act_bf16, maxpool2d_fwd_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)stream>>>((const T*)x, N, H, W, C / 4, (T*)out, (uchar4*)arg,
+                                                                                                  (const float4*)bn_scale, (const float4*)bn_shift));
     return tri_check_launch("tri_maxpool2d_fwd");
 }
 

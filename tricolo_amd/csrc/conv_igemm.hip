@@ -869,6 +869,7 @@ static int conv_bn(int cout) { return cout % 128 == 0 ? 128 : (cout % 64 == 0 ? 
 
 // One plan per (geometry, direction), used by the launchers AND by the workspace / statistics-size queries.
 struct ConvPlan {
+    int bn;               // output-channel tile
     int dma;              // 1: LDS-DMA kernel (bf16 activation storage, Cin % 64 == 0), 64-wide k-steps
     int brick;            // 0 generic im2col kernel, else channel chunk CB (32 / 64) of the brick kernel
     int R, brick_rows;    // brick: halo reach and staged rows
@@ -923,6 +924,14 @@ static ConvPlan conv_make_plan(int B, int ID, int IH, int IW, int cin, int OD, i
         }
     }
     if (!pl.brick && split_mode == 2 && cin % 64 == 0 && cout % 64 == 0 && !dma_disabled()) pl.dma = 1;
+    pl.bn = bn;
+    {   // The DMA kernel is latency-bound, not MFMA-bound, at this workload's layer sizes: 128x64 tiles (24 KiB stages, three
+        // workgroups per CU, twice the workgroups) beat 128x128 on every layer measured up to 384 wide tiles (sweep in
+        // profiles/r1/README.md).  Wide tiles are kept for launches that fill the GPU several times over anyway.
+        static int narrow = -1;
+        if (narrow < 0) { const char* e = getenv("TRICOLO_DMA_BN64"); narrow = e ? atoi(e) : 1024; }
+        if (pl.dma && bn == 128 && blocks < narrow) { pl.bn = 64; blocks *= 2; }
+    }
     if (!pl.brick) pl.nunits = pl.dma ? kpad / 64 : kpad / 32;
     int ks = 1;
     int min_per = pl.brick ? 3 : (pl.dma ? 2 : 4);                              // at least this many units per split
@@ -999,7 +1008,7 @@ static int conv_dispatch(ConvArgs& a, int act_bf16, void* workspace, size_t work
         a.slab = (float*)workspace;
     }
     a.dOW = make_fastdiv(a.OW); a.dOH = make_fastdiv(a.OH); a.dOD = make_fastdiv(a.OD); a.dCin = make_fastdiv(a.Cin);
-    if (pl.dma) return a.Cout % 128 == 0 ? launch_dma<128>(a, stream) : launch_dma<64>(a, stream);
+    if (pl.dma) return pl.bn == 128 ? launch_dma<128>(a, stream) : launch_dma<64>(a, stream);
     if (pl.brick) {
         const int bn = conv_bn(a.Cout);
 #define TRI_BRICK(BN_, CB_)                                                                               \

@@ -137,9 +137,8 @@ class MVCNNEncoder(TriModule):
         self._packed = self._pack_all(N, images.shape[2], images.shape[3], prec, train and save, images.device)
         x0 = ops.nchw3_to_nhwc4(images, dtype=ops.act_dtype(prec))
         y, co, g = self._conv_bn(x0, self.net_1[0], self.net_1[1], prec, train)
-        z = ops.bn_act(y, co, relu=True)
-        x, parg = ops.maxpool2d_fwd(z, want_arg=save)
-        saved = {"stem": (x0, y, co, g, z, parg), "blocks": [], "B": B, "N": N}
+        x, parg = ops.maxpool2d_fwd(y, want_arg=save, bn=co)            # BN + ReLU + 3x3/2 max-pool: relu(bn(y)) is never stored
+        saved = {"stem": (x0, y, co, g, parg), "blocks": [], "B": B, "N": N}
         for blk in self._blocks():
             y1, co1, g1 = self._conv_bn(x, blk.conv1, blk.bn1, prec, train)
             a1 = ops.bn_act(y1, co1, relu=True)
@@ -196,8 +195,8 @@ class MVCNNEncoder(TriModule):
                 dx = g                                                         # identity branch
             dx = ops.conv_dgrad(dy1, g1, self._packed[(id(blk.conv1), True)], out=dx, accumulate=True)
             dout = dx
-        x0, y, co, g0, z, parg = saved["stem"]
-        dzs = ops.maxpool2d_bwd(parg, dout, tuple(z.shape))
+        x0, y, co, g0, parg = saved["stem"]
+        dzs = ops.maxpool2d_bwd(parg, dout, tuple(y.shape))
         dy, gr[self.net_1[1].weight], gr[self.net_1[1].bias] = ops.bn_bwd(y, dzs, co, self.net_1[1].weight, count_host=g0.M, relu=True)
         wgrad_async(x0, dy, g0, self.net_1[0].weight)
         side.join(*[gr[p] for p in self._param_list() if p.dim() == 4])

@@ -344,12 +344,14 @@ def pool3d_bwd_route(y, co: BNCoeffs, mask, pooled, dpooled, B, D, C):
     return g
 
 
-def maxpool2d_fwd(x, want_arg=True):
-    """3x3/2/pad-1 max-pool; also returns the winning-tap byte map used by maxpool2d_bwd."""
+def maxpool2d_fwd(x, want_arg=True, bn: BNCoeffs = None):
+    """3x3/2/pad-1 max-pool; also returns the winning-tap byte map used by maxpool2d_bwd.
+    With ``bn`` the pooled tensor is relu(x * scale + shift): BatchNorm + ReLU + MaxPool2d in one pass."""
     N, _, H, W, C = x.shape
     out = torch.empty((N, 1, (H + 1) // 2, (W + 1) // 2, C), dtype=x.dtype, device=x.device)
     arg = torch.empty(out.shape, dtype=torch.uint8, device=x.device) if want_arg else None
-    check(lib().tri_maxpool2d_fwd(ptr(_act(x)), N, H, W, C, ptr(out), ptr(arg), _abf(x), stream()), "tri_maxpool2d_fwd")
+    check(lib().tri_maxpool2d_fwd(ptr(_act(x)), N, H, W, C, ptr(out), ptr(arg), ptr(bn.scale if bn else None), ptr(bn.shift if bn else None),
+                                  _abf(x), stream()), "tri_maxpool2d_fwd")
     return out, arg
 
 
