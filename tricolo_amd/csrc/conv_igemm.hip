@@ -34,6 +34,12 @@ struct ConvArgs {
     FastDiv dOW, dOH, dOD, dCin;
 };
 
+// v rotated right by N lanes inside its row of 16 lanes (DPP row_ror)
+template <int N>
+__device__ __forceinline__ float row_ror(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, false));
+}
+
 // Shared epilogue: acc[a][b][r] = out[m = a-tile row (lane & 15)][n = b-tile col 4 * (lane >> 4) + r].
 template <typename AT, int BN, int TM, int TN, int WAVES_M, int WM, int WN>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[TM][TN], int m0, int n0, int mtile, int wm, int wn, int fr,
@@ -95,8 +101,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[TM
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float s = cs[b][r], q = cq[b][r];
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+                // the 16 rows of a fragment are the 16 lanes of one DPP row: rotate-and-add on the VALU instead of 8
+                // ds_bpermute round trips per column (measured: statistics were 3,300 of a tile's ~31,000 cycles)
+                s += row_ror<8>(s); q += row_ror<8>(q);
+                s += row_ror<4>(s); q += row_ror<4>(q);
+                s += row_ror<2>(s); q += row_ror<2>(q);
+                s += row_ror<1>(s); q += row_ror<1>(q);
                 if (fr == 0) {
                     int col = wn * WN + b * 16 + fq * 4 + r;
                     red[(wm * BN + col) * 2 + 0] = s;
@@ -743,6 +753,232 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs p) {
     conv_epilogue<AT, BN, TM, TN, WAVES_M, WM, WN>(p, acc, m0, n0, mtile, wm, wn, fr, fq, t, split, any_active, red);
 }
 
+// ================================================================================================ halo kernel
+// Stride-1 "same" 3x3 / 3x3x3 layers with bf16 activation storage (every BasicBlock conv of ResNet-18 past the
+// down-sampling ones, voxel levels 2-4, and their data gradients).  The im2col view reads every input row 9 / 27
+// times; conv_dma_kernel pays for each of those reads in L2->LDS traffic and, worse, in one exposed memory latency
+// per 64-wide k-step (ablation in profiles/r1/README.md: with MFMA, A loads and epilogue all removed the kernel
+// still takes 65 % of its time).  Here a workgroup DMAs the 64-channel slice of the rows its 128 outputs can touch
+// (positions m0 - R .. m0 + 127 + R, R = one row + one pixel (+ one plane)) into LDS ONCE per channel chunk and
+// serves all taps from it: a tap is a row offset into the brick, image borders are handled by zeroing the A
+// fragment of invalid (row, tap) pairs in registers.  Per (chunk, tap) unit only the 8 KiB weight slice streams
+// in (3-slot ring, two units ahead), the next chunk's brick streams in under 9 / 27 units of MFMA work.
+__device__ __forceinline__ void wait_vmcnt(int n) {
+    switch (n) {
+#define TRI_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+        TRI_W(0) TRI_W(1) TRI_W(2) TRI_W(3) TRI_W(4) TRI_W(5) TRI_W(6) TRI_W(7) TRI_W(8) TRI_W(9) TRI_W(10) TRI_W(11) TRI_W(12)
+        TRI_W(13) TRI_W(14) TRI_W(15) TRI_W(16) TRI_W(17) TRI_W(18) TRI_W(19) TRI_W(20) TRI_W(21) TRI_W(22) TRI_W(23) TRI_W(24)
+        TRI_W(25) TRI_W(26) TRI_W(27) TRI_W(28) TRI_W(29) TRI_W(30) TRI_W(31) TRI_W(32)
+#undef TRI_W
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+// LDS-DMA issued through inline asm: the compiler then knows nothing about LDS being written asynchronously and does not
+// put its own (conservative, vmcnt(0)) wait in front of every ds_read that follows - the counted waits + barriers of the
+// kernel are the only synchronisation, which is what lets DMAs stay in flight across several compute units of work.
+typedef int v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4i make_rsrc_words(const void* base, unsigned bytes) {
+    return (v4i){(int)(unsigned)(size_t)base, (int)(((size_t)base >> 32) & 0xffff), (int)bytes, 0x00020000};
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
+#else
+    return 0;
+#endif
+}
+// lds_dst must be wave-uniform (the hardware adds lane * 16)
+__device__ __forceinline__ void dma16_async(v4i rsrc, unsigned lds_dst, int voff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                 :: "s"(__builtin_amdgcn_readfirstlane(lds_dst)), "v"(voff), "s"(rsrc) : "memory", "m0");
+#endif
+}
+
+template <int BN>
+__global__ __launch_bounds__(256) void conv_halo_kernel(const ConvArgs p) {
+    typedef bf16_t AT;
+    constexpr int BM = 128;
+    constexpr int WAVES_N = 2, WAVES_M = 2;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 16, TN = WN / 16;
+    constexpr int B_BYTES = BN * 128, NBI = BN / 32;             // weight slice of one unit; its DMA instructions per thread
+    constexpr int RING = 4, AHEAD = RING - 1;                    // weight slices in flight ahead of the MFMAs
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int brick_bytes = p.brick_rows * 128;                   // brick_rows is a multiple of 32
+    const int nbuf = p.steps_per_split > 1 ? 2 : 1;               // one chunk per workgroup: no second brick buffer
+    char* const ring = smem + nbuf * brick_bytes;
+    int* lut_pos = (int*)(ring + RING * B_BYTES);                 // [64] position offset of the tap
+    int* lut_sh = lut_pos + 64;
+    float* red = (float*)(ring + RING * B_BYTES + 512);
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int NT = p.Cout / BN;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int mtile = wg / NT, ntile = wg - mtile * NT;
+    const int m0 = mtile * BM, n0 = ntile * BN;
+    const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int split = blockIdx.y;
+
+    if (t < 64) {
+        int kd = 0, kh = 0, kw = 0;
+        if (t < p.ntaps) {
+            kw = t % p.KW;
+            int r = t / p.KW;
+            kh = r % p.KH;
+            kd = r / p.KH;
+        }
+        lut_sh[t] = kw | ((8 + kh) << 8) | ((16 + kd) << 16);
+        const int po = ((kd - p.pd) * p.IH + (kh - p.ph)) * p.IW + (kw - p.pw);
+        lut_pos[t] = p.transposed ? -po : po;
+    }
+    // tiles without an active output site (submanifold layers) do nothing at all
+    int any_active = 1;
+    if (p.row_mask) {
+        any_active = 0;
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            int m = m0 + wm * WM + a * 16 + fr;
+            any_active |= (m < p.M && p.row_mask[m] != 0) ? 1 : 0;
+        }
+    }
+    any_active = __syncthreads_or(any_active);
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (any_active) {
+        const int ntaps = p.ntaps;
+        const int nchunks = p.Cin >> 6;
+        const int c_begin = split * p.steps_per_split;           // splits are whole channel chunks
+        const int c_end = min(nchunks, c_begin + p.steps_per_split);
+        const int nunits = (c_end - c_begin) * ntaps;
+        const int nbrick = p.brick_rows >> 5;                    // brick DMA instructions per thread
+        const v4i rsrc = make_rsrc_words(p.in, p.in_bytes);
+        const v4i wrsrc = make_rsrc_words(p.w_hi + (size_t)n0 * p.Kpad, (unsigned)(BN * p.Kpad * 2));
+        const unsigned lds0 = lds_addr(smem) + wave * 1024;       // this wave's 1 KiB slice of every 4 KiB DMA group
+        const unsigned ring0 = lds0 + nbuf * brick_bytes;
+        // brick DMA: instruction i of this thread covers brick row 32 i + (t >> 3), LDS slot (t & 7); the slot holds
+        // source chunk slot ^ ((row >> 1) & 7) and (32 i) >> 1 is a multiple of 8, so the chunk is the same for every i
+        const int brow0 = t >> 3;
+        const int bchunk = (t & 7) ^ ((brow0 >> 1) & 7);
+        const int boff0 = ((m0 - p.R + brow0) * p.Cin + bchunk * 8) * 2;   // negative rows wrap to huge unsigned offsets -> zeros
+        const int bstep = 32 * p.Cin * 2;
+        int woff[NBI];
+#pragma unroll
+        for (int i = 0; i < NBI; ++i) {
+            int n = (t >> 3) + 32 * i;
+            woff[i] = (n * p.Kpad + ((t & 7) ^ ((n >> 1) & 7)) * 8) * 2;
+        }
+        auto issue_brick = [&](int c) {
+            unsigned dst = lds0 + ((c - c_begin) & (nbuf - 1)) * brick_bytes;
+            int voff = boff0 + c * 128;
+            for (int i = 0; i < nbrick; ++i) {
+                dma16_async(rsrc, dst, voff);
+                dst += 4096;
+                voff += bstep;
+            }
+        };
+        auto issue_w = [&](int c, int tap, int slot) {
+            const int kb = (tap * p.Cin + c * 64) * 2;
+#pragma unroll
+            for (int i = 0; i < NBI; ++i) dma16_async(wrsrc, ring0 + slot * B_BYTES + i * 4096, woff[i] + kb);
+        };
+
+        // DMA completes in issue order.  Issue order: brick(c0), W(0) .. W(AHEAD - 1), then unit u issues W(u + AHEAD) and, at
+        // tap 0, the next chunk's brick.  Everything is in flight while the per-row validity bits are worked out below.
+        issue_brick(c_begin);
+#pragma unroll
+        for (int k = 0; k < AHEAD; ++k)
+            if (k < nunits) issue_w(c_begin + k / ntaps, k % ntaps, k);
+
+        // validity bits of the 4 fragment rows this lane feeds to the MFMAs (rows wm*64 + a*16 + fr)
+        unsigned rmask[TM];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            int m = m0 + wm * WM + a * 16 + fr;
+            bool valid = m < p.M;
+            uint32_t mm = valid ? (uint32_t)m : 0u;
+            uint32_t q1 = fdiv(mm, p.dOW);
+            int ow = mm - q1 * p.OW;
+            uint32_t q2 = fdiv(q1, p.dOH);
+            int oh = q1 - q2 * p.OH;
+            uint32_t b = fdiv(q2, p.dOD);
+            int od = q2 - b * p.OD;
+            unsigned mk;
+            if (p.transposed) {
+                mk = axis_mask_t(ow + p.pw, p.KW, p.IW, 1) | (axis_mask_t(oh + p.ph, p.KH, p.IH, 1) << 8) |
+                     (axis_mask_t(od + p.pd, p.KD, p.ID, 1) << 16);
+            } else {
+                mk = axis_mask(ow - p.pw, p.KW, p.IW) | (axis_mask(oh - p.ph, p.KH, p.IH) << 8) | (axis_mask(od - p.pd, p.KD, p.ID) << 16);
+            }
+            rmask[a] = valid ? mk : 0u;
+        }
+
+        // fragment row r of the tile sits at brick row r + R + tap offset
+        const int arow0 = wm * WM + fr + p.R;
+        auto compute = [&](int c, int tap, int slot) {
+            const char* brick = smem + ((c - c_begin) & (nbuf - 1)) * brick_bytes;
+            const char* bb = ring + slot * B_BYTES;
+            const int po = lut_pos[tap], sh = lut_sh[tap];
+            const int sx = sh & 255, sy = (sh >> 8) & 255, sz = (sh >> 16) & 255;
+            unsigned keep[TM];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) keep[a] = (((rmask[a] >> sx) & (rmask[a] >> sy) & (rmask[a] >> sz)) & 1u) ? 0xffffffffu : 0u;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 ah[TM];
+#pragma unroll
+                for (int a = 0; a < TM; ++a) {
+                    const int br = arow0 + a * 16 + po;
+                    uint4 v = *(const uint4*)(brick + br * 128 + ((((kk * 4 + fq) ^ (br >> 1)) & 7) << 4));
+                    v.x &= keep[a]; v.y &= keep[a]; v.z &= keep[a]; v.w &= keep[a];
+                    ah[a] = __builtin_bit_cast(bf16x8, v);
+                }
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    bf16x8 bhf = *(const bf16x8*)(bb + brick_off<64>(wn * WN + b * 16 + fr, kk * 4 + fq));
+#pragma unroll
+                    for (int a = 0; a < TM; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhf, ah[a], acc[a][b], 0, 0, 0);
+                }
+            }
+        };
+
+        // vmcnt bookkeeping: at the top of unit u the DMA instructions YOUNGER than W(u) are the W's issued by units u - 1 and
+        // u - 2 and any brick issued by units u - 1, u - 2, u - 3 (a brick is issued after that unit's W)
+        int w1 = nunits > 2 ? NBI : 0, w2 = nunits > 1 ? NBI : 0, b1 = 0, b2 = 0, b3 = 0;
+        int c = c_begin, tap = 0, slot = 0;
+        for (int u = 0; u < nunits; ++u) {
+            const int young = w1 + w2 + b1 + b2 + b3;
+            if (young == 2 * NBI) wait_vmcnt(2 * NBI);            // steady state: a compile-time constant, no switch
+            else wait_vmcnt(young);                                // W(u) - and everything older, bricks included - has landed
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            int issued_w = 0, issued_b = 0;
+            if (u + AHEAD < nunits) {
+                int tapn = tap + AHEAD, cn = c;
+                if (tapn >= ntaps) { tapn -= ntaps; ++cn; }
+                int slotn = slot + AHEAD;
+                if (slotn >= RING) slotn -= RING;
+                issue_w(cn, tapn, slotn);
+                issued_w = NBI;
+            }
+            if (tap == 0 && c + 1 < c_end) { issue_brick(c + 1); issued_b = nbrick; }
+            compute(c, tap, slot);
+            w2 = w1; w1 = issued_w;
+            b3 = b2; b2 = b1; b1 = issued_b;
+            if (++tap == ntaps) { tap = 0; ++c; }
+            if (++slot == RING) slot = 0;
+        }
+        __syncthreads();
+    }
+    conv_epilogue<AT, BN, TM, TN, WAVES_M, WM, WN>(p, acc, m0, n0, mtile, wm, wn, fr, fq, t, split, any_active, red);
+}
+
 // out = act(sum_split slab + bias) * mask (+ out), plus BatchNorm partial sums per 32-row chunk.
 // One block = 32 rows x 64 columns (16 row lanes x 16 float4 column groups), grid = (row chunks, column chunks), so even
 // a 256-row layer spreads its slab read over dozens of CUs.
@@ -870,6 +1106,7 @@ static int conv_bn(int cout) { return cout % 128 == 0 ? 128 : (cout % 64 == 0 ? 
 // One plan per (geometry, direction), used by the launchers AND by the workspace / statistics-size queries.
 struct ConvPlan {
     int bn;               // output-channel tile
+    int halo;             // 1: conv_halo_kernel (bf16 storage, stride-1 same 3x3 / 3x3x3, Cin % 64 == 0); units = 64-channel chunks
     int dma;              // 1: LDS-DMA kernel (bf16 activation storage, Cin % 64 == 0), 64-wide k-steps
     int brick;            // 0 generic im2col kernel, else channel chunk CB (32 / 64) of the brick kernel
     int R, brick_rows;    // brick: halo reach and staged rows
@@ -893,6 +1130,16 @@ static int conv_target_blocks() {                               // tuning aid: T
     static int v = -1;
     if (v < 0) { const char* e = getenv("TRICOLO_CONV_BLOCKS"); v = (e && atoi(e) > 0) ? atoi(e) : 0; }
     return v;
+}
+
+// conv_halo_kernel is bit-exact (tests/test_gpu_ops.py with TRICOLO_HALO=1) and cuts the L2->LDS operand traffic of the
+// 3x3 layers ~6x, but measured 10-25 % SLOWER than conv_dma_kernel in round 1: s_memtime stamps show both kernels spend
+// their time in per-tile fixed costs (prologue ~5,000 cycles, epilogue ~6,000) and in ~2,000-cycle steps whose length is
+// set by instruction issue + one DMA latency, not by operand bytes (profiles/r1/README.md).  Opt-in until that is fixed.
+static bool halo_disabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("TRICOLO_HALO"); v = (e && e[0] == '1') ? 0 : 1; }
+    return v == 1;
 }
 
 static bool dma_disabled() {
@@ -925,6 +1172,27 @@ static ConvPlan conv_make_plan(int B, int ID, int IH, int IW, int cin, int OD, i
     }
     if (!pl.brick && split_mode == 2 && cin % 64 == 0 && cout % 64 == 0 && !dma_disabled()) pl.dma = 1;
     pl.bn = bn;
+    if (pl.dma && same && ntaps >= 9 && !halo_disabled()) {
+        int R = (pd * IH + ph) * IW + pw;
+        int rows = (128 + 2 * R + 31) / 32 * 32;                 // 32 brick rows per DMA instruction of the 4 waves
+        size_t smem = (size_t)2 * rows * 128 + 4 * 64 * 128 + 512 + (size_t)4 * 64 * 2 * sizeof(float);
+        if (smem <= 160 * 1024 && rows / 32 <= 24) {
+            pl.halo = 1; pl.bn = 64; pl.R = R; pl.brick_rows = rows; pl.smem = smem;
+            blocks = (int)((M + 127) / 128) * (cout / 64);
+            const int nchunks = cin / 64;
+            pl.nunits = nchunks;
+            int ks = 1;
+            if (blocks < 384 && nchunks >= 2) {
+                const int target = conv_target_blocks() ? conv_target_blocks() : 256;
+                ks = (target + blocks - 1) / blocks;
+                if (ks > nchunks) ks = nchunks;
+            }
+            pl.per_split = (nchunks + ks - 1) / ks;
+            pl.ksplit = (nchunks + pl.per_split - 1) / pl.per_split;
+            if (pl.per_split == 1) pl.smem -= (size_t)rows * 128;   // a single chunk per workgroup needs one brick buffer
+            return pl;
+        }
+    }
     {   // The DMA kernel is latency-bound, not MFMA-bound, at this workload's layer sizes: 128x64 tiles (24 KiB stages, three
         // workgroups per CU, twice the workgroups) beat 128x128 on every layer measured up to 384 wide tiles (sweep in
         // profiles/r1/README.md).  Wide tiles are kept for launches that fill the GPU several times over anyway.
@@ -960,6 +1228,21 @@ static int launch_brick(const ConvArgs& a, const ConvPlan& pl, hipStream_t strea
     int rc = tri_check_launch("tri_conv(brick)");
     if (rc || a.ksplit == 1) return rc;
     conv_splitk_finish_kernel<AT><<<dim3((a.M + 31) / 32, a.Cout / 64), 256, 0, stream>>>(a);
+    return tri_check_launch("tri_conv_splitk_finish");
+}
+
+template <int BN>
+static int launch_halo(const ConvArgs& a, const ConvPlan& pl, hipStream_t stream) {
+    static size_t attr = 0;
+    if (pl.smem > attr) {
+        hipFuncSetAttribute((const void*)conv_halo_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.smem);
+        attr = pl.smem;
+    }
+    int mt = (a.M + 127) / 128, nt = a.Cout / BN;
+    conv_halo_kernel<BN><<<dim3(mt * nt, a.ksplit), 256, pl.smem, stream>>>(a);
+    int rc = tri_check_launch("tri_conv(halo)");
+    if (rc || a.ksplit == 1) return rc;
+    conv_splitk_finish_kernel<bf16_t><<<dim3((a.M + 31) / 32, a.Cout / 64), 256, 0, stream>>>(a);
     return tri_check_launch("tri_conv_splitk_finish");
 }
 
@@ -1008,6 +1291,7 @@ static int conv_dispatch(ConvArgs& a, int act_bf16, void* workspace, size_t work
         a.slab = (float*)workspace;
     }
     a.dOW = make_fastdiv(a.OW); a.dOH = make_fastdiv(a.OH); a.dOD = make_fastdiv(a.OD); a.dCin = make_fastdiv(a.Cin);
+    if (pl.halo) return launch_halo<64>(a, pl, stream);
     if (pl.dma) return pl.bn == 128 ? launch_dma<128>(a, stream) : launch_dma<64>(a, stream);
     if (pl.brick) {
         const int bn = conv_bn(a.Cout);
@@ -1044,7 +1328,7 @@ extern "C" int tri_conv_kernel_family(const TriConvDesc* d, int transposed, int 
                                               d->pad_d, d->pad_h, d->pad_w, split3)
                              : conv_make_plan(d->B, d->ID, d->IH, d->IW, d->Cin, d->OD, d->OH, d->OW, d->Cout, d->KD, d->KH, d->KW, d->stride,
                                               d->pad_d, d->pad_h, d->pad_w, split3);
-    return pl.dma ? 2 : (pl.brick ? 1 : 0);
+    return pl.halo ? 3 : (pl.dma ? 2 : (pl.brick ? 1 : 0));
 }
 
 // out[B,OD,OH,OW,Cout] = conv(in[B,ID,IH,IW,Cin], W) (+bias, act 0 none / 1 relu / 2 tanh); rows with row_mask==0 are

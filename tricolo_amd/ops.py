@@ -67,8 +67,10 @@ def _igemm_symbol(g, transposed, split, t):
     bn = 128 if cout % 128 == 0 else (64 if cout % 64 == 0 else 32)
     bf = t.dtype == torch.bfloat16
     fam = g.kernel_family[(transposed, 1 if split else (2 if bf else 0))]
+    if fam == 3:
+        return "conv_halo_kernel<64>"
     if fam == 2:
-        return f"conv_dma_kernel<{bn}>"
+        return f"conv_dma_kernel<{64 if g.M * (cout // bn) < 1024 * 128 else bn}>"
     return f"{'conv_brick_kernel' if fam == 1 else 'conv_igemm_kernel'}<{bn},{2 if split else 1},{'bf16' if bf else 'float'}>"
 
 
