@@ -50,6 +50,17 @@ int tri_weight_prep_multi(const TriPrepDesc* descs_dev, int n, void* stream);
 int tri_weight_prep(const float* w, long s_row, long s_tap, long s_inner, int rows, int ntaps, int inner, int inner_pad,
                     void* w_hi, void* w_lo, void* stream);
 
+/* ---- dense layers with <= 64 rows (MLP heads at the per-GPU batch) ---------------------------------------------
+ * nn.Linear forward / backward of sparse_cnn.py:39-44, mv_cnn.py:21-26, bigru.py:12, clip_text.py:9-14 in three launches,
+ * reading the fp32 parameter directly (no packed copy).  x [M,K], w [N,K] (torch layout), y / dout [M,N]; act 0 none /
+ * 1 relu / 2 tanh; the backward entry points take the forward OUTPUT y and apply act' themselves.  split3 = bf16x3. */
+int tri_linear_small_supported(int M, int K, int N);               /* M <= 64, K % 128 == 0, N % 128 == 0 */
+int tri_linear_small_fwd(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, int act, int split3, void* stream);
+int tri_linear_small_dgrad(const float* dout, const float* y, const float* w, float* dx, int M, int K, int N, int act, int split3,
+                           void* stream);
+int tri_linear_small_wgrad(const float* x, const float* dout, const float* y, float* dw, float* db /* may be NULL */, int M, int K, int N,
+                           int act, int split3, void* stream);
+
 /* ---- implicit-GEMM convolution on MFMA ------------------------------------------------------------------------
  * tri_conv_fwd replaces spconv.SubMConv3d (sparse_cnn.py:12,17,22,27,32; row_mask = active-site mask gives the
  * submanifold rule), every torchvision conv2d of net_1 (mv_cnn.py:29) and nn.Linear (sparse_cnn.py:39-44,

@@ -185,6 +185,34 @@ def test_linear_spatial_flatten_matches_channels_first():
 
 
 # ------------------------------------------------------------------------------------------------ BatchNorm
+@pytest.mark.parametrize("M,K,N", [(32, 512, 512), (1, 128, 128), (19, 768, 512), (64, 256, 384)])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_linear_small_matches_torch(M, K, N, act):
+    """Dense layers with <= 64 rows (MLP heads): three dedicated launches.  Integer inputs are exact in both precision
+    modes; real inputs are checked against float64 with the bf16x3 (near-fp32) and bf16 tolerances."""
+    from tricolo_amd.layers import linear_bwd, linear_fwd
+    assert ops.linear_small_supported(M, K, N)
+    f = {0: lambda v: v, 1: torch.relu, 2: torch.tanh}[act]
+    for precision in ("bf16", "bf16x3"):
+        x, w, b = ints((M, K), -3, 3, 1), ints((N, K), -2, 2, 2), ints((N,), -2, 2, 3)
+        if act != 2:
+            out = linear_fwd(x.to(DEV), w.to(DEV), b.to(DEV), act, precision)
+            assert torch.equal(out.cpu(), f(x @ w.t() + b))
+        g = torch.Generator().manual_seed(5)
+        x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / np.sqrt(K), torch.randn(N, generator=g)
+        xr, wr, br = x.double().requires_grad_(), w.double().requires_grad_(), b.double().requires_grad_()
+        ref = f(xr @ wr.t() + br)
+        dout = torch.randn(M, N, generator=g)
+        ref.backward(dout.double())
+        out = linear_fwd(x.to(DEV), w.to(DEV), b.to(DEV), act, precision)
+        dx, dw, db = linear_bwd(x.to(DEV), w.to(DEV), out, dout.to(DEV), act, precision)
+        tol = 2e-5 if precision == "bf16x3" else 3e-2
+        np.testing.assert_allclose(out.cpu().numpy(), ref.detach().numpy(), atol=tol, rtol=tol)
+        np.testing.assert_allclose(dx.cpu().numpy(), xr.grad.numpy(), atol=tol, rtol=tol)
+        np.testing.assert_allclose(dw.cpu().numpy(), wr.grad.numpy(), atol=tol * 20, rtol=tol)      # |dW| ~ 10: 32-term sums of O(1) products
+        np.testing.assert_allclose(db.cpu().numpy(), br.grad.numpy(), atol=tol * 4, rtol=tol)
+
+
 def test_bn2d_forward_backward_matches_torch():
     g = torch.Generator().manual_seed(3)
     N, H, W, C = 4, 6, 6, 64

@@ -73,6 +73,31 @@ template <> struct Act<bf16_t> {
     static __device__ __forceinline__ void st4(bf16_t* p, const float4& v) { *(bf16x4*)p = to_bf16x4(v); }
 };
 
+// ---- asynchronous global -> LDS copies --------------------------------------------------------------------------
+// LDS-DMA issued through inline asm: the compiler then knows nothing about LDS being written asynchronously and does not
+// put its own (conservative, vmcnt(0)) wait in front of every ds_read that follows - the counted waits + barriers of the
+// kernel are the only synchronisation, which is what lets DMAs stay in flight across several compute units of work.
+typedef int v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4i make_rsrc_words(const void* base, unsigned bytes) {
+    return (v4i){(int)(unsigned)(size_t)base, (int)(((size_t)base >> 32) & 0xffff), (int)bytes, 0x00020000};
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
+#else
+    return 0;
+#endif
+}
+// lds_dst must be wave-uniform (the hardware adds lane * 16).  M0 is named in the clobber list; clang treats it as a
+// reserved register and only warns (-Wno-inline-asm in the Makefile) - the kernels that use this helper have no other
+// M0 consumer (no movrel indexing, no compiler-issued LDS-DMA), and tests/test_gpu_ops.py checks them bit-exactly.
+__device__ __forceinline__ void dma16_async(v4i rsrc, unsigned lds_dst, int voff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                 :: "s"(__builtin_amdgcn_readfirstlane(lds_dst)), "v"(voff), "s"(rsrc) : "memory", "m0");
+#endif
+}
+
 // XCD-aware bijective remap (cdna_hip_programming.md T1): blocks that share operand panels get consecutive
 // logical ids on one XCD, so the panel is fetched into that XCD's L2 once.
 __device__ __forceinline__ int xcd_remap(int orig, int nwg) {

@@ -604,7 +604,18 @@ __device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t rsrc, char* d
 #endif
 }
 
-template <int BN>
+__device__ __forceinline__ void wait_vmcnt(int n) {
+    switch (n) {
+#define TRI_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+        TRI_W(0) TRI_W(1) TRI_W(2) TRI_W(3) TRI_W(4) TRI_W(5) TRI_W(6) TRI_W(7) TRI_W(8) TRI_W(9) TRI_W(10) TRI_W(11) TRI_W(12)
+        TRI_W(13) TRI_W(14) TRI_W(15) TRI_W(16) TRI_W(17) TRI_W(18) TRI_W(19) TRI_W(20) TRI_W(21) TRI_W(22) TRI_W(23) TRI_W(24)
+        TRI_W(25) TRI_W(26) TRI_W(27) TRI_W(28) TRI_W(29) TRI_W(30) TRI_W(31) TRI_W(32)
+#undef TRI_W
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+template <int BN, int NST>
 __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs p) {
     typedef bf16_t AT;
     constexpr int BM = 128, BK = 64;
@@ -612,9 +623,9 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs p) {
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 16, TN = WN / 16;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int* lut_off = (int*)(smem + 2 * STAGE);
+    int* lut_off = (int*)(smem + NST * STAGE);
     int* lut_sh = lut_off + 64;
-    float* red = (float*)(smem + 2 * STAGE + 512);
+    float* red = (float*)(smem + NST * STAGE + 512);
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int NT = p.Cout / BN;
@@ -686,9 +697,9 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs p) {
         const int nk_total = p.Kpad >> 6;
         const int ks0 = split * p.steps_per_split;
         const int ks1 = min(nk_total, ks0 + p.steps_per_split);
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t wrsrc =
-            __builtin_amdgcn_make_buffer_rsrc((void*)(p.w_hi + (size_t)n0 * p.Kpad), 0, (unsigned)(BN * p.Kpad * 2), 0x00020000);
+        const v4i rsrc = make_rsrc_words(p.in, p.in_bytes);
+        const v4i wrsrc = make_rsrc_words(p.w_hi + (size_t)n0 * p.Kpad, (unsigned)(BN * p.Kpad * 2));
+        const unsigned lds0 = lds_addr(smem) + wave * 1024;       // this wave's 1 KiB slice of every 4 KiB DMA group
         int woff[BN / 32];
 #pragma unroll
         for (int i = 0; i < BN / 32; ++i) {
@@ -697,7 +708,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs p) {
         }
 
         auto issue = [&](int ks, int buf) {
-            char* base = smem + buf * STAGE;
+            const unsigned base = lds0 + buf * STAGE;
             const int kb = ks * BK;
             int tap, c0;
             if (p.cin_shift >= 0) { tap = kb >> p.cin_shift; c0 = kb & ((1 << p.cin_shift) - 1); }
@@ -711,13 +722,11 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs p) {
                 unsigned mk = rmask[i];
                 bool ok = tv && (((mk >> sx) & (mk >> sy) & (mk >> sz)) & 1u);
                 int voff = ok ? rowoff[i] + toff : (int)0x80000000;         // out of range -> zeros land in LDS, branch-free
-                char* dst = base + (wave * 8 + 32 * i) * 128;              // wave-uniform; the hardware adds lane * 16
-                dma16(rsrc, dst, voff);
+                dma16_async(rsrc, base + i * 4096, voff);
             }
 #pragma unroll
             for (int i = 0; i < BN / 32; ++i) {
-                char* dst = base + A_BYTES + (wave * 8 + 32 * i) * 128;
-                dma16(wrsrc, dst, woff[i] + kb * 2);
+                dma16_async(wrsrc, base + A_BYTES + i * 4096, woff[i] + kb * 2);
             }
         };
         auto compute = [&](int buf) {
@@ -738,14 +747,27 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs p) {
         };
 
         if (ks0 < ks1) {
-            issue(ks0, 0);
+            // NST - 1 stages in flight ahead of the MFMAs.  The DMAs are asm-issued (common.h) and complete in order, so
+            // "stage ks has landed" == "at most the PER instructions of each younger stage are still outstanding".
+            constexpr int PER = 4 + BN / 32;
+#pragma unroll
+            for (int d = 0; d < NST - 1; ++d)
+                if (ks0 + d < ks1) issue(ks0 + d, d);
+            int buf = 0;
             for (int ks = ks0; ks < ks1; ++ks) {
-                const int buf = (ks - ks0) & 1;
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's DMAs of stage `buf` have landed
-                __builtin_amdgcn_s_barrier();                            // ... and everybody else's; all reads of buf^1 are done
+                const int younger = min(ks1 - 1 - ks, NST - 2);
+                if (NST == 2 || younger == 0) wait_vmcnt(0);
+                else if (younger == 1) wait_vmcnt(PER);
+                else wait_vmcnt(2 * PER);
+                __builtin_amdgcn_s_barrier();                            // everybody's stage ks is visible; all reads of stage ks - 1 are done
                 asm volatile("" ::: "memory");
-                if (ks + 1 < ks1) issue(ks + 1, buf ^ 1);                // next stage streams in under the MFMAs below
+                if (ks + NST - 1 < ks1) {
+                    int nb = buf + NST - 1;
+                    if (nb >= NST) nb -= NST;
+                    issue(ks + NST - 1, nb);                             // refills the buffer stage ks - 1 was computed from
+                }
                 compute(buf);
+                if (++buf == NST) buf = 0;
             }
         }
         __syncthreads();
@@ -763,39 +785,6 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs p) {
 // serves all taps from it: a tap is a row offset into the brick, image borders are handled by zeroing the A
 // fragment of invalid (row, tap) pairs in registers.  Per (chunk, tap) unit only the 8 KiB weight slice streams
 // in (3-slot ring, two units ahead), the next chunk's brick streams in under 9 / 27 units of MFMA work.
-__device__ __forceinline__ void wait_vmcnt(int n) {
-    switch (n) {
-#define TRI_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
-        TRI_W(0) TRI_W(1) TRI_W(2) TRI_W(3) TRI_W(4) TRI_W(5) TRI_W(6) TRI_W(7) TRI_W(8) TRI_W(9) TRI_W(10) TRI_W(11) TRI_W(12)
-        TRI_W(13) TRI_W(14) TRI_W(15) TRI_W(16) TRI_W(17) TRI_W(18) TRI_W(19) TRI_W(20) TRI_W(21) TRI_W(22) TRI_W(23) TRI_W(24)
-        TRI_W(25) TRI_W(26) TRI_W(27) TRI_W(28) TRI_W(29) TRI_W(30) TRI_W(31) TRI_W(32)
-#undef TRI_W
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-}
-
-// LDS-DMA issued through inline asm: the compiler then knows nothing about LDS being written asynchronously and does not
-// put its own (conservative, vmcnt(0)) wait in front of every ds_read that follows - the counted waits + barriers of the
-// kernel are the only synchronisation, which is what lets DMAs stay in flight across several compute units of work.
-typedef int v4i __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ v4i make_rsrc_words(const void* base, unsigned bytes) {
-    return (v4i){(int)(unsigned)(size_t)base, (int)(((size_t)base >> 32) & 0xffff), (int)bytes, 0x00020000};
-}
-__device__ __forceinline__ unsigned lds_addr(const void* p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
-#else
-    return 0;
-#endif
-}
-// lds_dst must be wave-uniform (the hardware adds lane * 16)
-__device__ __forceinline__ void dma16_async(v4i rsrc, unsigned lds_dst, int voff) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-                 :: "s"(__builtin_amdgcn_readfirstlane(lds_dst)), "v"(voff), "s"(rsrc) : "memory", "m0");
-#endif
-}
-
 template <int BN>
 __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvArgs p) {
     typedef bf16_t AT;
@@ -1246,16 +1235,22 @@ static int launch_halo(const ConvArgs& a, const ConvPlan& pl, hipStream_t stream
     return tri_check_launch("tri_conv_splitk_finish");
 }
 
-template <int BN>
+static int dma_stages() {                                       // tuning aid: TRICOLO_DMA_STAGES = 2 | 3
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("TRICOLO_DMA_STAGES"); v = (e && atoi(e) == 3) ? 3 : 2; }
+    return v;
+}
+
+template <int BN, int NST>
 static int launch_dma(const ConvArgs& a, hipStream_t stream) {
-    constexpr size_t smem = 2 * (128 * 128 + BN * 128) + 512 + (size_t)4 * BN * 2 * sizeof(float);
+    constexpr size_t smem = NST * (128 * 128 + BN * 128) + 512 + (size_t)4 * BN * 2 * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute((const void*)conv_dma_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipFuncSetAttribute((const void*)conv_dma_kernel<BN, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr = true;
     }
     int mt = (a.M + 127) / 128, nt = a.Cout / BN;
-    conv_dma_kernel<BN><<<dim3(mt * nt, a.ksplit), 256, smem, stream>>>(a);
+    conv_dma_kernel<BN, NST><<<dim3(mt * nt, a.ksplit), 256, smem, stream>>>(a);
     int rc = tri_check_launch("tri_conv(dma)");
     if (rc || a.ksplit == 1) return rc;
     conv_splitk_finish_kernel<bf16_t><<<dim3((a.M + 31) / 32, a.Cout / 64), 256, 0, stream>>>(a);
@@ -1292,7 +1287,10 @@ static int conv_dispatch(ConvArgs& a, int act_bf16, void* workspace, size_t work
     }
     a.dOW = make_fastdiv(a.OW); a.dOH = make_fastdiv(a.OH); a.dOD = make_fastdiv(a.OD); a.dCin = make_fastdiv(a.Cin);
     if (pl.halo) return launch_halo<64>(a, pl, stream);
-    if (pl.dma) return pl.bn == 128 ? launch_dma<128>(a, stream) : launch_dma<64>(a, stream);
+    if (pl.dma) {
+        if (dma_stages() == 2) return pl.bn == 128 ? launch_dma<128, 2>(a, stream) : launch_dma<64, 2>(a, stream);
+        return pl.bn == 128 ? launch_dma<128, 3>(a, stream) : launch_dma<64, 3>(a, stream);
+    }
     if (pl.brick) {
         const int bn = conv_bn(a.Cout);
 #define TRI_BRICK(BN_, CB_)                                                                               \

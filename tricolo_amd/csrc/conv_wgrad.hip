@@ -280,16 +280,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
 
 // ================================================================================================ LDS-DMA variant
 // bf16 activation storage: dOut rows and input rows in HBM already are the bf16 LDS image, so both operand tiles go
-// global -> LDS with buffer_load_dwordx4 ... lds (16 B per lane, no VGPR staging / ds_write), 64 positions per step
+// global -> LDS with buffer_load_dwordx4 ... lds (16 B per lane, no VGPR staging / ds_write; issued through
+// dma16_async so that the copy really stays in flight under the MFMAs), 64 positions per step
 // (32 MFMAs per wave per barrier instead of 16) and the DMA of the next live step in flight under the MFMAs.
 // One wave-instruction fills 1 KiB = 1024 / ROWB consecutive tile rows; the nat_off bank swizzle is applied on the
 // SOURCE side (the lane that owns LDS slot s of row r fetches the chunk nat_off would have stored there).  The slot ->
 // chunk map of a lane is the same for every instruction and step, so (tap, channel, validity shifts) are per-lane constants.
-__device__ __forceinline__ void wdma16(const __amdgpu_buffer_rsrc_t rsrc, char* dst, unsigned voff) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)dst, 16, (int)voff, 0, 0, 0);
-#endif
-}
 template <int ROWB>
 __device__ __forceinline__ int nat_sw(int row) {
     constexpr int NCH = ROWB / 32;
@@ -383,9 +379,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs p) 
     }
     const int sx = y_sh & 255, sy = (y_sh >> 8) & 255, sz = (y_sh >> 16) & 255;
 
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    // (asm-issued DMA, see common.h: with the builtin the compiler waits vmcnt(0) before the first fragment read of every
+    //  step, i.e. the next stage's DMA never overlapped the MFMAs)
+    const v4i rsrc = make_rsrc_words(p.in, p.in_bytes);
     // rows m >= M of dOut fall outside this descriptor and arrive as zeros
-    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.dout, 0, (unsigned)p.M * p.Cout * 2, 0x00020000);
+    const v4i xrsrc = make_rsrc_words(p.dout, (unsigned)p.M * p.Cout * 2);
+    const unsigned lds0 = lds_addr(smem) + wave * 1024;
 
     auto step_live = [&](int ks) -> bool {
         if (!p.row_mask) return true;
@@ -401,11 +400,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs p) 
         return ks;
     };
     auto issue = [&](int ks, int buf) {
-        char* xb = smem + buf * STAGE;
-        char* yb = xb + X_BYTES;
+        const unsigned xb = lds0 + buf * STAGE;
+        const unsigned yb = xb + X_BYTES;
         const unsigned xbase = xoff + (unsigned)(ks * KB) * (unsigned)(p.Cout * 2);
 #pragma unroll
-        for (int i = 0; i < XNI; ++i) wdma16(xrsrc, xb + (4 * i + wave) * 1024, xbase + i * xstep);
+        for (int i = 0; i < XNI; ++i) dma16_async(xrsrc, xb + i * 4096, (int)(xbase + i * xstep));
         const int* po = lplan_off + (ks - ks_begin) * KB + yrow0;
         const unsigned* pm = lplan_mask + (ks - ks_begin) * KB + yrow0;
 #pragma unroll
@@ -414,7 +413,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs p) 
             unsigned rm = pm[4 * YRPI * i];
             bool ok = y_tv && (((rm >> sx) & (rm >> sy) & (rm >> sz)) & 1u);
             unsigned voff = ok ? (unsigned)(ro * 2 + y_toff) : 0x80000000u;
-            wdma16(rsrc, yb + (4 * i + wave) * 1024, voff);
+            dma16_async(rsrc, yb + i * 4096, (int)voff);
         }
     };
     auto compute = [&](int buf) {
@@ -595,7 +594,9 @@ static void wgrad_plan(const TriConvDesc* d, int act_bf16, int* BI, int* BJ_out,
         s = 448 / *tiles;
     } else {
         cap = *dma ? 60 : 96;
-        s = (wgrad_target_blocks() + *tiles - 1) / *tiles;      // narrow tiles / fp32 storage: ~3 workgroups per CU
+        // register-staged kernels (fp32 storage, 4-channel layers): ~3 workgroups per CU; 64-row DMA tiles: 448 (same sweep)
+        const int target = (*dma && wgrad_target_blocks() == WGRAD_TARGET_BLOCKS) ? 448 : wgrad_target_blocks();
+        s = (target + *tiles - 1) / *tiles;
     }
     if (s > max_by_steps) s = max_by_steps;
     if (s < 1) s = 1;

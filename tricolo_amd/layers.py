@@ -55,11 +55,21 @@ def linear_geom(rows: int, K: int, N: int, spatial: int = 1) -> ops.ConvGeom:
     return g
 
 
+_NO_SMALL = os.environ.get("TRICOLO_NO_SMALL", "0") == "1"      # A/B switch for the <= 64-row dense kernels
+
+
+def _small(x, w, spatial) -> bool:
+    return (not _NO_SMALL and spatial == 1 and x.dim() == 2 and x.dtype == torch.float32 and x.is_contiguous() and w.dim() == 2
+            and ops.linear_small_supported(x.shape[0], w.shape[1], w.shape[0]))
+
+
 def linear_fwd(x, w, b, act: int, precision: str, spatial: int = 1):
     """x [rows, spatial*K] channels-last -> act(x W^T + b) [rows, N] on the MFMA conv kernel (act 0/1 relu/2 tanh)."""
     rows = x.shape[0]
     N = w.shape[0]
     K = w.shape[1] // spatial
+    if _small(x, w, spatial):
+        return ops.linear_small_fwd(x, w, b, act, precision)        # <= 64 rows: one launch, no packed copy of W
     g = linear_geom(rows, K, N, spatial)
     packed = ops.pack_weight(w, g, precision)
     out = ops.conv_fwd(x, g, packed, bias=b, act=act)
@@ -71,6 +81,8 @@ def linear_bwd(x, w, out, dout, act: int, precision: str, spatial: int = 1, need
     rows = x.shape[0]
     N = w.shape[0]
     K = w.shape[1] // spatial
+    if _small(x, w, spatial) and w.dim() == 2:
+        return ops.linear_small_bwd(x, w, out, dout, act, precision, need_dx, need_db)
     g = linear_geom(rows, K, N, spatial)
     dpre = ops.act_bwd(dout.contiguous().clone(), out, act) if act else dout.contiguous()
     dw = ops.conv_wgrad(x, dpre, g, w, precision)

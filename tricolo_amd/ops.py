@@ -421,6 +421,36 @@ def l2norm_bwd(z, norm, dz, eps=1e-12):
     return dx
 
 
+# ------------------------------------------------------------------------------------------------ small dense layers
+def linear_small_supported(rows, K, N):
+    return bool(lib().tri_linear_small_supported(int(rows), int(K), int(N)))
+
+
+def linear_small_fwd(x, w, b, act, precision):
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    check(_timed("linear_small_fwd_kernel", 2.0 * M * K * N,
+                 lambda: lib().tri_linear_small_fwd(ptr(_f32(x)), ptr(_f32(w)), ptr(b), ptr(y), M, K, N, act, 1 if precision == "bf16x3" else 0,
+                                                    stream())), "tri_linear_small_fwd")
+    return y
+
+
+def linear_small_bwd(x, w, out, dout, act, precision, need_dx=True, need_db=True):
+    M, K = x.shape
+    N = w.shape[0]
+    s3 = 1 if precision == "bf16x3" else 0
+    dout = _f32(dout.contiguous())
+    dw = torch.empty_like(w)
+    db = torch.empty((N,), dtype=torch.float32, device=x.device) if need_db else None
+    check(lib().tri_linear_small_wgrad(ptr(_f32(x)), ptr(dout), ptr(out), ptr(dw), ptr(db), M, K, N, act, s3, stream()), "tri_linear_small_wgrad")
+    dx = None
+    if need_dx:
+        dx = torch.empty((M, K), dtype=torch.float32, device=x.device)
+        check(lib().tri_linear_small_dgrad(ptr(dout), ptr(out), ptr(_f32(w)), ptr(dx), M, K, N, act, s3, stream()), "tri_linear_small_dgrad")
+    return dx, dw, db
+
+
 def colsum(g):
     C = g.shape[-1]
     out = torch.empty((C,), dtype=torch.float32, device=g.device)
