@@ -72,7 +72,7 @@ int tri_linear_small_wgrad(const float* x, const float* dout, const float* y, fl
 int tri_conv_num_mtiles(const TriConvDesc* d, int split3);
 /* kernel family tri_conv_fwd (transposed = 0) / tri_conv_dgrad (transposed = 1) dispatches for this layer and mode:
  * 0 conv_igemm_kernel (register-staged im2col), 1 conv_brick_kernel, 2 conv_dma_kernel (LDS-DMA staging),
- * 3 conv_halo_kernel (LDS-DMA input brick shared by all taps).  For profilers. */
+ * 3 conv_halo_kernel (LDS-DMA input brick shared by all taps); bits 8.. hold the output-channel tile width.  For profilers. */
 int tri_conv_kernel_family(const TriConvDesc* d, int transposed, int split3);
 /* same for tri_conv_wgrad: 0 conv_wgrad_kernel, 2 conv_wgrad_dma_kernel (taken when act_bf16 != 0 and the layer qualifies) */
 int tri_conv_wgrad_kernel_family(const TriConvDesc* d, int act_bf16);

@@ -1326,7 +1326,7 @@ extern "C" int tri_conv_kernel_family(const TriConvDesc* d, int transposed, int 
                                               d->pad_d, d->pad_h, d->pad_w, split3)
                              : conv_make_plan(d->B, d->ID, d->IH, d->IW, d->Cin, d->OD, d->OH, d->OW, d->Cout, d->KD, d->KH, d->KW, d->stride,
                                               d->pad_d, d->pad_h, d->pad_w, split3);
-    return pl.halo ? 3 : (pl.dma ? 2 : (pl.brick ? 1 : 0));
+    return (pl.halo ? 3 : (pl.dma ? 2 : (pl.brick ? 1 : 0))) | (pl.bn << 8);
 }
 
 // out[B,OD,OH,OW,Cout] = conv(in[B,ID,IH,IW,Cin], W) (+bias, act 0 none / 1 relu / 2 tanh); rows with row_mask==0 are

@@ -63,15 +63,14 @@ def _timed(symbol, flops, fn):
 
 def _igemm_symbol(g, transposed, split, t):
     """Name of the kernel the C dispatch picks for this layer (what rocprofv3 reports), for the KernelTimer."""
-    cout = g.cin_stored if transposed else g.cout
-    bn = 128 if cout % 128 == 0 else (64 if cout % 64 == 0 else 32)
     bf = t.dtype == torch.bfloat16
-    fam = g.kernel_family[(transposed, 1 if split else (2 if bf else 0))]
+    code = g.kernel_family[(transposed, 1 if split else (2 if bf else 0))]
+    fam, bn = code & 255, code >> 8
     if fam == 3:
-        return "conv_halo_kernel<64>"
+        return f"conv_halo_kernel<{bn}>"
     if fam == 2:
-        return f"conv_dma_kernel<{64 if g.M * (cout // bn) < 1024 * 128 else bn}>"
-    return f"{'conv_brick_kernel' if fam == 1 else 'conv_igemm_kernel'}<{bn},{2 if split else 1},{'bf16' if bf else 'float'}>"
+        return f"conv_dma_kernel<{bn}, {3 if os.environ.get('TRICOLO_DMA_STAGES') == '3' else 2}>"
+    return f"{'conv_brick_kernel' if fam == 1 else 'conv_igemm_kernel'}<{bn}, {2 if split else 1}, {'bf16' if bf else 'float'}>"
 
 
 def _f32(t):
@@ -258,9 +257,9 @@ def conv_wgrad(x, dout, g: ConvGeom, like: torch.Tensor, precision: str, row_mas
     bj = 128 if bi == 128 else (256 if g.kpad <= 256 else 128)
     bf = x.dtype == torch.bfloat16
     if bf and g.wgrad_dma:
-        sym = f"conv_wgrad_dma_kernel<{bi},{bj}>"
+        sym = f"conv_wgrad_dma_kernel<{bi}, {bj}>"
     else:
-        sym = f"conv_wgrad_kernel<{bi},{bj},{2 if precision == 'bf16x3' else 1},{'bf16' if bf else 'float'}>"
+        sym = f"conv_wgrad_kernel<{bi}, {bj}, {2 if precision == 'bf16x3' else 1}, {'bf16' if bf else 'float'}>"
     check(_timed(sym, g.flops,
                  lambda: lib().tri_conv_wgrad(_C.C.byref(g.desc), ptr(_act(x)), ptr(_act(dout)), ptr(row_mask), ptr(plan), ptr(ws),
                                               ws.numel(), ptr(dw), s_co, s_tap, s_ci, g.cin, 1 if precision == "bf16x3" else 0,
