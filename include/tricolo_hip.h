@@ -104,13 +104,15 @@ int tri_bn_act(const void* y, const float* scale, const float* shift, const void
 int tri_relu_bwd(const void* dout, const void* out, void* g, long n, int act_bf16, void* stream);
 int tri_bn_bwd_num_blocks(long M);
 /* relu_scale / relu_shift (optional): g is the gradient w.r.t. relu(bn(y)); the mask y*scale+shift > 0 is recomputed */
+/* relu_out (optional): g is the gradient w.r.t. relu(bn(y) + residual) and relu_out that ReLU's saved output (mask out > 0) */
 int tri_bn_bwd_reduce(const void* y, const void* g, long M, int C, float* partial, const float* relu_scale, const float* relu_shift,
-                      int act_bf16, void* stream);
+                      const void* relu_out, int act_bf16, void* stream);
 int tri_bn_bwd_finalize(const float* partial, int nblk, int C, const int* count_dev, int count_host, const float* gamma,
                         const float* mean, const float* invstd, float* dgamma, float* dbeta, float* c1, float* c2, float* c3,
                         void* stream);
 int tri_bn_bwd_apply(const void* y, const void* g, const float* c1, const float* c2, const float* c3, const uint8_t* row_mask,
-                     void* dy, long M, int C, const float* relu_scale, const float* relu_shift, int act_bf16, void* stream);
+                     void* dy, long M, int C, const float* relu_scale, const float* relu_shift, const void* relu_out,
+                     void* g_masked /* optional: receives g * (relu_out > 0), may alias g */, int act_bf16, void* stream);
 
 /* ---- pooling -------------------------------------------------------------------------------------------------
  * BN + ReLU + mask + spconv.SparseMaxPool3d(2,2) fused (sparse_cnn.py:13-15 ...), its backward routing;

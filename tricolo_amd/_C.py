@@ -54,9 +54,9 @@ SIGNATURES = {
     "tri_bn_act": (I, [P, P, P, P, P, P, P, L, I, I, I, P]),
     "tri_relu_bwd": (I, [P, P, P, L, I, P]),
     "tri_bn_bwd_num_blocks": (I, [L]),
-    "tri_bn_bwd_reduce": (I, [P, P, L, I, P, P, P, I, P]),
+    "tri_bn_bwd_reduce": (I, [P, P, L, I, P, P, P, P, I, P]),
     "tri_bn_bwd_finalize": (I, [P, I, I, P, I, P, P, P, P, P, P, P, P, P]),
-    "tri_bn_bwd_apply": (I, [P, P, P, P, P, P, P, L, I, P, P, I, P]),
+    "tri_bn_bwd_apply": (I, [P, P, P, P, P, P, P, L, I, P, P, P, P, I, P]),
     "tri_bn_relu_pool3d_fwd": (I, [P, P, P, P, I, I, I, P, P, I, P]),
     "tri_pool3d_bwd_route": (I, [P, P, P, P, P, P, I, I, I, P, I, P]),
     "tri_maxpool2d_fwd": (I, [P, I, I, I, I, P, P, P, P, I, P]),

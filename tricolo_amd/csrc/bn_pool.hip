@@ -144,7 +144,8 @@ extern "C" int tri_relu_bwd(const void* dout, const void* out, void* g, long n, 
 static inline int bnb_rows(long M) { return M >= 65536 ? 256 : 64; }
 template <typename T>
 __global__ void bn_bwd_reduce_kernel(const T* __restrict__ y, const T* __restrict__ g, long M, int C, float* __restrict__ partial,
-                                     int BNB_ROWS, const float4* __restrict__ rs, const float4* __restrict__ rb) {
+                                     int BNB_ROWS, const float4* __restrict__ rs, const float4* __restrict__ rb,
+                                     const T* __restrict__ ro) {
     extern __shared__ float sh[];                      // [rows_per_pass][C4*4][2]
     const int C4 = C >> 2;
     const int tpr = C4 < 256 ? C4 : 256;               // threads per row
@@ -164,6 +165,10 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ y, const T* __restric
                 float4 gv = Act<T>::ld4(g + r * C + c4 * 4), yv = Act<T>::ld4(y + r * C + c4 * 4);
                 gv.x = __fmaf_rn(yv.x, s4.x, b4.x) > 0.f ? gv.x : 0.f; gv.y = __fmaf_rn(yv.y, s4.y, b4.y) > 0.f ? gv.y : 0.f;
                 gv.z = __fmaf_rn(yv.z, s4.z, b4.z) > 0.f ? gv.z : 0.f; gv.w = __fmaf_rn(yv.w, s4.w, b4.w) > 0.f ? gv.w : 0.f;
+                if (ro) {                                           // ReLU taken after a residual add: mask from the saved output
+                    const float4 ov = Act<T>::ld4(ro + r * C + c4 * 4);
+                    gv.x = ov.x > 0.f ? gv.x : 0.f; gv.y = ov.y > 0.f ? gv.y : 0.f; gv.z = ov.z > 0.f ? gv.z : 0.f; gv.w = ov.w > 0.f ? gv.w : 0.f;
+                }
                 sg.x += gv.x; sg.y += gv.y; sg.z += gv.z; sg.w += gv.w;
                 sgy.x += gv.x * yv.x; sgy.y += gv.y * yv.y; sgy.z += gv.z * yv.z; sgy.w += gv.w * yv.w;
             }
@@ -189,15 +194,16 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ y, const T* __restric
 extern "C" int tri_bn_bwd_num_blocks(long M) { return (int)((M + bnb_rows(M) - 1) / bnb_rows(M)); }
 // relu_scale / relu_shift (optional, [C]): the BN output went through ReLU and `g` is the gradient w.r.t. the ReLU OUTPUT;
 // the mask (y*scale + shift > 0, the forward's own expression) is recomputed instead of materialising relu_bwd's result.
+// relu_out (optional, same shape as y): the ReLU came after a residual add (BasicBlock output); its mask is out > 0.
 extern "C" int tri_bn_bwd_reduce(const void* y, const void* g, long M, int C, float* partial, const float* relu_scale,
-                                 const float* relu_shift, int act_bf16, void* stream) {
+                                 const float* relu_shift, const void* relu_out, int act_bf16, void* stream) {
     if (C % 4) { tri_set_error("tri_bn_bwd_reduce: C must be a multiple of 4"); return TRI_ERR_ARG; }
     int rows = bnb_rows(M);
     int nblk = (int)((M + rows - 1) / rows);
     int C4 = C / 4, tpr = C4 < 256 ? C4 : 256, rpp = 256 / tpr;
     size_t smem = (size_t)rpp * tpr * 8 * sizeof(float);
     TRI_ACT_DISPATCH(act_bf16, bn_bwd_reduce_kernel<T><<<nblk, 256, smem, (hipStream_t)stream>>>((const T*)y, (const T*)g, M, C, partial, rows,
-                                                                                                  (const float4*)relu_scale, (const float4*)relu_shift));
+                                                                                                  (const float4*)relu_scale, (const float4*)relu_shift, (const T*)relu_out));
     return tri_check_launch("tri_bn_bwd_reduce");
 }
 
@@ -245,7 +251,7 @@ template <typename T>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ y, const T* g, const float4* __restrict__ c1,
                                     const float4* __restrict__ c2, const float4* __restrict__ c3,
                                     const uint8_t* __restrict__ row_mask, T* dy, long total4, int C4,
-                                    const float4* __restrict__ rs, const float4* __restrict__ rb) {
+                                    const float4* __restrict__ rs, const float4* __restrict__ rb, const T* __restrict__ ro, T* gm) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
         long row = i / C4;
         int c = (int)(i - row * C4);
@@ -257,6 +263,11 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ y, const T* g, const f
                 gv.x = __fmaf_rn(yv.x, s4.x, b4.x) > 0.f ? gv.x : 0.f; gv.y = __fmaf_rn(yv.y, s4.y, b4.y) > 0.f ? gv.y : 0.f;
                 gv.z = __fmaf_rn(yv.z, s4.z, b4.z) > 0.f ? gv.z : 0.f; gv.w = __fmaf_rn(yv.w, s4.w, b4.w) > 0.f ? gv.w : 0.f;
             }
+            if (ro) {
+                const float4 ov = Act<T>::ld4(ro + i * 4);
+                gv.x = ov.x > 0.f ? gv.x : 0.f; gv.y = ov.y > 0.f ? gv.y : 0.f; gv.z = ov.z > 0.f ? gv.z : 0.f; gv.w = ov.w > 0.f ? gv.w : 0.f;
+                if (gm) Act<T>::st4(gm + i * 4, gv);                // the masked gradient also feeds the identity / down-sample branch
+            }
             o.x = a.x * gv.x + b.x + d.x * yv.x; o.y = a.y * gv.y + b.y + d.y * yv.y;
             o.z = a.z * gv.z + b.z + d.z * yv.z; o.w = a.w * gv.w + b.w + d.w * yv.w;
         }
@@ -265,11 +276,11 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ y, const T* g, const f
 }
 extern "C" int tri_bn_bwd_apply(const void* y, const void* g, const float* c1, const float* c2, const float* c3,
                                 const uint8_t* row_mask, void* dy, long M, int C, const float* relu_scale, const float* relu_shift,
-                                int act_bf16, void* stream) {
+                                const void* relu_out, void* g_masked, int act_bf16, void* stream) {
     long total4 = M * (C / 4);
     TRI_ACT_DISPATCH(act_bf16, bn_bwd_apply_kernel<T><<<ew_grid(total4), 256, 0, (hipStream_t)stream>>>(
         (const T*)y, (const T*)g, (const float4*)c1, (const float4*)c2, (const float4*)c3, row_mask, (T*)dy, total4, C / 4,
-        (const float4*)relu_scale, (const float4*)relu_shift));
+        (const float4*)relu_scale, (const float4*)relu_shift, (const T*)relu_out, (T*)g_masked));
     return tri_check_launch("tri_bn_bwd_apply");
 }
 

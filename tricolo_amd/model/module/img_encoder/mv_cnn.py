@@ -179,8 +179,11 @@ class MVCNNEncoder(TriModule):
 
         for blk, sv in zip(reversed(blocks), reversed(saved["blocks"])):
             x, y1, co1, g1, a1, y2, co2, g2, yd, cod, gd, out = sv
-            g = ops.relu_bwd(dout, out)                                       # grad of the block's pre-activation sum
-            dy2, gr[blk.bn2.weight], gr[blk.bn2.bias] = ops.bn_bwd(y2, g, co2, blk.bn2.weight, count_host=g2.M, inplace=False)
+            # relu(bn2(y2) + residual) backward inside the BN passes; g = dout * (out > 0) (gradient of the pre-activation sum,
+            # also the residual branch's gradient) is written by the apply pass in place of dout
+            dy2, gr[blk.bn2.weight], gr[blk.bn2.bias] = ops.bn_bwd(y2, dout, co2, blk.bn2.weight, count_host=g2.M, inplace=False,
+                                                                   relu_out=out, g_masked=dout)
+            g = dout
             wgrad_async(a1, dy2, g2, blk.conv2.weight)
             da1 = ops.conv_dgrad(dy2, g2, self._packed[(id(blk.conv2), True)])
             # relu(bn1(y1)) backward: the ReLU mask is recomputed from y1 inside the BN passes (no relu_bwd pass over a1)

@@ -307,23 +307,27 @@ def relu_bwd(dout, out, inplace=True):
     return g
 
 
-def bn_bwd(y, g, co: BNCoeffs, gamma, count_dev=None, count_host=0, row_mask=None, inplace=True, relu=False):
+def bn_bwd(y, g, co: BNCoeffs, gamma, count_dev=None, count_host=0, row_mask=None, inplace=True, relu=False, relu_out=None,
+           g_masked=None):
     """Returns (dy, dgamma, dbeta).  g = gradient w.r.t. the BN output (already activation-masked), or - with relu=True -
-    w.r.t. relu(bn(y)): the ReLU mask is then recomputed from y inside the two passes (no separate relu_bwd pass)."""
+    w.r.t. relu(bn(y)): the ReLU mask is then recomputed from y inside the two passes (no separate relu_bwd pass), or -
+    with relu_out - w.r.t. relu(bn(y) + residual) whose saved output is relu_out; g_masked (may alias g) then receives
+    g * (relu_out > 0), the gradient of the pre-activation sum that the residual branch needs too."""
     rs, rb = (co.scale, co.shift) if relu else (None, None)
     C = y.shape[-1]
     M = y.numel() // C
     nblk = lib().tri_bn_bwd_num_blocks(M)
     partial = torch.empty((nblk, 2, C), dtype=torch.float32, device=y.device)
     assert y.dtype == g.dtype
-    check(lib().tri_bn_bwd_reduce(ptr(_act(y)), ptr(_act(g)), M, C, ptr(partial), ptr(rs), ptr(rb), _abf(y), stream()), "tri_bn_bwd_reduce")
+    check(lib().tri_bn_bwd_reduce(ptr(_act(y)), ptr(_act(g)), M, C, ptr(partial), ptr(rs), ptr(rb), ptr(relu_out), _abf(y), stream()),
+          "tri_bn_bwd_reduce")
     buf = torch.empty((5, C), dtype=torch.float32, device=y.device)
     check(lib().tri_bn_bwd_finalize(ptr(partial), nblk, C, ptr(count_dev), int(count_host), ptr(gamma), ptr(co.mean),
                                     ptr(co.invstd), ptr(buf[0]), ptr(buf[1]), ptr(buf[2]), ptr(buf[3]), ptr(buf[4]), stream()),
           "tri_bn_bwd_finalize")
     dy = g if inplace else torch.empty_like(g)
     check(lib().tri_bn_bwd_apply(ptr(y), ptr(g), ptr(buf[2]), ptr(buf[3]), ptr(buf[4]), ptr(row_mask), ptr(dy), M, C, ptr(rs), ptr(rb),
-                                 _abf(y), stream()), "tri_bn_bwd_apply")
+                                 ptr(relu_out), ptr(g_masked), _abf(y), stream()), "tri_bn_bwd_apply")
     return dy, buf[0], buf[1]
 
 
