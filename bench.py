@@ -96,7 +96,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    force_dist = os.environ.get("TRICOLO_FORCE_DIST", "0") == "1"      # world-of-one run of the data-parallel code path
+    if world > 1 or force_dist:
+        if force_dist and "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=device)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
@@ -117,9 +120,27 @@ def main():
         losses = parallel.dp_training_step(net, batch, opt)
         return losses["train_loss/total_loss"]
 
-    # ---- optional HIP-graph capture of the whole step (single GPU; collectives stay eager for N > 1)
+    # ---- HIP-graph capture of the step.  N = 1: one graph.  N > 1: three graphs around the two eager collectives
+    # (parallel.GraphedDPStep); any capture failure falls back to the eager step.
     graphs = None
-    use_graph = (not args.no_graph) and world == 1
+    dp_graph = (world > 1 or force_dist) and not args.no_graph
+    if dp_graph:
+        try:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for i in range(2):
+                    step(batches[i % len(batches)])                  # also creates the RCCL communicator before any capture
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            graphs = [parallel.GraphedDPStep(net, opt, b) for b in batches]
+            torch.cuda.synchronize()
+        except Exception as e:                      # noqa: BLE001
+            if rank == 0:
+                print(f"[bench] graph-split DP step unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            graphs = None
+            torch.cuda.synchronize()
+    use_graph = (not args.no_graph) and not dp_graph
     if use_graph:
         try:
             s = torch.cuda.Stream()
@@ -144,7 +165,10 @@ def main():
 
     def run(i):
         if graphs is not None:
-            g, l = graphs[i % len(graphs)]
+            item = graphs[i % len(graphs)]
+            if dp_graph:
+                return item.replay()
+            g, l = item
             g.replay()
             return l
         return step(batches[i % len(batches)])
@@ -210,11 +234,11 @@ def main():
             "config": {"workload": f"BASELINE configs[3] per-GPU shard: Tri(I+V) SparseCNN {args.voxel_size}^3 + MVCNN "
                                    f"{args.num_views}x{args.image_size}^2 + BiGRU-96, fwd+bwd+Adam",
                        "global_batch": gb, "per_gpu_batch": B, "parallelism": f"dp{world}",
-                       "hip_graph": graphs is not None, "final_loss": round(final_loss, 5)},
+                       "hip_graph": (("3 graphs + eager collectives" if dp_graph else True) if graphs is not None else False), "final_loss": round(final_loss, 5)},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

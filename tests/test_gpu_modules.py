@@ -228,6 +228,37 @@ def test_fused_adam_equals_torch_adam_on_the_same_net(golden):
         opt.step()
 
 
+def test_graph_split_dp_step_equals_eager_dp_step(monkeypatch):
+    """parallel.GraphedDPStep (three HIP graphs around the two eager collectives, the N > 1 bench path) against the
+    eager dp_training_step from identical weights on the same batch, in a one-rank RCCL world with the data-parallel
+    code path forced on.  Same kernels, same order: the loss trajectories must agree to fp32 round-off."""
+    import torch.distributed as dist
+    from tricolo_amd import parallel
+    monkeypatch.setenv("TRICOLO_FORCE_DIST", "1")
+    for k, v in dict(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1").items():
+        monkeypatch.setenv(k, v)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    try:
+        net_a, _ = _build_net("BiGRUEncoder", "MVCNNEncoder", "SparseCNNEncoder", 32, 2, 64)
+        net_b, _ = _build_net("BiGRUEncoder", "MVCNNEncoder", "SparseCNNEncoder", 32, 2, 64)     # same recipe weights
+        batch = syn.batch_to_device(syn.make_batch(8, voxel_size=32, num_views=2, image_size=64, seed=syn.BASE_SEED + 31), DEV)
+        opt_a, opt_b = net_a.configure_optimizers(), net_b.configure_optimizers()
+        for o in (opt_a, opt_b):
+            o.prepare()
+        eager = []
+        for _ in range(5):
+            eager.append(parallel.dp_training_step(net_a, batch, opt_a)["train_loss/total_loss"].item())
+        # the graph-split step needs the same warm-up the bench does (lazy buffers, RCCL communicator) - done on net_b too
+        warm = [parallel.dp_training_step(net_b, batch, opt_b)["train_loss/total_loss"].item() for _ in range(2)]
+        torch.cuda.synchronize()
+        gstep = parallel.GraphedDPStep(net_b, opt_b, batch)
+        graphed = warm + [gstep.replay().item() for _ in range(3)]
+        np.testing.assert_allclose(graphed, eager, rtol=2e-4, atol=2e-4)
+        assert eager[-1] < eager[0]
+    finally:
+        dist.destroy_process_group()
+
+
 def test_plain_bf16_mode_stated_tolerance(golden):
     """bf16 operands (1 MFMA product): the documented bound is 1e-2 on the loss and 5e-3 on unit-norm embeddings."""
     g = golden("step_cfg4_tri")

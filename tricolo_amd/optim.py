@@ -67,6 +67,18 @@ class FusedAdam(torch.optim.Optimizer):
         return torch.cat(parts)
 
     @torch.no_grad()
+    def apply_flat(self, g: torch.Tensor, grad_scale: float = 1.0):
+        """The update half of step() for an already packed (and, data-parallel, already all-reduced) flat gradient.
+        parallel.GraphedDPStep captures flat_grad() and apply_flat() into separate HIP graphs around the eager all-reduce."""
+        if not self._flatten:
+            raise RuntimeError("apply_flat needs flatten=True")
+        group = self.param_groups[0]
+        b1, b2 = group["betas"]
+        ops.adam_tick(self._step_dev)
+        ops.adam_step(self._flat_p, g, self._flat_m, self._flat_v, self._step_dev, group["lr"], b1, b2, group["eps"],
+                      group["weight_decay"], grad_scale)
+
+    @torch.no_grad()
     def step(self, closure=None, grad_scale: float = 1.0, reduce_fn=None):
         """reduce_fn(flat_grad) (optional) runs between gradient packing and the update - the data-parallel hook."""
         loss = closure() if closure is not None else None

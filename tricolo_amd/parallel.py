@@ -13,12 +13,18 @@ rank computes NT-Xent over the full global batch.  Design
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
 
 def is_dist() -> bool:
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    """True when the data-parallel exchange steps must run.  TRICOLO_FORCE_DIST=1 also takes that path in a world of one
+    (how the graph-split step below is exercised on a single-GPU box)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("TRICOLO_FORCE_DIST", "0") == "1"
 
 
 class _AllGatherRows(torch.autograd.Function):
@@ -89,3 +95,60 @@ def dp_training_step(net, batch, optimizer=None):
     if optimizer is not None:
         optimizer.step()
     return losses
+
+
+class GraphedDPStep:
+    """The data-parallel step as THREE HIP graphs with the two collectives issued eagerly between them:
+
+        graph A   towers forward -> packed local embeddings [B_local, 512 * n_mod]
+        eager     all_gather_into_tensor(full, packed)                      (RCCL over xGMI)
+        graph B   global NT-Xent on `full`, backward to this rank's rows, towers backward, flat gradient pack
+        eager     all_reduce(flat gradient, SUM)
+        graph C   fused Adam on the flat buffers
+
+    Collectives are deliberately NOT captured (RCCL under hipGraph capture cannot be validated on a one-GPU box); the
+    ~400 kernel launches of the step are, so a replayed step costs three graph launches + two collectives on the host
+    instead of ~7 ms of Python launch overhead.  The graphs share one memory pool: activations saved by graph A's forward
+    are consumed by graph B's backward.  One instance per resident batch (inputs are static)."""
+
+    def __init__(self, net, optimizer, batch):
+        if not getattr(optimizer, "_flatten", False):
+            raise RuntimeError("GraphedDPStep needs FusedAdam(flatten=True)")
+        self.net, self.opt = net, optimizer
+        world, rank = dist.get_world_size(), dist.get_rank()
+        pool = torch.cuda.graph_pool_handle()
+        self.gA, self.gB, self.gC = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        optimizer.zero_grad(set_to_none=True)
+        # thread_local: the process group's watchdog thread keeps polling events of earlier collectives while this thread
+        # captures; under the default global mode that poll is an illegal call and aborts the process
+        mode = dict(pool=pool, capture_error_mode="thread_local")
+        with torch.cuda.graph(self.gA, **mode):
+            out = net(batch)
+            keys = list(out.keys())
+            dims = [out[k].shape[1] for k in keys]
+            packed = torch.cat([out[k] for k in keys], dim=1)
+        rows = packed.shape[0]
+        self.packed = packed
+        self.full = torch.zeros((world * rows, packed.shape[1]), dtype=packed.dtype, device=packed.device)
+        with torch.cuda.graph(self.gB, **mode):
+            leaf = self.full.detach().requires_grad_()
+            glob, off = {}, 0
+            for k, d in zip(keys, dims):
+                glob[k] = leaf[:, off:off + d].contiguous()
+                off += d
+            losses = net._calculate_losses(glob, "train_loss")
+            total = losses["train_loss/total_loss"]
+            (dfull,) = torch.autograd.grad(total, leaf)                 # identical on every rank: no reduce-scatter needed
+            packed.backward(dfull[rank * rows:(rank + 1) * rows].contiguous())
+            self.flat = optimizer.flat_grad()
+            self.loss = total.detach()
+        with torch.cuda.graph(self.gC, **mode):
+            optimizer.apply_flat(self.flat)
+
+    def replay(self):
+        self.gA.replay()
+        dist.all_gather_into_tensor(self.full, self.packed)
+        self.gB.replay()
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        self.gC.replay()
+        return self.loss
