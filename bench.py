@@ -191,10 +191,12 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    # ---- roofline leg: per-kernel HIP-event timing of eager steps (rank 0), dominant kernel by time
+    # ---- roofline leg: per-kernel HIP-event timing of eager steps, dominant kernel by time.  Rank 0 records; at N > 1
+    # EVERY rank runs the steps (they contain the collectives - a rank-0-only step would wait for its peers forever).
     roof = None
-    if rank == 0:
-        ops.TIMER = ops.KernelTimer()
+    if rank == 0 or world > 1:
+        if rank == 0:
+            ops.TIMER = ops.KernelTimer()
         nprof = 3
         # serialise the streams for this leg: a kernel's HIP-event duration must not include the other towers' kernels
         # sharing the GPU with it (the timed region above keeps towers / weight gradients on parallel streams)
@@ -206,6 +208,8 @@ def main():
             # bracket back-to-back kernel execution instead of host launch gaps (eager launches cost ~10 us each)
             torch.cuda._sleep(int(60e6))
             step(batches[i % len(batches)])
+        torch.cuda.synchronize()
+    if rank == 0:
         agg = ops.TIMER.summary()
         ops.TIMER = None
         if agg:
@@ -220,7 +224,7 @@ def main():
                                         "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in agg.items()}}
 
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:             # the CPU leg is an N = 1 artefact (task contract)
         cpu = cpu_baseline(args, cfg)
 
     if rank == 0:
@@ -237,9 +241,17 @@ def main():
                        "hip_graph": (("3 graphs + eager collectives" if dp_graph else True) if graphs is not None else False), "final_loss": round(final_loss, 5)},
             "roofline": roof, "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
     if dist.is_initialized():
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints a version banner through C stdio; push it out first so that the JSON line is the LAST line on stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:                           # noqa: BLE001
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
