@@ -50,6 +50,13 @@ int tri_weight_prep_multi(const TriPrepDesc* descs_dev, int n, void* stream);
 int tri_weight_prep(const float* w, long s_row, long s_tap, long s_inner, int rows, int ntaps, int inner, int inner_pad,
                     void* w_hi, void* w_lo, void* stream);
 
+/* ---- text -> shape retrieval ------------------------------------------------------------------------
+ * Device-side replacement of eval_retrieval.py:70-82,184-187: float64 similarities text[Nq,D] . shape[Ns,D]^T, the k best
+ * shapes per query (descending, equal similarities -> higher index first, i.e. numpy's ascending argsort flipped) and the
+ * 0-based rank of the query's own shape label[q] in the full ordering (first_hit, may be NULL together with label). */
+int tri_retrieval_topk(const float* text, const float* shape, const int* label, int Nq, int Ns, int D, int k, int* topk_idx /* [Nq,k] */,
+                       double* topk_sim /* [Nq,k] */, int* first_hit /* [Nq] */, void* stream);
+
 /* ---- dense layers with <= 64 rows (MLP heads at the per-GPU batch) ---------------------------------------------
  * nn.Linear forward / backward of sparse_cnn.py:39-44, mv_cnn.py:21-26, bigru.py:12, clip_text.py:9-14 in three launches,
  * reading the fp32 parameter directly (no packed copy).  x [M,K], w [N,K] (torch layout), y / dout [M,N]; act 0 none /

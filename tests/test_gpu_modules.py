@@ -259,6 +259,34 @@ def test_graph_split_dp_step_equals_eager_dp_step(monkeypatch):
         dist.destroy_process_group()
 
 
+def test_retrieval_metrics_on_device_match_reference(golden):
+    """compute_metrics with the device ranking (tri_retrieval_topk) against the numbers and the top-5 index
+    matrix the REAL reference compute_metrics produced for the same embeddings (tests/golden/retrieval.npz), and against
+    the host algorithm on a set with exact ties (duplicate shape rows)."""
+    from tricolo_amd.evaluation.eval_retrieval import compute_metrics
+    g = golden("retrieval")
+    shape = g["text"] * 0 + g["image"] + g["voxel"]
+    tuples = [(None, "cat", str(mid), g["text"][i], shape[i]) for i, mid in enumerate(g["model_ids"])]
+    r = compute_metrics("Text2Shape", {"caption_embedding_tuples": tuples})
+    np.testing.assert_array_equal(r["indices"], g["indices"])
+    np.testing.assert_allclose(r["recall_rate"], g["recall_rate"], atol=0)
+    np.testing.assert_allclose(r["ndcg"], g["ndcg"], atol=1e-12)
+    np.testing.assert_allclose(r["precision"], g["precision"], atol=1e-12)
+    assert abs(r["mrr"] - float(g["mrr"])) < 1e-12
+    # exact ties: every shape row appears twice under two ids; descending order with the higher index first
+    rng = np.random.default_rng(3)
+    base = rng.standard_normal((40, 64)).astype(np.float32)
+    shp = np.concatenate([base, base])
+    txt = base[rng.integers(0, 40, 96)] + 0.01 * rng.standard_normal((96, 64)).astype(np.float32)
+    lab = rng.integers(0, 80, 96).astype(np.int32)
+    idx, sim, hit = ops.retrieval_topk(torch.from_numpy(txt).to(DEV), torch.from_numpy(shp).to(DEV), torch.from_numpy(lab).to(DEV), 5)
+    sims = txt.astype(np.float64) @ shp.astype(np.float64).T
+    order = np.flip(np.argsort(sims, axis=1, kind="stable"), 1)
+    np.testing.assert_array_equal(idx.cpu().numpy(), order[:, :5])
+    np.testing.assert_array_equal(hit.cpu().numpy(), np.argmax(order == lab[:, None], axis=1))
+    np.testing.assert_allclose(sim.cpu().numpy(), np.take_along_axis(sims, order[:, :5], 1), rtol=1e-13, atol=1e-13)
+
+
 def test_plain_bf16_mode_stated_tolerance(golden):
     """bf16 operands (1 MFMA product): the documented bound is 1e-2 on the loss and 5e-3 on unit-norm embeddings."""
     g = golden("step_cfg4_tri")

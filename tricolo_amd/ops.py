@@ -424,6 +424,19 @@ def l2norm_bwd(z, norm, dz, eps=1e-12):
     return dx
 
 
+# ------------------------------------------------------------------------------------------------ retrieval
+def retrieval_topk(text, shape, labels, k=5):
+    """text [Nq,D], shape [Ns,D] fp32 on the GPU, labels [Nq] int32 -> (indices [Nq,k] i32, sims [Nq,k] f64, first_hit [Nq] i32)."""
+    Nq, D = text.shape
+    Ns = shape.shape[0]
+    idx = torch.empty((Nq, k), dtype=torch.int32, device=text.device)
+    sim = torch.empty((Nq, k), dtype=torch.float64, device=text.device)
+    hit = torch.empty((Nq,), dtype=torch.int32, device=text.device)
+    check(lib().tri_retrieval_topk(ptr(_f32(text)), ptr(_f32(shape)), ptr(labels), Nq, Ns, D, k, ptr(idx), ptr(sim), ptr(hit), stream()),
+          "tri_retrieval_topk")
+    return idx, sim, hit
+
+
 # ------------------------------------------------------------------------------------------------ small dense layers
 def linear_small_supported(rows, K, N):
     return bool(lib().tri_linear_small_supported(int(rows), int(K), int(N)))
