@@ -137,8 +137,14 @@ int tri_avgpool_viewmax_bwd(const float* dout, const int* arg, int B, int V, int
 
 /* ---- layout converters (batch layout of tricolo/data/data_module.py:40-65) ---------------------------------------- */
 int tri_voxel_scatter(const int* locs, const float* feats, int n, int B, int V, void* dense, uint8_t* mask, int act_bf16, void* stream);
+/* the dataset's dense RGBA u8 grids [B,4,V,V,V] straight to the tower input (active <=> alpha != 0, feats =
+ * RGB / 255; general_dataset.py:47-51,92-93) - no CPU COO build, no scatter.  mask must hold B*V^3 bytes (padded to 32). */
+int tri_voxel_from_rgba_u8(const uint8_t* rgba, int B, int V, void* dense, uint8_t* mask, int act_bf16, void* stream);
 int tri_mask_count(const uint8_t* mask, long n, int* count, void* stream);
 int tri_nchw3_to_nhwc4(const float* x, int N, int H, int W, void* out, int act_bf16, void* stream);
+/* u8 images [N,3,H,W] -> channels-last [N,H,W,4], (u8/255 - mean[c]) / std[c] as ToTensor + Normalize of
+ * general_dataset.py:87-89; mean3 / std3 are HOST pointers to three floats. */
+int tri_nchw3_u8_to_nhwc4(const uint8_t* x, int N, int H, int W, const float* mean3, const float* std3, void* out, int act_bf16, void* stream);
 
 /* ---- row ops ------------------------------------------------------------------------------------------------------
  * F.normalize(dim=1) (sparse_cnn.py:51, mv_cnn.py:33, bigru.py:18), bias gradients, activation backward. */

@@ -287,6 +287,34 @@ def test_retrieval_metrics_on_device_match_reference(golden):
     np.testing.assert_allclose(sim.cpu().numpy(), np.take_along_axis(sims, order[:, :5], 1), rtol=1e-13, atol=1e-13)
 
 
+def test_u8_input_staging_is_bit_identical_to_the_host_prepared_inputs():
+    """dense RGBA u8 grids and u8 renderings handed straight to the towers (mask / RGB/255 / CLIP Normalize
+    derived on the device) give the very same embeddings as the reference's CPU-prepared COO batch and f32 images."""
+    from tricolo_amd.data.synthetic import make_images_u8, normalise_images
+    batch = syn.make_batch(4, voxel_size=32, num_views=None, seed=syn.BASE_SEED + 41, keep_grids=True)
+    enc = SparseCNNEncoder(32, 32, 512, 512, precision="bf16x3")
+    fill_module(enc)
+    enc = enc.to(DEV).eval()
+    with torch.no_grad():
+        a = enc({k: v.to(DEV) for k, v in batch["voxels"].items()}, 4)
+        b = enc({"rgba": batch["voxel_grids_u8"].to(DEV)}, 4)
+    assert torch.equal(a, b)
+    dense, mask = ops.voxel_from_rgba(batch["voxel_grids_u8"].to(DEV))
+    dense2, mask2 = ops.voxel_scatter(batch["voxels"]["locs"].to(DEV), batch["voxels"]["feats"].to(DEV), 4, 32)
+    assert torch.equal(dense, dense2) and torch.equal(mask, mask2)
+    rng = np.random.default_rng(5)
+    u8 = torch.from_numpy(np.stack([make_images_u8(rng, 2, 64) for _ in range(3)])).view(6, 3, 64, 64)
+    f32 = normalise_images(u8.numpy())
+    x_a = ops.nchw3_to_nhwc4(f32.to(DEV))
+    x_b = ops.nchw3_u8_to_nhwc4(u8.to(DEV))
+    assert torch.equal(x_a, x_b)
+    img = MVCNNEncoder(512, 512, "resnet18", 2, precision="bf16x3")
+    fill_module(img)
+    img = img.to(DEV).eval()
+    with torch.no_grad():
+        assert torch.equal(img(f32.to(DEV)), img(u8.to(DEV)))
+
+
 def test_plain_bf16_mode_stated_tolerance(golden):
     """bf16 operands (1 MFMA product): the documented bound is 1e-2 on the loss and 5e-3 on unit-norm embeddings."""
     g = golden("step_cfg4_tri")

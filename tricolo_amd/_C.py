@@ -65,6 +65,8 @@ SIGNATURES = {
     "tri_avgpool_viewmax_fwd": (I, [P, I, I, I, I, P, P, I, P]),
     "tri_avgpool_viewmax_bwd": (I, [P, P, I, I, I, I, P, I, P]),
     "tri_voxel_scatter": (I, [P, P, I, I, I, P, P, I, P]),
+    "tri_voxel_from_rgba_u8": (I, [P, I, I, P, P, I, P]),
+    "tri_nchw3_u8_to_nhwc4": (I, [P, I, I, I, P, P, P, I, P]),
     "tri_mask_count": (I, [P, L, P, P]),
     "tri_nchw3_to_nhwc4": (I, [P, I, I, I, P, I, P]),
     "tri_l2norm_fwd": (I, [P, I, I, F, P, P, P]),

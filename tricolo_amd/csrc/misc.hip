@@ -50,6 +50,29 @@ extern "C" int tri_voxel_scatter(const int* locs, const float* feats, int n, int
     return tri_check_launch("tri_voxel_scatter");
 }
 
+// Dense RGBA u8 grids (the dataset's on-disk format, general_dataset.py:47-51,92-93) straight to the tower's input: site
+// active <=> alpha != 0, feats = RGB / 255.  Replaces the CPU nonzero / COO build + tri_voxel_scatter with one coalesced
+// pass: 4 plane bytes in, one (r,g,b,0) quad + one mask byte out per voxel; 4x less H2D than the f32 COO features.
+template <typename T>
+__global__ void voxel_from_rgba_kernel(const uint8_t* __restrict__ rgba, long V3, long total, T* __restrict__ dense,
+                                       uint8_t* __restrict__ mask) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long b = i / V3, p = i - b * V3;
+        const uint8_t* g = rgba + b * 4 * V3 + p;
+        const bool on = g[3 * V3] != 0;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (on) v = make_float4((float)g[0] / 255.f, (float)g[V3] / 255.f, (float)g[2 * V3] / 255.f, 0.f);
+        Act<T>::st4(dense + i * 4, v);
+        mask[i] = on ? 1 : 0;
+    }
+}
+extern "C" int tri_voxel_from_rgba_u8(const uint8_t* rgba, int B, int V, void* dense, uint8_t* mask, int act_bf16, void* stream) {
+    const long V3 = (long)V * V * V, total = (long)B * V3;
+    if (act_bf16) voxel_from_rgba_kernel<bf16_t><<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(rgba, V3, total, (bf16_t*)dense, mask);
+    else voxel_from_rgba_kernel<float><<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(rgba, V3, total, (float*)dense, mask);
+    return tri_check_launch("tri_voxel_from_rgba_u8");
+}
+
 // count of non-zero mask bytes -> *count (device int)
 __global__ void mask_count_kernel(const uint8_t* __restrict__ mask, long n, int* __restrict__ count) {
     int local = 0;
@@ -83,6 +106,30 @@ extern "C" int tri_nchw3_to_nhwc4(const float* x, int N, int H, int W, void* out
     if (act_bf16) nchw3_to_nhwc4_kernel<bf16_t><<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(x, HW, total, (bf16_t*)out);
     else nchw3_to_nhwc4_kernel<float><<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(x, HW, total, (float*)out);
     return tri_check_launch("tri_nchw3_to_nhwc4");
+}
+
+// u8 [N,3,H,W] -> [N,H,W,4] normalised exactly like torchvision's ToTensor + Normalize in general_dataset.py:87-89:
+// (u8 / 255 - mean[c]) / std[c] in fp32, zero 4th channel.  The f32 image batch never exists (4x less H2D and HBM).
+template <typename T>
+__global__ void nchw3_u8_to_nhwc4_kernel(const uint8_t* __restrict__ x, long HW, long total, float m0, float m1, float m2, float s0,
+                                         float s1, float s2, T* __restrict__ out) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long n = i / HW, p = i - n * HW;
+        const uint8_t* b = x + n * 3 * HW + p;
+        Act<T>::st4(out + i * 4, make_float4(((float)b[0] / 255.f - m0) / s0, ((float)b[HW] / 255.f - m1) / s1,
+                                             ((float)b[2 * HW] / 255.f - m2) / s2, 0.f));
+    }
+}
+extern "C" int tri_nchw3_u8_to_nhwc4(const uint8_t* x, int N, int H, int W, const float* mean3, const float* std3, void* out, int act_bf16,
+                                     void* stream) {
+    long HW = (long)H * W, total = (long)N * HW;
+    if (act_bf16)
+        nchw3_u8_to_nhwc4_kernel<bf16_t><<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(x, HW, total, mean3[0], mean3[1], mean3[2], std3[0],
+                                                                                         std3[1], std3[2], (bf16_t*)out);
+    else
+        nchw3_u8_to_nhwc4_kernel<float><<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(x, HW, total, mean3[0], mean3[1], mean3[2], std3[0],
+                                                                                        std3[1], std3[2], (float*)out);
+    return tri_check_launch("tri_nchw3_u8_to_nhwc4");
 }
 
 // ------------------------------------------------------------------------------------------------ row L2 normalise

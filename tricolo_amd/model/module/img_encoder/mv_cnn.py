@@ -135,7 +135,10 @@ class MVCNNEncoder(TriModule):
             raise RuntimeError("mat shape: number of images is not a multiple of num_views")
         B = N // self.num_views
         self._packed = self._pack_all(N, images.shape[2], images.shape[3], prec, train and save, images.device)
-        x0 = ops.nchw3_to_nhwc4(images, dtype=ops.act_dtype(prec))
+        if images.dtype == torch.uint8:                         # raw renderings: ToTensor + CLIP Normalize on the device (8f-2)
+            x0 = ops.nchw3_u8_to_nhwc4(images, dtype=ops.act_dtype(prec))
+        else:
+            x0 = ops.nchw3_to_nhwc4(images, dtype=ops.act_dtype(prec))
         y, co, g = self._conv_bn(x0, self.net_1[0], self.net_1[1], prec, train)
         x, parg = ops.maxpool2d_fwd(y, want_arg=save, bn=co)            # BN + ReLU + 3x3/2 max-pool: relu(bn(y)) is never stored
         saved = {"stem": (x0, y, co, g, parg), "blocks": [], "B": B, "N": N}

@@ -93,7 +93,10 @@ class SparseCNNEncoder(TriModule):
     def _forward_impl(self, locs, feats, B, save: bool):
         prec, V, train = self._prec(), self.voxel_size, self.training
         self._packed = self._pack_all(B, prec, train and save, feats.device)
-        x, mask = ops.voxel_scatter(locs, feats, B, V, dtype=ops.act_dtype(prec))
+        if locs is None:                                        # feats = dense RGBA u8 grids [B,4,V,V,V] (SURVEY 8f-2 input)
+            x, mask = ops.voxel_from_rgba(feats, dtype=ops.act_dtype(prec))
+        else:
+            x, mask = ops.voxel_scatter(locs, feats, B, V, dtype=ops.act_dtype(prec))
         count = ops.mask_count(mask, B * V ** 3)
         saved = {"levels": [], "B": B}
         for l in range(5):
@@ -142,7 +145,14 @@ class SparseCNNEncoder(TriModule):
         return grads
 
     def forward(self, x, batch_size):
-        locs, feats = x["locs"], x["feats"]
+        """x = {'locs', 'feats'} as data_module.py:52-64 builds it, or - beyond the reference - {'rgba': u8 [B,4,V,V,V]},
+        the dataset's dense grids: active sites / features are then derived on the device (no CPU COO build)."""
+        if "rgba" in x:
+            locs, feats = None, x["rgba"]
+            if tuple(feats.shape[1:]) != (4, self.voxel_size, self.voxel_size, self.voxel_size) or feats.dtype != torch.uint8:
+                raise RuntimeError("voxels['rgba'] must be uint8 [B, 4, V, V, V]")
+        else:
+            locs, feats = x["locs"], x["feats"]
         require_gpu(feats, "SparseCNNEncoder")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             return _VoxelTowerFn.apply(self, locs, feats, int(batch_size), *self._param_list())

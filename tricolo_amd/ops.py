@@ -394,6 +394,17 @@ def voxel_scatter(locs, feats, B, V, dtype=torch.float32):
     return dense, mask
 
 
+def voxel_from_rgba(rgba_u8, dtype=torch.float32):
+    """Dense RGBA u8 grids [B,4,V,V,V] (the dataset's storage format) -> (channels-last grid [B,V,V,V,4], site mask)."""
+    B, C, V = rgba_u8.shape[0], rgba_u8.shape[1], rgba_u8.shape[2]
+    assert C == 4 and rgba_u8.dtype == torch.uint8 and rgba_u8.shape[2:] == (V, V, V)
+    dense = torch.empty((B, V, V, V, 4), dtype=dtype, device=rgba_u8.device)
+    sites = B * V ** 3
+    mask = torch.zeros(((sites + 31) // 32 * 32,), dtype=torch.uint8, device=rgba_u8.device)
+    check(lib().tri_voxel_from_rgba_u8(ptr(rgba_u8.contiguous()), B, V, ptr(dense), ptr(mask), _abf(dense), stream()), "tri_voxel_from_rgba_u8")
+    return dense, mask
+
+
 def mask_count(mask, n):
     cnt = torch.empty((1,), dtype=torch.int32, device=mask.device)
     check(lib().tri_mask_count(ptr(mask), n, ptr(cnt), stream()), "tri_mask_count")
@@ -405,6 +416,22 @@ def nchw3_to_nhwc4(x, dtype=torch.float32):
     assert C == 3
     out = torch.empty((N, 1, H, W, 4), dtype=dtype, device=x.device)
     check(lib().tri_nchw3_to_nhwc4(ptr(_f32(x.contiguous())), N, H, W, ptr(out), _abf(out), stream()), "tri_nchw3_to_nhwc4")
+    return out
+
+
+_CLIP_MEAN = (C_F3 := _C.C.c_float * 3)(0.48145466, 0.4578275, 0.40821073)      # general_dataset.py:88
+_CLIP_STD = C_F3(0.26862954, 0.26130258, 0.27577711)
+
+
+def nchw3_u8_to_nhwc4(x_u8, dtype=torch.float32, mean=None, std=None):
+    """u8 images [N,3,H,W] -> channels-last [N,1,H,W,4], ToTensor + CLIP Normalize done on the device."""
+    N, C, H, W = x_u8.shape
+    assert C == 3 and x_u8.dtype == torch.uint8
+    out = torch.empty((N, 1, H, W, 4), dtype=dtype, device=x_u8.device)
+    m = C_F3(*mean) if mean is not None else _CLIP_MEAN
+    sd = C_F3(*std) if std is not None else _CLIP_STD
+    check(lib().tri_nchw3_u8_to_nhwc4(ptr(x_u8.contiguous()), N, H, W, _C.C.cast(m, _C.C.c_void_p), _C.C.cast(sd, _C.C.c_void_p), ptr(out),
+                                      _abf(out), stream()), "tri_nchw3_u8_to_nhwc4")
     return out
 
 
