@@ -88,6 +88,29 @@ def test_conv_fwd_float_split_precision(case):
     assert (out1 - ref).abs().max().item() < 3e-2 * scale          # plain bf16 operands
 
 
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+def test_batched_weight_packing_equals_per_layer_packing(precision):
+    """tri_weight_prep_multi (LDS-transposed fast paths per parameter layout) against the element-wise tri_weight_prep for
+    every layer shape of the towers, forward and data-gradient operands."""
+    packer = ops.WeightPacker()
+    ref = {}
+    for case in CONV_CASES + [("c3x3_512", 1, (1, 4, 4), 512, 512, (1, 3, 3), 1, (0, 1, 1), "torch"),
+                              ("ds1x1_odd", 1, (1, 8, 8), 72, 200, (1, 1, 1), 2, (0, 0, 0), "torch"),
+                              ("vox_odd", 1, (4, 4, 4), 40, 72, (3, 3, 3), 1, (1, 1, 1), "spconv")]:
+        _, _, wp, _, g = make_case(case, integer=False, seed=7)
+        w = wp.to(DEV)
+        for tr in (False, True):
+            if tr and (g.cin != g.cin_stored or g.cin % 4):
+                continue
+            packer.add((case[0], tr), w, g, transposed=tr)
+            ref[(case[0], tr)] = ops.pack_weight(w, g, precision, transposed=tr)
+    out = packer.run(precision, torch.device(DEV))
+    for key, (hi, lo) in ref.items():
+        assert torch.equal(out[key][0], hi), key
+        if lo is not None:
+            assert torch.equal(out[key][1], lo), key
+
+
 def test_conv_fwd_mask_bias_act_stats():
     case = CONV_CASES[1]
     x, w, wp, xcl, g = make_case(case, integer=True, seed=3)

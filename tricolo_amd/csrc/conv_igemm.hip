@@ -1031,20 +1031,86 @@ __global__ void weight_prep_kernel(const float* __restrict__ w, long s_row, long
     if (lo) lo[idx] = (bf16_t)(v - (float)h);
 }
 
-// All layers of a tower in ONE launch: blockIdx.y selects the descriptor, blockIdx.x grid-strides over its elements.
-__global__ void weight_prep_multi_kernel(const TriPrepDesc* __restrict__ descs) {
+// All layers of a tower in ONE launch: blockIdx.y selects the descriptor, blockIdx.x grid-strides over its work.
+// The element-wise form above reads the parameter with whatever stride the layout dictates (36 B between consecutive
+// input channels of a torchvision [Cout,Cin,3,3] weight, a whole filter between consecutive output channels for the
+// data-gradient operand): every wave touches dozens of cache lines per load.  The three layouts the towers use are
+// therefore transposed through LDS - contiguous runs in, contiguous bf16 rows out; anything else takes the generic loop.
+__device__ __forceinline__ void prep_store(bf16_t* hi, bf16_t* lo, size_t idx, float v) {
+    const bf16_t h = (bf16_t)v;
+    hi[idx] = h;
+    if (lo) lo[idx] = (bf16_t)(v - (float)h);
+}
+
+__global__ __launch_bounds__(256) void weight_prep_multi_kernel(const TriPrepDesc* __restrict__ descs) {
+    __shared__ float tile[64 * 73];                              // 18.25 KiB: one filter row, or a 64 x (<= 72) + 1 transpose tile
     const TriPrepDesc d = descs[blockIdx.y];
-    const long total = (long)d.rows * d.kpad;
     bf16_t* hi = (bf16_t*)d.hi;
     bf16_t* lo = (bf16_t*)d.lo;
+    const int t = threadIdx.x, nt = d.ntaps;
+    const long span = (long)d.inner * nt;
+    if (nt > 1 && d.s_tap == 1 && d.s_inner == nt && d.s_row == span && span <= 64 * 73 && d.inner == d.inner_pad) {
+        // forward operand of a [Cout,Cin,taps] weight: one contiguous filter per row; dst[tap * Cin + ci] = src[ci * taps + tap]
+        for (int row = blockIdx.x; row < d.rows; row += gridDim.x) {
+            const float* src = d.w + (size_t)row * d.s_row;
+            for (int e = t; e < span; e += 256) tile[e] = src[e];
+            __syncthreads();
+            for (int k = t; k < d.kpad; k += 256) {
+                const int tap = k / d.inner_pad, i = k - tap * d.inner_pad;
+                prep_store(hi, lo, (size_t)row * d.kpad + k, tap < nt ? tile[i * nt + tap] : 0.f);
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    const bool torch_t = nt > 1 && nt <= 9 && d.s_tap == 1 && d.s_row == nt && d.s_inner == (long)d.rows * nt;   // [inner][rows][taps]
+    const bool plane_t = d.s_row == 1 && d.s_tap == d.rows && d.s_inner == (long)d.rows * nt;                   // [inner][taps][rows]
+    if ((torch_t || plane_t) && d.inner == d.inner_pad) {
+        // data-gradient operand: dst[row = ci][tap * Cout + co].  Tiles of RT rows x 64 inner; a source run is RT * taps (torch_t)
+        // or RT (plane_t, one tap at a time) contiguous floats per inner index.
+        const int RT = torch_t ? 8 : 32;
+        const int run = torch_t ? RT * nt : RT, ld = run + 1;     // odd leading dimension: conflict-free column reads
+        const int planes = torch_t ? 1 : nt;
+        const int rtiles = (d.rows + RT - 1) / RT, itiles = (d.inner + 63) / 64;
+        const long ntile = (long)rtiles * itiles * planes;
+        for (long tl = blockIdx.x; tl < ntile; tl += gridDim.x) {
+            const int plane = (int)(tl / ((long)rtiles * itiles));
+            const int rem = (int)(tl - (long)plane * rtiles * itiles);
+            const int r0 = (rem / itiles) * RT, i0 = (rem % itiles) * 64;
+            const int rows_here = min(RT, d.rows - r0);
+            const int run_here = torch_t ? rows_here * nt : rows_here;
+            for (int e = t; e < 64 * run; e += 256) {
+                const int il = e / run, r = e - il * run;
+                float v = 0.f;
+                if (i0 + il < d.inner && r < run_here)
+                    v = d.w[(size_t)(i0 + il) * d.s_inner + (torch_t ? (size_t)r0 * nt + r : (size_t)plane * d.s_tap + r0 + r)];
+                tile[il * ld + r] = v;
+            }
+            __syncthreads();
+            for (int e = t; e < 64 * run; e += 256) {
+                const int il = e & 63, r = e >> 6;                // r = row_l * taps + tap (torch_t) or row_l (plane_t)
+                const int row_l = torch_t ? r / nt : r, tap = torch_t ? r - row_l * nt : plane;
+                if (row_l < rows_here && i0 + il < d.inner)
+                    prep_store(hi, lo, (size_t)(r0 + row_l) * d.kpad + (size_t)tap * d.inner_pad + i0 + il, tile[il * ld + r]);
+            }
+            __syncthreads();
+        }
+        // zero the K padding of every row (kpad is the tap * inner extent rounded up to 32)
+        const int kused = nt * d.inner_pad, padw = d.kpad - kused;
+        if (padw > 0)
+            for (long e = (long)blockIdx.x * 256 + t; e < (long)d.rows * padw; e += (long)gridDim.x * 256) {
+                const int row = (int)(e / padw), k = kused + (int)(e - (long)row * padw);
+                prep_store(hi, lo, (size_t)row * d.kpad + k, 0.f);
+            }
+        return;
+    }
+    const long total = (long)d.rows * d.kpad;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         int row = (int)(idx / d.kpad), k = (int)(idx - (long)row * d.kpad);
         int tap = k / d.inner_pad, i = k - tap * d.inner_pad;
         float v = 0.f;
         if (tap < d.ntaps && i < d.inner) v = d.w[row * d.s_row + tap * d.s_tap + i * d.s_inner];
-        bf16_t h = (bf16_t)v;
-        hi[idx] = h;
-        if (lo) lo[idx] = (bf16_t)(v - (float)h);
+        prep_store(hi, lo, idx, v);
     }
 }
 
