@@ -142,7 +142,9 @@ extern "C" int tri_relu_bwd(const void* dout, const void* out, void* g, long n, 
 // and the coefficients of dy = c1*g + c2 + c3*y; pass 3: apply (rows with row_mask == 0 stay zero).
 // rows per block: 256 for large tensors, 64 for small ones (so that a 3,072-row layer still fills 48 CUs)
 static inline int bnb_rows(long M) { return M >= 65536 ? 256 : 64; }
-template <typename T>
+// MASK (compile time - a run-time test inside the row loop cost 1.6-2.5x on every launch): 0 g is final, 1 ReLU mask
+// recomputed from y, 2 ReLU mask from the saved output `ro`
+template <typename T, int MASK>
 __global__ void bn_bwd_reduce_kernel(const T* __restrict__ y, const T* __restrict__ g, long M, int C, float* __restrict__ partial,
                                      int BNB_ROWS, const float4* __restrict__ rs, const float4* __restrict__ rb,
                                      const T* __restrict__ ro) {
@@ -157,15 +159,17 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ y, const T* __restric
     for (int cc = 0; cc < cpt; ++cc) {
         int c4 = tc + cc * tpr;
         float4 sg = make_float4(0, 0, 0, 0), sgy = make_float4(0, 0, 0, 0);
-        float4 s4 = make_float4(0, 0, 0, 0), b4 = make_float4(1, 1, 1, 1);      // no ReLU: y*0 + 1 > 0 always
-        if (rs && c4 < C4) { s4 = rs[c4]; b4 = rb[c4]; }
+        float4 s4 = make_float4(0, 0, 0, 0), b4 = make_float4(1, 1, 1, 1);
+        if (MASK == 1 && c4 < C4) { s4 = rs[c4]; b4 = rb[c4]; }
         if (c4 < C4 && tr < rpp)
 #pragma unroll 4
             for (long r = r0 + tr; r < r1; r += rpp) {
                 float4 gv = Act<T>::ld4(g + r * C + c4 * 4), yv = Act<T>::ld4(y + r * C + c4 * 4);
-                gv.x = __fmaf_rn(yv.x, s4.x, b4.x) > 0.f ? gv.x : 0.f; gv.y = __fmaf_rn(yv.y, s4.y, b4.y) > 0.f ? gv.y : 0.f;
-                gv.z = __fmaf_rn(yv.z, s4.z, b4.z) > 0.f ? gv.z : 0.f; gv.w = __fmaf_rn(yv.w, s4.w, b4.w) > 0.f ? gv.w : 0.f;
-                if (ro) {                                           // ReLU taken after a residual add: mask from the saved output
+                if (MASK == 1) {
+                    gv.x = __fmaf_rn(yv.x, s4.x, b4.x) > 0.f ? gv.x : 0.f; gv.y = __fmaf_rn(yv.y, s4.y, b4.y) > 0.f ? gv.y : 0.f;
+                    gv.z = __fmaf_rn(yv.z, s4.z, b4.z) > 0.f ? gv.z : 0.f; gv.w = __fmaf_rn(yv.w, s4.w, b4.w) > 0.f ? gv.w : 0.f;
+                }
+                if (MASK == 2) {                                    // ReLU taken after a residual add: mask from the saved output
                     const float4 ov = Act<T>::ld4(ro + r * C + c4 * 4);
                     gv.x = ov.x > 0.f ? gv.x : 0.f; gv.y = ov.y > 0.f ? gv.y : 0.f; gv.z = ov.z > 0.f ? gv.z : 0.f; gv.w = ov.w > 0.f ? gv.w : 0.f;
                 }
@@ -202,8 +206,14 @@ extern "C" int tri_bn_bwd_reduce(const void* y, const void* g, long M, int C, fl
     int nblk = (int)((M + rows - 1) / rows);
     int C4 = C / 4, tpr = C4 < 256 ? C4 : 256, rpp = 256 / tpr;
     size_t smem = (size_t)rpp * tpr * 8 * sizeof(float);
-    TRI_ACT_DISPATCH(act_bf16, bn_bwd_reduce_kernel<T><<<nblk, 256, smem, (hipStream_t)stream>>>((const T*)y, (const T*)g, M, C, partial, rows,
-                                                                                                  (const float4*)relu_scale, (const float4*)relu_shift, (const T*)relu_out));
+    if (relu_scale && relu_out) { tri_set_error("tri_bn_bwd_reduce: give either relu_scale/shift or relu_out"); return TRI_ERR_ARG; }
+#define TRI_BNR(MASK_)                                                                                                              \
+    TRI_ACT_DISPATCH(act_bf16, bn_bwd_reduce_kernel<T, MASK_><<<nblk, 256, smem, (hipStream_t)stream>>>(                             \
+        (const T*)y, (const T*)g, M, C, partial, rows, (const float4*)relu_scale, (const float4*)relu_shift, (const T*)relu_out))
+    if (relu_out) TRI_BNR(2);
+    else if (relu_scale) TRI_BNR(1);
+    else TRI_BNR(0);
+#undef TRI_BNR
     return tri_check_launch("tri_bn_bwd_reduce");
 }
 
@@ -247,7 +257,7 @@ extern "C" int tri_bn_bwd_finalize(const float* partial, int nblk, int C, const 
     return tri_check_launch("tri_bn_bwd_finalize");
 }
 
-template <typename T>
+template <typename T, int MASK>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ y, const T* g, const float4* __restrict__ c1,
                                     const float4* __restrict__ c2, const float4* __restrict__ c3,
                                     const uint8_t* __restrict__ row_mask, T* dy, long total4, int C4,
@@ -258,12 +268,12 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ y, const T* g, const f
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
         if (!row_mask || row_mask[row]) {
             float4 yv = Act<T>::ld4(y + i * 4), gv = Act<T>::ld4(g + i * 4), a = c1[c], b = c2[c], d = c3[c];
-            if (rs) {                                               // ReLU mask recomputed from y (see tri_bn_bwd_reduce)
+            if (MASK == 1) {                                        // ReLU mask recomputed from y (see tri_bn_bwd_reduce)
                 const float4 s4 = rs[c], b4 = rb[c];
                 gv.x = __fmaf_rn(yv.x, s4.x, b4.x) > 0.f ? gv.x : 0.f; gv.y = __fmaf_rn(yv.y, s4.y, b4.y) > 0.f ? gv.y : 0.f;
                 gv.z = __fmaf_rn(yv.z, s4.z, b4.z) > 0.f ? gv.z : 0.f; gv.w = __fmaf_rn(yv.w, s4.w, b4.w) > 0.f ? gv.w : 0.f;
             }
-            if (ro) {
+            if (MASK == 2) {
                 const float4 ov = Act<T>::ld4(ro + i * 4);
                 gv.x = ov.x > 0.f ? gv.x : 0.f; gv.y = ov.y > 0.f ? gv.y : 0.f; gv.z = ov.z > 0.f ? gv.z : 0.f; gv.w = ov.w > 0.f ? gv.w : 0.f;
                 if (gm) Act<T>::st4(gm + i * 4, gv);                // the masked gradient also feeds the identity / down-sample branch
@@ -278,9 +288,14 @@ extern "C" int tri_bn_bwd_apply(const void* y, const void* g, const float* c1, c
                                 const uint8_t* row_mask, void* dy, long M, int C, const float* relu_scale, const float* relu_shift,
                                 const void* relu_out, void* g_masked, int act_bf16, void* stream) {
     long total4 = M * (C / 4);
-    TRI_ACT_DISPATCH(act_bf16, bn_bwd_apply_kernel<T><<<ew_grid(total4), 256, 0, (hipStream_t)stream>>>(
-        (const T*)y, (const T*)g, (const float4*)c1, (const float4*)c2, (const float4*)c3, row_mask, (T*)dy, total4, C / 4,
-        (const float4*)relu_scale, (const float4*)relu_shift, (const T*)relu_out, (T*)g_masked));
+#define TRI_BNA(MASK_)                                                                                                              \
+    TRI_ACT_DISPATCH(act_bf16, bn_bwd_apply_kernel<T, MASK_><<<ew_grid(total4), 256, 0, (hipStream_t)stream>>>(                      \
+        (const T*)y, (const T*)g, (const float4*)c1, (const float4*)c2, (const float4*)c3, row_mask, (T*)dy, total4, C / 4,          \
+        (const float4*)relu_scale, (const float4*)relu_shift, (const T*)relu_out, (T*)g_masked))
+    if (relu_out) TRI_BNA(2);
+    else if (relu_scale) TRI_BNA(1);
+    else TRI_BNA(0);
+#undef TRI_BNA
     return tri_check_launch("tri_bn_bwd_apply");
 }
 
