@@ -50,6 +50,12 @@ int tri_weight_prep_multi(const TriPrepDesc* descs_dev, int n, void* stream);
 int tri_weight_prep(const float* w, long s_row, long s_tap, long s_inner, int rows, int ntaps, int inner, int inner_pad,
                     void* w_hi, void* w_lo, void* stream);
 
+/* ---- token embedding (bigru.py:10,15) ------------------------------------------------------------------------------
+ * fwd: emb[L,B,D] = W[tokens[B,L]] (already in the GRU's time-major order); bwd: dense dW[V,D], occurrences summed in
+ * ascending (l, b) order (deterministic), row padding_idx zero (nn.Embedding(padding_idx=0) semantics). */
+int tri_embedding_fwd(const int* tokens, const float* weight, int B, int L, int D, float* out, void* stream);
+int tri_embedding_bwd(const int* tokens, const float* dout, int B, int L, int V, int D, int padding_idx, float* dweight, void* stream);
+
 /* ---- text -> shape retrieval ------------------------------------------------------------------------
  * Device-side replacement of eval_retrieval.py:70-82,184-187: float64 similarities text[Nq,D] . shape[Ns,D]^T, the k best
  * shapes per query (descending, equal similarities -> higher index first, i.e. numpy's ascending argsort flipped) and the

@@ -238,6 +238,24 @@ def test_linear_small_matches_torch(M, K, N, act):
         np.testing.assert_allclose(db.cpu().numpy(), dpre.sum(0).numpy(), atol=tol * 4, rtol=tol)
 
 
+def test_embedding_kernels_match_torch():
+    """Token lookup into time-major order and the deterministic dense weight gradient (duplicates, padding row)."""
+    g = torch.Generator().manual_seed(23)
+    B, L, V, D = 7, 96, 50, 256
+    tok = torch.randint(0, V, (B, L), generator=g, dtype=torch.int32)       # small vocabulary: many duplicates and pads
+    w = torch.randn(V, D, generator=g)
+    w[0] = 0
+    wr = w.clone().requires_grad_()
+    ref = F.embedding(tok.t().contiguous().long(), wr, padding_idx=0)
+    dout = ints((L, B, D), -3, 3, 29)                                       # integer gradients: any summation order is exact
+    ref.backward(dout)
+    out = ops.embedding_fwd(tok.to(DEV), w.to(DEV))
+    assert torch.equal(out.cpu(), ref.detach())
+    dw = ops.embedding_bwd(tok.to(DEV), dout.to(DEV), V)
+    assert torch.equal(dw.cpu(), wr.grad)
+    assert torch.count_nonzero(dw[0]) == 0
+
+
 def test_bn2d_forward_backward_matches_torch():
     g = torch.Generator().manual_seed(3)
     N, H, W, C = 4, 6, 6, 64

@@ -35,6 +35,8 @@ SIGNATURES = {
     "tri_conv_kpad": (I, [I, I]),
     "tri_weight_prep": (I, [P, L, L, L, I, I, I, I, P, P, P]),
     "tri_weight_prep_multi": (I, [P, I, P]),
+    "tri_embedding_fwd": (I, [P, P, I, I, I, P, P]),
+    "tri_embedding_bwd": (I, [P, P, I, I, I, I, I, P, P]),
     "tri_retrieval_topk": (I, [P, P, P, I, I, I, I, P, P, P, P]),
     "tri_linear_small_supported": (I, [I, I, I]),
     "tri_linear_small_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),

@@ -91,6 +91,66 @@ extern "C" int tri_mask_count(const uint8_t* mask, long n, int* count, void* str
     return tri_check_launch("tri_mask_count");
 }
 
+// ------------------------------------------------------------------------------------------------ token embedding
+// emb[l][b][:] = W[tok[b][l]][:]   (bigru.py:15: embedding_layer(x).transpose(0, 1); padding row 0 of W is zero by init)
+__global__ void embedding_fwd_kernel(const int* __restrict__ tok, const float4* __restrict__ w, int B, int L, int D4,
+                                     float4* __restrict__ out) {
+    const long total = (long)B * L * D4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int d = (int)(i % D4);
+        const long r = i / D4;
+        const int l = (int)(r / B), b = (int)(r - (long)l * B);
+        out[i] = w[(long)tok[b * L + l] * D4 + d];
+    }
+}
+extern "C" int tri_embedding_fwd(const int* tokens, const float* weight, int B, int L, int D, float* out, void* stream) {
+    if (D % 4) { tri_set_error("tri_embedding_fwd: D must be a multiple of 4"); return TRI_ERR_ARG; }
+    embedding_fwd_kernel<<<ew_grid((long)B * L * (D / 4)), 256, 0, (hipStream_t)stream>>>(tokens, (const float4*)weight, B, L, D / 4,
+                                                                                         (float4*)out);
+    return tri_check_launch("tri_embedding_fwd");
+}
+// dW[v][:] = sum over the occurrences (l, b) of token v, in ascending (l, b) order, of dout[l][b][:]; dW[padding_idx] = 0.
+// One workgroup per vocabulary row: the 256 threads ballot the whole token list into LDS bit masks once, then every thread
+// walks the (few) set bits and accumulates its own column - deterministic, no atomics, no sort (ATen's sort-based
+// embedding_dense_backward took 143 us for 3,072 tokens).
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const int* __restrict__ tok, const float* __restrict__ dout, int B, int L, int D,
+                                                            int padding_idx, float* __restrict__ dw) {
+    extern __shared__ unsigned long long masks[];                // [ceil(B*L / 64)]
+    const int v = blockIdx.x, t = threadIdx.x, n = B * L;
+    const int nm = (n + 63) >> 6;
+    for (int base = 0; base < n; base += 256) {
+        const int r = base + t;
+        bool hit = false;
+        if (r < n) {
+            const int l = r / B, b = r - l * B;
+            hit = tok[b * L + l] == v;
+        }
+        const unsigned long long m = __ballot(hit);
+        if ((t & 63) == 0 && (base >> 6) + (t >> 6) < nm) masks[(base >> 6) + (t >> 6)] = m;
+    }
+    __syncthreads();
+    for (int d = t; d < D; d += 256) {
+        float acc = 0.f;
+        if (v != padding_idx)
+            for (int w = 0; w < nm; ++w) {
+                unsigned long long m = masks[w];
+                while (m) {
+                    const int bit = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    acc += dout[(size_t)(w * 64 + bit) * D + d];
+                }
+            }
+        dw[(size_t)v * D + d] = acc;
+    }
+}
+extern "C" int tri_embedding_bwd(const int* tokens, const float* dout, int B, int L, int V, int D, int padding_idx, float* dweight,
+                                 void* stream) {
+    size_t smem = (size_t)((B * L + 63) / 64) * 8;
+    if (smem > 60 * 1024) { tri_set_error("tri_embedding_bwd: more than 491,520 tokens per call"); return TRI_ERR_UNSUPPORTED; }
+    embedding_bwd_kernel<<<V, 256, smem, (hipStream_t)stream>>>(tokens, dout, B, L, D, padding_idx, dweight);
+    return tri_check_launch("tri_embedding_bwd");
+}
+
 // ------------------------------------------------------------------------------------------------ image layout
 // x [N,3,H,W] f32 (tricolo_net.py:51 flatten of data_dict["images"]) -> [N,H,W,4] with a zero 4th channel
 template <typename T>

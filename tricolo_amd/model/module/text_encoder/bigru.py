@@ -53,6 +53,22 @@ class _BiGRUFn(torch.autograd.Function):
         return (demb, dw_ih[:384], dw_hh[0], db_ih[0], db_hh[0], dw_ih[384:], dw_hh[1], db_ih[1], db_hh[1], None)
 
 
+class _EmbeddingFn(torch.autograd.Function):
+    """nn.Embedding(padding_idx=0) lookup straight into time-major order, deterministic dense weight gradient."""
+
+    @staticmethod
+    def forward(ctx, tokens, weight):
+        tok = tokens.to(torch.int32).contiguous()
+        ctx.save_for_backward(tok)
+        ctx.vocab = weight.shape[0]
+        return ops.embedding_fwd(tok, weight)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (tok,) = ctx.saved_tensors
+        return None, ops.embedding_bwd(tok, dout, ctx.vocab, padding_idx=0)
+
+
 class BiGRUEncoder(TriModule):
     def __init__(self, vocab_size, out_dim, precision=None, **kwargs):
         super().__init__()
@@ -64,7 +80,7 @@ class BiGRUEncoder(TriModule):
     def forward(self, x, data_dict=None):
         require_gpu(x, "BiGRUEncoder")
         prec = self.precision or ops.default_precision()
-        emb = F.embedding(x.t().contiguous().long(), self.embedding_layer.weight, padding_idx=0)    # [L,B,256], bigru.py:15
+        emb = _EmbeddingFn.apply(x, self.embedding_layer.weight)                                        # [L,B,256], bigru.py:15
         g = self.gru
         feat = _BiGRUFn.apply(emb, g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0, g.weight_ih_l0_reverse,
                               g.weight_hh_l0_reverse, g.bias_ih_l0_reverse, g.bias_hh_l0_reverse, prec)   # bigru.py:16-17

@@ -451,6 +451,24 @@ def l2norm_bwd(z, norm, dz, eps=1e-12):
     return dx
 
 
+# ------------------------------------------------------------------------------------------------ token embedding
+def embedding_fwd(tokens, weight):
+    """tokens [B,L] int32, weight [V,D] -> [L,B,D] (time-major, what the GRU consumes)."""
+    B, L = tokens.shape
+    D = weight.shape[1]
+    out = torch.empty((L, B, D), dtype=torch.float32, device=weight.device)
+    check(lib().tri_embedding_fwd(ptr(tokens), ptr(_f32(weight)), B, L, D, ptr(out), stream()), "tri_embedding_fwd")
+    return out
+
+
+def embedding_bwd(tokens, dout, V, padding_idx=0):
+    B, L = tokens.shape
+    D = dout.shape[-1]
+    dw = torch.empty((V, D), dtype=torch.float32, device=dout.device)
+    check(lib().tri_embedding_bwd(ptr(tokens), ptr(_f32(dout.contiguous())), B, L, V, D, padding_idx, ptr(dw), stream()), "tri_embedding_bwd")
+    return dw
+
+
 # ------------------------------------------------------------------------------------------------ retrieval
 def retrieval_topk(text, shape, labels, k=5):
     """text [Nq,D], shape [Ns,D] fp32 on the GPU, labels [Nq] int32 -> (indices [Nq,k] i32, sims [Nq,k] f64, first_hit [Nq] i32)."""
