@@ -94,8 +94,13 @@ size_t tri_conv_workspace(const TriConvDesc* d, int transposed);
 int tri_conv_fwd(const TriConvDesc* d, const void* in, const void* w_hi, const void* w_lo, void* out, const uint8_t* row_mask,
                  const float* bias, int act, int accumulate, float* stats, int act_bf16, void* workspace, size_t workspace_bytes,
                  void* stream);
-int tri_conv_dgrad(const TriConvDesc* d, const void* dout, const void* wt_hi, const void* wt_lo, void* din,
-                   const uint8_t* row_mask, int accumulate, int act_bf16, void* workspace, size_t workspace_bytes, void* stream);
+int tri_conv_dgrad(const TriConvDesc* d, const void* dout, const void* wt_hi, const void* wt_lo, void* din, const uint8_t* row_mask,
+                   int accumulate, int act_bf16, void* workspace, size_t workspace_bytes,
+                   const int* row_pos /* optional [B*ID*IH*IW]: a permutation of the input positions, the order in which the
+                                         kernel's row tiles visit them.  For stride 2 pass the positions sorted by the parity of
+                                         (coordinate + pad) per axis: a tile then only runs the 1-4 taps of 9 its rows can use
+                                         (the other products are structurally zero).  Purely an execution-order hint. */,
+                   void* stream);
 size_t tri_conv_wgrad_workspace(const TriConvDesc* d);
 /* gather plan of a layer geometry (origin offset + tap validity bits per output position): build once, reuse every step */
 size_t tri_conv_plan_bytes(const TriConvDesc* d);

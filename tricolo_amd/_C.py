@@ -47,7 +47,7 @@ SIGNATURES = {
     "tri_conv_kernel_family": (I, [DP, I, I]),
     "tri_conv_wgrad_kernel_family": (I, [DP, I]),
     "tri_conv_fwd": (I, [DP, P, P, P, P, P, P, I, I, P, I, P, Z, P]),
-    "tri_conv_dgrad": (I, [DP, P, P, P, P, P, I, I, P, Z, P]),
+    "tri_conv_dgrad": (I, [DP, P, P, P, P, P, I, I, P, Z, P, P]),
     "tri_conv_wgrad_workspace": (Z, [DP]),
     "tri_conv_plan_bytes": (Z, [DP]),
     "tri_conv_plan_build": (I, [DP, P, P]),

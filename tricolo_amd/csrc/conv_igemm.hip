@@ -21,6 +21,7 @@ struct ConvArgs {
     const bf16_t* w_lo;
     void* out;
     const uint8_t* row_mask;   // per output position; 0 -> row forced to zero, all-zero tiles are skipped
+    const int* row_pos;        // optional row -> output position table (conv_dma_kernel, no split-K): rows may be visited in any order
     const float* bias;
     float* stats;              // [num_mtiles][2][Cout] per-tile column sum / sum of squares (BatchNorm statistics)
     float* slab;               // split-K partial sums [ksplit][M][Cout] (ksplit > 1)
@@ -72,11 +73,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[TM
         const int m = m0 + wm * WM + a * 16 + fr;
         if (m < p.M) {
             const float live = (p.row_mask && p.row_mask[m] == 0) ? 0.f : 1.f;
+            const size_t mo = p.row_pos ? (size_t)p.row_pos[m] : (size_t)m;        // where this row lives in the output tensor
 #pragma unroll
             for (int b = 0; b < TN; ++b) {
                 const int n = n0 + wn * WN + b * 16 + fq * 4;
                 f32x4 v = acc[a][b];
-                AT* o = (AT*)p.out + (size_t)m * p.Cout + n;
+                AT* o = (AT*)p.out + mo * p.Cout + n;
                 if (!plain) {
                     if (p.bias) v += *(const f32x4*)(p.bias + n);
                     if (p.act == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
@@ -657,7 +659,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs p) {
         int row = (t >> 3) + 32 * i;
         int m = m0 + row;
         bool valid = m < p.M;
-        uint32_t mm = valid ? (uint32_t)m : 0u;
+        uint32_t mm = valid ? (uint32_t)(p.row_pos ? p.row_pos[m] : m) : 0u;       // output position of this tile row
         uint32_t q1 = fdiv(mm, p.dOW);
         int ow = mm - q1 * p.OW;
         uint32_t q2 = fdiv(q1, p.dOH);
@@ -680,6 +682,21 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs p) {
         rmask[i] = valid ? mk : 0u;
         // byte offset of the chunk this lane fetches for that row (tap / channel-step offsets are added per k-step)
         rowoff[i] = (((((int)b * p.ID + z0) * p.IH + y0) * p.IW + x0) * p.Cin + (slot ^ ((row >> 1) & 7)) * 8) * 2;
+    }
+    // Rows visited out of order (row_pos: the stride-2 data gradient sorts them by tap-parity class) share few taps per tile.
+    // The per-axis OR of the rows' validity bits bounds the taps any row of the tile can use; k-steps of other taps are
+    // dropped from this workgroup's step list (exactly the 5-8 of 9 taps whose parity cannot match for a one-class tile).
+    __shared__ unsigned wave_axes[4];
+    __shared__ int live_steps[128], nlive_s;
+    if (p.row_pos) {
+        unsigned ax = rmask[0] | rmask[1] | rmask[2] | rmask[3];
+        ax |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)ax, 0x128, 0xf, 0xf, false);
+        ax |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)ax, 0x124, 0xf, 0xf, false);
+        ax |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)ax, 0x122, 0xf, 0xf, false);
+        ax |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)ax, 0x121, 0xf, 0xf, false);
+        ax = (unsigned)(__builtin_amdgcn_readlane((int)ax, 0) | __builtin_amdgcn_readlane((int)ax, 16) |
+                        __builtin_amdgcn_readlane((int)ax, 32) | __builtin_amdgcn_readlane((int)ax, 48));
+        if (lane == 0) wave_axes[wave] = ax;
     }
     any_active = __syncthreads_or(any_active);
 
@@ -746,25 +763,52 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs p) {
             }
         };
 
-        if (ks0 < ks1) {
+        int nl = ks1 - ks0;
+        if (p.row_pos) {
+            if (wave == 0) {
+                const unsigned axes = wave_axes[0] | wave_axes[1] | wave_axes[2] | wave_axes[3];
+                int count = 0;
+                for (int base = 0; base < ks1 - ks0; base += 64) {
+                    const int ks = ks0 + base + lane;
+                    bool ok = false;
+                    if (ks < ks1) {
+                        const int kb = ks * BK;
+                        const int tap = p.cin_shift >= 0 ? (kb >> p.cin_shift) : (int)fdiv((uint32_t)kb, p.dCin);
+                        if (tap < p.ntaps) {
+                            const int sh = lut_sh[tap];
+                            ok = ((axes >> (sh & 255)) & (axes >> ((sh >> 8) & 255)) & (axes >> ((sh >> 16) & 255))) & 1u;
+                        }
+                    }
+                    const unsigned long long bal = __ballot(ok);
+                    if (ok && count + __popcll(bal & ((1ull << lane) - 1ull)) < 128)
+                        live_steps[count + __popcll(bal & ((1ull << lane) - 1ull))] = ks;
+                    count += __popcll(bal);
+                }
+                if (lane == 0) nlive_s = count;
+            }
+            __syncthreads();
+            nl = nlive_s;
+        }
+        auto step_at = [&](int j) { return p.row_pos ? live_steps[j] : ks0 + j; };
+        if (nl > 0) {
             // NST - 1 stages in flight ahead of the MFMAs.  The DMAs are asm-issued (common.h) and complete in order, so
             // "stage ks has landed" == "at most the PER instructions of each younger stage are still outstanding".
             constexpr int PER = 4 + BN / 32;
 #pragma unroll
             for (int d = 0; d < NST - 1; ++d)
-                if (ks0 + d < ks1) issue(ks0 + d, d);
+                if (d < nl) issue(step_at(d), d);
             int buf = 0;
-            for (int ks = ks0; ks < ks1; ++ks) {
-                const int younger = min(ks1 - 1 - ks, NST - 2);
+            for (int j = 0; j < nl; ++j) {
+                const int younger = min(nl - 1 - j, NST - 2);
                 if (NST == 2 || younger == 0) wait_vmcnt(0);
                 else if (younger == 1) wait_vmcnt(PER);
                 else wait_vmcnt(2 * PER);
-                __builtin_amdgcn_s_barrier();                            // everybody's stage ks is visible; all reads of stage ks - 1 are done
+                __builtin_amdgcn_s_barrier();                            // everybody's stage j is visible; all reads of stage j - 1 are done
                 asm volatile("" ::: "memory");
-                if (ks + NST - 1 < ks1) {
+                if (j + NST - 1 < nl) {
                     int nb = buf + NST - 1;
                     if (nb >= NST) nb -= NST;
-                    issue(ks + NST - 1, nb);                             // refills the buffer stage ks - 1 was computed from
+                    issue(step_at(j + NST - 1), nb);                     // refills the buffer stage j - 1 was computed from
                 }
                 compute(buf);
                 if (++buf == NST) buf = 0;
@@ -1352,6 +1396,8 @@ static int conv_dispatch(ConvArgs& a, int act_bf16, void* workspace, size_t work
         a.slab = (float*)workspace;
     }
     a.dOW = make_fastdiv(a.OW); a.dOH = make_fastdiv(a.OH); a.dOD = make_fastdiv(a.OD); a.dCin = make_fastdiv(a.Cin);
+    // row_pos is an optimisation hint: honoured by the DMA kernel without split-K, dropped (identity order) everywhere else
+    if (a.row_pos && !(pl.dma && !pl.halo && pl.ksplit == 1 && !a.row_mask && !a.stats && a.Kpad / 64 <= 128)) a.row_pos = nullptr;
     if (pl.halo) return launch_halo<64>(a, pl, stream);
     if (pl.dma) {
         if (dma_stages() == 2) return pl.bn == 128 ? launch_dma<128, 2>(a, stream) : launch_dma<64, 2>(a, stream);
@@ -1439,10 +1485,10 @@ extern "C" int tri_conv_fwd(const TriConvDesc* d, const void* in, const void* w_
 // with swapped strides.  `d` is the FORWARD descriptor of the layer.
 extern "C" int tri_conv_dgrad(const TriConvDesc* d, const void* dout, const void* wt_hi, const void* wt_lo, void* din,
                               const uint8_t* row_mask, int accumulate, int act_bf16, void* workspace, size_t workspace_bytes,
-                              void* stream) {
+                              const int* row_pos, void* stream) {
     ConvArgs a{};
     a.in = dout; a.w_hi = (const bf16_t*)wt_hi; a.w_lo = (const bf16_t*)wt_lo; a.out = din;
-    a.row_mask = row_mask; a.bias = nullptr; a.stats = nullptr;
+    a.row_mask = row_mask; a.bias = nullptr; a.stats = nullptr; a.row_pos = row_pos;
     a.B = d->B; a.ID = d->OD; a.IH = d->OH; a.IW = d->OW; a.Cin = d->Cout;       // gather source = dout grid
     a.OD = d->ID; a.OH = d->IH; a.OW = d->IW; a.Cout = d->Cin;                   // rows = input positions
     a.KD = d->KD; a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pd = d->pad_d; a.ph = d->pad_h; a.pw = d->pad_w;

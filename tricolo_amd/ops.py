@@ -127,6 +127,25 @@ class ConvGeom:
         self.fwd_ws = lib().tri_conv_workspace(_C.C.byref(self.desc), 0)
         self.dgrad_ws = lib().tri_conv_workspace(_C.C.byref(self.desc), 1) if cin == cin_stored and cin % 32 == 0 else 0
 
+    def dgrad_row_order(self, device):
+        """Stride-2 layers: the input positions sorted by the parity class of (coordinate + pad) per axis - the order in which
+        tri_conv_dgrad should visit its rows so that a tile only runs the taps its rows can use.  None for stride 1."""
+        if self.stride != 2 or self.ntaps == 1:                  # 1x1 / 2: one tap, nothing to skip (and scattered rows cost)
+            return None
+        t = self._plans.get(("rowpos", device))
+        if t is None:
+            ID, IH, IW = self.in_grid
+            pd, ph, pw = self.pad
+            pos = torch.arange(self.M_in, dtype=torch.int64)
+            x, r = pos % IW, pos // IW
+            y, r = r % IH, r // IH
+            z = r % ID
+            cls = (((z + pd) & 1) << 2) | (((y + ph) & 1) << 1) | ((x + pw) & 1)
+            order = torch.sort(cls * self.M_in + pos).indices          # by class, ascending position inside a class
+            t = order.to(torch.int32).to(device)
+            self._plans[("rowpos", device)] = t
+        return t
+
     def plan(self, device):
         """Gather plan (built once per geometry and device, reused by every step's wgrad)."""
         pl = self._plans.get(device)
@@ -220,6 +239,9 @@ def conv_fwd(x, g: ConvGeom, packed, row_mask=None, bias=None, act=0, want_stats
     return (out, stats) if want_stats else out
 
 
+_ROW_ORDER = os.environ.get("TRICOLO_NO_ROW_ORDER", "0") != "1"      # A/B switch: parity-class row order for stride-2 data gradients
+
+
 def conv_dgrad(dout, g: ConvGeom, packed_t, row_mask=None, out=None, accumulate=False):
     hi, lo = packed_t
     ID, IH, IW = g.in_grid
@@ -227,10 +249,11 @@ def conv_dgrad(dout, g: ConvGeom, packed_t, row_mask=None, out=None, accumulate=
         out = torch.empty((g.B, ID, IH, IW, g.cin_stored), dtype=dout.dtype, device=dout.device)
     assert out.dtype == dout.dtype
     ws = _workspace(g.dgrad_ws, dout.device) if g.dgrad_ws else None
+    rowpos = g.dgrad_row_order(dout.device) if (row_mask is None and _ROW_ORDER) else None
     check(_timed(_igemm_symbol(g, True, lo is not None, dout), g.flops,
                  lambda: lib().tri_conv_dgrad(_C.C.byref(g.desc), ptr(_act(dout)), ptr(hi), ptr(lo), ptr(out), ptr(row_mask),
                                               1 if accumulate else 0, _abf(dout), ptr(ws), ws.numel() if ws is not None else 0,
-                                              stream())), "tri_conv_dgrad")
+                                              ptr(rowpos), stream())), "tri_conv_dgrad")
     return out
 
 
