@@ -227,6 +227,18 @@ def main():
                     "all_kernels": {k: {"launches_per_step": v["launches"] // nprof, "ms_per_step": round(v["ms"] / nprof, 3),
                                         "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in agg.items()}}
 
+    # HBM bytes per launch of that kernel from the committed PMC passes over this same command (PMC cannot run inside bench.py:
+    # two separate `rocprofv3 --pmc` runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes; profiles/r1/pmc_step_traffic.json)
+    if roof is not None:
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1", "pmc_step_traffic.json")) as f:
+                pmc = json.load(f)["kernels"].get(roof["kernel"])
+            if pmc and args.precision == "bf16":
+                roof["traffic"] = pmc["hbm_read_bytes_per_launch"] + (pmc["hbm_write_bytes_per_launch"] or 0)
+                roof["traffic_unit"] = "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r1/pmc_step_traffic.json)"
+        except Exception:                           # noqa: BLE001
+            pass
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:             # the CPU leg is an N = 1 artefact (task contract)
         cpu = cpu_baseline(args, cfg)
