@@ -399,6 +399,18 @@ def test_maxpool2d_and_viewmax():
     assert torch.equal(out.cpu().view(N, 5, 5, C).permute(0, 3, 1, 2), ref.detach())
     dx = ops.maxpool2d_bwd(parg, dout.permute(0, 2, 3, 1).contiguous().to(DEV), tuple(xcl.shape))
     np.testing.assert_allclose(dx.cpu().view(N, H, W, C).permute(0, 3, 1, 2).numpy(), xr.grad.numpy(), atol=1e-6)
+    # odd extents take the per-pixel backward kernel, even ones the 2x2-block kernel: both against torch
+    for (h2, w2) in ((9, 7), (8, 12)):
+        x2 = torch.randint(0, 6, (2, 8, h2, w2), generator=g).float()
+        x2r = x2.clone().requires_grad_()
+        ref2 = F.max_pool2d(x2r, 3, 2, 1)
+        d2 = ints(tuple(ref2.shape), -3, 3, 31)
+        ref2.backward(d2)
+        x2cl = x2.permute(0, 2, 3, 1).contiguous().view(2, 1, h2, w2, 8).to(DEV)
+        o2, a2 = ops.maxpool2d_fwd(x2cl)
+        assert torch.equal(o2.cpu().view(2, ref2.shape[2], ref2.shape[3], 8).permute(0, 3, 1, 2), ref2.detach())
+        dx2 = ops.maxpool2d_bwd(a2, d2.permute(0, 2, 3, 1).contiguous().to(DEV), tuple(x2cl.shape))
+        assert torch.equal(dx2.cpu().view(2, h2, w2, 8).permute(0, 3, 1, 2), x2r.grad)
     # BN + ReLU + max-pool in one pass == bn_act followed by the plain pool (values and winning taps)
     co = ops.bn_eval_coeffs(C, (torch.rand(C, generator=g) + 0.5).to(DEV), torch.randn(C, generator=g).to(DEV),
                             torch.full((C,), 2.5).to(DEV), torch.ones(C).to(DEV))
