@@ -186,6 +186,11 @@ int tri_ntxent_fwd_bwd(const float* za, const float* zb, int B, int D, float tem
 int tri_adam_tick(int* step, void* stream);
 int tri_adam_step(float* p, const float* g, float* m, float* v, long n, const int* step, float lr, float b1, float b2, float eps,
                   float wd, float gscale, void* stream);
+/* the same update with the gradients read in place: grad_ptrs = DEVICE array of nseg device pointers (NULL = no gradient: treated
+ * as zeros), grad_starts = DEVICE array of the flat start offset of each segment (ascending, first 0); segment sizes and n are
+ * multiples of 4, gradient tensors 16-byte aligned.  Saves the flat-gradient concatenation pass of the single-GPU step. */
+int tri_adam_step_segments(float* p, const void* grad_ptrs, const long* grad_starts, int nseg, float* m, float* v, long n,
+                           const int* step, float lr, float b1, float b2, float eps, float wd, float gscale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -82,6 +82,7 @@ SIGNATURES = {
     "tri_ntxent_fwd_bwd": (I, [P, P, I, I, F, F, I, P, P, P, P, Z, P]),
     "tri_adam_tick": (I, [P, P]),
     "tri_adam_step": (I, [P, P, P, P, L, P, F, F, F, F, F, F, P]),
+    "tri_adam_step_segments": (I, [P, P, P, I, P, P, L, P, F, F, F, F, F, F, P]),
 }
 
 _lib = None

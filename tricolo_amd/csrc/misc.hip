@@ -294,6 +294,52 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
         p[i] = pi - step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
     }
 }
+// Same update, gradients read in place from the per-parameter tensors autograd produced (segment table: device pointer and
+// flat start offset of every parameter, ascending) - no concatenation pass over the 74 MB of gradients first.  Four elements
+// per thread; segment sizes / starts are multiples of 4 and the gradient tensors 16-byte aligned (checked by the caller).
+#define ADAM_MAX_SEG 1024
+__global__ __launch_bounds__(256) void adam_seg_kernel(float* __restrict__ p, const float* const* __restrict__ gptr,
+                                                       const long* __restrict__ gstart, int nseg, float* __restrict__ m,
+                                                       float* __restrict__ v, long n4, const int* __restrict__ step, float lr, float b1,
+                                                       float b2, float eps, float wd, float gscale) {
+    __shared__ long sstart[ADAM_MAX_SEG];
+    __shared__ const float* sptr[ADAM_MAX_SEG];
+    for (int i = threadIdx.x; i < nseg; i += 256) { sstart[i] = gstart[i]; sptr[i] = gptr[i]; }
+    __syncthreads();
+    const int t = *step;
+    const float bc1 = 1.f - powf(b1, (float)t), bc2 = 1.f - powf(b2, (float)t);
+    const float step_size = lr / bc1, inv_sqrt_bc2 = 1.f / sqrtf(bc2);
+    for (long i4 = (long)blockIdx.x * blockDim.x + threadIdx.x; i4 < n4; i4 += (long)gridDim.x * blockDim.x) {
+        const long i = i4 * 4;
+        int lo = 0, hi = nseg - 1;                                  // last segment whose start is <= i
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (sstart[mid] <= i) lo = mid; else hi = mid - 1;
+        }
+        const float* gs = sptr[lo];
+        float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gs) gv = *(const float4*)(gs + (i - sstart[lo]));
+        float4 pv = *(const float4*)(p + i), mv = *(const float4*)(m + i), vv = *(const float4*)(v + i);
+#define ADAM1(P, G, M, V)                                   \
+    {                                                       \
+        const float gi = G * gscale + wd * P;               \
+        M = b1 * M + (1.f - b1) * gi;                       \
+        V = b2 * V + (1.f - b2) * gi * gi;                  \
+        P = P - step_size * M / (sqrtf(V) * inv_sqrt_bc2 + eps); \
+    }
+        ADAM1(pv.x, gv.x, mv.x, vv.x) ADAM1(pv.y, gv.y, mv.y, vv.y) ADAM1(pv.z, gv.z, mv.z, vv.z) ADAM1(pv.w, gv.w, mv.w, vv.w)
+#undef ADAM1
+        *(float4*)(p + i) = pv; *(float4*)(m + i) = mv; *(float4*)(v + i) = vv;
+    }
+}
+extern "C" int tri_adam_step_segments(float* p, const void* grad_ptrs, const long* grad_starts, int nseg, float* m, float* v, long n,
+                                      const int* step, float lr, float b1, float b2, float eps, float wd, float gscale, void* stream) {
+    if (nseg < 1 || nseg > ADAM_MAX_SEG || n % 4) { tri_set_error("tri_adam_step_segments: 1..1024 segments, n % 4 == 0"); return TRI_ERR_ARG; }
+    adam_seg_kernel<<<ew_grid(n / 4), 256, 0, (hipStream_t)stream>>>(p, (const float* const*)grad_ptrs, grad_starts, nseg, m, v, n / 4, step, lr,
+                                                                      b1, b2, eps, wd, gscale);
+    return tri_check_launch("tri_adam_step_segments");
+}
+
 extern "C" int tri_adam_step(float* p, const float* g, float* m, float* v, long n, const int* step, float lr, float b1, float b2,
                              float eps, float wd, float gscale, void* stream) {
     adam_kernel<<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, step, lr, b1, b2, eps, wd, gscale);

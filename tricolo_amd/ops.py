@@ -588,6 +588,12 @@ def adam_tick(step):
     check(lib().tri_adam_tick(ptr(step), stream()), "tri_adam_tick")
 
 
+def adam_step_segments(p, grad_ptrs, grad_starts, m, v, step, lr, b1, b2, eps, wd, gscale=1.0):
+    """Fused Adam over the flat buffers with the gradients read in place through a device (pointer, start) table."""
+    check(lib().tri_adam_step_segments(ptr(p), ptr(grad_ptrs), ptr(grad_starts), grad_starts.numel(), ptr(m), ptr(v), p.numel(), ptr(step),
+                                       lr, b1, b2, eps, wd, gscale, stream()), "tri_adam_step_segments")
+
+
 def adam_step(p, g, m, v, step, lr, b1, b2, eps, wd, gscale=1.0):
     check(lib().tri_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(step), lr, b1, b2, eps, wd, gscale, stream()),
           "tri_adam_step")

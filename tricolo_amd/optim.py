@@ -48,6 +48,23 @@ class FusedAdam(torch.optim.Optimizer):
             self._flat_p = flat
             self._flat_m = torch.zeros_like(flat)
             self._flat_v = torch.zeros_like(flat)
+            # segment table for the in-place gradient read (single-GPU step): flat start of every parameter, and a pinned
+            # host + device pair for the gradient pointers, refreshed per step (captured once under a HIP graph)
+            self._seg_ok = all(n % 4 == 0 for n in sizes) and len(sizes) <= 1024
+            if self._seg_ok:
+                starts = [0]
+                for n in sizes[:-1]:
+                    starts.append(starts[-1] + n)
+                self._seg_start = torch.tensor(starts, dtype=torch.int64, device=dev)
+                # eager steps: a small ring of pinned staging buffers, each guarded by an event (the stream may lag the host by
+                # many kernels, so a buffer is only refilled after its previous copy ran); a HIP-graph capture gets a staging
+                # buffer of its own that is never written again (the captured copy re-reads it on every replay)
+                self._seg_ring = [[torch.zeros((len(sizes),), dtype=torch.int64).pin_memory(), None] for _ in range(4)]
+                self._seg_ring_i = 0
+                self._seg_capture_pool = [torch.zeros((len(sizes),), dtype=torch.int64).pin_memory() for _ in range(8)]
+                self._seg_captured = []
+                self._seg_ptr = torch.zeros((len(sizes),), dtype=torch.int64, device=dev)
+                self._seg_keep = None
             off = 0
             for p, n in zip(params, sizes):                          # torch-compatible per-parameter state views
                 self.state[p]["exp_avg"] = self._flat_m[off:off + n].view(p.shape)
@@ -65,6 +82,43 @@ class FusedAdam(torch.optim.Optimizer):
             g = p.grad
             parts.append(g.reshape(-1) if g is not None else torch.zeros(p.numel(), dtype=torch.float32, device=p.device))
         return torch.cat(parts)
+
+    def _update_from_segments(self, group, b1, b2, grad_scale) -> bool:
+        """Single-GPU step without the concatenation pass: the kernel reads every gradient where autograd left it."""
+        grads, ptrs = [], []
+        for p in self._params:
+            g = p.grad
+            if g is not None:
+                if g.dtype != torch.float32 or not g.is_cuda:
+                    return False
+                if not g.is_contiguous():
+                    g = g.contiguous()
+                if g.data_ptr() % 16:
+                    return False
+            grads.append(g)
+            ptrs.append(g.data_ptr() if g is not None else 0)
+        capturing = torch.cuda.is_current_stream_capturing()
+        if capturing:
+            if not self._seg_capture_pool:                           # (pinned memory cannot be allocated inside a capture)
+                return False
+            host = self._seg_capture_pool.pop()
+            host.copy_(torch.tensor(ptrs, dtype=torch.int64))
+            self._seg_captured.append(host)                          # owned by the graph from now on
+        else:
+            slot = self._seg_ring[self._seg_ring_i]
+            self._seg_ring_i = (self._seg_ring_i + 1) % len(self._seg_ring)
+            if slot[1] is not None:
+                slot[1].synchronize()
+            host = slot[0]
+            host.copy_(torch.tensor(ptrs, dtype=torch.int64))
+        self._seg_keep = grads                                       # keep temporaries alive until the next step
+        self._seg_ptr.copy_(host, non_blocking=True)
+        if not capturing:
+            slot[1] = torch.cuda.Event()
+            slot[1].record()
+        ops.adam_step_segments(self._flat_p, self._seg_ptr, self._seg_start, self._flat_m, self._flat_v, self._step_dev, group["lr"],
+                               b1, b2, group["eps"], group["weight_decay"], grad_scale)
+        return True
 
     @torch.no_grad()
     def apply_flat(self, g: torch.Tensor, grad_scale: float = 1.0):
@@ -89,6 +143,8 @@ class FusedAdam(torch.optim.Optimizer):
         b1, b2 = group["betas"]
         ops.adam_tick(self._step_dev)                       # step += 1 on the device, once per optimizer step
         if self._flatten:
+            if reduce_fn is None and self._seg_ok and self._update_from_segments(group, b1, b2, grad_scale):
+                return loss
             g = self.flat_grad()
             if reduce_fn is not None:
                 reduce_fn(g)
