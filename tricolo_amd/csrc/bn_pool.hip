@@ -22,6 +22,15 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int ntiles
     // once (the 4-channel x 64-lane version spent 12-30 us in a dependent-load chain on the 1,536 - 6,144 record layers)
     __shared__ double ssum[4], ssq[4];
     const int c = blockIdx.x;
+    // the finishing thread's operands are requested first: their latency then overlaps the record loads instead of
+    // following the reduction (these 50 launches per step are pure latency on the step's critical path)
+    float pg = 0.f, pb = 0.f, prm = 0.f, prv = 0.f;
+    int pcount = count_host;
+    if (threadIdx.x == 0) {
+        pg = gamma[c]; pb = beta[c];
+        if (running_mean) { prm = running_mean[c]; prv = running_var[c]; }
+        if (count_dev) pcount = *count_dev;
+    }
     double s = 0.0, q = 0.0;
 #pragma unroll 8
     for (int tIdx = threadIdx.x; tIdx < ntiles; tIdx += 256) {
@@ -35,7 +44,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int ntiles
     if (threadIdx.x == 0) {
         s = (ssum[0] + ssum[1]) + (ssum[2] + ssum[3]);
         q = (ssq[0] + ssq[1]) + (ssq[2] + ssq[3]);
-        double n = count_dev ? (double)(*count_dev) : (double)count_host;
+        double n = (double)pcount;
         if (n < 1.0) {                       // SparseSequential skips BN when there is no active site
             mean_out[c] = 0.f; invstd_out[c] = 0.f; scale_out[c] = 0.f; shift_out[c] = 0.f;
             return;
@@ -46,13 +55,13 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int ntiles
         double invstd = 1.0 / sqrt(var + (double)eps);
         mean_out[c] = (float)mean;
         invstd_out[c] = (float)invstd;
-        float sc = (float)((double)gamma[c] * invstd);
+        float sc = (float)((double)pg * invstd);
         scale_out[c] = sc;
-        shift_out[c] = (float)((double)beta[c] - mean * (double)gamma[c] * invstd);
+        shift_out[c] = (float)((double)pb - mean * (double)pg * invstd);
         if (running_mean) {
             double unb = n > 1.0 ? var * n / (n - 1.0) : var;
-            running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
-            running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+            running_mean[c] = (float)((1.0 - momentum) * prm + momentum * mean);
+            running_var[c] = (float)((1.0 - momentum) * prv + momentum * unb);
         }
         if (num_batches_tracked && c == 0) *num_batches_tracked += 1;
     }
@@ -223,6 +232,12 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nb
                                        float* __restrict__ c1, float* __restrict__ c2, float* __restrict__ c3) {
     __shared__ double ssum[4], ssq[4];                              // one channel per block, see bn_finalize_kernel
     const int c = blockIdx.x;
+    float pmu = 0.f, pis = 0.f, pga = 0.f;
+    int pcount = count_host;
+    if (threadIdx.x == 0) {                                         // requested up front, see bn_finalize_kernel
+        pmu = mean[c]; pis = invstd[c]; pga = gamma[c];
+        if (count_dev) pcount = *count_dev;
+    }
     double s = 0.0, q = 0.0;
 #pragma unroll 8
     for (int b = threadIdx.x; b < nblk; b += 256) {
@@ -236,9 +251,9 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nb
     if (threadIdx.x == 0) {
         s = (ssum[0] + ssum[1]) + (ssum[2] + ssum[3]);
         q = (ssq[0] + ssq[1]) + (ssq[2] + ssq[3]);
-        double n = count_dev ? (double)(*count_dev) : (double)count_host;
+        double n = (double)pcount;
         if (n < 1.0) { dgamma[c] = 0.f; dbeta[c] = 0.f; c1[c] = 0.f; c2[c] = 0.f; c3[c] = 0.f; return; }
-        double mu = mean[c], is = invstd[c], ga = gamma[c];
+        double mu = pmu, is = pis, ga = pga;
         double dbe = s;                                   // sum g
         double dga = is * (q - mu * s);                   // sum g * xhat
         dgamma[c] = (float)dga;
