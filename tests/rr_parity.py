@@ -1,12 +1,13 @@
 #!/usr/bin/env python
-"""Retrieval-quality parity on a learnable held-out synthetic set (north-star: RR@1 within +-0.2 of the reference).
+"""(Checker script, kept under tests/ because it drives the CPU oracle - test infrastructure - next to the HIP path;
+not collected by pytest.)  Retrieval-quality parity on a learnable held-out synthetic set (north-star: RR@1 within +-0.2 of the reference).
 
 Trains the HIP path (MI355X) and the CPU oracle (restatement of the reference step, pinned to the reference by
 tests/golden) from IDENTICAL weights on IDENTICAL batches for a fixed number of steps, then embeds the same held-out
 captions / shapes in eval mode with both, and reports RR@1 / RR@5 / NDCG@5 / MRR through the reference's metric
 (eval_retrieval.compute_metrics semantics) plus the agreement of the top-1 retrieved indices.
 
-    python tools/rr_parity.py [--steps 40] [--batch 32] [--train-shapes 256] [--eval-shapes 256] [--precision bf16x3]
+    python tests/rr_parity.py [--steps 40] [--batch 32] [--train-shapes 256] [--eval-shapes 256] [--precision bf16x3]
 """
 import argparse
 import json
