@@ -6,10 +6,9 @@ ascending argsort flipped (:75-82, which fixes the tie order), RR@k counts queri
 
 The ranking itself runs on the GPU: `tri_retrieval_topk` computes the float64 similarities, the five
 best shapes per query and the rank of the query's own shape in one launch (csrc/retrieval.hip); the host only builds the
-label tables from the model_id strings and turns [Nq,5] indices + [Nq] ranks into the four numbers.  `backend="numpy"`
-is the reference's own host algorithm, kept for machines without a GPU and as the A/B partner in the tests - it is
-never selected silently: the default backend raises when the HIP library or a GPU is missing.
-Unlike the reference it does not write nearest.jsonl into the CWD unless asked.
+label tables from the model_id strings and turns [Nq,5] indices + [Nq] ranks into the four numbers.  There is no host
+ranking path in this package: without the HIP library / a GPU the call raises (the reference's numpy algorithm lives in
+oracle/retrieval.py, test infrastructure).  Unlike the reference it does not write nearest.jsonl into the CWD unless asked.
 """
 import json
 
@@ -35,20 +34,12 @@ def construct_embeddings_matrix(dataset, embeddings_dict):
     return text, shape, labels, np.arange(len(shapes)), model_id_to_label, len(tuples), label_to_model_id
 
 
-def nearest_neighbors(shape, text, n_neighbors):
-    sims = np.dot(text, shape.T)
-    sort_indices = np.argsort(sims, axis=1)
-    distances = np.flip(np.sort(sims, axis=1)[:, -n_neighbors:])
-    indices = np.flip(sort_indices[:, -n_neighbors:], 1)
-    return distances, indices, np.flip(sort_indices, 1)
-
-
 def nearest_neighbors_hip(shape, text, labels, n_neighbors):
     """Device path: (distances [Nq,k] f64, indices [Nq,k], first_hit [Nq]) from csrc/retrieval.hip."""
     import torch
     from .. import ops
     if not torch.cuda.is_available():
-        raise RuntimeError("compute_metrics(backend='hip') needs an MI355X; pass backend='numpy' for the host algorithm")
+        raise RuntimeError("compute_metrics ranks on the GPU (tri_retrieval_topk) and there is no CPU fallback: no MI355X visible")
     dev = torch.device("cuda")
     t = torch.from_numpy(np.ascontiguousarray(text, dtype=np.float32)).to(dev)     # the f64 text matrix holds f32 values
     s = torch.from_numpy(np.ascontiguousarray(shape, dtype=np.float32)).to(dev)
@@ -57,14 +48,12 @@ def nearest_neighbors_hip(shape, text, labels, n_neighbors):
     return sim.cpu().numpy(), idx.cpu().numpy().astype(np.int64), hit.cpu().numpy().astype(np.int64)
 
 
-def compute_pr_at_k(indices, sort_indices, labels, n_neighbors, num_embeddings, fit_labels, first_hit=None):
+def compute_pr_at_k(indices, first_hit, labels, n_neighbors, num_embeddings, fit_labels):
     nearest = fit_labels[indices]
     rel = (nearest == labels[:, None]).astype(np.float32)
     num_correct = np.cumsum(rel, axis=1)
     num_relevant = np.bincount(fit_labels)[labels]
     rel_ideal = (np.arange(n_neighbors)[None, :] < np.minimum(num_relevant, n_neighbors)[:, None]).astype(np.float32)
-    if first_hit is None:
-        first_hit = np.argmax(fit_labels[sort_indices] == labels[:, None], axis=1)
     mrr = float(np.mean(1.0 / (first_hit + 1)))
     dcg_d = np.log2(np.arange(1, n_neighbors + 1) + 1)
     dcg = np.cumsum((np.exp2(rel) - 1) / dcg_d, axis=1)
@@ -78,17 +67,11 @@ def compute_pr_at_k(indices, sort_indices, labels, n_neighbors, num_embeddings, 
     }
 
 
-def compute_metrics(dataset, embeddings_dict, print_results=False, nearest_path=None, backend="hip"):
+def compute_metrics(dataset, embeddings_dict, print_results=False, nearest_path=None):
     text, shape, labels, fit_labels, _, num, label_to_model_id = construct_embeddings_matrix(dataset, embeddings_dict)
     n_neighbors = 5
-    if backend == "hip":
-        distances, indices, first_hit = nearest_neighbors_hip(shape, text, labels, n_neighbors)
-        pr_at_k = compute_pr_at_k(indices, None, labels, n_neighbors, num, fit_labels, first_hit=first_hit)
-    elif backend == "numpy":
-        distances, indices, sort_indices = nearest_neighbors(shape, text, n_neighbors)
-        pr_at_k = compute_pr_at_k(indices, sort_indices, labels, n_neighbors, num, fit_labels)
-    else:
-        raise ValueError("backend must be 'hip' or 'numpy'")
+    distances, indices, first_hit = nearest_neighbors_hip(shape, text, labels, n_neighbors)
+    pr_at_k = compute_pr_at_k(indices, first_hit, labels, n_neighbors, num, fit_labels)
     pr_at_k["indices"] = indices
     if nearest_path is not None:
         tuples = embeddings_dict["caption_embedding_tuples"]
