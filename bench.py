@@ -205,8 +205,9 @@ def main():
         # serialise the streams for this leg: a kernel's HIP-event duration must not include the other towers' kernels
         # sharing the GPU with it (the timed region above keeps towers / weight gradients on parallel streams)
         net.overlap_towers = False
-        if getattr(net.image_encoder, "_side", None) is not None:
-            net.image_encoder._side.enabled = False
+        for side_name in ("_side", "_side_ds"):
+            if getattr(net.image_encoder, side_name, None) is not None:
+                getattr(net.image_encoder, side_name).enabled = False
         for i in range(nprof):
             # park the GPU on a spin kernel first so the host enqueues the whole step ahead of it: the HIP events then
             # bracket back-to-back kernel execution instead of host launch gaps (eager launches cost ~10 us each)

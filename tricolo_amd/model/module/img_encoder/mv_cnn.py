@@ -63,6 +63,7 @@ class MVCNNEncoder(TriModule):
         self.__dict__["_packers"] = {}
         self.__dict__["_packed"] = {}
         self.__dict__["_side"] = SideStream("img")
+        self.__dict__["_side_ds"] = SideStream("imgds")         # down-sample branch of layer2-4's first block
 
     def _prec(self):
         return self.precision or ops.default_precision()
@@ -143,11 +144,15 @@ class MVCNNEncoder(TriModule):
         x, parg = ops.maxpool2d_fwd(y, want_arg=save, bn=co)            # BN + ReLU + 3x3/2 max-pool: relu(bn(y)) is never stored
         saved = {"stem": (x0, y, co, g, parg), "blocks": [], "B": B, "N": N}
         for blk in self._blocks():
+            ds = blk.downsample is not None
+            if ds:                                                 # 1x1/2 conv + BN of the shortcut: independent of conv1 / conv2
+                with torch.cuda.stream(self._side_ds.fork(x)):
+                    yd, cod, gd = self._conv_bn(x, blk.downsample[0], blk.downsample[1], prec, train)
             y1, co1, g1 = self._conv_bn(x, blk.conv1, blk.bn1, prec, train)
             a1 = ops.bn_act(y1, co1, relu=True)
             y2, co2, g2 = self._conv_bn(a1, blk.conv2, blk.bn2, prec, train)
-            if blk.downsample is not None:
-                yd, cod, gd = self._conv_bn(x, blk.downsample[0], blk.downsample[1], prec, train)
+            if ds:
+                self._side_ds.join(yd, cod.scale, cod.shift)
                 out = ops.bn_act(y2, co2, relu=True, res=yd, res_co=cod)
             else:
                 yd = cod = gd = None
@@ -187,16 +192,19 @@ class MVCNNEncoder(TriModule):
             dy2, gr[blk.bn2.weight], gr[blk.bn2.bias] = ops.bn_bwd(y2, dout, co2, blk.bn2.weight, count_host=g2.M, inplace=False,
                                                                    relu_out=out, g_masked=dout)
             g = dout
+            if blk.downsample is not None:                         # shortcut branch next to the conv2 / conv1 chain
+                with torch.cuda.stream(self._side_ds.fork(g, yd)):
+                    dyd, gr[blk.downsample[1].weight], gr[blk.downsample[1].bias] = ops.bn_bwd(
+                        yd, g, cod, blk.downsample[1].weight, count_host=gd.M, inplace=False)
+                    gr[blk.downsample[0].weight] = ops.conv_wgrad(x, dyd, gd, blk.downsample[0].weight, prec)
+                    dx = ops.conv_dgrad(dyd, gd, self._packed[(id(blk.downsample[0]), True)])
             wgrad_async(a1, dy2, g2, blk.conv2.weight)
             da1 = ops.conv_dgrad(dy2, g2, self._packed[(id(blk.conv2), True)])
             # relu(bn1(y1)) backward: the ReLU mask is recomputed from y1 inside the BN passes (no relu_bwd pass over a1)
             dy1, gr[blk.bn1.weight], gr[blk.bn1.bias] = ops.bn_bwd(y1, da1, co1, blk.bn1.weight, count_host=g1.M, relu=True)
             wgrad_async(x, dy1, g1, blk.conv1.weight)
             if blk.downsample is not None:
-                dyd, gr[blk.downsample[1].weight], gr[blk.downsample[1].bias] = ops.bn_bwd(
-                    yd, g, cod, blk.downsample[1].weight, count_host=gd.M)
-                wgrad_async(x, dyd, gd, blk.downsample[0].weight)
-                dx = ops.conv_dgrad(dyd, gd, self._packed[(id(blk.downsample[0]), True)])
+                self._side_ds.join(dx, gr[blk.downsample[0].weight], gr[blk.downsample[1].weight], gr[blk.downsample[1].bias])
             else:
                 dx = g                                                         # identity branch
             dx = ops.conv_dgrad(dy1, g1, self._packed[(id(blk.conv1), True)], out=dx, accumulate=True)
