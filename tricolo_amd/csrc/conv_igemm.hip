@@ -598,14 +598,6 @@ __global__ __launch_bounds__(256) void conv_brick_kernel(const ConvArgs p) {
 // bank swizzle is applied on the SOURCE side: lane (row, slot) fetches chunk slot ^ ((row >> 1) & 7) and the
 // fragment reads apply the same XOR (cdna_hip_programming.md rule 21).  Invalid (row, tap) pairs use an out-of-range
 // buffer offset, for which the buffer unit returns - and writes to LDS - zeros.
-// 16 bytes per lane, global -> LDS at (wave-uniform dst) + lane * 16.  The LDS address space only exists in the device
-// pass, so the builtin is hidden from the host pass (which only needs the kernel's launch stub).
-__device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t rsrc, char* dst, int voff) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)dst, 16, voff, 0, 0, 0);
-#endif
-}
-
 __device__ __forceinline__ void wait_vmcnt(int n) {
     switch (n) {
 #define TRI_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
