@@ -14,6 +14,8 @@ view max are fused.  The whole tower (forward and backward) is one autograd node
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -180,8 +182,19 @@ class MVCNNEncoder(TriModule):
         blocks = self._blocks()
         side = self._side
 
+        # Weight gradients need only x and dy and could run beside the dgrad / BatchNorm-backward chain on a side stream
+        # (TRICOLO_WG_PATTERN=s; =sm alternates).  Measured with the round-1 kernels that is a LOSS: two GPU-filling kernels
+        # side by side thrash each other (all on the side stream 4.23 ms per step, alternating 4.09-4.15, all inline 3.93-3.97),
+        # so they are issued inline on the tower's stream.
+        pattern = os.environ.get("TRICOLO_WG_PATTERN", "m")
+        turn = [0]
+
         def wgrad_async(x, dy, g, w):
-            """dW on the side stream (needs only x and dy, both final at this point)."""
+            ch = pattern[turn[0] % len(pattern)]
+            turn[0] += 1
+            if ch == "m":
+                gr[w] = ops.conv_wgrad(x, dy, g, w, prec)
+                return
             with torch.cuda.stream(side.fork(x, dy)):
                 gr[w] = ops.conv_wgrad(x, dy, g, w, prec)
 
