@@ -25,7 +25,7 @@ import torch.distributed as dist
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "bf16x3": 2500.0}      # dense bf16 MFMA peak (MI355X_MICROARCH.md)
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "bf16x3": 2500.0, "f16": 2500.0}      # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 
 
 def build_net(args, device):
@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--precision", default=os.environ.get("TRICOLO_PRECISION", "bf16"), choices=["bf16", "bf16x3"])
+    ap.add_argument("--precision", default=os.environ.get("TRICOLO_PRECISION", "bf16"), choices=["bf16", "bf16x3", "f16"])
     ap.add_argument("--per-gpu-batch", type=int, default=32)
     ap.add_argument("--voxel-size", type=int, default=32)
     ap.add_argument("--num-views", type=int, default=6)

@@ -8,8 +8,9 @@
  * Conventions: plain pointers + sizes, all pointers are DEVICE pointers unless noted; `stream` is a hipStream_t
  * passed as void*; every call is asynchronous on that stream, allocates nothing, keeps no global state and returns
  * 0 on success, a hipError_t (>0) or a negative TRI_ERR_* code otherwise (text via tri_last_error()).  Activations
- * are channels-last [B, D, H, W, C] (2D tensors use D = 1), C a multiple of 4, stored fp32 (act_bf16 = 0: parity /
- * bf16x3 mode) or bf16 (act_bf16 = 1: plain bf16 mode, half the bytes of every pass); arithmetic is fp32 either way.
+ * are channels-last [B, D, H, W, C] (2D tensors use D = 1), C a multiple of 4, stored as `act_fmt` says:
+ * TRI_FMT_F32 (0: bf16x3 mode), TRI_FMT_BF16 (1: bf16 mode) or TRI_FMT_F16 (2: f16 mode; the 16-bit formats move half
+ * the bytes of every pass and ARE the MFMA operand type of the conv kernels); accumulation / statistics are fp32 always.
  */
 #ifndef TRICOLO_HIP_H
 #define TRICOLO_HIP_H
@@ -19,6 +20,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+#define TRI_FMT_F32 0
+#define TRI_FMT_BF16 1
+#define TRI_FMT_F16 2
 
 int tri_version(void);
 const char* tri_last_error(void);
@@ -32,8 +37,9 @@ typedef struct TriConvDesc {
 
 /* ---- weight packing -----------------------------------------------------------------------------------------
  * fp32 parameter in the reference's own layout (addressed by element strides) -> MFMA operand rows
- * dst[row][tap * inner_pad + i], bf16, zero padded to tri_conv_kpad(ntaps, inner_pad).  w_lo != NULL additionally
- * receives the residual x - bf16(x) (3-product split mode, fp32-grade accuracy).
+ * dst[row][tap * inner_pad + i], bf16 (fmt TRI_FMT_BF16 or 0) or f16 (fmt TRI_FMT_F16), zero padded to
+ * tri_conv_kpad(ntaps, inner_pad).  w_lo != NULL (bf16 only) additionally receives the residual x - bf16(x)
+ * (3-product split mode, fp32-grade accuracy).
  *   forward operand : rows = Cout, inner = Cin     dgrad operand : rows = Cin, inner = Cout (swap the strides)
  * Layouts: spconv SubMConv3d weight [Cout,kd,kh,kw,Cin] (sparse_cnn.py:12-32), torchvision conv [Cout,Cin,kh,kw]
  * (mv_cnn.py:44), nn.Linear [out,in]. */
@@ -42,13 +48,13 @@ int tri_conv_kpad(int ntaps, int cin_stored);
 typedef struct TriPrepDesc {
     const float* w;
     void* hi;
-    void* lo;            /* NULL in plain bf16 mode */
+    void* lo;            /* NULL in the single-operand modes (bf16, f16) */
     long s_row, s_tap, s_inner;
-    int rows, ntaps, inner, inner_pad, kpad, reserved;
+    int rows, ntaps, inner, inner_pad, kpad, fmt;
 } TriPrepDesc;
 int tri_weight_prep_multi(const TriPrepDesc* descs_dev, int n, void* stream);
 int tri_weight_prep(const float* w, long s_row, long s_tap, long s_inner, int rows, int ntaps, int inner, int inner_pad,
-                    void* w_hi, void* w_lo, void* stream);
+                    void* w_hi, void* w_lo, int fmt, void* stream);
 
 /* ---- token embedding (bigru.py:10,15) ------------------------------------------------------------------------------
  * fwd: emb[L,B,D] = W[tokens[B,L]] (already in the GRU's time-major order); bwd: dense dW[V,D], occurrences summed in
@@ -81,21 +87,21 @@ int tri_linear_small_wgrad(const float* x, const float* dout, const float* y, fl
  * stats (optional) receives [tri_conv_num_mtiles][2][Cout] per-tile column sums / sums of squares for BatchNorm.
  * tri_conv_dgrad / tri_conv_wgrad replace the autograd backward of the same call sites; `d` is always the FORWARD
  * descriptor.  wgrad writes dw through element strides, i.e. directly in the reference's parameter layout. */
-/* split3: 0 = bf16 operands / fp32 activations, 1 = bf16x3 (hi + lo operands), 2 = bf16 operands / bf16 activation storage */
+/* split3: 0 = bf16 operands / fp32 activations, 1 = bf16x3 (hi + lo operands), 2 = 16-bit operands and activation storage (bf16 or f16) */
 int tri_conv_num_mtiles(const TriConvDesc* d, int split3);
 /* kernel family tri_conv_fwd (transposed = 0) / tri_conv_dgrad (transposed = 1) dispatches for this layer and mode:
- * 0 conv_igemm_kernel (register-staged im2col), 1 conv_brick_kernel, 2 conv_dma_kernel (LDS-DMA staging),
- * 3 conv_halo_kernel (LDS-DMA input brick shared by all taps); bits 8.. hold the output-channel tile width.  For profilers. */
+ * 0 conv_igemm_kernel (register-staged im2col), 2 conv_dma_kernel (LDS-DMA staging); bits 8.. hold the output-channel
+ * tile width.  For profilers. */
 int tri_conv_kernel_family(const TriConvDesc* d, int transposed, int split3);
-/* same for tri_conv_wgrad: 0 conv_wgrad_kernel, 2 conv_wgrad_dma_kernel (taken when act_bf16 != 0 and the layer qualifies) */
-int tri_conv_wgrad_kernel_family(const TriConvDesc* d, int act_bf16);
+/* same for tri_conv_wgrad: 0 conv_wgrad_kernel, 2 conv_wgrad_dma_kernel (taken when act_fmt != 0 and the layer qualifies) */
+int tri_conv_wgrad_kernel_family(const TriConvDesc* d, int act_fmt);
 /* split-K scratch a small-M layer needs (0 = none): pass at least this many bytes to tri_conv_fwd / tri_conv_dgrad */
 size_t tri_conv_workspace(const TriConvDesc* d, int transposed);
 int tri_conv_fwd(const TriConvDesc* d, const void* in, const void* w_hi, const void* w_lo, void* out, const uint8_t* row_mask,
-                 const float* bias, int act, int accumulate, float* stats, int act_bf16, void* workspace, size_t workspace_bytes,
+                 const float* bias, int act, int accumulate, float* stats, int act_fmt, void* workspace, size_t workspace_bytes,
                  void* stream);
 int tri_conv_dgrad(const TriConvDesc* d, const void* dout, const void* wt_hi, const void* wt_lo, void* din, const uint8_t* row_mask,
-                   int accumulate, int act_bf16, void* workspace, size_t workspace_bytes,
+                   int accumulate, int act_fmt, void* workspace, size_t workspace_bytes,
                    const int* row_pos /* optional [B*ID*IH*IW]: a permutation of the input positions, the order in which the
                                          kernel's row tiles visit them.  For stride 2 pass the positions sorted by the parity of
                                          (coordinate + pad) per axis: a tile then only runs the 1-4 taps of 9 its rows can use
@@ -107,7 +113,7 @@ size_t tri_conv_plan_bytes(const TriConvDesc* d);
 int tri_conv_plan_build(const TriConvDesc* d, void* plan, void* stream);
 int tri_conv_wgrad(const TriConvDesc* d, const void* in, const void* dout, const uint8_t* row_mask, const void* plan /* required */,
                    void* workspace, size_t workspace_bytes, float* dw, long s_co, long s_tap, long s_ci, int cin_real, int split3,
-                   int act_bf16, void* stream);
+                   int act_fmt, float out_scale /* dw = out_scale * sum: undoes the f16 mode's gradient scaling */, void* stream);
 
 /* ---- BatchNorm (train-mode statistics, eps / momentum as torch.nn.BatchNorm1d/2d) ----------------------------------
  * Replaces nn.BatchNorm1d over active voxels (sparse_cnn.py:13,18,23,28,33; count from a device counter) and the 20
@@ -118,44 +124,45 @@ int tri_bn_finalize(const float* partial, int ntiles, int C, const int* count_de
 int tri_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps, float* mean,
                        float* invstd, float* scale, float* shift, void* stream);
 int tri_bn_act(const void* y, const float* scale, const float* shift, const void* res, const float* rscale, const float* rshift,
-               void* out, long M, int C, int relu, int act_bf16, void* stream);
-int tri_relu_bwd(const void* dout, const void* out, void* g, long n, int act_bf16, void* stream);
+               void* out, long M, int C, int relu, int act_fmt, void* stream);
+int tri_relu_bwd(const void* dout, const void* out, void* g, long n, int act_fmt, void* stream);
 int tri_bn_bwd_num_blocks(long M);
 /* relu_scale / relu_shift (optional): g is the gradient w.r.t. relu(bn(y)); the mask y*scale+shift > 0 is recomputed */
 /* relu_out (optional): g is the gradient w.r.t. relu(bn(y) + residual) and relu_out that ReLU's saved output (mask out > 0) */
 int tri_bn_bwd_reduce(const void* y, const void* g, long M, int C, float* partial, const float* relu_scale, const float* relu_shift,
-                      const void* relu_out, int act_bf16, void* stream);
+                      const void* relu_out, int act_fmt, void* stream);
 int tri_bn_bwd_finalize(const float* partial, int nblk, int C, const int* count_dev, int count_host, const float* gamma,
                         const float* mean, const float* invstd, float* dgamma, float* dbeta, float* c1, float* c2, float* c3,
+                        float out_scale /* dgamma, dbeta *= out_scale (g carries the f16 mode's gradient scale; dy keeps it) */,
                         void* stream);
 int tri_bn_bwd_apply(const void* y, const void* g, const float* c1, const float* c2, const float* c3, const uint8_t* row_mask,
                      void* dy, long M, int C, const float* relu_scale, const float* relu_shift, const void* relu_out,
-                     void* g_masked /* optional: receives g * (relu_out > 0), may alias g */, int act_bf16, void* stream);
+                     void* g_masked /* optional: receives g * (relu_out > 0), may alias g */, int act_fmt, void* stream);
 
 /* ---- pooling -------------------------------------------------------------------------------------------------
  * BN + ReLU + mask + spconv.SparseMaxPool3d(2,2) fused (sparse_cnn.py:13-15 ...), its backward routing;
  * nn.MaxPool2d(3,2,1) of the ResNet stem; AdaptiveAvgPool2d + torch.max over views (mv_cnn.py:29-31). */
 int tri_bn_relu_pool3d_fwd(const void* y, const float* scale, const float* shift, const uint8_t* mask, int B, int D, int C,
-                           void* pooled, uint8_t* mask_out, int act_bf16, void* stream);
+                           void* pooled, uint8_t* mask_out, int act_fmt, void* stream);
 int tri_pool3d_bwd_route(const void* y, const float* scale, const float* shift, const uint8_t* mask, const void* pooled,
-                         const void* dpooled, int B, int D, int C, void* g, int act_bf16, void* stream);
+                         const void* dpooled, int B, int D, int C, void* g, int act_fmt, void* stream);
 /* bn_scale / bn_shift (optional, [C]): pools relu(x * scale + shift), i.e. BatchNorm + ReLU + MaxPool2d of the ResNet stem in one pass */
 int tri_maxpool2d_fwd(const void* x, int N, int H, int W, int C, void* out, uint8_t* arg /* [N,Ho,Wo,C] winning tap, may be NULL */,
-                      const float* bn_scale, const float* bn_shift, int act_bf16, void* stream);
-int tri_maxpool2d_bwd(const uint8_t* arg, const void* dout, int N, int H, int W, int C, void* dx, int act_bf16, void* stream);
-int tri_avgpool_viewmax_fwd(const void* x, int B, int V, int HW, int C, float* out, int* arg, int act_bf16, void* stream);
-int tri_avgpool_viewmax_bwd(const float* dout, const int* arg, int B, int V, int HW, int C, void* dx, int act_bf16, void* stream);
+                      const float* bn_scale, const float* bn_shift, int act_fmt, void* stream);
+int tri_maxpool2d_bwd(const uint8_t* arg, const void* dout, int N, int H, int W, int C, void* dx, int act_fmt, void* stream);
+int tri_avgpool_viewmax_fwd(const void* x, int B, int V, int HW, int C, float* out, int* arg, int act_fmt, void* stream);
+int tri_avgpool_viewmax_bwd(const float* dout, const int* arg, int B, int V, int HW, int C, void* dx, int act_fmt, float scale, void* stream);
 
 /* ---- layout converters (batch layout of tricolo/data/data_module.py:40-65) ---------------------------------------- */
-int tri_voxel_scatter(const int* locs, const float* feats, int n, int B, int V, void* dense, uint8_t* mask, int act_bf16, void* stream);
+int tri_voxel_scatter(const int* locs, const float* feats, int n, int B, int V, void* dense, uint8_t* mask, int act_fmt, void* stream);
 /* the dataset's dense RGBA u8 grids [B,4,V,V,V] straight to the tower input (active <=> alpha != 0, feats =
  * RGB / 255; general_dataset.py:47-51,92-93) - no CPU COO build, no scatter.  mask must hold B*V^3 bytes (padded to 32). */
-int tri_voxel_from_rgba_u8(const uint8_t* rgba, int B, int V, void* dense, uint8_t* mask, int act_bf16, void* stream);
+int tri_voxel_from_rgba_u8(const uint8_t* rgba, int B, int V, void* dense, uint8_t* mask, int act_fmt, void* stream);
 int tri_mask_count(const uint8_t* mask, long n, int* count, void* stream);
-int tri_nchw3_to_nhwc4(const float* x, int N, int H, int W, void* out, int act_bf16, void* stream);
+int tri_nchw3_to_nhwc4(const float* x, int N, int H, int W, void* out, int act_fmt, void* stream);
 /* u8 images [N,3,H,W] -> channels-last [N,H,W,4], (u8/255 - mean[c]) / std[c] as ToTensor + Normalize of
  * general_dataset.py:87-89; mean3 / std3 are HOST pointers to three floats. */
-int tri_nchw3_u8_to_nhwc4(const uint8_t* x, int N, int H, int W, const float* mean3, const float* std3, void* out, int act_bf16, void* stream);
+int tri_nchw3_u8_to_nhwc4(const uint8_t* x, int N, int H, int W, const float* mean3, const float* std3, void* out, int act_fmt, void* stream);
 
 /* ---- row ops ------------------------------------------------------------------------------------------------------
  * F.normalize(dim=1) (sparse_cnn.py:51, mv_cnn.py:33, bigru.py:18), bias gradients, activation backward. */
@@ -164,6 +171,9 @@ int tri_l2norm_bwd(const float* z, const float* norm, const float* dz, int rows,
 int tri_colsum(const float* g, long M, int C, float* out, void* stream);
 int tri_axpy(const float* x, float a, float* y, long n, void* stream);
 int tri_act_bwd(const float* dout, const float* out, float* g, long n, int act, void* stream);
+/* dst (act_fmt storage) = scale * src (fp32), and back: the fp32 heads <-> 16-bit tower boundary of the voxel tower */
+int tri_cast_from_f32(const float* src, void* dst, long n, float scale, int act_fmt, void* stream);
+int tri_cast_to_f32(const void* src, float* dst, long n, int act_fmt, void* stream);
 
 /* ---- persistent bidirectional GRU recurrence (nn.GRU(256,128,bidirectional) of text_encoder/bigru.py:11,17) -----------
  * xproj [L][B][768] = x_t W_ih^T + b_ih for both directions (768 = dir*384 + gate*128 + unit, gate order r,z,n);
@@ -184,13 +194,16 @@ int tri_ntxent_fwd_bwd(const float* za, const float* zb, int B, int D, float tem
 
 /* ---- Adam (torch.optim.Adam as instantiated by config/config.yaml:50-53, tricolo_net.py:43-44) ------------------------ */
 int tri_adam_tick(int* step, void* stream);
-int tri_adam_step(float* p, const float* g, float* m, float* v, long n, const int* step, float lr, float b1, float b2, float eps,
-                  float wd, float gscale, void* stream);
-/* the same update with the gradients read in place: grad_ptrs = DEVICE array of nseg device pointers (NULL = no gradient: treated
- * as zeros), grad_starts = DEVICE array of the flat start offset of each segment (ascending, first 0); segment sizes and n are
+/* lr_dev (optional, DEVICE float): when not NULL the learning rate is read from it at run time, so a captured HIP graph
+ * follows a schedule (LrDecayCallback of train.py) without re-capture; `lr` is used otherwise.  Bias corrections in double. */
+int tri_adam_step(float* p, const float* g, float* m, float* v, long n, const int* step, float lr, const float* lr_dev, float b1, float b2,
+                  float eps, float wd, float gscale, void* stream);
+/* the same update with the gradients read in place: grad_ptrs = DEVICE array of nseg device pointers (NULL = no gradient: the
+ * segment is SKIPPED like torch.optim.Adam skips parameters whose .grad is None), grad_starts = DEVICE array of the flat start offset of each segment (ascending, first 0); segment sizes and n are
  * multiples of 4, gradient tensors 16-byte aligned.  Saves the flat-gradient concatenation pass of the single-GPU step. */
 int tri_adam_step_segments(float* p, const void* grad_ptrs, const long* grad_starts, int nseg, float* m, float* v, long n,
-                           const int* step, float lr, float b1, float b2, float eps, float wd, float gscale, void* stream);
+                           const int* step, float lr, const float* lr_dev, float b1, float b2, float eps, float wd, float gscale,
+                           void* stream);
 
 #ifdef __cplusplus
 }

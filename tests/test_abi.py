@@ -33,7 +33,7 @@ def test_header_symbols_are_exported_and_bound():
 def test_host_helpers_without_gpu():
     from tricolo_amd import _C, ops
     g = ops.ConvGeom(2, (32, 32, 32), 3, 4, 32, (3, 3, 3), 1, (1, 1, 1), (81, 3, 1))
-    assert g.out_grid == (32, 32, 32) and g.kpad == 128 and g.M == 65536 and g.num_mtiles["bf16"] == 512
+    assert g.out_grid == (32, 32, 32) and g.kpad == 128 and g.M == 65536 and g.num_mtiles[0] == 512
     g2 = ops.ConvGeom(12, (1, 128, 128), 3, 4, 64, (1, 7, 7), 2, (0, 3, 3), (147, 1, 49))
     assert g2.out_grid == (1, 64, 64) and g2.flops == 2 * 12 * 64 * 64 * 49 * 3 * 64
     assert g2.wgrad_ws > 0

@@ -38,8 +38,26 @@ def _sha(*ts):
     return h.hexdigest()
 
 
-def _check_grads(module, g, prefix, rtol=GRAD_RTOL):
-    bad = []
+import json
+import os
+
+_REPORT = {}
+
+
+def _report(key, value):
+    """Measured deviations are collected in gpurun_out/parity_report.json (copied to profiles/ for the record)."""
+    _REPORT[key] = value
+    try:
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open("gpurun_out/parity_report.json", "w") as f:
+            json.dump(_REPORT, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+def _check_grads(module, g, prefix, rtol=GRAD_RTOL, sample_mult=5.0, tag=None):
+    """Gradient norms within rtol and the 16 sampled entries of every parameter gradient within sample_mult * rtol * rms."""
+    bad, worst_n, worst_s = [], 0.0, 0.0
     for name, p in module.named_parameters():
         key = f"{prefix}gradnorm/{name}"
         if key not in g:
@@ -48,8 +66,13 @@ def _check_grads(module, g, prefix, rtol=GRAD_RTOL):
         n, s = probe(p.grad.cpu())
         ref_n, ref_s = float(g[key]), g[f"{prefix}gradsample/{name}"]
         scale = max(ref_n / np.sqrt(p.numel()), 1e-8)
-        if abs(n - ref_n) > rtol * max(ref_n, 1e-6) or np.abs(s - ref_s).max() > 50 * rtol * scale + 1e-7:
-            bad.append((name, n, ref_n, float(np.abs(s - ref_s).max())))
+        dn, ds = abs(n - ref_n) / max(ref_n, 1e-6), float(np.abs(s - ref_s).max()) / scale
+        worst_n, worst_s = max(worst_n, dn), max(worst_s, ds)
+        if dn > rtol or ds > sample_mult * rtol + 1e-7 / scale:
+            bad.append((name, n, ref_n, dn, ds))
+    if tag:
+        _report(f"grads/{tag}", {"worst_rel_norm_diff": worst_n, "worst_sample_diff_over_rms": worst_s, "rtol": rtol,
+                                 "sample_bound_over_rms": sample_mult * rtol})
     assert not bad, bad
 
 
@@ -69,7 +92,7 @@ def test_bigru_matches_reference(golden):
     z = m(batch["tokens"].to(DEV), batch)
     np.testing.assert_allclose(z.detach().cpu().numpy(), g["z"], atol=EMB_TOL)
     (z * torch.from_numpy(g["upstream"]).to(DEV)).sum().backward()
-    _check_grads(m, g, "")
+    _check_grads(m, g, "", tag="bigru")
     zp = m(torch.zeros((2, 96), dtype=torch.int32, device=DEV), {})
     np.testing.assert_allclose(zp.detach().cpu().numpy(), g["z_allpad"], atol=EMB_TOL)
 
@@ -97,7 +120,7 @@ def test_voxel_encoder_matches_reference(golden, tag, V, B, seed):
     z = m(batch["voxels"], B)
     np.testing.assert_allclose(z.detach().cpu().numpy(), g[f"{tag}/z"], atol=EMB_TOL)
     (z * torch.from_numpy(g[f"{tag}/upstream"]).to(DEV)).sum().backward()
-    _check_grads(m, g, f"{tag}/")
+    _check_grads(m, g, f"{tag}/", tag=f"voxel_{tag}")
     # running statistics after one train-mode forward
     for name, v in m.state_dict().items():
         if "running" in name:
@@ -139,7 +162,7 @@ def test_mvcnn_encoder_matches_reference(golden, tag, B, nv, S):
     z = m(batch["images"].flatten(end_dim=1).to(DEV), batch)
     np.testing.assert_allclose(z.detach().cpu().numpy(), g[f"{tag}/z"], atol=EMB_TOL)
     (z * torch.from_numpy(g[f"{tag}/upstream"]).to(DEV)).sum().backward()
-    _check_grads(m, g, f"{tag}/", rtol=2e-2)
+    _check_grads(m, g, f"{tag}/", rtol=2e-2, tag=f"mvcnn_{tag}")
     for name, v in m.state_dict().items():
         if "running" in name:
             n, s = probe(v.cpu())
@@ -206,9 +229,10 @@ def test_training_steps_match_reference(golden, case):
         if step == 0:
             for k, v in emb.items():
                 np.testing.assert_allclose(v.grad.cpu().numpy(), g[f"demb/{k}"], atol=2e-5, err_msg=k)
-            _check_grads(net, g, "", rtol=2e-2)
+            _check_grads(net, g, "", rtol=2e-2, tag=f"step_{tag}")
         opt.step()
     print(tag, report)
+    _report(f"trajectory/{tag}", {str(k): {"hip": v[0], "reference": v[1], "abs_diff": abs(v[0] - v[1])} for k, v in report.items()})
     # after Adam updates (sign-like first steps amplify tiny gradient differences) the bound is looser and stated:
     for step in (1, 2, 3):
         assert abs(report[step][0] - report[step][1]) < 2e-2, report
@@ -327,6 +351,130 @@ def test_plain_bf16_mode_stated_tolerance(golden):
     edif = {k: float(np.abs(v.detach().cpu().numpy() - g[f"emb/{k}"]).max()) for k, v in emb.items()}
     print("bf16 mode loss diffs", diffs, "embedding max diffs", edif)
     assert max(diffs.values()) < 1e-2 and max(edif.values()) < 5e-3
+
+
+@pytest.mark.parametrize("case", STEP_CASES, ids=[c[0] for c in STEP_CASES])
+def test_f16_mode_meets_the_1e3_parity_bound(golden, case):
+    """The f16 mode (f16 activation storage + f16 MFMA operands, fp32 accumulation, bf16x3 heads / GRU) against the golden
+    vectors of the REAL fp32 reference: step-0 pair losses, total loss and unit-norm embeddings within 1e-3 - the north-star
+    bound - on every BASELINE config that has a fixture.  This is the mode bench.py quotes as `value`."""
+    tag, text, image, voxel, V, nv, S, B, seed_off, clip_text = case
+    g = golden(f"step_{tag}")
+    ops.set_default_precision("f16")
+    net, cfg = _build_net(text, image, voxel, V, nv or 6, S)
+    batch = syn.batch_to_device(syn.make_batch(B, voxel_size=V if voxel else None, num_views=nv if image else None, image_size=S,
+                                               clip_text=clip_text, seed=syn.BASE_SEED + seed_off), DEV)
+    opt = net.configure_optimizers()
+    emb = net(batch)
+    for k in emb:
+        emb[k].retain_grad()
+    losses = net._calculate_losses(emb, "train_loss")
+    diffs = {k: abs(v.item() - float(g[f"step0/{k}"])) for k, v in losses.items()}
+    edif = {k: float(np.abs(v.detach().cpu().numpy() - g[f"emb/{k}"]).max()) for k, v in emb.items()}
+    losses["train_loss/total_loss"].backward()
+    gdif = {k: float(np.abs(v.grad.cpu().numpy() - g[f"demb/{k}"]).max()) for k, v in emb.items()}
+    for p in net.parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all()
+    opt.step()
+    after = net._calculate_losses(net(batch), "train_loss")["train_loss/total_loss"].item()
+    _report(f"f16/{tag}", {"loss_abs_diff": diffs, "embedding_max_abs_diff": edif, "dloss_dembedding_max_abs_diff": gdif,
+                           "loss_after_1_step": after, "reference_after_1_step": float(g["step1/total_loss"])})
+    assert max(diffs.values()) < 1e-3, diffs
+    assert max(edif.values()) < 1e-3, edif
+    assert max(gdif.values()) < 1e-3, gdif
+    assert abs(after - float(g["step1/total_loss"])) < 2e-2
+
+
+@pytest.mark.parametrize("prec,gbound", [("bf16", 6e-2), ("f16", 2e-2)])
+def test_16bit_modes_backward_on_bi_v(golden, prec, gbound):
+    """BASELINE config 2 names bf16 on Bi(V): backward of the 16-bit storage paths at module level against the fp32 reference's
+    gradients (voxel tower + BiGRU; no ReLU/max routing chaos of the ResNet here) with a stated bound on the gradient norms."""
+    g = golden("step_cfg1_biV")
+    ops.set_default_precision(prec)
+    net, cfg = _build_net("BiGRUEncoder", None, "SparseCNNEncoder", 32, 6, 128)
+    batch = syn.batch_to_device(syn.make_batch(8, voxel_size=32, num_views=None, seed=syn.BASE_SEED + 1), DEV)
+    emb = net(batch)
+    losses = net._calculate_losses(emb, "train_loss")
+    losses["train_loss/total_loss"].backward()
+    _check_grads(net, g, "", rtol=gbound, sample_mult=5.0, tag=f"biV_{prec}")
+    ldiff = abs(losses["train_loss/total_loss"].item() - float(g["step0/train_loss/total_loss"]))
+    _report(f"biV_{prec}/loss_abs_diff", ldiff)
+    assert ldiff < (1e-3 if prec == "f16" else 1e-2)
+
+
+def test_fused_adam_state_dict_round_trip_and_device_lr():
+    """optimizer state must survive save -> load (Lightning `optimizer_states`), in torch.optim.Adam's own format,
+    and a learning-rate change must reach a step that is replayed from a HIP graph."""
+    from tricolo_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    ws = [torch.randn(64, 32), torch.randn(128), torch.randn(16, 8, 4)]
+    grads = [[torch.randn_like(w) for w in ws] for _ in range(6)]
+
+    def make(cls):
+        ps = [torch.nn.Parameter(w.clone().to(DEV)) for w in ws]
+        return ps, cls(ps, lr=3.5e-4, weight_decay=1e-6)
+
+    def run(ps, opt, steps):
+        for gs in steps:
+            for p, gr in zip(ps, gs):
+                p.grad = gr.clone().to(DEV)
+            opt.step()
+
+    pt, ot = make(torch.optim.Adam)
+    pf, of = make(FusedAdam)
+    run(pt, ot, grads[:3]); run(pf, of, grads[:3])
+    sd = of.state_dict()
+    assert all(set(st) == {"step", "exp_avg", "exp_avg_sq"} for st in sd["state"].values())
+    assert all(float(st["step"]) == 3.0 for st in sd["state"].values())
+    # FusedAdam -> torch.optim.Adam and back, then three more steps with a decayed learning rate
+    p2, o2 = make(torch.optim.Adam)
+    p3, o3 = make(FusedAdam)
+    with torch.no_grad():
+        for a, b, c in zip(p2, p3, pf):
+            a.copy_(c); b.copy_(c)
+    o2.load_state_dict(sd)
+    o3.load_state_dict(ot.state_dict())
+    for o in (ot, o2, o3, of):
+        o.param_groups[0]["lr"] = 1e-4
+    run(pt, ot, grads[3:]); run(p2, o2, grads[3:]); run(p3, o3, grads[3:]); run(pf, of, grads[3:])
+    for a, b, c, d in zip(pt, p2, p3, pf):
+        np.testing.assert_allclose(b.detach().cpu().numpy(), a.detach().cpu().numpy(), atol=3e-7)
+        np.testing.assert_allclose(c.detach().cpu().numpy(), a.detach().cpu().numpy(), atol=3e-7)
+        np.testing.assert_allclose(d.detach().cpu().numpy(), a.detach().cpu().numpy(), atol=3e-7)
+    # parameters without a gradient are skipped like torch does (no weight decay, no moment decay)
+    pa, oa = make(torch.optim.Adam)
+    pb, ob = make(FusedAdam)
+    for ps, o in ((pa, oa), (pb, ob)):
+        for p, gr in zip(ps, grads[0]):
+            p.grad = gr.clone().to(DEV)
+        ps[1].grad = None
+        o.step()
+    for a, b in zip(pa, pb):
+        np.testing.assert_allclose(b.detach().cpu().numpy(), a.detach().cpu().numpy(), atol=3e-7)
+    # graph replay follows the device-side learning rate
+    pg, og = make(FusedAdam)
+    og.prepare()
+    for p, gr in zip(pg, grads[0]):
+        p.grad = gr.clone().to(DEV)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        og.step()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        og.step()
+    pr, orf = make(torch.optim.Adam)
+    for p, gr in zip(pr, grads[0]):
+        p.grad = gr.clone().to(DEV)
+    orf.step(); orf.step()
+    og.param_groups[0]["lr"] = orf.param_groups[0]["lr"] = 7e-5
+    og.sync_lr()
+    graph.replay()
+    orf.step()
+    for a, b in zip(pr, pg):
+        np.testing.assert_allclose(b.detach().cpu().numpy(), a.detach().cpu().numpy(), atol=3e-7)
 
 
 def test_cpu_input_fails_loudly():

@@ -88,7 +88,7 @@ def test_conv_fwd_float_split_precision(case):
     assert (out1 - ref).abs().max().item() < 3e-2 * scale          # plain bf16 operands
 
 
-@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3", "f16"])
 def test_batched_weight_packing_equals_per_layer_packing(precision):
     """tri_weight_prep_multi (LDS-transposed fast paths per parameter layout) against the element-wise tri_weight_prep for
     every layer shape of the towers, forward and data-gradient operands."""
@@ -168,6 +168,61 @@ def test_conv_wgrad_integer_exact(case, precision):
     dw = ops.conv_wgrad(xcl.to(DEV), cl3(dy).to(DEV), g, wp.to(DEV), precision).cpu()
     assert dw.shape == ref.shape
     assert torch.equal(dw, ref), f"max abs diff {(dw - ref).abs().max().item()}"
+
+
+# Real-valued data: the lo terms of the 3-product split (a_lo*b_hi + a_hi*b_lo) only matter here - integer data has lo == 0.
+# Reference in float64; bound 2e-5 * scale for bf16x3 (operand error ~2^-17), 3e-2 * scale for single bf16 operands.
+@pytest.mark.parametrize("case", DGRAD_CASES, ids=[c[0] for c in DGRAD_CASES])
+def test_conv_dgrad_float_split_precision(case):
+    x, w, wp, xcl, g = make_case(case, integer=False, seed=71)
+    xr = x.double().requires_grad_()
+    y = F.conv3d(xr, w.double(), stride=case[6], padding=case[7])
+    dy = torch.randn(tuple(y.shape), generator=torch.Generator().manual_seed(73))
+    y.backward(dy.double())
+    ref = cl3(xr.grad)
+    scale = ref.abs().max().item()
+    dx3 = ops.conv_dgrad(cl3(dy).to(DEV), g, ops.pack_weight(wp.to(DEV), g, "bf16x3", transposed=True)).cpu().double()
+    dx1 = ops.conv_dgrad(cl3(dy).to(DEV), g, ops.pack_weight(wp.to(DEV), g, "bf16", transposed=True)).cpu().double()
+    assert (dx3 - ref).abs().max().item() < 2e-5 * scale
+    assert (dx1 - ref).abs().max().item() < 3e-2 * scale
+    assert (dx1 - ref).abs().max().item() > 1e-4 * scale          # the single-operand path really is the coarser one
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_wgrad_float_split_precision(case):
+    x, w, wp, xcl, g = make_case(case, integer=False, seed=79)
+    wr = w.double().requires_grad_()
+    y = F.conv3d(x.double(), wr, stride=case[6], padding=case[7])
+    dy = torch.randn(tuple(y.shape), generator=torch.Generator().manual_seed(83))
+    y.backward(dy.double())
+    ref = wr.grad.permute(0, 2, 3, 4, 1).contiguous() if case[8] == "spconv" else wr.grad
+    scale = ref.abs().max().item()
+    dw3 = ops.conv_wgrad(xcl.to(DEV), cl3(dy).to(DEV), g, wp.to(DEV), "bf16x3").cpu().double()
+    dw1 = ops.conv_wgrad(xcl.to(DEV), cl3(dy).to(DEV), g, wp.to(DEV), "bf16").cpu().double()
+    assert (dw3 - ref).abs().max().item() < 2e-5 * scale
+    assert (dw1 - ref).abs().max().item() < 3e-2 * scale
+    assert (dw1 - ref).abs().max().item() > 1e-5 * scale
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_f16_storage_float_precision(case):
+    """f16 mode: operands and results rounded to f16 (11 significand bits) - 8x tighter than bf16 storage; fwd / dgrad / wgrad."""
+    x, w, wp, xcl, g = make_case(case, integer=False, seed=89)
+    xr, wr = x.double().requires_grad_(), w.double().requires_grad_()
+    y = F.conv3d(xr, wr, stride=case[6], padding=case[7])
+    dy = torch.randn(tuple(y.shape), generator=torch.Generator().manual_seed(97))
+    y.backward(dy.double())
+    h = torch.float16
+    out = ops.conv_fwd(xcl.to(DEV).to(h), g, ops.pack_weight(wp.to(DEV), g, "f16")).cpu().double()
+    ref = cl3(y.detach())
+    assert (out - ref).abs().max().item() < 2e-3 * ref.abs().max().item()
+    refw = wr.grad.permute(0, 2, 3, 4, 1).contiguous() if case[8] == "spconv" else wr.grad
+    dw = ops.conv_wgrad(xcl.to(DEV).to(h), cl3(dy).to(DEV).to(h), g, wp.to(DEV), "f16", out_scale=0.5).cpu().double()
+    assert (2.0 * dw - refw).abs().max().item() < 2e-3 * refw.abs().max().item()
+    if case[3] != 3:
+        dx = ops.conv_dgrad(cl3(dy).to(DEV).to(h), g, ops.pack_weight(wp.to(DEV), g, "f16", transposed=True)).cpu().double()
+        refx = cl3(xr.grad)
+        assert (dx - refx).abs().max().item() < 2e-3 * refx.abs().max().item()
 
 
 def test_conv_wgrad_masked_steps_skipped():
@@ -539,7 +594,9 @@ def test_gru_recurrence_matches_explicit_equations(precision, tol, B, L):
         np.testing.assert_allclose(dgh[d].cpu().double().sum(0).numpy(), br.grad[d].double().numpy(), atol=tol * 50)
 
 
-# ------------------------------------------------------------------------------------------- bf16 activation storage
+# ------------------------------------------------------------------------------------------- 16-bit activation storage
+STORE16 = [(torch.bfloat16, "bf16"), (torch.float16, "f16")]
+STORE16_IDS = ["bf16", "f16"]
 BF16_CASES = [c for c in CONV_CASES if c[0] in ("vox_l0", "vox_l1", "vox_l3", "stem7x7", "c3x3s1", "c3x3s2", "c1x1s2", "odd14", "linear", "clip768")] + [
     # Cin % 64 == 0 layers run the LDS-DMA kernel in this mode; these two fill the GPU (no split-K) / use Cout % 128 != 0
     ("big_nosplit", 12, (1, 64, 64), 64, 64, (1, 3, 3), 1, (0, 1, 1), "torch"),
@@ -548,14 +605,15 @@ BF16_CASES = [c for c in CONV_CASES if c[0] in ("vox_l0", "vox_l1", "vox_l3", "s
 
 
 @pytest.mark.parametrize("case", BF16_CASES, ids=[c[0] for c in BF16_CASES])
-def test_conv_bf16_storage_integer_exact(case):
-    """bf16 mode stores activations as bf16: operands are exact, the fp32 accumulator is rounded once on store."""
+@pytest.mark.parametrize("store,prec", STORE16, ids=STORE16_IDS)
+def test_conv_16bit_storage_integer_exact(case, store, prec):
+    """The bf16 / f16 modes store activations in 16 bits: operands are exact, the fp32 accumulator is rounded once on store."""
     x, w, wp, xcl, g = make_case(case, integer=True, seed=51)
     ref = cl3(F.conv3d(x, w, stride=case[6], padding=case[7]))
-    packed = ops.pack_weight(wp.to(DEV), g, "bf16")
-    out = ops.conv_fwd(xcl.to(DEV).to(torch.bfloat16), g, packed)
-    assert out.dtype == torch.bfloat16
-    assert torch.equal(out.cpu(), ref.to(torch.bfloat16))
+    packed = ops.pack_weight(wp.to(DEV), g, prec)
+    out = ops.conv_fwd(xcl.to(DEV).to(store), g, packed)
+    assert out.dtype == store
+    assert torch.equal(out.cpu(), ref.to(store))
     # wgrad (fp32 result, exact) and dgrad (bf16 result, rounded once)
     wr = w.clone().requires_grad_()
     xr = x.clone().requires_grad_()
@@ -563,14 +621,15 @@ def test_conv_bf16_storage_integer_exact(case):
     dy = ints(tuple(y.shape), -2, 2, 53)
     y.backward(dy)
     refw = wr.grad.permute(0, 2, 3, 4, 1).contiguous() if case[8] == "spconv" else wr.grad
-    dw = ops.conv_wgrad(xcl.to(DEV).to(torch.bfloat16), cl3(dy).to(DEV).to(torch.bfloat16), g, wp.to(DEV), "bf16")
+    dw = ops.conv_wgrad(xcl.to(DEV).to(store), cl3(dy).to(DEV).to(store), g, wp.to(DEV), prec)
     assert torch.equal(dw.cpu(), refw)
     if case[3] != 3:
-        dx = ops.conv_dgrad(cl3(dy).to(DEV).to(torch.bfloat16), g, ops.pack_weight(wp.to(DEV), g, "bf16", transposed=True))
-        assert torch.equal(dx.cpu(), cl3(xr.grad).to(torch.bfloat16))
+        dx = ops.conv_dgrad(cl3(dy).to(DEV).to(store), g, ops.pack_weight(wp.to(DEV), g, prec, transposed=True))
+        assert torch.equal(dx.cpu(), cl3(xr.grad).to(store))
 
 
-def test_conv_bf16_storage_masked_stats():
+@pytest.mark.parametrize("store,prec", STORE16, ids=STORE16_IDS)
+def test_conv_16bit_storage_masked_stats(store, prec):
     """Submanifold rule + BatchNorm partial sums through the LDS-DMA kernel (Cin = 64) and its split-K finish."""
     case = ("vox_m", 2, (8, 8, 8), 64, 128, (3, 3, 3), 1, (1, 1, 1), "spconv")
     x, w, wp, xcl, g = make_case(case, integer=True, seed=61)
@@ -579,9 +638,9 @@ def test_conv_bf16_storage_masked_stats():
     mask = (torch.rand(M, generator=gen) < 0.3).to(torch.uint8)
     mask[:256] = 0                                                  # two fully inactive 128-row tiles
     full = cl3(F.conv3d(x, w, padding=1)).reshape(M, -1)
-    ref = (full * mask[:, None].float()).to(torch.bfloat16)
-    packed = ops.pack_weight(wp.to(DEV), g, "bf16")
-    out, stats = ops.conv_fwd(xcl.to(DEV).to(torch.bfloat16), g, packed, row_mask=mask.to(DEV), want_stats=True)
+    ref = (full * mask[:, None].float()).to(store)
+    packed = ops.pack_weight(wp.to(DEV), g, prec)
+    out, stats = ops.conv_fwd(xcl.to(DEV).to(store), g, packed, row_mask=mask.to(DEV), want_stats=True)
     assert torch.equal(out.cpu().reshape(M, -1), ref)
     st = stats.cpu().double().sum(0)
     exact = ref.double()                                            # statistics of what BatchNorm reads back (the stored bf16)
@@ -591,19 +650,19 @@ def test_conv_bf16_storage_masked_stats():
     xr = x.clone().requires_grad_()
     wr = w.clone().requires_grad_()
     F.conv3d(xr, wr, padding=1).backward(cf3(dy.view(2, 8, 8, 8, 128)))
-    dw = ops.conv_wgrad(xcl.to(DEV).to(torch.bfloat16), dy.view(2, 8, 8, 8, 128).to(DEV).to(torch.bfloat16), g, wp.to(DEV), "bf16",
+    dw = ops.conv_wgrad(xcl.to(DEV).to(store), dy.view(2, 8, 8, 8, 128).to(DEV).to(store), g, wp.to(DEV), prec,
                         row_mask=mask.to(DEV))                      # 64-position steps without an active site are skipped
     assert torch.equal(dw.cpu(), wr.grad.permute(0, 2, 3, 4, 1).contiguous())
-    dx = ops.conv_dgrad(dy.view(2, 8, 8, 8, 128).to(DEV).to(torch.bfloat16), g, ops.pack_weight(wp.to(DEV), g, "bf16", transposed=True),
+    dx = ops.conv_dgrad(dy.view(2, 8, 8, 8, 128).to(DEV).to(store), g, ops.pack_weight(wp.to(DEV), g, prec, transposed=True),
                         row_mask=mask.to(DEV))
-    assert torch.equal(dx.cpu().reshape(M, -1), (cl3(xr.grad).reshape(M, -1) * mask[:, None].float()).to(torch.bfloat16))
+    assert torch.equal(dx.cpu().reshape(M, -1), (cl3(xr.grad).reshape(M, -1) * mask[:, None].float()).to(store))
 
 
-def test_elementwise_kernels_bf16_storage():
+@pytest.mark.parametrize("bf", [torch.bfloat16, torch.float16], ids=STORE16_IDS)
+def test_elementwise_kernels_16bit_storage(bf):
     g = torch.Generator().manual_seed(61)
     N, H, W, C = 4, 8, 8, 64
     M = N * H * W
-    bf = torch.bfloat16
     y = (torch.randn(M, C, generator=g) * 2).to(bf)
     res = torch.randn(M, C, generator=g).to(bf)
     gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1

@@ -22,7 +22,7 @@ class TriConvDesc(C.Structure):
 class TriPrepDesc(C.Structure):
     _fields_ = [("w", C.c_void_p), ("hi", C.c_void_p), ("lo", C.c_void_p), ("s_row", C.c_long), ("s_tap", C.c_long),
                 ("s_inner", C.c_long), ("rows", C.c_int), ("ntaps", C.c_int), ("inner", C.c_int), ("inner_pad", C.c_int),
-                ("kpad", C.c_int), ("reserved", C.c_int)]
+                ("kpad", C.c_int), ("fmt", C.c_int)]
 
 
 P, I, L, F, Z = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
@@ -33,7 +33,7 @@ SIGNATURES = {
     "tri_version": (I, []),
     "tri_last_error": (C.c_char_p, []),
     "tri_conv_kpad": (I, [I, I]),
-    "tri_weight_prep": (I, [P, L, L, L, I, I, I, I, P, P, P]),
+    "tri_weight_prep": (I, [P, L, L, L, I, I, I, I, P, P, I, P]),
     "tri_weight_prep_multi": (I, [P, I, P]),
     "tri_embedding_fwd": (I, [P, P, I, I, I, P, P]),
     "tri_embedding_bwd": (I, [P, P, I, I, I, I, I, P, P]),
@@ -51,21 +51,21 @@ SIGNATURES = {
     "tri_conv_wgrad_workspace": (Z, [DP]),
     "tri_conv_plan_bytes": (Z, [DP]),
     "tri_conv_plan_build": (I, [DP, P, P]),
-    "tri_conv_wgrad": (I, [DP, P, P, P, P, P, Z, P, L, L, L, I, I, I, P]),
+    "tri_conv_wgrad": (I, [DP, P, P, P, P, P, Z, P, L, L, L, I, I, I, F, P]),
     "tri_bn_finalize": (I, [P, I, I, P, I, P, P, P, P, P, F, F, P, P, P, P, P]),
     "tri_bn_eval_coeffs": (I, [I, P, P, P, P, F, P, P, P, P, P]),
     "tri_bn_act": (I, [P, P, P, P, P, P, P, L, I, I, I, P]),
     "tri_relu_bwd": (I, [P, P, P, L, I, P]),
     "tri_bn_bwd_num_blocks": (I, [L]),
     "tri_bn_bwd_reduce": (I, [P, P, L, I, P, P, P, P, I, P]),
-    "tri_bn_bwd_finalize": (I, [P, I, I, P, I, P, P, P, P, P, P, P, P, P]),
+    "tri_bn_bwd_finalize": (I, [P, I, I, P, I, P, P, P, P, P, P, P, P, F, P]),
     "tri_bn_bwd_apply": (I, [P, P, P, P, P, P, P, L, I, P, P, P, P, I, P]),
     "tri_bn_relu_pool3d_fwd": (I, [P, P, P, P, I, I, I, P, P, I, P]),
     "tri_pool3d_bwd_route": (I, [P, P, P, P, P, P, I, I, I, P, I, P]),
     "tri_maxpool2d_fwd": (I, [P, I, I, I, I, P, P, P, P, I, P]),
     "tri_maxpool2d_bwd": (I, [P, P, I, I, I, I, P, I, P]),
     "tri_avgpool_viewmax_fwd": (I, [P, I, I, I, I, P, P, I, P]),
-    "tri_avgpool_viewmax_bwd": (I, [P, P, I, I, I, I, P, I, P]),
+    "tri_avgpool_viewmax_bwd": (I, [P, P, I, I, I, I, P, I, F, P]),
     "tri_voxel_scatter": (I, [P, P, I, I, I, P, P, I, P]),
     "tri_voxel_from_rgba_u8": (I, [P, I, I, P, P, I, P]),
     "tri_nchw3_u8_to_nhwc4": (I, [P, I, I, I, P, P, P, I, P]),
@@ -76,13 +76,15 @@ SIGNATURES = {
     "tri_colsum": (I, [P, L, I, P, P]),
     "tri_axpy": (I, [P, F, P, L, P]),
     "tri_act_bwd": (I, [P, P, P, L, I, P]),
+    "tri_cast_from_f32": (I, [P, P, L, F, I, P]),
+    "tri_cast_to_f32": (I, [P, P, L, I, P]),
     "tri_gru_fwd": (I, [P, P, P, I, I, P, P, P, I, P]),
     "tri_gru_bwd": (I, [P, P, P, P, I, I, P, P, P, P, I, P]),
     "tri_ntxent_workspace": (Z, [I, I]),
     "tri_ntxent_fwd_bwd": (I, [P, P, I, I, F, F, I, P, P, P, P, Z, P]),
     "tri_adam_tick": (I, [P, P]),
-    "tri_adam_step": (I, [P, P, P, P, L, P, F, F, F, F, F, F, P]),
-    "tri_adam_step_segments": (I, [P, P, P, I, P, P, L, P, F, F, F, F, F, F, P]),
+    "tri_adam_step": (I, [P, P, P, P, L, P, F, P, F, F, F, F, F, P]),
+    "tri_adam_step_segments": (I, [P, P, P, I, P, P, L, P, F, P, F, F, F, F, F, P]),
 }
 
 _lib = None

@@ -112,20 +112,15 @@ __global__ void bn_act_kernel(const T* __restrict__ y, const float4* __restrict_
         Act<T>::st4(out + i * 4, v);
     }
 }
-#define TRI_ACT_DISPATCH(flag, ...)                  \
-    do {                                             \
-        if (flag) { using T = bf16_t; __VA_ARGS__; } \
-        else { using T = float; __VA_ARGS__; }       \
-    } while (0)
 static inline int ew_grid(long total) {
     long b = (total + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
 }
 extern "C" int tri_bn_act(const void* y, const float* scale, const float* shift, const void* res, const float* rscale,
-                          const float* rshift, void* out, long M, int C, int relu, int act_bf16, void* stream) {
+                          const float* rshift, void* out, long M, int C, int relu, int act_fmt, void* stream) {
     if (C % 4) { tri_set_error("tri_bn_act: C must be a multiple of 4"); return TRI_ERR_ARG; }
     long total4 = M * (C / 4);
-    TRI_ACT_DISPATCH(act_bf16, bn_act_kernel<T><<<ew_grid(total4), 256, 0, (hipStream_t)stream>>>(
+    TRI_ACT_DISPATCH(act_fmt, bn_act_kernel<T><<<ew_grid(total4), 256, 0, (hipStream_t)stream>>>(
         (const T*)y, (const float4*)scale, (const float4*)shift, (const T*)res, (const float4*)rscale, (const float4*)rshift, (T*)out,
         total4, C / 4, relu));
     return tri_check_launch("tri_bn_act");
@@ -140,9 +135,9 @@ __global__ void relu_bwd_kernel(const T* dout, const T* __restrict__ out, T* g, 
         Act<T>::st4(g + i * 4, d);
     }
 }
-extern "C" int tri_relu_bwd(const void* dout, const void* out, void* g, long n, int act_bf16, void* stream) {
+extern "C" int tri_relu_bwd(const void* dout, const void* out, void* g, long n, int act_fmt, void* stream) {
     if (n % 4) { tri_set_error("tri_relu_bwd: n must be a multiple of 4"); return TRI_ERR_ARG; }
-    TRI_ACT_DISPATCH(act_bf16, relu_bwd_kernel<T><<<ew_grid(n / 4), 256, 0, (hipStream_t)stream>>>((const T*)dout, (const T*)out, (T*)g, n / 4));
+    TRI_ACT_DISPATCH(act_fmt, relu_bwd_kernel<T><<<ew_grid(n / 4), 256, 0, (hipStream_t)stream>>>((const T*)dout, (const T*)out, (T*)g, n / 4));
     return tri_check_launch("tri_relu_bwd");
 }
 
@@ -209,7 +204,7 @@ extern "C" int tri_bn_bwd_num_blocks(long M) { return (int)((M + bnb_rows(M) - 1
 // the mask (y*scale + shift > 0, the forward's own expression) is recomputed instead of materialising relu_bwd's result.
 // relu_out (optional, same shape as y): the ReLU came after a residual add (BasicBlock output); its mask is out > 0.
 extern "C" int tri_bn_bwd_reduce(const void* y, const void* g, long M, int C, float* partial, const float* relu_scale,
-                                 const float* relu_shift, const void* relu_out, int act_bf16, void* stream) {
+                                 const float* relu_shift, const void* relu_out, int act_fmt, void* stream) {
     if (C % 4) { tri_set_error("tri_bn_bwd_reduce: C must be a multiple of 4"); return TRI_ERR_ARG; }
     int rows = bnb_rows(M);
     int nblk = (int)((M + rows - 1) / rows);
@@ -217,7 +212,7 @@ extern "C" int tri_bn_bwd_reduce(const void* y, const void* g, long M, int C, fl
     size_t smem = (size_t)rpp * tpr * 8 * sizeof(float);
     if (relu_scale && relu_out) { tri_set_error("tri_bn_bwd_reduce: give either relu_scale/shift or relu_out"); return TRI_ERR_ARG; }
 #define TRI_BNR(MASK_)                                                                                                              \
-    TRI_ACT_DISPATCH(act_bf16, bn_bwd_reduce_kernel<T, MASK_><<<nblk, 256, smem, (hipStream_t)stream>>>(                             \
+    TRI_ACT_DISPATCH(act_fmt, bn_bwd_reduce_kernel<T, MASK_><<<nblk, 256, smem, (hipStream_t)stream>>>(                             \
         (const T*)y, (const T*)g, M, C, partial, rows, (const float4*)relu_scale, (const float4*)relu_shift, (const T*)relu_out))
     if (relu_out) TRI_BNR(2);
     else if (relu_scale) TRI_BNR(1);
@@ -229,7 +224,7 @@ extern "C" int tri_bn_bwd_reduce(const void* y, const void* g, long M, int C, fl
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, const int* __restrict__ count_dev,
                                        int count_host, const float* __restrict__ gamma, const float* __restrict__ mean,
                                        const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                       float* __restrict__ c1, float* __restrict__ c2, float* __restrict__ c3) {
+                                       float* __restrict__ c1, float* __restrict__ c2, float* __restrict__ c3, float out_scale) {
     __shared__ double ssum[4], ssq[4];                              // one channel per block, see bn_finalize_kernel
     const int c = blockIdx.x;
     float pmu = 0.f, pis = 0.f, pga = 0.f;
@@ -256,8 +251,8 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nb
         double mu = pmu, is = pis, ga = pga;
         double dbe = s;                                   // sum g
         double dga = is * (q - mu * s);                   // sum g * xhat
-        dgamma[c] = (float)dga;
-        dbeta[c] = (float)dbe;
+        dgamma[c] = (float)(dga * (double)out_scale);     // parameter gradients leave the tower unscaled (f16 mode: g is scaled)
+        dbeta[c] = (float)(dbe * (double)out_scale);
         double k1 = ga * is;
         double k3 = -ga * is * is * dga / n;
         double k2 = -k1 * dbe / n - k3 * mu;
@@ -266,9 +261,9 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nb
 }
 extern "C" int tri_bn_bwd_finalize(const float* partial, int nblk, int C, const int* count_dev, int count_host, const float* gamma,
                                    const float* mean, const float* invstd, float* dgamma, float* dbeta, float* c1, float* c2,
-                                   float* c3, void* stream) {
+                                   float* c3, float out_scale, void* stream) {
     bn_bwd_finalize_kernel<<<C, 256, 0, (hipStream_t)stream>>>(partial, nblk, C, count_dev, count_host, gamma, mean,
-                                                                          invstd, dgamma, dbeta, c1, c2, c3);
+                                                                          invstd, dgamma, dbeta, c1, c2, c3, out_scale);
     return tri_check_launch("tri_bn_bwd_finalize");
 }
 
@@ -301,10 +296,10 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ y, const T* g, const f
 }
 extern "C" int tri_bn_bwd_apply(const void* y, const void* g, const float* c1, const float* c2, const float* c3,
                                 const uint8_t* row_mask, void* dy, long M, int C, const float* relu_scale, const float* relu_shift,
-                                const void* relu_out, void* g_masked, int act_bf16, void* stream) {
+                                const void* relu_out, void* g_masked, int act_fmt, void* stream) {
     long total4 = M * (C / 4);
 #define TRI_BNA(MASK_)                                                                                                              \
-    TRI_ACT_DISPATCH(act_bf16, bn_bwd_apply_kernel<T, MASK_><<<ew_grid(total4), 256, 0, (hipStream_t)stream>>>(                      \
+    TRI_ACT_DISPATCH(act_fmt, bn_bwd_apply_kernel<T, MASK_><<<ew_grid(total4), 256, 0, (hipStream_t)stream>>>(                      \
         (const T*)y, (const T*)g, (const float4*)c1, (const float4*)c2, (const float4*)c3, row_mask, (T*)dy, total4, C / 4,          \
         (const float4*)relu_scale, (const float4*)relu_shift, (const T*)relu_out, (T*)g_masked))
     if (relu_out) TRI_BNA(2);
@@ -346,17 +341,17 @@ __global__ void bn_relu_pool3d_fwd_kernel(const T* __restrict__ y, const float4*
     }
 }
 extern "C" int tri_bn_relu_pool3d_fwd(const void* y, const float* scale, const float* shift, const uint8_t* mask, int B, int D, int C,
-                                      void* pooled, uint8_t* mask_out, int act_bf16, void* stream) {
+                                      void* pooled, uint8_t* mask_out, int act_fmt, void* stream) {
     if (C % 4 || D % 2) { tri_set_error("tri_bn_relu_pool3d_fwd: C%4 or D%2"); return TRI_ERR_ARG; }
     long total = (long)B * (D / 2) * (D / 2) * (D / 2) * (C / 4);
-    TRI_ACT_DISPATCH(act_bf16, bn_relu_pool3d_fwd_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(
+    TRI_ACT_DISPATCH(act_fmt, bn_relu_pool3d_fwd_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(
         (const T*)y, (const float4*)scale, (const float4*)shift, mask, B, D, C / 4, (T*)pooled, mask_out));
     return tri_check_launch("tri_bn_relu_pool3d_fwd");
 }
 
 // g[B,D,D,D,C] = gradient w.r.t. the BN output: dpooled routed to the FIRST child (d,h,w scan order, as
 // torch.max_pool3d) whose post-ReLU value equals the pooled maximum and is > 0; zero elsewhere / at inactive sites.
-// (with bf16 storage the recomputed value is rounded like the stored maximum before the comparison)
+// (with 16-bit storage the recomputed value is rounded like the stored maximum before the comparison)
 template <typename T>
 __global__ void pool3d_bwd_route_kernel(const T* __restrict__ y, const float4* __restrict__ scale, const float4* __restrict__ shift,
                                         const uint8_t* __restrict__ mask, const T* __restrict__ pooled,
@@ -380,7 +375,7 @@ __global__ void pool3d_bwd_route_kernel(const T* __restrict__ y, const float4* _
                 float4 v = Act<T>::ld4(y + (ip * C4 + c) * 4);
                 float zx = fmaxf(__fmaf_rn(v.x, s.x, t.x), 0.f), zy = fmaxf(__fmaf_rn(v.y, s.y, t.y), 0.f);
                 float zz = fmaxf(__fmaf_rn(v.z, s.z, t.z), 0.f), zw = fmaxf(__fmaf_rn(v.w, s.w, t.w), 0.f);
-                if (sizeof(T) == 2) { zx = (float)(bf16_t)zx; zy = (float)(bf16_t)zy; zz = (float)(bf16_t)zz; zw = (float)(bf16_t)zw; }
+                zx = Act<T>::rnd(zx); zy = Act<T>::rnd(zy); zz = Act<T>::rnd(zz); zw = Act<T>::rnd(zw);
                 if (!dx && zx == pm.x && zx > 0.f) { o.x = dp.x; dx = true; }
                 if (!dy && zy == pm.y && zy > 0.f) { o.y = dp.y; dy = true; }
                 if (!dz && zz == pm.z && zz > 0.f) { o.z = dp.z; dz = true; }
@@ -391,9 +386,9 @@ __global__ void pool3d_bwd_route_kernel(const T* __restrict__ y, const float4* _
     }
 }
 extern "C" int tri_pool3d_bwd_route(const void* y, const float* scale, const float* shift, const uint8_t* mask, const void* pooled,
-                                    const void* dpooled, int B, int D, int C, void* g, int act_bf16, void* stream) {
+                                    const void* dpooled, int B, int D, int C, void* g, int act_fmt, void* stream) {
     long total = (long)B * (D / 2) * (D / 2) * (D / 2) * (C / 4);
-    TRI_ACT_DISPATCH(act_bf16, pool3d_bwd_route_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(
+    TRI_ACT_DISPATCH(act_fmt, pool3d_bwd_route_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(
         (const T*)y, (const float4*)scale, (const float4*)shift, mask, (const T*)pooled, (const T*)dpooled, B, D, C / 4, (T*)g));
     return tri_check_launch("tri_pool3d_bwd_route");
 }
@@ -442,9 +437,9 @@ __global__ void maxpool2d_fwd_kernel(const T* __restrict__ x, int N, int H, int 
 }
 // bn_scale / bn_shift (optional, [C]): pool relu(x * scale + shift) - the ResNet stem's BN + ReLU + max-pool in one pass
 extern "C" int tri_maxpool2d_fwd(const void* x, int N, int H, int W, int C, void* out, uint8_t* arg, const float* bn_scale,
-                                 const float* bn_shift, int act_bf16, void* stream) {
+                                 const float* bn_shift, int act_fmt, void* stream) {
     long total = (long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
-    TRI_ACT_DISPATCH(act_bf16, maxpool2d_fwd_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)stream>>>((const T*)x, N, H, W, C / 4, (T*)out, (uchar4*)arg,
+    TRI_ACT_DISPATCH(act_fmt, maxpool2d_fwd_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)stream>>>((const T*)x, N, H, W, C / 4, (T*)out, (uchar4*)arg,
                                                                                                   (const float4*)bn_scale, (const float4*)bn_shift));
     return tri_check_launch("tri_maxpool2d_fwd");
 }
@@ -521,14 +516,14 @@ __global__ void maxpool2d_bwd2x2_kernel(const uchar4* __restrict__ arg, const T*
         Act<T>::st4(o + ((long)W + 1) * C4 * 4, p11);
     }
 }
-extern "C" int tri_maxpool2d_bwd(const uint8_t* arg, const void* dout, int N, int H, int W, int C, void* dx, int act_bf16, void* stream) {
+extern "C" int tri_maxpool2d_bwd(const uint8_t* arg, const void* dout, int N, int H, int W, int C, void* dx, int act_fmt, void* stream) {
     if (H % 2 == 0 && W % 2 == 0) {
         long total = (long)N * (H / 2) * (W / 2) * (C / 4);
-        TRI_ACT_DISPATCH(act_bf16, maxpool2d_bwd2x2_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)stream>>>((const uchar4*)arg, (const T*)dout, N, H, W, C / 4, (T*)dx));
+        TRI_ACT_DISPATCH(act_fmt, maxpool2d_bwd2x2_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)stream>>>((const uchar4*)arg, (const T*)dout, N, H, W, C / 4, (T*)dx));
         return tri_check_launch("tri_maxpool2d_bwd");
     }
     long total = (long)N * H * W * (C / 4);
-    TRI_ACT_DISPATCH(act_bf16, maxpool2d_bwd_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)stream>>>((const uchar4*)arg, (const T*)dout, N, H, W, C / 4, (T*)dx));
+    TRI_ACT_DISPATCH(act_fmt, maxpool2d_bwd_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)stream>>>((const uchar4*)arg, (const T*)dout, N, H, W, C / 4, (T*)dx));
     return tri_check_launch("tri_maxpool2d_bwd");
 }
 
@@ -553,16 +548,16 @@ __global__ void avgpool_viewmax_fwd_kernel(const T* __restrict__ x, int B, int V
     out[i] = best;
     arg[i] = bi;
 }
-extern "C" int tri_avgpool_viewmax_fwd(const void* x, int B, int V, int HW, int C, float* out, int* arg, int act_bf16, void* stream) {
+extern "C" int tri_avgpool_viewmax_fwd(const void* x, int B, int V, int HW, int C, float* out, int* arg, int act_fmt, void* stream) {
     long total = (long)B * C;
-    TRI_ACT_DISPATCH(act_bf16, avgpool_viewmax_fwd_kernel<T><<<(int)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>((const T*)x, B, V, HW, C, out, arg));
+    TRI_ACT_DISPATCH(act_fmt, avgpool_viewmax_fwd_kernel<T><<<(int)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>((const T*)x, B, V, HW, C, out, arg));
     return tri_check_launch("tri_avgpool_viewmax_fwd");
 }
 template <typename T>
 __global__ void avgpool_viewmax_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ arg, int B, int V, int HW, int C,
-                                           T* __restrict__ dx) {
+                                           T* __restrict__ dx, float scale) {
     const long total = (long)B * V * HW * C;
-    float inv = 1.0f / (float)HW;
+    float inv = scale / (float)HW;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         int c = (int)(i % C);
         long r = i / C / HW;
@@ -570,8 +565,9 @@ __global__ void avgpool_viewmax_bwd_kernel(const float* __restrict__ dout, const
         dx[i] = (T)((arg[(long)b * C + c] == v) ? dout[(long)b * C + c] * inv : 0.f);
     }
 }
-extern "C" int tri_avgpool_viewmax_bwd(const float* dout, const int* arg, int B, int V, int HW, int C, void* dx, int act_bf16, void* stream) {
+extern "C" int tri_avgpool_viewmax_bwd(const float* dout, const int* arg, int B, int V, int HW, int C, void* dx, int act_fmt, float scale,
+                                       void* stream) {
     long total = (long)B * V * HW * C;
-    TRI_ACT_DISPATCH(act_bf16, avgpool_viewmax_bwd_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(dout, arg, B, V, HW, C, (T*)dx));
+    TRI_ACT_DISPATCH(act_fmt, avgpool_viewmax_bwd_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(dout, arg, B, V, HW, C, (T*)dx, scale));
     return tri_check_launch("tri_avgpool_viewmax_bwd");
 }

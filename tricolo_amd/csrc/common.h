@@ -7,6 +7,9 @@ typedef __bf16 bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16_t;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 #define TRI_OK 0
 #define TRI_ERR_ARG (-1)
@@ -56,13 +59,21 @@ __device__ __forceinline__ bf16x4 to_bf16x4(const float4& v) {
 }
 
 // ---- activation storage ---------------------------------------------------------------------------------------
-// Big activation tensors are fp32 (parity / bf16x3 mode) or bf16 (bf16 mode: half the HBM and L2 bytes of every pass).
-// All arithmetic is fp32 either way; these helpers move 4 consecutive channels.
+// Big activation tensors are fp32 (bf16x3 mode), bf16 (bf16 mode) or f16 (f16 mode: the 16-bit modes move half the HBM
+// and L2 bytes of every pass; f16 keeps 11 significand bits against bf16's 8, which is what puts the f16 mode inside the
+// 1e-3 parity bound).  All arithmetic is fp32 either way; these helpers move 4 consecutive channels.
+// The C ABI names the storage type by an int `act_fmt`: 0 fp32, 1 bf16, 2 f16.
+#ifndef TRI_FMT_F32
+#define TRI_FMT_F32 0
+#define TRI_FMT_BF16 1
+#define TRI_FMT_F16 2
+#endif
 template <typename T> struct Act;
 template <> struct Act<float> {
     static constexpr int BYTES = 4;
     static __device__ __forceinline__ float4 ld4(const float* p) { return *(const float4*)p; }
     static __device__ __forceinline__ void st4(float* p, const float4& v) { *(float4*)p = v; }
+    static __device__ __forceinline__ float rnd(float v) { return v; }           // value as it will be read back
 };
 template <> struct Act<bf16_t> {
     static constexpr int BYTES = 2;
@@ -71,7 +82,43 @@ template <> struct Act<bf16_t> {
         return make_float4((float)r[0], (float)r[1], (float)r[2], (float)r[3]);
     }
     static __device__ __forceinline__ void st4(bf16_t* p, const float4& v) { *(bf16x4*)p = to_bf16x4(v); }
+    static __device__ __forceinline__ float rnd(float v) { return (float)(bf16_t)v; }
 };
+template <> struct Act<f16_t> {
+    static constexpr int BYTES = 2;
+    static __device__ __forceinline__ float4 ld4(const f16_t* p) {
+        f16x4 r = *(const f16x4*)p;
+        return make_float4((float)r[0], (float)r[1], (float)r[2], (float)r[3]);
+    }
+    static __device__ __forceinline__ void st4(f16_t* p, const float4& v) {
+        f16x4 h;
+        h[0] = (f16_t)v.x; h[1] = (f16_t)v.y; h[2] = (f16_t)v.z; h[3] = (f16_t)v.w;
+        *(f16x4*)p = h;
+    }
+    static __device__ __forceinline__ float rnd(float v) { return (float)(f16_t)v; }
+};
+// run `...` with T bound to the storage type that act_fmt names
+#define TRI_ACT_DISPATCH(fmt, ...)                                       \
+    do {                                                                 \
+        if ((fmt) == TRI_FMT_BF16) { using T = bf16_t; __VA_ARGS__; }    \
+        else if ((fmt) == TRI_FMT_F16) { using T = f16_t; __VA_ARGS__; } \
+        else { using T = float; __VA_ARGS__; }                           \
+    } while (0)
+
+// ---- MFMA operand element types ---------------------------------------------------------------------------------
+// E = bf16_t or f16_t: both issue v_mfma_f32_16x16x32_* at the same rate with fp32 accumulation.  fp32-stored
+// activations are converted (and, in the 3-product mode, split) to bf16 operands; 16-bit storage IS the operand type.
+template <typename E> struct Mma;
+template <> struct Mma<bf16_t> {
+    typedef bf16x8 v8;
+    static __device__ __forceinline__ f32x4 mma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct Mma<f16_t> {
+    typedef f16x8 v8;
+    static __device__ __forceinline__ f32x4 mma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+template <typename AT> struct OpOf { typedef bf16_t E; };
+template <> struct OpOf<f16_t> { typedef f16_t E; };
 
 // ---- asynchronous global -> LDS copies --------------------------------------------------------------------------
 // LDS-DMA issued through inline asm: the compiler then knows nothing about LDS being written asynchronously and does not

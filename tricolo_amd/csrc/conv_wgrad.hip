@@ -41,15 +41,15 @@ __device__ __forceinline__ int nat_off(int row, int byte) {
     int sw = NCH >= 8 ? ((row & 3) | (((row >> 3) & 1) << 2)) : (((row >> 1) & 1) | (((row >> 3) & 1) << 1));
     return row * ROWB + ((((byte >> 5) ^ sw) & (NCH - 1)) << 5) + (byte & 31);
 }
-template <int ROWB>
-__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int col0, int g, int q, int pq) {
+template <int ROWB, typename V8>
+__device__ __forceinline__ V8 tr_frag(const char* tile, int col0, int g, int q, int pq) {
     // rows 8g+q and 8g+4+q, columns col0 + 4*pq .. +3 (bf16)
     const int byte = (col0 + 4 * pq) * 2;
     s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(tile + nat_off<ROWB>(8 * g + q, byte)));
     s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(tile + nat_off<ROWB>(8 * g + 4 + q, byte)));
     typedef short s16x8 __attribute__((ext_vector_type(8)));
     s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(bf16x8, r);
+    return __builtin_bit_cast(V8, r);
 }
 
 template <int BI, int BJ, int NSPLIT, typename AT>
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
                 float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (m < p.M && co < p.Cout) {
                     if (sizeof(AT) == 4) x = *(const float4*)((const float*)p.dout + (size_t)m * p.Cout + co);
-                    else { uint2 h = *(const uint2*)((const bf16_t*)p.dout + (size_t)m * p.Cout + co); x.x = __builtin_bit_cast(float, h.x); x.y = __builtin_bit_cast(float, h.y); }
+                    else { uint2 h = *(const uint2*)((const uint16_t*)p.dout + (size_t)m * p.Cout + co); x.x = __builtin_bit_cast(float, h.x); x.y = __builtin_bit_cast(float, h.y); }
                 }
                 v[u] = x;
             } else {
@@ -224,24 +224,26 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
     auto compute = [&](int buf) {
         const char* xb = smem + buf * STAGE;
         const char* yb = xb + NSPLIT * X_BYTES;
-        bf16x8 ah[TM], al[TM];
+        typedef Mma<typename OpOf<AT>::E> MM;
+        typedef typename MM::v8 v8;
+        v8 ah[TM], al[TM];
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
-            ah[a] = tr_frag<XROW>(xb, wi * WI + a * 16, fg, fqq, fp);
-            if (NSPLIT == 2) al[a] = tr_frag<XROW>(xb + X_BYTES, wi * WI + a * 16, fg, fqq, fp);
+            ah[a] = tr_frag<XROW, v8>(xb, wi * WI + a * 16, fg, fqq, fp);
+            if (NSPLIT == 2) al[a] = tr_frag<XROW, v8>(xb + X_BYTES, wi * WI + a * 16, fg, fqq, fp);
         }
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
-            bf16x8 bhf = tr_frag<YROW>(yb, wj * WJ + b * 16, fg, fqq, fp);
-            bf16x8 blf;
-            if (NSPLIT == 2) blf = tr_frag<YROW>(yb + Y_BYTES, wj * WJ + b * 16, fg, fqq, fp);
+            v8 bhf = tr_frag<YROW, v8>(yb, wj * WJ + b * 16, fg, fqq, fp);
+            v8 blf;
+            if (NSPLIT == 2) blf = tr_frag<YROW, v8>(yb + Y_BYTES, wj * WJ + b * 16, fg, fqq, fp);
 #pragma unroll
             for (int a = 0; a < TM; ++a) {
                 if (NSPLIT == 2) {
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[a], bhf, acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[a], blf, acc[a][b], 0, 0, 0);
+                    acc[a][b] = MM::mma(al[a], bhf, acc[a][b]);
+                    acc[a][b] = MM::mma(ah[a], blf, acc[a][b]);
                 }
-                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[a], bhf, acc[a][b], 0, 0, 0);
+                acc[a][b] = MM::mma(ah[a], bhf, acc[a][b]);
             }
         }
     };
@@ -292,8 +294,10 @@ __device__ __forceinline__ int nat_sw(int row) {
     return NCH >= 8 ? ((row & 3) | (((row >> 3) & 1) << 2)) : (((row >> 1) & 1) | (((row >> 3) & 1) << 1));
 }
 
-template <int BI, int BJ>
+template <int BI, int BJ, typename E>
 __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs p) {
+    typedef Mma<E> MM;
+    typedef typename MM::v8 v8;
     constexpr int KB = 64;
     constexpr int WI = BI / 2, WJ = BJ / 2, TM = WI / 16, TN = WJ / 16;
     constexpr int XROW = BI * 2, YROW = BJ * 2;
@@ -421,14 +425,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs p) 
         const char* yb = xb + X_BYTES;
 #pragma unroll
         for (int h = 0; h < KB / 32; ++h) {
-            bf16x8 ah[TM];
+            v8 ah[TM];
 #pragma unroll
-            for (int a = 0; a < TM; ++a) ah[a] = tr_frag<XROW>(xb + h * 32 * XROW, wi * WI + a * 16, fg, fqq, fp);
+            for (int a = 0; a < TM; ++a) ah[a] = tr_frag<XROW, v8>(xb + h * 32 * XROW, wi * WI + a * 16, fg, fqq, fp);
 #pragma unroll
             for (int b = 0; b < TN; ++b) {
-                bf16x8 bhf = tr_frag<YROW>(yb + h * 32 * YROW, wj * WJ + b * 16, fg, fqq, fp);
+                v8 bhf = tr_frag<YROW, v8>(yb + h * 32 * YROW, wj * WJ + b * 16, fg, fqq, fp);
 #pragma unroll
-                for (int a = 0; a < TM; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[a], bhf, acc[a][b], 0, 0, 0);
+                for (int a = 0; a < TM; ++a) acc[a][b] = MM::mma(ah[a], bhf, acc[a][b]);
             }
         }
     };
@@ -470,7 +474,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs p) 
 // and a tiny dW (stem, voxel level 0) still put a few hundred thousand loads in flight.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, int Cout, int Kpad, int ntaps,
                                                            int cin_stored, int cin_real, float* __restrict__ dw, long s_co, long s_tap,
-                                                           long s_ci, int zlanes) {
+                                                           long s_ci, int zlanes, float out_scale) {
     __shared__ float4 part[256];
     const int kq = 256 / zlanes;                                 // quads per block
     const int ql = threadIdx.x % kq, zl = threadIdx.x / kq;
@@ -495,6 +499,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
             float4 v = part[z * kq + ql];
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
+        s.x *= out_scale; s.y *= out_scale; s.z *= out_scale; s.w *= out_scale;
         const int tap = k / cin_stored, ci = k - tap * cin_stored;   // cin_stored % 4 == 0: the quad stays inside one tap
         float* d = dw + co * s_co + tap * s_tap + ci * s_ci;
         if (s_ci == 1 && cin_real == cin_stored && (((uintptr_t)d) & 15) == 0) *(float4*)d = s;
@@ -567,9 +572,9 @@ static bool wgrad_dma_disabled() {
     return v == 1;
 }
 
-// act_bf16 != 0 asks for the plan of the bf16-storage call; *dma is set when that call runs the LDS-DMA kernel
+// act_fmt != 0 asks for the plan of the bf16-storage call; *dma is set when that call runs the LDS-DMA kernel
 // (64-position steps), and steps_per_split is then in 64-position units.
-static void wgrad_plan(const TriConvDesc* d, int act_bf16, int* BI, int* BJ_out, int* tiles, int* splits, int* steps_per_split, int* Kpad,
+static void wgrad_plan(const TriConvDesc* d, int act_fmt, int* BI, int* BJ_out, int* tiles, int* splits, int* steps_per_split, int* Kpad,
                        int* dma) {
     int ntaps = d->KD * d->KH * d->KW;
     *Kpad = (ntaps * d->Cin + 31) / 32 * 32;
@@ -579,12 +584,12 @@ static void wgrad_plan(const TriConvDesc* d, int act_bf16, int* BI, int* BJ_out,
     int it = (d->Cout + *BI - 1) / *BI, jt = (*Kpad + BJ - 1) / BJ;
     *tiles = it * jt;
     long M = (long)d->B * d->OD * d->OH * d->OW;
-    *dma = (act_bf16 && BJ == 128 && d->Cin % 8 == 0 && d->Cout % *BI == 0 && !wgrad_dma_disabled()) ? 1 : 0;
+    *dma = (act_fmt && BJ == 128 && d->Cin % 8 == 0 && d->Cout % *BI == 0 && !wgrad_dma_disabled()) ? 1 : 0;
     const int unit = *dma ? 64 : 32;
     int steps = (int)((M + unit - 1) / unit);
     int max_by_steps = steps / 4 > 0 ? steps / 4 : 1;           // at least 4 k-steps per split
     int s, cap;
-    if (act_bf16 && *BI == 128 && wgrad_target_blocks() == WGRAD_TARGET_BLOCKS) {
+    if (act_fmt && *BI == 128 && wgrad_target_blocks() == WGRAD_TARGET_BLOCKS) {
         // 128x128 bf16-storage tiles (64 KiB of operand stages -> 2 workgroups per CU): at most ONE resident round of
         // workgroups, and not quite full (7/8 of the 512 slots).  More splits only add slab traffic (splits x Cout x K
         // fp32 written + re-read by the reduce) and a second, partly empty round; measured sweep in profiles/r1/README.md.
@@ -618,22 +623,22 @@ extern "C" size_t tri_conv_wgrad_workspace(const TriConvDesc* d) {
 }
 
 // 0: conv_wgrad_kernel (register-staged), 2: conv_wgrad_dma_kernel (bf16 activation storage, LDS-DMA).  For profilers.
-extern "C" int tri_conv_wgrad_kernel_family(const TriConvDesc* d, int act_bf16) {
+extern "C" int tri_conv_wgrad_kernel_family(const TriConvDesc* d, int act_fmt) {
     int BI, BJ, tiles, splits, sps, Kpad, dma;
-    wgrad_plan(d, act_bf16, &BI, &BJ, &tiles, &splits, &sps, &Kpad, &dma);
+    wgrad_plan(d, act_fmt, &BI, &BJ, &tiles, &splits, &sps, &Kpad, &dma);
     return dma ? 2 : 0;
 }
 
-template <int BI, int BJ>
+template <int BI, int BJ, typename E>
 static int launch_wgrad_dma(const WgradArgs& a, int tiles, int splits, hipStream_t stream) {
     constexpr int STAGE = 64 * (BI * 2 + BJ * 2);
     size_t smem = 2 * STAGE + 512 + (size_t)a.steps_per_split * 512;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel<BI, BJ>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE + 512 + 96 * 512);
+        hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel<BI, BJ, E>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE + 512 + 96 * 512);
         attr_set = true;
     }
-    conv_wgrad_dma_kernel<BI, BJ><<<dim3(((splits + 7) / 8) * 8 * tiles), 256, smem, stream>>>(a);
+    conv_wgrad_dma_kernel<BI, BJ, E><<<dim3(((splits + 7) / 8) * 8 * tiles), 256, smem, stream>>>(a);
     return tri_check_launch("tri_conv_wgrad(dma)");
 }
 
@@ -657,10 +662,10 @@ static int launch_wgrad(const WgradArgs& a, int tiles, int splits, hipStream_t s
 // multiple of 32 bytes) marks live positions; split3 != 0 selects the 3-product bf16 split mode.
 extern "C" int tri_conv_wgrad(const TriConvDesc* d, const void* in, const void* dout, const uint8_t* row_mask, const void* plan,
                               void* workspace, size_t workspace_bytes, float* dw, long s_co, long s_tap, long s_ci, int cin_real,
-                              int split3, int act_bf16, void* stream) {
+                              int split3, int act_fmt, float out_scale, void* stream) {
     if (d->Cin % 4 != 0 || d->Cout % 4 != 0) { tri_set_error("wgrad: channels must be multiples of 4"); return TRI_ERR_ARG; }
     int BI, BJ, tiles, splits, sps, Kpad, dma;
-    wgrad_plan(d, act_bf16, &BI, &BJ, &tiles, &splits, &sps, &Kpad, &dma);
+    wgrad_plan(d, act_fmt, &BI, &BJ, &tiles, &splits, &sps, &Kpad, &dma);
     if (workspace_bytes < (size_t)splits * d->Cout * Kpad * sizeof(float)) { tri_set_error("wgrad: workspace too small"); return TRI_ERR_ARG; }
     WgradArgs a{};
     a.in = in; a.dout = dout; a.row_mask = row_mask; a.slab = (float*)workspace;
@@ -675,8 +680,8 @@ extern "C" int tri_conv_wgrad(const TriConvDesc* d, const void* in, const void* 
     a.steps_per_split = sps;
     a.ntiles = tiles;
     a.nsplits = splits;
-    size_t in_bytes = (size_t)a.B * a.ID * a.IH * a.IW * a.Cin * (act_bf16 ? 2 : 4);
-    if (act_bf16 && split3) { tri_set_error("wgrad: bf16 activation storage is for the plain bf16 mode"); return TRI_ERR_ARG; }
+    size_t in_bytes = (size_t)a.B * a.ID * a.IH * a.IW * a.Cin * (act_fmt ? 2 : 4);
+    if (act_fmt && split3) { tri_set_error("wgrad: 16-bit activation storage takes single operands (no 3-product split)"); return TRI_ERR_ARG; }
     if (!plan) { tri_set_error("wgrad: a gather plan from tri_conv_plan_build is required"); return TRI_ERR_ARG; }
     if (in_bytes >= ((size_t)1 << 31)) { tri_set_error("wgrad: input tensor >= 2 GiB (32-bit buffer offsets)"); return TRI_ERR_UNSUPPORTED; }
     {
@@ -689,11 +694,13 @@ extern "C" int tri_conv_wgrad(const TriConvDesc* d, const void* in, const void* 
     hipStream_t s = (hipStream_t)stream;
     int rc;
 #define TRI_WG(BI_, BJ_)                                                                                   \
-    (act_bf16 ? launch_wgrad<BI_, BJ_, 1, bf16_t>(a, tiles, splits, s)                                     \
+    (act_fmt == TRI_FMT_F16 ? launch_wgrad<BI_, BJ_, 1, f16_t>(a, tiles, splits, s)                      \
+     : act_fmt == TRI_FMT_BF16 ? launch_wgrad<BI_, BJ_, 1, bf16_t>(a, tiles, splits, s)                  \
               : (split3 ? launch_wgrad<BI_, BJ_, 2, float>(a, tiles, splits, s) : launch_wgrad<BI_, BJ_, 1, float>(a, tiles, splits, s)))
     if (dma) {
         if ((size_t)a.M * a.Cout * 2 >= ((size_t)1 << 31)) { tri_set_error("wgrad: dOut tensor >= 2 GiB (32-bit buffer offsets)"); return TRI_ERR_UNSUPPORTED; }
-        rc = BI == 128 ? launch_wgrad_dma<128, 128>(a, tiles, splits, s) : launch_wgrad_dma<64, 128>(a, tiles, splits, s);
+        if (act_fmt == TRI_FMT_F16) rc = BI == 128 ? launch_wgrad_dma<128, 128, f16_t>(a, tiles, splits, s) : launch_wgrad_dma<64, 128, f16_t>(a, tiles, splits, s);
+        else rc = BI == 128 ? launch_wgrad_dma<128, 128, bf16_t>(a, tiles, splits, s) : launch_wgrad_dma<64, 128, bf16_t>(a, tiles, splits, s);
     } else if (BI == 128) rc = TRI_WG(128, 128);
     else if (BJ == 256) rc = TRI_WG(64, 256);
     else rc = TRI_WG(64, 128);
@@ -704,6 +711,6 @@ extern "C" int tri_conv_wgrad(const TriConvDesc* d, const void* in, const void* 
     while (zlanes < 64 && zlanes * 2 <= splits && quads * zlanes < 262144) zlanes *= 2;
     const int kq = 256 / zlanes;
     wgrad_reduce_kernel<<<(unsigned)((quads + kq - 1) / kq), 256, 0, s>>>((const float*)workspace, splits, d->Cout, Kpad, a.ntaps, d->Cin,
-                                                                          cin_real, dw, s_co, s_tap, s_ci, zlanes);
+                                                                          cin_real, dw, s_co, s_tap, s_ci, zlanes, out_scale);
     return tri_check_launch("tri_wgrad_reduce");
 }

@@ -37,16 +37,13 @@ __global__ void voxel_scatter_kernel(const int* __restrict__ locs, const float* 
     Act<T>::st4(dense + pos * 4, make_float4(feats[i * 3], feats[i * 3 + 1], feats[i * 3 + 2], 0.f));
     mask[pos] = 1;
 }
-extern "C" int tri_voxel_scatter(const int* locs, const float* feats, int n, int B, int V, void* dense, uint8_t* mask, int act_bf16,
+extern "C" int tri_voxel_scatter(const int* locs, const float* feats, int n, int B, int V, void* dense, uint8_t* mask, int act_fmt,
                                  void* stream) {
     hipStream_t s = (hipStream_t)stream;
     size_t sites = (size_t)B * V * V * V;
-    hipMemsetAsync(dense, 0, sites * 4 * (act_bf16 ? 2 : 4), s);
+    hipMemsetAsync(dense, 0, sites * 4 * (act_fmt ? 2 : 4), s);
     hipMemsetAsync(mask, 0, sites, s);
-    if (n > 0) {
-        if (act_bf16) voxel_scatter_kernel<bf16_t><<<(n + 255) / 256, 256, 0, s>>>(locs, feats, n, B, V, (bf16_t*)dense, mask);
-        else voxel_scatter_kernel<float><<<(n + 255) / 256, 256, 0, s>>>(locs, feats, n, B, V, (float*)dense, mask);
-    }
+    if (n > 0) TRI_ACT_DISPATCH(act_fmt, voxel_scatter_kernel<T><<<(n + 255) / 256, 256, 0, s>>>(locs, feats, n, B, V, (T*)dense, mask));
     return tri_check_launch("tri_voxel_scatter");
 }
 
@@ -66,10 +63,9 @@ __global__ void voxel_from_rgba_kernel(const uint8_t* __restrict__ rgba, long V3
         mask[i] = on ? 1 : 0;
     }
 }
-extern "C" int tri_voxel_from_rgba_u8(const uint8_t* rgba, int B, int V, void* dense, uint8_t* mask, int act_bf16, void* stream) {
+extern "C" int tri_voxel_from_rgba_u8(const uint8_t* rgba, int B, int V, void* dense, uint8_t* mask, int act_fmt, void* stream) {
     const long V3 = (long)V * V * V, total = (long)B * V3;
-    if (act_bf16) voxel_from_rgba_kernel<bf16_t><<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(rgba, V3, total, (bf16_t*)dense, mask);
-    else voxel_from_rgba_kernel<float><<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(rgba, V3, total, (float*)dense, mask);
+    TRI_ACT_DISPATCH(act_fmt, voxel_from_rgba_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(rgba, V3, total, (T*)dense, mask));
     return tri_check_launch("tri_voxel_from_rgba_u8");
 }
 
@@ -161,10 +157,9 @@ __global__ void nchw3_to_nhwc4_kernel(const float* __restrict__ x, long HW, long
         Act<T>::st4(out + i * 4, make_float4(b[0], b[HW], b[2 * HW], 0.f));
     }
 }
-extern "C" int tri_nchw3_to_nhwc4(const float* x, int N, int H, int W, void* out, int act_bf16, void* stream) {
+extern "C" int tri_nchw3_to_nhwc4(const float* x, int N, int H, int W, void* out, int act_fmt, void* stream) {
     long HW = (long)H * W, total = (long)N * HW;
-    if (act_bf16) nchw3_to_nhwc4_kernel<bf16_t><<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(x, HW, total, (bf16_t*)out);
-    else nchw3_to_nhwc4_kernel<float><<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(x, HW, total, (float*)out);
+    TRI_ACT_DISPATCH(act_fmt, nchw3_to_nhwc4_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(x, HW, total, (T*)out));
     return tri_check_launch("tri_nchw3_to_nhwc4");
 }
 
@@ -180,15 +175,11 @@ __global__ void nchw3_u8_to_nhwc4_kernel(const uint8_t* __restrict__ x, long HW,
                                              ((float)b[2 * HW] / 255.f - m2) / s2, 0.f));
     }
 }
-extern "C" int tri_nchw3_u8_to_nhwc4(const uint8_t* x, int N, int H, int W, const float* mean3, const float* std3, void* out, int act_bf16,
+extern "C" int tri_nchw3_u8_to_nhwc4(const uint8_t* x, int N, int H, int W, const float* mean3, const float* std3, void* out, int act_fmt,
                                      void* stream) {
     long HW = (long)H * W, total = (long)N * HW;
-    if (act_bf16)
-        nchw3_u8_to_nhwc4_kernel<bf16_t><<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(x, HW, total, mean3[0], mean3[1], mean3[2], std3[0],
-                                                                                         std3[1], std3[2], (bf16_t*)out);
-    else
-        nchw3_u8_to_nhwc4_kernel<float><<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(x, HW, total, mean3[0], mean3[1], mean3[2], std3[0],
-                                                                                        std3[1], std3[2], (float*)out);
+    TRI_ACT_DISPATCH(act_fmt, nchw3_u8_to_nhwc4_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(
+        x, HW, total, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], (T*)out));
     return tri_check_launch("tri_nchw3_u8_to_nhwc4");
 }
 
@@ -271,6 +262,29 @@ extern "C" int tri_act_bwd(const float* dout, const float* out, float* g, long n
     return tri_check_launch("tri_act_bwd");
 }
 
+// fp32 <-> activation-storage casts at the boundary between the fp32 heads and a 16-bit tower
+template <typename T>
+__global__ void cast_from_f32_kernel(const float4* __restrict__ src, T* __restrict__ dst, long n4, float scale) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 v = src[i];
+        Act<T>::st4(dst + i * 4, make_float4(v.x * scale, v.y * scale, v.z * scale, v.w * scale));
+    }
+}
+template <typename T>
+__global__ void cast_to_f32_kernel(const T* __restrict__ src, float4* __restrict__ dst, long n4) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) dst[i] = Act<T>::ld4(src + i * 4);
+}
+extern "C" int tri_cast_from_f32(const float* src, void* dst, long n, float scale, int act_fmt, void* stream) {
+    if (n % 4) { tri_set_error("tri_cast_from_f32: n must be a multiple of 4"); return TRI_ERR_ARG; }
+    TRI_ACT_DISPATCH(act_fmt, cast_from_f32_kernel<T><<<ew_grid(n / 4), 256, 0, (hipStream_t)stream>>>((const float4*)src, (T*)dst, n / 4, scale));
+    return tri_check_launch("tri_cast_from_f32");
+}
+extern "C" int tri_cast_to_f32(const void* src, float* dst, long n, int act_fmt, void* stream) {
+    if (n % 4) { tri_set_error("tri_cast_to_f32: n must be a multiple of 4"); return TRI_ERR_ARG; }
+    TRI_ACT_DISPATCH(act_fmt, cast_to_f32_kernel<T><<<ew_grid(n / 4), 256, 0, (hipStream_t)stream>>>((const T*)src, (float4*)dst, n / 4));
+    return tri_check_launch("tri_cast_to_f32");
+}
+
 // ------------------------------------------------------------------------------------------------ fused Adam
 // torch.optim.Adam(lr, betas, eps, weight_decay) single-tensor update, L2-in-gradient (config.yaml:50-53,
 // tricolo_net.py:43-44).  `step` lives on the device (incremented by tri_adam_tick) so the launch is graph-replayable.
@@ -279,11 +293,21 @@ extern "C" int tri_adam_tick(int* step, void* stream) {
     adam_tick_kernel<<<1, 1, 0, (hipStream_t)stream>>>(step);
     return tri_check_launch("tri_adam_tick");
 }
+// bias corrections as torch computes them (Python doubles): 1 - beta^t in double, then step_size / bias_correction2_sqrt
+struct AdamCoef { float step_size, inv_sqrt_bc2; };
+__device__ __forceinline__ AdamCoef adam_coef(int t, float lr, const float* lr_dev, float b1, float b2) {
+    const double bc1 = 1.0 - pow((double)b1, (double)t), bc2 = 1.0 - pow((double)b2, (double)t);
+    const double l = lr_dev ? (double)*lr_dev : (double)lr;
+    AdamCoef c;
+    c.step_size = (float)(l / bc1);
+    c.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    return c;
+}
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
-                            const int* __restrict__ step, float lr, float b1, float b2, float eps, float wd, float gscale) {
-    const int t = *step;
-    const float bc1 = 1.f - powf(b1, (float)t), bc2 = 1.f - powf(b2, (float)t);
-    const float step_size = lr / bc1, inv_sqrt_bc2 = 1.f / sqrtf(bc2);
+                            const int* __restrict__ step, float lr, const float* __restrict__ lr_dev, float b1, float b2, float eps,
+                            float wd, float gscale) {
+    const AdamCoef co = adam_coef(*step, lr, lr_dev, b1, b2);
+    const float step_size = co.step_size, inv_sqrt_bc2 = co.inv_sqrt_bc2;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         float pi = p[i];
         float gi = g[i] * gscale + wd * pi;
@@ -300,15 +324,15 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 #define ADAM_MAX_SEG 1024
 __global__ __launch_bounds__(256) void adam_seg_kernel(float* __restrict__ p, const float* const* __restrict__ gptr,
                                                        const long* __restrict__ gstart, int nseg, float* __restrict__ m,
-                                                       float* __restrict__ v, long n4, const int* __restrict__ step, float lr, float b1,
-                                                       float b2, float eps, float wd, float gscale) {
+                                                       float* __restrict__ v, long n4, const int* __restrict__ step, float lr,
+                                                       const float* __restrict__ lr_dev, float b1, float b2, float eps, float wd,
+                                                       float gscale) {
     __shared__ long sstart[ADAM_MAX_SEG];
     __shared__ const float* sptr[ADAM_MAX_SEG];
     for (int i = threadIdx.x; i < nseg; i += 256) { sstart[i] = gstart[i]; sptr[i] = gptr[i]; }
     __syncthreads();
-    const int t = *step;
-    const float bc1 = 1.f - powf(b1, (float)t), bc2 = 1.f - powf(b2, (float)t);
-    const float step_size = lr / bc1, inv_sqrt_bc2 = 1.f / sqrtf(bc2);
+    const AdamCoef co = adam_coef(*step, lr, lr_dev, b1, b2);
+    const float step_size = co.step_size, inv_sqrt_bc2 = co.inv_sqrt_bc2;
     for (long i4 = (long)blockIdx.x * blockDim.x + threadIdx.x; i4 < n4; i4 += (long)gridDim.x * blockDim.x) {
         const long i = i4 * 4;
         int lo = 0, hi = nseg - 1;                                  // last segment whose start is <= i
@@ -317,8 +341,8 @@ __global__ __launch_bounds__(256) void adam_seg_kernel(float* __restrict__ p, co
             if (sstart[mid] <= i) lo = mid; else hi = mid - 1;
         }
         const float* gs = sptr[lo];
-        float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gs) gv = *(const float4*)(gs + (i - sstart[lo]));
+        if (!gs) continue;                                          // no gradient: torch.optim.Adam leaves p, m, v untouched
+        const float4 gv = *(const float4*)(gs + (i - sstart[lo]));
         float4 pv = *(const float4*)(p + i), mv = *(const float4*)(m + i), vv = *(const float4*)(v + i);
 #define ADAM1(P, G, M, V)                                   \
     {                                                       \
@@ -333,15 +357,16 @@ __global__ __launch_bounds__(256) void adam_seg_kernel(float* __restrict__ p, co
     }
 }
 extern "C" int tri_adam_step_segments(float* p, const void* grad_ptrs, const long* grad_starts, int nseg, float* m, float* v, long n,
-                                      const int* step, float lr, float b1, float b2, float eps, float wd, float gscale, void* stream) {
+                                      const int* step, float lr, const float* lr_dev, float b1, float b2, float eps, float wd, float gscale,
+                                      void* stream) {
     if (nseg < 1 || nseg > ADAM_MAX_SEG || n % 4) { tri_set_error("tri_adam_step_segments: 1..1024 segments, n % 4 == 0"); return TRI_ERR_ARG; }
     adam_seg_kernel<<<ew_grid(n / 4), 256, 0, (hipStream_t)stream>>>(p, (const float* const*)grad_ptrs, grad_starts, nseg, m, v, n / 4, step, lr,
-                                                                      b1, b2, eps, wd, gscale);
+                                                                      lr_dev, b1, b2, eps, wd, gscale);
     return tri_check_launch("tri_adam_step_segments");
 }
 
-extern "C" int tri_adam_step(float* p, const float* g, float* m, float* v, long n, const int* step, float lr, float b1, float b2,
-                             float eps, float wd, float gscale, void* stream) {
-    adam_kernel<<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, step, lr, b1, b2, eps, wd, gscale);
+extern "C" int tri_adam_step(float* p, const float* g, float* m, float* v, long n, const int* step, float lr, const float* lr_dev,
+                             float b1, float b2, float eps, float wd, float gscale, void* stream) {
+    adam_kernel<<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, step, lr, lr_dev, b1, b2, eps, wd, gscale);
     return tri_check_launch("tri_adam_step");
 }

@@ -65,6 +65,7 @@ def _small(x, w, spatial) -> bool:
 
 def linear_fwd(x, w, b, act: int, precision: str, spatial: int = 1):
     """x [rows, spatial*K] channels-last -> act(x W^T + b) [rows, N] on the MFMA conv kernel (act 0/1 relu/2 tanh)."""
+    precision = ops.head_precision(precision)
     rows = x.shape[0]
     N = w.shape[0]
     K = w.shape[1] // spatial
@@ -78,6 +79,7 @@ def linear_fwd(x, w, b, act: int, precision: str, spatial: int = 1):
 
 def linear_bwd(x, w, out, dout, act: int, precision: str, spatial: int = 1, need_dx: bool = True, need_db: bool = True):
     """Backward of linear_fwd.  Returns (dx | None, dw, db)."""
+    precision = ops.head_precision(precision)
     rows = x.shape[0]
     N = w.shape[0]
     K = w.shape[1] // spatial

@@ -178,7 +178,10 @@ class MVCNNEncoder(TriModule):
         dh, gr[self.mlp[2].weight], gr[self.mlp[2].bias] = linear_bwd(saved["h"], self.mlp[2].weight, saved["o"], do, 0, prec)
         df, gr[self.mlp[0].weight], gr[self.mlp[0].bias] = linear_bwd(saved["f"], self.mlp[0].weight, saved["h"], dh, 1, prec)
         dp, gr[self.net_2.weight], gr[self.net_2.bias] = linear_bwd(saved["pooled"], self.net_2.weight, saved["f"], df, 0, prec)
-        dout = ops.avgpool_viewmax_bwd(dp, saved["arg"], saved["feat_shape"], B, self.num_views, dtype=ops.act_dtype(prec))
+        # f16 mode: activation gradients are carried times gs (ops.F16_GRAD_SCALE); parameter-gradient kernels undo it
+        gs = ops.grad_scale(prec)
+        ugs = 1.0 / gs
+        dout = ops.avgpool_viewmax_bwd(dp, saved["arg"], saved["feat_shape"], B, self.num_views, dtype=ops.act_dtype(prec), scale=gs)
         blocks = self._blocks()
         side = self._side
 
@@ -193,28 +196,28 @@ class MVCNNEncoder(TriModule):
             ch = pattern[turn[0] % len(pattern)]
             turn[0] += 1
             if ch == "m":
-                gr[w] = ops.conv_wgrad(x, dy, g, w, prec)
+                gr[w] = ops.conv_wgrad(x, dy, g, w, prec, out_scale=ugs)
                 return
             with torch.cuda.stream(side.fork(x, dy)):
-                gr[w] = ops.conv_wgrad(x, dy, g, w, prec)
+                gr[w] = ops.conv_wgrad(x, dy, g, w, prec, out_scale=ugs)
 
         for blk, sv in zip(reversed(blocks), reversed(saved["blocks"])):
             x, y1, co1, g1, a1, y2, co2, g2, yd, cod, gd, out = sv
             # relu(bn2(y2) + residual) backward inside the BN passes; g = dout * (out > 0) (gradient of the pre-activation sum,
             # also the residual branch's gradient) is written by the apply pass in place of dout
             dy2, gr[blk.bn2.weight], gr[blk.bn2.bias] = ops.bn_bwd(y2, dout, co2, blk.bn2.weight, count_host=g2.M, inplace=False,
-                                                                   relu_out=out, g_masked=dout)
+                                                                   relu_out=out, g_masked=dout, out_scale=ugs)
             g = dout
             if blk.downsample is not None:                         # shortcut branch next to the conv2 / conv1 chain
                 with torch.cuda.stream(self._side_ds.fork(g, yd)):
                     dyd, gr[blk.downsample[1].weight], gr[blk.downsample[1].bias] = ops.bn_bwd(
-                        yd, g, cod, blk.downsample[1].weight, count_host=gd.M, inplace=False)
-                    gr[blk.downsample[0].weight] = ops.conv_wgrad(x, dyd, gd, blk.downsample[0].weight, prec)
+                        yd, g, cod, blk.downsample[1].weight, count_host=gd.M, inplace=False, out_scale=ugs)
+                    gr[blk.downsample[0].weight] = ops.conv_wgrad(x, dyd, gd, blk.downsample[0].weight, prec, out_scale=ugs)
                     dx = ops.conv_dgrad(dyd, gd, self._packed[(id(blk.downsample[0]), True)])
             wgrad_async(a1, dy2, g2, blk.conv2.weight)
             da1 = ops.conv_dgrad(dy2, g2, self._packed[(id(blk.conv2), True)])
             # relu(bn1(y1)) backward: the ReLU mask is recomputed from y1 inside the BN passes (no relu_bwd pass over a1)
-            dy1, gr[blk.bn1.weight], gr[blk.bn1.bias] = ops.bn_bwd(y1, da1, co1, blk.bn1.weight, count_host=g1.M, relu=True)
+            dy1, gr[blk.bn1.weight], gr[blk.bn1.bias] = ops.bn_bwd(y1, da1, co1, blk.bn1.weight, count_host=g1.M, relu=True, out_scale=ugs)
             wgrad_async(x, dy1, g1, blk.conv1.weight)
             if blk.downsample is not None:
                 self._side_ds.join(dx, gr[blk.downsample[0].weight], gr[blk.downsample[1].weight], gr[blk.downsample[1].bias])
@@ -224,7 +227,7 @@ class MVCNNEncoder(TriModule):
             dout = dx
         x0, y, co, g0, parg = saved["stem"]
         dzs = ops.maxpool2d_bwd(parg, dout, tuple(y.shape))
-        dy, gr[self.net_1[1].weight], gr[self.net_1[1].bias] = ops.bn_bwd(y, dzs, co, self.net_1[1].weight, count_host=g0.M, relu=True)
+        dy, gr[self.net_1[1].weight], gr[self.net_1[1].bias] = ops.bn_bwd(y, dzs, co, self.net_1[1].weight, count_host=g0.M, relu=True, out_scale=ugs)
         wgrad_async(x0, dy, g0, self.net_1[0].weight)
         side.join(*[gr[p] for p in self._param_list() if p.dim() == 4])
         return [gr[p] for p in self._param_list()]

@@ -116,7 +116,7 @@ class SparseCNNEncoder(TriModule):
             if save:
                 saved["levels"].append((x, y, mask, count, co, pooled))
             x, mask, count = pooled, mask_out, count_out
-        flat = x.view(B, -1).float()                           # channels-last [B, v, v, v, C]; the head runs in fp32
+        flat = ops.cast_to_f32(x.view(B, -1))                  # channels-last [B, v, v, v, C]; the head runs in fp32
         h = linear_fwd(flat, self.mlp[0].weight, self.mlp[0].bias, 1, prec, spatial=self.spatial)
         o = linear_fwd(h, self.mlp[2].weight, self.mlp[2].bias, 0, prec)
         z, norm = ops.l2norm_fwd(o)
@@ -130,15 +130,17 @@ class SparseCNNEncoder(TriModule):
         do = ops.l2norm_bwd(saved["z"], saved["norm"], dz)
         dh, grads[17], grads[18] = linear_bwd(saved["h"], self.mlp[2].weight, saved["o"], do, 0, prec)
         dflat, grads[15], grads[16] = linear_bwd(saved["flat"], self.mlp[0].weight, saved["h"], dh, 1, prec, spatial=self.spatial)
-        dx = dflat.to(ops.act_dtype(prec))
+        gs = ops.grad_scale(prec)                              # f16 mode: activation gradients carried times gs (see mv_cnn.py)
+        ugs = 1.0 / gs
+        dx = ops.cast_from_f32(dflat.contiguous(), ops.act_dtype(prec), gs)
         for l in range(4, -1, -1):
             D, C = V >> l, self.chans[l + 1]
             g = self._geom(B, l)
             x, y, mask, count, co, pooled = saved["levels"][l]
             conv, bn = self.sparseModel[str(4 * l)], self.sparseModel[str(4 * l + 1)]
             gz = ops.pool3d_bwd_route(y, co, mask, pooled, dx.contiguous(), B, D, C)
-            dy, dgamma, dbeta = ops.bn_bwd(y, gz, co, bn.weight, count_dev=count, row_mask=mask)
-            grads[3 * l] = ops.conv_wgrad(x, dy, g, conv.weight, prec, row_mask=mask)
+            dy, dgamma, dbeta = ops.bn_bwd(y, gz, co, bn.weight, count_dev=count, row_mask=mask, out_scale=ugs)
+            grads[3 * l] = ops.conv_wgrad(x, dy, g, conv.weight, prec, row_mask=mask, out_scale=ugs)
             grads[3 * l + 1], grads[3 * l + 2] = dgamma, dbeta
             if l > 0:
                 dx = ops.conv_dgrad(dy, g, self._packed[(l, True)], row_mask=mask)

@@ -1,6 +1,10 @@
 """Tensor-level wrappers over the C ABI (one Python function per kernel family).
 
-All tensors are fp32, contiguous, channels-last ([B, D, H, W, C]; 2D tensors carry D = 1) and live on the GPU.
+Precision modes: "bf16x3" fp32 activation storage, 3-product split bf16 operands (strict parity);
+"f16" f16 activation storage and operands, fp32 accumulation, bf16x3 heads / GRU (inside the 1e-3 parity bound at the
+speed of the bf16 mode); "bf16" bf16 storage and operands (throughput mode of BASELINE config 2).
+
+All tensors are contiguous, channels-last ([B, D, H, W, C]; 2D tensors carry D = 1) and live on the GPU.
 Nothing here falls back to torch arithmetic: every function launches a kernel of libtricolo_hip.so on the
 current torch stream (so the calls can be captured into a HIP graph together with the rest of the step).
 """
@@ -13,7 +17,13 @@ import torch
 from . import _C
 from ._C import check, lib, make_desc, ptr, stream
 
-_PRECISIONS = ("bf16", "bf16x3")
+_PRECISIONS = ("bf16", "bf16x3", "f16")
+_FMT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}        # act_fmt of include/tricolo_hip.h
+# Gradients of the big activation tensors are stored in f16 in the f16 mode.  Their magnitude shrinks with the number of
+# positions they spread over (1e-6 .. 1e-5 per element in layer1 at batch 32 x 6 views), below f16's normal range
+# (6.1e-5): they are carried multiplied by 2^12 from the first 16-bit gradient tensor of a tower to the parameter-gradient
+# kernels, which multiply by 2^-12 (exact).  f16 max is 65504.
+F16_GRAD_SCALE = 4096.0
 _default_precision = os.environ.get("TRICOLO_PRECISION", "bf16x3")
 
 
@@ -61,16 +71,17 @@ def _timed(symbol, flops, fn):
     return TIMER.run(symbol, flops, fn) if TIMER is not None else fn()
 
 
+_TNAME = {torch.float32: "float", torch.bfloat16: "bf16", torch.float16: "f16"}
+
+
 def _igemm_symbol(g, transposed, split, t):
     """Name of the kernel the C dispatch picks for this layer (what rocprofv3 reports), for the KernelTimer."""
-    bf = t.dtype == torch.bfloat16
-    code = g.kernel_family[(transposed, 1 if split else (2 if bf else 0))]
+    h16 = t.dtype != torch.float32
+    code = g.kernel_family[(transposed, 1 if split else (2 if h16 else 0))]
     fam, bn = code & 255, code >> 8
-    if fam == 3:
-        return f"conv_halo_kernel<{bn}>"
     if fam == 2:
-        return f"conv_dma_kernel<{bn}, {3 if os.environ.get('TRICOLO_DMA_STAGES') == '3' else 2}>"
-    return f"{'conv_brick_kernel' if fam == 1 else 'conv_igemm_kernel'}<{bn}, {2 if split else 1}, {'bf16' if bf else 'float'}>"
+        return f"conv_dma_kernel<{bn}, {3 if os.environ.get('TRICOLO_DMA_STAGES') == '3' else 2}, {_TNAME[t.dtype]}>"
+    return f"conv_igemm_kernel<{bn}, {2 if split else 1}, {_TNAME[t.dtype]}>"
 
 
 def _f32(t):
@@ -79,20 +90,42 @@ def _f32(t):
 
 
 def _act(t):
-    """Activation tensor: contiguous fp32 (parity / bf16x3 mode) or bf16 (bf16 mode storage)."""
-    assert t.dtype in (torch.float32, torch.bfloat16) and t.is_contiguous(), "expected contiguous fp32 / bf16 activations"
+    """Activation tensor: contiguous fp32 (bf16x3 mode), bf16 (bf16 mode) or f16 (f16 mode)."""
+    assert t.dtype in _FMT and t.is_contiguous(), "expected contiguous fp32 / bf16 / f16 activations"
     return t
 
 
 def _abf(t) -> int:
-    return 1 if t.dtype == torch.bfloat16 else 0
+    """act_fmt of a tensor: 0 fp32, 1 bf16, 2 f16."""
+    return _FMT[t.dtype]
 
 
 def act_dtype(precision: str):
-    """Storage type of the big activation tensors for a precision mode (TRICOLO_ACT_FP32=1 forces fp32 storage)."""
+    """Storage type of the big activation tensors for a precision mode (TRICOLO_ACT_FP32=1 forces fp32 storage in bf16 mode)."""
+    if precision == "f16":
+        return torch.float16
     if precision == "bf16" and os.environ.get("TRICOLO_ACT_FP32", "0") != "1":
         return torch.bfloat16
     return torch.float32
+
+
+def split3(precision: str) -> int:
+    """3-product split bf16 operands in the fp32 kernels (heads, GRU): the strict mode and the f16 mode."""
+    return 1 if precision in ("bf16x3", "f16") else 0
+
+
+def head_precision(precision: str) -> str:
+    """Precision of the dense fp32 layers (MLP heads, GRU input projection): the f16 mode runs them in bf16x3."""
+    return "bf16x3" if precision == "f16" else precision
+
+
+def grad_scale(precision: str) -> float:
+    return F16_GRAD_SCALE if precision == "f16" else 1.0
+
+
+def _conv_mode(x, lo) -> int:
+    """Plan index of the conv entry points: 0 bf16 operands / fp32 storage, 1 bf16x3, 2 16-bit storage."""
+    return 1 if lo is not None else (2 if x.dtype != torch.float32 else 0)
 
 
 class ConvGeom:
@@ -117,8 +150,7 @@ class ConvGeom:
         self.kpad_t = lib().tri_conv_kpad(self.ntaps, cout)
         self.M = B * OD * OH * OW
         self.M_in = B * ID * IH * IW
-        self.num_mtiles = {m: lib().tri_conv_num_mtiles(_C.C.byref(self.desc), {"bf16x3": 1, "bf16": 0, "bf16s": 2}[m])
-                           for m in (*_PRECISIONS, "bf16s")}          # bf16s: bf16 operands AND bf16 activation storage
+        self.num_mtiles = {m: lib().tri_conv_num_mtiles(_C.C.byref(self.desc), m) for m in (0, 1, 2)}     # by _conv_mode
         self.kernel_family = {(tr, m): lib().tri_conv_kernel_family(_C.C.byref(self.desc), 1 if tr else 0, m)
                               for tr in (False, True) for m in (0, 1, 2)}
         self.wgrad_ws = lib().tri_conv_wgrad_workspace(_C.C.byref(self.desc))
@@ -169,9 +201,9 @@ def pack_weight(w: torch.Tensor, g: ConvGeom, precision: str, transposed: bool =
         rows, inner, inner_pad, kpad, s_row, s_inner = g.cin_stored, g.cout, g.cout, g.kpad_t, s_ci, s_co
         if g.cin != g.cin_stored:
             raise RuntimeError("dgrad operand requested for a layer with padded input channels")
-    hi = torch.empty((rows, kpad), dtype=torch.bfloat16, device=w.device)
+    hi = torch.empty((rows, kpad), dtype=torch.float16 if precision == "f16" else torch.bfloat16, device=w.device)
     lo = torch.empty_like(hi) if precision == "bf16x3" else None
-    check(lib().tri_weight_prep(ptr(_f32(w)), s_row, s_tap, s_inner, rows, g.ntaps, inner, inner_pad, ptr(hi), ptr(lo), stream()),
+    check(lib().tri_weight_prep(ptr(_f32(w)), s_row, s_tap, s_inner, rows, g.ntaps, inner, inner_pad, ptr(hi), ptr(lo), _abf(hi), stream()),
           "tri_weight_prep")
     return hi, lo
 
@@ -201,10 +233,11 @@ class WeightPacker:
                 rows, inner, inner_pad, kpad, s_row, s_inner = g.cout, g.cin, g.cin_stored, g.kpad, s_co, s_ci
             else:
                 rows, inner, inner_pad, kpad, s_row, s_inner = g.cin_stored, g.cout, g.cout, g.kpad_t, s_ci, s_co
-            hi = torch.empty((rows, kpad), dtype=torch.bfloat16, device=device)
+            hi = torch.empty((rows, kpad), dtype=torch.float16 if precision == "f16" else torch.bfloat16, device=device)
             lo = torch.empty_like(hi) if precision == "bf16x3" else None
             bufs[key] = (hi, lo)
             d = descs[i]
+            d.fmt = _abf(hi)
             d.w, d.hi, d.lo = w.data_ptr(), hi.data_ptr(), (lo.data_ptr() if lo is not None else None)
             d.s_row, d.s_tap, d.s_inner = s_row, s_tap, s_inner
             d.rows, d.ntaps, d.inner, d.inner_pad, d.kpad = rows, g.ntaps, inner, inner_pad, kpad
@@ -229,8 +262,7 @@ def conv_fwd(x, g: ConvGeom, packed, row_mask=None, bias=None, act=0, want_stats
     if out is None:
         out = torch.empty((g.B, OD, OH, OW, g.cout), dtype=x.dtype, device=x.device)
     assert out.dtype == x.dtype
-    stats = (torch.empty((g.num_mtiles["bf16x3" if lo is not None else ("bf16s" if x.dtype == torch.bfloat16 else "bf16")], 2, g.cout), dtype=torch.float32, device=x.device)
-             if want_stats else None)
+    stats = torch.empty((g.num_mtiles[_conv_mode(x, lo)], 2, g.cout), dtype=torch.float32, device=x.device) if want_stats else None
     ws = _workspace(g.fwd_ws, x.device) if g.fwd_ws else None
     check(_timed(_igemm_symbol(g, False, lo is not None, x), g.flops,
                  lambda: lib().tri_conv_fwd(_C.C.byref(g.desc), ptr(_act(x)), ptr(hi), ptr(lo), ptr(out), ptr(row_mask), ptr(bias),
@@ -269,8 +301,8 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
     return ws
 
 
-def conv_wgrad(x, dout, g: ConvGeom, like: torch.Tensor, precision: str, row_mask=None):
-    """Gradient of the layer's parameter, returned in the parameter's own layout (shape of ``like``)."""
+def conv_wgrad(x, dout, g: ConvGeom, like: torch.Tensor, precision: str, row_mask=None, out_scale: float = 1.0):
+    """Gradient of the layer's parameter, returned in the parameter's own layout (shape of ``like``), times out_scale."""
     assert x.dtype == dout.dtype
     dw = torch.empty_like(like)
     ws = _workspace(g.wgrad_ws, x.device)
@@ -278,15 +310,15 @@ def conv_wgrad(x, dout, g: ConvGeom, like: torch.Tensor, precision: str, row_mas
     s_co, s_tap, s_ci = g.strides
     bi = 128 if (g.cout % 128 == 0 and g.kpad >= 128) else 64
     bj = 128 if bi == 128 else (256 if g.kpad <= 256 else 128)
-    bf = x.dtype == torch.bfloat16
-    if bf and g.wgrad_dma:
-        sym = f"conv_wgrad_dma_kernel<{bi}, {bj}>"
+    h16 = x.dtype != torch.float32
+    s3 = 1 if (precision == "bf16x3" and not h16) else 0
+    if h16 and g.wgrad_dma:
+        sym = f"conv_wgrad_dma_kernel<{bi}, {bj}, {_TNAME[x.dtype]}>"
     else:
-        sym = f"conv_wgrad_kernel<{bi}, {bj}, {2 if precision == 'bf16x3' else 1}, {'bf16' if bf else 'float'}>"
+        sym = f"conv_wgrad_kernel<{bi}, {bj}, {2 if s3 else 1}, {_TNAME[x.dtype]}>"
     check(_timed(sym, g.flops,
                  lambda: lib().tri_conv_wgrad(_C.C.byref(g.desc), ptr(_act(x)), ptr(_act(dout)), ptr(row_mask), ptr(plan), ptr(ws),
-                                              ws.numel(), ptr(dw), s_co, s_tap, s_ci, g.cin, 1 if precision == "bf16x3" else 0,
-                                              _abf(x), stream())),
+                                              ws.numel(), ptr(dw), s_co, s_tap, s_ci, g.cin, s3, _abf(x), float(out_scale), stream())),
           "tri_conv_wgrad")
     return dw
 
@@ -331,11 +363,12 @@ def relu_bwd(dout, out, inplace=True):
 
 
 def bn_bwd(y, g, co: BNCoeffs, gamma, count_dev=None, count_host=0, row_mask=None, inplace=True, relu=False, relu_out=None,
-           g_masked=None):
+           g_masked=None, out_scale: float = 1.0):
     """Returns (dy, dgamma, dbeta).  g = gradient w.r.t. the BN output (already activation-masked), or - with relu=True -
     w.r.t. relu(bn(y)): the ReLU mask is then recomputed from y inside the two passes (no separate relu_bwd pass), or -
     with relu_out - w.r.t. relu(bn(y) + residual) whose saved output is relu_out; g_masked (may alias g) then receives
-    g * (relu_out > 0), the gradient of the pre-activation sum that the residual branch needs too."""
+    g * (relu_out > 0), the gradient of the pre-activation sum that the residual branch needs too.
+    out_scale multiplies dgamma / dbeta only (f16 mode: g and dy carry F16_GRAD_SCALE, parameter gradients do not)."""
     rs, rb = (co.scale, co.shift) if relu else (None, None)
     C = y.shape[-1]
     M = y.numel() // C
@@ -346,7 +379,7 @@ def bn_bwd(y, g, co: BNCoeffs, gamma, count_dev=None, count_host=0, row_mask=Non
           "tri_bn_bwd_reduce")
     buf = torch.empty((5, C), dtype=torch.float32, device=y.device)
     check(lib().tri_bn_bwd_finalize(ptr(partial), nblk, C, ptr(count_dev), int(count_host), ptr(gamma), ptr(co.mean),
-                                    ptr(co.invstd), ptr(buf[0]), ptr(buf[1]), ptr(buf[2]), ptr(buf[3]), ptr(buf[4]), stream()),
+                                    ptr(co.invstd), ptr(buf[0]), ptr(buf[1]), ptr(buf[2]), ptr(buf[3]), ptr(buf[4]), float(out_scale), stream()),
           "tri_bn_bwd_finalize")
     dy = g if inplace else torch.empty_like(g)
     check(lib().tri_bn_bwd_apply(ptr(y), ptr(g), ptr(buf[2]), ptr(buf[3]), ptr(buf[4]), ptr(row_mask), ptr(dy), M, C, ptr(rs), ptr(rb),
@@ -398,11 +431,29 @@ def avgpool_viewmax_fwd(x, B, V):
     return out, arg
 
 
-def avgpool_viewmax_bwd(dout, arg, shape, B, V, dtype=torch.float32):
+def avgpool_viewmax_bwd(dout, arg, shape, B, V, dtype=torch.float32, scale: float = 1.0):
     N, _, H, W, C = shape
     dx = torch.empty(shape, dtype=dtype, device=dout.device)
-    check(lib().tri_avgpool_viewmax_bwd(ptr(_f32(dout)), ptr(arg), B, V, H * W, C, ptr(dx), _abf(dx), stream()), "tri_avgpool_viewmax_bwd")
+    check(lib().tri_avgpool_viewmax_bwd(ptr(_f32(dout)), ptr(arg), B, V, H * W, C, ptr(dx), _abf(dx), float(scale), stream()),
+          "tri_avgpool_viewmax_bwd")
     return dx
+
+
+def cast_from_f32(x, dtype, scale: float = 1.0):
+    """scale * x (fp32) stored as `dtype` - the fp32 head -> 16-bit tower boundary (one launch, no ATen copy)."""
+    if dtype == torch.float32 and scale == 1.0:
+        return x
+    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    check(lib().tri_cast_from_f32(ptr(_f32(x)), ptr(out), x.numel(), float(scale), _abf(out), stream()), "tri_cast_from_f32")
+    return out
+
+
+def cast_to_f32(x):
+    if x.dtype == torch.float32:
+        return x
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    check(lib().tri_cast_to_f32(ptr(_act(x)), ptr(out), x.numel(), _abf(x), stream()), "tri_cast_to_f32")
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ layouts
@@ -515,7 +566,7 @@ def linear_small_fwd(x, w, b, act, precision):
     N = w.shape[0]
     y = torch.empty((M, N), dtype=torch.float32, device=x.device)
     check(_timed("linear_small_fwd_kernel", 2.0 * M * K * N,
-                 lambda: lib().tri_linear_small_fwd(ptr(_f32(x)), ptr(_f32(w)), ptr(b), ptr(y), M, K, N, act, 1 if precision == "bf16x3" else 0,
+                 lambda: lib().tri_linear_small_fwd(ptr(_f32(x)), ptr(_f32(w)), ptr(b), ptr(y), M, K, N, act, split3(precision),
                                                     stream())), "tri_linear_small_fwd")
     return y
 
@@ -523,7 +574,7 @@ def linear_small_fwd(x, w, b, act, precision):
 def linear_small_bwd(x, w, out, dout, act, precision, need_dx=True, need_db=True):
     M, K = x.shape
     N = w.shape[0]
-    s3 = 1 if precision == "bf16x3" else 0
+    s3 = split3(precision)
     dout = _f32(dout.contiguous())
     dw = torch.empty_like(w)
     db = torch.empty((N,), dtype=torch.float32, device=x.device) if need_db else None
@@ -555,7 +606,7 @@ def gru_fwd(xproj, w_hh, b_hh, B, L, precision):
     gates = torch.empty((2, L, B, 4, 128), dtype=torch.float32, device=dev)
     hfinal = torch.empty((B, 256), dtype=torch.float32, device=dev)
     check(lib().tri_gru_fwd(ptr(_f32(xproj)), ptr(_f32(w_hh)), ptr(_f32(b_hh)), B, L, ptr(hs), ptr(gates), ptr(hfinal),
-                            1 if precision == "bf16x3" else 0, stream()), "tri_gru_fwd")
+                            split3(precision), stream()), "tri_gru_fwd")
     return hfinal, hs, gates
 
 
@@ -566,7 +617,7 @@ def gru_bwd(dhfinal, w_hh, hs, gates, B, L, precision):
     hprev = torch.empty((2, L * B, 128), dtype=torch.float32, device=dev)
     dbias = torch.empty(((B + 15) // 16, 2, 4, 128), dtype=torch.float32, device=dev)
     check(lib().tri_gru_bwd(ptr(_f32(dhfinal.contiguous())), ptr(_f32(w_hh)), ptr(hs), ptr(gates), B, L, ptr(dgi), ptr(dgh), ptr(hprev),
-                            ptr(dbias), 1 if precision == "bf16x3" else 0, stream()), "tri_gru_bwd")
+                            ptr(dbias), split3(precision), stream()), "tri_gru_bwd")
     return dgi, dgh, hprev, dbias
 
 
@@ -588,12 +639,13 @@ def adam_tick(step):
     check(lib().tri_adam_tick(ptr(step), stream()), "tri_adam_tick")
 
 
-def adam_step_segments(p, grad_ptrs, grad_starts, m, v, step, lr, b1, b2, eps, wd, gscale=1.0):
-    """Fused Adam over the flat buffers with the gradients read in place through a device (pointer, start) table."""
+def adam_step_segments(p, grad_ptrs, grad_starts, m, v, step, lr, b1, b2, eps, wd, gscale=1.0, lr_dev=None):
+    """Fused Adam over the flat buffers with the gradients read in place through a device (pointer, start) table.
+    lr_dev (1-element fp32 device tensor) overrides lr at run time: a captured graph then follows an LR schedule."""
     check(lib().tri_adam_step_segments(ptr(p), ptr(grad_ptrs), ptr(grad_starts), grad_starts.numel(), ptr(m), ptr(v), p.numel(), ptr(step),
-                                       lr, b1, b2, eps, wd, gscale, stream()), "tri_adam_step_segments")
+                                       lr, ptr(lr_dev), b1, b2, eps, wd, gscale, stream()), "tri_adam_step_segments")
 
 
-def adam_step(p, g, m, v, step, lr, b1, b2, eps, wd, gscale=1.0):
-    check(lib().tri_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(step), lr, b1, b2, eps, wd, gscale, stream()),
+def adam_step(p, g, m, v, step, lr, b1, b2, eps, wd, gscale=1.0, lr_dev=None):
+    check(lib().tri_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(step), lr, ptr(lr_dev), b1, b2, eps, wd, gscale, stream()),
           "tri_adam_step")

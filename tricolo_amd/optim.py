@@ -6,7 +6,12 @@ tricolo_amd/config/config.yaml); ``torch.optim.Adam`` keeps working on the same 
 MI355X design: all parameters are re-bound (once) to views of ONE flat fp32 buffer; each step concatenates the
 gradients into one flat buffer (a single copy kernel), optionally hands that buffer to the data-parallel all-reduce
 (one collective for the whole model: xGMI rings are per-link bound, so fewer and bigger), and updates everything with
-ONE kernel launch.  The step counter lives on the device, so the optimizer step is HIP-graph capturable.
+ONE kernel launch.  The step counter AND the learning rate live on the device, so the optimizer step is HIP-graph
+capturable and a replayed graph follows an LR schedule (the reference's LrDecayCallback, tricolo/callback/lr_decay.py):
+change ``param_groups[0]["lr"]`` as usual; eager steps pick it up by themselves, graph replays after ``sync_lr()``.
+
+``state_dict()`` / ``load_state_dict()`` speak torch.optim.Adam's format (per-parameter ``step``, ``exp_avg``,
+``exp_avg_sq``), so Lightning's ``optimizer_states`` checkpoints resume in either optimizer.
 """
 import torch
 
@@ -17,8 +22,10 @@ class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, flatten=True):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._flatten = flatten and len(self.param_groups) == 1
-        self._flat_p = self._flat_m = self._flat_v = self._step_dev = None
+        self._flat_p = self._flat_m = self._flat_v = self._step_dev = self._lr_dev = None
+        self._lr_host = None
         self._params = None
+        self._pending_state = None
 
     # ------------------------------------------------------------------ state
     def prepare(self):
@@ -36,6 +43,8 @@ class FusedAdam(torch.optim.Optimizer):
         dev = params[0].device
         self._params = params
         self._step_dev = torch.zeros((1,), dtype=torch.int32, device=dev)
+        self._lr_dev = torch.zeros((1,), dtype=torch.float32, device=dev)
+        self.sync_lr()
         if self._flatten:
             sizes = [p.numel() for p in params]
             flat = torch.empty((sum(sizes),), dtype=torch.float32, device=dev)
@@ -74,6 +83,76 @@ class FusedAdam(torch.optim.Optimizer):
             for p in params:
                 self.state[p]["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 self.state[p]["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        if self._pending_state is not None:                          # load_state_dict() came before the first step
+            sd, self._pending_state = self._pending_state, None
+            self._restore(sd)
+
+    def sync_lr(self):
+        """Copy param_groups[0]['lr'] to the device scalar the kernels read.  Eager steps call it themselves; call it after
+        changing the learning rate when the step is replayed from a HIP graph (it cannot run inside a capture)."""
+        if self._lr_dev is None:
+            return
+        lr = float(self.param_groups[0]["lr"])
+        if lr == self._lr_host:
+            return
+        if torch.cuda.is_current_stream_capturing():
+            if self._lr_host is None:
+                raise RuntimeError("FusedAdam: call prepare() before capturing the step into a HIP graph")
+            return                                                   # picked up by the next sync_lr() outside the capture
+        self._lr_dev.fill_(lr)
+        self._lr_host = lr
+
+    # ------------------------------------------------------------------ checkpoint format of torch.optim.Adam
+    def state_dict(self):
+        """torch.optim.Adam's layout: state[i] = {'step': 0-d fp32 tensor, 'exp_avg', 'exp_avg_sq'} (what Lightning stores
+        under ``optimizer_states`` and ``trainer.fit(ckpt_path=...)`` restores, train.py:41-45)."""
+        if self._step_dev is not None:
+            step = self._step_dev.to(torch.float32).reshape(())
+            for p in self._params:
+                self.state[p]["step"] = step.clone()
+        sd = super().state_dict()
+        if self._step_dev is not None:
+            for p in self._params:
+                self.state[p].pop("step", None)
+        return sd
+
+    def _restore(self, sd):
+        params = [p for g in self.param_groups for p in g["params"]]
+        ids = [i for g in sd["param_groups"] for i in g["params"]]
+        steps = set()
+        with torch.no_grad():
+            for p, i in zip(params, ids):
+                st = sd["state"].get(i)
+                if st is None or p not in self.state:
+                    continue
+                self.state[p]["exp_avg"].copy_(st["exp_avg"])        # in place: the kernels read the flat buffers behind these views
+                self.state[p]["exp_avg_sq"].copy_(st["exp_avg_sq"])
+                if "step" in st:
+                    steps.add(int(float(st["step"])))
+            if len(steps) > 1:
+                raise RuntimeError(f"FusedAdam keeps ONE step counter; the checkpoint holds different per-parameter steps {sorted(steps)}")
+            if steps:
+                self._step_dev.fill_(steps.pop())
+        for g, gs in zip(self.param_groups, sd["param_groups"]):
+            for k, v in gs.items():
+                if k != "params":
+                    g[k] = v
+        self._lr_host = None
+        self.sync_lr()
+
+    def load_state_dict(self, state_dict):
+        if len(state_dict["param_groups"]) != len(self.param_groups):
+            raise ValueError("loaded state dict has a different number of parameter groups")
+        n_here = [len(g["params"]) for g in self.param_groups]
+        if [len(g["params"]) for g in state_dict["param_groups"]] != n_here:
+            raise ValueError("loaded state dict contains a parameter group that doesn't match the size of optimizer's group")
+        params = [p for g in self.param_groups for p in g["params"]]
+        if params and all(p.is_cuda for p in params):
+            self.prepare()
+        if self._step_dev is None:                                   # parameters not on the GPU yet: applied by prepare()
+            self._pending_state = state_dict
+            return
+        self._restore(state_dict)
 
     def flat_grad(self):
         """All gradients as one contiguous fp32 buffer in parameter order (zeros for parameters without a gradient)."""
@@ -117,7 +196,7 @@ class FusedAdam(torch.optim.Optimizer):
             slot[1] = torch.cuda.Event()
             slot[1].record()
         ops.adam_step_segments(self._flat_p, self._seg_ptr, self._seg_start, self._flat_m, self._flat_v, self._step_dev, group["lr"],
-                               b1, b2, group["eps"], group["weight_decay"], grad_scale)
+                               b1, b2, group["eps"], group["weight_decay"], grad_scale, lr_dev=self._lr_dev)
         return True
 
     @torch.no_grad()
@@ -128,9 +207,10 @@ class FusedAdam(torch.optim.Optimizer):
             raise RuntimeError("apply_flat needs flatten=True")
         group = self.param_groups[0]
         b1, b2 = group["betas"]
+        self.sync_lr()
         ops.adam_tick(self._step_dev)
         ops.adam_step(self._flat_p, g, self._flat_m, self._flat_v, self._step_dev, group["lr"], b1, b2, group["eps"],
-                      group["weight_decay"], grad_scale)
+                      group["weight_decay"], grad_scale, lr_dev=self._lr_dev)
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale: float = 1.0, reduce_fn=None):
@@ -141,15 +221,20 @@ class FusedAdam(torch.optim.Optimizer):
             return loss
         group = self.param_groups[0]
         b1, b2 = group["betas"]
+        self.sync_lr()
         ops.adam_tick(self._step_dev)                       # step += 1 on the device, once per optimizer step
         if self._flatten:
             if reduce_fn is None and self._seg_ok and self._update_from_segments(group, b1, b2, grad_scale):
                 return loss
+            if any(p.grad is None for p in self._params):
+                # torch.optim.Adam skips such parameters entirely (no weight decay, no moment decay); the flat kernel cannot
+                raise RuntimeError("FusedAdam(flatten=True): a parameter has no gradient; the packed-gradient path (data-parallel "
+                                   "reduce_fn, or parameter sizes not multiples of 4) needs one for every parameter")
             g = self.flat_grad()
             if reduce_fn is not None:
                 reduce_fn(g)
             ops.adam_step(self._flat_p, g, self._flat_m, self._flat_v, self._step_dev, group["lr"], b1, b2, group["eps"],
-                          group["weight_decay"], grad_scale)
+                          group["weight_decay"], grad_scale, lr_dev=self._lr_dev)
             return loss
         if reduce_fn is not None:
             raise RuntimeError("reduce_fn needs flatten=True")
@@ -161,5 +246,5 @@ class FusedAdam(torch.optim.Optimizer):
                 st = self.state[p]
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 ops.adam_step(p, g, st["exp_avg"], st["exp_avg_sq"], self._step_dev, group["lr"], b1, b2, group["eps"],
-                              group["weight_decay"], grad_scale)
+                              group["weight_decay"], grad_scale)             # per-group lr by value: this path is never graph-captured
         return loss
