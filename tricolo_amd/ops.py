@@ -311,7 +311,7 @@ def conv_wgrad(x, dout, g: ConvGeom, like: torch.Tensor, precision: str, row_mas
     bi = 128 if (g.cout % 128 == 0 and g.kpad >= 128) else 64
     bj = 128 if bi == 128 else (256 if g.kpad <= 256 else 128)
     h16 = x.dtype != torch.float32
-    s3 = 1 if (precision == "bf16x3" and not h16) else 0
+    s3 = 1 if (split3(precision) and not h16) else 0          # fp32 tensors (heads, GRU) take the 3-product split in the f16 mode too
     if h16 and g.wgrad_dma:
         sym = f"conv_wgrad_dma_kernel<{bi}, {bj}, {_TNAME[x.dtype]}>"
     else:
