@@ -187,10 +187,20 @@ int tri_gru_bwd(const float* dhfinal, const float* w_hh, const float* hs, const 
                 float* hprev, float* dbias /* [ceil(B/16)][2][4][128] per-chunk sums of (dr, dz, dn_input, dn_hidden) */,
                 int split3, void* stream);
 
+/* up to 8 contiguous fp32 segments copied in one launch; srcs / dsts / n are HOST arrays of device pointers / element counts
+ * (the per-step [w_ih_f; w_ih_r] ... concatenations of the nn.GRU parameters, bigru.py:11) */
+int tri_copy_segments(const void* const* srcs, void* const* dsts, const long* n, int count, void* stream);
+/* nn.GRU bias gradients from tri_gru_bwd's dbias: db_ih[dir] = (dr, dz, dn_input), db_hh[dir] = (dr, dz, dn_hidden), [384] each */
+int tri_gru_bias_grads(const float* dbias, int nchunk, float* db_ih_f, float* db_hh_f, float* db_ih_r, float* db_hh_r, void* stream);
+
 /* ---- NT-Xent loss, forward + backward fused (tricolo/loss/nt_xent.py:24-74) ------------------------------------------ */
 size_t tri_ntxent_workspace(int B, int D);
 int tri_ntxent_fwd_bwd(const float* za, const float* zb, int B, int D, float temperature, float alpha, int norm, float* loss,
                        float* dza, float* dzb, void* workspace, size_t workspace_bytes, void* stream);
+/* gradient half alone, from the workspace a tri_ntxent_fwd_bwd(dza = dzb = NULL) call filled; dloss (optional DEVICE scalar)
+ * = upstream d(total)/d(loss), folded in */
+int tri_ntxent_bwd(const float* za, const float* zb, int B, int D, float temperature, float alpha, int norm, const float* dloss,
+                   float* dza, float* dzb, const void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- Adam (torch.optim.Adam as instantiated by config/config.yaml:50-53, tricolo_net.py:43-44) ------------------------ */
 int tri_adam_tick(int* step, void* stream);

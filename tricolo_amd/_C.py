@@ -82,6 +82,9 @@ SIGNATURES = {
     "tri_gru_bwd": (I, [P, P, P, P, I, I, P, P, P, P, I, P]),
     "tri_ntxent_workspace": (Z, [I, I]),
     "tri_ntxent_fwd_bwd": (I, [P, P, I, I, F, F, I, P, P, P, P, Z, P]),
+    "tri_ntxent_bwd": (I, [P, P, I, I, F, F, I, P, P, P, P, Z, P]),
+    "tri_copy_segments": (I, [P, P, P, I, P]),
+    "tri_gru_bias_grads": (I, [P, I, P, P, P, P, P]),
     "tri_adam_tick": (I, [P, P]),
     "tri_adam_step": (I, [P, P, P, P, L, P, F, P, F, F, F, F, F, P]),
     "tri_adam_step_segments": (I, [P, P, P, I, P, P, L, P, F, P, F, F, F, F, F, P]),

@@ -262,6 +262,46 @@ extern "C" int tri_act_bwd(const float* dout, const float* out, float* g, long n
     return tri_check_launch("tri_act_bwd");
 }
 
+// Up to 8 contiguous fp32 segments copied in one launch (blockIdx.y = segment): the per-step concatenations of the nn.GRU
+// parameters ([w_ih_f; w_ih_r], [b_ih_f; b_ih_r], stack(w_hh), stack(b_hh)) without four ATen cat kernels.
+struct SegCopy { const float* src[8]; float* dst[8]; long n[8]; };
+__global__ void seg_copy_kernel(SegCopy s) {
+    const float* src = s.src[blockIdx.y];
+    float* dst = s.dst[blockIdx.y];
+    const long n = s.n[blockIdx.y];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+// srcs / dsts / n are HOST arrays of `count` (<= 8) device pointers / element counts
+extern "C" int tri_copy_segments(const void* const* srcs, void* const* dsts, const long* n, int count, void* stream) {
+    if (count < 1 || count > 8) { tri_set_error("tri_copy_segments: 1..8 segments"); return TRI_ERR_ARG; }
+    SegCopy s{};
+    long nmax = 0;
+    for (int i = 0; i < count; ++i) { s.src[i] = (const float*)srcs[i]; s.dst[i] = (float*)dsts[i]; s.n[i] = n[i]; if (n[i] > nmax) nmax = n[i]; }
+    int gx = (int)((nmax + 255) / 256);
+    seg_copy_kernel<<<dim3(gx < 1 ? 1 : (gx > 256 ? 256 : gx), count), 256, 0, (hipStream_t)stream>>>(s);
+    return tri_check_launch("tri_copy_segments");
+}
+
+// nn.GRU bias gradients from tri_gru_bwd's per-chunk sums dbias [nchunk][2 dir][4 (dr, dz, dn_input, dn_hidden)][128]:
+// db_ih[dir] = (dr, dz, dn_input), db_hh[dir] = (dr, dz, dn_hidden)  ([384] each; fixed summation order over the chunks)
+__global__ void gru_bias_grads_kernel(const float* __restrict__ dbias, int nchunk, float* __restrict__ db_ih_f, float* __restrict__ db_hh_f,
+                                      float* __restrict__ db_ih_r, float* __restrict__ db_hh_r) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;        // [2][4][128]
+    if (e >= 1024) return;
+    float s = 0.f;
+    for (int c = 0; c < nchunk; ++c) s += dbias[(size_t)c * 1024 + e];
+    const int d = e >> 9, gate = (e >> 7) & 3, u = e & 127;
+    float* ih = d ? db_ih_r : db_ih_f;
+    float* hh = d ? db_hh_r : db_hh_f;
+    if (gate < 2) { ih[gate * 128 + u] = s; hh[gate * 128 + u] = s; }
+    else if (gate == 2) ih[256 + u] = s;
+    else hh[256 + u] = s;
+}
+extern "C" int tri_gru_bias_grads(const float* dbias, int nchunk, float* db_ih_f, float* db_hh_f, float* db_ih_r, float* db_hh_r, void* stream) {
+    gru_bias_grads_kernel<<<4, 256, 0, (hipStream_t)stream>>>(dbias, nchunk, db_ih_f, db_hh_f, db_ih_r, db_hh_r);
+    return tri_check_launch("tri_gru_bias_grads");
+}
+
 // fp32 <-> activation-storage casts at the boundary between the fp32 heads and a 16-bit tower
 template <typename T>
 __global__ void cast_from_f32_kernel(const float4* __restrict__ src, T* __restrict__ dst, long n4, float scale) {

@@ -123,11 +123,12 @@ __global__ __launch_bounds__(256) void ntx_grad_kernel(const float* __restrict__
                                                        const float* __restrict__ lse_col, const float* __restrict__ ahat,
                                                        const float* __restrict__ bhat, const float* __restrict__ na,
                                                        const float* __restrict__ nb, int B, int D, float inv_T, float alpha, int norm,
-                                                       float eps, float* __restrict__ dza, float* __restrict__ dzb) {
+                                                       float eps, float* __restrict__ dza, float* __restrict__ dzb,
+                                                       const float* __restrict__ dloss) {
     extern __shared__ float w[];                 // [B] coefficients dS_ij (side 0) or dS_ji (side 1), times 1/T
     __shared__ float sh[4];
     const int i = blockIdx.x, side = blockIdx.y, t = threadIdx.x;
-    const float invB = 1.0f / (float)B;
+    const float invB = (dloss ? *dloss : 1.0f) / (float)B;      // upstream d(total)/d(loss) folded into the coefficients
     for (int j = t; j < B; j += 256) {
         float s, pr, pc;
         if (side == 0) { s = S[(long)i * B + j]; pr = expf(s - lse_row[i]); pc = expf(s - lse_col[j]); }
@@ -215,6 +216,27 @@ extern "C" int tri_ntxent_fwd_bwd(const float* za, const float* zb, int B, int D
     ntx_loss_sum_kernel<<<1, 64, 0, s>>>(rowloss, B, loss);
     if (dza && dzb)
         ntx_grad_kernel<<<dim3(B, 2), 256, (size_t)B * sizeof(float), s>>>(S, lse_row, lse_col, a, b, na, nb, B, D, inv_T, alpha, norm,
-                                                                            eps, dza, dzb);
+                                                                            eps, dza, dzb, nullptr);
     return tri_check_launch("tri_ntxent_fwd_bwd");
+}
+
+// The gradient half on its own, for a `workspace` that a tri_ntxent_fwd_bwd(..., dza = dzb = NULL, ...) call filled: dza / dzb =
+// (*dloss) * d loss / d za, zb.  Lets autograd's backward launch ONE kernel per pair with the upstream scalar folded in
+// (no elementwise `grad * dloss` passes).
+extern "C" int tri_ntxent_bwd(const float* za, const float* zb, int B, int D, float temperature, float alpha, int norm,
+                              const float* dloss, float* dza, float* dzb, const void* workspace, size_t workspace_bytes, void* stream) {
+    if (B < 1 || D < 1 || D > 2048 || B > 8192) { tri_set_error("tri_ntxent: need 1<=B<=8192, 1<=D<=2048"); return TRI_ERR_ARG; }
+    if (workspace_bytes < tri_ntxent_workspace(B, D)) { tri_set_error("tri_ntxent: workspace too small"); return TRI_ERR_ARG; }
+    const char* w = (const char*)workspace;
+    const float* ahat = (const float*)w; w += al256((size_t)B * D * 4);
+    const float* bhat = (const float*)w; w += al256((size_t)B * D * 4);
+    const float* na = (const float*)w; w += al256((size_t)B * 4);
+    const float* nb = (const float*)w; w += al256((size_t)B * 4);
+    const float* lse_row = (const float*)w; w += al256((size_t)B * 4);
+    const float* lse_col = (const float*)w; w += al256((size_t)B * 4);
+    w += al256((size_t)B * 4);
+    const float* S = (const float*)w;
+    ntx_grad_kernel<<<dim3(B, 2), 256, (size_t)B * sizeof(float), (hipStream_t)stream>>>(
+        S, lse_row, lse_col, norm ? ahat : za, norm ? bhat : zb, na, nb, B, D, 1.0f / temperature, alpha, norm, 1e-12f, dza, dzb, dloss);
+    return tri_check_launch("tri_ntxent_bwd");
 }

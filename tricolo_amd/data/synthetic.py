@@ -211,3 +211,62 @@ def collate_items(items, voxel: bool, views: bool) -> dict:
             feats.append(f)
         d["voxels"] = {"locs": torch.from_numpy(np.concatenate(locs)), "feats": torch.from_numpy(np.concatenate(feats))}
     return d
+
+
+# ------------------------------------------------------------------------------------------------------
+# Held-out retrieval set (SURVEY.md section 8d "Held-out retrieval set"): shapes are COMPOSITIONS of a few factors
+# (colour, part kind, size, octant); voxels, renderings and caption tokens are all functions of the factors plus
+# per-instance noise, so a model trained on one draw of shapes retrieves UNSEEN shapes of the same factor space.
+# ------------------------------------------------------------------------------------------------------
+FACTOR_SIZES = (8, 2, 4, 8)                       # colour, kind (box / ellipsoid), size class, octant -> 512 combinations
+_PALETTE = ((220, 40, 40), (40, 200, 60), (50, 70, 230), (230, 210, 50), (200, 60, 210), (60, 210, 220), (240, 140, 40), (150, 150, 150))
+
+
+def factor_words(f, vocab_size: int = DEFAULT_VOCAB):
+    """One vocabulary word per factor value (disjoint ranges)."""
+    c, k, s, o = f
+    return [10 + c, 30 + k, 50 + s, 70 + o]
+
+
+def make_factor_shape(rng: np.random.Generator, f, V: int, num_views: int | None, S: int):
+    """(RGBA u8 grid [4,V,V,V], u8 views [nv,3,S,S] | None) of one instance of factor combination f."""
+    c, k, s, o = f
+    half0 = max(2, V * (3 + 2 * s) // 32)                              # size class -> half extent (3, 5, 7, 9 at 32^3)
+    half = np.array([half0 + int(rng.integers(0, 2)) for _ in range(3)])
+    q = V // 4
+    cen = np.array([q + (V // 2) * ((o >> 2) & 1), q + (V // 2) * ((o >> 1) & 1), q + (V // 2) * (o & 1)]) + rng.integers(-1, 2, size=3)
+    base = np.array(_PALETTE[c])
+    attrs = {"nparts": 1, "half": half[None], "cen": cen[None], "kind": np.array([k]), "base": base[None]}
+    grid = make_voxel_grid_u8(rng, V, attrs)
+    imgs = None
+    if num_views:
+        img_attr = np.zeros((num_views, 3, 4), dtype=np.int64)
+        for v in range(num_views):
+            for ch in range(3):
+                img_attr[v, ch] = (1 + s, 1 + (o % 4) + k, (o >> 2) + v, 40 + base[ch] * 140 // 255)
+        imgs = make_images_u8(rng, num_views, S, {"img": img_attr})
+    return grid, imgs
+
+
+def make_factor_retrieval_set(num_shapes: int, captions_per_shape: int, voxel_size: int, num_views: int | None, image_size: int,
+                              seed: int, distinct: bool, vocab_size: int = DEFAULT_VOCAB, max_noise_words: int = 4):
+    """List of items {'shape', 'factors', 'tokens', 'grid', 'imgs'}.  distinct=True draws num_shapes DIFFERENT factor
+    combinations (the held-out set: a caption then identifies exactly one shape); otherwise combinations repeat freely."""
+    rng = np.random.default_rng(seed)
+    ncomb = int(np.prod(FACTOR_SIZES))
+    if distinct:
+        assert num_shapes <= ncomb
+        combos = rng.permutation(ncomb)[:num_shapes]
+    else:
+        combos = rng.integers(0, ncomb, size=num_shapes)
+    items = []
+    for sidx, cidx in enumerate(combos):
+        f = np.unravel_index(int(cidx), FACTOR_SIZES)
+        grid, imgs = make_factor_shape(rng, f, voxel_size, num_views, image_size)
+        for _ in range(captions_per_shape):
+            w = factor_words(f, vocab_size) + [int(x) for x in rng.integers(200, vocab_size, size=int(rng.integers(0, max_noise_words + 1)))]
+            w = [w[i] for i in rng.permutation(len(w))]
+            tok = np.zeros(MAX_TOKENS, dtype=np.int32)
+            tok[:len(w)] = w
+            items.append({"shape": sidx, "factors": tuple(int(x) for x in f), "tokens": tok, "grid": grid, "imgs": imgs})
+    return items

@@ -12,16 +12,19 @@ from ..layers import TriModule, require_gpu
 class _NTXentFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, zis, zjs, temperature, alpha, norm):
-        need = zis.requires_grad or zjs.requires_grad
-        loss, dza, dzb = ops.ntxent_fwd_bwd(zis, zjs, temperature, alpha, norm, want_grad=need)
-        if need:
-            ctx.save_for_backward(dza, dzb)          # gradients come out of the same launch sequence as the loss
+        zis, zjs = zis.contiguous(), zjs.contiguous()
+        loss, ws = ops.ntxent_fwd(zis, zjs, temperature, alpha, norm)
+        ctx.save_for_backward(zis, zjs, ws)          # S, the log-sum-exps and the normalised rows stay in the workspace
+        ctx.hyper = (temperature, alpha, norm)
         return loss
 
     @staticmethod
     def backward(ctx, dloss):
-        dza, dzb = ctx.saved_tensors
-        return dza * dloss, dzb * dloss, None, None, None
+        zis, zjs, ws = ctx.saved_tensors
+        t, a, n = ctx.hyper
+        # one launch; the upstream scalar is folded into the kernel's coefficients (no elementwise grad * dloss passes)
+        dza, dzb = ops.ntxent_bwd(zis, zjs, ws, t, a, n, dloss=dloss.contiguous().to(torch.float32))
+        return dza, dzb, None, None, None
 
 
 class NTXentLoss(TriModule):

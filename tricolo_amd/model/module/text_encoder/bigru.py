@@ -28,10 +28,14 @@ class _BiGRUFn(torch.autograd.Function):
     def forward(ctx, emb, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r, precision):
         L, B, I = emb.shape
         x2d = emb.contiguous().view(L * B, I)
-        w_ih = torch.cat([w_ih_f, w_ih_r], dim=0)                       # [768, 256]
-        b_ih = torch.cat([b_ih_f, b_ih_r], dim=0)
-        w_hh = torch.stack([w_hh_f, w_hh_r]).contiguous()               # [2, 384, 128]
-        b_hh = torch.stack([b_hh_f, b_hh_r]).contiguous()
+        # [w_ih_f; w_ih_r], [b_ih_f; b_ih_r], stack(w_hh), stack(b_hh) in one buffer, ONE copy launch (the eight nn.GRU
+        # parameters keep their reference names / shapes; the fused kernels want the two directions side by side)
+        buf = torch.empty((768 * I + 768 + 768 * 128 + 768,), dtype=torch.float32, device=emb.device)
+        w_ih, b_ih = buf[:768 * I].view(768, I), buf[768 * I:768 * I + 768]
+        w_hh = buf[768 * I + 768:768 * I + 768 + 768 * 128].view(2, 384, 128)
+        b_hh = buf[768 * I + 768 + 768 * 128:].view(2, 384)
+        ops.copy_segments([(w_ih_f.contiguous(), w_ih[:384]), (w_ih_r.contiguous(), w_ih[384:]), (b_ih_f, b_ih[:384]), (b_ih_r, b_ih[384:]),
+                           (w_hh_f.contiguous(), w_hh[0]), (w_hh_r.contiguous(), w_hh[1]), (b_hh_f, b_hh[0]), (b_hh_r, b_hh[1])])
         xproj = linear_fwd(x2d, w_ih, b_ih, 0, precision)               # [L*B, 768]
         hfinal, hs, gates = ops.gru_fwd(xproj, w_hh, b_hh, B, L, precision)
         ctx.save_for_backward(x2d, w_ih, w_hh, hs, gates)
@@ -46,11 +50,9 @@ class _BiGRUFn(torch.autograd.Function):
         dx, dw_ih, _ = linear_bwd(x2d, w_ih, None, dgi, 0, prec, need_dx=ctx.needs_input_grad[0], need_db=False)
         g_hh = linear_geom(L * B, 128, 384)
         dw_hh = [ops.conv_wgrad(hprev[d], dgh[d], g_hh, w_hh[d], prec) for d in range(2)]
-        db = dbias.sum(0)                                   # [2, 4, 128]: (dr, dz, dn_input, dn_hidden) summed in-kernel over t, rows
-        db_ih = [db[d, :3].reshape(384) for d in range(2)]
-        db_hh = [torch.cat([db[d, :2].reshape(256), db[d, 3]]) for d in range(2)]
+        db_ih_f, db_hh_f, db_ih_r, db_hh_r = ops.gru_bias_grads(dbias)     # per-chunk (dr, dz, dn_input, dn_hidden) sums -> nn.GRU biases
         demb = dx.view(L, B, I) if dx is not None else None
-        return (demb, dw_ih[:384], dw_hh[0], db_ih[0], db_hh[0], dw_ih[384:], dw_hh[1], db_ih[1], db_hh[1], None)
+        return (demb, dw_ih[:384], dw_hh[0], db_ih_f, db_hh_f, dw_ih[384:], dw_hh[1], db_ih_r, db_hh_r, None)
 
 
 class _EmbeddingFn(torch.autograd.Function):

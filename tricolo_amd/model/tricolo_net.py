@@ -4,7 +4,7 @@ Same construction from a Hydra-style cfg (encoders chosen by NAME in cfg.model.{
 from cfg.model.modules.<name> via `_target_`, loss from cfg.loss[cfg.loss.name], optimizer from cfg.optimizer),
 same forward / _calculate_losses / training_step / validation_step / test_step hooks and the same loss names
 (`train_loss/text_image_loss`, ... `total_loss`), so Lightning's Trainer can drive it when Lightning is installed;
-`tricolo_amd.trainer` drives it when it is not.  Modality order text, image, voxel matters: alpha_weight is
+`tricolo_amd.train.fit` drives it when it is not.  Modality order text, image, voxel matters: alpha_weight is
 asymmetric and the earlier modality is `zis` (tricolo_net.py:47-53,59-63).
 """
 import os

@@ -622,6 +622,44 @@ def gru_bwd(dhfinal, w_hh, hs, gates, B, L, precision):
 
 
 # ------------------------------------------------------------------------------------------------ NT-Xent
+def copy_segments(pairs):
+    """[(src, dst), ...] (<= 8 contiguous fp32 tensors each way, equal sizes per pair) copied in ONE launch."""
+    n = len(pairs)
+    PA, LA = _C.C.c_void_p * n, _C.C.c_long * n
+    for s, d in pairs:
+        assert s.numel() == d.numel() and s.is_contiguous() and d.is_contiguous() and s.dtype == d.dtype == torch.float32
+    check(lib().tri_copy_segments(PA(*[ptr(s) for s, _ in pairs]), PA(*[ptr(d) for _, d in pairs]), LA(*[s.numel() for s, _ in pairs]), n,
+                                  stream()), "tri_copy_segments")
+
+
+def gru_bias_grads(dbias):
+    """dbias [nchunk, 2, 4, 128] from gru_bwd -> (db_ih_f, db_hh_f, db_ih_r, db_hh_r), [384] each, one launch."""
+    out = torch.empty((4, 384), dtype=torch.float32, device=dbias.device)
+    check(lib().tri_gru_bias_grads(ptr(_f32(dbias)), dbias.shape[0], ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]), stream()),
+          "tri_gru_bias_grads")
+    return out[0], out[1], out[2], out[3]
+
+
+def ntxent_fwd(za, zb, temperature, alpha, norm=True):
+    """Loss only; returns (loss, workspace) - hand the workspace to ntxent_bwd."""
+    B, D = za.shape
+    loss = torch.empty((), dtype=torch.float32, device=za.device)
+    nbytes = lib().tri_ntxent_workspace(B, D)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=za.device)
+    check(lib().tri_ntxent_fwd_bwd(ptr(_f32(za)), ptr(_f32(zb)), B, D, float(temperature), float(alpha), 1 if norm else 0, ptr(loss), None,
+                                   None, ptr(ws), nbytes, stream()), "tri_ntxent_fwd_bwd")
+    return loss, ws
+
+
+def ntxent_bwd(za, zb, ws, temperature, alpha, norm=True, dloss=None):
+    """(dza, dzb) times the upstream scalar dloss (device tensor) in one launch."""
+    B, D = za.shape
+    dza, dzb = torch.empty_like(za), torch.empty_like(zb)
+    check(lib().tri_ntxent_bwd(ptr(_f32(za)), ptr(_f32(zb)), B, D, float(temperature), float(alpha), 1 if norm else 0, ptr(dloss), ptr(dza),
+                               ptr(dzb), ptr(ws), ws.numel(), stream()), "tri_ntxent_bwd")
+    return dza, dzb
+
+
 def ntxent_fwd_bwd(za, zb, temperature, alpha, norm=True, want_grad=True):
     B, D = za.shape
     loss = torch.empty((), dtype=torch.float32, device=za.device)

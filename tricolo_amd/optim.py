@@ -106,14 +106,11 @@ class FusedAdam(torch.optim.Optimizer):
     def state_dict(self):
         """torch.optim.Adam's layout: state[i] = {'step': 0-d fp32 tensor, 'exp_avg', 'exp_avg_sq'} (what Lightning stores
         under ``optimizer_states`` and ``trainer.fit(ckpt_path=...)`` restores, train.py:41-45)."""
-        if self._step_dev is not None:
-            step = self._step_dev.to(torch.float32).reshape(())
-            for p in self._params:
-                self.state[p]["step"] = step.clone()
         sd = super().state_dict()
         if self._step_dev is not None:
-            for p in self._params:
-                self.state[p].pop("step", None)
+            step = self._step_dev.to(torch.float32).reshape(())
+            # (the packed per-parameter dicts ARE self.state's own: copy them before adding the counter)
+            sd["state"] = {k: dict(v, step=step.clone()) for k, v in sd["state"].items()}
         return sd
 
     def _restore(self, sd):
