@@ -109,8 +109,10 @@ class FusedAdam(torch.optim.Optimizer):
         sd = super().state_dict()
         if self._step_dev is not None:
             step = self._step_dev.to(torch.float32).reshape(())
-            # (the packed per-parameter dicts ARE self.state's own: copy them before adding the counter)
-            sd["state"] = {k: dict(v, step=step.clone()) for k, v in sd["state"].items()}
+            # the packed per-parameter dicts ARE self.state's own and the moments are views of the flat buffers the kernels
+            # update: hand out copies (an optimizer that load_state_dict()s this dict in the same process keeps the tensors)
+            sd["state"] = {k: {"step": step.clone(), "exp_avg": v["exp_avg"].clone(), "exp_avg_sq": v["exp_avg_sq"].clone()}
+                           for k, v in sd["state"].items()}
         return sd
 
     def _restore(self, sd):
