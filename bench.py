@@ -129,8 +129,9 @@ def cpu_baseline(a, cfg):
 
 def voxel_fwd_roofline(net, batch, B, nrep=3):
     """The five SubMConv3d forwards (sparse_cnn.py:12,17,22,27,32) timed by HIP events on their launch stream, with dense
-    and EXECUTED FLOPs: the kernels skip 128-site tiles without an active site, so executed = active tiles x 128 x 27 x
-    Cin x Cout x 2, the tile count taken on the device from the level's site mask.  `active_row_flops` is what a perfectly
+    and EXECUTED FLOPs = executed 128-row tiles x 128 x 27 x Cin x Cout x 2, the tile count taken on the device from the level's
+    site mask: levels that run over the compact active-site list execute ceil(active / 128) tiles, split-K levels (site mask)
+    every 128-site tile that holds an active site.  `active_row_flops` is what a perfectly
     row-compacted kernel would execute."""
     from tricolo_amd import ops
     enc = net.voxel_encoder
@@ -143,11 +144,12 @@ def voxel_fwd_roofline(net, batch, B, nrep=3):
     torch.cuda.synchronize()
     recs = [(s, f, a.elapsed_time(b)) for (s, f, a, b) in ops.TIMER.records if s.startswith("conv_")]
     ops.TIMER = None
-    assert len(recs) == 5 * nrep, len(recs)
+    per = len(recs) // nrep                        # 5 SubMConv3d launches first, then (64^3: 8 head sites) mlp[0] on the conv path
+    assert per >= 5 and per * nrep == len(recs), len(recs)
     levels, tot_ms, tot_dense, tot_exec, tot_rows = [], 0.0, 0, 0, 0
     V = enc.voxel_size
     for l in range(5):
-        x, y, mask, count, co, pooled = saved["levels"][l]
+        x, y, mask, count, co, pooled, rows, used_rows = saved["levels"][l]
         D = V >> l
         M = B * D ** 3
         cin, cout = enc.chans[l], enc.chans[l + 1]
@@ -155,16 +157,18 @@ def voxel_fwd_roofline(net, batch, B, nrep=3):
         pad = (-M) % 128
         if pad:
             m = torch.cat([m, m.new_zeros(pad)])
-        tiles = int(m.view(-1, 128).any(dim=1).sum().item())
         active = int(m.sum().item())
-        ms = sorted(recs[r * 5 + l][2] for r in range(nrep))[nrep // 2]
+        # executed row tiles: the compact row list packs the active sites into ceil(active / 128) tiles; split-K levels (site
+        # mask instead of a list) still run every 128-site tile that holds an active site
+        tiles = (active + 127) // 128 if used_rows else int(m.view(-1, 128).any(dim=1).sum().item())
+        ms = sorted(recs[r * per + l][2] for r in range(nrep))[nrep // 2]
         dense = 2 * M * 27 * cin * cout
         execd = 2 * tiles * 128 * 27 * cin * cout
         rowf = 2 * active * 27 * cin * cout
         e = x.element_size()
         hbm = M * (4 if cin == 3 else cin) * e + M * cout * e            # input read once + output written once
         levels.append({"level": l, "kernel": recs[l][0], "grid": D, "cin": cin, "cout": cout, "sites": M, "active_sites": active,
-                       "tiles": (M + 127) // 128, "active_tiles": tiles, "ms": round(ms, 4), "dense_tflops": round(dense / ms / 1e9, 1),
+                       "tiles": (M + 127) // 128, "executed_tiles": tiles, "compact_rows": bool(used_rows), "ms": round(ms, 4), "dense_tflops": round(dense / ms / 1e9, 1),
                        "executed_tflops": round(execd / ms / 1e9, 1), "active_row_tflops": round(rowf / ms / 1e9, 1),
                        "algorithmic_hbm_gbs": round(hbm / ms / 1e6, 1)})
         tot_ms += ms; tot_dense += dense; tot_exec += execd; tot_rows += rowf

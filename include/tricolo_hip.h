@@ -91,7 +91,7 @@ int tri_linear_small_wgrad(const float* x, const float* dout, const float* y, fl
 int tri_conv_num_mtiles(const TriConvDesc* d, int split3);
 /* kernel family tri_conv_fwd (transposed = 0) / tri_conv_dgrad (transposed = 1) dispatches for this layer and mode:
  * 0 conv_igemm_kernel (register-staged im2col), 2 conv_dma_kernel (LDS-DMA staging); bits 8.. hold the output-channel
- * tile width.  For profilers. */
+ * tile width; bit 16 set = the layer runs split-K in this mode (compact row lists are refused, use row_mask).  For profilers. */
 int tri_conv_kernel_family(const TriConvDesc* d, int transposed, int split3);
 /* same for tri_conv_wgrad: 0 conv_wgrad_kernel, 2 conv_wgrad_dma_kernel (taken when act_fmt != 0 and the layer qualifies) */
 int tri_conv_wgrad_kernel_family(const TriConvDesc* d, int act_fmt);
@@ -99,6 +99,7 @@ int tri_conv_wgrad_kernel_family(const TriConvDesc* d, int act_fmt);
 size_t tri_conv_workspace(const TriConvDesc* d, int transposed);
 int tri_conv_fwd(const TriConvDesc* d, const void* in, const void* w_hi, const void* w_lo, void* out, const uint8_t* row_mask,
                  const float* bias, int act, int accumulate, float* stats, int act_fmt, void* workspace, size_t workspace_bytes,
+                 const int* row_pos /* optional compact row list, see tri_mask_compact */, const int* row_count /* DEVICE int */,
                  void* stream);
 int tri_conv_dgrad(const TriConvDesc* d, const void* dout, const void* wt_hi, const void* wt_lo, void* din, const uint8_t* row_mask,
                    int accumulate, int act_fmt, void* workspace, size_t workspace_bytes,
@@ -106,6 +107,8 @@ int tri_conv_dgrad(const TriConvDesc* d, const void* dout, const void* wt_hi, co
                                          kernel's row tiles visit them.  For stride 2 pass the positions sorted by the parity of
                                          (coordinate + pad) per axis: a tile then only runs the 1-4 taps of 9 its rows can use
                                          (the other products are structurally zero).  Purely an execution-order hint. */,
+                   const int* row_count /* optional DEVICE int: row_pos is a COMPACT list, only rows [0, *row_count) are computed
+                                           (submanifold layers: the active sites, tri_mask_compact); other rows of din are NOT written */,
                    void* stream);
 size_t tri_conv_wgrad_workspace(const TriConvDesc* d);
 /* gather plan of a layer geometry (origin offset + tap validity bits per output position): build once, reuse every step */
@@ -130,7 +133,8 @@ int tri_bn_bwd_num_blocks(long M);
 /* relu_scale / relu_shift (optional): g is the gradient w.r.t. relu(bn(y)); the mask y*scale+shift > 0 is recomputed */
 /* relu_out (optional): g is the gradient w.r.t. relu(bn(y) + residual) and relu_out that ReLU's saved output (mask out > 0) */
 int tri_bn_bwd_reduce(const void* y, const void* g, long M, int C, float* partial, const float* relu_scale, const float* relu_shift,
-                      const void* relu_out, int act_fmt, void* stream);
+                      const void* relu_out, const uint8_t* row_mask /* optional: rows with 0 are skipped (never read) */, int act_fmt,
+                      void* stream);
 int tri_bn_bwd_finalize(const float* partial, int nblk, int C, const int* count_dev, int count_host, const float* gamma,
                         const float* mean, const float* invstd, float* dgamma, float* dbeta, float* c1, float* c2, float* c3,
                         float out_scale /* dgamma, dbeta *= out_scale (g carries the f16 mode's gradient scale; dy keeps it) */,
@@ -159,6 +163,12 @@ int tri_voxel_scatter(const int* locs, const float* feats, int n, int B, int V, 
  * RGB / 255; general_dataset.py:47-51,92-93) - no CPU COO build, no scatter.  mask must hold B*V^3 bytes (padded to 32). */
 int tri_voxel_from_rgba_u8(const uint8_t* rgba, int B, int V, void* dense, uint8_t* mask, int act_fmt, void* stream);
 int tri_mask_count(const uint8_t* mask, long n, int* count, void* stream);
+/* active-site list of a submanifold level: row_pos[0 .. *count) = positions with mask != 0, ascending; *count = how many.
+ * Hand row_pos + count to tri_conv_fwd / tri_conv_dgrad: they then compute (and write) ONLY those rows - executed work =
+ * active work (spconv's rulebook idea on a dense index space).  Layers that run split-K (tri_conv_kernel_family bit 16)
+ * take row_mask instead.  scratch: tri_mask_compact_scratch(n) bytes. */
+size_t tri_mask_compact_scratch(long n);
+int tri_mask_compact(const uint8_t* mask, long n, int* row_pos, int* count, void* scratch, void* stream);
 int tri_nchw3_to_nhwc4(const float* x, int N, int H, int W, void* out, int act_fmt, void* stream);
 /* u8 images [N,3,H,W] -> channels-last [N,H,W,4], (u8/255 - mean[c]) / std[c] as ToTensor + Normalize of
  * general_dataset.py:87-89; mean3 / std3 are HOST pointers to three floats. */

@@ -473,7 +473,7 @@ def test_fused_adam_state_dict_round_trip_and_device_lr():
     pr, orf = make(torch.optim.Adam)
     for p, gr in zip(pr, grads[0]):
         p.grad = gr.clone().to(DEV)
-    orf.step(); orf.step()
+    orf.step()                                                   # (the capture itself executes nothing)
     og.param_groups[0]["lr"] = orf.param_groups[0]["lr"] = 7e-5
     og.sync_lr()
     graph.replay()

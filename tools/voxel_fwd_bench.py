@@ -39,7 +39,7 @@ def main():
                         f"L0 HBM {r['level0_hbm']['achieved']:.0f} GB/s")
             for l in r["levels"]:
                 rows.append(f"    L{l['level']} {l['kernel']:34s} {l['grid']:3d}^3 {l['cin']:3d}->{l['cout']:3d}  active {l['active_sites']:8d}/{l['sites']:9d} sites, "
-                            f"{l['active_tiles']:6d}/{l['tiles']:6d} tiles  {l['ms']:.4f} ms  dense {l['dense_tflops']:7.1f}  executed {l['executed_tflops']:7.1f}  "
+                            f"{l['executed_tiles']:6d}/{l['tiles']:6d} tiles{'*' if l['compact_rows'] else ' '}  {l['ms']:.4f} ms  dense {l['dense_tflops']:7.1f}  executed {l['executed_tflops']:7.1f}  "
                             f"active-row {l['active_row_tflops']:6.1f} TF  {l['algorithmic_hbm_gbs']:7.1f} GB/s")
             del net
             torch.cuda.empty_cache()

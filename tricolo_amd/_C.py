@@ -46,8 +46,8 @@ SIGNATURES = {
     "tri_conv_workspace": (Z, [DP, I]),
     "tri_conv_kernel_family": (I, [DP, I, I]),
     "tri_conv_wgrad_kernel_family": (I, [DP, I]),
-    "tri_conv_fwd": (I, [DP, P, P, P, P, P, P, I, I, P, I, P, Z, P]),
-    "tri_conv_dgrad": (I, [DP, P, P, P, P, P, I, I, P, Z, P, P]),
+    "tri_conv_fwd": (I, [DP, P, P, P, P, P, P, I, I, P, I, P, Z, P, P, P]),
+    "tri_conv_dgrad": (I, [DP, P, P, P, P, P, I, I, P, Z, P, P, P]),
     "tri_conv_wgrad_workspace": (Z, [DP]),
     "tri_conv_plan_bytes": (Z, [DP]),
     "tri_conv_plan_build": (I, [DP, P, P]),
@@ -57,7 +57,7 @@ SIGNATURES = {
     "tri_bn_act": (I, [P, P, P, P, P, P, P, L, I, I, I, P]),
     "tri_relu_bwd": (I, [P, P, P, L, I, P]),
     "tri_bn_bwd_num_blocks": (I, [L]),
-    "tri_bn_bwd_reduce": (I, [P, P, L, I, P, P, P, P, I, P]),
+    "tri_bn_bwd_reduce": (I, [P, P, L, I, P, P, P, P, P, I, P]),
     "tri_bn_bwd_finalize": (I, [P, I, I, P, I, P, P, P, P, P, P, P, P, F, P]),
     "tri_bn_bwd_apply": (I, [P, P, P, P, P, P, P, L, I, P, P, P, P, I, P]),
     "tri_bn_relu_pool3d_fwd": (I, [P, P, P, P, I, I, I, P, P, I, P]),
@@ -70,6 +70,8 @@ SIGNATURES = {
     "tri_voxel_from_rgba_u8": (I, [P, I, I, P, P, I, P]),
     "tri_nchw3_u8_to_nhwc4": (I, [P, I, I, I, P, P, P, I, P]),
     "tri_mask_count": (I, [P, L, P, P]),
+    "tri_mask_compact_scratch": (Z, [L]),
+    "tri_mask_compact": (I, [P, L, P, P, P, P]),
     "tri_nchw3_to_nhwc4": (I, [P, I, I, I, P, I, P]),
     "tri_l2norm_fwd": (I, [P, I, I, F, P, P, P]),
     "tri_l2norm_bwd": (I, [P, P, P, I, I, F, P, P]),

@@ -18,32 +18,33 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int ntiles
                                    float* running_mean, float* running_var, long long* num_batches_tracked, float momentum,
                                    float eps, float* __restrict__ mean_out, float* __restrict__ invstd_out,
                                    float* __restrict__ scale_out, float* __restrict__ shift_out) {
-    // one channel per block, 256 record lanes: every load of the [ntiles][2][C] table is independent and in flight at
-    // once (the 4-channel x 64-lane version spent 12-30 us in a dependent-load chain on the 1,536 - 6,144 record layers)
-    __shared__ double ssum[4], ssq[4];
-    const int c = blockIdx.x;
-    // the finishing thread's operands are requested first: their latency then overlaps the record loads instead of
-    // following the reduction (these 50 launches per step are pure latency on the step's critical path)
+    // 16 channels per block (one 64-byte segment of every record row) x 64 record lanes: a wave-instruction then reads 4 whole
+    // 64-byte segments instead of 64 scattered dwords (the one-channel-per-block form touched a different cache line per lane:
+    // 6.3-6.7 us per launch, 50 launches per step on the critical path), and every load is still independent and in flight at once.
+    __shared__ double ssum[64][17], ssq[64][17];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    // the finishing threads' operands are requested first: their latency overlaps the record loads
     float pg = 0.f, pb = 0.f, prm = 0.f, prv = 0.f;
     int pcount = count_host;
-    if (threadIdx.x == 0) {
+    if (rl == 0 && c < C) {
         pg = gamma[c]; pb = beta[c];
         if (running_mean) { prm = running_mean[c]; prv = running_var[c]; }
         if (count_dev) pcount = *count_dev;
     }
     double s = 0.0, q = 0.0;
+    if (c < C)
 #pragma unroll 8
-    for (int tIdx = threadIdx.x; tIdx < ntiles; tIdx += 256) {
-        s += (double)partial[((size_t)tIdx * 2 + 0) * C + c];
-        q += (double)partial[((size_t)tIdx * 2 + 1) * C + c];
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
-    if ((threadIdx.x & 63) == 0) { ssum[threadIdx.x >> 6] = s; ssq[threadIdx.x >> 6] = q; }
+        for (int tIdx = rl; tIdx < ntiles; tIdx += 64) {
+            s += (double)partial[((size_t)tIdx * 2 + 0) * C + c];
+            q += (double)partial[((size_t)tIdx * 2 + 1) * C + c];
+        }
+    ssum[rl][cl] = s; ssq[rl][cl] = q;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        s = (ssum[0] + ssum[1]) + (ssum[2] + ssum[3]);
-        q = (ssq[0] + ssq[1]) + (ssq[2] + ssq[3]);
+    if (rl == 0 && c < C) {
+        s = 0.0; q = 0.0;
+#pragma unroll 8
+        for (int r = 0; r < 64; ++r) { s += ssum[r][cl]; q += ssq[r][cl]; }     // fixed order: bitwise reproducible
         double n = (double)pcount;
         if (n < 1.0) {                       // SparseSequential skips BN when there is no active site
             mean_out[c] = 0.f; invstd_out[c] = 0.f; scale_out[c] = 0.f; shift_out[c] = 0.f;
@@ -70,7 +71,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int ntiles
 extern "C" int tri_bn_finalize(const float* partial, int ntiles, int C, const int* count_dev, int count_host, const float* gamma,
                                const float* beta, float* running_mean, float* running_var, long long* num_batches_tracked,
                                float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, void* stream) {
-    bn_finalize_kernel<<<C, 256, 0, (hipStream_t)stream>>>(partial, ntiles, C, count_dev, count_host, gamma, beta,
+    bn_finalize_kernel<<<(C + 15) / 16, 1024, 0, (hipStream_t)stream>>>(partial, ntiles, C, count_dev, count_host, gamma, beta,
                                                                       running_mean, running_var, num_batches_tracked, momentum,
                                                                       eps, mean, invstd, scale, shift);
     return tri_check_launch("tri_bn_finalize");
@@ -151,7 +152,7 @@ static inline int bnb_rows(long M) { return M >= 65536 ? 256 : 64; }
 template <typename T, int MASK>
 __global__ void bn_bwd_reduce_kernel(const T* __restrict__ y, const T* __restrict__ g, long M, int C, float* __restrict__ partial,
                                      int BNB_ROWS, const float4* __restrict__ rs, const float4* __restrict__ rb,
-                                     const T* __restrict__ ro) {
+                                     const T* __restrict__ ro, const uint8_t* __restrict__ row_mask) {
     extern __shared__ float sh[];                      // [rows_per_pass][C4*4][2]
     const int C4 = C >> 2;
     const int tpr = C4 < 256 ? C4 : 256;               // threads per row
@@ -168,6 +169,7 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ y, const T* __restric
         if (c4 < C4 && tr < rpp)
 #pragma unroll 4
             for (long r = r0 + tr; r < r1; r += rpp) {
+                if (row_mask && !row_mask[r]) continue;          // inactive sites: y / g rows are not even written (compact conv rows)
                 float4 gv = Act<T>::ld4(g + r * C + c4 * 4), yv = Act<T>::ld4(y + r * C + c4 * 4);
                 if (MASK == 1) {
                     gv.x = __fmaf_rn(yv.x, s4.x, b4.x) > 0.f ? gv.x : 0.f; gv.y = __fmaf_rn(yv.y, s4.y, b4.y) > 0.f ? gv.y : 0.f;
@@ -204,7 +206,7 @@ extern "C" int tri_bn_bwd_num_blocks(long M) { return (int)((M + bnb_rows(M) - 1
 // the mask (y*scale + shift > 0, the forward's own expression) is recomputed instead of materialising relu_bwd's result.
 // relu_out (optional, same shape as y): the ReLU came after a residual add (BasicBlock output); its mask is out > 0.
 extern "C" int tri_bn_bwd_reduce(const void* y, const void* g, long M, int C, float* partial, const float* relu_scale,
-                                 const float* relu_shift, const void* relu_out, int act_fmt, void* stream) {
+                                 const float* relu_shift, const void* relu_out, const uint8_t* row_mask, int act_fmt, void* stream) {
     if (C % 4) { tri_set_error("tri_bn_bwd_reduce: C must be a multiple of 4"); return TRI_ERR_ARG; }
     int rows = bnb_rows(M);
     int nblk = (int)((M + rows - 1) / rows);
@@ -213,7 +215,7 @@ extern "C" int tri_bn_bwd_reduce(const void* y, const void* g, long M, int C, fl
     if (relu_scale && relu_out) { tri_set_error("tri_bn_bwd_reduce: give either relu_scale/shift or relu_out"); return TRI_ERR_ARG; }
 #define TRI_BNR(MASK_)                                                                                                              \
     TRI_ACT_DISPATCH(act_fmt, bn_bwd_reduce_kernel<T, MASK_><<<nblk, 256, smem, (hipStream_t)stream>>>(                             \
-        (const T*)y, (const T*)g, M, C, partial, rows, (const float4*)relu_scale, (const float4*)relu_shift, (const T*)relu_out))
+        (const T*)y, (const T*)g, M, C, partial, rows, (const float4*)relu_scale, (const float4*)relu_shift, (const T*)relu_out, row_mask))
     if (relu_out) TRI_BNR(2);
     else if (relu_scale) TRI_BNR(1);
     else TRI_BNR(0);
@@ -225,27 +227,28 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nb
                                        int count_host, const float* __restrict__ gamma, const float* __restrict__ mean,
                                        const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                        float* __restrict__ c1, float* __restrict__ c2, float* __restrict__ c3, float out_scale) {
-    __shared__ double ssum[4], ssq[4];                              // one channel per block, see bn_finalize_kernel
-    const int c = blockIdx.x;
+    __shared__ double ssum[64][17], ssq[64][17];                    // 16 channels x 64 record lanes per block, see bn_finalize_kernel
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     float pmu = 0.f, pis = 0.f, pga = 0.f;
     int pcount = count_host;
-    if (threadIdx.x == 0) {                                         // requested up front, see bn_finalize_kernel
+    if (rl == 0 && c < C) {                                         // requested up front, see bn_finalize_kernel
         pmu = mean[c]; pis = invstd[c]; pga = gamma[c];
         if (count_dev) pcount = *count_dev;
     }
     double s = 0.0, q = 0.0;
+    if (c < C)
 #pragma unroll 8
-    for (int b = threadIdx.x; b < nblk; b += 256) {
-        s += (double)partial[((size_t)b * 2 + 0) * C + c];
-        q += (double)partial[((size_t)b * 2 + 1) * C + c];
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
-    if ((threadIdx.x & 63) == 0) { ssum[threadIdx.x >> 6] = s; ssq[threadIdx.x >> 6] = q; }
+        for (int b = rl; b < nblk; b += 64) {
+            s += (double)partial[((size_t)b * 2 + 0) * C + c];
+            q += (double)partial[((size_t)b * 2 + 1) * C + c];
+        }
+    ssum[rl][cl] = s; ssq[rl][cl] = q;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        s = (ssum[0] + ssum[1]) + (ssum[2] + ssum[3]);
-        q = (ssq[0] + ssq[1]) + (ssq[2] + ssq[3]);
+    if (rl == 0 && c < C) {
+        s = 0.0; q = 0.0;
+#pragma unroll 8
+        for (int r = 0; r < 64; ++r) { s += ssum[r][cl]; q += ssq[r][cl]; }
         double n = (double)pcount;
         if (n < 1.0) { dgamma[c] = 0.f; dbeta[c] = 0.f; c1[c] = 0.f; c2[c] = 0.f; c3[c] = 0.f; return; }
         double mu = pmu, is = pis, ga = pga;
@@ -262,7 +265,7 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nb
 extern "C" int tri_bn_bwd_finalize(const float* partial, int nblk, int C, const int* count_dev, int count_host, const float* gamma,
                                    const float* mean, const float* invstd, float* dgamma, float* dbeta, float* c1, float* c2,
                                    float* c3, float out_scale, void* stream) {
-    bn_bwd_finalize_kernel<<<C, 256, 0, (hipStream_t)stream>>>(partial, nblk, C, count_dev, count_host, gamma, mean,
+    bn_bwd_finalize_kernel<<<(C + 15) / 16, 1024, 0, (hipStream_t)stream>>>(partial, nblk, C, count_dev, count_host, gamma, mean,
                                                                           invstd, dgamma, dbeta, c1, c2, c3, out_scale);
     return tri_check_launch("tri_bn_bwd_finalize");
 }
@@ -350,7 +353,8 @@ extern "C" int tri_bn_relu_pool3d_fwd(const void* y, const float* scale, const f
 }
 
 // g[B,D,D,D,C] = gradient w.r.t. the BN output: dpooled routed to the FIRST child (d,h,w scan order, as
-// torch.max_pool3d) whose post-ReLU value equals the pooled maximum and is > 0; zero elsewhere / at inactive sites.
+// torch.max_pool3d) whose post-ReLU value equals the pooled maximum and is > 0; zero elsewhere; rows of INACTIVE sites are
+// left unwritten (tri_bn_bwd_reduce / tri_bn_bwd_apply skip them by the same mask, the latter writes their zeros).
 // (with 16-bit storage the recomputed value is rounded like the stored maximum before the comparison)
 template <typename T>
 __global__ void pool3d_bwd_route_kernel(const T* __restrict__ y, const float4* __restrict__ scale, const float4* __restrict__ shift,
@@ -370,8 +374,9 @@ __global__ void pool3d_bwd_route_kernel(const T* __restrict__ y, const float4* _
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             long ip = (((long)b * D + (oz * 2 + (k >> 2))) * D + (oy * 2 + ((k >> 1) & 1))) * D + (ox * 2 + (k & 1));
+            if (!mask[ip]) continue;                   // rows of inactive sites are never read (bn_bwd reduce / apply skip them)
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (mask[ip]) {
+            {
                 float4 v = Act<T>::ld4(y + (ip * C4 + c) * 4);
                 float zx = fmaxf(__fmaf_rn(v.x, s.x, t.x), 0.f), zy = fmaxf(__fmaf_rn(v.y, s.y, t.y), 0.f);
                 float zz = fmaxf(__fmaf_rn(v.z, s.z, t.z), 0.f), zw = fmaxf(__fmaf_rn(v.w, s.w, t.w), 0.f);

@@ -21,7 +21,8 @@ struct ConvArgs {
     const void* w_lo;          // bf16 lo part (3-product mode) or NULL
     void* out;
     const uint8_t* row_mask;   // per output position; 0 -> row forced to zero, all-zero tiles are skipped
-    const int* row_pos;        // optional row -> output position table (conv_dma_kernel, no split-K): rows may be visited in any order
+    const int* row_pos;        // optional row -> output position table (no split-K): rows may be visited in any order
+    const int* row_count;      // optional DEVICE int: only rows [0, *row_count) of row_pos exist (compact active-site list)
     const float* bias;
     float* stats;              // [num_mtiles][2][Cout] per-tile column sum / sum of squares (BatchNorm statistics)
     float* slab;               // split-K partial sums [ksplit][M][Cout] (ksplit > 1)
@@ -44,7 +45,7 @@ __device__ __forceinline__ float row_ror(float v) {
 // Shared epilogue: acc[a][b][r] = out[m = a-tile row (lane & 15)][n = b-tile col 4 * (lane >> 4) + r].
 template <typename AT, int BN, int TM, int TN, int WAVES_M, int WM, int WN>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[TM][TN], int m0, int n0, int mtile, int wm, int wn, int fr,
-                                              int fq, int t, int split, int any_active, float* red) {
+                                              int fq, int t, int split, int any_active, float* red, int Meff) {
     if (p.ksplit > 1) {
         // split-K: raw partial sums only; conv_splitk_finish_kernel applies mask / bias / activation / statistics
         if (!any_active) return;
@@ -52,7 +53,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[TM
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
             int m = m0 + wm * WM + a * 16 + fr;
-            if (m < p.M)
+            if (m < Meff)
 #pragma unroll
                 for (int b = 0; b < TN; ++b) {
                     int n = n0 + wn * WN + b * 16 + fq * 4;
@@ -71,7 +72,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[TM
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
         const int m = m0 + wm * WM + a * 16 + fr;
-        if (m < p.M) {
+        if (m < Meff) {
             const float live = (p.row_mask && p.row_mask[m] == 0) ? 0.f : 1.f;
             const size_t mo = p.row_pos ? (size_t)p.row_pos[m] : (size_t)m;        // where this row lives in the output tensor
 #pragma unroll
@@ -164,6 +165,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     const int mtile = wg / NT, ntile = wg - mtile * NT;
     const int m0 = mtile * BM, n0 = ntile * BN;
     const int sshift = (p.stride == 2) ? 1 : 0;
+    const int Meff = p.row_count ? min(*p.row_count, p.M) : p.M;
+    if (m0 >= Meff) {                                   // tile past the end of the compact row list: empty statistics record, nothing else
+        if (p.stats && p.ksplit == 1 && t < BN) {
+            p.stats[((size_t)mtile * 2 + 0) * p.Cout + n0 + t] = 0.f;
+            p.stats[((size_t)mtile * 2 + 1) * p.Cout + n0 + t] = 0.f;
+        }
+        return;
+    }
 
     if (t < 64) {
         int kd = 0, kh = 0, kw = 0;
@@ -186,8 +195,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int m = m0 + (t >> 3) + 32 * i;
-        bool valid = m < p.M;
-        uint32_t mm = valid ? (uint32_t)m : 0u;
+        bool valid = m < Meff;
+        uint32_t mm = valid ? (uint32_t)(p.row_pos ? p.row_pos[m] : m) : 0u;      // output position of this tile row
         uint32_t q1 = fdiv(mm, p.dOW);
         int ow = mm - q1 * p.OW;
         uint32_t q2 = fdiv(q1, p.dOH);
@@ -353,7 +362,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
         }
     }
 
-    conv_epilogue<AT, BN, TM, TN, WAVES_M, WM, WN>(p, acc, m0, n0, mtile, wm, wn, fr, fq, t, split, any_active, red);
+    conv_epilogue<AT, BN, TM, TN, WAVES_M, WM, WN>(p, acc, m0, n0, mtile, wm, wn, fr, fq, t, split, any_active, red, Meff);
 }
 
 // byte offset of 16-byte chunk `chunk` of row `row` in a [rows][64 k] bf16 / f16 tile (128-B rows: 8 chunks, XOR with (row / 2) % 8)
@@ -398,6 +407,14 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs p) {
     const int mtile = wg / NT, ntile = wg - mtile * NT;
     const int m0 = mtile * BM, n0 = ntile * BN;
     const int sshift = (p.stride == 2) ? 1 : 0;
+    const int Meff = p.row_count ? min(*p.row_count, p.M) : p.M;
+    if (m0 >= Meff) {                                   // tile past the end of the compact row list (see conv_igemm_kernel)
+        if (p.stats && p.ksplit == 1 && t < BN) {
+            p.stats[((size_t)mtile * 2 + 0) * p.Cout + n0 + t] = 0.f;
+            p.stats[((size_t)mtile * 2 + 1) * p.Cout + n0 + t] = 0.f;
+        }
+        return;
+    }
 
     if (t < 64) {
         int kd = 0, kh = 0, kw = 0;
@@ -421,7 +438,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs p) {
     for (int i = 0; i < 4; ++i) {
         int row = (t >> 3) + 32 * i;
         int m = m0 + row;
-        bool valid = m < p.M;
+        bool valid = m < Meff;
         uint32_t mm = valid ? (uint32_t)(p.row_pos ? p.row_pos[m] : m) : 0u;       // output position of this tile row
         uint32_t q1 = fdiv(mm, p.dOW);
         int ow = mm - q1 * p.OW;
@@ -579,7 +596,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs p) {
         }
         __syncthreads();
     }
-    conv_epilogue<AT, BN, TM, TN, WAVES_M, WM, WN>(p, acc, m0, n0, mtile, wm, wn, fr, fq, t, split, any_active, red);
+    conv_epilogue<AT, BN, TM, TN, WAVES_M, WM, WN>(p, acc, m0, n0, mtile, wm, wn, fr, fq, t, split, any_active, red, Meff);
 }
 
 template <typename AT>
@@ -882,8 +899,17 @@ static int conv_dispatch(ConvArgs& a, int act_fmt, void* workspace, size_t works
         a.slab = (float*)workspace;
     }
     a.dOW = make_fastdiv(a.OW); a.dOH = make_fastdiv(a.OH); a.dOD = make_fastdiv(a.OD); a.dCin = make_fastdiv(a.Cin);
-    // row_pos is an optimisation hint: honoured by the DMA kernel without split-K, dropped (identity order) everywhere else
-    if (a.row_pos && !(pl.dma && pl.ksplit == 1 && !a.row_mask && !a.stats && a.Kpad / 64 <= 128)) a.row_pos = nullptr;
+    if (a.row_count) {
+        // compact row list (row_pos[0 .. *row_count) are the rows to compute): not an order hint, it changes WHICH rows run, so
+        // the kernel must honour it - any layer without split-K does (the split-K finish kernel walks positions, not the list)
+        if (!a.row_pos) { tri_set_error("conv: row_count needs row_pos"); return TRI_ERR_ARG; }
+        if (pl.ksplit > 1 || (pl.dma && a.Kpad / 64 > 128)) {
+            tri_set_error("conv: this layer runs split-K - pass row_mask instead of a compact row list (tri_conv_kernel_family bit 16)");
+            return TRI_ERR_ARG;
+        }
+    } else if (a.row_pos && !(pl.dma && pl.ksplit == 1 && !a.row_mask && !a.stats && a.Kpad / 64 <= 128)) {
+        a.row_pos = nullptr;          // a pure visiting-order hint: honoured by the DMA kernel without split-K, dropped elsewhere
+    }
     if (pl.dma) return act_fmt == TRI_FMT_F16 ? launch_dma_any<f16_t>(a, pl.bn, stream) : launch_dma_any<bf16_t>(a, pl.bn, stream);
 #define TRI_CONV(BN_)                                                                                     \
     (act_fmt == TRI_FMT_F16 ? launch_conv<BN_, 1, f16_t>(a, stream)                                       \
@@ -913,7 +939,7 @@ extern "C" int tri_conv_kernel_family(const TriConvDesc* d, int transposed, int 
                                               d->pad_d, d->pad_h, d->pad_w, split3)
                              : conv_make_plan(d->B, d->ID, d->IH, d->IW, d->Cin, d->OD, d->OH, d->OW, d->Cout, d->KD, d->KH, d->KW, d->stride,
                                               d->pad_d, d->pad_h, d->pad_w, split3);
-    return (pl.dma ? 2 : 0) | (pl.bn << 8);
+    return (pl.dma ? 2 : 0) | (pl.bn << 8) | ((pl.ksplit > 1 || (pl.dma && tri_conv_kpad(d->KD * d->KH * d->KW, transposed ? d->Cout : d->Cin) / 64 > 128)) ? (1 << 16) : 0);
 }
 
 // out[B,OD,OH,OW,Cout] = conv(in[B,ID,IH,IW,Cin], W) (+bias, act 0 none / 1 relu / 2 tanh); rows with row_mask==0 are
@@ -943,10 +969,10 @@ extern "C" size_t tri_conv_workspace(const TriConvDesc* d, int transposed) {
 
 extern "C" int tri_conv_fwd(const TriConvDesc* d, const void* in, const void* w_hi, const void* w_lo, void* out,
                             const uint8_t* row_mask, const float* bias, int act, int accumulate, float* stats, int act_fmt,
-                            void* workspace, size_t workspace_bytes, void* stream) {
+                            void* workspace, size_t workspace_bytes, const int* row_pos, const int* row_count, void* stream) {
     ConvArgs a{};
     a.in = in; a.w_hi = w_hi; a.w_lo = w_lo; a.out = out;
-    a.row_mask = row_mask; a.bias = bias; a.stats = stats;
+    a.row_mask = row_mask; a.bias = bias; a.stats = stats; a.row_pos = row_pos; a.row_count = row_count;
     a.B = d->B; a.ID = d->ID; a.IH = d->IH; a.IW = d->IW; a.Cin = d->Cin;
     a.OD = d->OD; a.OH = d->OH; a.OW = d->OW; a.Cout = d->Cout;
     a.KD = d->KD; a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pd = d->pad_d; a.ph = d->pad_h; a.pw = d->pad_w;
@@ -960,10 +986,10 @@ extern "C" int tri_conv_fwd(const TriConvDesc* d, const void* in, const void* w_
 // with swapped strides.  `d` is the FORWARD descriptor of the layer.
 extern "C" int tri_conv_dgrad(const TriConvDesc* d, const void* dout, const void* wt_hi, const void* wt_lo, void* din,
                               const uint8_t* row_mask, int accumulate, int act_fmt, void* workspace, size_t workspace_bytes,
-                              const int* row_pos, void* stream) {
+                              const int* row_pos, const int* row_count, void* stream) {
     ConvArgs a{};
     a.in = dout; a.w_hi = wt_hi; a.w_lo = wt_lo; a.out = din;
-    a.row_mask = row_mask; a.bias = nullptr; a.stats = nullptr; a.row_pos = row_pos;
+    a.row_mask = row_mask; a.bias = nullptr; a.stats = nullptr; a.row_pos = row_pos; a.row_count = row_count;
     a.B = d->B; a.ID = d->OD; a.IH = d->OH; a.IW = d->OW; a.Cin = d->Cout;       // gather source = dout grid
     a.OD = d->ID; a.OH = d->IH; a.OW = d->IW; a.Cout = d->Cin;                   // rows = input positions
     a.KD = d->KD; a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pd = d->pad_d; a.ph = d->pad_h; a.pw = d->pad_w;

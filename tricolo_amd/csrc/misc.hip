@@ -87,6 +87,84 @@ extern "C" int tri_mask_count(const uint8_t* mask, long n, int* count, void* str
     return tri_check_launch("tri_mask_count");
 }
 
+// Active-site list of a level: row_pos[0 .. count) = the positions p with mask[p] != 0 in ASCENDING order (deterministic),
+// *count = their number.  The submanifold convolutions then visit only these rows (tri_conv_fwd / tri_conv_dgrad with
+// row_pos + row_count): executed work = active work, instead of every 128-site tile that contains one active site.
+// Three small launches: per-block counts (2,048 sites per block), one-block exclusive scan, ordered write.
+#define CMP_SITES 2048
+__device__ __forceinline__ unsigned cmp_load8(const uint8_t* __restrict__ mask, long base, long n, unsigned long long* bits) {
+    unsigned long long v = 0;
+    if (base + 8 <= n) v = *(const unsigned long long*)(mask + base);            // mask buffers are 32-byte padded and aligned
+    else
+        for (int k = 0; k < 8; ++k)
+            if (base + k < n) v |= (unsigned long long)mask[base + k] << (8 * k);
+    unsigned cnt = 0;
+    unsigned long long nz = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if ((v >> (8 * k)) & 0xff) { ++cnt; nz |= 1ull << k; }
+    *bits = nz;
+    return cnt;
+}
+__global__ __launch_bounds__(256) void mask_block_count_kernel(const uint8_t* __restrict__ mask, long n, int* __restrict__ block_count) {
+    __shared__ int ws[4];
+    unsigned long long bits;
+    int c = (int)cmp_load8(mask, (long)blockIdx.x * CMP_SITES + threadIdx.x * 8, n, &bits);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_count[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+// exclusive scan of block_count[0 .. nb) in place; *count = total
+__global__ __launch_bounds__(1024) void mask_scan_kernel(int* __restrict__ block_count, int nb, int* __restrict__ count) {
+    __shared__ int part[1024];
+    const int t = threadIdx.x;
+    const int per = (nb + 1023) / 1024;
+    const int b0 = t * per, b1 = min(nb, b0 + per);
+    int s = 0;
+    for (int b = b0; b < b1; ++b) s += block_count[b];
+    part[t] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {                         // Hillis-Steele inclusive scan over the 1,024 partial sums
+        int v = t >= o ? part[t - o] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = part[t] - s;
+    for (int b = b0; b < b1; ++b) { int c = block_count[b]; block_count[b] = run; run += c; }
+    if (t == 1023) *count = part[1023];
+}
+__global__ __launch_bounds__(256) void mask_block_write_kernel(const uint8_t* __restrict__ mask, long n, const int* __restrict__ block_base,
+                                                               int* __restrict__ row_pos) {
+    __shared__ int ws[4];
+    unsigned long long bits;
+    const long base = (long)blockIdx.x * CMP_SITES + threadIdx.x * 8;
+    const int c = (int)cmp_load8(mask, base, n, &bits);
+    int incl = c;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+    if (lane == 63) ws[wave] = incl;
+    __syncthreads();
+    int off = block_base[blockIdx.x] + incl - c;
+    for (int w = 0; w < wave; ++w) off += ws[w];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if ((bits >> k) & 1ull) row_pos[off++] = (int)(base + k);
+}
+extern "C" size_t tri_mask_compact_scratch(long n) { return (size_t)((n + CMP_SITES - 1) / CMP_SITES + 1) * sizeof(int); }
+extern "C" int tri_mask_compact(const uint8_t* mask, long n, int* row_pos, int* count, void* scratch, void* stream) {
+    if (n < 1 || n >= ((long)1 << 31)) { tri_set_error("tri_mask_compact: 1 <= n < 2^31 sites"); return TRI_ERR_ARG; }
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = (int)((n + CMP_SITES - 1) / CMP_SITES);
+    mask_block_count_kernel<<<nb, 256, 0, s>>>(mask, n, (int*)scratch);
+    mask_scan_kernel<<<1, 1024, 0, s>>>((int*)scratch, nb, count);
+    mask_block_write_kernel<<<nb, 256, 0, s>>>(mask, n, (const int*)scratch, row_pos);
+    return tri_check_launch("tri_mask_compact");
+}
+
 // ------------------------------------------------------------------------------------------------ token embedding
 // emb[l][b][:] = W[tok[b][l]][:]   (bigru.py:15: embedding_layer(x).transpose(0, 1); padding row 0 of W is zero by init)
 __global__ void embedding_fwd_kernel(const int* __restrict__ tok, const float4* __restrict__ w, int B, int L, int D4,

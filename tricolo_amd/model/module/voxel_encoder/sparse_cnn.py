@@ -7,14 +7,17 @@ layout, sparseModel.{1,5,9,13,17}.{weight,bias,running_mean,running_var,num_batc
 One deliberate generalisation (SURVEY.md section 0.2): mlp[0].in_features = z_dim * (voxel_size // 32)**3 instead of
 the hard-coded 4096 (identical at 64^3, and makes the 32^3 configs of BASELINE.json runnable).
 
-MI355X design: the COO batch is scattered once into a dense channels-last grid + site mask; every SubMConv3d is a
-masked implicit-GEMM on MFMA (inactive 128-site tiles are skipped, inactive rows written as zeros); BatchNorm
-statistics come out of the conv epilogue; BN + ReLU + mask + 2^3 max-pool is one HBM pass.  Forward and backward
+MI355X design: the COO batch is scattered once into a dense channels-last grid + site mask; per level the active sites are
+listed in ascending order (tri_mask_compact) and every SubMConv3d / its data gradient is an implicit GEMM on MFMA over THAT
+row list - executed work = active work, rows of inactive sites are neither computed nor written and no consumer reads them
+(layers small enough to run split-K take the site mask instead: inactive 128-site tiles skipped, inactive rows zeroed);
+BatchNorm statistics come out of the conv epilogue; BN + ReLU + mask + 2^3 max-pool is one HBM pass.  Forward and backward
 of the whole tower are ONE autograd node, so a step costs a handful of Python calls and is HIP-graph capturable.
 """
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -97,25 +100,29 @@ class SparseCNNEncoder(TriModule):
             x, mask = ops.voxel_from_rgba(feats, dtype=ops.act_dtype(prec))
         else:
             x, mask = ops.voxel_scatter(locs, feats, B, V, dtype=ops.act_dtype(prec))
-        count = ops.mask_count(mask, B * V ** 3)
+        compact = os.environ.get("TRICOLO_VOXEL_COMPACT", "1") != "0"        # A/B switch: mask-only (tile skipping) path
+        rows = ops.mask_compact(mask, B * V ** 3)                             # (active positions ascending, device count)
+        count = rows[1]
         saved = {"levels": [], "B": B}
         for l in range(5):
             D, C = V >> l, self.chans[l + 1]
             g = self._geom(B, l)
             conv, bn = self.sparseModel[str(4 * l)], self.sparseModel[str(4 * l + 1)]
             packed = self._packed[(l, False)]
+            use_rows = compact and not g.splitk(False, ops._conv_mode(x, packed[1]))
+            sel = dict(rows=rows) if use_rows else dict(row_mask=mask)
             if train:
-                y, stats = ops.conv_fwd(x, g, packed, row_mask=mask, want_stats=True)
+                y, stats = ops.conv_fwd(x, g, packed, want_stats=True, **sel)
                 co = ops.bn_finalize(stats, C, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
                                      count_dev=count, momentum=bn.momentum, eps=bn.eps)
             else:
-                y = ops.conv_fwd(x, g, packed, row_mask=mask)
+                y = ops.conv_fwd(x, g, packed, **sel)
                 co = ops.bn_eval_coeffs(C, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
             pooled, mask_out = ops.bn_relu_pool3d_fwd(y, co, mask, B, D, C)
-            count_out = ops.mask_count(mask_out, B * (D // 2) ** 3)
+            rows_out = ops.mask_compact(mask_out, B * (D // 2) ** 3) if l < 4 else (None, None)
             if save:
-                saved["levels"].append((x, y, mask, count, co, pooled))
-            x, mask, count = pooled, mask_out, count_out
+                saved["levels"].append((x, y, mask, count, co, pooled, rows, use_rows))
+            x, mask, rows, count = pooled, mask_out, rows_out, rows_out[1]
         flat = ops.cast_to_f32(x.view(B, -1))                  # channels-last [B, v, v, v, C]; the head runs in fp32
         h = linear_fwd(flat, self.mlp[0].weight, self.mlp[0].bias, 1, prec, spatial=self.spatial)
         o = linear_fwd(h, self.mlp[2].weight, self.mlp[2].bias, 0, prec)
@@ -136,14 +143,18 @@ class SparseCNNEncoder(TriModule):
         for l in range(4, -1, -1):
             D, C = V >> l, self.chans[l + 1]
             g = self._geom(B, l)
-            x, y, mask, count, co, pooled = saved["levels"][l]
+            x, y, mask, count, co, pooled, rows, _ = saved["levels"][l]
             conv, bn = self.sparseModel[str(4 * l)], self.sparseModel[str(4 * l + 1)]
             gz = ops.pool3d_bwd_route(y, co, mask, pooled, dx.contiguous(), B, D, C)
             dy, dgamma, dbeta = ops.bn_bwd(y, gz, co, bn.weight, count_dev=count, row_mask=mask, out_scale=ugs)
             grads[3 * l] = ops.conv_wgrad(x, dy, g, conv.weight, prec, row_mask=mask, out_scale=ugs)
             grads[3 * l + 1], grads[3 * l + 2] = dgamma, dbeta
             if l > 0:
-                dx = ops.conv_dgrad(dy, g, self._packed[(l, True)], row_mask=mask)
+                pt = self._packed[(l, True)]
+                if os.environ.get("TRICOLO_VOXEL_COMPACT", "1") != "0" and not g.splitk(True, ops._conv_mode(dy, pt[1])):
+                    dx = ops.conv_dgrad(dy, g, pt, rows=rows)                   # only the active input sites are computed / written
+                else:
+                    dx = ops.conv_dgrad(dy, g, pt, row_mask=mask)
         return grads
 
     def forward(self, x, batch_size):

@@ -78,7 +78,7 @@ def _igemm_symbol(g, transposed, split, t):
     """Name of the kernel the C dispatch picks for this layer (what rocprofv3 reports), for the KernelTimer."""
     h16 = t.dtype != torch.float32
     code = g.kernel_family[(transposed, 1 if split else (2 if h16 else 0))]
-    fam, bn = code & 255, code >> 8
+    fam, bn = code & 255, (code >> 8) & 255
     if fam == 2:
         return f"conv_dma_kernel<{bn}, {3 if os.environ.get('TRICOLO_DMA_STAGES') == '3' else 2}, {_TNAME[t.dtype]}>"
     return f"conv_igemm_kernel<{bn}, {2 if split else 1}, {_TNAME[t.dtype]}>"
@@ -178,6 +178,11 @@ class ConvGeom:
             self._plans[("rowpos", device)] = t
         return t
 
+    def splitk(self, transposed: bool, mode: int) -> bool:
+        """True when tri_conv_fwd / tri_conv_dgrad runs this layer split-K in plan `mode` (_conv_mode): such launches take
+        row_mask, not a compact row list."""
+        return bool(self.kernel_family[(transposed, mode)] >> 16 & 1)
+
     def plan(self, device):
         """Gather plan (built once per geometry and device, reused by every step's wgrad)."""
         pl = self._plans.get(device)
@@ -256,7 +261,8 @@ class WeightPacker:
         return bufs
 
 
-def conv_fwd(x, g: ConvGeom, packed, row_mask=None, bias=None, act=0, want_stats=False, out=None, accumulate=False):
+def conv_fwd(x, g: ConvGeom, packed, row_mask=None, bias=None, act=0, want_stats=False, out=None, accumulate=False, rows=None):
+    """rows = (row_pos, count) from mask_compact: only those rows are computed and WRITTEN (submanifold layers; pass no row_mask)."""
     hi, lo = packed
     OD, OH, OW = g.out_grid
     if out is None:
@@ -267,25 +273,28 @@ def conv_fwd(x, g: ConvGeom, packed, row_mask=None, bias=None, act=0, want_stats
     check(_timed(_igemm_symbol(g, False, lo is not None, x), g.flops,
                  lambda: lib().tri_conv_fwd(_C.C.byref(g.desc), ptr(_act(x)), ptr(hi), ptr(lo), ptr(out), ptr(row_mask), ptr(bias),
                                             act, 1 if accumulate else 0, ptr(stats), _abf(x), ptr(ws),
-                                            ws.numel() if ws is not None else 0, stream())), "tri_conv_fwd")
+                                            ws.numel() if ws is not None else 0, ptr(rows[0]) if rows else None,
+                                            ptr(rows[1]) if rows else None, stream())), "tri_conv_fwd")
     return (out, stats) if want_stats else out
 
 
 _ROW_ORDER = os.environ.get("TRICOLO_NO_ROW_ORDER", "0") != "1"      # A/B switch: parity-class row order for stride-2 data gradients
 
 
-def conv_dgrad(dout, g: ConvGeom, packed_t, row_mask=None, out=None, accumulate=False):
+def conv_dgrad(dout, g: ConvGeom, packed_t, row_mask=None, out=None, accumulate=False, rows=None):
     hi, lo = packed_t
     ID, IH, IW = g.in_grid
     if out is None:
         out = torch.empty((g.B, ID, IH, IW, g.cin_stored), dtype=dout.dtype, device=dout.device)
     assert out.dtype == dout.dtype
     ws = _workspace(g.dgrad_ws, dout.device) if g.dgrad_ws else None
-    rowpos = g.dgrad_row_order(dout.device) if (row_mask is None and _ROW_ORDER) else None
+    rowpos = g.dgrad_row_order(dout.device) if (row_mask is None and rows is None and _ROW_ORDER) else None
+    if rows is not None:
+        rowpos = rows[0]
     check(_timed(_igemm_symbol(g, True, lo is not None, dout), g.flops,
                  lambda: lib().tri_conv_dgrad(_C.C.byref(g.desc), ptr(_act(dout)), ptr(hi), ptr(lo), ptr(out), ptr(row_mask),
                                               1 if accumulate else 0, _abf(dout), ptr(ws), ws.numel() if ws is not None else 0,
-                                              ptr(rowpos), stream())), "tri_conv_dgrad")
+                                              ptr(rowpos), ptr(rows[1]) if rows else None, stream())), "tri_conv_dgrad")
     return out
 
 
@@ -364,6 +373,7 @@ def relu_bwd(dout, out, inplace=True):
 
 def bn_bwd(y, g, co: BNCoeffs, gamma, count_dev=None, count_host=0, row_mask=None, inplace=True, relu=False, relu_out=None,
            g_masked=None, out_scale: float = 1.0):
+    # row_mask: rows with 0 are never read by either pass (their y / g may be unwritten) and come out as zeros in dy
     """Returns (dy, dgamma, dbeta).  g = gradient w.r.t. the BN output (already activation-masked), or - with relu=True -
     w.r.t. relu(bn(y)): the ReLU mask is then recomputed from y inside the two passes (no separate relu_bwd pass), or -
     with relu_out - w.r.t. relu(bn(y) + residual) whose saved output is relu_out; g_masked (may alias g) then receives
@@ -375,7 +385,7 @@ def bn_bwd(y, g, co: BNCoeffs, gamma, count_dev=None, count_host=0, row_mask=Non
     nblk = lib().tri_bn_bwd_num_blocks(M)
     partial = torch.empty((nblk, 2, C), dtype=torch.float32, device=y.device)
     assert y.dtype == g.dtype
-    check(lib().tri_bn_bwd_reduce(ptr(_act(y)), ptr(_act(g)), M, C, ptr(partial), ptr(rs), ptr(rb), ptr(relu_out), _abf(y), stream()),
+    check(lib().tri_bn_bwd_reduce(ptr(_act(y)), ptr(_act(g)), M, C, ptr(partial), ptr(rs), ptr(rb), ptr(relu_out), ptr(row_mask), _abf(y), stream()),
           "tri_bn_bwd_reduce")
     buf = torch.empty((5, C), dtype=torch.float32, device=y.device)
     check(lib().tri_bn_bwd_finalize(ptr(partial), nblk, C, ptr(count_dev), int(count_host), ptr(gamma), ptr(co.mean),
@@ -477,6 +487,15 @@ def voxel_from_rgba(rgba_u8, dtype=torch.float32):
     mask = torch.zeros(((sites + 31) // 32 * 32,), dtype=torch.uint8, device=rgba_u8.device)
     check(lib().tri_voxel_from_rgba_u8(ptr(rgba_u8.contiguous()), B, V, ptr(dense), ptr(mask), _abf(dense), stream()), "tri_voxel_from_rgba_u8")
     return dense, mask
+
+
+def mask_compact(mask, n):
+    """(row_pos [n] int32 - the first `count` entries are the active positions in ascending order, count [1] int32 on the device)."""
+    row_pos = torch.empty((n,), dtype=torch.int32, device=mask.device)
+    count = torch.empty((1,), dtype=torch.int32, device=mask.device)
+    scratch = torch.empty((lib().tri_mask_compact_scratch(n),), dtype=torch.uint8, device=mask.device)
+    check(lib().tri_mask_compact(ptr(mask), n, ptr(row_pos), ptr(count), ptr(scratch), stream()), "tri_mask_compact")
+    return row_pos, count
 
 
 def mask_count(mask, n):
