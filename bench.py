@@ -166,7 +166,10 @@ def voxel_fwd_roofline(net, batch, B, nrep=3):
         execd = 2 * tiles * 128 * 27 * cin * cout
         rowf = 2 * active * 27 * cin * cout
         e = x.element_size()
-        hbm = M * (4 if cin == 3 else cin) * e + M * cout * e            # input read once + output written once
+        cs = 4 if cin == 3 else cin
+        # algorithmic HBM bytes: every needed input row once + every written output row once.  Over a compact row list only the
+        # active sites' rows are written and (up to the 3^3 halo, counted as one extra shell = x2) read; a dense pass moves all M rows
+        hbm = (min(M, 2 * active) * cs + active * cout) * e if used_rows else M * (cs + cout) * e
         levels.append({"level": l, "kernel": recs[l][0], "grid": D, "cin": cin, "cout": cout, "sites": M, "active_sites": active,
                        "tiles": (M + 127) // 128, "executed_tiles": tiles, "compact_rows": bool(used_rows), "ms": round(ms, 4), "dense_tflops": round(dense / ms / 1e9, 1),
                        "executed_tflops": round(execd / ms / 1e9, 1), "active_row_tflops": round(rowf / ms / 1e9, 1),
@@ -180,7 +183,8 @@ def voxel_fwd_roofline(net, batch, B, nrep=3):
             "frac_dense_equivalent": round(tot_dense / tot_ms / 1e9 / MFMA_PEAK_TFLOPS, 4),
             "level0_hbm": {"bound": "hbm", "achieved": l0["algorithmic_hbm_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(l0["algorithmic_hbm_gbs"] / HBM_PEAK_GBS, 4),
-                           "note": "level 0 (3 -> 32 channels, 74 FLOP/B) is HBM-bound: bytes = input once + output once"},
+                           "note": "level 0 (3 -> 32 channels, 74 FLOP/B) is HBM-bound: bytes = needed input rows once + written output "
+                                   "rows once (active sites only when the level runs over the compact row list)"},
             "levels": levels}
 
 

@@ -161,7 +161,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int NT = p.Cout / BN;
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    // compact row lists fill only the first ceil(count / 128) tiles: the XCD remap would hand that contiguous range to ONE XCD
+    // (measured: level 0 at 64^3 x 64 took 0.88 ms on an eighth of the chip against 0.67 ms for the 2.6x more tiles of the
+    // tile-skipping path), so those launches keep the dispatcher's round-robin order
+    const int wg = p.row_count ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
     const int mtile = wg / NT, ntile = wg - mtile * NT;
     const int m0 = mtile * BM, n0 = ntile * BN;
     const int sshift = (p.stride == 2) ? 1 : 0;
@@ -403,7 +406,10 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs p) {
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int NT = p.Cout / BN;
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    // compact row lists fill only the first ceil(count / 128) tiles: the XCD remap would hand that contiguous range to ONE XCD
+    // (measured: level 0 at 64^3 x 64 took 0.88 ms on an eighth of the chip against 0.67 ms for the 2.6x more tiles of the
+    // tile-skipping path), so those launches keep the dispatcher's round-robin order
+    const int wg = p.row_count ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
     const int mtile = wg / NT, ntile = wg - mtile * NT;
     const int m0 = mtile * BM, n0 = ntile * BN;
     const int sshift = (p.stride == 2) ? 1 : 0;

@@ -66,6 +66,8 @@ class MVCNNEncoder(TriModule):
         self.__dict__["_packed"] = {}
         self.__dict__["_side"] = SideStream("img")
         self.__dict__["_side_ds"] = SideStream("imgds")         # down-sample branch of layer2-4's first block
+        self.__dict__["split_backward"] = False                 # True: lower / upper halves are separate autograd nodes (DP overlap)
+        self.__dict__["split_tensor"] = None
 
     def _prec(self):
         return self.precision or ops.default_precision()
@@ -131,12 +133,41 @@ class MVCNNEncoder(TriModule):
             co = ops.bn_eval_coeffs(g.cout, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
         return y, co, g
 
-    def _forward_impl(self, images, save: bool):
+    # The tower is written as a LOWER half (stem, layer1, layer2 -> feature map x2) and an UPPER half (layer3, layer4, pool,
+    # heads).  Single-GPU steps run both inside ONE autograd node; the data-parallel step can ask for two nodes
+    # (split_backward = True): 96 % of the tower's gradient bytes (layer3-4 + heads) are then final when the upper node's
+    # backward returns and are all-reduced under the lower half's backward (parallel.dp_training_step).
+    N_LOWER_BLOCKS = 4
+
+    def _lower_params(self):
+        return self._param_list()[:3 + sum(9 if b.downsample is not None else 6 for b in self._blocks()[:self.N_LOWER_BLOCKS])]
+
+    def _upper_params(self):
+        return self._param_list()[len(self._lower_params()):]
+
+    def _run_block(self, blk, x, prec, train, save, store):
+        ds = blk.downsample is not None
+        if ds:                                                 # 1x1/2 conv + BN of the shortcut: independent of conv1 / conv2
+            with torch.cuda.stream(self._side_ds.fork(x)):
+                yd, cod, gd = self._conv_bn(x, blk.downsample[0], blk.downsample[1], prec, train)
+        y1, co1, g1 = self._conv_bn(x, blk.conv1, blk.bn1, prec, train)
+        a1 = ops.bn_act(y1, co1, relu=True)
+        y2, co2, g2 = self._conv_bn(a1, blk.conv2, blk.bn2, prec, train)
+        if ds:
+            self._side_ds.join(yd, cod.scale, cod.shift)
+            out = ops.bn_act(y2, co2, relu=True, res=yd, res_co=cod)
+        else:
+            yd = cod = gd = None
+            out = ops.bn_act(y2, co2, relu=True, res=x)
+        if save:
+            store.append((x, y1, co1, g1, a1, y2, co2, g2, yd, cod, gd, out))
+        return out
+
+    def _forward_lower(self, images, save: bool):
         prec, train = self._prec(), self.training
         N = images.shape[0]
         if N % self.num_views:
             raise RuntimeError("mat shape: number of images is not a multiple of num_views")
-        B = N // self.num_views
         self._packed = self._pack_all(N, images.shape[2], images.shape[3], prec, train and save, images.device)
         if images.dtype == torch.uint8:                         # raw renderings: ToTensor + CLIP Normalize on the device (8f-2)
             x0 = ops.nchw3_u8_to_nhwc4(images, dtype=ops.act_dtype(prec))
@@ -144,24 +175,18 @@ class MVCNNEncoder(TriModule):
             x0 = ops.nchw3_to_nhwc4(images, dtype=ops.act_dtype(prec))
         y, co, g = self._conv_bn(x0, self.net_1[0], self.net_1[1], prec, train)
         x, parg = ops.maxpool2d_fwd(y, want_arg=save, bn=co)            # BN + ReLU + 3x3/2 max-pool: relu(bn(y)) is never stored
-        saved = {"stem": (x0, y, co, g, parg), "blocks": [], "B": B, "N": N}
-        for blk in self._blocks():
-            ds = blk.downsample is not None
-            if ds:                                                 # 1x1/2 conv + BN of the shortcut: independent of conv1 / conv2
-                with torch.cuda.stream(self._side_ds.fork(x)):
-                    yd, cod, gd = self._conv_bn(x, blk.downsample[0], blk.downsample[1], prec, train)
-            y1, co1, g1 = self._conv_bn(x, blk.conv1, blk.bn1, prec, train)
-            a1 = ops.bn_act(y1, co1, relu=True)
-            y2, co2, g2 = self._conv_bn(a1, blk.conv2, blk.bn2, prec, train)
-            if ds:
-                self._side_ds.join(yd, cod.scale, cod.shift)
-                out = ops.bn_act(y2, co2, relu=True, res=yd, res_co=cod)
-            else:
-                yd = cod = gd = None
-                out = ops.bn_act(y2, co2, relu=True, res=x)
-            if save:
-                saved["blocks"].append((x, y1, co1, g1, a1, y2, co2, g2, yd, cod, gd, out))
-            x = out
+        saved = {"stem": (x0, y, co, g, parg), "blocks": [], "N": N}
+        for blk in self._blocks()[:self.N_LOWER_BLOCKS]:
+            x = self._run_block(blk, x, prec, train, save, saved["blocks"])
+        return x, saved
+
+    def _forward_upper(self, x, save: bool):
+        prec, train = self._prec(), self.training
+        N = x.shape[0]
+        B = N // self.num_views
+        saved = {"blocks": [], "B": B, "N": N}
+        for blk in self._blocks()[self.N_LOWER_BLOCKS:]:
+            x = self._run_block(blk, x, prec, train, save, saved["blocks"])
         pooled, arg = ops.avgpool_viewmax_fwd(x, B, self.num_views)
         f = linear_fwd(pooled, self.net_2.weight, self.net_2.bias, 0, prec)
         h = linear_fwd(f, self.mlp[0].weight, self.mlp[0].bias, 1, prec)
@@ -171,20 +196,14 @@ class MVCNNEncoder(TriModule):
             saved.update(feat_shape=tuple(x.shape), pooled=pooled, arg=arg, f=f, h=h, o=o, z=zz, norm=norm)
         return zz, saved
 
-    def _backward_impl(self, saved, dz):
-        prec, B, N = self._prec(), saved["B"], saved["N"]
-        gr = {}
-        do = ops.l2norm_bwd(saved["z"], saved["norm"], dz)
-        dh, gr[self.mlp[2].weight], gr[self.mlp[2].bias] = linear_bwd(saved["h"], self.mlp[2].weight, saved["o"], do, 0, prec)
-        df, gr[self.mlp[0].weight], gr[self.mlp[0].bias] = linear_bwd(saved["f"], self.mlp[0].weight, saved["h"], dh, 1, prec)
-        dp, gr[self.net_2.weight], gr[self.net_2.bias] = linear_bwd(saved["pooled"], self.net_2.weight, saved["f"], df, 0, prec)
-        # f16 mode: activation gradients are carried times gs (ops.F16_GRAD_SCALE); parameter-gradient kernels undo it
-        gs = ops.grad_scale(prec)
-        ugs = 1.0 / gs
-        dout = ops.avgpool_viewmax_bwd(dp, saved["arg"], saved["feat_shape"], B, self.num_views, dtype=ops.act_dtype(prec), scale=gs)
-        blocks = self._blocks()
-        side = self._side
+    def _forward_impl(self, images, save: bool):
+        x2, lo = self._forward_lower(images, save)
+        zz, hi = self._forward_upper(x2, save)
+        return zz, {"lower": lo, "upper": hi}
 
+    def _backward_blocks(self, blocks, saved_blocks, dout, gr, prec, ugs):
+        """BasicBlock backward over `blocks` (last first); returns the gradient w.r.t. the first block's input."""
+        side = self._side
         # Weight gradients need only x and dy and could run beside the dgrad / BatchNorm-backward chain on a side stream
         # (TRICOLO_WG_PATTERN=s; =sm alternates).  Measured with the round-1 kernels that is a LOSS: two GPU-filling kernels
         # side by side thrash each other (all on the side stream 4.23 ms per step, alternating 4.09-4.15, all inline 3.93-3.97),
@@ -201,7 +220,7 @@ class MVCNNEncoder(TriModule):
             with torch.cuda.stream(side.fork(x, dy)):
                 gr[w] = ops.conv_wgrad(x, dy, g, w, prec, out_scale=ugs)
 
-        for blk, sv in zip(reversed(blocks), reversed(saved["blocks"])):
+        for blk, sv in zip(reversed(blocks), reversed(saved_blocks)):
             x, y1, co1, g1, a1, y2, co2, g2, yd, cod, gd, out = sv
             # relu(bn2(y2) + residual) backward inside the BN passes; g = dout * (out > 0) (gradient of the pre-activation sum,
             # also the residual branch's gradient) is written by the apply pass in place of dout
@@ -225,16 +244,45 @@ class MVCNNEncoder(TriModule):
                 dx = g                                                         # identity branch
             dx = ops.conv_dgrad(dy1, g1, self._packed[(id(blk.conv1), True)], out=dx, accumulate=True)
             dout = dx
+        side.join(*[v for v in gr.values() if v.dim() == 4])
+        return dout
+
+    def _backward_upper(self, saved, dz):
+        """-> (gradient w.r.t. the lower half's output x2 - carried times ops.grad_scale in the f16 mode -, upper parameter grads)."""
+        prec, B = self._prec(), saved["B"]
+        gr = {}
+        do = ops.l2norm_bwd(saved["z"], saved["norm"], dz)
+        dh, gr[self.mlp[2].weight], gr[self.mlp[2].bias] = linear_bwd(saved["h"], self.mlp[2].weight, saved["o"], do, 0, prec)
+        df, gr[self.mlp[0].weight], gr[self.mlp[0].bias] = linear_bwd(saved["f"], self.mlp[0].weight, saved["h"], dh, 1, prec)
+        dp, gr[self.net_2.weight], gr[self.net_2.bias] = linear_bwd(saved["pooled"], self.net_2.weight, saved["f"], df, 0, prec)
+        # f16 mode: activation gradients are carried times gs (ops.F16_GRAD_SCALE); parameter-gradient kernels undo it
+        gs = ops.grad_scale(prec)
+        dout = ops.avgpool_viewmax_bwd(dp, saved["arg"], saved["feat_shape"], B, self.num_views, dtype=ops.act_dtype(prec), scale=gs)
+        dx2 = self._backward_blocks(self._blocks()[self.N_LOWER_BLOCKS:], saved["blocks"], dout, gr, prec, 1.0 / gs)
+        return dx2, [gr[p] for p in self._upper_params()]
+
+    def _backward_lower(self, saved, dout):
+        prec = self._prec()
+        ugs = 1.0 / ops.grad_scale(prec)
+        gr = {}
+        dout = self._backward_blocks(self._blocks()[:self.N_LOWER_BLOCKS], saved["blocks"], dout, gr, prec, ugs)
         x0, y, co, g0, parg = saved["stem"]
         dzs = ops.maxpool2d_bwd(parg, dout, tuple(y.shape))
         dy, gr[self.net_1[1].weight], gr[self.net_1[1].bias] = ops.bn_bwd(y, dzs, co, self.net_1[1].weight, count_host=g0.M, relu=True, out_scale=ugs)
-        wgrad_async(x0, dy, g0, self.net_1[0].weight)
-        side.join(*[gr[p] for p in self._param_list() if p.dim() == 4])
-        return [gr[p] for p in self._param_list()]
+        gr[self.net_1[0].weight] = ops.conv_wgrad(x0, dy, g0, self.net_1[0].weight, prec, out_scale=ugs)
+        return [gr[p] for p in self._lower_params()]
+
+    def _backward_impl(self, saved, dz):
+        dx2, up = self._backward_upper(saved["upper"], dz)
+        return self._backward_lower(saved["lower"], dx2) + up
 
     def forward(self, x, data_dict=None):
         require_gpu(x, "MVCNNEncoder")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            if self.split_backward:                               # two autograd nodes; the feature map between them is exposed
+                x2 = _MVCNNLowerFn.apply(self, x, *self._lower_params())
+                self.__dict__["split_tensor"] = x2
+                return _MVCNNUpperFn.apply(self, x2, *self._upper_params())
             return _MVCNNTowerFn.apply(self, x, *self._param_list())
         z, _ = self._forward_impl(x, save=False)
         return z
@@ -252,3 +300,33 @@ class _MVCNNTowerFn(torch.autograd.Function):
         grads = ctx.module._backward_impl(ctx.saved, dz.contiguous())
         ctx.saved = None
         return (None, None, *grads)
+
+
+class _MVCNNLowerFn(torch.autograd.Function):
+    """stem + layer1 + layer2 as their own autograd node (data-parallel gradient overlap, see MVCNNEncoder.split_backward)."""
+
+    @staticmethod
+    def forward(ctx, module, images, *params):
+        x2, saved = module._forward_lower(images, save=True)
+        ctx.module, ctx.saved = module, saved
+        return x2
+
+    @staticmethod
+    def backward(ctx, dx2):
+        grads = ctx.module._backward_lower(ctx.saved, dx2.contiguous())
+        ctx.saved = None
+        return (None, None, *grads)
+
+
+class _MVCNNUpperFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, x2, *params):
+        z, saved = module._forward_upper(x2, save=True)
+        ctx.module, ctx.saved = module, saved
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        dx2, grads = ctx.module._backward_upper(ctx.saved, dz.contiguous())
+        ctx.saved = None
+        return (None, dx2, *grads)
