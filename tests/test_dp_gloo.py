@@ -58,6 +58,19 @@ def _worker(rank, world, port, out_dir):
     flat2 = flat.clone() / 2
     parallel.allreduce_flat(flat2)                                # SUM of two halves == the already-reduced gradient
     res = {"total": total.item(), "flat_ok": bool(torch.allclose(flat2, flat, rtol=1e-6, atol=1e-8))}
+    # the overlapped two-stage backward (parallel.backward_overlapped): cut at the output of layer2 of the image tower, the early
+    # parameters' gradient ranges all-reduced asynchronously while the part below the cut still runs - same reduced gradient
+    cut = {}
+    enc = net.image_encoder
+    hook = enc.net_1[5].register_forward_hook(lambda m, i, o: cut.__setitem__("x", o))
+    late = [p for idx in (0, 1, 4, 5) for p in enc.net_1[idx].parameters()]
+    split = parallel.BackwardSplit(net, late, lambda: cut["x"])
+    glob2 = parallel.gather_embeddings(net(shard))
+    hook.remove()
+    total2 = sum(om.nt_xent_ref(glob2[a], glob2[b], 0.1, 0.25) for a, b in combinations(glob2.keys(), 2))
+    flat3 = parallel.backward_overlapped(total2, split, list(net.parameters()))
+    res["overlap_ok"] = bool(torch.allclose(flat3, flat, rtol=1e-5, atol=1e-7))
+    res["overlap_late_fraction"] = sum(p.numel() for p in late) / flat.numel()
     res.update({f"loss/{k}": v for k, v in per_pair.items()})
     for k, v in glob.items():
         res[f"emb/{k}"] = v.detach().numpy()
@@ -77,6 +90,7 @@ def test_dp2_gather_and_gradient_allreduce_match_reference(golden, tmp_path):
     for r in (r0, r1):
         assert abs(float(r["total"]) - float(g["total_loss"])) < 2e-5                    # identical global loss on every rank
         assert bool(r["flat_ok"])
+        assert bool(r["overlap_ok"]) and float(r["overlap_late_fraction"]) < 0.06       # two-bucket path == single bucket
         for k in ("text_image", "text_voxel", "image_voxel"):
             assert abs(float(r[f"loss/{k}"]) - float(g[f"loss/{k}"])) < 2e-5
         for k in ("text_features", "image_features", "voxel_features"):

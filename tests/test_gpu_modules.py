@@ -282,6 +282,21 @@ def test_graph_split_dp_step_equals_eager_dp_step(monkeypatch):
         graphed = warm + [gstep.replay().item() for _ in range(3)]
         np.testing.assert_allclose(graphed, eager, rtol=2e-4, atol=2e-4)
         assert eager[-1] < eager[0]
+        # the overlapped variant: image tower as two autograd nodes, backward in two stages around the exposed feature map, the
+        # early gradient ranges reduced asynchronously under the second stage - eagerly and as four graphs
+        net_c, _ = _build_net("BiGRUEncoder", "MVCNNEncoder", "SparseCNNEncoder", 32, 2, 64)
+        opt_c = net_c.configure_optimizers()
+        opt_c.prepare()
+        split = parallel.BackwardSplit.for_net(net_c)
+        assert split is not None and len(split.late_params) == 30
+        n_late = sum(p.numel() for p in split.late_params)
+        n_all = sum(p.numel() for p in net_c.parameters())
+        assert n_late < 0.06 * n_all                                         # > 94 % of the gradient bytes reduce early
+        over = [parallel.dp_training_step(net_c, batch, opt_c, split=split)["train_loss/total_loss"].item() for _ in range(2)]
+        torch.cuda.synchronize()
+        gover = parallel.GraphedDPStep(net_c, opt_c, batch, split=split)
+        over += [gover.replay().item() for _ in range(3)]
+        np.testing.assert_allclose(over, eager, rtol=2e-4, atol=2e-4)
     finally:
         dist.destroy_process_group()
 

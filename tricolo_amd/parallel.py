@@ -175,7 +175,7 @@ def dp_training_step(net, batch, optimizer=None, split: BackwardSplit | None = N
 
 
 class GraphedDPStep:
-    """The data-parallel step as THREE HIP graphs with the two collectives issued eagerly between them:
+    """The data-parallel step as HIP graphs with the collectives issued eagerly between them:
 
         graph A   towers forward -> packed local embeddings [B_local, 512 * n_mod]
         eager     all_gather_into_tensor(full, packed)                      (RCCL over xGMI)
@@ -183,19 +183,28 @@ class GraphedDPStep:
         eager     all_reduce(flat gradient, SUM)
         graph C   fused Adam on the flat buffers
 
+    With `split` (BackwardSplit.for_net) graph B is cut in two at the image tower's layer2 / layer3 boundary:
+
+        graph B1  loss, backward of the text / voxel towers and of the image tower's upper half, pack of those gradients
+        eager     all_reduce(early ranges of the flat gradient, async)      <- 96 % of the bytes, runs UNDER graph B2
+        graph B2  backward of stem + layer1 + layer2, pack of the late range
+        eager     all_reduce(late range, async); wait for both
+
     Collectives are deliberately NOT captured (RCCL under hipGraph capture cannot be validated on a one-GPU box); the
-    ~400 kernel launches of the step are, so a replayed step costs three graph launches + two collectives on the host
+    ~400 kernel launches of the step are, so a replayed step costs a few graph launches + the collectives on the host
     instead of ~7 ms of Python launch overhead.  The graphs share one memory pool: activations saved by graph A's forward
     are consumed by graph B's backward.  One instance per resident batch (inputs are static)."""
 
-    def __init__(self, net, optimizer, batch):
+    def __init__(self, net, optimizer, batch, split: BackwardSplit | None = None):
         if not getattr(optimizer, "_flatten", False):
             raise RuntimeError("GraphedDPStep needs FusedAdam(flatten=True)")
-        self.net, self.opt = net, optimizer
+        self.net, self.opt, self.split = net, optimizer, split
         world, rank = dist.get_world_size(), dist.get_rank()
         pool = torch.cuda.graph_pool_handle()
         self.gA, self.gB, self.gC = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        self.gB2 = torch.cuda.CUDAGraph() if split is not None else None
         optimizer.zero_grad(set_to_none=True)
+        optimizer.prepare()
         # thread_local: the process group's watchdog thread keeps polling events of earlier collectives while this thread
         # captures; under the default global mode that poll is an illegal call and aborts the process
         mode = dict(pool=pool, capture_error_mode="thread_local")
@@ -207,6 +216,11 @@ class GraphedDPStep:
         rows = packed.shape[0]
         self.packed = packed
         self.full = torch.zeros((world * rows, packed.shape[1]), dtype=packed.dtype, device=packed.device)
+        order = optimizer._params
+        if split is not None:
+            self.early_runs, total_n = _runs(split.early_params, order)
+            self.late_runs, _ = _runs(split.late_params, order)
+            self.flat = torch.zeros((total_n,), dtype=torch.float32, device=packed.device)
         with torch.cuda.graph(self.gB, **mode):
             leaf = self.full.detach().requires_grad_()
             glob, off = {}, 0
@@ -216,9 +230,25 @@ class GraphedDPStep:
             losses = net._calculate_losses(glob, "train_loss")
             total = losses["train_loss/total_loss"]
             (dfull,) = torch.autograd.grad(total, leaf)                 # identical on every rank: no reduce-scatter needed
-            packed.backward(dfull[rank * rows:(rank + 1) * rows].contiguous())
-            self.flat = optimizer.flat_grad()
+            dlocal = dfull[rank * rows:(rank + 1) * rows].contiguous()
+            if split is None:
+                packed.backward(dlocal)
+                self.flat = optimizer.flat_grad()
+            else:
+                x = split.split_tensor()
+                g1 = torch.autograd.grad(packed, split.early_params + [x], grad_outputs=dlocal, allow_unused=True)
+                gmap = {id(p): g for p, g in zip(split.early_params, g1[:-1])}
+                for s_, e_, ps in self.early_runs:
+                    torch.cat([(gmap[id(p)] if gmap[id(p)] is not None else torch.zeros_like(p)).reshape(-1) for p in ps],
+                              out=self.flat[s_:e_])
             self.loss = total.detach()
+        if split is not None:
+            with torch.cuda.graph(self.gB2, **mode):
+                g2 = torch.autograd.grad(x, split.late_params, grad_outputs=g1[-1], allow_unused=True)
+                gmap = {id(p): g for p, g in zip(split.late_params, g2)}
+                for s_, e_, ps in self.late_runs:
+                    torch.cat([(gmap[id(p)] if gmap[id(p)] is not None else torch.zeros_like(p)).reshape(-1) for p in ps],
+                              out=self.flat[s_:e_])
         with torch.cuda.graph(self.gC, **mode):
             optimizer.apply_flat(self.flat)
 
@@ -226,6 +256,13 @@ class GraphedDPStep:
         self.gA.replay()
         dist.all_gather_into_tensor(self.full, self.packed)
         self.gB.replay()
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        if self.split is None:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        else:
+            hs = [dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, async_op=True) for s, e, _ in self.early_runs]
+            self.gB2.replay()                                           # runs while the early ranges are being reduced
+            hs += [dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, async_op=True) for s, e, _ in self.late_runs]
+            for h in hs:
+                h.wait()
         self.gC.replay()
         return self.loss
