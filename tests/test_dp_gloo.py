@@ -58,13 +58,16 @@ def _worker(rank, world, port, out_dir):
     flat2 = flat.clone() / 2
     parallel.allreduce_flat(flat2)                                # SUM of two halves == the already-reduced gradient
     res = {"total": total.item(), "flat_ok": bool(torch.allclose(flat2, flat, rtol=1e-6, atol=1e-8))}
+    for name, p in net.named_parameters():
+        n, s = probe(p.grad)
+        res[f"gradnorm/{name}"] = n
     # the overlapped two-stage backward (parallel.backward_overlapped): cut at the output of layer2 of the image tower, the early
     # parameters' gradient ranges all-reduced asynchronously while the part below the cut still runs - same reduced gradient
-    cut = {}
     enc = net.image_encoder
-    hook = enc.net_1[5].register_forward_hook(lambda m, i, o: cut.__setitem__("x", o))
     late = [p for idx in (0, 1, 4, 5) for p in enc.net_1[idx].parameters()]
-    split = parallel.BackwardSplit(net, late, lambda: cut["x"])
+    split = parallel.BackwardSplit(net, late)
+    hook = enc.net_1[5].register_forward_hook(lambda m, i, o: split.gate(o))      # the gate replaces layer2's output
+    net.zero_grad(set_to_none=True)
     glob2 = parallel.gather_embeddings(net(shard))
     hook.remove()
     total2 = sum(om.nt_xent_ref(glob2[a], glob2[b], 0.1, 0.25) for a, b in combinations(glob2.keys(), 2))
@@ -74,9 +77,6 @@ def _worker(rank, world, port, out_dir):
     res.update({f"loss/{k}": v for k, v in per_pair.items()})
     for k, v in glob.items():
         res[f"emb/{k}"] = v.detach().numpy()
-    for name, p in net.named_parameters():
-        n, s = probe(p.grad)
-        res[f"gradnorm/{name}"] = n
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **res)
     dist.destroy_process_group()
 

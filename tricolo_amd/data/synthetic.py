@@ -215,35 +215,40 @@ def collate_items(items, voxel: bool, views: bool) -> dict:
 
 # ------------------------------------------------------------------------------------------------------
 # Held-out retrieval set (SURVEY.md section 8d "Held-out retrieval set"): shapes are COMPOSITIONS of a few factors
-# (colour, part kind, size, octant); voxels, renderings and caption tokens are all functions of the factors plus
-# per-instance noise, so a model trained on one draw of shapes retrieves UNSEEN shapes of the same factor space.
+# (body colour, body kind, body size, colour of a small second part); voxels, renderings and caption tokens are all
+# functions of the factors plus per-instance noise, so a model trained on one draw of shapes retrieves UNSEEN shapes of
+# the same factor space.  (A position factor was tried first and dropped: five conv + max-pool levels down to one site
+# make the towers translation-invariant by construction - 84 % of the oracle's held-out errors were octant confusions.)
 # ------------------------------------------------------------------------------------------------------
-FACTOR_SIZES = (8, 2, 4, 8)                       # colour, kind (box / ellipsoid), size class, octant -> 512 combinations
+FACTOR_SIZES = (8, 2, 4, 8)                       # body colour, kind (box / ellipsoid), size class, cap colour -> 512 combinations
 _PALETTE = ((220, 40, 40), (40, 200, 60), (50, 70, 230), (230, 210, 50), (200, 60, 210), (60, 210, 220), (240, 140, 40), (150, 150, 150))
 
 
 def factor_words(f, vocab_size: int = DEFAULT_VOCAB):
     """One vocabulary word per factor value (disjoint ranges)."""
-    c, k, s, o = f
-    return [10 + c, 30 + k, 50 + s, 70 + o]
+    c, k, s, c2 = f
+    return [10 + c, 30 + k, 50 + s, 70 + c2]
 
 
 def make_factor_shape(rng: np.random.Generator, f, V: int, num_views: int | None, S: int):
     """(RGBA u8 grid [4,V,V,V], u8 views [nv,3,S,S] | None) of one instance of factor combination f."""
-    c, k, s, o = f
+    c, k, s, c2 = f
     half0 = max(2, V * (3 + 2 * s) // 32)                              # size class -> half extent (3, 5, 7, 9 at 32^3)
     half = np.array([half0 + int(rng.integers(0, 2)) for _ in range(3)])
-    q = V // 4
-    cen = np.array([q + (V // 2) * ((o >> 2) & 1), q + (V // 2) * ((o >> 1) & 1), q + (V // 2) * (o & 1)]) + rng.integers(-1, 2, size=3)
-    base = np.array(_PALETTE[c])
-    attrs = {"nparts": 1, "half": half[None], "cen": cen[None], "kind": np.array([k]), "base": base[None]}
+    cen = np.array([V * 13 // 32, V // 2, V // 2]) + rng.integers(-1, 2, size=3)
+    hcap = np.array([max(2, V // 16)] * 3)
+    ccap = cen + np.array([half[0] + hcap[0] + 1, 0, 0])               # the cap sits on top of the body (never overlaps it)
+    base, base2 = np.array(_PALETTE[c]), np.array(_PALETTE[c2])
+    attrs = {"nparts": 2, "half": np.stack([half, hcap]), "cen": np.stack([cen, ccap]), "kind": np.array([k, 0]),
+             "base": np.stack([base, base2])}
     grid = make_voxel_grid_u8(rng, V, attrs)
     imgs = None
     if num_views:
         img_attr = np.zeros((num_views, 3, 4), dtype=np.int64)
         for v in range(num_views):
+            col = base if v % 2 == 0 else base2                         # even views show the body colour, odd views the cap colour
             for ch in range(3):
-                img_attr[v, ch] = (1 + s, 1 + (o % 4) + k, (o >> 2) + v, 40 + base[ch] * 140 // 255)
+                img_attr[v, ch] = (1 + s, 1 + 2 * k, v, 40 + col[ch] * 140 // 255)
         imgs = make_images_u8(rng, num_views, S, {"img": img_attr})
     return grid, imgs
 

@@ -66,8 +66,7 @@ class MVCNNEncoder(TriModule):
         self.__dict__["_packed"] = {}
         self.__dict__["_side"] = SideStream("img")
         self.__dict__["_side_ds"] = SideStream("imgds")         # down-sample branch of layer2-4's first block
-        self.__dict__["split_backward"] = False                 # True: lower / upper halves are separate autograd nodes (DP overlap)
-        self.__dict__["split_tensor"] = None
+        self.__dict__["split"] = None                           # parallel.BackwardSplit: lower / upper halves as separate autograd nodes
 
     def _prec(self):
         return self.precision or ops.default_precision()
@@ -134,9 +133,10 @@ class MVCNNEncoder(TriModule):
         return y, co, g
 
     # The tower is written as a LOWER half (stem, layer1, layer2 -> feature map x2) and an UPPER half (layer3, layer4, pool,
-    # heads).  Single-GPU steps run both inside ONE autograd node; the data-parallel step can ask for two nodes
-    # (split_backward = True): 96 % of the tower's gradient bytes (layer3-4 + heads) are then final when the upper node's
-    # backward returns and are all-reduced under the lower half's backward (parallel.dp_training_step).
+    # heads).  Single-GPU steps run both inside ONE autograd node; the data-parallel step installs a parallel.BackwardSplit
+    # (self.split) and gets two nodes with the split's gradient gate between them: 96 % of the tower's gradient bytes (layer3-4
+    # + heads) are then final when the upper node's backward returns and are all-reduced under the lower half's backward
+    # (parallel.dp_training_step).
     N_LOWER_BLOCKS = 4
 
     def _lower_params(self):
@@ -279,10 +279,9 @@ class MVCNNEncoder(TriModule):
     def forward(self, x, data_dict=None):
         require_gpu(x, "MVCNNEncoder")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            if self.split_backward:                               # two autograd nodes; the feature map between them is exposed
+            if self.split is not None:                            # two autograd nodes with the split's gate between them
                 x2 = _MVCNNLowerFn.apply(self, x, *self._lower_params())
-                self.__dict__["split_tensor"] = x2
-                return _MVCNNUpperFn.apply(self, x2, *self._upper_params())
+                return _MVCNNUpperFn.apply(self, self.split.gate(x2), *self._upper_params())
             return _MVCNNTowerFn.apply(self, x, *self._param_list())
         z, _ = self._forward_impl(x, save=False)
         return z
@@ -308,11 +307,14 @@ class _MVCNNLowerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, images, *params):
         x2, saved = module._forward_lower(images, save=True)
-        ctx.module, ctx.saved = module, saved
+        ctx.module, ctx.saved, ctx.nparams = module, saved, len(params)
+        ctx.set_materialize_grads(False)
         return x2
 
     @staticmethod
     def backward(ctx, dx2):
+        if dx2 is None:                                           # the gate above is deferring: this node runs in stage 2
+            return (None, None) + (None,) * ctx.nparams
         grads = ctx.module._backward_lower(ctx.saved, dx2.contiguous())
         ctx.saved = None
         return (None, None, *grads)

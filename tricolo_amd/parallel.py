@@ -81,25 +81,41 @@ def allreduce_flat(flat: torch.Tensor) -> None:
 
 class BackwardSplit:
     """Where the backward pass can be cut so that the gradient all-reduce of everything ABOVE the cut overlaps the backward of
-    what lies BELOW it.  `late_params` belong to the part below the cut (they get their gradients last), `split_tensor()` returns
-    the activation at the cut of the forward that just ran.  For TriCoLoNet on the HIP modules: the image tower's stem + layer1 +
-    layer2 (4 % of the model's gradient bytes) lie below the feature map MVCNNEncoder exposes when split_backward is set; the
-    text tower, the voxel tower and layer3-4 + heads of the image tower (96 %) are reduced while that part still runs."""
+    what lies BELOW it.  The forward pass routes the activation at the cut through gate(), which hands the upper part a detached
+    leaf: stage 1 (an ordinary backward from the loss) then ends there with d loss / d cut in the leaf's .grad and never touches
+    the graph below; stage 2 is an ordinary backward from the cut tensor with that gradient.  A plain loss.backward() on a
+    module with an installed split would silently skip the lower part - the leaf's hook raises instead.  `late_params` belong
+    to the part below (they get their gradients last).  For TriCoLoNet on the HIP modules: the image tower's stem + layer1 + layer2 (4 % of the
+    model's gradient bytes) lie below the gate MVCNNEncoder installs when it is given a split; the text tower, the voxel tower
+    and layer3-4 + heads of the image tower (96 %) are reduced while that part still runs."""
 
-    def __init__(self, net, late_params, split_tensor):
+    def __init__(self, net, late_params):
         self.late_params = list(late_params)
         late = {id(p) for p in self.late_params}
         self.early_params = [p for p in net.parameters() if p.requires_grad and id(p) not in late]
-        self.split_tensor = split_tensor
+        self.defer, self.cut, self.leaf = False, None, None
+
+    def _check(self, g):
+        if not self.defer:
+            raise RuntimeError("this module has a parallel.BackwardSplit installed: run its backward through "
+                               "parallel.backward_overlapped / dp_training_step(split=...) (stage 1 + stage 2), not loss.backward()")
+        return g
+
+    def gate(self, x):
+        self.cut = x
+        self.leaf = x.detach().requires_grad_()
+        self.leaf.register_hook(self._check)
+        return self.leaf
 
     @staticmethod
     def for_net(net):
         """The split of a tricolo_amd TriCoLoNet with an MVCNNEncoder image tower (None when there is nothing to split)."""
         enc = getattr(net, "image_encoder", None)
-        if enc is None or not hasattr(enc, "split_backward"):
+        if enc is None or not hasattr(enc, "_lower_params"):
             return None
-        enc.split_backward = True
-        return BackwardSplit(net, enc._lower_params(), lambda: enc.split_tensor)
+        split = BackwardSplit(net, enc._lower_params())
+        enc.__dict__["split"] = split
+        return split
 
 
 def _runs(params, order):
@@ -122,27 +138,44 @@ def _runs(params, order):
     return runs, off
 
 
+def _pack(params, out):
+    torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params], out=out)
+
+
+def backward_stage1(root, grad_root, split: BackwardSplit):
+    """Backward from `root` down to the gate: everything above the cut gets its .grad, the gate keeps d root / d cut."""
+    if split.leaf is None:
+        raise RuntimeError("BackwardSplit: the forward pass did not go through the gate (is the split installed in the module?)")
+    split.defer = True
+    try:
+        torch.autograd.backward(root, grad_root)
+    finally:
+        split.defer = False
+
+
+def backward_stage2(split: BackwardSplit):
+    """The part below the gate, from the gradient stage 1 left there."""
+    torch.autograd.backward(split.cut, split.leaf.grad)
+    split.cut = split.leaf = None
+
+
 def backward_overlapped(total, split: BackwardSplit, order, flat=None):
-    """Backward of `total` in two stages around split.split_tensor(), the SUM all-reduce of the early parameters' gradients
+    """Backward of `total` in two stages around the split's gate, the SUM all-reduce of the early parameters' gradients
     issued asynchronously between them.  `order` = the parameters in flat-buffer order (FusedAdam's); returns the flat,
-    fully reduced gradient (every rank holds d L_global / d theta)."""
-    dev = order[0].device
+    fully reduced gradient (every rank holds d L_global / d theta).  Both stages are ordinary autograd.backward() calls."""
     early_runs, total_n = _runs(split.early_params, order)
     late_runs, _ = _runs(split.late_params, order)
     if flat is None:
-        flat = torch.empty((total_n,), dtype=torch.float32, device=dev)
-    x = split.split_tensor()
-    g1 = torch.autograd.grad(total, split.early_params + [x], allow_unused=True)
-    gmap = {id(p): g for p, g in zip(split.early_params, g1[:-1])}
+        flat = torch.empty((total_n,), dtype=torch.float32, device=order[0].device)
     handles = []
+    backward_stage1(total, None, split)
     for s, e, ps in early_runs:
-        torch.cat([(gmap[id(p)] if gmap[id(p)] is not None else torch.zeros_like(p)).reshape(-1) for p in ps], out=flat[s:e])
+        _pack(ps, flat[s:e])
         if is_dist():
             handles.append(dist.all_reduce(flat[s:e], op=dist.ReduceOp.SUM, async_op=True))     # runs under stage 2
-    g2 = torch.autograd.grad(x, split.late_params, grad_outputs=g1[-1], allow_unused=True)
-    gmap = {id(p): g for p, g in zip(split.late_params, g2)}
+    backward_stage2(split)
     for s, e, ps in late_runs:
-        torch.cat([(gmap[id(p)] if gmap[id(p)] is not None else torch.zeros_like(p)).reshape(-1) for p in ps], out=flat[s:e])
+        _pack(ps, flat[s:e])
         if is_dist():
             handles.append(dist.all_reduce(flat[s:e], op=dist.ReduceOp.SUM, async_op=True))
     for h in handles:
@@ -235,20 +268,15 @@ class GraphedDPStep:
                 packed.backward(dlocal)
                 self.flat = optimizer.flat_grad()
             else:
-                x = split.split_tensor()
-                g1 = torch.autograd.grad(packed, split.early_params + [x], grad_outputs=dlocal, allow_unused=True)
-                gmap = {id(p): g for p, g in zip(split.early_params, g1[:-1])}
+                backward_stage1(packed, dlocal, split)
                 for s_, e_, ps in self.early_runs:
-                    torch.cat([(gmap[id(p)] if gmap[id(p)] is not None else torch.zeros_like(p)).reshape(-1) for p in ps],
-                              out=self.flat[s_:e_])
+                    _pack(ps, self.flat[s_:e_])
             self.loss = total.detach()
         if split is not None:
             with torch.cuda.graph(self.gB2, **mode):
-                g2 = torch.autograd.grad(x, split.late_params, grad_outputs=g1[-1], allow_unused=True)
-                gmap = {id(p): g for p, g in zip(split.late_params, g2)}
+                backward_stage2(split)
                 for s_, e_, ps in self.late_runs:
-                    torch.cat([(gmap[id(p)] if gmap[id(p)] is not None else torch.zeros_like(p)).reshape(-1) for p in ps],
-                              out=self.flat[s_:e_])
+                    _pack(ps, self.flat[s_:e_])
         with torch.cuda.graph(self.gC, **mode):
             optimizer.apply_flat(self.flat)
 
