@@ -199,10 +199,12 @@ def run_mode(a, precision, world, rank, device, want_voxel_roofline):
     batches = make_batches(a, rank, device, a.resident_batches)
     force_dist = os.environ.get("TRICOLO_FORCE_DIST", "0") == "1"
 
-    # N > 1: the image tower runs as two autograd nodes so that the all-reduce of 96 % of the gradient bytes overlaps the rest of
-    # the backward (parallel.BackwardSplit); TRICOLO_DP_OVERLAP=0 keeps the single-bucket step
+    # N > 1, TRICOLO_DP_OVERLAP=1: two-stage backward (parallel.BackwardSplit) - the all-reduce of the early two thirds of the
+    # gradient bytes runs under the second stage.  Off by default: on ONE GPU the cut costs 0.45 ms of GPU time per step (two
+    # graphs instead of one: 1.78 + 1.51 ms against 2.85 ms, profiles/r2/README.md), about what the hidden part of the 74 MB
+    # all-reduce is expected to take at 8 GPUs - without a multi-GPU box to measure on, the simpler single-bucket step stays.
     split = None
-    if (world > 1 or force_dist) and os.environ.get("TRICOLO_DP_OVERLAP", "1") != "0":
+    if (world > 1 or force_dist) and os.environ.get("TRICOLO_DP_OVERLAP", "0") == "1":
         split = parallel.BackwardSplit.for_net(net)
 
     def step(batch):

@@ -288,10 +288,10 @@ def test_graph_split_dp_step_equals_eager_dp_step(monkeypatch):
         opt_c = net_c.configure_optimizers()
         opt_c.prepare()
         split = parallel.BackwardSplit.for_net(net_c)
-        assert split is not None and len(split.late_params) == 30
+        assert split is not None and len(split.late_params) == 30 + 19        # image stem + layer1-2, and the voxel tower
         n_late = sum(p.numel() for p in split.late_params)
         n_all = sum(p.numel() for p in net_c.parameters())
-        assert n_late < 0.06 * n_all                                         # > 94 % of the gradient bytes reduce early
+        assert n_late < 0.35 * n_all                                         # two thirds of the gradient bytes reduce early
         over = [parallel.dp_training_step(net_c, batch, opt_c, split=split)["train_loss/total_loss"].item() for _ in range(2)]
         torch.cuda.synchronize()
         gover = parallel.GraphedDPStep(net_c, opt_c, batch, split=split)

@@ -29,4 +29,22 @@ g = parallel.GraphedDPStep(net, opt, batch, split=split)
 print("captured", flush=True)
 for i in range(3):
     print("replay", g.replay().item(), flush=True)
+import time
+for name, gg in (("split", g),) + ((("single", g0),) if os.environ.get("FIRST", "0") == "1" else ()):
+    for _ in range(20): gg.replay()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(50): gg.replay()
+    t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+    print(f"{name}: host enqueue {(t1 - t0) / 50 * 1e3:.3f} ms/step, total {(t2 - t0) / 50 * 1e3:.3f} ms/step", flush=True)
+    # pieces of the split replay on the host
+    if name == "split":
+        import torch.distributed as dist
+        def tm(fn, n=50):
+            torch.cuda.synchronize(); a = time.perf_counter()
+            for _ in range(n): fn()
+            b = time.perf_counter(); torch.cuda.synchronize(); return (b - a) / n * 1e3, (time.perf_counter() - a) / n * 1e3
+        print("gA", tm(gg.gA.replay), "gB", tm(gg.gB.replay), "gB2", tm(gg.gB2.replay), "gC", tm(gg.gC.replay))
+        print("allgather", tm(lambda: dist.all_gather_into_tensor(gg.full, gg.packed)))
+        s_, e_, _ = gg.early_runs[-1]
+        print("allreduce sync", tm(lambda: dist.all_reduce(gg.flat[s_:e_])), "async+wait", tm(lambda: dist.all_reduce(gg.flat[s_:e_], async_op=True).wait()))
 dist.destroy_process_group()

@@ -60,6 +60,7 @@ class TriCoLoNet(TriModule):
         self.loss_fn = _instantiate(getattr(cfg.loss, cfg.loss.name))
         self.val_test_step_outputs = []
         self.overlap_towers = os.environ.get("TRICOLO_OVERLAP", "1") != "0"
+        self.__dict__["dp_split"] = None            # parallel.BackwardSplit (data-parallel gradient overlap): gates the voxel output
         self.__dict__["_side_streams"] = None
 
     # Lightning supplies .hparams / log_dict / log / print when present; minimal stand-ins otherwise
@@ -95,7 +96,7 @@ class TriCoLoNet(TriModule):
             if self.image_encoder is not None:
                 output_dict["image_features"] = self.image_encoder(data_dict["images"].flatten(end_dim=1), data_dict)
             if self.voxel_encoder is not None:
-                output_dict["voxel_features"] = self.voxel_encoder(data_dict["voxels"], len(data_dict["model_id"]))
+                output_dict["voxel_features"] = self._gate(self.voxel_encoder(data_dict["voxels"], len(data_dict["model_id"])))
             return output_dict
         main = torch.cuda.current_stream()
         if self._side_streams is None:
@@ -108,7 +109,7 @@ class TriCoLoNet(TriModule):
         if self.voxel_encoder is not None:
             s_vox.wait_stream(main)
             with torch.cuda.stream(s_vox):
-                vox = self.voxel_encoder(data_dict["voxels"], len(data_dict["model_id"]))
+                vox = self._gate(self.voxel_encoder(data_dict["voxels"], len(data_dict["model_id"])))
         img = self.image_encoder(data_dict["images"].flatten(end_dim=1), data_dict)
         main.wait_stream(s_text)
         text.record_stream(main)
@@ -118,6 +119,9 @@ class TriCoLoNet(TriModule):
             vox.record_stream(main)
             output_dict["voxel_features"] = vox
         return output_dict
+
+    def _gate(self, z):
+        return self.dp_split.gate(z) if (self.dp_split is not None and torch.is_grad_enabled() and z.requires_grad) else z
 
     def _calculate_losses(self, output_dict, loss_prefix):
         loss_dict = {}

@@ -85,15 +85,18 @@ class BackwardSplit:
     leaf: stage 1 (an ordinary backward from the loss) then ends there with d loss / d cut in the leaf's .grad and never touches
     the graph below; stage 2 is an ordinary backward from the cut tensor with that gradient.  A plain loss.backward() on a
     module with an installed split would silently skip the lower part - the leaf's hook raises instead.  `late_params` belong
-    to the part below (they get their gradients last).  For TriCoLoNet on the HIP modules: the image tower's stem + layer1 + layer2 (4 % of the
-    model's gradient bytes) lie below the gate MVCNNEncoder installs when it is given a split; the text tower, the voxel tower
-    and layer3-4 + heads of the image tower (96 %) are reduced while that part still runs."""
+    to the part below (they get their gradients last).  Several gates may be open in one forward pass (stage 2 then runs
+    from all cuts at once).  For TriCoLoNet on the HIP modules there are two: inside the image tower between layer2 and layer3
+    (MVCNNEncoder installs it when it is given a split) and at the voxel tower's output (TriCoLoNet.forward).  Stage 1 = text
+    tower + image layer3-4 + heads (68 % of the gradient bytes, reduced while stage 2 runs); stage 2 = image stem + layer1-2
+    beside the whole voxel tower on its own stream - measured on one GPU, a single gate inside the image tower cost 0.43 ms per
+    step because the voxel tower's backward, no longer hidden under the image tower's, then bounded stage 1."""
 
     def __init__(self, net, late_params):
         self.late_params = list(late_params)
         late = {id(p) for p in self.late_params}
         self.early_params = [p for p in net.parameters() if p.requires_grad and id(p) not in late]
-        self.defer, self.cut, self.leaf = False, None, None
+        self.defer, self.cuts, self.leaves, self._open = False, [], [], False
 
     def _check(self, g):
         if not self.defer:
@@ -102,10 +105,13 @@ class BackwardSplit:
         return g
 
     def gate(self, x):
-        self.cut = x
-        self.leaf = x.detach().requires_grad_()
-        self.leaf.register_hook(self._check)
-        return self.leaf
+        if not self._open:                                   # first gate of a new forward pass
+            self.cuts, self.leaves, self._open = [], [], True
+        leaf = x.detach().requires_grad_()
+        leaf.register_hook(self._check)
+        self.cuts.append(x)
+        self.leaves.append(leaf)
+        return leaf
 
     @staticmethod
     def for_net(net):
@@ -113,8 +119,13 @@ class BackwardSplit:
         enc = getattr(net, "image_encoder", None)
         if enc is None or not hasattr(enc, "_lower_params"):
             return None
-        split = BackwardSplit(net, enc._lower_params())
+        late = list(enc._lower_params())
+        vox = getattr(net, "voxel_encoder", None)
+        if vox is not None:
+            late += [p for p in vox.parameters() if p.requires_grad]
+        split = BackwardSplit(net, late)
         enc.__dict__["split"] = split
+        net.__dict__["dp_split"] = split                     # TriCoLoNet.forward gates the voxel tower's output
         return split
 
 
@@ -144,8 +155,9 @@ def _pack(params, out):
 
 def backward_stage1(root, grad_root, split: BackwardSplit):
     """Backward from `root` down to the gate: everything above the cut gets its .grad, the gate keeps d root / d cut."""
-    if split.leaf is None:
-        raise RuntimeError("BackwardSplit: the forward pass did not go through the gate (is the split installed in the module?)")
+    if not split.leaves:
+        raise RuntimeError("BackwardSplit: the forward pass did not go through a gate (is the split installed in the module?)")
+    split._open = False
     split.defer = True
     try:
         torch.autograd.backward(root, grad_root)
@@ -155,8 +167,8 @@ def backward_stage1(root, grad_root, split: BackwardSplit):
 
 def backward_stage2(split: BackwardSplit):
     """The part below the gate, from the gradient stage 1 left there."""
-    torch.autograd.backward(split.cut, split.leaf.grad)
-    split.cut = split.leaf = None
+    torch.autograd.backward(split.cuts, [l.grad for l in split.leaves])
+    split.cuts, split.leaves = [], []
 
 
 def backward_overlapped(total, split: BackwardSplit, order, flat=None):
