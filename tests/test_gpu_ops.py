@@ -601,6 +601,15 @@ BF16_CASES = [c for c in CONV_CASES if c[0] in ("vox_l0", "vox_l1", "vox_l3", "s
     # Cin % 64 == 0 layers run the LDS-DMA kernel in this mode; these two fill the GPU (no split-K) / use Cout % 128 != 0
     ("big_nosplit", 12, (1, 64, 64), 64, 64, (1, 3, 3), 1, (0, 1, 1), "torch"),
     ("cout192", 2, (1, 12, 12), 128, 192, (1, 3, 3), 1, (0, 1, 1), "torch"),
+    # conv_halo2d_kernel geometries (2D 3x3 / 1 / pad 1): several whole images per tile with a partial last tile, 4x4 images,
+    # rows that do not divide the tile (14, 20, 56 wide), two channel chunks / two output-channel tiles, a persistent
+    # workgroup that walks several tiles
+    ("h_8x8", 5, (1, 8, 8), 128, 128, (1, 3, 3), 1, (0, 1, 1), "torch"),
+    ("h_4x4", 7, (1, 4, 4), 256, 64, (1, 3, 3), 1, (0, 1, 1), "torch"),
+    ("h_14", 3, (1, 14, 14), 64, 128, (1, 3, 3), 1, (0, 1, 1), "torch"),
+    ("h_28x20", 2, (1, 28, 20), 64, 64, (1, 3, 3), 1, (0, 1, 1), "torch"),
+    ("h_56", 1, (1, 56, 56), 64, 64, (1, 3, 3), 1, (0, 1, 1), "torch"),
+    ("h_many", 40, (1, 32, 32), 64, 64, (1, 3, 3), 1, (0, 1, 1), "torch"),
 ]
 
 
@@ -626,6 +635,19 @@ def test_conv_16bit_storage_integer_exact(case, store, prec):
     if case[3] != 3:
         dx = ops.conv_dgrad(cl3(dy).to(DEV).to(store), g, ops.pack_weight(wp.to(DEV), g, prec, transposed=True))
         assert torch.equal(dx.cpu(), cl3(xr.grad).to(store))
+    if case[5] == (1, 3, 3) and case[6] == 1:
+        # the resolution-keeping 3x3 layers (conv_halo2d_kernel): BatchNorm partial sums of the stored values, and the
+        # accumulate epilogue the residual branch of a BasicBlock uses
+        out2, stats = ops.conv_fwd(xcl.to(DEV).to(store), g, packed, want_stats=True)
+        assert torch.equal(out2.cpu(), ref.to(store))
+        exact = ref.to(store).double().reshape(-1, case[4])
+        st = stats.cpu().double().sum(0)
+        np.testing.assert_allclose(st[0].numpy(), exact.sum(0).numpy(), rtol=1e-6, atol=1e-2)
+        np.testing.assert_allclose(st[1].numpy(), (exact ** 2).sum(0).numpy(), rtol=1e-6, atol=1e-2)
+        base = ints(tuple(cl3(xr.grad).shape), -5, 5, 59)
+        dx2 = ops.conv_dgrad(cl3(dy).to(DEV).to(store), g, ops.pack_weight(wp.to(DEV), g, prec, transposed=True),
+                             out=base.clone().to(DEV).to(store), accumulate=True)
+        assert torch.equal(dx2.cpu(), (cl3(xr.grad) + base).to(store))
 
 
 @pytest.mark.parametrize("store,prec", STORE16, ids=STORE16_IDS)

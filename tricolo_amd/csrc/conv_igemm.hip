@@ -33,7 +33,8 @@ struct ConvArgs {
     int Kpad, M, ntaps, cin_shift, ksplit, steps_per_split;
     unsigned in_bytes;
     int nunits;
-    FastDiv dOW, dOH, dOD, dCin;
+    int h_tr, h_rows, h_slab_bytes, h_nr, h_mtiles;    // halo kernel: image rows per tile, slab rows, slab bytes, ring slots, row tiles
+    FastDiv dOW, dOH, dOD, dCin, dP, dH2;
 };
 
 // v rotated right by N lanes inside its row of 16 lanes (DPP row_ror)
@@ -605,6 +606,179 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs p) {
     conv_epilogue<AT, BN, TM, TN, WAVES_M, WM, WN>(p, acc, m0, n0, mtile, wm, wn, fr, fq, t, split, any_active, red, Meff);
 }
 
+
+// ================================================================================================ halo kernel (2D, 3x3 / 1 / pad 1)
+// Every BasicBlock conv of ResNet-18 that keeps its resolution (16 of the 20 convs, and their data gradients) is a 3x3,
+// stride-1, pad-1 convolution.  conv_dma_kernel gathers their im2col rows tap by tap: each input pixel crosses the L2 -> LDS
+// path 9 times and every 128 x 64 tile re-streams the whole weight panel - 24 KB per 1 MFLOP, which is what bounds it
+// (measured ~34 B / clk / CU through the LDS-DMA path against 64 B / clk peak and ~20 TB/s chip-wide from L2).
+// Here a workgroup owns TR whole image rows (BM = 64 * TM = 256 or 128 positions) x 64 output channels and is persistent:
+//   * the input rows it needs (TR rows + a halo row above and below every image segment, a zero pixel left and right of every
+//     row) are DMA'd ONCE per 64-channel chunk into an LDS slab - borders, image boundaries inside the tile and rows past the
+//     tensor are out-of-range fetches, i.e. zeros in LDS, so the MFMA loop has no masks at all: tap (dy, dx) is the same slab
+//     read shifted by dy * P + dx pixels;
+//   * weights stream through a ring of [64 x 64] (tap, chunk) units, NR - 1 units in flight, one barrier per unit (32 / 16
+//     MFMAs per wave); the slab of the NEXT chunk / tile is fetched while the 9 taps of the current chunk run;
+//   * the unit stream runs across tile boundaries: the next tile's first units and slab are in flight under this tile's epilogue.
+// L2 -> LDS bytes per MFLOP drop 2.5-4x (layer1: 6.1 KB against 24 KB).  Same packed weights, same epilogue (statistics,
+// accumulate) as the other kernels; `transposed` flips the tap shifts (data gradient).
+// Slab geometry: pixel (slab row s, column x) at byte (s * P + x) * 128, its 16-byte chunks XOR-swizzled by (pixel >> 1) & 7.
+// With h0 = first image row of the tile, slab row s holds block row b = (s + h0) % (H + 2) of image (s + h0) / (H + 2) relative
+// to the tile's first image: b = 0 and b = H + 1 are that image's halo rows (zeros), b = 1 .. H its rows 0 .. H - 1.
+template <int TM, typename AT>
+__global__ __launch_bounds__(256) void conv_halo2d_kernel(const ConvArgs p) {
+    typedef Mma<typename OpOf<AT>::E> MM;
+    typedef typename MM::v8 v8;
+    constexpr int BN = 64, TN = 4, WM = 16 * TM, W_BYTES = BN * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int slab_bytes = p.h_slab_bytes;
+    char* const ring = smem + 2 * slab_bytes;
+    float* const red = (float*)(ring + p.h_nr * W_BYTES);
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int H = p.IH, W = p.IW, P = W + 2, TR = p.h_tr, NH = p.B * H;
+    const int NT = p.Cout / BN, nchunks = p.Cin >> 6, U = 9 * nchunks;
+    const int items = p.h_mtiles * NT, G = gridDim.x;
+    if ((int)blockIdx.x >= items) return;
+    const int NR = p.h_nr, S = slab_bytes >> 12;                       // ring slots; DMA rounds (4 waves x 1 KiB) per slab
+    const int zero_pix = p.h_rows * P;                                  // one pixel past the slab rows: always zero
+    const v4i in_rsrc = make_rsrc_words(p.in, p.in_bytes);
+    const v4i w_rsrc = make_rsrc_words(p.w_hi, (unsigned)((size_t)p.Cout * p.Kpad * 2));
+    const unsigned lds_slab = lds_addr(smem) + wave * 1024, lds_ring = lds_addr(ring) + wave * 1024;
+
+    // tile-independent lane constants: (row, column) of the positions this lane feeds to the MFMAs
+    int pj[TM], px[TM];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+        const unsigned pa = wave * WM + a * 16 + fr;
+        pj[a] = (int)fdiv(pa, p.dOW);
+        px[a] = (int)pa - pj[a] * W;
+    }
+    const int wrow = wave * 8 + (lane >> 3), wslot = lane & 7;           // weight DMA: row inside a 32-row round, 16-byte slot
+    const int spix = wave * 8 + (lane >> 3);                             // slab DMA: pixel inside a 32-pixel round
+
+    auto issue_slab = [&](int mtile, int chunk, int buf) {
+        const int g0 = mtile * TR;
+        const int n0 = (int)fdiv((unsigned)g0, p.dOH), h0 = g0 - n0 * H;
+        const unsigned dst = lds_slab + buf * slab_bytes;
+        for (int r = 0; r < S; ++r) {
+            const int sp = r * 32 + spix;
+            const int srow = (int)fdiv((unsigned)sp, p.dP), sx = sp - srow * P;
+            const int V = srow + h0;
+            const int i = (int)fdiv((unsigned)V, p.dH2), b = V - i * (H + 2);
+            const int g = (n0 + i) * H + b - 1, x = sx - 1;
+            const bool ok = srow < p.h_rows && b >= 1 && b <= H && x >= 0 && x < W && g < NH;
+            const int voff = ok ? ((g * W + x) * p.Cin + chunk * 64 + ((wslot ^ ((sp >> 1) & 7)) << 3)) * 2 : (int)0x80000000;
+            dma16_async(in_rsrc, dst + r * 4096, voff);
+        }
+    };
+    auto issue_w = [&](int ntile, int u, int slot) {
+        const int chunk = u / 9, tap = u - chunk * 9;
+        const unsigned dst = lds_ring + slot * W_BYTES;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int n = r * 32 + wrow;
+            const int voff = ((ntile * BN + n) * p.Kpad + tap * p.Cin + chunk * 64 + ((wslot ^ ((n >> 1) & 7)) << 3)) * 2;
+            dma16_async(w_rsrc, dst + r * 4096, voff);
+        }
+    };
+
+    // ---- cursors of the global unit stream of this workgroup: compute (item, u) and weight-issue (w_item, w_u) run NR - 1
+    // units apart; slabs alternate between the two buffers, one per (item, chunk)
+    int item = blockIdx.x, w_item = blockIdx.x, w_u = 0;
+    int q = 0;                                                           // units computed so far
+    int wq = 0;                                                          // weight units issued so far
+    int cbuf = 0;                                                        // slab buffer of the chunk being computed
+    int slab_step = -1000000;                                            // value of q when the youngest slab DMA was issued
+    bool slab_before_w = false;
+    issue_slab(item / NT, 0, 0);
+    for (int d = 0; d < NR - 1 && w_item < items; ++d) {
+        issue_w(w_item % NT, w_u, wq % NR);
+        ++wq;
+        if (++w_u == U) { w_u = 0; w_item += G; }
+    }
+
+    for (; item < items; item += G) {
+        const int mtile = item / NT, ntile = item - mtile * NT;
+        const int g0 = mtile * TR;
+        const int n0img = (int)fdiv((unsigned)g0, p.dOH), h0 = g0 - n0img * H;
+        const int TRt = min(TR, NH - g0);
+        const int npos = TRt * W;
+        int pix0[TM], tmul[TM];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            const int pa = wave * WM + a * 16 + fr;
+            const int hj = h0 + pj[a];
+            const int i = (int)fdiv((unsigned)hj, p.dOH), h = hj - i * H;
+            const bool ok = pa < npos;
+            pix0[a] = ok ? (i * (H + 2) + h + 1 - h0) * P + px[a] + 1 : zero_pix;
+            tmul[a] = ok ? 1 : 0;
+        }
+        f32x4 acc[TM][TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        int chunk = 0, tap = 0;
+        for (int u = 0; u < U; ++u, ++q) {
+            // unit q's weights were issued NR - 1 steps ago: everything younger may still be in flight
+            {
+                const int younger_w = min(wq - 1 - q, NR - 2);
+                const int after = q - (NR - 1);                           // step at which unit q's weights were issued (prologue: < 0)
+                const bool slab_younger = slab_step > after || (slab_step == after && !slab_before_w);
+                wait_vmcnt(2 * max(younger_w, 0) + (slab_younger ? S : 0));
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (tap == 0) {                                               // first tap of a chunk: fetch the slab of the next chunk / tile
+                int nchunk = chunk + 1, nitem = item;
+                if (nchunk == nchunks) { nchunk = 0; nitem = item + G; }
+                if (nitem < items) {
+                    issue_slab(nitem / NT, nchunk, cbuf ^ 1);
+                    slab_step = q;
+                    slab_before_w = true;
+                }
+            }
+            if (w_item < items) {
+                issue_w(w_item % NT, w_u, wq % NR);
+                ++wq;
+                if (++w_u == U) { w_u = 0; w_item += G; }
+            }
+            {
+                const int ky = tap / 3, kx = tap - ky * 3;
+                const int shift = p.transposed ? ((1 - ky) * P + (1 - kx)) : ((ky - 1) * P + (kx - 1));
+                const char* sl = smem + cbuf * slab_bytes;
+                const char* wl = ring + (q % NR) * W_BYTES;
+                int abase[TM], asw[TM];
+#pragma unroll
+                for (int a = 0; a < TM; ++a) {
+                    const int pix = pix0[a] + tmul[a] * shift;
+                    abase[a] = pix * 128;
+                    asw[a] = (pix >> 1) & 7;
+                }
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    v8 ah[TM];
+#pragma unroll
+                    for (int a = 0; a < TM; ++a) ah[a] = *(const v8*)(sl + abase[a] + (((kk * 4 + fq) ^ asw[a]) << 4));
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) {
+                        v8 bh = *(const v8*)(wl + dma_off(b * 16 + fr, kk * 4 + fq));
+#pragma unroll
+                        for (int a = 0; a < TM; ++a) acc[a][b] = MM::mma(bh, ah[a], acc[a][b]);
+                    }
+                }
+            }
+            if (++tap == 9) { tap = 0; ++chunk; cbuf ^= 1; }
+        }
+        // rows of this tile are the contiguous positions [g0 * W, g0 * W + npos)
+        conv_epilogue<AT, BN, TM, TN, 4, WM, BN>(p, acc, g0 * W, ntile * BN, mtile, wave, 0, fr, fq, t, 0, 1, red, min(p.M, g0 * W + npos));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 template <typename AT>
 __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const ConvArgs p) {
     __shared__ float red[16][64][2];
@@ -797,6 +971,8 @@ static int conv_bn(int cout) { return cout % 128 == 0 ? 128 : (cout % 64 == 0 ? 
 // One plan per (geometry, direction), used by the launchers AND by the workspace / statistics-size queries.
 struct ConvPlan {
     int bn;               // output-channel tile
+    int halo;             // 0, or TM (4 / 2) of conv_halo2d_kernel: 2D 3x3 / 1 / pad 1, 16-bit storage, Cin % 64 == 0, Cout % 64 == 0
+    int h_tr, h_rows, h_slab_bytes, h_nr, h_mtiles;
     int dma;              // 1: LDS-DMA kernel (16-bit activation storage, Cin % 64 == 0), 64-wide k-steps
     int nunits;           // k-steps (32 wide, or 64 wide for the DMA kernel)
     int ksplit, per_split;
@@ -808,6 +984,44 @@ static int conv_target_blocks() {                               // tuning aid: T
     static int v = -1;
     if (v < 0) { const char* e = getenv("TRICOLO_CONV_BLOCKS"); v = (e && atoi(e) > 0) ? atoi(e) : 0; }
     return v;
+}
+
+static bool halo_disabled() {                                   // A/B switch: TRICOLO_NO_HALO=1 keeps conv_dma_kernel for the 3x3 layers
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("TRICOLO_NO_HALO"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+
+static int num_cus() {
+    static int v = 0;
+    if (!v) {
+        int dev = 0;
+        hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) v = pr.multiProcessorCount;
+        else v = 256;                                                // MI355X; also the answer on a box without a GPU (plan queries)
+    }
+    return v;
+}
+
+// geometry of conv_halo2d_kernel for row tiles of 64 * TM positions; false when the layer does not fit
+static bool halo_geometry(int B, int H, int W, int cout, int TM, ConvPlan* pl) {
+    const int BM = 64 * TM, P = W + 2;
+    if (W > BM) return false;
+    int TR = BM / W;
+    if (TR > B * H) TR = B * H;
+    int k;                                                           // image segments a tile can touch
+    if (H % TR == 0) k = 1;
+    else if (TR % H == 0) k = TR / H;
+    else k = (TR + H - 2) / H + 1;
+    const int rows = TR + 2 * k;
+    const int slab = ((rows * P + 1) * 128 + 4095) / 4096 * 4096;
+    int nr = (163840 - 2 * slab - 2048 - 512) / 8192;
+    if (nr > 6) nr = 6;
+    if (nr < 4) return false;
+    pl->halo = TM; pl->h_tr = TR; pl->h_rows = rows; pl->h_slab_bytes = slab; pl->h_nr = nr;
+    pl->h_mtiles = (B * H + TR - 1) / TR;
+    (void)cout;
+    return true;
 }
 
 static bool dma_disabled() {
@@ -828,6 +1042,22 @@ static ConvPlan conv_make_plan(int B, int ID, int IH, int IW, int cin, int OD, i
     int blocks = (int)((M + 127) / 128) * (cout / bn);
     if (split_mode == 2 && cin % 64 == 0 && cout % 64 == 0 && !dma_disabled()) pl.dma = 1;
     pl.bn = bn;
+    if (pl.dma && !halo_disabled() && KD == 1 && KH == 3 && KW == 3 && stride == 1 && pd == 0 && ph == 1 && pw == 1 && ID == 1 && OD == 1 &&
+        IH == OH && IW == OW && (long)B * IH * IW * cin * 2 < ((long)1 << 31)) {
+        // 256-position tiles when they still give every CU a workgroup, else 128-position tiles
+        ConvPlan t4{}, t2{};
+        const bool ok4 = halo_geometry(B, IH, IW, cout, 4, &t4), ok2 = halo_geometry(B, IH, IW, cout, 2, &t2);
+        const ConvPlan* pick = nullptr;
+        if (ok4 && (long)t4.h_mtiles * (cout / 64) >= (3 * num_cus()) / 4) pick = &t4;
+        else if (ok2) pick = &t2;
+        else if (ok4) pick = &t4;
+        if (pick) {
+            pl.halo = pick->halo; pl.h_tr = pick->h_tr; pl.h_rows = pick->h_rows; pl.h_slab_bytes = pick->h_slab_bytes;
+            pl.h_nr = pick->h_nr; pl.h_mtiles = pick->h_mtiles;
+            pl.bn = 64; pl.nunits = 9 * (cin / 64); pl.ksplit = 1; pl.per_split = pl.nunits;
+            return pl;
+        }
+    }
     {   // The DMA kernel is latency-bound, not MFMA-bound, at this workload's layer sizes: 128x64 tiles (24 KiB stages, three
         // workgroups per CU, twice the workgroups) beat 128x128 on every layer measured up to 384 wide tiles (sweep in
         // profiles/r1/README.md).  Wide tiles are kept for launches that fill the GPU several times over anyway.
@@ -870,6 +1100,22 @@ static int launch_dma(const ConvArgs& a, hipStream_t stream) {
     if (rc || a.ksplit == 1) return rc;
     conv_splitk_finish_kernel<AT><<<dim3((a.M + 31) / 32, a.Cout / 64), 256, 0, stream>>>(a);
     return tri_check_launch("tri_conv_splitk_finish");
+}
+
+template <int TM, typename AT>
+static int launch_halo(ConvArgs& a, const ConvPlan& pl, hipStream_t stream) {
+    a.h_tr = pl.h_tr; a.h_rows = pl.h_rows; a.h_slab_bytes = pl.h_slab_bytes; a.h_nr = pl.h_nr; a.h_mtiles = pl.h_mtiles;
+    a.dP = make_fastdiv(a.IW + 2); a.dH2 = make_fastdiv(a.IH + 2);
+    const size_t smem = (size_t)2 * pl.h_slab_bytes + (size_t)pl.h_nr * 8192 + 2048;
+    static size_t attr = 0;
+    if (smem > attr) {
+        hipFuncSetAttribute((const void*)conv_halo2d_kernel<TM, AT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr = smem;
+    }
+    const int items = pl.h_mtiles * (a.Cout / 64);
+    const int grid = items < num_cus() ? items : num_cus();            // persistent: one workgroup per CU (the slabs take the LDS)
+    conv_halo2d_kernel<TM, AT><<<grid, 256, smem, stream>>>(a);
+    return tri_check_launch("tri_conv(halo)");
 }
 
 template <typename AT>
@@ -916,6 +1162,11 @@ static int conv_dispatch(ConvArgs& a, int act_fmt, void* workspace, size_t works
     } else if (a.row_pos && !(pl.dma && pl.ksplit == 1 && !a.row_mask && !a.stats && a.Kpad / 64 <= 128)) {
         a.row_pos = nullptr;          // a pure visiting-order hint: honoured by the DMA kernel without split-K, dropped elsewhere
     }
+    if (pl.halo && !a.row_mask && !a.row_count && !a.bias && a.act == 0) {
+        a.row_pos = nullptr;
+        if (pl.halo == 4) return act_fmt == TRI_FMT_F16 ? launch_halo<4, f16_t>(a, pl, stream) : launch_halo<4, bf16_t>(a, pl, stream);
+        return act_fmt == TRI_FMT_F16 ? launch_halo<2, f16_t>(a, pl, stream) : launch_halo<2, bf16_t>(a, pl, stream);
+    }
     if (pl.dma) return act_fmt == TRI_FMT_F16 ? launch_dma_any<f16_t>(a, pl.bn, stream) : launch_dma_any<bf16_t>(a, pl.bn, stream);
 #define TRI_CONV(BN_)                                                                                     \
     (act_fmt == TRI_FMT_F16 ? launch_conv<BN_, 1, f16_t>(a, stream)                                       \
@@ -936,6 +1187,7 @@ extern "C" int tri_conv_num_mtiles(const TriConvDesc* d, int split3) {
     long M = (long)d->B * d->OD * d->OH * d->OW;
     ConvPlan pl = conv_make_plan(d->B, d->ID, d->IH, d->IW, d->Cin, d->OD, d->OH, d->OW, d->Cout, d->KD, d->KH, d->KW, d->stride, d->pad_d,
                                  d->pad_h, d->pad_w, split3);
+    if (pl.halo) return pl.h_mtiles;
     return pl.ksplit > 1 ? (int)((M + 31) / 32) : (int)((M + 127) / 128);
 }
 
@@ -945,6 +1197,7 @@ extern "C" int tri_conv_kernel_family(const TriConvDesc* d, int transposed, int 
                                               d->pad_d, d->pad_h, d->pad_w, split3)
                              : conv_make_plan(d->B, d->ID, d->IH, d->IW, d->Cin, d->OD, d->OH, d->OW, d->Cout, d->KD, d->KH, d->KW, d->stride,
                                               d->pad_d, d->pad_h, d->pad_w, split3);
+    if (pl.halo) return 3 | (pl.halo << 8);
     return (pl.dma ? 2 : 0) | (pl.bn << 8) | ((pl.ksplit > 1 || (pl.dma && tri_conv_kpad(d->KD * d->KH * d->KW, transposed ? d->Cout : d->Cin) / 64 > 128)) ? (1 << 16) : 0);
 }
 

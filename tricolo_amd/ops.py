@@ -79,6 +79,8 @@ def _igemm_symbol(g, transposed, split, t):
     h16 = t.dtype != torch.float32
     code = g.kernel_family[(transposed, 1 if split else (2 if h16 else 0))]
     fam, bn = code & 255, (code >> 8) & 255
+    if fam == 3:
+        return f"conv_halo2d_kernel<{bn}, {_TNAME[t.dtype]}>"
     if fam == 2:
         return f"conv_dma_kernel<{bn}, {3 if os.environ.get('TRICOLO_DMA_STAGES') == '3' else 2}, {_TNAME[t.dtype]}>"
     return f"conv_igemm_kernel<{bn}, {2 if split else 1}, {_TNAME[t.dtype]}>"
