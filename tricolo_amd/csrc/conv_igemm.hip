@@ -34,6 +34,8 @@ struct ConvArgs {
     unsigned in_bytes;
     int nunits;
     int h_tr, h_rows, h_slab_bytes, h_nr, h_mtiles;    // halo kernel: image rows per tile, slab rows, slab bytes, ring slots, row tiles
+    int h_dbuf;
+    int h_abl;                                          // tuning aid (TRICOLO_HALO_ABL): ablation bits, 0 in production
     FastDiv dOW, dOH, dOD, dCin, dP, dH2;
 };
 
@@ -610,109 +612,147 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs p) {
 // ================================================================================================ halo kernel (2D, 3x3 / 1 / pad 1)
 // Every BasicBlock conv of ResNet-18 that keeps its resolution (16 of the 20 convs, and their data gradients) is a 3x3,
 // stride-1, pad-1 convolution.  conv_dma_kernel gathers their im2col rows tap by tap: each input pixel crosses the L2 -> LDS
-// path 9 times and every 128 x 64 tile re-streams the whole weight panel - 24 KB per 1 MFLOP, which is what bounds it
-// (measured ~34 B / clk / CU through the LDS-DMA path against 64 B / clk peak and ~20 TB/s chip-wide from L2).
-// Here a workgroup owns TR whole image rows (BM = 64 * TM = 256 or 128 positions) x 64 output channels and is persistent:
-//   * the input rows it needs (TR rows + a halo row above and below every image segment, a zero pixel left and right of every
-//     row) are DMA'd ONCE per 64-channel chunk into an LDS slab - borders, image boundaries inside the tile and rows past the
-//     tensor are out-of-range fetches, i.e. zeros in LDS, so the MFMA loop has no masks at all: tap (dy, dx) is the same slab
-//     read shifted by dy * P + dx pixels;
-//   * weights stream through a ring of [64 x 64] (tap, chunk) units, NR - 1 units in flight, one barrier per unit (32 / 16
-//     MFMAs per wave); the slab of the NEXT chunk / tile is fetched while the 9 taps of the current chunk run;
-//   * the unit stream runs across tile boundaries: the next tile's first units and slab are in flight under this tile's epilogue.
-// L2 -> LDS bytes per MFLOP drop 2.5-4x (layer1: 6.1 KB against 24 KB).  Same packed weights, same epilogue (statistics,
-// accumulate) as the other kernels; `transposed` flips the tap shifts (data gradient).
-// Slab geometry: pixel (slab row s, column x) at byte (s * P + x) * 128, its 16-byte chunks XOR-swizzled by (pixel >> 1) & 7.
-// With h0 = first image row of the tile, slab row s holds block row b = (s + h0) % (H + 2) of image (s + h0) / (H + 2) relative
-// to the tile's first image: b = 0 and b = H + 1 are that image's halo rows (zeros), b = 1 .. H its rows 0 .. H - 1.
+// path 9 times and every 128 x 64 tile re-streams the whole weight panel (24 KB per MFLOP).  Here a PERSISTENT workgroup
+// (up to three per CU: the slab of a 128-position tile is ~25 KB) walks tiles of TR whole image rows (64 * TM positions) x 64
+// output channels:
+//   * the input rows a tile needs (TR rows + a halo row above and below every image segment, a zero pixel left and right of
+//     every row) are DMA'd ONCE per 64-channel chunk into an LDS slab - borders, image boundaries inside the tile and rows past
+//     the tensor are out-of-range fetches, i.e. zeros in LDS, so the MFMA loop has no masks: tap (dy, dx) is the same slab read
+//     shifted by dy * P + dx pixels (P = W + 2); ONE slab buffer - its refill between chunks is exposed to this workgroup and
+//     hidden by the co-resident ones; the next TILE's slab is fetched under this tile's epilogue;
+//   * weights stream through a ring of three [64 x 64] (tap, chunk) units, two in flight, one barrier per unit; the stream
+//     runs across tile boundaries, so the next tile's first units are in flight under this tile's epilogue.
+// L2 -> LDS bytes per MFLOP drop 2.5-4x (layer1: 6.1 KB against 24 KB).  What the first two versions taught (ablations in
+// profiles/r2/README.md): at these tile sizes (9 units = 4,600 MFMA cycles on layer1) the kernel is bound by INSTRUCTION ISSUE,
+// not by bytes - a 2,085-instruction prologue (fast divisions for the slab map) and a 4,452-instruction generic epilogue per
+// tile cost 13 + 10 us of a 34 us launch, and two co-resident workgroups run them in lockstep, not against each other's MFMAs.
+// So: everything that depends only on the geometry is computed once per workgroup (slab source offsets, fragment pixels),
+// every cursor is incremental (no division / modulo in the loop), ring waits are immediates, and the conv + BatchNorm epilogue
+// is a dedicated lean one.
+// Geometries: H % TR == 0 (a tile stays inside one image; its halo rows exist unless it touches the image's top / bottom)
+// or TR % H == 0 (whole images per tile, every halo row is zero); anything else stays on conv_dma_kernel.
+// Slab: pixel (slab row s, column x) at byte (s * P + x) * 128, its 16-byte chunks XOR-swizzled by (pixel >> 1) & 7; one extra
+// always-zero pixel after the last row serves the MFMA rows past the end of a partial last tile.
+#define HALO_MAX_ROUNDS 10
+#ifndef HALO_NR
+#define HALO_NR 3
+#endif
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_c() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 template <int TM, typename AT>
 __global__ __launch_bounds__(256) void conv_halo2d_kernel(const ConvArgs p) {
     typedef Mma<typename OpOf<AT>::E> MM;
     typedef typename MM::v8 v8;
-    constexpr int BN = 64, TN = 4, WM = 16 * TM, W_BYTES = BN * 128;
+    constexpr int BN = 64, TN = 4, WM = 16 * TM, W_BYTES = BN * 128, NR = HALO_NR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int slab_bytes = p.h_slab_bytes;
-    char* const ring = smem + 2 * slab_bytes;
-    float* const red = (float*)(ring + p.h_nr * W_BYTES);
+    char* const ring = smem + slab_bytes;
+    float* const red = (float*)(ring + NR * W_BYTES);
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const int H = p.IH, W = p.IW, P = W + 2, TR = p.h_tr, NH = p.B * H;
-    const int NT = p.Cout / BN, nchunks = p.Cin >> 6, U = 9 * nchunks;
+    const int NT = p.Cout / BN, nchunks = p.Cin >> 6;
     const int items = p.h_mtiles * NT, G = gridDim.x;
-    if ((int)blockIdx.x >= items) return;
-    const int NR = p.h_nr, S = slab_bytes >> 12;                       // ring slots; DMA rounds (4 waves x 1 KiB) per slab
-    const int zero_pix = p.h_rows * P;                                  // one pixel past the slab rows: always zero
-    const v4i in_rsrc = make_rsrc_words(p.in, p.in_bytes);
+    const int S = slab_bytes >> 12;                                     // DMA rounds (4 waves x 1 KiB) per slab
+    const int zero_pix = p.h_rows * P;
+    const v4i in_rsrc = make_rsrc_words(p.in, p.in_bytes);              // rows past the tensor are out of range = zeros
     const v4i w_rsrc = make_rsrc_words(p.w_hi, (unsigned)((size_t)p.Cout * p.Kpad * 2));
     const unsigned lds_slab = lds_addr(smem) + wave * 1024, lds_ring = lds_addr(ring) + wave * 1024;
+    const int whole = (TR % H == 0) ? 1 : 0;                            // whole images per tile (else H % TR == 0: one image segment)
 
-    // tile-independent lane constants: (row, column) of the positions this lane feeds to the MFMAs
-    int pj[TM], px[TM];
+    // ---- geometry-only lane constants (once per workgroup) -------------------------------------------------------------
+    // slab source of this lane per DMA round: byte offset relative to the tile's first row (-1: always zero) and whether the
+    // pixel lies in the halo row above / below an image segment (then it exists only if the tile does not touch that border)
+    int soff[HALO_MAX_ROUNDS];
+    unsigned stop = 0, sbot = 0;
+    {
+        const int spix = wave * 8 + (lane >> 3), slot = lane & 7;
+#pragma unroll
+        for (int r = 0; r < HALO_MAX_ROUNDS; ++r) {
+            const int sp = r * 32 + spix;
+            const int srow = (int)fdiv((unsigned)sp, p.dP), sx = sp - srow * P;
+            bool ok = srow < p.h_rows && sx >= 1 && sx <= W;
+            int grel;
+            if (whole) {
+                const int i = (int)fdiv((unsigned)srow, p.dH2), b = srow - i * (H + 2);
+                ok = ok && b >= 1 && b <= H;
+                grel = i * H + b - 1;
+            } else {
+                grel = srow - 1;
+                if (ok && grel < 0) stop |= 1u << r;
+                if (ok && grel >= TR) sbot |= 1u << r;
+            }
+            soff[r] = ok ? ((grel * W + sx - 1) * p.Cin + ((slot ^ ((sp >> 1) & 7)) << 3)) * 2 : -1;
+        }
+    }
+    // fragment rows of this lane: slab pixel of the centre tap
+    int pixc[TM];
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
         const unsigned pa = wave * WM + a * 16 + fr;
-        pj[a] = (int)fdiv(pa, p.dOW);
-        px[a] = (int)pa - pj[a] * W;
+        const int j = (int)fdiv(pa, p.dOW), x = (int)pa - j * W;
+        const int i = whole ? (int)fdiv((unsigned)j, p.dOH) : 0;
+        pixc[a] = (j + 1 + 2 * i) * P + x + 1;
     }
-    const int wrow = wave * 8 + (lane >> 3), wslot = lane & 7;           // weight DMA: row inside a 32-row round, 16-byte slot
-    const int spix = wave * 8 + (lane >> 3);                             // slab DMA: pixel inside a 32-pixel round
-
-    auto issue_slab = [&](int mtile, int chunk, int buf) {
-        const int g0 = mtile * TR;
-        const int n0 = (int)fdiv((unsigned)g0, p.dOH), h0 = g0 - n0 * H;
-        const unsigned dst = lds_slab + buf * slab_bytes;
-        for (int r = 0; r < S; ++r) {
-            const int sp = r * 32 + spix;
-            const int srow = (int)fdiv((unsigned)sp, p.dP), sx = sp - srow * P;
-            const int V = srow + h0;
-            const int i = (int)fdiv((unsigned)V, p.dH2), b = V - i * (H + 2);
-            const int g = (n0 + i) * H + b - 1, x = sx - 1;
-            const bool ok = srow < p.h_rows && b >= 1 && b <= H && x >= 0 && x < W && g < NH;
-            const int voff = ok ? ((g * W + x) * p.Cin + chunk * 64 + ((wslot ^ ((sp >> 1) & 7)) << 3)) * 2 : (int)0x80000000;
-            dma16_async(in_rsrc, dst + r * 4096, voff);
-        }
-    };
-    auto issue_w = [&](int ntile, int u, int slot) {
-        const int chunk = u / 9, tap = u - chunk * 9;
-        const unsigned dst = lds_ring + slot * W_BYTES;
+    int woff[2];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int n = r * 32 + wrow;
-            const int voff = ((ntile * BN + n) * p.Kpad + tap * p.Cin + chunk * 64 + ((wslot ^ ((n >> 1) & 7)) << 3)) * 2;
-            dma16_async(w_rsrc, dst + r * 4096, voff);
+    for (int r = 0; r < 2; ++r) {
+        const int n = r * 32 + wave * 8 + (lane >> 3);
+        woff[r] = (n * p.Kpad + (((lane & 7) ^ ((n >> 1) & 7)) << 3)) * 2;
+    }
+
+    auto issue_slab = [&](int g0_, int chunk) {
+        int top_ok = 1, bot_ok = 1;
+        if (!whole) {
+            const int h0_ = g0_ - (int)fdiv((unsigned)g0_, p.dOH) * H;
+            top_ok = h0_ > 0;
+            bot_ok = h0_ + TR < H;
+        }
+        const unsigned kill = (top_ok ? 0u : stop) | (bot_ok ? 0u : sbot);
+        const int cb = g0_ * W * p.Cin * 2 + chunk * 128;
+#pragma unroll
+        for (int r = 0; r < HALO_MAX_ROUNDS; ++r)
+            if (r < S) dma16_async(in_rsrc, lds_slab + r * 4096, (soff[r] == -1 || ((kill >> r) & 1u)) ? (int)0x80000000 : soff[r] + cb);
+    };
+    // weight stream cursor: item, (chunk, tap) -> k offset, ring slot; runs NR - 1 units ahead, across tile boundaries
+    int w_item = blockIdx.x, w_nb = (w_item % NT) * BN * p.Kpad, w_k = 0, w_tap = 0, w_chunk = 0, w_slot = 0, w_ahead = 0;
+    auto issue_w = [&]() {
+        const unsigned dst = lds_ring + w_slot * W_BYTES;
+        const int kb = (w_nb + w_k) * 2;
+        dma16_async(w_rsrc, dst, woff[0] + kb);
+        dma16_async(w_rsrc, dst + 4096, woff[1] + kb);
+        ++w_ahead;
+        if (++w_slot == NR) w_slot = 0;
+        w_k += p.Cin;
+        if (++w_tap == 9) {
+            w_tap = 0;
+            if (++w_chunk == nchunks) {
+                w_chunk = 0;
+                w_item += G;
+                if (w_item < items) w_nb = (w_item - (w_item / NT) * NT) * BN * p.Kpad;
+            }
+            w_k = w_chunk * 64;
         }
     };
 
-    // ---- cursors of the global unit stream of this workgroup: compute (item, u) and weight-issue (w_item, w_u) run NR - 1
-    // units apart; slabs alternate between the two buffers, one per (item, chunk)
-    int item = blockIdx.x, w_item = blockIdx.x, w_u = 0;
-    int q = 0;                                                           // units computed so far
-    int wq = 0;                                                          // weight units issued so far
-    int cbuf = 0;                                                        // slab buffer of the chunk being computed
-    int slab_step = -1000000;                                            // value of q when the youngest slab DMA was issued
-    bool slab_before_w = false;
-    issue_slab(item / NT, 0, 0);
-    for (int d = 0; d < NR - 1 && w_item < items; ++d) {
-        issue_w(w_item % NT, w_u, wq % NR);
-        ++wq;
-        if (++w_u == U) { w_u = 0; w_item += G; }
+    int item = blockIdx.x;
+    if (item >= items) return;
+    {
+        issue_slab((item / NT) * TR, 0);
+#pragma unroll
+        for (int d = 0; d < NR - 1; ++d) issue_w();                       // NR - 1 units ahead (a tile has >= 9 units)
     }
-
+    int c_slot = 0;
     for (; item < items; item += G) {
         const int mtile = item / NT, ntile = item - mtile * NT;
         const int g0 = mtile * TR;
-        const int n0img = (int)fdiv((unsigned)g0, p.dOH), h0 = g0 - n0img * H;
-        const int TRt = min(TR, NH - g0);
-        const int npos = TRt * W;
+        const int npos = min(TR, NH - g0) * W;
         int pix0[TM], tmul[TM];
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
-            const int pa = wave * WM + a * 16 + fr;
-            const int hj = h0 + pj[a];
-            const int i = (int)fdiv((unsigned)hj, p.dOH), h = hj - i * H;
-            const bool ok = pa < npos;
-            pix0[a] = ok ? (i * (H + 2) + h + 1 - h0) * P + px[a] + 1 : zero_pix;
+            const bool ok = wave * WM + a * 16 + fr < npos;
+            pix0[a] = ok ? pixc[a] : zero_pix;
             tmul[a] = ok ? 1 : 0;
         }
         f32x4 acc[TM][TN];
@@ -721,62 +761,113 @@ __global__ __launch_bounds__(256) void conv_halo2d_kernel(const ConvArgs p) {
 #pragma unroll
             for (int b = 0; b < TN; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-        int chunk = 0, tap = 0;
-        for (int u = 0; u < U; ++u, ++q) {
-            // unit q's weights were issued NR - 1 steps ago: everything younger may still be in flight
-            {
-                const int younger_w = min(wq - 1 - q, NR - 2);
-                const int after = q - (NR - 1);                           // step at which unit q's weights were issued (prologue: < 0)
-                const bool slab_younger = slab_step > after || (slab_step == after && !slab_before_w);
-                wait_vmcnt(2 * max(younger_w, 0) + (slab_younger ? S : 0));
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            if (chunk > 0) {                                              // refill the (single) slab buffer between two chunks of a tile
+                __builtin_amdgcn_s_barrier();                             // every wave is done reading the previous chunk
+                asm volatile("" ::: "memory");
+                issue_slab(g0, chunk);
             }
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (tap == 0) {                                               // first tap of a chunk: fetch the slab of the next chunk / tile
-                int nchunk = chunk + 1, nitem = item;
-                if (nchunk == nchunks) { nchunk = 0; nitem = item + G; }
-                if (nitem < items) {
-                    issue_slab(nitem / NT, nchunk, cbuf ^ 1);
-                    slab_step = q;
-                    slab_before_w = true;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the slab is the youngest DMA: everything has landed
+            // (rolled tap loop: unrolled, the nine taps' fragment addresses were hoisted and spilled to scratch - whose reloads
+            //  are VMEM operations that wait for every LDS-DMA in flight)
+            int shift = p.transposed ? (P + 1) : -(P + 1), kx = 0;        // tap (ky, kx) reads the slab shifted by (ky - 1) * P + (kx - 1); negated for the data gradient
+#pragma unroll 1
+            for (int tap = 0; tap < 9; ++tap) {
+                // this unit's weights were issued NR - 1 units ago; the NR - 2 units issued after them may still be in flight
+                --w_ahead;
+                if (tap > 0) {
+                    if (w_ahead == NR - 2) wait_vmcnt_c<2 * (NR - 2)>();
+                    else wait_vmcnt(2 * w_ahead);                         // the last units of the stream
                 }
-            }
-            if (w_item < items) {
-                issue_w(w_item % NT, w_u, wq % NR);
-                ++wq;
-                if (++w_u == U) { w_u = 0; w_item += G; }
-            }
-            {
-                const int ky = tap / 3, kx = tap - ky * 3;
-                const int shift = p.transposed ? ((1 - ky) * P + (1 - kx)) : ((ky - 1) * P + (kx - 1));
-                const char* sl = smem + cbuf * slab_bytes;
-                const char* wl = ring + (q % NR) * W_BYTES;
-                int abase[TM], asw[TM];
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (w_item < items) issue_w();
+                if (!(p.h_abl & 1)) {
+                    const char* wl = ring + c_slot * W_BYTES;
+                    int abase[TM], asw[TM];
 #pragma unroll
-                for (int a = 0; a < TM; ++a) {
-                    const int pix = pix0[a] + tmul[a] * shift;
-                    abase[a] = pix * 128;
-                    asw[a] = (pix >> 1) & 7;
+                    for (int a = 0; a < TM; ++a) {
+                        const int pix = pix0[a] + tmul[a] * shift;
+                        abase[a] = pix * 128;
+                        asw[a] = (pix >> 1) & 7;
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+                        v8 ah[TM];
+#pragma unroll
+                        for (int a = 0; a < TM; ++a) ah[a] = *(const v8*)(smem + abase[a] + (((kk * 4 + fq) ^ asw[a]) << 4));
+#pragma unroll
+                        for (int b = 0; b < TN; ++b) {
+                            v8 bh = *(const v8*)(wl + dma_off(b * 16 + fr, kk * 4 + fq));
+#pragma unroll
+                            for (int a = 0; a < TM; ++a) acc[a][b] = MM::mma(bh, ah[a], acc[a][b]);
+                        }
+                    }
                 }
+                if (++c_slot == NR) c_slot = 0;
+                const int step = (++kx == 3) ? (kx = 0, P - 2) : 1;       // next tap: one pixel right, or down a row and two left
+                shift += p.transposed ? -step : step;
+            }
+        }
+        // the next tile's slab is fetched under this tile's epilogue
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (item + G < items) issue_slab(((item + G) / NT) * TR, 0);
+
+        // ---- lean epilogue (conv + BatchNorm statistics, or accumulate for the data gradient): rows = positions [g0 W, g0 W + npos)
+        if (!(p.h_abl & 4)) {
+            AT* const out = (AT*)p.out + ((size_t)g0 * W) * p.Cout + ntile * BN;
+            f32x4 cs[TN], cq[TN];
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    v8 ah[TM];
+            for (int b = 0; b < TN; ++b) { cs[b] = (f32x4){0.f, 0.f, 0.f, 0.f}; cq[b] = cs[b]; }
 #pragma unroll
-                    for (int a = 0; a < TM; ++a) ah[a] = *(const v8*)(sl + abase[a] + (((kk * 4 + fq) ^ asw[a]) << 4));
+            for (int a = 0; a < TM; ++a) {
+                const int m = wave * WM + a * 16 + fr;
+                if (m < npos) {
 #pragma unroll
                     for (int b = 0; b < TN; ++b) {
-                        v8 bh = *(const v8*)(wl + dma_off(b * 16 + fr, kk * 4 + fq));
-#pragma unroll
-                        for (int a = 0; a < TM; ++a) acc[a][b] = MM::mma(bh, ah[a], acc[a][b]);
+                        AT* o = out + (size_t)m * p.Cout + b * 16 + fq * 4;
+                        f32x4 v = acc[a][b];
+                        if (p.accumulate) { float4 e = Act<AT>::ld4(o); v[0] += e.x; v[1] += e.y; v[2] += e.z; v[3] += e.w; }
+                        Act<AT>::st4(o, make_float4(v[0], v[1], v[2], v[3]));
+                        if (p.stats) {                                    // statistics of what BatchNorm will read back
+                            v[0] = Act<AT>::rnd(v[0]); v[1] = Act<AT>::rnd(v[1]); v[2] = Act<AT>::rnd(v[2]); v[3] = Act<AT>::rnd(v[3]);
+                            cs[b] += v;
+                            cq[b] += v * v;
+                        }
                     }
                 }
             }
-            if (++tap == 9) { tap = 0; ++chunk; cbuf ^= 1; }
+            if (p.stats && !(p.h_abl & 16)) {
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float s_ = cs[b][r], q_ = cq[b][r];
+                        s_ += row_ror<8>(s_); q_ += row_ror<8>(q_);
+                        s_ += row_ror<4>(s_); q_ += row_ror<4>(q_);
+                        s_ += row_ror<2>(s_); q_ += row_ror<2>(q_);
+                        s_ += row_ror<1>(s_); q_ += row_ror<1>(q_);
+                        if (fr == 0) {
+                            const int col = b * 16 + fq * 4 + r;
+                            red[(wave * BN + col) * 2 + 0] = s_;
+                            red[(wave * BN + col) * 2 + 1] = q_;
+                        }
+                    }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (t < BN) {
+                    float s_ = 0.f, q_ = 0.f;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) { s_ += red[(w * BN + t) * 2]; q_ += red[(w * BN + t) * 2 + 1]; }
+                    p.stats[((size_t)mtile * 2 + 0) * p.Cout + ntile * BN + t] = s_;
+                    p.stats[((size_t)mtile * 2 + 1) * p.Cout + ntile * BN + t] = q_;
+                }
+                // (the next write to `red` comes after at least nine more barriers)
+            }
         }
-        // rows of this tile are the contiguous positions [g0 * W, g0 * W + npos)
-        conv_epilogue<AT, BN, TM, TN, 4, WM, BN>(p, acc, g0 * W, ntile * BN, mtile, wave, 0, fr, fq, t, 0, 1, red, min(p.M, g0 * W + npos));
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 template <typename AT>
@@ -972,7 +1063,7 @@ static int conv_bn(int cout) { return cout % 128 == 0 ? 128 : (cout % 64 == 0 ? 
 struct ConvPlan {
     int bn;               // output-channel tile
     int halo;             // 0, or TM (4 / 2) of conv_halo2d_kernel: 2D 3x3 / 1 / pad 1, 16-bit storage, Cin % 64 == 0, Cout % 64 == 0
-    int h_tr, h_rows, h_slab_bytes, h_nr, h_mtiles;
+    int h_tr, h_rows, h_slab_bytes, h_nr, h_mtiles, h_dbuf;
     int dma;              // 1: LDS-DMA kernel (16-bit activation storage, Cin % 64 == 0), 64-wide k-steps
     int nunits;           // k-steps (32 wide, or 64 wide for the DMA kernel)
     int ksplit, per_split;
@@ -1007,20 +1098,17 @@ static int num_cus() {
 static bool halo_geometry(int B, int H, int W, int cout, int TM, ConvPlan* pl) {
     const int BM = 64 * TM, P = W + 2;
     if (W > BM) return false;
-    int TR = BM / W;
-    if (TR > B * H) TR = B * H;
-    int k;                                                           // image segments a tile can touch
-    if (H % TR == 0) k = 1;
-    else if (TR % H == 0) k = TR / H;
-    else k = (TR + H - 2) / H + 1;
+    const int TR = BM / W;
+    int k;                                                           // image segments of a tile
+    if (H % TR == 0) k = 1;                                          // a tile stays inside one image
+    else if (TR % H == 0) k = TR / H;                                // whole images per tile
+    else return false;                                               // tiles would cross image boundaries at arbitrary rows
     const int rows = TR + 2 * k;
     const int slab = ((rows * P + 1) * 128 + 4095) / 4096 * 4096;
-    int nr = (163840 - 2 * slab - 2048 - 512) / 8192;
-    if (nr > 6) nr = 6;
-    if (nr < 4) return false;
-    pl->halo = TM; pl->h_tr = TR; pl->h_rows = rows; pl->h_slab_bytes = slab; pl->h_nr = nr;
-    pl->h_mtiles = (B * H + TR - 1) / TR;
+    if (slab / 4096 > 10) return false;                              // HALO_MAX_ROUNDS
     (void)cout;
+    pl->halo = TM; pl->h_tr = TR; pl->h_rows = rows; pl->h_slab_bytes = slab; pl->h_nr = 3; pl->h_dbuf = 0;
+    pl->h_mtiles = (B * H + TR - 1) / TR;
     return true;
 }
 
@@ -1044,16 +1132,13 @@ static ConvPlan conv_make_plan(int B, int ID, int IH, int IW, int cin, int OD, i
     pl.bn = bn;
     if (pl.dma && !halo_disabled() && KD == 1 && KH == 3 && KW == 3 && stride == 1 && pd == 0 && ph == 1 && pw == 1 && ID == 1 && OD == 1 &&
         IH == OH && IW == OW && (long)B * IH * IW * cin * 2 < ((long)1 << 31)) {
-        // 256-position tiles when they still give every CU a workgroup, else 128-position tiles
-        ConvPlan t4{}, t2{};
-        const bool ok4 = halo_geometry(B, IH, IW, cout, 4, &t4), ok2 = halo_geometry(B, IH, IW, cout, 2, &t2);
-        const ConvPlan* pick = nullptr;
-        if (ok4 && (long)t4.h_mtiles * (cout / 64) >= (3 * num_cus()) / 4) pick = &t4;
-        else if (ok2) pick = &t2;
-        else if (ok4) pick = &t4;
+        // 128-position tiles: a ~25 KB slab + 24 KB ring lets three workgroups share a CU (the kernel is bound by instruction
+        // issue and latency, not by operand bytes: occupancy matters more than the bigger tile's reuse)
+        ConvPlan t2{};
+        const ConvPlan* pick = halo_geometry(B, IH, IW, cout, 2, &t2) ? &t2 : nullptr;
         if (pick) {
             pl.halo = pick->halo; pl.h_tr = pick->h_tr; pl.h_rows = pick->h_rows; pl.h_slab_bytes = pick->h_slab_bytes;
-            pl.h_nr = pick->h_nr; pl.h_mtiles = pick->h_mtiles;
+            pl.h_nr = pick->h_nr; pl.h_mtiles = pick->h_mtiles; pl.h_dbuf = pick->h_dbuf;
             pl.bn = 64; pl.nunits = 9 * (cin / 64); pl.ksplit = 1; pl.per_split = pl.nunits;
             return pl;
         }
@@ -1105,16 +1190,19 @@ static int launch_dma(const ConvArgs& a, hipStream_t stream) {
 template <int TM, typename AT>
 static int launch_halo(ConvArgs& a, const ConvPlan& pl, hipStream_t stream) {
     a.h_tr = pl.h_tr; a.h_rows = pl.h_rows; a.h_slab_bytes = pl.h_slab_bytes; a.h_nr = pl.h_nr; a.h_mtiles = pl.h_mtiles;
+    a.h_dbuf = pl.h_dbuf;
+    { static int abl = -1; if (abl < 0) { const char* e = getenv("TRICOLO_HALO_ABL"); abl = e ? atoi(e) : 0; } a.h_abl = abl; }
     a.dP = make_fastdiv(a.IW + 2); a.dH2 = make_fastdiv(a.IH + 2);
-    const size_t smem = (size_t)2 * pl.h_slab_bytes + (size_t)pl.h_nr * 8192 + 2048;
+    const size_t smem = (size_t)pl.h_slab_bytes + (size_t)HALO_NR * 8192 + 2048;
+    const int per_cu = (int)(163840 / (smem + 256)) < 3 ? (int)(163840 / (smem + 256)) : 3;
     static size_t attr = 0;
     if (smem > attr) {
         hipFuncSetAttribute((const void*)conv_halo2d_kernel<TM, AT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr = smem;
     }
     const int items = pl.h_mtiles * (a.Cout / 64);
-    const int grid = items < num_cus() ? items : num_cus();            // persistent: one workgroup per CU (the slabs take the LDS)
-    conv_halo2d_kernel<TM, AT><<<grid, 256, smem, stream>>>(a);
+    const int slots = num_cus() * (per_cu < 1 ? 1 : per_cu);
+    conv_halo2d_kernel<TM, AT><<<items < slots ? items : slots, 256, smem, stream>>>(a);                // persistent workgroups
     return tri_check_launch("tri_conv(halo)");
 }
 
@@ -1164,7 +1252,6 @@ static int conv_dispatch(ConvArgs& a, int act_fmt, void* workspace, size_t works
     }
     if (pl.halo && !a.row_mask && !a.row_count && !a.bias && a.act == 0) {
         a.row_pos = nullptr;
-        if (pl.halo == 4) return act_fmt == TRI_FMT_F16 ? launch_halo<4, f16_t>(a, pl, stream) : launch_halo<4, bf16_t>(a, pl, stream);
         return act_fmt == TRI_FMT_F16 ? launch_halo<2, f16_t>(a, pl, stream) : launch_halo<2, bf16_t>(a, pl, stream);
     }
     if (pl.dma) return act_fmt == TRI_FMT_F16 ? launch_dma_any<f16_t>(a, pl.bn, stream) : launch_dma_any<bf16_t>(a, pl.bn, stream);
