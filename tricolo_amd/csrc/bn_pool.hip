@@ -18,33 +18,32 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int ntiles
                                    float* running_mean, float* running_var, long long* num_batches_tracked, float momentum,
                                    float eps, float* __restrict__ mean_out, float* __restrict__ invstd_out,
                                    float* __restrict__ scale_out, float* __restrict__ shift_out) {
-    // 16 channels per block (one 64-byte segment of every record row) x 64 record lanes: a wave-instruction then reads 4 whole
-    // 64-byte segments instead of 64 scattered dwords (the one-channel-per-block form touched a different cache line per lane:
-    // 6.3-6.7 us per launch, 50 launches per step on the critical path), and every load is still independent and in flight at once.
-    __shared__ double ssum[64][17], ssq[64][17];
-    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
-    // the finishing threads' operands are requested first: their latency overlaps the record loads
+    // one channel per block, 256 record lanes: every load of the [ntiles][2][C] table is independent and in flight at
+    // once (the 4-channel x 64-lane version spent 12-30 us in a dependent-load chain on the 1,536 - 6,144 record layers)
+    __shared__ double ssum[4], ssq[4];
+    const int c = blockIdx.x;
+    // the finishing thread's operands are requested first: their latency then overlaps the record loads instead of
+    // following the reduction (these 50 launches per step are pure latency on the step's critical path)
     float pg = 0.f, pb = 0.f, prm = 0.f, prv = 0.f;
     int pcount = count_host;
-    if (rl == 0 && c < C) {
+    if (threadIdx.x == 0) {
         pg = gamma[c]; pb = beta[c];
         if (running_mean) { prm = running_mean[c]; prv = running_var[c]; }
         if (count_dev) pcount = *count_dev;
     }
     double s = 0.0, q = 0.0;
-    if (c < C)
 #pragma unroll 8
-        for (int tIdx = rl; tIdx < ntiles; tIdx += 64) {
-            s += (double)partial[((size_t)tIdx * 2 + 0) * C + c];
-            q += (double)partial[((size_t)tIdx * 2 + 1) * C + c];
-        }
-    ssum[rl][cl] = s; ssq[rl][cl] = q;
+    for (int tIdx = threadIdx.x; tIdx < ntiles; tIdx += 256) {
+        s += (double)partial[((size_t)tIdx * 2 + 0) * C + c];
+        q += (double)partial[((size_t)tIdx * 2 + 1) * C + c];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+    if ((threadIdx.x & 63) == 0) { ssum[threadIdx.x >> 6] = s; ssq[threadIdx.x >> 6] = q; }
     __syncthreads();
-    if (rl == 0 && c < C) {
-        s = 0.0; q = 0.0;
-#pragma unroll 8
-        for (int r = 0; r < 64; ++r) { s += ssum[r][cl]; q += ssq[r][cl]; }     // fixed order: bitwise reproducible
+    if (threadIdx.x == 0) {
+        s = (ssum[0] + ssum[1]) + (ssum[2] + ssum[3]);
+        q = (ssq[0] + ssq[1]) + (ssq[2] + ssq[3]);
         double n = (double)pcount;
         if (n < 1.0) {                       // SparseSequential skips BN when there is no active site
             mean_out[c] = 0.f; invstd_out[c] = 0.f; scale_out[c] = 0.f; shift_out[c] = 0.f;
@@ -71,7 +70,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int ntiles
 extern "C" int tri_bn_finalize(const float* partial, int ntiles, int C, const int* count_dev, int count_host, const float* gamma,
                                const float* beta, float* running_mean, float* running_var, long long* num_batches_tracked,
                                float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, void* stream) {
-    bn_finalize_kernel<<<(C + 15) / 16, 1024, 0, (hipStream_t)stream>>>(partial, ntiles, C, count_dev, count_host, gamma, beta,
+    bn_finalize_kernel<<<C, 256, 0, (hipStream_t)stream>>>(partial, ntiles, C, count_dev, count_host, gamma, beta,
                                                                       running_mean, running_var, num_batches_tracked, momentum,
                                                                       eps, mean, invstd, scale, shift);
     return tri_check_launch("tri_bn_finalize");
@@ -149,7 +148,7 @@ extern "C" int tri_relu_bwd(const void* dout, const void* out, void* g, long n, 
 static inline int bnb_rows(long M) { return M >= 65536 ? 256 : 64; }
 // MASK (compile time - a run-time test inside the row loop cost 1.6-2.5x on every launch): 0 g is final, 1 ReLU mask
 // recomputed from y, 2 ReLU mask from the saved output `ro`
-template <typename T, int MASK>
+template <typename T, int MASK, bool ROWMASK>
 __global__ void bn_bwd_reduce_kernel(const T* __restrict__ y, const T* __restrict__ g, long M, int C, float* __restrict__ partial,
                                      int BNB_ROWS, const float4* __restrict__ rs, const float4* __restrict__ rb,
                                      const T* __restrict__ ro, const uint8_t* __restrict__ row_mask) {
@@ -169,7 +168,8 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ y, const T* __restric
         if (c4 < C4 && tr < rpp)
 #pragma unroll 4
             for (long r = r0 + tr; r < r1; r += rpp) {
-                if (row_mask && !row_mask[r]) continue;          // inactive sites: y / g rows are not even written (compact conv rows)
+                if (ROWMASK && !row_mask[r]) continue;           // inactive sites: y / g rows are not even written (compact conv rows)
+                                                                 // (compile-time flag: a run-time test here halved the speed of every launch)
                 float4 gv = Act<T>::ld4(g + r * C + c4 * 4), yv = Act<T>::ld4(y + r * C + c4 * 4);
                 if (MASK == 1) {
                     gv.x = __fmaf_rn(yv.x, s4.x, b4.x) > 0.f ? gv.x : 0.f; gv.y = __fmaf_rn(yv.y, s4.y, b4.y) > 0.f ? gv.y : 0.f;
@@ -214,8 +214,12 @@ extern "C" int tri_bn_bwd_reduce(const void* y, const void* g, long M, int C, fl
     size_t smem = (size_t)rpp * tpr * 8 * sizeof(float);
     if (relu_scale && relu_out) { tri_set_error("tri_bn_bwd_reduce: give either relu_scale/shift or relu_out"); return TRI_ERR_ARG; }
 #define TRI_BNR(MASK_)                                                                                                              \
-    TRI_ACT_DISPATCH(act_fmt, bn_bwd_reduce_kernel<T, MASK_><<<nblk, 256, smem, (hipStream_t)stream>>>(                             \
-        (const T*)y, (const T*)g, M, C, partial, rows, (const float4*)relu_scale, (const float4*)relu_shift, (const T*)relu_out, row_mask))
+    do {                                                                                                                            \
+        if (row_mask) TRI_ACT_DISPATCH(act_fmt, bn_bwd_reduce_kernel<T, MASK_, true><<<nblk, 256, smem, (hipStream_t)stream>>>(       \
+            (const T*)y, (const T*)g, M, C, partial, rows, (const float4*)relu_scale, (const float4*)relu_shift, (const T*)relu_out, row_mask)); \
+        else TRI_ACT_DISPATCH(act_fmt, bn_bwd_reduce_kernel<T, MASK_, false><<<nblk, 256, smem, (hipStream_t)stream>>>(               \
+            (const T*)y, (const T*)g, M, C, partial, rows, (const float4*)relu_scale, (const float4*)relu_shift, (const T*)relu_out, row_mask)); \
+    } while (0)
     if (relu_out) TRI_BNR(2);
     else if (relu_scale) TRI_BNR(1);
     else TRI_BNR(0);
@@ -227,28 +231,27 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nb
                                        int count_host, const float* __restrict__ gamma, const float* __restrict__ mean,
                                        const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                        float* __restrict__ c1, float* __restrict__ c2, float* __restrict__ c3, float out_scale) {
-    __shared__ double ssum[64][17], ssq[64][17];                    // 16 channels x 64 record lanes per block, see bn_finalize_kernel
-    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
+    __shared__ double ssum[4], ssq[4];                              // one channel per block, see bn_finalize_kernel
+    const int c = blockIdx.x;
     float pmu = 0.f, pis = 0.f, pga = 0.f;
     int pcount = count_host;
-    if (rl == 0 && c < C) {                                         // requested up front, see bn_finalize_kernel
+    if (threadIdx.x == 0) {                                         // requested up front, see bn_finalize_kernel
         pmu = mean[c]; pis = invstd[c]; pga = gamma[c];
         if (count_dev) pcount = *count_dev;
     }
     double s = 0.0, q = 0.0;
-    if (c < C)
 #pragma unroll 8
-        for (int b = rl; b < nblk; b += 64) {
-            s += (double)partial[((size_t)b * 2 + 0) * C + c];
-            q += (double)partial[((size_t)b * 2 + 1) * C + c];
-        }
-    ssum[rl][cl] = s; ssq[rl][cl] = q;
+    for (int b = threadIdx.x; b < nblk; b += 256) {
+        s += (double)partial[((size_t)b * 2 + 0) * C + c];
+        q += (double)partial[((size_t)b * 2 + 1) * C + c];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+    if ((threadIdx.x & 63) == 0) { ssum[threadIdx.x >> 6] = s; ssq[threadIdx.x >> 6] = q; }
     __syncthreads();
-    if (rl == 0 && c < C) {
-        s = 0.0; q = 0.0;
-#pragma unroll 8
-        for (int r = 0; r < 64; ++r) { s += ssum[r][cl]; q += ssq[r][cl]; }
+    if (threadIdx.x == 0) {
+        s = (ssum[0] + ssum[1]) + (ssum[2] + ssum[3]);
+        q = (ssq[0] + ssq[1]) + (ssq[2] + ssq[3]);
         double n = (double)pcount;
         if (n < 1.0) { dgamma[c] = 0.f; dbeta[c] = 0.f; c1[c] = 0.f; c2[c] = 0.f; c3[c] = 0.f; return; }
         double mu = pmu, is = pis, ga = pga;
@@ -265,7 +268,7 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nb
 extern "C" int tri_bn_bwd_finalize(const float* partial, int nblk, int C, const int* count_dev, int count_host, const float* gamma,
                                    const float* mean, const float* invstd, float* dgamma, float* dbeta, float* c1, float* c2,
                                    float* c3, float out_scale, void* stream) {
-    bn_bwd_finalize_kernel<<<(C + 15) / 16, 1024, 0, (hipStream_t)stream>>>(partial, nblk, C, count_dev, count_host, gamma, mean,
+    bn_bwd_finalize_kernel<<<C, 256, 0, (hipStream_t)stream>>>(partial, nblk, C, count_dev, count_host, gamma, mean,
                                                                           invstd, dgamma, dbeta, c1, c2, c3, out_scale);
     return tri_check_launch("tri_bn_bwd_finalize");
 }
