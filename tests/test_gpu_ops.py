@@ -610,6 +610,8 @@ BF16_CASES = [c for c in CONV_CASES if c[0] in ("vox_l0", "vox_l1", "vox_l3", "s
     ("h_28x20", 2, (1, 28, 20), 64, 64, (1, 3, 3), 1, (0, 1, 1), "torch"),
     ("h_56", 1, (1, 56, 56), 64, 64, (1, 3, 3), 1, (0, 1, 1), "torch"),
     ("h_many", 40, (1, 32, 32), 64, 64, (1, 3, 3), 1, (0, 1, 1), "torch"),
+    # more tiles than CUs with four output-channel tiles and two channel chunks each (the weight stream crosses tile boundaries)
+    ("h_320", 160, (1, 8, 8), 128, 256, (1, 3, 3), 1, (0, 1, 1), "torch"),
 ]
 
 
