@@ -309,17 +309,15 @@ def run_mode(a, precision, world, rank, device, want_voxel_roofline):
                                         "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in agg.items()}}
             # HBM bytes per launch of that kernel from the committed PMC passes over this same command (PMC cannot run inside
             # bench.py: separate `rocprofv3 --pmc` runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes)
-            for rel in ("profiles/r2/pmc_step_traffic.json", "profiles/r1/pmc_step_traffic.json"):
-                try:
-                    with open(os.path.join(REPO, rel)) as f:
-                        doc = json.load(f)
-                    pmc = doc["kernels"].get(sym)
-                    if pmc and doc.get("precision", "bf16") == precision:
-                        roof["traffic"] = pmc["hbm_read_bytes_per_launch"] + (pmc["hbm_write_bytes_per_launch"] or 0)
-                        roof["traffic_unit"] = f"HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, {rel})"
-                        break
-                except Exception:                   # noqa: BLE001
-                    pass
+            rel = f"profiles/r2/pmc_traffic_{precision}.json"
+            try:
+                with open(os.path.join(REPO, rel)) as f:
+                    pmc = json.load(f)["kernels"].get(sym)
+                if pmc:
+                    roof["traffic"] = pmc["fetch_bytes_per_launch"] + pmc["write_bytes_per_launch"]
+                    roof["traffic_unit"] = f"fabric bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, mean over the step's launches; {rel})"
+            except Exception:                       # noqa: BLE001  no committed PMC pass for this mode: traffic stays null
+                pass
         if want_voxel_roofline and net.voxel_encoder is not None and "locs" in batches[0]["voxels"]:
             vox_roof = voxel_fwd_roofline(net, batches[0], B)
     res = {"value": round(B * world * a.steps / elapsed, 2), "ms_per_step": round(elapsed / a.steps * 1e3, 3),

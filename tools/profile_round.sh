@@ -1,0 +1,21 @@
+#!/bin/bash
+# Round evidence recipe (run on the GPU box from the repo root):  bash tools/profile_round.sh <tag>
+# Writes gpurun_out/<tag>_*: the -m gpu test log, bench.py JSON lines (default run + configs 2/3/5), rocprofv3 kernel stats
+# for the f16 and bf16x3 modes and the two PMC passes (FETCH_SIZE / WRITE_SIZE in separate runs, MI355X_MICROARCH.md).
+tag=${1:-r2}
+R=$PWD
+O=$R/gpurun_out
+mkdir -p $O
+python -m pytest tests -m gpu -q 2>&1 | tail -8 > $O/${tag}_gpu_tests.txt
+python bench.py > $O/${tag}_bench_default.json 2> $O/${tag}_bench_default.err
+for c in 2 3 5; do python bench.py --config $c --modes "" --no-cpu-baseline > $O/${tag}_bench_cfg$c.json 2> $O/${tag}_bench_cfg$c.err; done
+cd /tmp && export TMPDIR=/tmp
+for p in f16 bf16x3; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_prof_$p -- python3 $R/bench.py --steps 20 --warmup 5 --precision $p --modes "" --no-cpu-baseline > $O/${tag}_prof_$p.json 2> $O/${tag}_prof_$p.err
+done
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${tag}_pmc_fetch -- python3 $R/bench.py --steps 3 --warmup 2 --precision f16 --modes "" --no-cpu-baseline > $O/${tag}_pmc_fetch.json 2> $O/${tag}_pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${tag}_pmc_write -- python3 $R/bench.py --steps 3 --warmup 2 --precision f16 --modes "" --no-cpu-baseline > $O/${tag}_pmc_write.json 2> $O/${tag}_pmc_write.err
+cd $R
+# keep the merged-back payload small: kernel traces are large, the stats CSVs are what gets committed
+find $O/${tag}_prof_* -name "*kernel_trace.csv" -size +20M -delete
+ls -la $O | tail -30
