@@ -117,6 +117,25 @@ int tri_conv_plan_build(const TriConvDesc* d, void* plan, void* stream);
 int tri_conv_wgrad(const TriConvDesc* d, const void* in, const void* dout, const uint8_t* row_mask, const void* plan /* required */,
                    void* workspace, size_t workspace_bytes, float* dw, long s_co, long s_tap, long s_ci, int cin_real, int split3,
                    int act_fmt, float out_scale /* dw = out_scale * sum: undoes the f16 mode's gradient scaling */, void* stream);
+/* The same in two halves, so that a tower's backward pays ONE reduce launch instead of one per layer: tri_conv_wgrad_partial runs
+ * the position-split partial kernel into `workspace` (which must stay untouched until the reduce) and fills *pending;
+ * tri_wgrad_reduce_grouped sums the slabs of n pending layers into their dw (any n; TRI_WGRAD_GROUP_MAX layers per launch).
+ * Same arithmetic and summation order as tri_conv_wgrad: results are bitwise identical. */
+#ifndef TRI_WGRAD_GROUP_MAX
+#define TRI_WGRAD_GROUP_MAX 24
+#endif
+typedef struct TriWgradReduce {
+    const float* slab;
+    float* dw;
+    long s_co, s_tap, s_ci;
+    int splits, Cout, Kpad, ntaps, cin_stored, cin_real, zlanes, nblocks;
+    float out_scale;
+    int reserved;
+} TriWgradReduce;
+int tri_conv_wgrad_partial(const TriConvDesc* d, const void* in, const void* dout, const uint8_t* row_mask, const void* plan /* required */,
+                           void* workspace, size_t workspace_bytes, float* dw, long s_co, long s_tap, long s_ci, int cin_real, int split3,
+                           int act_fmt, float out_scale, TriWgradReduce* pending /* HOST, out */, void* stream);
+int tri_wgrad_reduce_grouped(const TriWgradReduce* pending /* HOST array */, int n, void* stream);
 
 /* ---- BatchNorm (train-mode statistics, eps / momentum as torch.nn.BatchNorm1d/2d) ----------------------------------
  * Replaces nn.BatchNorm1d over active voxels (sparse_cnn.py:13,18,23,28,33; count from a device counter) and the 20
@@ -158,6 +177,7 @@ int tri_avgpool_viewmax_fwd(const void* x, int B, int V, int HW, int C, float* o
 int tri_avgpool_viewmax_bwd(const float* dout, const int* arg, int B, int V, int HW, int C, void* dx, int act_fmt, float scale, void* stream);
 
 /* ---- layout converters (batch layout of tricolo/data/data_module.py:40-65) ---------------------------------------- */
+/* dense [B,V,V,V,4] and mask [B*V^3 padded to 32 bytes] are zero-filled by the call (one fill when mask directly follows dense) */
 int tri_voxel_scatter(const int* locs, const float* feats, int n, int B, int V, void* dense, uint8_t* mask, int act_fmt, void* stream);
 /* the dataset's dense RGBA u8 grids [B,4,V,V,V] straight to the tower input (active <=> alpha != 0, feats =
  * RGB / 255; general_dataset.py:47-51,92-93) - no CPU COO build, no scatter.  mask must hold B*V^3 bytes (padded to 32). */
@@ -211,6 +231,18 @@ int tri_ntxent_fwd_bwd(const float* za, const float* zb, int B, int D, float tem
  * = upstream d(total)/d(loss), folded in */
 int tri_ntxent_bwd(const float* za, const float* zb, int B, int D, float temperature, float alpha, int norm, const float* dloss,
                    float* dza, float* dzb, const void* workspace, size_t workspace_bytes, void* stream);
+/* All pairs of a step at once (tricolo_net.py:56-63: the loss of every pair of modalities, summed): M = 2 or 3 embeddings
+ * z[m] [B, D] (HOST array of device pointers, in the reference's modality order - the earlier one of a pair is the alpha
+ * side), 4 launches forward, 1 backward.  losses [P + 1] (device) = the pair losses in itertools.combinations order, then
+ * their sum ((l0 + l1) + l2 in fp32, as Python's sum()).  The backward takes the upstream gradients of the pair losses
+ * (HOST array of device scalars, NULL entries / NULL array = 0) and of the total (device scalar or NULL) and writes
+ * dz[m] = sum over m's pairs.  B <= 512, D % 4 == 0, D <= 2048 (TRI_ERR_UNSUPPORTED otherwise: use the per-pair calls). */
+size_t tri_ntxent_multi_workspace(int M, int B, int D);
+int tri_ntxent_multi_fwd(const float* const* z, int M, int B, int D, float temperature, float alpha, int norm, float* losses,
+                         void* workspace, size_t workspace_bytes, void* stream);
+int tri_ntxent_multi_bwd(const float* const* z, int M, int B, int D, float temperature, float alpha, int norm,
+                         const float* const* dpair, const float* dtotal, float* const* dz, const void* workspace,
+                         size_t workspace_bytes, void* stream);
 
 /* ---- Adam (torch.optim.Adam as instantiated by config/config.yaml:50-53, tricolo_net.py:43-44) ------------------------ */
 int tri_adam_tick(int* step, void* stream);

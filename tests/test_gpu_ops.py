@@ -719,3 +719,88 @@ def test_elementwise_kernels_16bit_storage(bf):
     assert torch.equal(po.float().cpu().view(N, 5, 5, C).permute(0, 3, 1, 2), refp.detach())
     dxp = ops.maxpool2d_bwd(parg, dp.permute(0, 2, 3, 1).contiguous().to(DEV).to(bf), tuple(xcl.shape))
     assert torch.equal(dxp.float().cpu().view(N, 10, 10, C).permute(0, 3, 1, 2), xr.grad)
+
+
+@pytest.mark.parametrize("store,prec", [(torch.float32, "bf16x3"), (torch.float16, "f16")], ids=["bf16x3", "f16"])
+def test_wgrad_grouped_reduce_is_bitwise_the_per_layer_reduce(store, prec):
+    """tri_conv_wgrad_partial + ONE tri_wgrad_reduce_grouped over many layers (more than TRI_WGRAD_GROUP_MAX = 24, so the
+    list is cut into two launches) against tri_conv_wgrad layer by layer: same partial kernels, same summation order."""
+    names = ("vox_l0", "vox_l1", "stem7x7", "c3x3s1", "c3x3s2", "c1x1s2", "odd14", "linear", "vox_l3")
+    cases = [c for c in CONV_CASES if c[0] in names]
+    batch = ops.WgradBatch(torch.device(DEV))
+    refs, outs = [], []
+    for i in range(27):
+        case = cases[i % len(cases)]
+        x, w, wp, xcl, g = make_case(case, integer=False, seed=100 + i)
+        gen = torch.Generator().manual_seed(500 + i)
+        dy = torch.randn((g.B, *g.out_grid, g.cout), generator=gen)
+        xd, dyd = xcl.to(DEV).to(store), dy.to(DEV).to(store)
+        scale = 1.0 if i % 2 else 0.25
+        refs.append(ops.conv_wgrad(xd, dyd, g, wp.to(DEV), prec, out_scale=scale))
+        outs.append(ops.conv_wgrad(xd, dyd, g, wp.to(DEV), prec, out_scale=scale, batch=batch))
+    assert len(batch.descs) == 27
+    batch.flush()
+    assert batch.descs == [] and batch.off == 0
+    torch.cuda.synchronize()
+    for i, (r, o) in enumerate(zip(refs, outs)):
+        assert torch.equal(r, o), f"layer {i}: max abs diff {(r - o).abs().max().item()}"
+    # the arena is reused by the next batch of the stream (same slabs, no new allocation)
+    n_chunks = len(batch.chunks)
+    b2 = ops.WgradBatch(torch.device(DEV))
+    case = cases[3]
+    x, w, wp, xcl, g = make_case(case, integer=True, seed=7)
+    dy = ints((g.B, *g.out_grid, g.cout), -2, 2, 9)
+    o = ops.conv_wgrad(xcl.to(DEV).to(store), dy.to(DEV).to(store), g, wp.to(DEV), prec, batch=b2)
+    b2.flush()
+    assert len(b2.chunks) == n_chunks and b2.chunks is batch.chunks
+    assert torch.equal(o, ops.conv_wgrad(xcl.to(DEV).to(store), dy.to(DEV).to(store), g, wp.to(DEV), prec))
+
+
+@pytest.mark.parametrize("M,B,D,norm", [(3, 32, 512, True), (3, 5, 512, True), (2, 8, 512, True), (3, 300, 512, True), (3, 7, 64, False)],
+                         ids=["tri_b32", "tri_b5", "bi_b8", "tri_b300", "tri_nonorm"])
+def test_ntxent_all_pairs_equals_the_pair_by_pair_loop(M, B, D, norm):
+    """NTXentLoss.all_pairs (4 + 1 launches for every pair of the step, tricolo_net.py:56-63) against the per-pair kernels
+    (themselves pinned to the real NTXentLoss by the golden test above) and against float64: pair losses, their sum in Python's
+    order, and each embedding's gradient summed over its pairs - with upstream gradients on the total AND on one pair loss."""
+    from itertools import combinations
+
+    from oracle.modules import nt_xent_numpy
+    from tricolo_amd.loss.nt_xent import NTXentLoss
+    g = torch.Generator().manual_seed(31 + B)
+    zs = [torch.randn(B, D, generator=g) for _ in range(M)]
+    zs[1][: B // 2] += 2 * zs[0][: B // 2]
+    T, alpha = 0.1, 0.25
+    loss_fn = NTXentLoss(T, alpha)
+    zd = [z.to(DEV).requires_grad_() for z in zs]
+    pairs, total = loss_fn.all_pairs(zd, norm=norm)
+    assert len(pairs) == M * (M - 1) // 2
+    zr = [z.to(DEV).requires_grad_() for z in zs]
+    ref_pairs = [loss_fn(zr[a], zr[b], norm=norm) for a, b in combinations(range(M), 2)]
+    ref_total = sum(ref_pairs)
+    for l, r in zip(pairs, ref_pairs):
+        assert abs(l.item() - r.item()) <= 2e-6 * max(1.0, abs(r.item()))
+    assert total.item() == sum(p.item() for p in [torch.tensor(x.item(), dtype=torch.float32) for x in pairs]) or \
+        abs(total.item() - ref_total.item()) < 1e-5
+    (total * 1.5 + pairs[0] * 0.5).backward()
+    (ref_total * 1.5 + ref_pairs[0] * 0.5).backward()
+    for a, b in zip(zd, zr):
+        np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.cpu().numpy(), rtol=1e-5, atol=2e-7)
+    if norm:
+        # float64 restatement: gradient of 1.5 * sum(pairs) + 0.5 * pair0
+        acc = [np.zeros((B, D)) for _ in range(M)]
+        for k, (a, b) in enumerate(combinations(range(M), 2)):
+            l64, da, db = nt_xent_numpy(zs[a].numpy(), zs[b].numpy(), T, alpha)
+            assert abs(pairs[k].item() - l64) < 2e-5
+            wgt = 1.5 + (0.5 if k == 0 else 0.0)
+            acc[a] += wgt * da
+            acc[b] += wgt * db
+        for m in range(M):
+            np.testing.assert_allclose(zd[m].grad.cpu().numpy(), acc[m], atol=3e-6)
+
+
+def test_ntxent_all_pairs_declines_shapes_outside_the_fused_range():
+    from tricolo_amd.loss.nt_xent import NTXentLoss
+    loss_fn = NTXentLoss(0.1, 0.25)
+    assert loss_fn.all_pairs([torch.randn(600, 512, device=DEV) for _ in range(3)]) is None        # B > 512: per-pair path
+    assert loss_fn.all_pairs([torch.randn(8, 512, device=DEV) for _ in range(4)]) is None          # four modalities
+    assert loss_fn.all_pairs([torch.randn(8, 510, device=DEV) for _ in range(2)]) is None          # D % 4

@@ -25,6 +25,12 @@ class TriPrepDesc(C.Structure):
                 ("kpad", C.c_int), ("fmt", C.c_int)]
 
 
+class TriWgradReduce(C.Structure):
+    _fields_ = [("slab", C.c_void_p), ("dw", C.c_void_p), ("s_co", C.c_long), ("s_tap", C.c_long), ("s_ci", C.c_long)] + \
+               [(n, C.c_int) for n in ("splits", "Cout", "Kpad", "ntaps", "cin_stored", "cin_real", "zlanes", "nblocks")] + \
+               [("out_scale", C.c_float), ("reserved", C.c_int)]
+
+
 P, I, L, F, Z = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
 DP = C.POINTER(TriConvDesc)
 
@@ -52,6 +58,8 @@ SIGNATURES = {
     "tri_conv_plan_bytes": (Z, [DP]),
     "tri_conv_plan_build": (I, [DP, P, P]),
     "tri_conv_wgrad": (I, [DP, P, P, P, P, P, Z, P, L, L, L, I, I, I, F, P]),
+    "tri_conv_wgrad_partial": (I, [DP, P, P, P, P, P, Z, P, L, L, L, I, I, I, F, P, P]),
+    "tri_wgrad_reduce_grouped": (I, [P, I, P]),
     "tri_bn_finalize": (I, [P, I, I, P, I, P, P, P, P, P, F, F, P, P, P, P, P]),
     "tri_bn_eval_coeffs": (I, [I, P, P, P, P, F, P, P, P, P, P]),
     "tri_bn_act": (I, [P, P, P, P, P, P, P, L, I, I, I, P]),
@@ -85,6 +93,9 @@ SIGNATURES = {
     "tri_ntxent_workspace": (Z, [I, I]),
     "tri_ntxent_fwd_bwd": (I, [P, P, I, I, F, F, I, P, P, P, P, Z, P]),
     "tri_ntxent_bwd": (I, [P, P, I, I, F, F, I, P, P, P, P, Z, P]),
+    "tri_ntxent_multi_workspace": (Z, [I, I, I]),
+    "tri_ntxent_multi_fwd": (I, [P, I, I, I, F, F, I, P, P, Z, P]),
+    "tri_ntxent_multi_bwd": (I, [P, I, I, I, F, F, I, P, P, P, P, Z, P]),
     "tri_copy_segments": (I, [P, P, P, I, P]),
     "tri_gru_bias_grads": (I, [P, I, P, P, P, P, P]),
     "tri_adam_tick": (I, [P, P]),

@@ -345,6 +345,9 @@ __global__ void bn_relu_pool3d_fwd_kernel(const T* __restrict__ y, const float4*
         Act<T>::st4(pooled + i * 4, best);             // best >= 0: ReLU folded into the max with the zero init
         if (c == 0) mask_out[pos] = (uint8_t)any;
     }
+    // every site's byte is written above; the padding of mask_out (to 32 bytes) is zeroed here, so callers pre-fill nothing
+    const long npos = (long)B * Do * Do * Do, pad = (npos + 31) / 32 * 32;
+    if (blockIdx.x == 0 && npos + threadIdx.x < pad) mask_out[npos + threadIdx.x] = 0;
 }
 extern "C" int tri_bn_relu_pool3d_fwd(const void* y, const float* scale, const float* shift, const uint8_t* mask, int B, int D, int C,
                                       void* pooled, uint8_t* mask_out, int act_fmt, void* stream) {

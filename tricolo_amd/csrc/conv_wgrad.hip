@@ -472,14 +472,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs p) 
 // split lanes: lane z sums splits z, z + zlanes, ... and lane 0 adds the partials in a fixed order (bitwise
 // reproducible for a given layer shape).  zlanes grows with splits / outputs so that the layers with hundreds of splits
 // and a tiny dW (stem, voxel level 0) still put a few hundred thousand loads in flight.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, int Cout, int Kpad, int ntaps,
-                                                           int cin_stored, int cin_real, float* __restrict__ dw, long s_co, long s_tap,
-                                                           long s_ci, int zlanes, float out_scale) {
-    __shared__ float4 part[256];
+__device__ __forceinline__ void wgrad_reduce_block(const float* __restrict__ slab, int splits, int Cout, int Kpad, int ntaps, int cin_stored,
+                                                   int cin_real, float* __restrict__ dw, long s_co, long s_tap, long s_ci, int zlanes,
+                                                   float out_scale, unsigned block, float4* part) {
     const int kq = 256 / zlanes;                                 // quads per block
     const int ql = threadIdx.x % kq, zl = threadIdx.x / kq;
     const int K4 = (ntaps * cin_stored) >> 2;
-    const long quad = (long)blockIdx.x * kq + ql;
+    const long quad = (long)block * kq + ql;
     const bool live = quad < (long)Cout * K4;
     const int co = live ? (int)(quad / K4) : 0, k = live ? (int)(quad - (long)co * K4) * 4 : 0;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -510,6 +509,27 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
             if (ci + 3 < cin_real) d[3 * s_ci] = s.w;
         }
     }
+}
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, int Cout, int Kpad, int ntaps,
+                                                           int cin_stored, int cin_real, float* __restrict__ dw, long s_co, long s_tap,
+                                                           long s_ci, int zlanes, float out_scale) {
+    __shared__ float4 part[256];
+    wgrad_reduce_block(slab, splits, Cout, Kpad, ntaps, cin_stored, cin_real, dw, s_co, s_tap, s_ci, zlanes, out_scale, blockIdx.x, part);
+}
+// Grouped form: the reduces of up to TRI_WGRAD_GROUP_MAX layers in ONE launch (their partial kernels ran earlier into per-layer
+// slabs - tri_conv_wgrad_partial).  A tower's backward then pays one reduce launch instead of one per layer (28 launches of
+// 5-23 us each per step, every one of them on the critical path between a weight-gradient kernel and the next data gradient).
+struct WgradGroup {
+    TriWgradReduce d[TRI_WGRAD_GROUP_MAX];
+    int first_block[TRI_WGRAD_GROUP_MAX + 1];
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_grouped_kernel(const WgradGroup g, int n) {
+    __shared__ float4 part[256];
+    int i = 0;
+    while (i + 1 < n && (int)blockIdx.x >= g.first_block[i + 1]) ++i;
+    const TriWgradReduce& r = g.d[i];
+    wgrad_reduce_block(r.slab, r.splits, r.Cout, r.Kpad, r.ntaps, r.cin_stored, r.cin_real, r.dw, r.s_co, r.s_tap, r.s_ci, r.zlanes,
+                       r.out_scale, blockIdx.x - g.first_block[i], part);
 }
 
 static int ilog2_exact(int v) {
@@ -660,9 +680,10 @@ static int launch_wgrad(const WgradArgs& a, int tiles, int splits, hipStream_t s
 // dw (addressed by element strides s_co / s_tap / s_ci, i.e. directly in the reference's parameter layout)
 //   = sum over positions of dout x im2col(in).  row_mask (optional, per output position, buffer padded to a
 // multiple of 32 bytes) marks live positions; split3 != 0 selects the 3-product bf16 split mode.
-extern "C" int tri_conv_wgrad(const TriConvDesc* d, const void* in, const void* dout, const uint8_t* row_mask, const void* plan,
-                              void* workspace, size_t workspace_bytes, float* dw, long s_co, long s_tap, long s_ci, int cin_real,
-                              int split3, int act_fmt, float out_scale, void* stream) {
+extern "C" int tri_conv_wgrad_partial(const TriConvDesc* d, const void* in, const void* dout, const uint8_t* row_mask, const void* plan,
+                                      void* workspace, size_t workspace_bytes, float* dw, long s_co, long s_tap, long s_ci, int cin_real,
+                                      int split3, int act_fmt, float out_scale, TriWgradReduce* pending, void* stream) {
+    if (!pending) { tri_set_error("wgrad: pending descriptor is NULL"); return TRI_ERR_ARG; }
     if (d->Cin % 4 != 0 || d->Cout % 4 != 0) { tri_set_error("wgrad: channels must be multiples of 4"); return TRI_ERR_ARG; }
     int BI, BJ, tiles, splits, sps, Kpad, dma;
     wgrad_plan(d, act_fmt, &BI, &BJ, &tiles, &splits, &sps, &Kpad, &dma);
@@ -710,7 +731,40 @@ extern "C" int tri_conv_wgrad(const TriConvDesc* d, const void* in, const void* 
     int zlanes = 1;
     while (zlanes < 64 && zlanes * 2 <= splits && quads * zlanes < 262144) zlanes *= 2;
     const int kq = 256 / zlanes;
-    wgrad_reduce_kernel<<<(unsigned)((quads + kq - 1) / kq), 256, 0, s>>>((const float*)workspace, splits, d->Cout, Kpad, a.ntaps, d->Cin,
-                                                                          cin_real, dw, s_co, s_tap, s_ci, zlanes, out_scale);
+    pending->slab = (const float*)workspace; pending->dw = dw; pending->s_co = s_co; pending->s_tap = s_tap; pending->s_ci = s_ci;
+    pending->splits = splits; pending->Cout = d->Cout; pending->Kpad = Kpad; pending->ntaps = a.ntaps; pending->cin_stored = d->Cin;
+    pending->cin_real = cin_real; pending->zlanes = zlanes; pending->nblocks = (int)((quads + kq - 1) / kq); pending->out_scale = out_scale;
+    return 0;
+}
+
+extern "C" int tri_wgrad_reduce_grouped(const TriWgradReduce* pending, int n, void* stream) {
+    if (n < 0 || (n > 0 && !pending)) { tri_set_error("wgrad reduce: bad descriptor list"); return TRI_ERR_ARG; }
+    for (int base = 0; base < n; base += TRI_WGRAD_GROUP_MAX) {
+        const int m = n - base < TRI_WGRAD_GROUP_MAX ? n - base : TRI_WGRAD_GROUP_MAX;
+        WgradGroup g{};
+        int blocks = 0;
+        for (int i = 0; i < m; ++i) {
+            g.d[i] = pending[base + i];
+            if (g.d[i].nblocks <= 0 || g.d[i].zlanes <= 0 || 256 % g.d[i].zlanes) { tri_set_error("wgrad reduce: descriptor not filled by tri_conv_wgrad_partial"); return TRI_ERR_ARG; }
+            g.first_block[i] = blocks;
+            blocks += g.d[i].nblocks;
+        }
+        g.first_block[m] = blocks;
+        wgrad_reduce_grouped_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(g, m);
+        int rc = tri_check_launch("tri_wgrad_reduce_grouped");
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+extern "C" int tri_conv_wgrad(const TriConvDesc* d, const void* in, const void* dout, const uint8_t* row_mask, const void* plan,
+                              void* workspace, size_t workspace_bytes, float* dw, long s_co, long s_tap, long s_ci, int cin_real,
+                              int split3, int act_fmt, float out_scale, void* stream) {
+    TriWgradReduce r;
+    int rc = tri_conv_wgrad_partial(d, in, dout, row_mask, plan, workspace, workspace_bytes, dw, s_co, s_tap, s_ci, cin_real, split3, act_fmt,
+                                    out_scale, &r, stream);
+    if (rc) return rc;
+    wgrad_reduce_kernel<<<(unsigned)r.nblocks, 256, 0, (hipStream_t)stream>>>(r.slab, r.splits, r.Cout, r.Kpad, r.ntaps, r.cin_stored, r.cin_real,
+                                                                             r.dw, r.s_co, r.s_tap, r.s_ci, r.zlanes, r.out_scale);
     return tri_check_launch("tri_wgrad_reduce");
 }

@@ -41,8 +41,10 @@ extern "C" int tri_voxel_scatter(const int* locs, const float* feats, int n, int
                                  void* stream) {
     hipStream_t s = (hipStream_t)stream;
     size_t sites = (size_t)B * V * V * V;
-    hipMemsetAsync(dense, 0, sites * 4 * (act_fmt ? 2 : 4), s);
-    hipMemsetAsync(mask, 0, sites, s);
+    // the mask is zeroed up to its 32-byte padding (callers need not pre-fill anything); one fill when it directly follows `dense`
+    const size_t dense_bytes = sites * 4 * (act_fmt ? 2 : 4), mask_bytes = (sites + 31) / 32 * 32;
+    if ((char*)dense + dense_bytes == (char*)mask) hipMemsetAsync(dense, 0, dense_bytes + mask_bytes, s);
+    else { hipMemsetAsync(dense, 0, dense_bytes, s); hipMemsetAsync(mask, 0, mask_bytes, s); }
     if (n > 0) TRI_ACT_DISPATCH(act_fmt, voxel_scatter_kernel<T><<<(n + 255) / 256, 256, 0, s>>>(locs, feats, n, B, V, (T*)dense, mask));
     return tri_check_launch("tri_voxel_scatter");
 }
@@ -66,6 +68,7 @@ __global__ void voxel_from_rgba_kernel(const uint8_t* __restrict__ rgba, long V3
 extern "C" int tri_voxel_from_rgba_u8(const uint8_t* rgba, int B, int V, void* dense, uint8_t* mask, int act_fmt, void* stream) {
     const long V3 = (long)V * V * V, total = (long)B * V3;
     TRI_ACT_DISPATCH(act_fmt, voxel_from_rgba_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(rgba, V3, total, (T*)dense, mask));
+    if (total % 32) hipMemsetAsync(mask + total, 0, 32 - total % 32, (hipStream_t)stream);      // padding bytes of the mask
     return tri_check_launch("tri_voxel_from_rgba_u8");
 }
 

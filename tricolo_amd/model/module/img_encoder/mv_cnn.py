@@ -201,7 +201,7 @@ class MVCNNEncoder(TriModule):
         zz, hi = self._forward_upper(x2, save)
         return zz, {"lower": lo, "upper": hi}
 
-    def _backward_blocks(self, blocks, saved_blocks, dout, gr, prec, ugs):
+    def _backward_blocks(self, blocks, saved_blocks, dout, gr, prec, ugs, batch=None):
         """BasicBlock backward over `blocks` (last first); returns the gradient w.r.t. the first block's input."""
         side = self._side
         # Weight gradients need only x and dy and could run beside the dgrad / BatchNorm-backward chain on a side stream
@@ -215,7 +215,7 @@ class MVCNNEncoder(TriModule):
             ch = pattern[turn[0] % len(pattern)]
             turn[0] += 1
             if ch == "m":
-                gr[w] = ops.conv_wgrad(x, dy, g, w, prec, out_scale=ugs)
+                gr[w] = ops.conv_wgrad(x, dy, g, w, prec, out_scale=ugs, batch=batch)     # reduced by the caller's batch.flush()
                 return
             with torch.cuda.stream(side.fork(x, dy)):
                 gr[w] = ops.conv_wgrad(x, dy, g, w, prec, out_scale=ugs)
@@ -247,10 +247,14 @@ class MVCNNEncoder(TriModule):
         side.join(*[v for v in gr.values() if v.dim() == 4])
         return dout
 
-    def _backward_upper(self, saved, dz):
-        """-> (gradient w.r.t. the lower half's output x2 - carried times ops.grad_scale in the f16 mode -, upper parameter grads)."""
+    def _backward_upper(self, saved, dz, batch=None):
+        """-> (gradient w.r.t. the lower half's output x2 - carried times ops.grad_scale in the f16 mode -, upper parameter grads).
+        Weight-gradient reduces of the main stream are deferred into `batch` (one grouped launch; the caller's, or an own one)."""
         prec, B = self._prec(), saved["B"]
         gr = {}
+        own = batch is None
+        if own:
+            batch = ops.wgrad_batch(dz.device)
         do = ops.l2norm_bwd(saved["z"], saved["norm"], dz)
         dh, gr[self.mlp[2].weight], gr[self.mlp[2].bias] = linear_bwd(saved["h"], self.mlp[2].weight, saved["o"], do, 0, prec)
         df, gr[self.mlp[0].weight], gr[self.mlp[0].bias] = linear_bwd(saved["f"], self.mlp[0].weight, saved["h"], dh, 1, prec)
@@ -258,23 +262,34 @@ class MVCNNEncoder(TriModule):
         # f16 mode: activation gradients are carried times gs (ops.F16_GRAD_SCALE); parameter-gradient kernels undo it
         gs = ops.grad_scale(prec)
         dout = ops.avgpool_viewmax_bwd(dp, saved["arg"], saved["feat_shape"], B, self.num_views, dtype=ops.act_dtype(prec), scale=gs)
-        dx2 = self._backward_blocks(self._blocks()[self.N_LOWER_BLOCKS:], saved["blocks"], dout, gr, prec, 1.0 / gs)
+        dx2 = self._backward_blocks(self._blocks()[self.N_LOWER_BLOCKS:], saved["blocks"], dout, gr, prec, 1.0 / gs, batch)
+        if own and batch is not None:
+            batch.flush()
         return dx2, [gr[p] for p in self._upper_params()]
 
-    def _backward_lower(self, saved, dout):
+    def _backward_lower(self, saved, dout, batch=None):
         prec = self._prec()
         ugs = 1.0 / ops.grad_scale(prec)
         gr = {}
-        dout = self._backward_blocks(self._blocks()[:self.N_LOWER_BLOCKS], saved["blocks"], dout, gr, prec, ugs)
+        own = batch is None
+        if own:
+            batch = ops.wgrad_batch(dout.device)
+        dout = self._backward_blocks(self._blocks()[:self.N_LOWER_BLOCKS], saved["blocks"], dout, gr, prec, ugs, batch)
         x0, y, co, g0, parg = saved["stem"]
         dzs = ops.maxpool2d_bwd(parg, dout, tuple(y.shape))
         dy, gr[self.net_1[1].weight], gr[self.net_1[1].bias] = ops.bn_bwd(y, dzs, co, self.net_1[1].weight, count_host=g0.M, relu=True, out_scale=ugs)
-        gr[self.net_1[0].weight] = ops.conv_wgrad(x0, dy, g0, self.net_1[0].weight, prec, out_scale=ugs)
+        gr[self.net_1[0].weight] = ops.conv_wgrad(x0, dy, g0, self.net_1[0].weight, prec, out_scale=ugs, batch=batch)
+        if own and batch is not None:
+            batch.flush()
         return [gr[p] for p in self._lower_params()]
 
     def _backward_impl(self, saved, dz):
-        dx2, up = self._backward_upper(saved["upper"], dz)
-        return self._backward_lower(saved["lower"], dx2) + up
+        batch = ops.wgrad_batch(dz.device)                         # one grouped reduce for the whole tower
+        dx2, up = self._backward_upper(saved["upper"], dz, batch)
+        lo = self._backward_lower(saved["lower"], dx2, batch)
+        if batch is not None:
+            batch.flush()
+        return lo + up
 
     def forward(self, x, data_dict=None):
         require_gpu(x, "MVCNNEncoder")

@@ -140,6 +140,7 @@ class SparseCNNEncoder(TriModule):
         gs = ops.grad_scale(prec)                              # f16 mode: activation gradients carried times gs (see mv_cnn.py)
         ugs = 1.0 / gs
         dx = ops.cast_from_f32(dflat.contiguous(), ops.act_dtype(prec), gs)
+        batch = ops.wgrad_batch(dz.device)                     # the five weight-gradient reduces in one launch at the end
         for l in range(4, -1, -1):
             D, C = V >> l, self.chans[l + 1]
             g = self._geom(B, l)
@@ -147,7 +148,7 @@ class SparseCNNEncoder(TriModule):
             conv, bn = self.sparseModel[str(4 * l)], self.sparseModel[str(4 * l + 1)]
             gz = ops.pool3d_bwd_route(y, co, mask, pooled, dx.contiguous(), B, D, C)
             dy, dgamma, dbeta = ops.bn_bwd(y, gz, co, bn.weight, count_dev=count, row_mask=mask, out_scale=ugs)
-            grads[3 * l] = ops.conv_wgrad(x, dy, g, conv.weight, prec, row_mask=mask, out_scale=ugs)
+            grads[3 * l] = ops.conv_wgrad(x, dy, g, conv.weight, prec, row_mask=mask, out_scale=ugs, batch=batch)
             grads[3 * l + 1], grads[3 * l + 2] = dgamma, dbeta
             if l > 0:
                 pt = self._packed[(l, True)]
@@ -155,6 +156,8 @@ class SparseCNNEncoder(TriModule):
                     dx = ops.conv_dgrad(dy, g, pt, rows=rows)                   # only the active input sites are computed / written
                 else:
                     dx = ops.conv_dgrad(dy, g, pt, row_mask=mask)
+        if batch is not None:
+            batch.flush()
         return grads
 
     def forward(self, x, batch_size):

@@ -125,6 +125,13 @@ class TriCoLoNet(TriModule):
 
     def _calculate_losses(self, output_dict, loss_prefix):
         loss_dict = {}
+        fused = getattr(self.loss_fn, "all_pairs", None)
+        res = fused(list(output_dict.values())) if (fused is not None and len(output_dict) in (2, 3)) else None
+        if res is not None:                        # same names, same values, same summation order as the loop below - one autograd node
+            for (a, b), l in zip(combinations(output_dict.keys(), 2), res[0]):
+                loss_dict[f"{loss_prefix}/{a[:-9]}_{b[:-9]}_loss"] = l
+            loss_dict[f"{loss_prefix}/total_loss"] = res[1]
+            return loss_dict
         for a, b in combinations(output_dict.keys(), 2):
             loss_dict[f"{loss_prefix}/{a[:-9]}_{b[:-9]}_loss"] = self.loss_fn(output_dict[a], output_dict[b])
         loss_dict[f"{loss_prefix}/total_loss"] = sum(loss_dict.values())

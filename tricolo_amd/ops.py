@@ -312,11 +312,53 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
     return ws
 
 
-def conv_wgrad(x, dout, g: ConvGeom, like: torch.Tensor, precision: str, row_mask=None, out_scale: float = 1.0):
-    """Gradient of the layer's parameter, returned in the parameter's own layout (shape of ``like``), times out_scale."""
+_WGRAD_GROUPED = os.environ.get("TRICOLO_WGRAD_GROUPED", "1") != "0"     # A/B switch: one reduce launch per layer instead
+
+
+class WgradBatch:
+    """Deferred weight-gradient reduces of one tower backward (tri_conv_wgrad_partial / tri_wgrad_reduce_grouped).
+
+    Every conv_wgrad(..., batch=b) launches only the position-split partial kernel, into a slab of its own carved from a
+    per-stream arena that persists across steps (so a captured HIP graph replays on the same memory); b.flush() sums all of
+    them in one launch.  The returned dw tensors hold garbage until then: flush before they leave the autograd Function."""
+    _arenas = {}
+
+    def __init__(self, device):
+        self.device = device
+        self.chunks = WgradBatch._arenas.setdefault((device, torch.cuda.current_stream().cuda_stream), [])
+        self.ci, self.off, self.descs = 0, 0, []
+
+    def slab(self, nbytes: int) -> torch.Tensor:
+        nbytes = (nbytes + 255) // 256 * 256
+        while True:
+            if self.ci < len(self.chunks):
+                if self.off + nbytes <= self.chunks[self.ci].numel():
+                    t = self.chunks[self.ci][self.off:self.off + nbytes]
+                    self.off += nbytes
+                    return t
+                self.ci, self.off = self.ci + 1, 0
+            else:
+                self.chunks.append(torch.empty(max(nbytes, 128 << 20), dtype=torch.uint8, device=self.device))
+
+    def flush(self):
+        n = len(self.descs)
+        if n:
+            arr = (_C.TriWgradReduce * n)(*self.descs)
+            check(lib().tri_wgrad_reduce_grouped(arr, n, stream()), "tri_wgrad_reduce_grouped")
+        self.ci, self.off, self.descs = 0, 0, []
+
+
+def wgrad_batch(device):
+    """A WgradBatch, or None when grouping is switched off (conv_wgrad then reduces per layer)."""
+    return WgradBatch(device) if _WGRAD_GROUPED else None
+
+
+def conv_wgrad(x, dout, g: ConvGeom, like: torch.Tensor, precision: str, row_mask=None, out_scale: float = 1.0, batch=None):
+    """Gradient of the layer's parameter, returned in the parameter's own layout (shape of ``like``), times out_scale.
+    With ``batch`` (a WgradBatch of the CURRENT stream) only the partial sums are launched; batch.flush() completes dw."""
     assert x.dtype == dout.dtype
     dw = torch.empty_like(like)
-    ws = _workspace(g.wgrad_ws, x.device)
+    ws = batch.slab(g.wgrad_ws) if batch is not None else _workspace(g.wgrad_ws, x.device)
     plan = g.plan(x.device)
     s_co, s_tap, s_ci = g.strides
     bi = 128 if (g.cout % 128 == 0 and g.kpad >= 128) else 64
@@ -327,6 +369,14 @@ def conv_wgrad(x, dout, g: ConvGeom, like: torch.Tensor, precision: str, row_mas
         sym = f"conv_wgrad_dma_kernel<{bi}, {bj}, {_TNAME[x.dtype]}>"
     else:
         sym = f"conv_wgrad_kernel<{bi}, {bj}, {2 if s3 else 1}, {_TNAME[x.dtype]}>"
+    if batch is not None:
+        desc = _C.TriWgradReduce()
+        check(_timed(sym, g.flops,
+                     lambda: lib().tri_conv_wgrad_partial(_C.C.byref(g.desc), ptr(_act(x)), ptr(_act(dout)), ptr(row_mask), ptr(plan),
+                                                          ptr(ws), ws.numel(), ptr(dw), s_co, s_tap, s_ci, g.cin, s3, _abf(x),
+                                                          float(out_scale), _C.C.byref(desc), stream())), "tri_conv_wgrad_partial")
+        batch.descs.append(desc)
+        return dw
     check(_timed(sym, g.flops,
                  lambda: lib().tri_conv_wgrad(_C.C.byref(g.desc), ptr(_act(x)), ptr(_act(dout)), ptr(row_mask), ptr(plan), ptr(ws),
                                               ws.numel(), ptr(dw), s_co, s_tap, s_ci, g.cin, s3, _abf(x), float(out_scale), stream())),
@@ -403,7 +453,7 @@ def bn_bwd(y, g, co: BNCoeffs, gamma, count_dev=None, count_host=0, row_mask=Non
 def bn_relu_pool3d_fwd(y, co: BNCoeffs, mask, B, D, C):
     Do = D // 2
     pooled = torch.empty((B, Do, Do, Do, C), dtype=y.dtype, device=y.device)
-    mask_out = torch.zeros(((B * Do ** 3 + 31) // 32 * 32,), dtype=torch.uint8, device=y.device)
+    mask_out = torch.empty(((B * Do ** 3 + 31) // 32 * 32,), dtype=torch.uint8, device=y.device)     # every byte written by the kernel
     check(lib().tri_bn_relu_pool3d_fwd(ptr(_act(y)), ptr(co.scale), ptr(co.shift), ptr(mask), B, D, C, ptr(pooled), ptr(mask_out),
                                        _abf(y), stream()), "tri_bn_relu_pool3d_fwd")
     return pooled, mask_out
@@ -471,9 +521,11 @@ def cast_to_f32(x):
 # ------------------------------------------------------------------------------------------------ layouts
 def voxel_scatter(locs, feats, B, V, dtype=torch.float32):
     n = locs.shape[0]
-    dense = torch.empty((B, V, V, V, 4), dtype=dtype, device=feats.device)
     sites = B * V ** 3
-    mask = torch.zeros(((sites + 31) // 32 * 32,), dtype=torch.uint8, device=feats.device)
+    esz = torch.empty((), dtype=dtype).element_size()
+    buf = torch.empty((sites * 4 * esz + (sites + 31) // 32 * 32,), dtype=torch.uint8, device=feats.device)   # grid + mask: one zero-fill
+    dense = buf[:sites * 4 * esz].view(dtype).view(B, V, V, V, 4)
+    mask = buf[sites * 4 * esz:]
     locs = locs.to(torch.int32).contiguous()
     check(lib().tri_voxel_scatter(ptr(locs), ptr(_f32(feats.contiguous())), n, B, V, ptr(dense), ptr(mask), _abf(dense), stream()),
           "tri_voxel_scatter")
@@ -486,7 +538,7 @@ def voxel_from_rgba(rgba_u8, dtype=torch.float32):
     assert C == 4 and rgba_u8.dtype == torch.uint8 and rgba_u8.shape[2:] == (V, V, V)
     dense = torch.empty((B, V, V, V, 4), dtype=dtype, device=rgba_u8.device)
     sites = B * V ** 3
-    mask = torch.zeros(((sites + 31) // 32 * 32,), dtype=torch.uint8, device=rgba_u8.device)
+    mask = torch.empty(((sites + 31) // 32 * 32,), dtype=torch.uint8, device=rgba_u8.device)      # fully written by the call
     check(lib().tri_voxel_from_rgba_u8(ptr(rgba_u8.contiguous()), B, V, ptr(dense), ptr(mask), _abf(dense), stream()), "tri_voxel_from_rgba_u8")
     return dense, mask
 
@@ -679,6 +731,53 @@ def ntxent_bwd(za, zb, ws, temperature, alpha, norm=True, dloss=None):
     check(lib().tri_ntxent_bwd(ptr(_f32(za)), ptr(_f32(zb)), B, D, float(temperature), float(alpha), 1 if norm else 0, ptr(dloss), ptr(dza),
                                ptr(dzb), ptr(ws), ws.numel(), stream()), "tri_ntxent_bwd")
     return dza, dzb
+
+
+_ONES = {}
+
+
+def one(device) -> torch.Tensor:
+    """A cached 0-d fp32 one on `device`: `loss.backward(gradient=ops.one(loss.device))` spares autograd's fill launch per step."""
+    device = torch.device(device)
+    t = _ONES.get(device)
+    if t is None:
+        t = torch.ones((), dtype=torch.float32, device=device)
+        _ONES[device] = t
+    return t
+
+
+def ntxent_multi_supported(B: int, D: int, M: int) -> bool:
+    return M in (2, 3) and 1 <= B <= 512 and 4 <= D <= 2048 and D % 4 == 0
+
+
+def ntxent_multi_fwd(zs, temperature, alpha, norm=True):
+    """Every pair of the M = 2 / 3 embeddings `zs` at once: (losses [P + 1] = pair losses in combination order, then their
+    sum; workspace for ntxent_multi_bwd)."""
+    M = len(zs)
+    B, D = zs[0].shape
+    P = M * (M - 1) // 2
+    losses = torch.empty((P + 1,), dtype=torch.float32, device=zs[0].device)
+    nbytes = lib().tri_ntxent_multi_workspace(M, B, D)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=zs[0].device)
+    zp = (_C.C.c_void_p * M)(*[ptr(_f32(z)) for z in zs])
+    check(lib().tri_ntxent_multi_fwd(zp, M, B, D, float(temperature), float(alpha), 1 if norm else 0, ptr(losses), ptr(ws), nbytes,
+                                     stream()), "tri_ntxent_multi_fwd")
+    return losses, ws
+
+
+def ntxent_multi_bwd(zs, ws, temperature, alpha, norm=True, dpairs=None, dtotal=None):
+    """Gradients of all M embeddings in one launch; dpairs (list of 0-d device tensors or None) / dtotal are the upstream
+    gradients of the pair losses / of their sum."""
+    M = len(zs)
+    B, D = zs[0].shape
+    P = M * (M - 1) // 2
+    dzs = [torch.empty_like(z) for z in zs]
+    zp = (_C.C.c_void_p * M)(*[ptr(_f32(z)) for z in zs])
+    dp = (_C.C.c_void_p * P)(*[ptr(d) for d in dpairs]) if dpairs is not None else None
+    dzp = (_C.C.c_void_p * M)(*[ptr(d) for d in dzs])
+    check(lib().tri_ntxent_multi_bwd(zp, M, B, D, float(temperature), float(alpha), 1 if norm else 0, dp, ptr(dtotal), dzp, ptr(ws),
+                                     ws.numel(), stream()), "tri_ntxent_multi_bwd")
+    return dzs
 
 
 def ntxent_fwd_bwd(za, zb, temperature, alpha, norm=True, want_grad=True):

@@ -18,6 +18,8 @@ import os
 import torch
 import torch.distributed as dist
 
+from . import ops
+
 
 def is_dist() -> bool:
     """True when the data-parallel exchange steps must run.  TRICOLO_FORCE_DIST=1 also takes that path in a world of one
@@ -209,7 +211,7 @@ def dp_training_step(net, batch, optimizer=None, split: BackwardSplit | None = N
         flat = backward_overlapped(losses["train_loss/total_loss"], split, optimizer._params)
         optimizer.apply_flat(flat)
         return losses
-    losses["train_loss/total_loss"].backward()
+    losses["train_loss/total_loss"].backward(gradient=ops.one(losses["train_loss/total_loss"].device))
     if optimizer is not None and getattr(optimizer, "_flatten", False):
         optimizer.step(reduce_fn=allreduce_flat if is_dist() else None)    # one bucket: pack -> all-reduce -> fused update
         return losses

@@ -19,6 +19,7 @@ from math import cos, pi
 import torch
 
 from . import config as tcfg
+from . import ops
 from .checkpoint import extract_state_dict, save_reference_checkpoint
 
 
@@ -52,7 +53,7 @@ def fit(net, cfg, train_batches, val_batches=None, device="cuda", ckpt_path: str
         for batch in train_batches(epoch):
             opt.zero_grad(set_to_none=True)
             loss = net.training_step(batch, step)
-            loss.backward()
+            loss.backward(gradient=ops.one(loss.device))
             opt.step()
             last, step = loss, step + 1
         rec = {"epoch": epoch, "global_step": step, "train_loss": float(last.item()) if last is not None else None,
