@@ -79,6 +79,9 @@ int tri_linear_small_dgrad(const float* dout, const float* y, const float* w, fl
                            void* stream);
 int tri_linear_small_wgrad(const float* x, const float* dout, const float* y, float* dw, float* db /* may be NULL */, int M, int K, int N,
                            int act, int split3, void* stream);
+/* tri_linear_small_wgrad + tri_linear_small_dgrad of one layer in a single launch (same results) */
+int tri_linear_small_bwd(const float* x, const float* dout, const float* y, const float* w, float* dx, float* dw, float* db, int M, int K,
+                         int N, int act, int split3, void* stream);
 
 /* ---- implicit-GEMM convolution on MFMA ------------------------------------------------------------------------
  * tri_conv_fwd replaces spconv.SubMConv3d (sparse_cnn.py:12,17,22,27,32; row_mask = active-site mask gives the

@@ -291,6 +291,9 @@ def test_linear_small_matches_torch(M, K, N, act):
         np.testing.assert_allclose(dx.cpu().numpy(), (dpre @ w.double()).numpy(), atol=tol, rtol=tol)
         np.testing.assert_allclose(dw.cpu().numpy(), (dpre.t() @ x.double()).numpy(), atol=tol * 20, rtol=tol)   # |dW| ~ 10
         np.testing.assert_allclose(db.cpu().numpy(), dpre.sum(0).numpy(), atol=tol * 4, rtol=tol)
+        # the one-launch backward (weight + data gradient tiles) against the weight-gradient entry point alone
+        _, dw1, db1 = linear_bwd(x.to(DEV), w.to(DEV), out, dout.to(DEV), act, precision, need_dx=False)
+        assert torch.equal(dw1, dw) and torch.equal(db1, db)
 
 
 def test_embedding_kernels_match_torch():
@@ -486,6 +489,19 @@ def test_maxpool2d_and_viewmax():
     np.testing.assert_allclose(pooled.cpu().numpy(), refv.detach().numpy(), atol=1e-6)
     dxf = ops.avgpool_viewmax_bwd(dp.to(DEV), arg, tuple(fcl.shape), B, V)
     np.testing.assert_allclose(dxf.cpu().view(B * V, 4, 4, 512).permute(0, 3, 1, 2).numpy(), fr.grad.numpy(), atol=1e-7)
+    # 12 views (config 5: more views than the kernel's 8 view slots), 16-bit storage, exact ties between views: torch.max returns
+    # the FIRST maximal view and so must the argmax map (it decides which view receives the gradient)
+    for store in (torch.float32, torch.float16):
+        B, V, C = 3, 12, 192
+        f = ints((B * V, C, 2, 2), -3, 3, 91)                      # small integers: many exact ties, sums exact in f16
+        f[7], f[20], f[35] = f[2].clone(), f[13].clone(), f[24].clone()   # whole views repeated inside a shape (slots 7 / 2, 0 / 5, 3 / 0)
+        y = F.adaptive_avg_pool2d(f, 1).view(B, V, C)
+        refv, refi = torch.max(y, 1)
+        fcl = f.permute(0, 2, 3, 1).contiguous().view(B * V, 1, 2, 2, C).to(DEV).to(store)
+        pooled, arg = ops.avgpool_viewmax_fwd(fcl, B, V)
+        assert torch.equal(pooled.cpu(), refv)
+        first = (y == refv[:, None, :]).float().argmax(1)           # first view attaining the maximum
+        assert torch.equal(arg.cpu().long(), first)
 
 
 def test_layout_kernels_and_row_ops():

@@ -48,6 +48,7 @@ SIGNATURES = {
     "tri_linear_small_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
     "tri_linear_small_dgrad": (I, [P, P, P, P, I, I, I, I, I, P]),
     "tri_linear_small_wgrad": (I, [P, P, P, P, P, I, I, I, I, I, P]),
+    "tri_linear_small_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "tri_conv_num_mtiles": (I, [DP, I]),
     "tri_conv_workspace": (Z, [DP, I]),
     "tri_conv_kernel_family": (I, [DP, I, I]),

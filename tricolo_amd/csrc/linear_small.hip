@@ -87,12 +87,11 @@ __global__ __launch_bounds__(256) void linear_small_fwd_kernel(const float* __re
 
 // dx[m][k] = sum_n g[m][n] W[n][k],  g = dout * act'(y);  grid = K / 16, 4 waves split N
 template <int NSPLIT>
-__global__ __launch_bounds__(256) void linear_small_dgrad_kernel(const float* __restrict__ dout, const float* __restrict__ yout,
-                                                                 const float* __restrict__ w, float* __restrict__ dx, int M, int K, int N,
-                                                                 int act) {
-    __shared__ f32x4 red[4][4][64];
+__device__ __forceinline__ void linear_small_dgrad_body(const float* __restrict__ dout, const float* __restrict__ yout,
+                                                        const float* __restrict__ w, float* __restrict__ dx, int M, int K, int N, int act,
+                                                        int bx, f32x4 (*red)[4][64]) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, fr = lane & 15, fq = lane >> 4;
-    const int k0 = blockIdx.x * 16;
+    const int k0 = bx * 16;
     const int MT = (M + 15) >> 4;
     f32x4 acc[4];
 #pragma unroll
@@ -138,15 +137,22 @@ __global__ __launch_bounds__(256) void linear_small_dgrad_kernel(const float* __
         if (m < M) *(f32x4*)(dx + (size_t)m * K + k0 + fq * 4) = s;
     }
 }
+template <int NSPLIT>
+__global__ __launch_bounds__(256) void linear_small_dgrad_kernel(const float* __restrict__ dout, const float* __restrict__ yout,
+                                                                 const float* __restrict__ w, float* __restrict__ dx, int M, int K, int N,
+                                                                 int act) {
+    __shared__ f32x4 red[4][4][64];
+    linear_small_dgrad_body<NSPLIT>(dout, yout, w, dx, M, K, N, act, blockIdx.x, red);
+}
 
 // dW[n][k] = sum_m g[m][n] x[m][k],  db[n] = sum_m g[m][n];  grid = (N / 16, K / 64): one 16 x 16 tile per wave, so that
 // all of a wave's loads are independent and issued at once (four tiles per wave in sequence measured 21 us per layer)
 template <int NSPLIT>
-__global__ __launch_bounds__(256) void linear_small_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dout,
-                                                                 const float* __restrict__ yout, float* __restrict__ dw,
-                                                                 float* __restrict__ db, int M, int K, int N, int act) {
+__device__ __forceinline__ void linear_small_wgrad_body(const float* __restrict__ x, const float* __restrict__ dout,
+                                                        const float* __restrict__ yout, float* __restrict__ dw, float* __restrict__ db,
+                                                        int M, int K, int N, int act, int bx, int by) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, fr = lane & 15, fq = lane >> 4;
-    const int n0 = blockIdx.x * 16, k0 = blockIdx.y * 64 + wave * 16;
+    const int n0 = bx * 16, k0 = by * 64 + wave * 16;
     const int MS = (M + 31) >> 5;                                    // 32-row contraction steps (1 or 2)
     bf16x8 ah[2], al[2];
 #pragma unroll
@@ -165,7 +171,7 @@ __global__ __launch_bounds__(256) void linear_small_wgrad_kernel(const float* __
         }
         split8(make_float4(av[0], av[1], av[2], av[3]), make_float4(av[4], av[5], av[6], av[7]), ah[s], al[s]);
     }
-    if (db && blockIdx.y == 0 && wave == 0) {                        // bias gradient from the same fragments' source
+    if (db && by == 0 && wave == 0) {                        // bias gradient from the same fragments' source
         float s = 0.f;
         if (lane < 16)
             for (int m = 0; m < M; ++m) {
@@ -194,6 +200,25 @@ __global__ __launch_bounds__(256) void linear_small_wgrad_kernel(const float* __
 #pragma unroll
         for (int r = 0; r < 4; ++r) dw[(size_t)(n0 + fq * 4 + r) * K + k0 + fr] = acc[r];
     }
+}
+template <int NSPLIT>
+__global__ __launch_bounds__(256) void linear_small_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dout,
+                                                                 const float* __restrict__ yout, float* __restrict__ dw,
+                                                                 float* __restrict__ db, int M, int K, int N, int act) {
+    linear_small_wgrad_body<NSPLIT>(x, dout, yout, dw, db, M, K, N, act, blockIdx.x, blockIdx.y);
+}
+// Both halves of a layer's backward in one launch (they share nothing but their inputs): the first N/16 * ceil(K/64) workgroups
+// are the weight-gradient tiles, the remaining K/16 the data-gradient columns.  Same arithmetic as the two kernels above.
+template <int NSPLIT>
+__global__ __launch_bounds__(256) void linear_small_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dout,
+                                                               const float* __restrict__ yout, const float* __restrict__ w,
+                                                               float* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db, int M,
+                                                               int K, int N, int act) {
+    __shared__ f32x4 red[4][4][64];
+    const int nbx = N / 16, nw = nbx * ((K + 63) / 64);
+    const int b = blockIdx.x;
+    if (b < nw) linear_small_wgrad_body<NSPLIT>(x, dout, yout, dw, db, M, K, N, act, b % nbx, b / nbx);
+    else linear_small_dgrad_body<NSPLIT>(dout, yout, w, dx, M, K, N, act, b - nw, red);
 }
 
 static int linear_small_ok(int M, int K, int N) {
@@ -224,4 +249,15 @@ extern "C" int tri_linear_small_wgrad(const float* x, const float* dout, const f
     if (split3) linear_small_wgrad_kernel<2><<<grid, 256, 0, (hipStream_t)stream>>>(x, dout, y, dw, db, M, K, N, act);
     else linear_small_wgrad_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(x, dout, y, dw, db, M, K, N, act);
     return tri_check_launch("tri_linear_small_wgrad");
+}
+
+// dW, db and dx of one layer in ONE launch (tri_linear_small_wgrad + tri_linear_small_dgrad: same results)
+extern "C" int tri_linear_small_bwd(const float* x, const float* dout, const float* y, const float* w, float* dx, float* dw, float* db, int M,
+                                    int K, int N, int act, int split3, void* stream) {
+    if (!linear_small_ok(M, K, N)) { tri_set_error("linear_small: needs rows <= 64, K % 128 == 0, N % 128 == 0"); return TRI_ERR_UNSUPPORTED; }
+    if (!dx || !dw) { tri_set_error("linear_small_bwd: dx and dw are required (use the single entry points otherwise)"); return TRI_ERR_ARG; }
+    const int blocks = (N / 16) * ((K + 63) / 64) + K / 16;
+    if (split3) linear_small_bwd_kernel<2><<<blocks, 256, 0, (hipStream_t)stream>>>(x, dout, y, w, dx, dw, db, M, K, N, act);
+    else linear_small_bwd_kernel<1><<<blocks, 256, 0, (hipStream_t)stream>>>(x, dout, y, w, dx, dw, db, M, K, N, act);
+    return tri_check_launch("tri_linear_small_bwd");
 }

@@ -66,6 +66,7 @@ class MVCNNEncoder(TriModule):
         self.__dict__["_packed"] = {}
         self.__dict__["_side"] = SideStream("img")
         self.__dict__["_side_ds"] = SideStream("imgds")         # down-sample branch of layer2-4's first block
+        self.__dict__["_side_prep"] = SideStream("imgprep")     # operand packing of layer1-4 next to the stem
         self.__dict__["split"] = None                           # parallel.BackwardSplit: lower / upper halves as separate autograd nodes
 
     def _prec(self):
@@ -96,12 +97,16 @@ class MVCNNEncoder(TriModule):
         return g
 
     def _pack_all(self, N, H, W, prec, train, device):
-        """One packing launch for every conv of the trunk (forward operands, plus data-gradient operands when training)."""
+        """Two packing launches: the stem's operand rows inline (the stem conv needs them at once), every other conv of the trunk
+        (forward operands, plus data-gradient operands when training: 45 MB read + written, ~50 us) on a side stream NEXT TO the
+        stem conv / BatchNorm / max-pool, which it used to precede on the tower's critical path.  join_packing() before layer1."""
         key = (N, H, W, train)
         packer = self._packers.get(key)
         if packer is None:
-            packer = ops.WeightPacker()
-            convs = [(self.net_1[0], H, W)]
+            packer = (ops.WeightPacker(), ops.WeightPacker())
+            stem_g = self._geom2d(N, H, W, self.net_1[0])
+            packer[0].add((id(self.net_1[0]), False), self.net_1[0].weight, stem_g)
+            convs = []
             h, w = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
             h, w = (h + 1) // 2, (w + 1) // 2
             for blk in self._blocks():
@@ -113,11 +118,23 @@ class MVCNNEncoder(TriModule):
                 convs.append((blk.conv2, h, w))
             for conv, ch, cw in convs:
                 g = self._geom2d(N, ch, cw, conv)
-                packer.add((id(conv), False), conv.weight, g)
-                if train and conv is not self.net_1[0]:
-                    packer.add((id(conv), True), conv.weight, g, transposed=True)
+                packer[1].add((id(conv), False), conv.weight, g)
+                if train:
+                    packer[1].add((id(conv), True), conv.weight, g, transposed=True)
             self._packers[key] = packer
-        return packer.run(prec, device)
+        packed = dict(packer[0].run(prec, device))
+        with torch.cuda.stream(self._side_prep.fork()):
+            rest = packer[1].run(prec, device)
+        packed.update(rest)
+        self.__dict__["_prep_pending"] = [t for pair in rest.values() for t in pair if t is not None]
+        return packed
+
+    def _join_packing(self):
+        """The trunk's operand rows (packed on the side stream by _pack_all) are needed from here on."""
+        pend = self.__dict__.get("_prep_pending")
+        if pend:
+            self._side_prep.join(*pend)
+            self.__dict__["_prep_pending"] = None
 
     def _conv_bn(self, x, conv, bn, prec, train):
         N, _, H, W, _ = x.shape
@@ -176,6 +193,7 @@ class MVCNNEncoder(TriModule):
         y, co, g = self._conv_bn(x0, self.net_1[0], self.net_1[1], prec, train)
         x, parg = ops.maxpool2d_fwd(y, want_arg=save, bn=co)            # BN + ReLU + 3x3/2 max-pool: relu(bn(y)) is never stored
         saved = {"stem": (x0, y, co, g, parg), "blocks": [], "N": N}
+        self._join_packing()
         for blk in self._blocks()[:self.N_LOWER_BLOCKS]:
             x = self._run_block(blk, x, prec, train, save, saved["blocks"])
         return x, saved

@@ -651,12 +651,13 @@ def linear_small_bwd(x, w, out, dout, act, precision, need_dx=True, need_db=True
     dout = _f32(dout.contiguous())
     dw = torch.empty_like(w)
     db = torch.empty((N,), dtype=torch.float32, device=x.device) if need_db else None
-    check(lib().tri_linear_small_wgrad(ptr(_f32(x)), ptr(dout), ptr(out), ptr(dw), ptr(db), M, K, N, act, s3, stream()), "tri_linear_small_wgrad")
-    dx = None
-    if need_dx:
+    if need_dx:                                              # weight- and data-gradient tiles in one launch
         dx = torch.empty((M, K), dtype=torch.float32, device=x.device)
-        check(lib().tri_linear_small_dgrad(ptr(dout), ptr(out), ptr(_f32(w)), ptr(dx), M, K, N, act, s3, stream()), "tri_linear_small_dgrad")
-    return dx, dw, db
+        check(lib().tri_linear_small_bwd(ptr(_f32(x)), ptr(dout), ptr(out), ptr(_f32(w)), ptr(dx), ptr(dw), ptr(db), M, K, N, act, s3,
+                                         stream()), "tri_linear_small_bwd")
+        return dx, dw, db
+    check(lib().tri_linear_small_wgrad(ptr(_f32(x)), ptr(dout), ptr(out), ptr(dw), ptr(db), M, K, N, act, s3, stream()), "tri_linear_small_wgrad")
+    return None, dw, db
 
 
 def colsum(g):
