@@ -329,7 +329,7 @@ def run_mode(a, precision, world, rank, device, want_voxel_roofline):
     return res, vox_roof, cfg
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -350,13 +350,18 @@ def main():
     ap.add_argument("--cpu-budget-s", type=float, default=30.0)
     ap.add_argument("--resident-batches", type=int, default=2)
     ap.add_argument("--preroll", type=int, default=40)
-    a = ap.parse_args()
+    a = ap.parse_args(argv)
     text, image, voxel, V, nv, S, pb = CONFIGS[a.config]
     a.text, a.image, a.voxel = text, image, voxel
     a.voxel_size = a.voxel_size or V
     a.num_views = a.num_views or nv
     a.image_size = a.image_size or S
     a.per_gpu_batch = a.per_gpu_batch or pb
+    return a
+
+
+def main():
+    a = parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -186,6 +186,8 @@ int tri_voxel_scatter(const int* locs, const float* feats, int n, int B, int V, 
  * RGB / 255; general_dataset.py:47-51,92-93) - no CPU COO build, no scatter.  mask must hold B*V^3 bytes (padded to 32). */
 int tri_voxel_from_rgba_u8(const uint8_t* rgba, int B, int V, void* dense, uint8_t* mask, int act_fmt, void* stream);
 int tri_mask_count(const uint8_t* mask, long n, int* count, void* stream);
+/* instrumentation: *slot = wall_clock64() (100 MHz) at this point of the stream; tools/step_timeline.py */
+int tri_debug_stamp(unsigned long long* slot, void* stream);
 /* active-site list of a submanifold level: row_pos[0 .. *count) = positions with mask != 0, ascending; *count = how many.
  * Hand row_pos + count to tri_conv_fwd / tri_conv_dgrad: they then compute (and write) ONLY those rows - executed work =
  * active work (spconv's rulebook idea on a dense index space).  Layers that run split-K (tri_conv_kernel_family bit 16)

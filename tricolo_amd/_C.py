@@ -79,6 +79,7 @@ SIGNATURES = {
     "tri_voxel_from_rgba_u8": (I, [P, I, I, P, P, I, P]),
     "tri_nchw3_u8_to_nhwc4": (I, [P, I, I, I, P, P, P, I, P]),
     "tri_mask_count": (I, [P, L, P, P]),
+    "tri_debug_stamp": (I, [P, P]),
     "tri_mask_compact_scratch": (Z, [L]),
     "tri_mask_compact": (I, [P, L, P, P, P, P]),
     "tri_nchw3_to_nhwc4": (I, [P, I, I, I, P, I, P]),

@@ -72,6 +72,15 @@ extern "C" int tri_voxel_from_rgba_u8(const uint8_t* rgba, int B, int V, void* d
     return tri_check_launch("tri_voxel_from_rgba_u8");
 }
 
+// Step timeline (tools/step_timeline.py): one lane writes the constant 100 MHz wall clock into *slot.  Launched between the
+// kernels of a (captured) step it timestamps the critical path without a profiler attached - rocprofv3's kernel trace inflates
+// and re-orders the gaps between the ~330 launches of a step.
+__global__ void stamp_kernel(unsigned long long* slot) { *slot = wall_clock64(); }
+extern "C" int tri_debug_stamp(unsigned long long* slot, void* stream) {
+    stamp_kernel<<<1, 1, 0, (hipStream_t)stream>>>(slot);
+    return tri_check_launch("tri_debug_stamp");
+}
+
 // count of non-zero mask bytes -> *count (device int)
 __global__ void mask_count_kernel(const uint8_t* __restrict__ mask, long n, int* __restrict__ count) {
     int local = 0;

@@ -192,10 +192,12 @@ class MVCNNEncoder(TriModule):
             x0 = ops.nchw3_to_nhwc4(images, dtype=ops.act_dtype(prec))
         y, co, g = self._conv_bn(x0, self.net_1[0], self.net_1[1], prec, train)
         x, parg = ops.maxpool2d_fwd(y, want_arg=save, bn=co)            # BN + ReLU + 3x3/2 max-pool: relu(bn(y)) is never stored
+        ops.stamp("image.fwd.stem.end")
         saved = {"stem": (x0, y, co, g, parg), "blocks": [], "N": N}
         self._join_packing()
         for blk in self._blocks()[:self.N_LOWER_BLOCKS]:
             x = self._run_block(blk, x, prec, train, save, saved["blocks"])
+        ops.stamp("image.fwd.layer2.end")
         return x, saved
 
     def _forward_upper(self, x, save: bool):
@@ -205,6 +207,7 @@ class MVCNNEncoder(TriModule):
         saved = {"blocks": [], "B": B, "N": N}
         for blk in self._blocks()[self.N_LOWER_BLOCKS:]:
             x = self._run_block(blk, x, prec, train, save, saved["blocks"])
+        ops.stamp("image.fwd.layer4.end")
         pooled, arg = ops.avgpool_viewmax_fwd(x, B, self.num_views)
         f = linear_fwd(pooled, self.net_2.weight, self.net_2.bias, 0, prec)
         h = linear_fwd(f, self.mlp[0].weight, self.mlp[0].bias, 1, prec)
@@ -270,6 +273,7 @@ class MVCNNEncoder(TriModule):
         Weight-gradient reduces of the main stream are deferred into `batch` (one grouped launch; the caller's, or an own one)."""
         prec, B = self._prec(), saved["B"]
         gr = {}
+        ops.stamp("image.bwd.start")
         own = batch is None
         if own:
             batch = ops.wgrad_batch(dz.device)
@@ -280,7 +284,9 @@ class MVCNNEncoder(TriModule):
         # f16 mode: activation gradients are carried times gs (ops.F16_GRAD_SCALE); parameter-gradient kernels undo it
         gs = ops.grad_scale(prec)
         dout = ops.avgpool_viewmax_bwd(dp, saved["arg"], saved["feat_shape"], B, self.num_views, dtype=ops.act_dtype(prec), scale=gs)
+        ops.stamp("image.bwd.heads.end")
         dx2 = self._backward_blocks(self._blocks()[self.N_LOWER_BLOCKS:], saved["blocks"], dout, gr, prec, 1.0 / gs, batch)
+        ops.stamp("image.bwd.layer3.end")
         if own and batch is not None:
             batch.flush()
         return dx2, [gr[p] for p in self._upper_params()]
@@ -294,6 +300,7 @@ class MVCNNEncoder(TriModule):
             batch = ops.wgrad_batch(dout.device)
         dout = self._backward_blocks(self._blocks()[:self.N_LOWER_BLOCKS], saved["blocks"], dout, gr, prec, ugs, batch)
         x0, y, co, g0, parg = saved["stem"]
+        ops.stamp("image.bwd.layer1.end")
         dzs = ops.maxpool2d_bwd(parg, dout, tuple(y.shape))
         dy, gr[self.net_1[1].weight], gr[self.net_1[1].bias] = ops.bn_bwd(y, dzs, co, self.net_1[1].weight, count_host=g0.M, relu=True, out_scale=ugs)
         gr[self.net_1[0].weight] = ops.conv_wgrad(x0, dy, g0, self.net_1[0].weight, prec, out_scale=ugs, batch=batch)
@@ -307,6 +314,7 @@ class MVCNNEncoder(TriModule):
         lo = self._backward_lower(saved["lower"], dx2, batch)
         if batch is not None:
             batch.flush()
+        ops.stamp("image.bwd.end")
         return lo + up
 
     def forward(self, x, data_dict=None):

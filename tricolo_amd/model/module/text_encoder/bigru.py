@@ -46,7 +46,9 @@ class _BiGRUFn(torch.autograd.Function):
     def backward(ctx, dhfinal):
         x2d, w_ih, w_hh, hs, gates = ctx.saved_tensors
         (L, B, I), prec = ctx.dims, ctx.precision
+        ops.stamp("text.bwd.gru.start")
         dgi, dgh, hprev, dbias = ops.gru_bwd(dhfinal, w_hh, hs, gates, B, L, prec)
+        ops.stamp("text.bwd.gru.end")
         dx, dw_ih, _ = linear_bwd(x2d, w_ih, None, dgi, 0, prec, need_dx=ctx.needs_input_grad[0], need_db=False)
         g_hh = linear_geom(L * B, 128, 384)
         dw_hh = [ops.conv_wgrad(hprev[d], dgh[d], g_hh, w_hh[d], prec) for d in range(2)]

@@ -134,6 +134,7 @@ class SparseCNNEncoder(TriModule):
     def _backward_impl(self, saved, dz):
         prec, V, B = self._prec(), self.voxel_size, saved["B"]
         grads = [None] * 19
+        ops.stamp("voxel.bwd.start")
         do = ops.l2norm_bwd(saved["z"], saved["norm"], dz)
         dh, grads[17], grads[18] = linear_bwd(saved["h"], self.mlp[2].weight, saved["o"], do, 0, prec)
         dflat, grads[15], grads[16] = linear_bwd(saved["flat"], self.mlp[0].weight, saved["h"], dh, 1, prec, spatial=self.spatial)
@@ -158,6 +159,7 @@ class SparseCNNEncoder(TriModule):
                     dx = ops.conv_dgrad(dy, g, pt, row_mask=mask)
         if batch is not None:
             batch.flush()
+        ops.stamp("voxel.bwd.end")
         return grads
 
     def forward(self, x, batch_size):

@@ -16,6 +16,7 @@ import numpy as np
 import torch
 
 from .. import config as tcfg
+from .. import ops
 from ..evaluation.eval_retrieval import compute_metrics
 from ..layers import TriModule
 
@@ -99,18 +100,26 @@ class TriCoLoNet(TriModule):
                 output_dict["voxel_features"] = self._gate(self.voxel_encoder(data_dict["voxels"], len(data_dict["model_id"])))
             return output_dict
         main = torch.cuda.current_stream()
+        ops.stamp("step.start")
         if self._side_streams is None:
             self._side_streams = (torch.cuda.Stream(), torch.cuda.Stream())
         s_text, s_vox = self._side_streams
+        # (Issue order matters under HIP-graph replay: the executor queues a branch issued later behind earlier ones when it folds
+        # them onto one internal stream.  Side towers first: their forward starts at once, their backward - autograd runs the
+        # latest-created node first - is issued after the image tower's and the voxel backward starts ~1.2 ms late; image tower
+        # first: the other way round.  Same step time either way (tools/step_timeline.py, profiles/r2/README.md).)
         s_text.wait_stream(main)
         with torch.cuda.stream(s_text):
             text = self.text_encoder(tokens, data_dict)
+            ops.stamp("text.fwd.end")
         vox = None
         if self.voxel_encoder is not None:
             s_vox.wait_stream(main)
             with torch.cuda.stream(s_vox):
                 vox = self._gate(self.voxel_encoder(data_dict["voxels"], len(data_dict["model_id"])))
+                ops.stamp("voxel.fwd.end")
         img = self.image_encoder(data_dict["images"].flatten(end_dim=1), data_dict)
+        ops.stamp("image.fwd.end")
         main.wait_stream(s_text)
         text.record_stream(main)
         output_dict = {"text_features": text, "image_features": img}
@@ -131,6 +140,7 @@ class TriCoLoNet(TriModule):
             for (a, b), l in zip(combinations(output_dict.keys(), 2), res[0]):
                 loss_dict[f"{loss_prefix}/{a[:-9]}_{b[:-9]}_loss"] = l
             loss_dict[f"{loss_prefix}/total_loss"] = res[1]
+            ops.stamp("loss.fwd.end")
             return loss_dict
         for a, b in combinations(output_dict.keys(), 2):
             loss_dict[f"{loss_prefix}/{a[:-9]}_{b[:-9]}_loss"] = self.loss_fn(output_dict[a], output_dict[b])

@@ -734,6 +734,21 @@ def ntxent_bwd(za, zb, ws, temperature, alpha, norm=True, dloss=None):
     return dza, dzb
 
 
+TIMELINE = None      # tools/step_timeline.py sets {"buf": int64 device tensor, "names": []}: stamp() then timestamps the stream
+
+
+def stamp(name: str):
+    """Device-side timestamp of this point of the current stream (no-op unless a timeline is being recorded)."""
+    tl = TIMELINE
+    if tl is None:
+        return
+    idx = len(tl["names"])
+    if idx >= tl["buf"].numel():
+        return
+    tl["names"].append(name)
+    check(lib().tri_debug_stamp(tl["buf"].data_ptr() + 8 * idx, stream()), "tri_debug_stamp")
+
+
 _ONES = {}
 
 

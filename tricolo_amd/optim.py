@@ -221,9 +221,11 @@ class FusedAdam(torch.optim.Optimizer):
         group = self.param_groups[0]
         b1, b2 = group["betas"]
         self.sync_lr()
+        ops.stamp("adam.start")
         ops.adam_tick(self._step_dev)                       # step += 1 on the device, once per optimizer step
         if self._flatten:
             if reduce_fn is None and self._seg_ok and self._update_from_segments(group, b1, b2, grad_scale):
+                ops.stamp("adam.end")
                 return loss
             if any(p.grad is None for p in self._params):
                 # torch.optim.Adam skips such parameters entirely (no weight decay, no moment decay); the flat kernel cannot
