@@ -176,6 +176,16 @@ int tri_pool3d_bwd_route(const void* y, const float* scale, const float* shift, 
 int tri_maxpool2d_fwd(const void* x, int N, int H, int W, int C, void* out, uint8_t* arg /* [N,Ho,Wo,C] winning tap, may be NULL */,
                       const float* bn_scale, const float* bn_shift, int act_fmt, void* stream);
 int tri_maxpool2d_bwd(const uint8_t* arg, const void* dout, int N, int H, int W, int C, void* dx, int act_fmt, void* stream);
+/* stem backward without materialising the max-pool gradient (conv -> BN -> ReLU -> MaxPool2d(3,2,1), mv_cnn.py:44): the BatchNorm
+ * backward passes read (y [N,H,W,C], arg [N,H/2,W/2,C], dpool [N,H/2,W/2,C]) and route the pooled gradient to the winning taps
+ * on the fly.  reduce -> tri_bn_bwd_finalize(partial, tri_maxpool_bn_bwd_num_blocks(...), C, count = N*H*W) -> apply.  Same
+ * values as tri_maxpool2d_bwd followed by tri_bn_bwd_reduce / _apply with relu_scale / relu_shift.  H, W even. */
+int tri_maxpool_bn_bwd_num_blocks(int N, int H, int W);
+int tri_maxpool_bn_bwd_reduce(const void* y, const uint8_t* arg, const void* dpool, int N, int H, int W, int C, float* partial,
+                              const float* relu_scale, const float* relu_shift, int act_fmt, void* stream);
+int tri_maxpool_bn_bwd_apply(const void* y, const uint8_t* arg, const void* dpool, int N, int H, int W, int C, const float* c1,
+                             const float* c2, const float* c3, const float* relu_scale, const float* relu_shift, void* dy, int act_fmt,
+                             void* stream);
 int tri_avgpool_viewmax_fwd(const void* x, int B, int V, int HW, int C, float* out, int* arg, int act_fmt, void* stream);
 int tri_avgpool_viewmax_bwd(const float* dout, const int* arg, int B, int V, int HW, int C, void* dx, int act_fmt, float scale, void* stream);
 

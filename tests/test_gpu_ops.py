@@ -820,3 +820,40 @@ def test_ntxent_all_pairs_declines_shapes_outside_the_fused_range():
     assert loss_fn.all_pairs([torch.randn(600, 512, device=DEV) for _ in range(3)]) is None        # B > 512: per-pair path
     assert loss_fn.all_pairs([torch.randn(8, 512, device=DEV) for _ in range(4)]) is None          # four modalities
     assert loss_fn.all_pairs([torch.randn(8, 510, device=DEV) for _ in range(2)]) is None          # D % 4
+
+
+@pytest.mark.parametrize("store", [torch.float32, torch.float16], ids=["f32", "f16"])
+def test_stem_bn_backward_from_the_pooled_gradient(store):
+    """conv -> BN -> ReLU -> MaxPool2d(3,2,1) backward with the max-pool routing folded into the two BatchNorm passes
+    (tri_maxpool_bn_bwd_*) against maxpool2d_bwd + bn_bwd(relu=True): integer-valued data make every sum exact, so the two
+    paths must agree bit for bit; real-valued data agree up to the order of the fp32 partial sums.  Also against autograd."""
+    for integer in (True, False):
+        g = torch.Generator().manual_seed(21)
+        N, C, H, W = 3, 64, 12, 20
+        y = (ints((N, H, W, C), -4, 4, 5) if integer else torch.randn(N, H, W, C, generator=g) * 2 + 0.3)
+        gamma = ints((C,), 1, 3, 6) if integer else torch.rand(C, generator=g) + 0.5
+        beta = ints((C,), -2, 2, 7) if integer else torch.randn(C, generator=g) * 0.3
+        yd = y.view(N, 1, H, W, C).to(DEV).to(store)
+        M = N * H * W
+        yf = yd.float().view(M, C)
+        stats = torch.stack([yf.double().sum(0).float(), (yf.double() ** 2).sum(0).float()]).view(1, 2, C)
+        co = ops.bn_finalize(stats, C, gamma.to(DEV), beta.to(DEV), None, None, None, count_host=M)
+        pooled, arg = ops.maxpool2d_fwd(yd, want_arg=True, bn=co)
+        dpool = (ints(tuple(pooled.shape), -3, 3, 8) if integer else torch.randn(pooled.shape, generator=g)).to(DEV).to(store)
+        dz = ops.maxpool2d_bwd(arg, dpool, tuple(yd.shape))
+        dy_a, dg_a, db_a = ops.bn_bwd(yd, dz.clone(), co, gamma.to(DEV), count_host=M, inplace=False, relu=True, out_scale=0.5)
+        dy_b, dg_b, db_b = ops.maxpool_bn_bwd(yd, arg, dpool, co, gamma.to(DEV), out_scale=0.5)
+        if integer:
+            assert torch.equal(dg_a, dg_b) and torch.equal(db_a, db_b) and torch.equal(dy_a, dy_b)
+        else:
+            np.testing.assert_allclose(dg_a.cpu().numpy(), dg_b.cpu().numpy(), rtol=2e-5, atol=2e-5)
+            np.testing.assert_allclose(db_a.cpu().numpy(), db_b.cpu().numpy(), rtol=2e-5, atol=2e-5)
+            tol = 2e-5 if store == torch.float32 else 4e-3
+            np.testing.assert_allclose(dy_a.float().cpu().numpy(), dy_b.float().cpu().numpy(), rtol=tol, atol=tol)
+    if store == torch.float32:                                   # the real-valued case against autograd
+        yr = y.permute(0, 3, 1, 2).clone().requires_grad_()
+        gr, br = gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+        out = F.max_pool2d(F.relu(F.batch_norm(yr, None, None, gr, br, True, 0.1, 1e-5)), 3, 2, 1)
+        out.backward(dpool.cpu().view(N, H // 2, W // 2, C).permute(0, 3, 1, 2))
+        np.testing.assert_allclose(dy_b.cpu().view(N, H, W, C).numpy(), yr.grad.permute(0, 2, 3, 1).numpy(), atol=5e-5, rtol=1e-4)
+        np.testing.assert_allclose(dg_b.cpu().numpy() * 2, gr.grad.numpy(), rtol=1e-4, atol=1e-4)

@@ -538,6 +538,148 @@ extern "C" int tri_maxpool2d_bwd(const uint8_t* arg, const void* dout, int N, in
     return tri_check_launch("tri_maxpool2d_bwd");
 }
 
+// ---- stem backward without the max-pool backward pass ------------------------------------------------------------------
+// conv 7x7/2 -> BN -> ReLU -> MaxPool2d(3, 2, 1) (mv_cnn.py:44, torchvision stem).  The gradient of relu(bn(y)) is the pooled
+// gradient routed to each window's winning tap - recomputable from the byte map and dpool (1/4 the positions) on the fly.  So
+// the BatchNorm backward reads (y, arg, dpool) instead of (y, dz): maxpool2d_bwd's pass (25 + 12 MB in, 100 MB out at the bench
+// shape) and the two re-reads of its 100 MB output disappear.  One thread = one 2x2 block of y positions x 4 channels, as
+// maxpool2d_bwd2x2_kernel: the block's pixels can only have won in the four windows (bh..bh+1, bw..bw+1).
+template <typename T>
+__device__ __forceinline__ void stem_route_2x2(const uchar4* __restrict__ arg, const T* __restrict__ dpool, int n, int bh, int bw, int Ho,
+                                               int Wo, int C4, int c, float4 g[4]) {
+    uchar4 a[2][2];
+    float4 d[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            a[u][v] = make_uchar4(255, 255, 255, 255);
+            d[u][v] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (bh + u < Ho && bw + v < Wo) {
+                const long o = (((long)n * Ho + bh + u) * Wo + bw + v) * C4 + c;
+                a[u][v] = arg[o];
+                d[u][v] = Act<T>::ld4(dpool + o * 4);
+            }
+        }
+#define TRI_PICK(A, D, TAP) make_float4(A.x == TAP ? D.x : 0.f, A.y == TAP ? D.y : 0.f, A.z == TAP ? D.z : 0.f, A.w == TAP ? D.w : 0.f)
+#define TRI_ADD4(P, Q) make_float4(P.x + Q.x, P.y + Q.y, P.z + Q.z, P.w + Q.w)
+    g[0] = TRI_PICK(a[0][0], d[0][0], 4);                                                  // (2bh,   2bw)
+    g[1] = TRI_ADD4(TRI_PICK(a[0][0], d[0][0], 5), TRI_PICK(a[0][1], d[0][1], 3));         // (2bh,   2bw+1)
+    g[2] = TRI_ADD4(TRI_PICK(a[0][0], d[0][0], 7), TRI_PICK(a[1][0], d[1][0], 1));         // (2bh+1, 2bw)
+    const float4 p = TRI_ADD4(TRI_PICK(a[0][0], d[0][0], 8), TRI_PICK(a[0][1], d[0][1], 6));
+    const float4 q = TRI_ADD4(TRI_PICK(a[1][0], d[1][0], 2), TRI_PICK(a[1][1], d[1][1], 0));
+    g[3] = TRI_ADD4(p, q);                                                                 // (2bh+1, 2bw+1): summation order of maxpool2d_bwd
+#undef TRI_PICK
+#undef TRI_ADD4
+}
+// values of the routed gradient are rounded to the storage type exactly where maxpool2d_bwd would have stored them
+template <typename T>
+__device__ __forceinline__ float4 rnd4(float4 v) { return make_float4(Act<T>::rnd(v.x), Act<T>::rnd(v.y), Act<T>::rnd(v.z), Act<T>::rnd(v.w)); }
+
+#define STEM_BLOCKS_PER_WG 64                                       // 2x2 blocks (256 positions) per workgroup, as bnb_rows of large tensors
+template <typename T>
+__global__ __launch_bounds__(256) void stem_bwd_reduce_kernel(const T* __restrict__ y, const uchar4* __restrict__ arg, const T* __restrict__ dpool,
+                                                              int N, int H, int W, int C, float* __restrict__ partial,
+                                                              const float4* __restrict__ rs, const float4* __restrict__ rb) {
+    extern __shared__ float sh[];                                  // [items_per_pass][C4][8]
+    const int C4 = C >> 2, Ho = H >> 1, Wo = W >> 1;
+    const int tpr = C4 < 256 ? C4 : 256, rpp = 256 / tpr;
+    const int tc = threadIdx.x % tpr, tr = threadIdx.x / tpr;
+    const long nb = (long)N * Ho * Wo;
+    const long r0 = (long)blockIdx.x * STEM_BLOCKS_PER_WG, r1 = r0 + STEM_BLOCKS_PER_WG < nb ? r0 + STEM_BLOCKS_PER_WG : nb;
+    float4 sg = make_float4(0, 0, 0, 0), sgy = make_float4(0, 0, 0, 0);
+    if (tc < C4 && tr < rpp) {
+        const float4 s4 = rs[tc], b4 = rb[tc];
+        for (long r = r0 + tr; r < r1; r += rpp) {
+            const int bw = (int)(r % Wo); const long q = r / Wo;
+            const int bh = (int)(q % Ho), n = (int)(q / Ho);
+            float4 g[4];
+            stem_route_2x2<T>(arg, dpool, n, bh, bw, Ho, Wo, C4, tc, g);
+            const T* yp = y + ((((long)n * H + 2 * bh) * W + 2 * bw) * C4 + tc) * 4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float4 yv = Act<T>::ld4(yp + ((long)(k >> 1) * W + (k & 1)) * C4 * 4);
+                float4 gv = rnd4<T>(g[k]);
+                gv.x = __fmaf_rn(yv.x, s4.x, b4.x) > 0.f ? gv.x : 0.f; gv.y = __fmaf_rn(yv.y, s4.y, b4.y) > 0.f ? gv.y : 0.f;
+                gv.z = __fmaf_rn(yv.z, s4.z, b4.z) > 0.f ? gv.z : 0.f; gv.w = __fmaf_rn(yv.w, s4.w, b4.w) > 0.f ? gv.w : 0.f;
+                sg.x += gv.x; sg.y += gv.y; sg.z += gv.z; sg.w += gv.w;
+                sgy.x += gv.x * yv.x; sgy.y += gv.y * yv.y; sgy.z += gv.z * yv.z; sgy.w += gv.w * yv.w;
+            }
+        }
+        float* p = sh + ((size_t)tr * tpr + tc) * 8;
+        p[0] = sg.x; p[1] = sg.y; p[2] = sg.z; p[3] = sg.w; p[4] = sgy.x; p[5] = sgy.y; p[6] = sgy.z; p[7] = sgy.w;
+    }
+    __syncthreads();
+    if (tr == 0 && tc < C4) {
+        float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int rr = 0; rr < rpp; ++rr) {
+            const float* p = sh + ((size_t)rr * tpr + tc) * 8;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] += p[k];
+        }
+        float* o = partial + (size_t)blockIdx.x * 2 * C;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { o[tc * 4 + k] = a[k]; o[C + tc * 4 + k] = a[4 + k]; }
+    }
+}
+template <typename T>
+__global__ void stem_bwd_apply_kernel(const T* __restrict__ y, const uchar4* __restrict__ arg, const T* __restrict__ dpool, int N, int H, int W,
+                                      int C4, const float4* __restrict__ c1, const float4* __restrict__ c2, const float4* __restrict__ c3,
+                                      const float4* __restrict__ rs, const float4* __restrict__ rb, T* __restrict__ dy) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    const long total = (long)N * Ho * Wo * C4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        long pos = i / C4;
+        const int bw = (int)(pos % Wo); const long q = pos / Wo;
+        const int bh = (int)(q % Ho), n = (int)(q / Ho);
+        float4 g[4];
+        stem_route_2x2<T>(arg, dpool, n, bh, bw, Ho, Wo, C4, c, g);
+        const float4 a = c1[c], b = c2[c], d = c3[c], s4 = rs[c], b4 = rb[c];
+        const long base = ((((long)n * H + 2 * bh) * W + 2 * bw) * C4 + c) * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long o = base + ((long)(k >> 1) * W + (k & 1)) * C4 * 4;
+            const float4 yv = Act<T>::ld4(y + o);
+            float4 gv = rnd4<T>(g[k]);
+            gv.x = __fmaf_rn(yv.x, s4.x, b4.x) > 0.f ? gv.x : 0.f; gv.y = __fmaf_rn(yv.y, s4.y, b4.y) > 0.f ? gv.y : 0.f;
+            gv.z = __fmaf_rn(yv.z, s4.z, b4.z) > 0.f ? gv.z : 0.f; gv.w = __fmaf_rn(yv.w, s4.w, b4.w) > 0.f ? gv.w : 0.f;
+            Act<T>::st4(dy + o, make_float4(a.x * gv.x + b.x + d.x * yv.x, a.y * gv.y + b.y + d.y * yv.y, a.z * gv.z + b.z + d.z * yv.z,
+                                            a.w * gv.w + b.w + d.w * yv.w));
+        }
+    }
+}
+extern "C" int tri_maxpool_bn_bwd_num_blocks(int N, int H, int W) {
+    return (int)(((long)N * (H / 2) * (W / 2) + STEM_BLOCKS_PER_WG - 1) / STEM_BLOCKS_PER_WG);
+}
+static int stem_args_ok(int H, int W, int C, const void* rs, const void* rb) {
+    if (H % 2 || W % 2 || C % 4 || C / 4 > 256) { tri_set_error("tri_maxpool_bn_bwd: needs even H, W and C % 4 == 0, C <= 1024"); return 0; }
+    if (!rs || !rb) { tri_set_error("tri_maxpool_bn_bwd: the forward's BN scale / shift are required (ReLU mask)"); return 0; }
+    return 1;
+}
+// partial [tri_maxpool_bn_bwd_num_blocks][2][C]: per-workgroup sums of g and g*y, g = gradient of relu(bn(y)) before the max-pool;
+// finish with tri_bn_bwd_finalize (count = N*H*W) and tri_maxpool_bn_bwd_apply
+extern "C" int tri_maxpool_bn_bwd_reduce(const void* y, const uint8_t* arg, const void* dpool, int N, int H, int W, int C, float* partial,
+                                         const float* relu_scale, const float* relu_shift, int act_fmt, void* stream) {
+    if (!stem_args_ok(H, W, C, relu_scale, relu_shift)) return TRI_ERR_ARG;
+    const int C4 = C / 4, tpr = C4 < 256 ? C4 : 256, rpp = 256 / tpr;
+    const size_t smem = (size_t)rpp * tpr * 8 * sizeof(float);
+    const int nblk = tri_maxpool_bn_bwd_num_blocks(N, H, W);
+    TRI_ACT_DISPATCH(act_fmt, stem_bwd_reduce_kernel<T><<<nblk, 256, smem, (hipStream_t)stream>>>(
+        (const T*)y, (const uchar4*)arg, (const T*)dpool, N, H, W, C, partial, (const float4*)relu_scale, (const float4*)relu_shift));
+    return tri_check_launch("tri_maxpool_bn_bwd_reduce");
+}
+extern "C" int tri_maxpool_bn_bwd_apply(const void* y, const uint8_t* arg, const void* dpool, int N, int H, int W, int C, const float* c1,
+                                        const float* c2, const float* c3, const float* relu_scale, const float* relu_shift, void* dy,
+                                        int act_fmt, void* stream) {
+    if (!stem_args_ok(H, W, C, relu_scale, relu_shift)) return TRI_ERR_ARG;
+    const long total = (long)N * (H / 2) * (W / 2) * (C / 4);
+    TRI_ACT_DISPATCH(act_fmt, stem_bwd_apply_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(
+        (const T*)y, (const uchar4*)arg, (const T*)dpool, N, H, W, C / 4, (const float4*)c1, (const float4*)c2, (const float4*)c3,
+        (const float4*)relu_scale, (const float4*)relu_shift, (T*)dy));
+    return tri_check_launch("tri_maxpool_bn_bwd_apply");
+}
+
 // ----------------------------------------------------- global average pool + max over the views of one shape
 // x [B*V, HW, C] -> out [B, C], argmax view index [B, C] (first maximum, as torch.max(dim=1))
 // block = (shape b, 128 channels): 32 channel quads x 8 view slots; a thread sums its views over HW in the k order of a plain loop

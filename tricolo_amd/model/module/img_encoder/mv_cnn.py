@@ -301,8 +301,13 @@ class MVCNNEncoder(TriModule):
         dout = self._backward_blocks(self._blocks()[:self.N_LOWER_BLOCKS], saved["blocks"], dout, gr, prec, ugs, batch)
         x0, y, co, g0, parg = saved["stem"]
         ops.stamp("image.bwd.layer1.end")
-        dzs = ops.maxpool2d_bwd(parg, dout, tuple(y.shape))
-        dy, gr[self.net_1[1].weight], gr[self.net_1[1].bias] = ops.bn_bwd(y, dzs, co, self.net_1[1].weight, count_host=g0.M, relu=True, out_scale=ugs)
+        if y.shape[2] % 2 == 0 and y.shape[3] % 2 == 0 and os.environ.get("TRICOLO_STEM_FUSED", "1") != "0":
+            # BatchNorm backward straight from the pooled gradient and the winning-tap map: no max-pool backward pass
+            dy, gr[self.net_1[1].weight], gr[self.net_1[1].bias] = ops.maxpool_bn_bwd(y, parg, dout, co, self.net_1[1].weight, out_scale=ugs)
+        else:
+            dzs = ops.maxpool2d_bwd(parg, dout, tuple(y.shape))
+            dy, gr[self.net_1[1].weight], gr[self.net_1[1].bias] = ops.bn_bwd(y, dzs, co, self.net_1[1].weight, count_host=g0.M, relu=True,
+                                                                              out_scale=ugs)
         gr[self.net_1[0].weight] = ops.conv_wgrad(x0, dy, g0, self.net_1[0].weight, prec, out_scale=ugs, batch=batch)
         if own and batch is not None:
             batch.flush()

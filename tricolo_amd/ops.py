@@ -478,6 +478,24 @@ def maxpool2d_fwd(x, want_arg=True, bn: BNCoeffs = None):
     return out, arg
 
 
+def maxpool_bn_bwd(y, arg, dpool, co: "BNCoeffs", gamma, out_scale: float = 1.0):
+    """Backward of relu(bn(y)) -> MaxPool2d(3, 2, 1) in the two BatchNorm passes (no max-pool backward pass, no 4x-sized gradient
+    tensor): (dy, dgamma, dbeta).  y [N,1,H,W,C], arg / dpool [N,1,H/2,W/2,C]; H, W even."""
+    N, _, H, W, C = y.shape
+    assert dpool.dtype == y.dtype and H % 2 == 0 and W % 2 == 0
+    nblk = lib().tri_maxpool_bn_bwd_num_blocks(N, H, W)
+    partial = torch.empty((nblk, 2, C), dtype=torch.float32, device=y.device)
+    check(lib().tri_maxpool_bn_bwd_reduce(ptr(_act(y)), ptr(arg), ptr(_act(dpool)), N, H, W, C, ptr(partial), ptr(co.scale), ptr(co.shift),
+                                          _abf(y), stream()), "tri_maxpool_bn_bwd_reduce")
+    buf = torch.empty((5, C), dtype=torch.float32, device=y.device)
+    check(lib().tri_bn_bwd_finalize(ptr(partial), nblk, C, None, N * H * W, ptr(gamma), ptr(co.mean), ptr(co.invstd), ptr(buf[0]),
+                                    ptr(buf[1]), ptr(buf[2]), ptr(buf[3]), ptr(buf[4]), float(out_scale), stream()), "tri_bn_bwd_finalize")
+    dy = torch.empty_like(y)
+    check(lib().tri_maxpool_bn_bwd_apply(ptr(y), ptr(arg), ptr(dpool), N, H, W, C, ptr(buf[2]), ptr(buf[3]), ptr(buf[4]), ptr(co.scale),
+                                         ptr(co.shift), ptr(dy), _abf(y), stream()), "tri_maxpool_bn_bwd_apply")
+    return dy, buf[0], buf[1]
+
+
 def maxpool2d_bwd(arg, dout, in_shape):
     N, _, H, W, C = in_shape
     dx = torch.empty(in_shape, dtype=dout.dtype, device=dout.device)
