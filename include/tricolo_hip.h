@@ -119,7 +119,10 @@ size_t tri_conv_plan_bytes(const TriConvDesc* d);
 int tri_conv_plan_build(const TriConvDesc* d, void* plan, void* stream);
 int tri_conv_wgrad(const TriConvDesc* d, const void* in, const void* dout, const uint8_t* row_mask, const void* plan /* required */,
                    void* workspace, size_t workspace_bytes, float* dw, long s_co, long s_tap, long s_ci, int cin_real, int split3,
-                   int act_fmt, float out_scale /* dw = out_scale * sum: undoes the f16 mode's gradient scaling */, void* stream);
+                   int act_fmt, float out_scale /* dw = out_scale * sum: undoes the f16 mode's gradient scaling */,
+                   const int* row_pos, const int* row_count /* optional compact list of the output positions to contract over
+                       (tri_mask_compact: the active sites of a submanifold layer) - executed work = active rows; row_mask unused */,
+                   void* stream);
 /* The same in two halves, so that a tower's backward pays ONE reduce launch instead of one per layer: tri_conv_wgrad_partial runs
  * the position-split partial kernel into `workspace` (which must stay untouched until the reduce) and fills *pending;
  * tri_wgrad_reduce_grouped sums the slabs of n pending layers into their dw (any n; TRI_WGRAD_GROUP_MAX layers per launch).
@@ -137,7 +140,8 @@ typedef struct TriWgradReduce {
 } TriWgradReduce;
 int tri_conv_wgrad_partial(const TriConvDesc* d, const void* in, const void* dout, const uint8_t* row_mask, const void* plan /* required */,
                            void* workspace, size_t workspace_bytes, float* dw, long s_co, long s_tap, long s_ci, int cin_real, int split3,
-                           int act_fmt, float out_scale, TriWgradReduce* pending /* HOST, out */, void* stream);
+                           int act_fmt, float out_scale, const int* row_pos, const int* row_count, TriWgradReduce* pending /* HOST, out */,
+                           void* stream);
 int tri_wgrad_reduce_grouped(const TriWgradReduce* pending /* HOST array */, int n, void* stream);
 
 /* ---- BatchNorm (train-mode statistics, eps / momentum as torch.nn.BatchNorm1d/2d) ----------------------------------

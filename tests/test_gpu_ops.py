@@ -857,3 +857,34 @@ def test_stem_bn_backward_from_the_pooled_gradient(store):
         out.backward(dpool.cpu().view(N, H // 2, W // 2, C).permute(0, 3, 1, 2))
         np.testing.assert_allclose(dy_b.cpu().view(N, H, W, C).numpy(), yr.grad.permute(0, 2, 3, 1).numpy(), atol=5e-5, rtol=1e-4)
         np.testing.assert_allclose(dg_b.cpu().numpy() * 2, gr.grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("store,prec", [(torch.float32, "bf16x3"), (torch.float16, "f16"), (torch.bfloat16, "bf16")], ids=["bf16x3", "f16", "bf16"])
+@pytest.mark.parametrize("name", ["vox_l0", "vox_l1", "vox_m64", "vox_l3"])
+def test_conv_wgrad_over_a_compact_row_list(name, store, prec):
+    """Weight gradient of a submanifold layer contracted over the active sites only (row_pos / row_count from
+    tri_mask_compact) == the masked weight gradient: dOut of inactive sites is zero, so both are the same sum; integer data
+    make it exact.  Occupancies from empty to full, list lengths that are not multiples of the 32 / 64-position steps."""
+    cases = {c[0]: c for c in CONV_CASES}
+    cases["vox_m64"] = ("vox_m64", 2, (8, 8, 8), 64, 128, (3, 3, 3), 1, (1, 1, 1), "spconv")
+    case = cases[name]
+    x, w, wp, xcl, g = make_case(case, integer=True, seed=81)
+    M = g.M
+    for frac, seed in ((0.13, 1), (1.0, 2), (0.0, 3), (0.004, 4)):
+        gen = torch.Generator().manual_seed(seed)
+        mask = (torch.rand(M, generator=gen) < frac).to(torch.uint8)
+        mpad = torch.zeros((M + 31) // 32 * 32, dtype=torch.uint8)
+        mpad[:M] = mask
+        dy = ints((M, g.cout), -2, 2, 83 + seed) * mask[:, None].float()
+        xd = (xcl.reshape(M, -1) * 1.0).view(xcl.shape).to(DEV).to(store)
+        dyd = dy.view(g.B, *g.out_grid, g.cout).to(DEV).to(store)
+        ref = ops.conv_wgrad(xd, dyd, g, wp.to(DEV), prec, row_mask=mpad.to(DEV))
+        rows = ops.mask_compact(mpad.to(DEV), M)
+        assert int(rows[1].item()) == int(mask.sum())
+        out = ops.conv_wgrad(xd, dyd, g, wp.to(DEV), prec, rows=rows)
+        assert torch.equal(out, ref), f"occupancy {frac}: max abs diff {(out - ref).abs().max().item()}"
+        # garbage in the rows of inactive sites must not matter: the list never visits them
+        junk = dyd.clone().view(M, -1)
+        junk[(mask == 0).to(DEV)] = 7.0
+        out2 = ops.conv_wgrad(xd, junk.view(dyd.shape), g, wp.to(DEV), prec, rows=rows)
+        assert torch.equal(out2, ref)

@@ -58,8 +58,8 @@ SIGNATURES = {
     "tri_conv_wgrad_workspace": (Z, [DP]),
     "tri_conv_plan_bytes": (Z, [DP]),
     "tri_conv_plan_build": (I, [DP, P, P]),
-    "tri_conv_wgrad": (I, [DP, P, P, P, P, P, Z, P, L, L, L, I, I, I, F, P]),
-    "tri_conv_wgrad_partial": (I, [DP, P, P, P, P, P, Z, P, L, L, L, I, I, I, F, P, P]),
+    "tri_conv_wgrad": (I, [DP, P, P, P, P, P, Z, P, L, L, L, I, I, I, F, P, P, P]),
+    "tri_conv_wgrad_partial": (I, [DP, P, P, P, P, P, Z, P, L, L, L, I, I, I, F, P, P, P, P]),
     "tri_wgrad_reduce_grouped": (I, [P, I, P]),
     "tri_bn_finalize": (I, [P, I, I, P, I, P, P, P, P, P, F, F, P, P, P, P, P]),
     "tri_bn_eval_coeffs": (I, [I, P, P, P, P, F, P, P, P, P, P]),

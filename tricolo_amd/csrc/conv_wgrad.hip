@@ -17,6 +17,8 @@ struct WgradArgs {
     const void* in;              // activations / gradients: fp32 or bf16 (kernel template parameter AT)
     const void* dout;
     const uint8_t* row_mask;
+    const int* row_pos;          // optional compact list of the output positions to contract over (submanifold layers: the
+    const int* row_count;        // active sites, tri_mask_compact) + its device-side length; then row_mask is not consulted
     float* slab;                 // [splits][Cout][Kpad]
     const int* plan_off;         // optional gather plan: element offset of each output position's origin voxel
     const unsigned* plan_mask;   //                       packed per-axis tap validity bits (8 per axis)
@@ -65,6 +67,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
     int* lut_off = lut + 64;
     int* lplan_off = lut + 128;                                  // [steps_per_split * 32] origin offsets of this block's positions
     unsigned* lplan_mask = (unsigned*)lplan_off + p.steps_per_split * 32;
+    int* lrow = (int*)lplan_mask + p.steps_per_split * 32;      // row list launches: the position of every list entry of this block
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int JT = (p.Kpad + BJ - 1) / BJ;
@@ -86,9 +89,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
     if (split >= p.nsplits) return;
     const int it = tile / JT, jt = tile - it * JT;
     const int i0 = it * BI, j0 = jt * BJ;
-    const int ks_begin = split * p.steps_per_split;
-    const int nsteps_total = (p.M + 31) >> 5;
-    const int ks_end = min(nsteps_total, ks_begin + p.steps_per_split);
+    // row list: the splits share the *row_count list entries evenly (the static steps_per_split is the bound for a full list)
+    const int nrows = p.row_count ? *p.row_count : p.M;
+    const int nsteps_total = (nrows + 31) >> 5;
+    const int sps = p.row_count ? (nsteps_total + p.nsplits - 1) / p.nsplits : p.steps_per_split;
+    const int ks_begin = split * sps;
+    const int ks_end = min(nsteps_total, ks_begin + sps);
 
     if (t < 64) {
         int kd = 0, kh = 0, kw = 0;
@@ -102,7 +108,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
         lut_off[t] = ((kd * p.IH + kh) * p.IW + kw) * p.Cin;
     }
     // the gather plan of this block's position range goes to LDS once: per-load plan reads then cost no VMEM issue
-    {
+    if (p.row_count) {
+        const int n = (ks_end - ks_begin) * 32;
+        for (int i = t; i < n; i += 256) {
+            const int idx = ks_begin * 32 + i;
+            const int m = idx < nrows ? p.row_pos[idx] : -1;
+            lrow[i] = m;
+            lplan_off[i] = m >= 0 ? p.plan_off[m] : 0;
+            lplan_mask[i] = m >= 0 ? p.plan_mask[m] : 0u;      // no valid tap: the gather of a padding entry delivers zeros
+        }
+    } else {
         const int n4 = (ks_end - ks_begin) * 8;                 // int4 chunks
         const int4* so = (const int4*)(p.plan_off + ks_begin * 32);
         const int4* sm = (const int4*)(p.plan_mask + ks_begin * 32);
@@ -146,7 +161,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
 
     // a 32-position step is live when any of its output sites is active (dense layers: always)
     auto step_live = [&](int ks) -> bool {
-        if (!p.row_mask) return true;
+        if (!p.row_mask || p.row_count) return true;
         int m = ks * 32;
         const uint32_t* mp = (const uint32_t*)(p.row_mask + m);          // mask buffers are padded to 32 bytes
         uint32_t any = 0;
@@ -166,16 +181,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
             int e = t + u * 256;
             if (e < XL) {
                 int quad = e % (BI / 4), pos = e / (BI / 4);
-                int m = mbase + pos, co = i0 + quad * 4;
+                int m = p.row_count ? lrow[mbase + pos - ks_begin * 32] : mbase + pos, co = i0 + quad * 4;
                 float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (m < p.M && co < p.Cout) {
+                if (m >= 0 && m < p.M && co < p.Cout) {
                     if (sizeof(AT) == 4) x = *(const float4*)((const float*)p.dout + (size_t)m * p.Cout + co);
                     else { uint2 h = *(const uint2*)((const uint16_t*)p.dout + (size_t)m * p.Cout + co); x.x = __builtin_bit_cast(float, h.x); x.y = __builtin_bit_cast(float, h.y); }
                 }
                 v[u] = x;
             } else {
                 int pos = (e - XL) / (BJ / 4);
-                int m = mbase + pos;
+                int m = mbase + pos;                                     // list index (row list) or position: the plan copy in LDS is indexed alike
                 int ro = lplan_off[m - ks_begin * 32];
                 unsigned rm = lplan_mask[m - ks_begin * 32];
                 int sh = y_sh[u];
@@ -310,6 +325,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs p) 
     int* lut_off = lut + 64;
     int* lplan_off = lut + 128;                                  // [steps_per_split * 64]
     unsigned* lplan_mask = (unsigned*)lplan_off + p.steps_per_split * KB;
+    int* lrow = (int*)lplan_mask + p.steps_per_split * KB;       // row list launches, see conv_wgrad_kernel
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int JT = (p.Kpad + BJ - 1) / BJ;
@@ -326,9 +342,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs p) 
     if (split >= p.nsplits) return;
     const int it = tile / JT, jt = tile - it * JT;
     const int i0 = it * BI, j0 = jt * BJ;
-    const int ks_begin = split * p.steps_per_split;
-    const int nsteps_total = (p.M + KB - 1) / KB;
-    const int ks_end = min(nsteps_total, ks_begin + p.steps_per_split);
+    const int nrows = p.row_count ? *p.row_count : p.M;
+    const int nsteps_total = (nrows + KB - 1) / KB;
+    const int sps = p.row_count ? (nsteps_total + p.nsplits - 1) / p.nsplits : p.steps_per_split;
+    const int ks_begin = split * sps;
+    const int ks_end = min(nsteps_total, ks_begin + sps);
 
     if (t < 64) {
         int kd = 0, kh = 0, kw = 0;
@@ -345,8 +363,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs p) 
         const int n = (ks_end - ks_begin) * KB, mpad = (p.M + 31) & ~31;
         for (int i = t; i < n; i += 256) {
             int m = ks_begin * KB + i;
-            lplan_off[i] = m < mpad ? p.plan_off[m] : 0;
-            lplan_mask[i] = m < mpad ? p.plan_mask[m] : 0u;
+            if (p.row_count) {
+                m = m < nrows ? p.row_pos[m] : -1;
+                lrow[i] = m;
+                lplan_off[i] = m >= 0 ? p.plan_off[m] : 0;
+                lplan_mask[i] = m >= 0 ? p.plan_mask[m] : 0u;
+            } else {
+                lplan_off[i] = m < mpad ? p.plan_off[m] : 0;
+                lplan_mask[i] = m < mpad ? p.plan_mask[m] : 0u;
+            }
         }
     }
     __syncthreads();
@@ -391,7 +416,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs p) 
     const unsigned lds0 = lds_addr(smem) + wave * 1024;
 
     auto step_live = [&](int ks) -> bool {
-        if (!p.row_mask) return true;
+        if (!p.row_mask || p.row_count) return true;
         int m = ks * KB;
         const uint32_t* mp = (const uint32_t*)(p.row_mask + m);          // mask buffers are padded to 32 bytes
         uint32_t any = 0;
@@ -406,9 +431,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs p) 
     auto issue = [&](int ks, int buf) {
         const unsigned xb = lds0 + buf * STAGE;
         const unsigned yb = xb + X_BYTES;
-        const unsigned xbase = xoff + (unsigned)(ks * KB) * (unsigned)(p.Cout * 2);
+        if (p.row_count) {                                           // dOut rows through the list: one LDS lookup per instruction
+            const int* lr = lrow + (ks - ks_begin) * KB + xrow0;
 #pragma unroll
-        for (int i = 0; i < XNI; ++i) dma16_async(xrsrc, xb + i * 4096, (int)(xbase + i * xstep));
+            for (int i = 0; i < XNI; ++i) {
+                const int m = lr[4 * XRPI * i];
+                dma16_async(xrsrc, xb + i * 4096, m >= 0 ? (int)((unsigned)(m * p.Cout + i0 + xchunk * 8) * 2u) : (int)0x80000000);
+            }
+        } else {
+            const unsigned xbase = xoff + (unsigned)(ks * KB) * (unsigned)(p.Cout * 2);
+#pragma unroll
+            for (int i = 0; i < XNI; ++i) dma16_async(xrsrc, xb + i * 4096, (int)(xbase + i * xstep));
+        }
         const int* po = lplan_off + (ks - ks_begin) * KB + yrow0;
         const unsigned* pm = lplan_mask + (ks - ks_begin) * KB + yrow0;
 #pragma unroll
@@ -594,8 +628,8 @@ static bool wgrad_dma_disabled() {
 
 // act_fmt != 0 asks for the plan of the bf16-storage call; *dma is set when that call runs the LDS-DMA kernel
 // (64-position steps), and steps_per_split is then in 64-position units.
-static void wgrad_plan(const TriConvDesc* d, int act_fmt, int* BI, int* BJ_out, int* tiles, int* splits, int* steps_per_split, int* Kpad,
-                       int* dma) {
+static void wgrad_plan(const TriConvDesc* d, int act_fmt, int rowlist, int* BI, int* BJ_out, int* tiles, int* splits, int* steps_per_split,
+                       int* Kpad, int* dma) {
     int ntaps = d->KD * d->KH * d->KW;
     *Kpad = (ntaps * d->Cin + 31) / 32 * 32;
     *BI = (d->Cout % 128 == 0 && *Kpad >= 128) ? 128 : 64;
@@ -614,7 +648,7 @@ static void wgrad_plan(const TriConvDesc* d, int act_fmt, int* BI, int* BJ_out, 
         // workgroups, and not quite full (7/8 of the 512 slots).  More splits only add slab traffic (splits x Cout x K
         // fp32 written + re-read by the reduce) and a second, partly empty round; measured sweep in profiles/r1/README.md.
         const int fixed = (*dma ? 2 * 64 * (*BI * 2 + BJ * 2) : 2 * (32 * *BI * 2 + 32 * BJ * 2)) + 512;
-        cap = (163840 / 2 - fixed) / (*dma ? 512 : 256);        // gather plan: 8 B per position of the split
+        cap = (163840 / 2 - fixed) / ((*dma ? 512 : 256) * (rowlist ? 3 : 2) / 2);   // gather plan: 8 B per position of the split (+ 4 B: row list)
         if (cap > 96) cap = 96;
         s = 448 / *tiles;
     } else {
@@ -633,9 +667,9 @@ static void wgrad_plan(const TriConvDesc* d, int act_fmt, int* BI, int* BJ_out, 
 
 extern "C" size_t tri_conv_wgrad_workspace(const TriConvDesc* d) {
     size_t need = 0;
-    for (int mode = 0; mode < 2; ++mode) {
+    for (int mode = 0; mode < 4; ++mode) {                        // fp32 / 16-bit storage x position range / row list
         int BI, BJ, tiles, splits, sps, Kpad, dma;
-        wgrad_plan(d, mode, &BI, &BJ, &tiles, &splits, &sps, &Kpad, &dma);
+        wgrad_plan(d, mode & 1, mode >> 1, &BI, &BJ, &tiles, &splits, &sps, &Kpad, &dma);
         size_t n = (size_t)splits * d->Cout * Kpad * sizeof(float);
         if (n > need) need = n;
     }
@@ -645,17 +679,17 @@ extern "C" size_t tri_conv_wgrad_workspace(const TriConvDesc* d) {
 // 0: conv_wgrad_kernel (register-staged), 2: conv_wgrad_dma_kernel (bf16 activation storage, LDS-DMA).  For profilers.
 extern "C" int tri_conv_wgrad_kernel_family(const TriConvDesc* d, int act_fmt) {
     int BI, BJ, tiles, splits, sps, Kpad, dma;
-    wgrad_plan(d, act_fmt, &BI, &BJ, &tiles, &splits, &sps, &Kpad, &dma);
+    wgrad_plan(d, act_fmt, 0, &BI, &BJ, &tiles, &splits, &sps, &Kpad, &dma);
     return dma ? 2 : 0;
 }
 
 template <int BI, int BJ, typename E>
 static int launch_wgrad_dma(const WgradArgs& a, int tiles, int splits, hipStream_t stream) {
     constexpr int STAGE = 64 * (BI * 2 + BJ * 2);
-    size_t smem = 2 * STAGE + 512 + (size_t)a.steps_per_split * 512;
+    size_t smem = 2 * STAGE + 512 + (size_t)a.steps_per_split * (a.row_count ? 768 : 512);     // + the list's positions (4 B each)
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel<BI, BJ, E>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE + 512 + 96 * 512);
+        hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel<BI, BJ, E>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE + 512 + 96 * 768);
         attr_set = true;
     }
     conv_wgrad_dma_kernel<BI, BJ, E><<<dim3(((splits + 7) / 8) * 8 * tiles), 256, smem, stream>>>(a);
@@ -666,11 +700,11 @@ static int launch_wgrad_dma(const WgradArgs& a, int tiles, int splits, hipStream
 template <int BI, int BJ, int NSPLIT, typename AT>
 static int launch_wgrad(const WgradArgs& a, int tiles, int splits, hipStream_t stream) {
     constexpr int STAGE = NSPLIT * (32 * BI * 2 + 32 * BJ * 2);
-    size_t smem = 2 * STAGE + 512 + (size_t)a.steps_per_split * 256;
+    size_t smem = 2 * STAGE + 512 + (size_t)a.steps_per_split * (a.row_count ? 384 : 256);
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute((const void*)conv_wgrad_kernel<BI, BJ, NSPLIT, AT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            2 * STAGE + 512 + WGRAD_MAX_STEPS * 256);
+                            2 * STAGE + 512 + WGRAD_MAX_STEPS * 384);
         attr_set = true;
     }
     conv_wgrad_kernel<BI, BJ, NSPLIT, AT><<<dim3(((splits + 7) / 8) * 8 * tiles), 256, smem, stream>>>(a);
@@ -682,14 +716,16 @@ static int launch_wgrad(const WgradArgs& a, int tiles, int splits, hipStream_t s
 // multiple of 32 bytes) marks live positions; split3 != 0 selects the 3-product bf16 split mode.
 extern "C" int tri_conv_wgrad_partial(const TriConvDesc* d, const void* in, const void* dout, const uint8_t* row_mask, const void* plan,
                                       void* workspace, size_t workspace_bytes, float* dw, long s_co, long s_tap, long s_ci, int cin_real,
-                                      int split3, int act_fmt, float out_scale, TriWgradReduce* pending, void* stream) {
+                                      int split3, int act_fmt, float out_scale, const int* row_pos, const int* row_count,
+                                      TriWgradReduce* pending, void* stream) {
     if (!pending) { tri_set_error("wgrad: pending descriptor is NULL"); return TRI_ERR_ARG; }
+    if ((row_pos == nullptr) != (row_count == nullptr)) { tri_set_error("wgrad: row_pos and row_count go together"); return TRI_ERR_ARG; }
     if (d->Cin % 4 != 0 || d->Cout % 4 != 0) { tri_set_error("wgrad: channels must be multiples of 4"); return TRI_ERR_ARG; }
     int BI, BJ, tiles, splits, sps, Kpad, dma;
-    wgrad_plan(d, act_fmt, &BI, &BJ, &tiles, &splits, &sps, &Kpad, &dma);
+    wgrad_plan(d, act_fmt, row_count != nullptr, &BI, &BJ, &tiles, &splits, &sps, &Kpad, &dma);
     if (workspace_bytes < (size_t)splits * d->Cout * Kpad * sizeof(float)) { tri_set_error("wgrad: workspace too small"); return TRI_ERR_ARG; }
     WgradArgs a{};
-    a.in = in; a.dout = dout; a.row_mask = row_mask; a.slab = (float*)workspace;
+    a.in = in; a.dout = dout; a.row_mask = row_mask; a.slab = (float*)workspace; a.row_pos = row_pos; a.row_count = row_count;
     a.B = d->B; a.ID = d->ID; a.IH = d->IH; a.IW = d->IW; a.Cin = d->Cin;
     a.OD = d->OD; a.OH = d->OH; a.OW = d->OW; a.Cout = d->Cout;
     a.KD = d->KD; a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pd = d->pad_d; a.ph = d->pad_h; a.pw = d->pad_w;
@@ -759,10 +795,10 @@ extern "C" int tri_wgrad_reduce_grouped(const TriWgradReduce* pending, int n, vo
 
 extern "C" int tri_conv_wgrad(const TriConvDesc* d, const void* in, const void* dout, const uint8_t* row_mask, const void* plan,
                               void* workspace, size_t workspace_bytes, float* dw, long s_co, long s_tap, long s_ci, int cin_real,
-                              int split3, int act_fmt, float out_scale, void* stream) {
+                              int split3, int act_fmt, float out_scale, const int* row_pos, const int* row_count, void* stream) {
     TriWgradReduce r;
     int rc = tri_conv_wgrad_partial(d, in, dout, row_mask, plan, workspace, workspace_bytes, dw, s_co, s_tap, s_ci, cin_real, split3, act_fmt,
-                                    out_scale, &r, stream);
+                                    out_scale, row_pos, row_count, &r, stream);
     if (rc) return rc;
     wgrad_reduce_kernel<<<(unsigned)r.nblocks, 256, 0, (hipStream_t)stream>>>(r.slab, r.splits, r.Cout, r.Kpad, r.ntaps, r.cin_stored, r.cin_real,
                                                                              r.dw, r.s_co, r.s_tap, r.s_ci, r.zlanes, r.out_scale);

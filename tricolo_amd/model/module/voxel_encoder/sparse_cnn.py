@@ -142,6 +142,7 @@ class SparseCNNEncoder(TriModule):
         ugs = 1.0 / gs
         dx = ops.cast_from_f32(dflat.contiguous(), ops.act_dtype(prec), gs)
         batch = ops.wgrad_batch(dz.device)                     # the five weight-gradient reduces in one launch at the end
+        compact = os.environ.get("TRICOLO_VOXEL_COMPACT", "1") != "0"
         for l in range(4, -1, -1):
             D, C = V >> l, self.chans[l + 1]
             g = self._geom(B, l)
@@ -149,11 +150,14 @@ class SparseCNNEncoder(TriModule):
             conv, bn = self.sparseModel[str(4 * l)], self.sparseModel[str(4 * l + 1)]
             gz = ops.pool3d_bwd_route(y, co, mask, pooled, dx.contiguous(), B, D, C)
             dy, dgamma, dbeta = ops.bn_bwd(y, gz, co, bn.weight, count_dev=count, row_mask=mask, out_scale=ugs)
-            grads[3 * l] = ops.conv_wgrad(x, dy, g, conv.weight, prec, row_mask=mask, out_scale=ugs, batch=batch)
+            if compact:                                          # contraction over the active sites only (row list of the level)
+                grads[3 * l] = ops.conv_wgrad(x, dy, g, conv.weight, prec, rows=rows, out_scale=ugs, batch=batch)
+            else:
+                grads[3 * l] = ops.conv_wgrad(x, dy, g, conv.weight, prec, row_mask=mask, out_scale=ugs, batch=batch)
             grads[3 * l + 1], grads[3 * l + 2] = dgamma, dbeta
             if l > 0:
                 pt = self._packed[(l, True)]
-                if os.environ.get("TRICOLO_VOXEL_COMPACT", "1") != "0" and not g.splitk(True, ops._conv_mode(dy, pt[1])):
+                if compact and not g.splitk(True, ops._conv_mode(dy, pt[1])):
                     dx = ops.conv_dgrad(dy, g, pt, rows=rows)                   # only the active input sites are computed / written
                 else:
                     dx = ops.conv_dgrad(dy, g, pt, row_mask=mask)

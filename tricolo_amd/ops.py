@@ -353,9 +353,11 @@ def wgrad_batch(device):
     return WgradBatch(device) if _WGRAD_GROUPED else None
 
 
-def conv_wgrad(x, dout, g: ConvGeom, like: torch.Tensor, precision: str, row_mask=None, out_scale: float = 1.0, batch=None):
+def conv_wgrad(x, dout, g: ConvGeom, like: torch.Tensor, precision: str, row_mask=None, out_scale: float = 1.0, batch=None, rows=None):
     """Gradient of the layer's parameter, returned in the parameter's own layout (shape of ``like``), times out_scale.
-    With ``batch`` (a WgradBatch of the CURRENT stream) only the partial sums are launched; batch.flush() completes dw."""
+    With ``batch`` (a WgradBatch of the CURRENT stream) only the partial sums are launched; batch.flush() completes dw.
+    rows = (row_pos, count) from mask_compact: the contraction runs over those output positions only (pass no row_mask)."""
+    assert rows is None or row_mask is None
     assert x.dtype == dout.dtype
     dw = torch.empty_like(like)
     ws = batch.slab(g.wgrad_ws) if batch is not None else _workspace(g.wgrad_ws, x.device)
@@ -374,12 +376,15 @@ def conv_wgrad(x, dout, g: ConvGeom, like: torch.Tensor, precision: str, row_mas
         check(_timed(sym, g.flops,
                      lambda: lib().tri_conv_wgrad_partial(_C.C.byref(g.desc), ptr(_act(x)), ptr(_act(dout)), ptr(row_mask), ptr(plan),
                                                           ptr(ws), ws.numel(), ptr(dw), s_co, s_tap, s_ci, g.cin, s3, _abf(x),
-                                                          float(out_scale), _C.C.byref(desc), stream())), "tri_conv_wgrad_partial")
+                                                          float(out_scale), ptr(rows[0]) if rows else None,
+                                                          ptr(rows[1]) if rows else None, _C.C.byref(desc), stream())),
+              "tri_conv_wgrad_partial")
         batch.descs.append(desc)
         return dw
     check(_timed(sym, g.flops,
                  lambda: lib().tri_conv_wgrad(_C.C.byref(g.desc), ptr(_act(x)), ptr(_act(dout)), ptr(row_mask), ptr(plan), ptr(ws),
-                                              ws.numel(), ptr(dw), s_co, s_tap, s_ci, g.cin, s3, _abf(x), float(out_scale), stream())),
+                                              ws.numel(), ptr(dw), s_co, s_tap, s_ci, g.cin, s3, _abf(x), float(out_scale),
+                                              ptr(rows[0]) if rows else None, ptr(rows[1]) if rows else None, stream())),
           "tri_conv_wgrad")
     return dw
 
