@@ -91,7 +91,8 @@ class TriCoLoNet(TriModule):
         replays each tower's backward on the stream its forward ran on, so the overlap holds both ways and is captured as
         parallel branches of the HIP graph.  Key order (text, image, voxel) is preserved: it fixes which side gets alpha."""
         tokens = data_dict["tokens"]
-        overlap = tokens.is_cuda and self.overlap_towers and (self.image_encoder is not None) and torch.is_grad_enabled()
+        n_side = int(self.image_encoder is not None) + int(self.voxel_encoder is not None)
+        overlap = tokens.is_cuda and self.overlap_towers and n_side >= 1 and torch.is_grad_enabled()
         if not overlap:
             output_dict = {"text_features": self.text_encoder(tokens, data_dict)}
             if self.image_encoder is not None:
@@ -104,6 +105,7 @@ class TriCoLoNet(TriModule):
         if self._side_streams is None:
             self._side_streams = (torch.cuda.Stream(), torch.cuda.Stream())
         s_text, s_vox = self._side_streams
+        # The heaviest tower runs on the caller's stream: the image tower, or - Bi(V) - the voxel tower; the others on side streams.
         # (Issue order matters under HIP-graph replay: the executor queues a branch issued later behind earlier ones when it folds
         # them onto one internal stream.  Side towers first: their forward starts at once, their backward - autograd runs the
         # latest-created node first - is issued after the image tower's and the voxel backward starts ~1.2 ms late; image tower
@@ -112,20 +114,26 @@ class TriCoLoNet(TriModule):
         with torch.cuda.stream(s_text):
             text = self.text_encoder(tokens, data_dict)
             ops.stamp("text.fwd.end")
-        vox = None
+        vox = img = None
         if self.voxel_encoder is not None:
-            s_vox.wait_stream(main)
-            with torch.cuda.stream(s_vox):
+            vox_on_main = self.image_encoder is None
+            if not vox_on_main:
+                s_vox.wait_stream(main)
+            with torch.cuda.stream(main if vox_on_main else s_vox):
                 vox = self._gate(self.voxel_encoder(data_dict["voxels"], len(data_dict["model_id"])))
                 ops.stamp("voxel.fwd.end")
-        img = self.image_encoder(data_dict["images"].flatten(end_dim=1), data_dict)
-        ops.stamp("image.fwd.end")
+        if self.image_encoder is not None:
+            img = self.image_encoder(data_dict["images"].flatten(end_dim=1), data_dict)
+            ops.stamp("image.fwd.end")
         main.wait_stream(s_text)
         text.record_stream(main)
-        output_dict = {"text_features": text, "image_features": img}
+        output_dict = {"text_features": text}
+        if img is not None:
+            output_dict["image_features"] = img
         if vox is not None:
-            main.wait_stream(s_vox)
-            vox.record_stream(main)
+            if self.image_encoder is not None:
+                main.wait_stream(s_vox)
+                vox.record_stream(main)
             output_dict["voxel_features"] = vox
         return output_dict
 
