@@ -628,6 +628,8 @@ BF16_CASES = [c for c in CONV_CASES if c[0] in ("vox_l0", "vox_l1", "vox_l3", "s
     ("h_many", 40, (1, 32, 32), 64, 64, (1, 3, 3), 1, (0, 1, 1), "torch"),
     # more tiles than CUs with four output-channel tiles and two channel chunks each (the weight stream crosses tile boundaries)
     ("h_320", 160, (1, 8, 8), 128, 256, (1, 3, 3), 1, (0, 1, 1), "torch"),
+    # 56-wide rows (two per tile, 112 of 128 positions used), four output-channel tiles, 7 tiles per CU
+    ("h_56x4", 32, (1, 56, 56), 64, 256, (1, 3, 3), 1, (0, 1, 1), "torch"),
 ]
 
 
