@@ -1,7 +1,8 @@
 #!/bin/bash
 # Round evidence recipe (run on the GPU box from the repo root):  bash tools/profile_round.sh <tag>
 # Writes gpurun_out/<tag>_*: the -m gpu test log, bench.py JSON lines (default run + configs 2/3/5), rocprofv3 kernel stats
-# for the f16 and bf16x3 modes and the two PMC passes (FETCH_SIZE / WRITE_SIZE in separate runs, MI355X_MICROARCH.md).
+# for the f16 and bf16x3 modes, the two PMC passes (FETCH_SIZE / WRITE_SIZE in separate runs, MI355X_MICROARCH.md) and the
+# in-graph step timelines (tools/step_timeline.py).
 tag=${1:-r2}
 R=$PWD
 O=$R/gpurun_out
@@ -9,6 +10,7 @@ mkdir -p $O
 python -m pytest tests -m gpu -q 2>&1 | tail -8 > $O/${tag}_gpu_tests.txt
 python bench.py > $O/${tag}_bench_default.json 2> $O/${tag}_bench_default.err
 for c in 2 3 5; do python bench.py --config $c --modes "" --no-cpu-baseline > $O/${tag}_bench_cfg$c.json 2> $O/${tag}_bench_cfg$c.err; done
+for c in 4 2 3 5; do python tools/step_timeline.py --config $c > $O/${tag}_timeline_cfg$c.txt 2>/dev/null; done
 cd /tmp && export TMPDIR=/tmp
 for p in f16 bf16x3; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_prof_$p -- python3 $R/bench.py --steps 20 --warmup 5 --precision $p --modes "" --no-cpu-baseline > $O/${tag}_prof_$p.json 2> $O/${tag}_prof_$p.err
