@@ -628,6 +628,14 @@ BF16_CASES = [c for c in CONV_CASES if c[0] in ("vox_l0", "vox_l1", "vox_l3", "s
     ("h_many", 40, (1, 32, 32), 64, 64, (1, 3, 3), 1, (0, 1, 1), "torch"),
     # more tiles than CUs with four output-channel tiles and two channel chunks each (the weight stream crosses tile boundaries)
     ("h_320", 160, (1, 8, 8), 128, 256, (1, 3, 3), 1, (0, 1, 1), "torch"),
+    # conv_stem_kernel (4 stored input channels, stride 2, 64 output channels): stem7x7 above (32 x 32 -> 16 x 16, one tile per
+    # image) and: several tiles per image with a partial last one (OH = 24, TH = 8), 3x3 and 5x5 kernels, a persistent workgroup
+    # that walks many tiles (more tiles than CUs), 112-wide output rows (7 position tiles per row, TH = 2)
+    ("stem_48", 2, (1, 48, 32), 3, 64, (1, 7, 7), 2, (0, 3, 3), "torch"),
+    ("stem_3x3", 3, (1, 32, 64), 3, 64, (1, 3, 3), 2, (0, 1, 1), "torch"),
+    ("stem_5x5", 2, (1, 20, 32), 3, 64, (1, 5, 5), 2, (0, 2, 2), "torch"),
+    ("stem_many", 70, (1, 32, 32), 3, 64, (1, 7, 7), 2, (0, 3, 3), "torch"),
+    ("stem_224", 1, (1, 56, 224), 3, 64, (1, 7, 7), 2, (0, 3, 3), "torch"),
     # 56-wide rows (two per tile, 112 of 128 positions used), four output-channel tiles, 7 tiles per CU
     ("h_56x4", 32, (1, 56, 56), 64, 256, (1, 3, 3), 1, (0, 1, 1), "torch"),
 ]
@@ -655,6 +663,15 @@ def test_conv_16bit_storage_integer_exact(case, store, prec):
     if case[3] != 3:
         dx = ops.conv_dgrad(cl3(dy).to(DEV).to(store), g, ops.pack_weight(wp.to(DEV), g, prec, transposed=True))
         assert torch.equal(dx.cpu(), cl3(xr.grad).to(store))
+    if case[0].startswith("stem"):
+        # one BatchNorm record per persistent workgroup of conv_stem_kernel: their sum is the whole tensor's column sum
+        assert (g.kernel_family[(False, 2)] & 255) == 4
+        out2, stats = ops.conv_fwd(xcl.to(DEV).to(store), g, packed, want_stats=True)
+        assert torch.equal(out2.cpu(), ref.to(store)) and stats.shape[0] == g.num_mtiles[2]
+        exact = ref.to(store).double().reshape(-1, case[4])
+        st = stats.cpu().double().sum(0)
+        np.testing.assert_allclose(st[0].numpy(), exact.sum(0).numpy(), rtol=1e-6, atol=1e-2)
+        np.testing.assert_allclose(st[1].numpy(), (exact ** 2).sum(0).numpy(), rtol=1e-6, atol=1e-2)
     if case[5] == (1, 3, 3) and case[6] == 1:
         # the resolution-keeping 3x3 layers (conv_halo2d_kernel): BatchNorm partial sums of the stored values, and the
         # accumulate epilogue the residual branch of a BasicBlock uses

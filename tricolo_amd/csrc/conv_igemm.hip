@@ -870,6 +870,189 @@ __global__ __launch_bounds__(256) void conv_halo2d_kernel(const ConvArgs p) {
     }
 }
 
+
+// ================================================================================================ stem kernel (2D, 4 stored input channels, stride 2)
+// conv1 of the ResNet trunk (7x7 / 2 / pad 3, 3 -> 64 channels, mv_cnn.py:44) through conv_igemm_kernel is a chain of exposed gather
+// latencies: 7 k-steps of 8-byte im2col loads per 128-position tile, 57-72 us at the bench shape against ~20 us for its 100 MB
+// of output.  With four stored channels one kernel ROW (kw = 0..7, ci = 0..3) is exactly one 32-wide MFMA k-step, so:
+//   * the whole filter bank lives in REGISTERS as MFMA A fragments (KH rows x 4 output-channel tiles x 4 VGPRs = 112 for 7x7 -> 64),
+//     loaded once per persistent workgroup;
+//   * the input rows a tile of TH output rows needs are staged ONCE in an LDS slab (8 B per pixel, borders zero); output column ow,
+//     k-group g reads pixels 2 ow - pad + 2 g, + 1 = the 16-byte chunk (ow + g) of slab row 2 r + kh: one conflict-free ds_read_b128 per
+//     16 positions and kernel row, no address arithmetic beyond an add;
+//   * the next tile's slab rows are prefetched into registers under the MFMAs of the current one (two slab buffers);
+//   * the BatchNorm column sums stay in registers across the workgroup's tiles: ONE record per workgroup.
+// Geometry (stem_geometry): KD = 1, stored Cin = 4, stride 2, KW <= 8, KH <= 8, Cout = 64, OW % 16 == 0, IW + pad <= 2 OW + 6.
+#define STEM_MAX_KH 8
+struct StemGeom { int TH, slab_rows, row_bytes, ptiles, tiles_per_img, ntiles, grid, npt; };
+// NPT = position tiles (16 positions) per wave and workgroup tile: 4 (256-position tiles, ~490 registers: one workgroup per CU) or
+// 2 (128-position tiles, <= 256 registers: two per CU, whose MFMAs overlap each other's epilogue / slab traffic)
+template <int KH, int NPT, typename AT>
+__global__ __launch_bounds__(256, NPT == 2 ? 2 : 1) void conv_stem_kernel(const ConvArgs p, const StemGeom sg) {
+    typedef Mma<typename OpOf<AT>::E> MM;
+    typedef typename MM::v8 v8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), fr = lane & 15, fq = lane >> 4;
+    const int slab_bytes = sg.slab_rows * sg.row_bytes;
+    float* const red = (float*)(smem + 2 * slab_bytes);                          // [4 waves][64][2]
+    const int OW = p.OW, IW = p.IW, IH = p.IH, OH = p.OH;
+    const int pt_per_row = OW >> 4;
+
+    // ---- filter bank -> registers: A fragment (kh, ct): row = output channel 16 ct + fr, k = (kw = 2 fq, 2 fq + 1) x 4 channels
+    v8 wf[KH][4];
+    {
+        const uint16_t* w = (const uint16_t*)p.w_hi;
+#pragma unroll
+        for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                const uint16_t* src = w + (size_t)(ct * 16 + fr) * p.Kpad + (kh * p.KW + 2 * fq) * 4;
+                uint2 lo = make_uint2(0u, 0u), hi = make_uint2(0u, 0u);
+                if (2 * fq < p.KW) lo = *(const uint2*)src;
+                if (2 * fq + 1 < p.KW) hi = *(const uint2*)(src + 4);
+                const uint4 raw = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                wf[kh][ct] = __builtin_bit_cast(v8, raw);
+            }
+        // the fragments are complete here; re-define them through an empty asm so that the compiler's waitcnt pass does not carry
+        // "pending global loads feed the MFMA operands" into the tile loop, where it became a vmcnt(0) in front of the first MFMA
+        // of every tile - i.e. a wait for the NEXT tile's prefetch that is supposed to fly under these MFMAs
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) asm volatile("" : "+v"(wf[kh][ct]));
+    }
+    // zero both slab buffers once: the border chunks are never written again
+    for (int i = t * 16; i < 2 * slab_bytes; i += 256 * 16) *(uint4*)(smem + i) = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+
+    // slab fill: 16-byte global loads of two pixels (x even) -> LDS at pixel x + pad (8-byte aligned: two ds_write_b64).  Which slab
+    // row / pixel pair a thread moves never changes: computed once (the tile loop ran ~1,500 instructions per wave with the divisions
+    // inside it - at one wave per SIMD that was 47 of the kernel's 65 us).
+    constexpr int MAXLD = 4;                                                     // loads per thread per tile (stem_geometry checks it)
+    const int ld_per_row = IW >> 1, nld = sg.slab_rows * ld_per_row;
+    int ld_row[MAXLD], ld_goff[MAXLD], ld_loff[MAXLD];
+#pragma unroll
+    for (int u = 0; u < MAXLD; ++u) {
+        const int e = t + u * 256;
+        const int srow = e / ld_per_row, xp = e - srow * ld_per_row;
+        ld_row[u] = e < nld ? srow : -(1 << 20);                                 // never a valid image row
+        ld_goff[u] = (srow * IW + 2 * xp) * 8;
+        ld_loff[u] = srow * sg.row_bytes + (2 * xp + p.pw) * 8;
+    }
+    uint4 pre[MAXLD];
+    auto fetch = [&](int tile) {
+        const int img = tile / sg.tiles_per_img, oh0 = (tile - img * sg.tiles_per_img) * sg.TH;
+        const int iy0 = oh0 * 2 - p.ph;
+        const char* base = (const char*)p.in + ((size_t)img * IH + iy0) * IW * 8;          // may point before the image: only valid rows are read
+#pragma unroll
+        for (int u = 0; u < MAXLD; ++u) {
+            pre[u] = make_uint4(0u, 0u, 0u, 0u);
+            if ((unsigned)(iy0 + ld_row[u]) < (unsigned)IH) pre[u] = *(const uint4*)(base + ld_goff[u]);
+        }
+    };
+    auto stash = [&](int buf) {
+        char* sb = smem + buf * slab_bytes;
+#pragma unroll
+        for (int u = 0; u < MAXLD; ++u)
+            if (ld_row[u] >= 0) {
+                char* d = sb + ld_loff[u];
+                *(uint2*)d = make_uint2(pre[u].x, pre[u].y);
+                *(uint2*)(d + 8) = make_uint2(pre[u].z, pre[u].w);
+            }
+    };
+
+    f32x4 cs[4], cq[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) { cs[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; cq[ct] = cs[ct]; }
+    // position tiles of this wave inside a workgroup tile: q = wave, wave + 4, ... (row q / pt_per_row, columns 16 (q % pt_per_row) ..);
+    // a tile index past the end recomputes tile 0 (branch-free MFMA loop), only its stores / statistics are skipped
+    int boff[NPT], ooff[NPT], orow[NPT];
+    bool inside[NPT];
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        const int q = wave + 4 * j;
+        const int qc = q < sg.ptiles ? q : 0;
+        const int r = qc / pt_per_row, c0 = (qc - r * pt_per_row) * 16;
+        inside[j] = q < sg.ptiles;
+        orow[j] = r;
+        boff[j] = (2 * r) * sg.row_bytes + (c0 + fr + fq) * 16;
+        ooff[j] = ((r * OW) + c0 + fr) * p.Cout + fq * 4;
+    }
+
+    int tile = blockIdx.x, buf = 0;
+    if (tile < sg.ntiles) { fetch(tile); stash(0); }
+    __syncthreads();
+    for (; tile < sg.ntiles; tile += gridDim.x) {
+        const int nxt = tile + gridDim.x;
+        if (nxt < sg.ntiles && !(p.h_abl & 8)) fetch(nxt);                       // in flight under this tile's MFMAs
+        const char* sb = smem + buf * slab_bytes;
+        const int img = tile / sg.tiles_per_img, oh0 = (tile - img * sg.tiles_per_img) * sg.TH;
+        f32x4 acc[NPT][4];
+#pragma unroll
+        for (int j = 0; j < NPT; ++j)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[j][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (!(p.h_abl & 1))
+#pragma unroll
+        for (int kh = 0; kh < KH; ++kh) {
+            v8 b[NPT];
+#pragma unroll
+            for (int j = 0; j < NPT; ++j) b[j] = *(const v8*)(sb + boff[j] + kh * sg.row_bytes);
+#pragma unroll
+            for (int j = 0; j < NPT; ++j)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) acc[j][ct] = MM::mma(wf[kh][ct], b[j], acc[j][ct]);
+        }
+        // epilogue: lane holds output channels 16 ct + 4 fq .. + 3 of position (row r, column c0 + fr): 8-byte stores
+        AT* const obase = (AT*)p.out + ((size_t)img * OH + oh0) * OW * p.Cout;
+#pragma unroll
+        for (int j = 0; j < NPT; ++j) {
+            if (inside[j] && oh0 + orow[j] < OH) {                               // wave-uniform
+                AT* o = obase + ooff[j];
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) {
+                    f32x4 v = acc[j][ct];
+                    if (!(p.h_abl & 4)) Act<AT>::st4(o + ct * 16, make_float4(v[0], v[1], v[2], v[3]));
+                    if (p.stats) {
+                        v[0] = Act<AT>::rnd(v[0]); v[1] = Act<AT>::rnd(v[1]); v[2] = Act<AT>::rnd(v[2]); v[3] = Act<AT>::rnd(v[3]);
+                        cs[ct] += v;
+                        cq[ct] += v * v;
+                    }
+                }
+            }
+        }
+        if (nxt < sg.ntiles) stash(buf ^ 1);
+        __syncthreads();                                                         // next slab visible, this one free
+        buf ^= 1;
+    }
+    if (p.stats) {                                                               // one record per workgroup
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s_ = cs[ct][r], q_ = cq[ct][r];
+                s_ += row_ror<8>(s_); q_ += row_ror<8>(q_);
+                s_ += row_ror<4>(s_); q_ += row_ror<4>(q_);
+                s_ += row_ror<2>(s_); q_ += row_ror<2>(q_);
+                s_ += row_ror<1>(s_); q_ += row_ror<1>(q_);
+                if (fr == 0) {
+                    const int col = ct * 16 + fq * 4 + r;
+                    red[(wave * 64 + col) * 2 + 0] = s_;
+                    red[(wave * 64 + col) * 2 + 1] = q_;
+                }
+            }
+        __syncthreads();
+        if (t < 64) {
+            float s_ = 0.f, q_ = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { s_ += red[(w * 64 + t) * 2]; q_ += red[(w * 64 + t) * 2 + 1]; }
+            p.stats[((size_t)blockIdx.x * 2 + 0) * p.Cout + t] = s_;
+            p.stats[((size_t)blockIdx.x * 2 + 1) * p.Cout + t] = q_;
+        }
+    }
+}
+
 template <typename AT>
 __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const ConvArgs p) {
     __shared__ float red[16][64][2];
@@ -1064,6 +1247,8 @@ struct ConvPlan {
     int bn;               // output-channel tile
     int halo;             // 0, or TM (4 / 2) of conv_halo2d_kernel: 2D 3x3 / 1 / pad 1, 16-bit storage, Cin % 64 == 0, Cout % 64 == 0
     int h_tr, h_rows, h_slab_bytes, h_nr, h_mtiles, h_dbuf;
+    int stem;             // 1: conv_stem_kernel (2D, 4 stored input channels, stride 2, Cout 64, 16-bit storage); records = stem_grid
+    int stem_grid;
     int dma;              // 1: LDS-DMA kernel (16-bit activation storage, Cin % 64 == 0), 64-wide k-steps
     int nunits;           // k-steps (32 wide, or 64 wide for the DMA kernel)
     int ksplit, per_split;
@@ -1112,6 +1297,35 @@ static bool halo_geometry(int B, int H, int W, int cout, int TM, ConvPlan* pl) {
     return true;
 }
 
+static bool stem_disabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("TRICOLO_NO_STEM"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+static bool stem_geometry(int B, int IH, int IW, int cin, int OH, int OW, int cout, int KD, int KH, int KW, int stride, int pd, int ph, int pw,
+                          StemGeom* g) {
+    if (KD != 1 || pd != 0 || cin != 4 || stride != 2 || cout != 64 || (KH != 3 && KH != 5 && KH != 7) || KW > 8 || OW % 16 || IW % 2) return false;
+    if (pw < 0 || ph < 0 || IW + pw > 2 * OW + 6 || (long)B * IH * IW * 8 >= ((long)1 << 31)) return false;
+    const int per_row = OW / 16;
+    static int npt = -1;                                             // position tiles per wave: 2 (two workgroups per CU) unless overridden
+    if (npt < 0) { const char* e = getenv("TRICOLO_STEM_NPT"); npt = (e && atoi(e) == 4) ? 4 : 2; }
+    if (per_row > 4 * npt) return false;
+    int TH = 4 * npt / per_row;                                      // <= 4 * npt position tiles per workgroup tile
+    if (TH > OH) TH = OH;
+    g->npt = npt;
+    g->TH = TH;
+    g->slab_rows = (TH - 1) * 2 + KH;
+    g->row_bytes = (OW + 3) * 16;
+    g->ptiles = TH * per_row;
+    g->tiles_per_img = (OH + TH - 1) / TH;
+    g->ntiles = B * g->tiles_per_img;
+    if (g->slab_rows * (IW / 2) > 256 * 4) return false;             // MAXLD of the kernel
+    if (2 * g->slab_rows * g->row_bytes + 4 * 64 * 2 * 4 > 160 * 1024 / 2) return false;
+    const int slots = num_cus() * (npt == 4 ? 1 : 2);
+    g->grid = g->ntiles < slots ? g->ntiles : slots;
+    return true;
+}
+
 static bool dma_disabled() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("TRICOLO_NO_DMA"); v = (e && e[0] == '1') ? 1 : 0; }
@@ -1130,6 +1344,14 @@ static ConvPlan conv_make_plan(int B, int ID, int IH, int IW, int cin, int OD, i
     int blocks = (int)((M + 127) / 128) * (cout / bn);
     if (split_mode == 2 && cin % 64 == 0 && cout % 64 == 0 && !dma_disabled()) pl.dma = 1;
     pl.bn = bn;
+    {
+        StemGeom sgm;
+        if (split_mode == 2 && !stem_disabled() && ID == 1 && OD == 1 &&
+            stem_geometry(B, IH, IW, cin, OH, OW, cout, KD, KH, KW, stride, pd, ph, pw, &sgm)) {
+            pl.stem = 1; pl.stem_grid = sgm.grid; pl.bn = 64; pl.nunits = KH; pl.ksplit = 1; pl.per_split = KH;
+            return pl;
+        }
+    }
     if (pl.dma && !halo_disabled() && KD == 1 && KH == 3 && KW == 3 && stride == 1 && pd == 0 && ph == 1 && pw == 1 && ID == 1 && OD == 1 &&
         IH == OH && IW == OW && (long)B * IH * IW * cin * 2 < ((long)1 << 31)) {
         // 128-position tiles: a ~25 KB slab + 24 KB ring lets three workgroups share a CU (the kernel is bound by instruction
@@ -1207,6 +1429,34 @@ static int launch_halo(ConvArgs& a, const ConvPlan& pl, hipStream_t stream) {
 }
 
 template <typename AT>
+static int launch_stem(ConvArgs& a, hipStream_t stream) {
+    StemGeom sg;
+    { static int abl = -1; if (abl < 0) { const char* e = getenv("TRICOLO_HALO_ABL"); abl = e ? atoi(e) : 0; } a.h_abl = abl; }
+    if (!stem_geometry(a.B, a.IH, a.IW, a.Cin, a.OH, a.OW, a.Cout, a.KD, a.KH, a.KW, a.stride, a.pd, a.ph, a.pw, &sg)) {
+        tri_set_error("conv(stem): geometry changed between plan and launch"); return TRI_ERR_ARG;
+    }
+    const size_t smem = (size_t)2 * sg.slab_rows * sg.row_bytes + 4 * 64 * 2 * sizeof(float);
+#define TRI_STEM(KH_)                                                                                                     \
+    case KH_: {                                                                                                           \
+        static bool attr = false;                                                                                         \
+        if (!attr) {                                                                                                      \
+            hipFuncSetAttribute((const void*)conv_stem_kernel<KH_, 2, AT>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
+            hipFuncSetAttribute((const void*)conv_stem_kernel<KH_, 4, AT>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
+            attr = true;                                                                                                  \
+        }                                                                                                                 \
+        if (sg.npt == 4) conv_stem_kernel<KH_, 4, AT><<<sg.grid, 256, smem, stream>>>(a, sg);                             \
+        else conv_stem_kernel<KH_, 2, AT><<<sg.grid, 256, smem, stream>>>(a, sg);                                         \
+        break;                                                                                                            \
+    }
+    switch (a.KH) {
+        TRI_STEM(7) TRI_STEM(3) TRI_STEM(5)
+        default: tri_set_error("conv(stem): kernel height not instantiated (3, 5, 7)"); return TRI_ERR_UNSUPPORTED;
+    }
+#undef TRI_STEM
+    return tri_check_launch("tri_conv(stem)");
+}
+
+template <typename AT>
 static int launch_dma_any(const ConvArgs& a, int bn, hipStream_t stream) {
     if (dma_stages() == 2) return bn == 128 ? launch_dma<128, 2, AT>(a, stream) : launch_dma<64, 2, AT>(a, stream);
     return bn == 128 ? launch_dma<128, 3, AT>(a, stream) : launch_dma<64, 3, AT>(a, stream);
@@ -1250,6 +1500,10 @@ static int conv_dispatch(ConvArgs& a, int act_fmt, void* workspace, size_t works
     } else if (a.row_pos && !(pl.dma && pl.ksplit == 1 && !a.row_mask && !a.stats && a.Kpad / 64 <= 128)) {
         a.row_pos = nullptr;          // a pure visiting-order hint: honoured by the DMA kernel without split-K, dropped elsewhere
     }
+    if (pl.stem && !a.transposed && !a.row_mask && !a.row_count && !a.bias && a.act == 0 && !a.accumulate) {
+        a.row_pos = nullptr;
+        return act_fmt == TRI_FMT_F16 ? launch_stem<f16_t>(a, stream) : launch_stem<bf16_t>(a, stream);
+    }
     if (pl.halo && !a.row_mask && !a.row_count && !a.bias && a.act == 0) {
         a.row_pos = nullptr;
         return act_fmt == TRI_FMT_F16 ? launch_halo<2, f16_t>(a, pl, stream) : launch_halo<2, bf16_t>(a, pl, stream);
@@ -1274,6 +1528,7 @@ extern "C" int tri_conv_num_mtiles(const TriConvDesc* d, int split3) {
     long M = (long)d->B * d->OD * d->OH * d->OW;
     ConvPlan pl = conv_make_plan(d->B, d->ID, d->IH, d->IW, d->Cin, d->OD, d->OH, d->OW, d->Cout, d->KD, d->KH, d->KW, d->stride, d->pad_d,
                                  d->pad_h, d->pad_w, split3);
+    if (pl.stem) return pl.stem_grid;
     if (pl.halo) return pl.h_mtiles;
     return pl.ksplit > 1 ? (int)((M + 31) / 32) : (int)((M + 127) / 128);
 }
@@ -1284,6 +1539,7 @@ extern "C" int tri_conv_kernel_family(const TriConvDesc* d, int transposed, int 
                                               d->pad_d, d->pad_h, d->pad_w, split3)
                              : conv_make_plan(d->B, d->ID, d->IH, d->IW, d->Cin, d->OD, d->OH, d->OW, d->Cout, d->KD, d->KH, d->KW, d->stride,
                                               d->pad_d, d->pad_h, d->pad_w, split3);
+    if (pl.stem && !transposed) return 4 | (64 << 8);
     if (pl.halo) return 3 | (pl.halo << 8);
     return (pl.dma ? 2 : 0) | (pl.bn << 8) | ((pl.ksplit > 1 || (pl.dma && tri_conv_kpad(d->KD * d->KH * d->KW, transposed ? d->Cout : d->Cin) / 64 > 128)) ? (1 << 16) : 0);
 }

@@ -79,6 +79,8 @@ def _igemm_symbol(g, transposed, split, t):
     h16 = t.dtype != torch.float32
     code = g.kernel_family[(transposed, 1 if split else (2 if h16 else 0))]
     fam, bn = code & 255, (code >> 8) & 255
+    if fam == 4:
+        return f"conv_stem_kernel<{g.kernel[1]}, {_TNAME[t.dtype]}>"
     if fam == 3:
         return f"conv_halo2d_kernel<{bn}, {_TNAME[t.dtype]}>"
     if fam == 2:
