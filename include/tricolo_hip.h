@@ -136,7 +136,7 @@ typedef struct TriWgradReduce {
     long s_co, s_tap, s_ci;
     int splits, Cout, Kpad, ntaps, cin_stored, cin_real, zlanes, nblocks;
     float out_scale;
-    int reserved;
+    int kw_real;                       /* 0, or (stem kernel's slabs: kernel rows padded to 8 taps) the real kernel width */
 } TriWgradReduce;
 int tri_conv_wgrad_partial(const TriConvDesc* d, const void* in, const void* dout, const uint8_t* row_mask, const void* plan /* required */,
                            void* workspace, size_t workspace_bytes, float* dw, long s_co, long s_tap, long s_ci, int cin_real, int split3,

@@ -1279,6 +1279,8 @@ static int num_cus() {
     return v;
 }
 
+int tri_internal_num_cus() { return num_cus(); }                     // for conv_wgrad.hip (not part of the C ABI header)
+
 // geometry of conv_halo2d_kernel for row tiles of 64 * TM positions; false when the layer does not fit
 static bool halo_geometry(int B, int H, int W, int cout, int TM, ConvPlan* pl) {
     const int BM = 64 * TM, P = W + 2;

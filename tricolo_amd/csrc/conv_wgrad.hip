@@ -501,6 +501,133 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs p) 
         }
 }
 
+// ================================================================================================ stem weight gradient
+// Weight gradient of a 2D convolution with 4 stored input channels and stride 2 (conv1 of the ResNet trunk, mv_cnn.py:44):
+//   dW[co][kh][kw][ci] = sum_pos dOut[pos][co] * In[2 oh - pad + kh][2 ow - pad + kw][ci]
+// Through conv_wgrad_kernel the im2col operand is an 8-byte gather per (position, tap): 61-85 us at the bench shape for 20 GFLOP.
+// As in conv_stem_kernel (conv_igemm.hip) one kernel ROW (kw = 0..7, ci = 0..3) is one 32-wide slice of K: the input rows of a
+// tile of two output rows are staged once in an LDS slab (8 B per pixel, borders zero), the dOut tile next to it in the natural
+// [position][channel] layout, and BOTH MFMA operands are read transposed with ds_read_b64_tr_b16 (positions are the contraction
+// index): the A fragment from the dOut tile as in the kernels above, the B fragment straight from the slab - row = position ow
+// (16 B apart at stride 2), 16 columns = 4 pixels x 4 channels starting at pixel 2 ow + 4 nt.  The 2 KH (kernel row, pixel quad)
+// slices are dealt to the four waves; a persistent workgroup keeps its 64 x KH x 32 partial sums in registers over all its tiles and
+// writes ONE fp32 slab, which tri_wgrad_reduce_grouped sums (kw padded to 8: TriWgradReduce.kw_real).
+struct StemWgradArgs {
+    const void* in; const void* dout; float* slab;
+    int B, IH, IW, OH, OW, KW, ph, pw;
+    int TH, slab_rows, row_bytes, groups, tiles_per_img, ntiles, h_abl;
+};
+#define STEM_WG_MAXG 8                                             // 32-position groups per tile (2 rows of <= 128 outputs)
+template <int KH, typename AT>
+__global__ __launch_bounds__(256, 2) void conv_stem_wgrad_kernel(const StemWgradArgs p) {
+    typedef Mma<typename OpOf<AT>::E> MM;
+    typedef typename MM::v8 v8;
+    constexpr int NPAIR = 2 * KH;                                  // (kernel row, pixel quad) slices of K, 16 columns each
+    constexpr int PPW = (NPAIR + 3) / 4;                           // slices per wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int fr = lane & 15, fg = lane >> 4, fqq = fr >> 2, fp = fr & 3;
+    const int OW = p.OW, OH = p.OH, IW = p.IW, IH = p.IH;
+    const int npos = p.TH * OW;                                    // positions per tile (multiple of 32)
+    char* const ytile = smem;                                      // [npos][64] 16-bit, nat_off<128> per 32-row group
+    char* const slab = smem + (size_t)npos * 128;
+    const int slab_bytes = p.slab_rows * p.row_bytes;
+
+    // slab byte offset of this lane's two position rows (8 fg + fqq, + 4) in every 32-position group, pixel quarter fp included
+    int poff[STEM_WG_MAXG][2];
+#pragma unroll
+    for (int g = 0; g < STEM_WG_MAXG; ++g)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int pos = g * 32 + 8 * fg + 4 * h + fqq;
+            const int r = pos / OW, ow = pos - r * OW;
+            poff[g][h] = (2 * r) * p.row_bytes + (2 * ow + fp) * 8;
+        }
+    // loads of a tile: dOut rows (16 B pieces) and slab pixel pairs; which piece a thread moves never changes
+    constexpr int YLD = STEM_WG_MAXG * 32 * 8 / 256, XLD = 4;      // per-thread maxima
+    const int ld_per_row = IW >> 1, nxl = p.slab_rows * ld_per_row;
+    int x_row[XLD], x_goff[XLD], x_loff[XLD];
+#pragma unroll
+    for (int u = 0; u < XLD; ++u) {
+        const int e = t + u * 256;
+        const int srow = e / ld_per_row, xp = e - srow * ld_per_row;
+        x_row[u] = e < nxl ? srow : -(1 << 20);
+        x_goff[u] = (srow * IW + 2 * xp) * 8;
+        x_loff[u] = srow * p.row_bytes + (2 * xp + p.pw) * 8;
+    }
+    for (int i = t * 16; i < slab_bytes; i += 256 * 16) *(uint4*)(slab + i) = make_uint4(0u, 0u, 0u, 0u);   // border chunks stay zero
+
+    f32x4 acc[PPW][4];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[j][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        const int img = tile / p.tiles_per_img, oh0 = (tile - img * p.tiles_per_img) * p.TH;
+        __syncthreads();                                           // the previous tile's reads (and the zero fill) are done
+        {   // dOut tile: position row e / 8, 16-byte piece e % 8
+            const char* ysrc = (const char*)p.dout + ((size_t)img * OH + oh0) * OW * 128;
+            const int live = min(p.TH, OH - oh0) * OW;             // rows past the image: zeros
+#pragma unroll
+            for (int u = 0; u < YLD; ++u) {
+                const int e = t + u * 256;
+                const int row = e >> 3, piece = e & 7;
+                if (row < npos) {
+                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                    if (row < live) v = *(const uint4*)(ysrc + (size_t)row * 128 + piece * 16);
+                    *(uint4*)(ytile + (row >> 5) * 4096 + nat_off<128>(row & 31, piece * 16)) = v;
+                }
+            }
+            const int iy0 = oh0 * 2 - p.ph;
+            const char* xsrc = (const char*)p.in + ((size_t)img * IH + iy0) * IW * 8;
+#pragma unroll
+            for (int u = 0; u < XLD; ++u)
+                if (x_row[u] >= 0) {
+                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                    if ((unsigned)(iy0 + x_row[u]) < (unsigned)IH) v = *(const uint4*)(xsrc + x_goff[u]);
+                    *(uint2*)(slab + x_loff[u]) = make_uint2(v.x, v.y);
+                    *(uint2*)(slab + x_loff[u] + 8) = make_uint2(v.z, v.w);
+                }
+        }
+        __syncthreads();
+        if (p.h_abl & 1) continue;
+#pragma unroll
+        for (int g = 0; g < STEM_WG_MAXG; ++g) {
+            if (g >= p.groups) break;
+            v8 af[4];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) af[ct] = tr_frag<128, v8>(ytile + g * 4096, ct * 16, fg, fqq, fp);
+#pragma unroll
+            for (int j = 0; j < PPW; ++j) {
+                const int pair = wave + 4 * j;                     // wave-uniform
+                if (pair < NPAIR) {
+                    const int kh = pair >> 1, nt = pair & 1;
+                    const int o = kh * p.row_bytes + nt * 32;
+                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(slab + poff[g][0] + o));
+                    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(slab + poff[g][1] + o));
+                    typedef short s16x8 __attribute__((ext_vector_type(8)));
+                    const s16x8 rr = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    const v8 bf = __builtin_bit_cast(v8, rr);
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) acc[j][ct] = MM::mma(af[ct], bf, acc[j][ct]);
+                }
+            }
+        }
+    }
+    // one slab per workgroup: [64][KH * 32], column kh * 32 + nt * 16 + fr = (kh, kw = 4 nt + fr / 4, ci = fr % 4)
+    float* out = p.slab + (size_t)blockIdx.x * 64 * (KH * 32);
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int pair = wave + 4 * j;
+        if (pair < NPAIR)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[(size_t)(ct * 16 + fg * 4 + r) * (KH * 32) + pair * 16 + fr] = acc[j][ct][r];
+    }
+}
+
 // dw[co*s_co + tap*s_tap + ci*s_ci] = sum_split slab[split][co][tap*cin_stored + ci]   (ci < cin_real)
 // Each thread owns 4 consecutive k (one 16-byte load per split) of one co; a block is (256 / zlanes) such quads x zlanes
 // split lanes: lane z sums splits z, z + zlanes, ... and lane 0 adds the partials in a fixed order (bitwise
@@ -508,7 +635,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs p) 
 // and a tiny dW (stem, voxel level 0) still put a few hundred thousand loads in flight.
 __device__ __forceinline__ void wgrad_reduce_block(const float* __restrict__ slab, int splits, int Cout, int Kpad, int ntaps, int cin_stored,
                                                    int cin_real, float* __restrict__ dw, long s_co, long s_tap, long s_ci, int zlanes,
-                                                   float out_scale, unsigned block, float4* part) {
+                                                   float out_scale, unsigned block, float4* part, int kw_real = 0) {
     const int kq = 256 / zlanes;                                 // quads per block
     const int ql = threadIdx.x % kq, zl = threadIdx.x / kq;
     const int K4 = (ntaps * cin_stored) >> 2;
@@ -533,7 +660,13 @@ __device__ __forceinline__ void wgrad_reduce_block(const float* __restrict__ sla
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
         s.x *= out_scale; s.y *= out_scale; s.z *= out_scale; s.w *= out_scale;
-        const int tap = k / cin_stored, ci = k - tap * cin_stored;   // cin_stored % 4 == 0: the quad stays inside one tap
+        int tap = k / cin_stored;
+        const int ci = k - tap * cin_stored;                         // cin_stored % 4 == 0: the quad stays inside one tap
+        if (kw_real) {                                               // stem slabs: kernel rows padded to 8 taps (conv_stem_wgrad_kernel)
+            const int kh = tap >> 3, kw = tap & 7;
+            if (kw >= kw_real) return;
+            tap = kh * kw_real + kw;
+        }
         float* d = dw + co * s_co + tap * s_tap + ci * s_ci;
         if (s_ci == 1 && cin_real == cin_stored && (((uintptr_t)d) & 15) == 0) *(float4*)d = s;
         else {
@@ -563,7 +696,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_grouped_kernel(const WgradGr
     while (i + 1 < n && (int)blockIdx.x >= g.first_block[i + 1]) ++i;
     const TriWgradReduce& r = g.d[i];
     wgrad_reduce_block(r.slab, r.splits, r.Cout, r.Kpad, r.ntaps, r.cin_stored, r.cin_real, r.dw, r.s_co, r.s_tap, r.s_ci, r.zlanes,
-                       r.out_scale, blockIdx.x - g.first_block[i], part);
+                       r.out_scale, blockIdx.x - g.first_block[i], part, r.kw_real);
 }
 
 static int ilog2_exact(int v) {
@@ -665,8 +798,40 @@ static void wgrad_plan(const TriConvDesc* d, int act_fmt, int rowlist, int* BI, 
     *splits = (steps + *steps_per_split - 1) / *steps_per_split;
 }
 
+int tri_internal_num_cus();                                         // conv_igemm.hip
+static bool stem_wgrad_disabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("TRICOLO_NO_STEM_WGRAD"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+// geometry of conv_stem_wgrad_kernel; false when the layer does not qualify (it then runs conv_wgrad_kernel)
+static bool stem_wgrad_geometry(const TriConvDesc* d, int act_fmt, StemWgradArgs* g, int* grid) {
+    if (!act_fmt || stem_wgrad_disabled()) return false;
+    if (d->KD != 1 || d->ID != 1 || d->pad_d != 0 || d->Cin != 4 || d->stride != 2 || d->Cout != 64) return false;
+    if ((d->KH != 3 && d->KH != 5 && d->KH != 7) || d->KW > 8 || d->OW % 16 || d->IW % 2 || d->OW > 128) return false;
+    if (d->pad_w < 0 || d->pad_h < 0 || d->IW + d->pad_w > 2 * d->OW + 6) return false;
+    if ((long)d->B * d->IH * d->IW * 8 >= ((long)1 << 31) || (long)d->B * d->OH * d->OW * 128 >= ((long)1 << 31)) return false;
+    int TH = d->OH >= 2 ? 2 : 1;
+    if ((TH * d->OW) % 32) return false;
+    g->B = d->B; g->IH = d->IH; g->IW = d->IW; g->OH = d->OH; g->OW = d->OW; g->KW = d->KW; g->ph = d->pad_h; g->pw = d->pad_w;
+    g->TH = TH;
+    g->slab_rows = (TH - 1) * 2 + d->KH;
+    g->row_bytes = (d->OW + 3) * 16;
+    g->groups = TH * d->OW / 32;
+    g->tiles_per_img = (d->OH + TH - 1) / TH;
+    g->ntiles = d->B * g->tiles_per_img;
+    if (g->groups > STEM_WG_MAXG || g->slab_rows * (d->IW / 2) > 256 * 4) return false;
+    const int slots = tri_internal_num_cus() * 2;
+    *grid = g->ntiles < slots ? g->ntiles : slots;
+    return true;
+}
+
 extern "C" size_t tri_conv_wgrad_workspace(const TriConvDesc* d) {
     size_t need = 0;
+    {
+        StemWgradArgs sg; int grid;
+        if (stem_wgrad_geometry(d, 1, &sg, &grid)) need = (size_t)grid * 64 * d->KH * 32 * sizeof(float);
+    }
     for (int mode = 0; mode < 4; ++mode) {                        // fp32 / 16-bit storage x position range / row list
         int BI, BJ, tiles, splits, sps, Kpad, dma;
         wgrad_plan(d, mode & 1, mode >> 1, &BI, &BJ, &tiles, &splits, &sps, &Kpad, &dma);
@@ -720,6 +885,44 @@ extern "C" int tri_conv_wgrad_partial(const TriConvDesc* d, const void* in, cons
                                       TriWgradReduce* pending, void* stream) {
     if (!pending) { tri_set_error("wgrad: pending descriptor is NULL"); return TRI_ERR_ARG; }
     if ((row_pos == nullptr) != (row_count == nullptr)) { tri_set_error("wgrad: row_pos and row_count go together"); return TRI_ERR_ARG; }
+    pending->kw_real = 0;
+    {
+        StemWgradArgs sg; int grid;
+        if (!row_mask && !row_count && !split3 && stem_wgrad_geometry(d, act_fmt, &sg, &grid)) {
+            const size_t need = (size_t)grid * 64 * d->KH * 32 * sizeof(float);
+            if (workspace_bytes < need) { tri_set_error("wgrad(stem): workspace too small"); return TRI_ERR_ARG; }
+            sg.in = in; sg.dout = dout; sg.slab = (float*)workspace;
+            { static int abl = -1; if (abl < 0) { const char* e = getenv("TRICOLO_HALO_ABL"); abl = e ? atoi(e) : 0; } sg.h_abl = abl; }
+            const size_t smem = (size_t)sg.TH * sg.OW * 128 + (size_t)sg.slab_rows * sg.row_bytes;
+            hipStream_t st = (hipStream_t)stream;
+#define TRI_SWG(KH_)                                                                                                           \
+    case KH_: {                                                                                                                \
+        static bool attr = false;                                                                                              \
+        if (!attr) {                                                                                                           \
+            hipFuncSetAttribute((const void*)conv_stem_wgrad_kernel<KH_, f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);  \
+            hipFuncSetAttribute((const void*)conv_stem_wgrad_kernel<KH_, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
+            attr = true;                                                                                                       \
+        }                                                                                                                      \
+        if (act_fmt == TRI_FMT_F16) conv_stem_wgrad_kernel<KH_, f16_t><<<grid, 256, smem, st>>>(sg);                           \
+        else conv_stem_wgrad_kernel<KH_, bf16_t><<<grid, 256, smem, st>>>(sg);                                                 \
+        break;                                                                                                                 \
+    }
+            switch (d->KH) { TRI_SWG(7) TRI_SWG(5) TRI_SWG(3) default: break; }
+#undef TRI_SWG
+            int rc = tri_check_launch("tri_conv_wgrad(stem)");
+            if (rc) return rc;
+            const int ntaps_p = d->KH * 8;
+            const long quads = (long)64 * ntaps_p;
+            int zlanes = 1;
+            while (zlanes < 64 && zlanes * 2 <= grid && quads * zlanes < 262144) zlanes *= 2;
+            const int kq = 256 / zlanes;
+            pending->slab = (const float*)workspace; pending->dw = dw; pending->s_co = s_co; pending->s_tap = s_tap; pending->s_ci = s_ci;
+            pending->splits = grid; pending->Cout = 64; pending->Kpad = d->KH * 32; pending->ntaps = ntaps_p; pending->cin_stored = 4;
+            pending->cin_real = cin_real; pending->zlanes = zlanes; pending->nblocks = (int)((quads + kq - 1) / kq);
+            pending->out_scale = out_scale; pending->kw_real = d->KW;
+            return 0;
+        }
+    }
     if (d->Cin % 4 != 0 || d->Cout % 4 != 0) { tri_set_error("wgrad: channels must be multiples of 4"); return TRI_ERR_ARG; }
     int BI, BJ, tiles, splits, sps, Kpad, dma;
     wgrad_plan(d, act_fmt, row_count != nullptr, &BI, &BJ, &tiles, &splits, &sps, &Kpad, &dma);
@@ -800,6 +1003,7 @@ extern "C" int tri_conv_wgrad(const TriConvDesc* d, const void* in, const void* 
     int rc = tri_conv_wgrad_partial(d, in, dout, row_mask, plan, workspace, workspace_bytes, dw, s_co, s_tap, s_ci, cin_real, split3, act_fmt,
                                     out_scale, row_pos, row_count, &r, stream);
     if (rc) return rc;
+    if (r.kw_real) return tri_wgrad_reduce_grouped(&r, 1, stream);        // (the padded-row mapping lives in the grouped kernel's argument table)
     wgrad_reduce_kernel<<<(unsigned)r.nblocks, 256, 0, (hipStream_t)stream>>>(r.slab, r.splits, r.Cout, r.Kpad, r.ntaps, r.cin_stored, r.cin_real,
                                                                              r.dw, r.s_co, r.s_tap, r.s_ci, r.zlanes, r.out_scale);
     return tri_check_launch("tri_wgrad_reduce");
