@@ -105,26 +105,34 @@ class TriCoLoNet(TriModule):
         if self._side_streams is None:
             self._side_streams = (torch.cuda.Stream(), torch.cuda.Stream())
         s_text, s_vox = self._side_streams
-        # The heaviest tower runs on the caller's stream: the image tower, or - Bi(V) - the voxel tower; the others on side streams.
-        # (Issue order matters under HIP-graph replay: the executor queues a branch issued later behind earlier ones when it folds
-        # them onto one internal stream.  Side towers first: their forward starts at once, their backward - autograd runs the
-        # latest-created node first - is issued after the image tower's and the voxel backward starts ~1.2 ms late; image tower
-        # first: the other way round.  Same step time either way (tools/step_timeline.py, profiles/r2/README.md).)
+        # The heaviest tower runs on the caller's stream: the image tower, or - Bi(V) - the voxel tower; the others on side streams
+        # forked at the start of the step.  ISSUE order matters under HIP-graph replay: the executor folds capture streams onto a
+        # few internal streams and a branch issued later queues behind branches issued earlier - including another tower's side
+        # branches (tools/step_timeline.py shows it).  Image tower first: autograd, which runs the latest-created node first, then
+        # issues the voxel and text backward BEFORE the image tower's and both start right after the loss; the price is a text
+        # forward that starts late (it still ends before the loss needs it, +0.05 ms).  Side towers first ("tvi") starts every forward
+        # at once but queues the voxel backward behind the image tower's down-sample branches: it starts 1.2 ms late and becomes
+        # the last kernel of the step.  Six orders measured: itv 3.34-3.44 ms, tvi 3.42-3.45, vti 3.42, vit 3.49, ivt 3.54, tiv 3.60.
+        # (Issuing the side towers from inside the image tower's forward, right after its stem, was tried too: the text forward
+        # still starts late - the folding is not a pure function of the issue order - and the step time is the same.)
+        order = os.environ.get("TRICOLO_TOWER_ORDER", "itv")               # issue order of the towers: i(mage), t(ext), v(oxel)
         s_text.wait_stream(main)
-        with torch.cuda.stream(s_text):
-            text = self.text_encoder(tokens, data_dict)
-            ops.stamp("text.fwd.end")
-        vox = img = None
-        if self.voxel_encoder is not None:
-            vox_on_main = self.image_encoder is None
-            if not vox_on_main:
-                s_vox.wait_stream(main)
-            with torch.cuda.stream(main if vox_on_main else s_vox):
-                vox = self._gate(self.voxel_encoder(data_dict["voxels"], len(data_dict["model_id"])))
-                ops.stamp("voxel.fwd.end")
-        if self.image_encoder is not None:
-            img = self.image_encoder(data_dict["images"].flatten(end_dim=1), data_dict)
-            ops.stamp("image.fwd.end")
+        vox = img = text = None
+        vox_on_main = self.image_encoder is None
+        if self.voxel_encoder is not None and not vox_on_main:
+            s_vox.wait_stream(main)
+        for which in order:
+            if which == "i" and self.image_encoder is not None:
+                img = self.image_encoder(data_dict["images"].flatten(end_dim=1), data_dict)
+                ops.stamp("image.fwd.end")
+            elif which == "t":
+                with torch.cuda.stream(s_text):
+                    text = self.text_encoder(tokens, data_dict)
+                    ops.stamp("text.fwd.end")
+            elif which == "v" and self.voxel_encoder is not None:
+                with torch.cuda.stream(main if vox_on_main else s_vox):
+                    vox = self._gate(self.voxel_encoder(data_dict["voxels"], len(data_dict["model_id"])))
+                    ops.stamp("voxel.fwd.end")
         main.wait_stream(s_text)
         text.record_stream(main)
         output_dict = {"text_features": text}
