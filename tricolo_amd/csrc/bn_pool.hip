@@ -145,7 +145,13 @@ extern "C" int tri_relu_bwd(const void* dout, const void* out, void* g, long n, 
 // Pass 1: per-block partial sums of g and g*y per channel ([nblk][2][C]); pass 2 (tri_bn_bwd_finalize): dgamma, dbeta
 // and the coefficients of dy = c1*g + c2 + c3*y; pass 3: apply (rows with row_mask == 0 stay zero).
 // rows per block: 256 for large tensors, 64 for small ones (so that a 3,072-row layer still fills 48 CUs)
-static inline int bnb_rows(long M) { return M >= 65536 ? 256 : 64; }
+// ... and at most ~2,048 workgroups (= records for bn_bwd_finalize: a 2.4 M-row layer of the 224^2 configurations had 9,408)
+static inline int bnb_rows(long M) {
+    if (M < 65536) return 64;
+    long rows = (M + 2047) / 2048;
+    rows = (rows + 63) / 64 * 64;
+    return (int)(rows < 256 ? 256 : rows);
+}
 // MASK (compile time - a run-time test inside the row loop cost 1.6-2.5x on every launch): 0 g is final, 1 ReLU mask
 // recomputed from y, 2 ReLU mask from the saved output `ro`
 template <typename T, int MASK, bool ROWMASK>
