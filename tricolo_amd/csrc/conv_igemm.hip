@@ -639,8 +639,45 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs p) {
 #endif
 template <int N>
 __device__ __forceinline__ void wait_vmcnt_c() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-template <int TM, typename AT>
-__global__ __launch_bounds__(256, TM == 2 ? 3 : 1) void conv_halo2d_kernel(const ConvArgs p) {     // three workgroups per CU (<= 170 VGPRs)
+// column sums of the lanes' (cs, cq) -> one [2][64] record: DPP row reduction, cross-wave through LDS
+template <int TN, int BN>
+__device__ __forceinline__ void halo_store_stats(const f32x4* cs, const f32x4* cq, float* red, float* stats, int Cout, int rec, int ntile, int wave,
+                                                 int fr, int fq, int t, bool raw_barrier) {
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float s_ = cs[b][r], q_ = cq[b][r];
+            s_ += row_ror<8>(s_); q_ += row_ror<8>(q_);
+            s_ += row_ror<4>(s_); q_ += row_ror<4>(q_);
+            s_ += row_ror<2>(s_); q_ += row_ror<2>(q_);
+            s_ += row_ror<1>(s_); q_ += row_ror<1>(q_);
+            if (fr == 0) {
+                const int col = b * 16 + fq * 4 + r;
+                red[(wave * BN + col) * 2 + 0] = s_;
+                red[(wave * BN + col) * 2 + 1] = q_;
+            }
+        }
+    if (raw_barrier) {                          // inside the tile loop: LDS-DMA in flight must not be waited for (no vmcnt wait)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    } else {
+        __syncthreads();
+    }
+    if (t < BN) {
+        float s_ = 0.f, q_ = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { s_ += red[(w * BN + t) * 2]; q_ += red[(w * BN + t) * 2 + 1]; }
+        stats[((size_t)rec * 2 + 0) * Cout + ntile * BN + t] = s_;
+        stats[((size_t)rec * 2 + 1) * Cout + ntile * BN + t] = q_;
+        // (per-tile use: the next write to `red` comes after at least nine more barriers)
+    }
+}
+
+// WGREC: BatchNorm records per persistent workgroup (launches with many tiles per workgroup) instead of per tile
+template <int TM, bool WGREC, typename AT>
+__global__ __launch_bounds__(256, WGREC ? 3 : 1) void conv_halo2d_kernel(const ConvArgs p) {     // WGREC: <= 170 VGPRs (three workgroups per CU)
     typedef Mma<typename OpOf<AT>::E> MM;
     typedef typename MM::v8 v8;
     constexpr int BN = 64, TN = 4, WM = 16 * TM, W_BYTES = BN * 128, NR = HALO_NR;
@@ -744,14 +781,19 @@ __global__ __launch_bounds__(256, TM == 2 ? 3 : 1) void conv_halo2d_kernel(const
         for (int d = 0; d < NR - 1; ++d) issue_w();                       // NR - 1 units ahead (a tile has >= 9 units)
     }
     int c_slot = 0;
-    // BatchNorm column sums of every tile this workgroup computes (all of them belong to output-channel tile blockIdx.x % NT: the
-    // grid is a multiple of NT): ONE record per workgroup, written after the tile loop - a 12 x 224^2 batch has 18,816 row tiles
-    // on layer1, whose per-tile records cost bn_finalize 33 us per layer, and every tile paid a cross-wave reduction + barrier
+    // WGREC: BatchNorm column sums of every tile this workgroup computes (all of them belong to output-channel tile blockIdx.x % NT:
+    // the grid is a multiple of NT) in ONE record per workgroup, written after the tile loop - a 12 x 224^2 batch has 18,816 row
+    // tiles on layer1, whose per-tile records cost bn_finalize 33 us per layer.  (Launches with only a few tiles per workgroup keep
+    // per-tile records: carrying the sums across the tile loop cost layer3 / layer4 of the bench shape 4-7 us.)
     f32x4 cs[TN], cq[TN];
 #pragma unroll
     for (int b = 0; b < TN; ++b) { cs[b] = (f32x4){0.f, 0.f, 0.f, 0.f}; cq[b] = cs[b]; }
     for (; item < items; item += G) {
         const int mtile = item / NT, ntile = item - mtile * NT;
+        if (!WGREC) {
+#pragma unroll
+            for (int b = 0; b < TN; ++b) { cs[b] = (f32x4){0.f, 0.f, 0.f, 0.f}; cq[b] = cs[b]; }
+        }
         const int g0 = mtile * TR;
         const int npos = min(TR, NH - g0) * W;
         int pix0[TM], tmul[TM];
@@ -841,34 +883,10 @@ __global__ __launch_bounds__(256, TM == 2 ? 3 : 1) void conv_halo2d_kernel(const
                     }
                 }
             }
+            if (!WGREC && p.stats && !(p.h_abl & 16)) halo_store_stats<TN, BN>(cs, cq, red, p.stats, p.Cout, mtile, ntile, wave, fr, fq, t, true);
         }
     }
-    if (p.stats && !(p.h_abl & 16)) {
-#pragma unroll
-        for (int b = 0; b < TN; ++b)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float s_ = cs[b][r], q_ = cq[b][r];
-                s_ += row_ror<8>(s_); q_ += row_ror<8>(q_);
-                s_ += row_ror<4>(s_); q_ += row_ror<4>(q_);
-                s_ += row_ror<2>(s_); q_ += row_ror<2>(q_);
-                s_ += row_ror<1>(s_); q_ += row_ror<1>(q_);
-                if (fr == 0) {
-                    const int col = b * 16 + fq * 4 + r;
-                    red[(wave * BN + col) * 2 + 0] = s_;
-                    red[(wave * BN + col) * 2 + 1] = q_;
-                }
-            }
-        __syncthreads();
-        if (t < BN) {
-            float s_ = 0.f, q_ = 0.f;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) { s_ += red[(w * BN + t) * 2]; q_ += red[(w * BN + t) * 2 + 1]; }
-            const int rec = blockIdx.x / NT, nt = blockIdx.x - rec * NT;
-            p.stats[((size_t)rec * 2 + 0) * p.Cout + nt * BN + t] = s_;
-            p.stats[((size_t)rec * 2 + 1) * p.Cout + nt * BN + t] = q_;
-        }
-    }
+    if (WGREC && p.stats && !(p.h_abl & 16)) halo_store_stats<TN, BN>(cs, cq, red, p.stats, p.Cout, blockIdx.x / NT, blockIdx.x % NT, wave, fr, fq, t, false);
 }
 
 
@@ -1248,7 +1266,8 @@ struct ConvPlan {
     int bn;               // output-channel tile
     int halo;             // 0, or TM (4 / 2) of conv_halo2d_kernel: 2D 3x3 / 1 / pad 1, 16-bit storage, Cin % 64 == 0, Cout % 64 == 0
     int h_tr, h_rows, h_slab_bytes, h_nr, h_mtiles, h_dbuf;
-    int h_grid;           // persistent workgroups of the halo launch (a multiple of the output-channel tiles); BatchNorm records = h_grid / (Cout / 64)
+    int h_grid;           // persistent workgroups of the halo launch (a multiple of the output-channel tiles)
+    int h_wgrec;          // 1: one BatchNorm record per workgroup (h_grid / (Cout / 64) records), 0: one per row tile (h_mtiles)
     int stem;             // 1: conv_stem_kernel (2D, 4 stored input channels, stride 2, Cout 64, 16-bit storage); records = stem_grid
     int stem_grid;
     int dma;              // 1: LDS-DMA kernel (16-bit activation storage, Cin % 64 == 0), 64-wide k-steps
@@ -1306,6 +1325,7 @@ static bool halo_geometry(int B, int H, int W, int cout, int TM, ConvPlan* pl) {
         int slots = num_cus() * per_cu / NT * NT;
         if (slots < NT) slots = NT;
         pl->h_grid = items < slots ? items : slots;
+        pl->h_wgrec = items >= 4 * slots ? 1 : 0;
     }
     return true;
 }
@@ -1373,7 +1393,7 @@ static ConvPlan conv_make_plan(int B, int ID, int IH, int IW, int cin, int OD, i
         const ConvPlan* pick = halo_geometry(B, IH, IW, cout, 2, &t2) ? &t2 : nullptr;
         if (pick) {
             pl.halo = pick->halo; pl.h_tr = pick->h_tr; pl.h_rows = pick->h_rows; pl.h_slab_bytes = pick->h_slab_bytes;
-            pl.h_nr = pick->h_nr; pl.h_mtiles = pick->h_mtiles; pl.h_dbuf = pick->h_dbuf; pl.h_grid = pick->h_grid;
+            pl.h_nr = pick->h_nr; pl.h_mtiles = pick->h_mtiles; pl.h_dbuf = pick->h_dbuf; pl.h_grid = pick->h_grid; pl.h_wgrec = pick->h_wgrec;
             pl.bn = 64; pl.nunits = 9 * (cin / 64); pl.ksplit = 1; pl.per_split = pl.nunits;
             return pl;
         }
@@ -1431,10 +1451,12 @@ static int launch_halo(ConvArgs& a, const ConvPlan& pl, hipStream_t stream) {
     const size_t smem = (size_t)pl.h_slab_bytes + (size_t)HALO_NR * 8192 + 2048;
     static size_t attr = 0;
     if (smem > attr) {
-        hipFuncSetAttribute((const void*)conv_halo2d_kernel<TM, AT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipFuncSetAttribute((const void*)conv_halo2d_kernel<TM, false, AT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipFuncSetAttribute((const void*)conv_halo2d_kernel<TM, true, AT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr = smem;
     }
-    conv_halo2d_kernel<TM, AT><<<pl.h_grid, 256, smem, stream>>>(a);                                    // persistent workgroups
+    if (pl.h_wgrec && a.stats) conv_halo2d_kernel<TM, true, AT><<<pl.h_grid, 256, smem, stream>>>(a);   // persistent workgroups
+    else conv_halo2d_kernel<TM, false, AT><<<pl.h_grid, 256, smem, stream>>>(a);
     return tri_check_launch("tri_conv(halo)");
 }
 
@@ -1539,7 +1561,7 @@ extern "C" int tri_conv_num_mtiles(const TriConvDesc* d, int split3) {
     ConvPlan pl = conv_make_plan(d->B, d->ID, d->IH, d->IW, d->Cin, d->OD, d->OH, d->OW, d->Cout, d->KD, d->KH, d->KW, d->stride, d->pad_d,
                                  d->pad_h, d->pad_w, split3);
     if (pl.stem) return pl.stem_grid;
-    if (pl.halo) return pl.h_grid / (d->Cout / 64);
+    if (pl.halo) return pl.h_wgrec ? pl.h_grid / (d->Cout / 64) : pl.h_mtiles;
     return pl.ksplit > 1 ? (int)((M + 31) / 32) : (int)((M + 127) / 128);
 }
 

@@ -82,7 +82,7 @@ def _igemm_symbol(g, transposed, split, t):
     if fam == 4:
         return f"conv_stem_kernel<{g.kernel[1]}, {_TNAME[t.dtype]}>"
     if fam == 3:
-        return f"conv_halo2d_kernel<{bn}, {_TNAME[t.dtype]}>"
+        return f"conv_halo2d_kernel<{bn}, {_TNAME[t.dtype]}>"     # (both record variants under one name)
     if fam == 2:
         return f"conv_dma_kernel<{bn}, {3 if os.environ.get('TRICOLO_DMA_STAGES') == '3' else 2}, {_TNAME[t.dtype]}>"
     return f"conv_igemm_kernel<{bn}, {2 if split else 1}, {_TNAME[t.dtype]}>"
