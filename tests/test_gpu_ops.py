@@ -631,6 +631,10 @@ BF16_CASES = [c for c in CONV_CASES if c[0] in ("vox_l0", "vox_l1", "vox_l3", "s
     # conv_stem_kernel (4 stored input channels, stride 2, 64 output channels): stem7x7 above (32 x 32 -> 16 x 16, one tile per
     # image) and: several tiles per image with a partial last one (OH = 24, TH = 8), 3x3 and 5x5 kernels, a persistent workgroup
     # that walks many tiles (more tiles than CUs), 112-wide output rows (7 position tiles per row, TH = 2)
+    # conv_wgrad_c64_kernel (64 -> 64 channels, 3x3 / 1, >= 6 row tiles per CU): 8 rows of 32 per tile, and 4 rows of 56 (7 position
+    # groups per tile, groups straddling image rows)
+    ("c64_32", 390, (1, 32, 32), 64, 64, (1, 3, 3), 1, (0, 1, 1), "torch"),
+    ("c64_56", 112, (1, 56, 56), 64, 64, (1, 3, 3), 1, (0, 1, 1), "torch"),
     ("stem_48", 2, (1, 48, 32), 3, 64, (1, 7, 7), 2, (0, 3, 3), "torch"),
     ("stem_3x3", 3, (1, 32, 64), 3, 64, (1, 3, 3), 2, (0, 1, 1), "torch"),
     ("stem_5x5", 2, (1, 20, 32), 3, 64, (1, 5, 5), 2, (0, 2, 2), "torch"),

@@ -628,6 +628,114 @@ __global__ __launch_bounds__(256, 2) void conv_stem_wgrad_kernel(const StemWgrad
     }
 }
 
+// ================================================================================================ 64 -> 64 channel 3x3 weight gradient
+// layer1 of the ResNet trunk (four 3x3 / 1 / pad 1 convolutions 64 -> 64, mv_cnn.py:44) has the most positions per weight of the
+// trunk and the smallest dW (64 x 576): through conv_wgrad_dma_kernel<64,128> its K = 576 is cut into 4.5 column tiles, each
+// re-reading the dOut tile and re-gathering its taps (39 us a layer at the bench shape, 525 us at 12 x 224^2).  Here, as in the
+// stem kernel above, a tile of TR whole image rows is staged ONCE - the input rows with a one-pixel halo in an LDS slab, the dOut
+// rows next to it - and ALL nine taps are formed from the slab: tap (ky, kx), channel quarter cq is the B fragment read (transposed,
+// ds_read_b64_tr_b16) at pixel (r + ky, x + kx), bytes 32 cq .. of its 128-byte channel row.  The 36 (tap, quarter) column tiles are
+// dealt to the four waves (9 each x 4 output-channel tiles = 144 accumulator registers); per 32 positions a wave issues 26
+// transposed reads for 36 MFMAs.  A persistent workgroup keeps its partial dW over all its tiles and writes ONE [64][576] fp32 slab
+// (standard k order: tri_wgrad_reduce_grouped sums them).
+// Slab: pixel (slab row s, column c) at ((s * (W + 2) + c) * 128) bytes, its four 32-byte channel quarters XOR-swizzled by
+// (pixel & 3) so that the four position rows of a transposed read hit different banks.
+struct C64WgradArgs {
+    const void* in; const void* dout; float* slab;
+    int B, H, W, TR, groups, tiles_per_img, ntiles, h_abl;
+};
+#define C64_MAXG 8                                                 // 32-position groups per tile (<= 256 positions)
+template <typename AT>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_c64_kernel(const C64WgradArgs p) {
+    typedef Mma<typename OpOf<AT>::E> MM;
+    typedef typename MM::v8 v8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int fr = lane & 15, fg = lane >> 4, fqq = fr >> 2, fp = fr & 3;
+    const int W = p.W, H = p.H, P = W + 2, TR = p.TR;
+    const int npos = TR * W;
+    char* const ytile = smem;                                      // [npos][64] 16-bit, nat_off<128> per 32-row group
+    char* const slab = smem + (size_t)npos * 128;
+    const int slab_px = (TR + 2) * P;
+
+    // transposed-read rows of this lane in group 0: (row, column) of positions 8 fg + fqq and + 4; advanced by 32 positions per group
+    int r0[2], x0[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int pos = 8 * fg + 4 * h + fqq;
+        r0[h] = pos / W; x0[h] = pos - r0[h] * W;
+    }
+    for (int i = t * 16; i < slab_px * 128; i += 256 * 16) *(uint4*)(slab + i) = make_uint4(0u, 0u, 0u, 0u);   // left / right halo stays zero
+
+    f32x4 acc[9][4];
+#pragma unroll
+    for (int j = 0; j < 9; ++j)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[j][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        const int img = tile / p.tiles_per_img, h0 = (tile - img * p.tiles_per_img) * TR;
+        __syncthreads();                                           // the previous tile's reads (and the zero fill) are done
+        {   // dOut tile: position row e / 8, 16-byte piece e % 8
+            const char* ysrc = (const char*)p.dout + ((size_t)img * H + h0) * W * 128;
+            for (int e = t; e < npos * 8; e += 256) {
+                const int row = e >> 3, piece = e & 7;
+                *(uint4*)(ytile + (row >> 5) * 4096 + nat_off<128>(row & 31, piece * 16)) = *(const uint4*)(ysrc + (size_t)row * 128 + piece * 16);
+            }
+            // slab rows h0 - 1 .. h0 + TR (zeros outside the image), columns 1 .. W
+            const char* xsrc = (const char*)p.in + (size_t)img * H * W * 128;
+            const int nchunk = (TR + 2) * W * 8;
+            for (int e = t; e < nchunk; e += 256) {
+                const int piece = e & 7, px = e >> 3;
+                const int srow = px / W, x = px - srow * W;
+                const int iy = h0 - 1 + srow;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if ((unsigned)iy < (unsigned)H) v = *(const uint4*)(xsrc + ((size_t)iy * W + x) * 128 + piece * 16);
+                const int pix = srow * P + x + 1;
+                *(uint4*)(slab + pix * 128 + ((((piece >> 1) ^ (pix & 3)) << 5) | ((piece & 1) << 4))) = v;
+            }
+        }
+        __syncthreads();
+        if (p.h_abl & 1) continue;
+        int rr0 = r0[0], xx0 = x0[0], rr1 = r0[1], xx1 = x0[1];
+#pragma unroll 1
+        for (int g = 0; g < p.groups; ++g) {
+            v8 af[4];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) af[ct] = tr_frag<128, v8>(ytile + g * 4096, ct * 16, fg, fqq, fp);
+            const int pc0 = rr0 * P + xx0, pc1 = rr1 * P + xx1;    // slab pixel of tap (0, 0) for the two position rows
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const int nt = wave + 4 * j;                       // column tile 0..35 = (tap, channel quarter), wave-uniform
+                const int tap = nt >> 2, cq = nt & 3;
+                const int ky = tap / 3, kx = tap - ky * 3;
+                const int toff = ky * P + kx;
+                const int p0 = pc0 + toff, p1 = pc1 + toff;
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(slab + p0 * 128 + ((cq ^ (p0 & 3)) << 5) + fp * 8));
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(slab + p1 * 128 + ((cq ^ (p1 & 3)) << 5) + fp * 8));
+                typedef short s16x8 __attribute__((ext_vector_type(8)));
+                const s16x8 rr = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const v8 bf = __builtin_bit_cast(v8, rr);
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) acc[j][ct] = MM::mma(af[ct], bf, acc[j][ct]);
+            }
+            xx0 += 32; while (xx0 >= W) { xx0 -= W; ++rr0; }
+            xx1 += 32; while (xx1 >= W) { xx1 -= W; ++rr1; }
+        }
+    }
+    // one slab per workgroup: [64][576], column k = tap * 64 + cq * 16 + fr
+    float* out = p.slab + (size_t)blockIdx.x * 64 * 576;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const int nt = wave + 4 * j;
+        const int k0 = (nt >> 2) * 64 + (nt & 3) * 16;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(size_t)(ct * 16 + fg * 4 + r) * 576 + k0 + fr] = acc[j][ct][r];
+    }
+}
+
 // dw[co*s_co + tap*s_tap + ci*s_ci] = sum_split slab[split][co][tap*cin_stored + ci]   (ci < cin_real)
 // Each thread owns 4 consecutive k (one 16-byte load per split) of one co; a block is (256 / zlanes) such quads x zlanes
 // split lanes: lane z sums splits z, z + zlanes, ... and lane 0 adds the partials in a fixed order (bitwise
@@ -826,11 +934,44 @@ static bool stem_wgrad_geometry(const TriConvDesc* d, int act_fmt, StemWgradArgs
     return true;
 }
 
+static bool c64_wgrad_disabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("TRICOLO_NO_C64_WGRAD"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+// geometry of conv_wgrad_c64_kernel; false when the layer does not qualify
+static bool c64_wgrad_geometry(const TriConvDesc* d, int act_fmt, C64WgradArgs* g, int* grid) {
+    if (!act_fmt || c64_wgrad_disabled()) return false;
+    if (d->KD != 1 || d->ID != 1 || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad_d != 0 || d->pad_h != 1 || d->pad_w != 1) return false;
+    if (d->Cin != 64 || d->Cout != 64 || d->OH != d->IH || d->OW != d->IW) return false;
+    if ((long)d->B * d->IH * d->IW * 128 >= ((long)1 << 31)) return false;
+    const int H = d->IH, W = d->IW;
+    int TR = 0;
+    for (int tr = 1; tr <= H; ++tr)                                  // most positions per tile: whole rows of one image, multiple of 32, <= 256
+        if (H % tr == 0 && (tr * W) % 32 == 0 && tr * W <= 32 * C64_MAXG) TR = tr;
+    if (!TR) return false;
+    if ((size_t)TR * W * 128 + (size_t)(TR + 2) * (W + 2) * 128 > 78 * 1024) return false;      // two workgroups per CU
+    g->B = d->B; g->H = H; g->W = W; g->TR = TR; g->groups = TR * W / 32;
+    g->tiles_per_img = H / TR; g->ntiles = d->B * g->tiles_per_img;
+    // 256-512 per-workgroup slabs of 147 KB: pays from ~6 row tiles per CU on (measured: per-GPU batch 64 of 6 x 128^2 5.03 -> 4.87 ms,
+    // 12 x 224^2 25.3 -> 24.6 ms; the bench shape's 3 tiles per CU 3.41 -> 3.44-3.48 ms, so it keeps conv_wgrad_dma_kernel)
+    static int min_per_cu = -1;
+    if (min_per_cu < 0) { const char* e = getenv("TRICOLO_C64_MIN_TILES_PER_CU"); min_per_cu = e ? atoi(e) : 6; }
+    if (g->ntiles < min_per_cu * tri_internal_num_cus()) return false;
+    static int per_cu = -1;
+    if (per_cu < 0) { const char* e = getenv("TRICOLO_C64_WGS_PER_CU"); per_cu = e ? atoi(e) : 2; }
+    *grid = tri_internal_num_cus() * (per_cu < 1 ? 1 : per_cu);
+    if (*grid > g->ntiles) *grid = g->ntiles;
+    return true;
+}
+
 extern "C" size_t tri_conv_wgrad_workspace(const TriConvDesc* d) {
     size_t need = 0;
     {
         StemWgradArgs sg; int grid;
         if (stem_wgrad_geometry(d, 1, &sg, &grid)) need = (size_t)grid * 64 * d->KH * 32 * sizeof(float);
+        C64WgradArgs cg;
+        if (c64_wgrad_geometry(d, 1, &cg, &grid)) need = (size_t)grid * 64 * 576 * sizeof(float);
     }
     for (int mode = 0; mode < 4; ++mode) {                        // fp32 / 16-bit storage x position range / row list
         int BI, BJ, tiles, splits, sps, Kpad, dma;
@@ -886,6 +1027,35 @@ extern "C" int tri_conv_wgrad_partial(const TriConvDesc* d, const void* in, cons
     if (!pending) { tri_set_error("wgrad: pending descriptor is NULL"); return TRI_ERR_ARG; }
     if ((row_pos == nullptr) != (row_count == nullptr)) { tri_set_error("wgrad: row_pos and row_count go together"); return TRI_ERR_ARG; }
     pending->kw_real = 0;
+    {
+        C64WgradArgs cg; int grid;
+        if (!row_mask && !row_count && !split3 && c64_wgrad_geometry(d, act_fmt, &cg, &grid)) {
+            const size_t need = (size_t)grid * 64 * 576 * sizeof(float);
+            if (workspace_bytes < need) { tri_set_error("wgrad(c64): workspace too small"); return TRI_ERR_ARG; }
+            cg.in = in; cg.dout = dout; cg.slab = (float*)workspace;
+            { static int abl = -1; if (abl < 0) { const char* e = getenv("TRICOLO_HALO_ABL"); abl = e ? atoi(e) : 0; } cg.h_abl = abl; }
+            const size_t smem = (size_t)cg.TR * cg.W * 128 + (size_t)(cg.TR + 2) * (cg.W + 2) * 128;
+            static bool attr = false;
+            if (!attr) {
+                hipFuncSetAttribute((const void*)conv_wgrad_c64_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+                hipFuncSetAttribute((const void*)conv_wgrad_c64_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+                attr = true;
+            }
+            if (act_fmt == TRI_FMT_F16) conv_wgrad_c64_kernel<f16_t><<<grid, 256, smem, (hipStream_t)stream>>>(cg);
+            else conv_wgrad_c64_kernel<bf16_t><<<grid, 256, smem, (hipStream_t)stream>>>(cg);
+            int rc = tri_check_launch("tri_conv_wgrad(c64)");
+            if (rc) return rc;
+            const long quads = (long)64 * 144;
+            int zlanes = 1;
+            while (zlanes < 64 && zlanes * 2 <= grid && quads * zlanes < 262144) zlanes *= 2;
+            const int kq = 256 / zlanes;
+            pending->slab = (const float*)workspace; pending->dw = dw; pending->s_co = s_co; pending->s_tap = s_tap; pending->s_ci = s_ci;
+            pending->splits = grid; pending->Cout = 64; pending->Kpad = 576; pending->ntaps = 9; pending->cin_stored = 64;
+            pending->cin_real = cin_real; pending->zlanes = zlanes; pending->nblocks = (int)((quads + kq - 1) / kq);
+            pending->out_scale = out_scale;
+            return 0;
+        }
+    }
     {
         StemWgradArgs sg; int grid;
         if (!row_mask && !row_count && !split3 && stem_wgrad_geometry(d, act_fmt, &sg, &grid)) {
