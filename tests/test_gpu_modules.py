@@ -110,6 +110,46 @@ def test_clip_text_matches_reference(golden):
         m(batch["tokens"], {})
 
 
+def test_clip_text_train_mode_dropout_with_an_injected_mask(monkeypatch):
+    """Train mode: Linear -> ReLU -> Dropout(0.1) -> Linear (clip_text.py:9-14).  The dropout mask of the GPU generator cannot be
+    reproduced on the CPU, so the mask is INJECTED: F.dropout in the module's namespace is replaced by a fixed Bernoulli(0.9) mask
+    scaled by 1 / 0.9 (exactly what nn.Dropout computes), and forward + every parameter gradient are compared with a float64
+    restatement of the same four lines using that mask."""
+    import tricolo_amd.model.module.text_encoder.clip_text as ct
+    gen = torch.Generator().manual_seed(41)
+    m = CLIPTextEncoder(out_dim=512).to(DEV).train()
+    B = 8
+    x = torch.randn(B, 768, generator=gen)
+    x = x / x.norm(dim=1, keepdim=True)                             # unit-norm CLIP vectors (extract_clip_feats.py:30-31)
+    mask = (torch.rand(B, 512, generator=gen) < 0.9).float()
+    calls = []
+
+    def fake_dropout(h, p, training):
+        calls.append((p, training))
+        return h * (mask.to(h.device) / (1.0 - p))
+    monkeypatch.setattr(ct.F, "dropout", fake_dropout)
+    z = m(torch.zeros((B, 96), dtype=torch.int32, device=DEV), {"clip_embeddings_text": x.to(DEV)})
+    assert calls == [(0.1, True)]
+    up = torch.randn(B, 512, generator=gen)
+    (z * up.to(DEV)).sum().backward()
+    w0, b0, w1, b1 = (t.detach().cpu().double().requires_grad_() for t in (m.mlp[0].weight, m.mlp[0].bias, m.mlp[3].weight, m.mlp[3].bias))
+    h = torch.relu(x.double() @ w0.t() + b0) * (mask.double() / 0.9)
+    zr = h @ w1.t() + b1
+    (zr * up.double()).sum().backward()
+    np.testing.assert_allclose(z.detach().cpu().numpy(), zr.detach().numpy(), atol=2e-5)
+    for p_, r_ in ((m.mlp[0].weight, w0), (m.mlp[0].bias, b0), (m.mlp[3].weight, w1), (m.mlp[3].bias, b1)):
+        np.testing.assert_allclose(p_.grad.cpu().numpy(), r_.grad.numpy(), atol=3e-5, rtol=2e-4)
+    # and the real thing: nn.Dropout semantics hold statistically (10 % of the hidden units zeroed, the rest scaled by 1 / 0.9)
+    monkeypatch.undo()
+    with torch.no_grad():
+        big = torch.randn(64, 768, device=DEV)
+        hid = torch.relu(big @ m.mlp[0].weight.t() + m.mlp[0].bias)
+        out = ct.F.dropout(hid, 0.1, True)
+        alive = hid > 0                                             # ReLU zeros say nothing about the mask
+        assert 0.87 < (out[alive] != 0).float().mean().item() < 0.93
+        np.testing.assert_allclose(out[out != 0].cpu().numpy(), (hid[out != 0] / 0.9).cpu().numpy(), rtol=1e-6)
+
+
 @pytest.mark.parametrize("tag,V,B,seed", [("v32", 32, 8, 1), ("v64", 64, 2, 8)])
 def test_voxel_encoder_matches_reference(golden, tag, V, B, seed):
     g = golden("voxel")
