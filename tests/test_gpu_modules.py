@@ -564,6 +564,44 @@ def test_config5_full_per_gpu_batch_properties(prec):
     assert np.isfinite(after) and after < total.item()
 
 
+@pytest.mark.parametrize("tag,text,image,voxel,V,nv,S,B", [
+    ("config2", "BiGRUEncoder", None, "SparseCNNEncoder", 32, 6, 128, 64),
+    ("config3", "BiGRUEncoder", "MVCNNEncoder", None, 32, 6, 128, 64),
+    ("config4", "BiGRUEncoder", "MVCNNEncoder", "SparseCNNEncoder", 32, 6, 128, 32),
+], ids=["config2", "config3", "config4"])
+def test_full_per_gpu_batch_properties_and_mode_agreement(tag, text, image, voxel, V, nv, S, B):
+    """BASELINE configs 2-4 at their real per-GPU batch (the fixtures hold 8 samples): the f16 step against the bf16x3 step of the
+    same weights on the same batch - step-0 loss within the north star's 1e-3, embeddings within 5e-4 - plus the size-independent
+    properties of test_config5_full_per_gpu_batch_properties.  These sizes also take kernel variants the fixtures never reach
+    (per-workgroup BatchNorm records, the slab-based layer1 weight gradient of config 3, row-list launches with > 10^5 rows)."""
+    res = {}
+    for prec in ("bf16x3", "f16"):
+        ops.set_default_precision(prec)
+        torch.manual_seed(1234)
+        net, cfg = _build_net(text, image, voxel, V, nv, S)
+        batch = syn.batch_to_device(syn.make_batch(B, voxel_size=V if voxel else None, num_views=nv if image else None, image_size=S,
+                                                   seed=syn.BASE_SEED + 61), DEV)
+        opt = net.configure_optimizers()
+        emb = net(batch)
+        for k, v in emb.items():
+            assert v.shape == (B, 512)
+            np.testing.assert_allclose(v.detach().norm(dim=1).cpu().numpy(), 1.0, atol=1e-4)
+        total = net._calculate_losses(emb, "train_loss")["train_loss/total_loss"]
+        total.backward()
+        for name, p in net.named_parameters():
+            assert p.grad is not None and torch.isfinite(p.grad).all(), name
+        opt.step()
+        after = net._calculate_losses(net(batch), "train_loss")["train_loss/total_loss"].item()
+        assert np.isfinite(after) and after < total.item()
+        res[prec] = (total.item(), after, {k: v.detach().float().cpu() for k, v in emb.items()})
+        del net, opt
+    dl = abs(res["f16"][0] - res["bf16x3"][0])
+    de = max(float((res["f16"][2][k] - res["bf16x3"][2][k]).abs().max()) for k in res["f16"][2])
+    _report(f"fullbatch/{tag}", {"loss_bf16x3": res["bf16x3"][0], "loss_f16": res["f16"][0], "loss_abs_diff": dl, "embedding_max_abs_diff": de,
+                                 "loss_after_1_step_bf16x3": res["bf16x3"][1], "loss_after_1_step_f16": res["f16"][1]})
+    assert dl < 1e-3 and de < 5e-4
+
+
 _HELDOUT_CACHE = {}
 
 
