@@ -59,18 +59,33 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
     for (int i = t; i < 2 * NSPLIT * 16 * 256 / 4; i += 512) ((int*)lds)[i] = 0;
     __syncthreads();
 
-    const size_t plane = (size_t)L * B * GRU_H;
-    int cur = 0;
-    for (int s = 0; s < L; ++s) {
-        const int tt = dir == 0 ? s : L - 1 - s;
-        // input projections of this step (issued first: latency hides under the MFMAs)
-        float xr[4], xz[4], xn[4];
+    // Input projections are prefetched THREE steps ahead: a step is ~600 cycles of MFMAs and gate math, a global load ~1-2 us.
+    // (Loaded at the top of the step that uses them, every one of the 96 steps waited a full load latency: 2.2 us per step,
+    // 214 us for the kernel - on the text tower's forward, which the loss of the whole step waits for.)
+    constexpr int PF = 3;
+    float xq[PF][12];
+    auto load_x = [&](int s_, float* dst) {
+        const int t_ = dir == 0 ? s_ : L - 1 - s_;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             int b = b0 + fq * 4 + r;
-            const float* xp = xproj + ((size_t)tt * B + (b < B ? b : 0)) * 768 + dir * 384 + unit;
-            xr[r] = xp[0]; xz[r] = xp[128]; xn[r] = xp[256];
+            const float* xp = xproj + ((size_t)(s_ < L ? t_ : 0) * B + (b < B ? b : 0)) * 768 + dir * 384 + unit;
+            dst[r] = xp[0]; dst[4 + r] = xp[128]; dst[8 + r] = xp[256];
         }
+    };
+#pragma unroll
+    for (int d = 0; d < PF; ++d) load_x(d, xq[d]);
+    int cur = 0;
+    for (int s = 0; s < L; ++s) {
+        const int tt = dir == 0 ? s : L - 1 - s;
+        float xr[4], xz[4], xn[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { xr[r] = xq[0][r]; xz[r] = xq[0][4 + r]; xn[r] = xq[0][8 + r]; }
+#pragma unroll
+        for (int d = 0; d + 1 < PF; ++d)
+#pragma unroll
+            for (int k = 0; k < 12; ++k) xq[d][k] = xq[d + 1][k];
+        load_x(s + PF, xq[PF - 1]);                                 // (past the end: a harmless re-read of step 0's row)
         const char* hb = lds + cur * (NSPLIT * 16 * 256);
         f32x4 acc[3];
 #pragma unroll
@@ -161,13 +176,37 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
         dh[r] = b < B ? dhfinal[(size_t)b * 256 + dir * GRU_H + unit] : 0.f;
     }
     float sb[4] = {0.f, 0.f, 0.f, 0.f};                      // bias-gradient partial sums of this lane's (rows, unit)
+    // saved gates and h_{t-1} of a step are prefetched two steps ahead (see gru_fwd_kernel: every step used to wait for them)
+    constexpr int PF = 2;
+    float gq[PF][20];                                         // [row][r, z, n, hn] + h_prev[row]
+    auto load_g = [&](int s_, float* dst) {
+        const int sc = s_ >= 0 ? s_ : 0;
+        const int t_ = dir == 0 ? sc : L - 1 - sc;
+        const int tp_ = dir == 0 ? t_ - 1 : t_ + 1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b = b0 + fq * 4 + r, bc = b < B ? b : 0;
+            const size_t o = ((size_t)dir * L + t_) * B + bc;
+            const float* gp = gates + o * 4 * GRU_H + unit;
+            dst[r * 4 + 0] = gp[0]; dst[r * 4 + 1] = gp[GRU_H]; dst[r * 4 + 2] = gp[2 * GRU_H]; dst[r * 4 + 3] = gp[3 * GRU_H];
+            dst[16 + r] = sc > 0 ? hs[(((size_t)dir * L + tp_) * B + bc) * GRU_H + unit] : 0.f;
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < PF; ++d) load_g(L - 1 - d, gq[d]);
     int cur = 0;
     for (int s = L - 1; s >= 0; --s) {
         const int tt = dir == 0 ? s : L - 1 - s;              // time index processed at forward step s
-        const int tp = dir == 0 ? tt - 1 : tt + 1;            // time index of h_{prev}
-        const bool has_prev = s > 0;
         char* gb = lds + cur * (NSPLIT * 16 * 768);
         float dhz[4];
+        float gcur[20];
+#pragma unroll
+        for (int k = 0; k < 20; ++k) gcur[k] = gq[0][k];
+#pragma unroll
+        for (int d = 0; d + 1 < PF; ++d)
+#pragma unroll
+            for (int k = 0; k < 20; ++k) gq[d][k] = gq[d + 1][k];
+        load_g(s - PF, gq[PF - 1]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             int row = fq * 4 + r, b = b0 + row;
@@ -175,9 +214,8 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
             dhz[r] = 0.f;
             if (b < B) {
                 size_t o = ((size_t)dir * L + tt) * B + b;
-                const float* gp = gates + o * 4 * GRU_H + unit;
-                float rg = gp[0], zg = gp[GRU_H], ng = gp[2 * GRU_H], ghn = gp[3 * GRU_H];
-                if (has_prev) hp = hs[(((size_t)dir * L + tp) * B + b) * GRU_H + unit];
+                float rg = gcur[r * 4 + 0], zg = gcur[r * 4 + 1], ng = gcur[r * 4 + 2], ghn = gcur[r * 4 + 3];
+                hp = gcur[16 + r];
                 float d = dh[r];
                 float dn = d * (1.f - zg);
                 float dz = d * (hp - ng);
