@@ -226,7 +226,7 @@ int tri_cast_to_f32(const void* src, float* dst, long n, int act_fmt, void* stre
 
 /* ---- persistent bidirectional GRU recurrence (nn.GRU(256,128,bidirectional) of text_encoder/bigru.py:11,17) -----------
  * xproj [L][B][768] = x_t W_ih^T + b_ih for both directions (768 = dir*384 + gate*128 + unit, gate order r,z,n);
- * w_hh [2][384][128], b_hh [2][384].  Outputs: hs [2][L][B][128], gates [2][L][B][4][128] (r,z,n,hn) saved for backward,
+ * w_hh [2][384][128], b_hh [2][384].  Outputs: hs [2][L][B][128], gates [2][L][B][128][4] (r,z,n,hn per unit) saved for backward,
  * hfinal [B][256] = cat(forward final state, reverse final state) (bigru.py:18).  tri_gru_bwd returns the gate
  * pre-activation gradients dgi [L][B][768], dgh [2][L][B][384] and h_{t-1} rows hprev [2][L][B][128]; the weight
  * gradients are then plain GEMMs (tri_conv_wgrad with 1x1 geometry). */

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
                                                       const float* __restrict__ b_hh,    // [2][384]
                                                       int B, int L,
                                                       float* __restrict__ hs,            // [2][L][B][128]  h after step t
-                                                      float* __restrict__ gates,         // [2][L][B][4][128] r, z, n, hn(+b)
+                                                      float* __restrict__ gates,         // [2][L][B][128][4] r, z, n, hn(+b) per unit
                                                       float* __restrict__ hfinal) {      // [B][256]
     __shared__ __attribute__((aligned(16))) char lds[2 * NSPLIT * 16 * 256];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -123,8 +123,7 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
             if (b < B) {
                 size_t o = ((size_t)dir * L + tt) * B + b;
                 hs[o * GRU_H + unit] = hnew;
-                float* gp = gates + o * 4 * GRU_H + unit;
-                gp[0] = rg; gp[GRU_H] = zg; gp[2 * GRU_H] = ng; gp[3 * GRU_H] = ghn;
+                *(float4*)(gates + (o * GRU_H + unit) * 4) = make_float4(rg, zg, ng, ghn);      // one 16-byte store per (row, unit)
             }
             // re-publish as bf16 (hi, lo): element (row, unit) -> chunk unit/8, byte (unit%8)*2
             bf16_t hh = (bf16_t)hnew;
@@ -149,7 +148,7 @@ template <int NSPLIT>
 __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ dhfinal,  // [B][256]
                                                       const float* __restrict__ w_hh,     // [2][384][128]
                                                       const float* __restrict__ hs,       // [2][L][B][128]
-                                                      const float* __restrict__ gates,    // [2][L][B][4][128]
+                                                      const float* __restrict__ gates,    // [2][L][B][128][4]
                                                       int B, int L,
                                                       float* __restrict__ dgi,            // [L][B][768]
                                                       float* __restrict__ dgh,            // [2][L][B][384]
@@ -192,8 +191,8 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
         for (int r = 0; r < 4; ++r) {
             const int b = b0 + fq * 4 + r, bc = b < B ? b : 0;
             const size_t o = ((size_t)dir * L + t_) * B + bc;
-            const float* gp = gates + o * 4 * GRU_H + unit;
-            dst[r * 4 + 0] = gp[0]; dst[r * 4 + 1] = gp[GRU_H]; dst[r * 4 + 2] = gp[2 * GRU_H]; dst[r * 4 + 3] = gp[3 * GRU_H];
+            const float4 gv = *(const float4*)(gates + (o * GRU_H + unit) * 4);
+            dst[r * 4 + 0] = gv.x; dst[r * 4 + 1] = gv.y; dst[r * 4 + 2] = gv.z; dst[r * 4 + 3] = gv.w;
             dst[16 + r] = sc > 0 ? hs[(((size_t)dir * L + tp_) * B + bc) * GRU_H + unit] : 0.f;
         }
     };

@@ -702,7 +702,7 @@ def act_bwd(dout, out, act, inplace=True):
 def gru_fwd(xproj, w_hh, b_hh, B, L, precision):
     dev = xproj.device
     hs = torch.empty((2, L, B, 128), dtype=torch.float32, device=dev)
-    gates = torch.empty((2, L, B, 4, 128), dtype=torch.float32, device=dev)
+    gates = torch.empty((2, L, B, 128, 4), dtype=torch.float32, device=dev)        # (r, z, n, hn) per unit: one 16-byte access
     hfinal = torch.empty((B, 256), dtype=torch.float32, device=dev)
     check(lib().tri_gru_fwd(ptr(_f32(xproj)), ptr(_f32(w_hh)), ptr(_f32(b_hh)), B, L, ptr(hs), ptr(gates), ptr(hfinal),
                             split3(precision), stream()), "tri_gru_fwd")
