@@ -36,6 +36,9 @@ struct ConvArgs {
     int h_tr, h_rows, h_slab_bytes, h_nr, h_mtiles;    // halo kernel: image rows per tile, slab rows, slab bytes, ring slots, row tiles
     int h_dbuf;
     int h_abl;                                          // tuning aid (TRICOLO_HALO_ABL): ablation bits, 0 in production
+#ifdef HALO_STAMPS
+    long long* h_dbg;                                   // tools/probes/halo_probe.hip: per-workgroup (id, cycle) stamps of wave 0
+#endif
     FastDiv dOW, dOH, dOD, dCin, dP, dH2;
 };
 
@@ -675,6 +678,23 @@ __device__ __forceinline__ void halo_store_stats(const f32x4* cs, const f32x4* c
     }
 }
 
+__device__ __forceinline__ v4i lds_read16(unsigned addr) {
+    v4i r;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr));
+    return r;
+}
+template <int OFF>
+__device__ __forceinline__ v4i lds_read16_off(unsigned addr) {
+    v4i r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+// wait until at most N LDS operations are outstanding; the fragments named become "defined here" for the compiler, so no MFMA that
+// consumes them can be scheduled above the wait
+template <int N>
+__device__ __forceinline__ void frag_wait(v4i (&a)[2], v4i (&b)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N));
+}
 // WGREC: BatchNorm records per persistent workgroup (launches with many tiles per workgroup) instead of per tile
 template <int TM, bool WGREC, typename AT>
 __global__ __launch_bounds__(256, WGREC ? 3 : 1) void conv_halo2d_kernel(const ConvArgs p) {     // WGREC: <= 170 VGPRs (three workgroups per CU)
@@ -688,6 +708,14 @@ __global__ __launch_bounds__(256, WGREC ? 3 : 1) void conv_halo2d_kernel(const C
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int fr = lane & 15, fq = lane >> 4;
+#ifdef HALO_STAMPS
+    int n_stamp = 0;
+    long long* const stl = (long long*)(smem + p.h_slab_bytes + HALO_NR * 8192 + 2048);      // wave 0's stamps (2 KiB past `red`)
+#define HSTAMP(id) do { if (wave == 0 && n_stamp < 255) { const long long c_ = __builtin_readcyclecounter(); if (lane == 0) stl[n_stamp] = ((long long)(id) << 48) | (c_ & 0xFFFFFFFFFFFFll); ++n_stamp; } } while (0)
+#else
+#define HSTAMP(id) do { } while (0)
+#endif
+    HSTAMP(1);
     const int H = p.IH, W = p.IW, P = W + 2, TR = p.h_tr, NH = p.B * H;
     const int NT = p.Cout / BN, nchunks = p.Cin >> 6;
     const int items = p.h_mtiles * NT, G = gridDim.x;
@@ -732,6 +760,10 @@ __global__ __launch_bounds__(256, WGREC ? 3 : 1) void conv_halo2d_kernel(const C
         const int i = whole ? (int)fdiv((unsigned)j, p.dOH) : 0;
         pixc[a] = (j + 1 + 2 * i) * P + x + 1;
     }
+    const unsigned lds_slab0 = lds_addr(smem), lds_ring0 = lds_addr(ring);
+    unsigned boff[2];                                                   // weight fragment of this lane inside a ring slot, per k-step
+    boff[0] = fr * 128 + (((fq ^ (fr >> 1)) & 7) << 4);
+    boff[1] = boff[0] ^ 64;
     int woff[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
@@ -757,8 +789,10 @@ __global__ __launch_bounds__(256, WGREC ? 3 : 1) void conv_halo2d_kernel(const C
     auto issue_w = [&]() {
         const unsigned dst = lds_ring + w_slot * W_BYTES;
         const int kb = (w_nb + w_k) * 2;
+        if (!(p.h_abl & 128)) {
         dma16_async(w_rsrc, dst, woff[0] + kb);
         dma16_async(w_rsrc, dst + 4096, woff[1] + kb);
+        }
         ++w_ahead;
         if (++w_slot == NR) w_slot = 0;
         w_k += p.Cin;
@@ -775,6 +809,7 @@ __global__ __launch_bounds__(256, WGREC ? 3 : 1) void conv_halo2d_kernel(const C
 
     int item = blockIdx.x;
     if (item >= items) return;
+    HSTAMP(2);                                                          // geometry constants done
     {
         issue_slab((item / NT) * TR, 0);
 #pragma unroll
@@ -815,7 +850,9 @@ __global__ __launch_bounds__(256, WGREC ? 3 : 1) void conv_halo2d_kernel(const C
                 asm volatile("" ::: "memory");
                 issue_slab(g0, chunk);
             }
+            HSTAMP(3);                                                    // slab issued
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the slab is the youngest DMA: everything has landed
+            HSTAMP(4);                                                    // slab landed
             // (rolled tap loop: unrolled, the nine taps' fragment addresses were hoisted and spilled to scratch - whose reloads
             //  are VMEM operations that wait for every LDS-DMA in flight)
             int shift = p.transposed ? (P + 1) : -(P + 1), kx = 0;        // tap (ky, kx) reads the slab shifted by (ky - 1) * P + (kx - 1); negated for the data gradient
@@ -823,35 +860,47 @@ __global__ __launch_bounds__(256, WGREC ? 3 : 1) void conv_halo2d_kernel(const C
             for (int tap = 0; tap < 9; ++tap) {
                 // this unit's weights were issued NR - 1 units ago; the NR - 2 units issued after them may still be in flight
                 --w_ahead;
-                if (tap > 0) {
+                if (tap > 0 && !(p.h_abl & 64)) {
                     if (w_ahead == NR - 2) wait_vmcnt_c<2 * (NR - 2)>();
                     else wait_vmcnt(2 * w_ahead);                         // the last units of the stream
                 }
+                HSTAMP(5);                                                // this unit's weights landed
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
+                HSTAMP(6);                                                // past the barrier
                 if (w_item < items) issue_w();
+                HSTAMP(7);                                                // next unit's weights issued
                 if (!(p.h_abl & 1)) {
-                    const char* wl = ring + c_slot * W_BYTES;
-                    int abase[TM], asw[TM];
+                    // all twelve fragment reads of the unit are issued before its first MFMA (inline asm: left to itself the compiler
+                    // re-uses four registers per operand and waits for the LDS before every MFMA pair - eight exposed LDS latencies
+                    // per unit, which at one to three waves per SIMD is most of the unit's time)
+                    const unsigned wb = lds_ring0 + c_slot * W_BYTES;
+                    unsigned aaddr[TM];
 #pragma unroll
                     for (int a = 0; a < TM; ++a) {
                         const int pix = pix0[a] + tmul[a] * shift;
-                        abase[a] = pix * 128;
-                        asw[a] = (pix >> 1) & 7;
+                        aaddr[a] = lds_slab0 + pix * 128 + ((fq ^ ((pix >> 1) & 7)) << 4);
                     }
+                    v4i ar[2][TM], br[2][TN];
 #pragma unroll
                     for (int kk = 0; kk < 2; ++kk) {
-                        v8 ah[TM];
 #pragma unroll
-                        for (int a = 0; a < TM; ++a) ah[a] = *(const v8*)(smem + abase[a] + (((kk * 4 + fq) ^ asw[a]) << 4));
+                        for (int a = 0; a < TM; ++a) ar[kk][a] = lds_read16(aaddr[a] ^ (kk << 6));
 #pragma unroll
-                        for (int b = 0; b < TN; ++b) {
-                            v8 bh = *(const v8*)(wl + dma_off(b * 16 + fr, kk * 4 + fq));
-#pragma unroll
-                            for (int a = 0; a < TM; ++a) acc[a][b] = MM::mma(bh, ah[a], acc[a][b]);
-                        }
+                        for (int b = 0; b < TN; ++b) br[kk][b] = lds_read16_off<0>(wb + boff[kk] + b * 2048);
                     }
+                    frag_wait<TM + TN>(ar[0], br[0]);                                  // the first k-step's fragments have landed
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+#pragma unroll
+                        for (int a = 0; a < TM; ++a) acc[a][b] = MM::mma(__builtin_bit_cast(v8, br[0][b]), __builtin_bit_cast(v8, ar[0][a]), acc[a][b]);
+                    frag_wait<0>(ar[1], br[1]);
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+#pragma unroll
+                        for (int a = 0; a < TM; ++a) acc[a][b] = MM::mma(__builtin_bit_cast(v8, br[1][b]), __builtin_bit_cast(v8, ar[1][a]), acc[a][b]);
                 }
+                HSTAMP(8);                                                // MFMAs issued
                 if (++c_slot == NR) c_slot = 0;
                 const int step = (++kx == 3) ? (kx = 0, P - 2) : 1;       // next tap: one pixel right, or down a row and two left
                 shift += p.transposed ? -step : step;
@@ -862,6 +911,7 @@ __global__ __launch_bounds__(256, WGREC ? 3 : 1) void conv_halo2d_kernel(const C
         asm volatile("" ::: "memory");
         if (item + G < items) issue_slab(((item + G) / NT) * TR, 0);
 
+        HSTAMP(9);                                                        // epilogue starts
         // ---- lean epilogue (conv + BatchNorm statistics, or accumulate for the data gradient): rows = positions [g0 W, g0 W + npos)
         if (!(p.h_abl & 4)) {
             AT* const out = (AT*)p.out + ((size_t)g0 * W) * p.Cout + ntile * BN;
@@ -883,10 +933,385 @@ __global__ __launch_bounds__(256, WGREC ? 3 : 1) void conv_halo2d_kernel(const C
                     }
                 }
             }
+            HSTAMP(10);                                                   // output stores issued
             if (!WGREC && p.stats && !(p.h_abl & 16)) halo_store_stats<TN, BN>(cs, cq, red, p.stats, p.Cout, mtile, ntile, wave, fr, fq, t, true);
         }
+        HSTAMP(11);                                                       // tile done
     }
+#ifdef HALO_STAMPS
+    if (wave == 0) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int i = lane; i < 255; i += 64) p.h_dbg[(size_t)blockIdx.x * 256 + i] = i < n_stamp ? stl[i] : 0;
+        if (lane == 0) p.h_dbg[(size_t)blockIdx.x * 256 + 255] = n_stamp;
+    }
+#endif
     if (WGREC && p.stats && !(p.h_abl & 16)) halo_store_stats<TN, BN>(cs, cq, red, p.stats, p.Cout, blockIdx.x / NT, blockIdx.x % NT, wave, fr, fq, t, false);
+}
+
+
+// ================================================================================================ halo kernel, row-unit pipeline
+// Same tiles, slab and operand layouts as conv_halo2d_kernel, restructured around what its in-kernel stamps showed
+// (tools/probes/halo_probe.hip): per 8 KiB tap unit a wave spent ~130 cycles waiting for the weights, ~220 issuing the next two
+// DMA pieces and ~540 in the block of 16 MFMAs (256 cycles of matrix work) because every fragment read was exposed.  Here
+//   * one ring slot is a kernel ROW of one 64-channel chunk (3 taps x 64 x 64 = 24 KiB): one barrier and one DMA wait per 48 MFMAs;
+//   * the fragments of k-step t + 2 are read (inline asm, three register sets) between the MFMAs of k-step t - across row units,
+//     chunks and tiles: the stream of row units of a workgroup is one software pipeline, the epilogue of a tile runs with the next
+//     tile's first fragments already in registers;
+//   * the next-but-one row unit's six weight pieces and the next chunk's (or tile's) slab pieces are issued in the k-steps right
+//     after the barrier that freed their buffers, four k-steps before the barrier that needs them (two slab buffers);
+//   * one workgroup per CU (148 KiB of LDS), BatchNorm sums carried in registers: one record per workgroup.
+#define HROWS_SLOT (3 * 8192)
+// DRIP: the tile's output waits in a 4 KiB LDS tile per wave and leaves as one full-row store per k-step of the NEXT tile's first kernel
+// row: with every workgroup of the launch in step, stores issued in the epilogue all hit the memory system at once and the waves
+// sat ~4k cycles per tile in store issue (probe stamps).  Launches whose slabs leave no room for the 16 KiB (DRIP = false) store
+// from the epilogue through a 2 KiB tile per wave.
+template <typename AT, bool DRIP, bool ACCUM>
+__global__ __launch_bounds__(256, 1) void conv_halo_rows_kernel(const ConvArgs p) {
+    typedef Mma<typename OpOf<AT>::E> MM;
+    typedef typename MM::v8 v8;
+    constexpr int BN = 64, TN = 4, TM = 2, WM = 32, SLOT = HROWS_SLOT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int slab_bytes = p.h_slab_bytes;
+    char* const ring = smem + 2 * slab_bytes;
+    float* const red = (float*)(ring + 3 * SLOT);
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+#ifdef HALO_STAMPS
+    int n_stamp = 0;
+    long long* const stl = (long long*)(smem + 2 * p.h_slab_bytes + 3 * HROWS_SLOT + (DRIP ? 16384 : 8192));
+#endif
+    HSTAMP(1);
+    const int H = p.IH, W = p.IW, P = W + 2, TR = p.h_tr, NH = p.B * H;
+    const int NT = p.Cout / BN, nchunks = p.Cin >> 6;
+    const int items = p.h_mtiles * NT, G = gridDim.x;
+    const int S = slab_bytes >> 12;
+    const int zero_pix = p.h_rows * P;
+    const int sgn = p.transposed ? -1 : 1;                              // tap (ky, kx) reads the slab shifted by +-((ky - 1) P + kx - 1)
+    const v4i in_rsrc = make_rsrc_words(p.in, p.in_bytes);
+    const v4i w_rsrc = make_rsrc_words(p.w_hi, (unsigned)((size_t)p.Cout * p.Kpad * 2));
+    const unsigned lds_slab0 = lds_addr(smem), lds_ring0 = lds_addr(ring);
+    const unsigned dma_slab = lds_slab0 + wave * 1024, dma_ring = lds_ring0 + wave * 1024;
+    const int whole = (TR % H == 0) ? 1 : 0;
+    if ((int)blockIdx.x >= items) return;
+
+    int woff[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int n = r * 32 + wave * 8 + (lane >> 3);
+        woff[r] = (n * p.Kpad + (((lane & 7) ^ ((n >> 1) & 7)) << 3)) * 2;
+    }
+    // ---- weight stream: one element per (tile, chunk); its three kernel rows go to ring slots 0, 1, 2 (slot == kernel row);
+    //      six 1 KiB pieces per wave and row
+    int w_item = blockIdx.x, w_chunk = 0;
+    const int w_nb = (blockIdx.x % NT) * BN * p.Kpad;                   // every tile of this workgroup has the same output-channel tile
+    auto w_pieces = [&](int ky, int j0, int j1) {
+        if (w_item < items) {
+            // the data gradient is the same correlation with the taps taken in reverse order (tap' = 8 - tap)
+            const int tap0 = p.transposed ? 8 - ky * 3 : ky * 3, tstep = p.transposed ? -1 : 1;
+            const int kb = (w_nb + w_chunk * 64) * 2;
+            const unsigned dst = dma_ring + ky * SLOT;
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                if (j >= j0 && j < j1)
+                    dma16_async(w_rsrc, dst + (j >> 1) * 8192 + (j & 1) * 4096, woff[j & 1] + kb + (tap0 + tstep * (j >> 1)) * p.Cin * 2);
+        }
+    };
+    auto w_advance = [&]() {
+        if (++w_chunk == nchunks) { w_chunk = 0; w_item += G; }
+    };
+
+    // issued first: the weight DMAs are in flight while the slab source table and the fragment addresses are computed
+    w_pieces(0, 0, 6);
+    if (nchunks == 1) {                                                 // 64 input channels: the three ring slots ARE the filter bank of this
+        w_pieces(1, 0, 6);                                              // workgroup's output-channel tile - loaded once, never streamed again
+        w_pieces(2, 0, 6);
+        w_item = items;
+    } else {
+        w_pieces(1, 0, 4);
+    }
+
+    // ---- geometry-only lane constants (as conv_halo2d_kernel) ----------------------------------------------------------
+    int soff[HALO_MAX_ROUNDS];
+    unsigned stop = 0, sbot = 0;
+    {
+        const int spix = wave * 8 + (lane >> 3), slot = lane & 7;
+#pragma unroll
+        for (int r = 0; r < HALO_MAX_ROUNDS; ++r) {
+            const int sp = r * 32 + spix;
+            const int srow = (int)fdiv((unsigned)sp, p.dP), sx = sp - srow * P;
+            bool ok = srow < p.h_rows && sx >= 1 && sx <= W;
+            int grel;
+            if (whole) {
+                const int i = (int)fdiv((unsigned)srow, p.dH2), b = srow - i * (H + 2);
+                ok = ok && b >= 1 && b <= H;
+                grel = i * H + b - 1;
+            } else {
+                grel = srow - 1;
+                if (ok && grel < 0) stop |= 1u << r;
+                if (ok && grel >= TR) sbot |= 1u << r;
+            }
+            soff[r] = ok ? ((grel * W + sx - 1) * p.Cin + ((slot ^ ((sp >> 1) & 7)) << 3)) * 2 : -1;
+        }
+    }
+    int pixc[TM];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+        const unsigned pa = wave * WM + a * 16 + fr;
+        const int j = (int)fdiv(pa, p.dOW), x = (int)pa - j * W;
+        const int i = whole ? (int)fdiv((unsigned)j, p.dOH) : 0;
+        pixc[a] = (j + 1 + 2 * i) * P + x + 1;
+    }
+    unsigned boff[2];
+    boff[0] = fr * 128 + (((fq ^ (fr >> 1)) & 7) << 4);
+    boff[1] = boff[0] ^ 64;
+
+    // ---- slab stream: one element per (tile, chunk), alternating between the two slab buffers -------------------------------
+    int s_item = blockIdx.x, s_chunk = 0, s_buf = 0, s_cb = 0;
+    unsigned s_kill = 0;
+    auto slab_setup = [&]() {                                           // source constants of the element the cursor points at
+        const int g0_ = (s_item / NT) * TR;
+        int top_ok = 1, bot_ok = 1;
+        if (!whole) {
+            const int h0_ = g0_ - (int)fdiv((unsigned)g0_, p.dOH) * H;
+            top_ok = h0_ > 0;
+            bot_ok = h0_ + TR < H;
+        }
+        s_kill = (top_ok ? 0u : stop) | (bot_ok ? 0u : sbot);
+        s_cb = g0_ * W * p.Cin * 2 + s_chunk * 128;
+    };
+    auto slab_pieces = [&](int r0, int r1) {
+        if (s_item < items) {
+            const unsigned dst = dma_slab + s_buf * slab_bytes;
+#pragma unroll
+            for (int r = 0; r < HALO_MAX_ROUNDS; ++r)
+                if (r >= r0 && r < r1 && r < S)
+                    dma16_async(in_rsrc, dst + r * 4096, (soff[r] == -1 || ((s_kill >> r) & 1u)) ? (int)0x80000000 : soff[r] + s_cb);
+        }
+    };
+    auto slab_advance = [&]() {
+        s_buf ^= 1;
+        if (++s_chunk == nchunks) { s_chunk = 0; s_item += G; }
+        if (s_item < items) slab_setup();
+    };
+    slab_setup();                                                       // the first slab, before the remaining constants
+    slab_pieces(0, HALO_MAX_ROUNDS);
+    slab_advance();
+    // ---- fragment addresses: every tap's slab address of this lane's two fragment rows, both 64-byte halves (buffer 0; the
+    //      other slab buffer is + slab_bytes), and the weight fragment bases of the three ring slots - no address arithmetic
+    //      is left in the k-steps
+    unsigned arel[9][TM][2], bbase[3][2];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        bbase[ky][0] = lds_ring0 + ky * SLOT + boff[0];
+        bbase[ky][1] = lds_ring0 + ky * SLOT + boff[1];
+    }
+    int cur_npos = -1;
+    auto set_rows = [&](int item_) {                                    // rows past the end of the last tile read the zero pixel
+        const int npos_ = min(TR, NH - (item_ / NT) * TR) * W;
+        if (npos_ == cur_npos) return;
+        cur_npos = npos_;
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            const bool ok = wave * WM + a * 16 + fr < npos_;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int pix = ok ? pixc[a] + (tap / 3 - 1) * P + (tap % 3 - 1) : zero_pix;
+                const unsigned rel = (pix << 7) | ((fq ^ ((pix >> 1) & 7)) << 4);
+                arel[tap][a][0] = lds_slab0 + rel;
+                arel[tap][a][1] = lds_slab0 + (rel ^ 64);
+            }
+        }
+    };
+    set_rows(blockIdx.x);
+
+    // ---- fragments: three register sets, set of k-step t = t % 3 (six k-steps per kernel row) -----------------------------
+    v4i fa[3][TM], fb[3][TN];
+    f32x4 acc[TM][TN], cs[TN], cq[TN];
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        cs[b] = (f32x4){0.f, 0.f, 0.f, 0.f}; cq[b] = cs[b];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) acc[a][b] = cs[b];
+    }
+    int c_item = blockIdx.x, c_chunk = 0, c_sbuf = 0;
+    // drip state: staged tile of the previous epilogue (rows m0 + 8 d, d = 0..3, 16 bytes per lane)
+    const unsigned d_lds0 = lds_addr(red) + wave * 4096 + (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 4) & 3)) << 4);
+    const unsigned d_lds1 = lds_addr(red) + wave * 4096 + (8 + (lane >> 3)) * 128 + (((lane & 7) ^ (4 + ((lane >> 4) & 3))) << 4);
+    const int d_m0 = wave * WM + (lane >> 3);
+    const size_t d_step = (size_t)8 * p.Cout * sizeof(AT);
+    char* d_ptr = nullptr;
+    int d_npos = 0;
+    bool d_on = false;
+    v4i d_q;
+#define HR_DRIP_READ(D) if (DRIP && d_on) d_q = ((D) & 1) ? lds_read16_off<((D) >> 1) * 2048>(d_lds1) : lds_read16_off<((D) >> 1) * 2048>(d_lds0);
+#define HR_DRIP_STORE(D)                                                                  \
+    if (DRIP && d_on) {                                                                   \
+        asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(d_q));                                 \
+        if (d_m0 + (D) * 8 < d_npos) *(v4i*)(d_ptr + (D) * d_step) = d_q;                  \
+    }
+
+#define HR_MMA(SET, A, B) acc[A][B] = MM::mma(__builtin_bit_cast(v8, fb[SET][B]), __builtin_bit_cast(v8, fa[SET][A]), acc[A][B])
+    // k-step: wait for set CUR, then its eight MFMAs with the six reads of set NX between them (the fragments of the k-step after
+    // the next: tap TAP, half KK of the 64 channels, slab buffer offset SB, ring slot KYR)
+#define HR_KSTEP(CUR, NX, SB, TAP, KYR, KK)                                                                           \
+    {                                                                                                                  \
+        frag_wait<6>(fa[CUR], fb[CUR]);                                                                                \
+        HR_MMA(CUR, 0, 0); fa[NX][0] = lds_read16(arel[TAP][0][KK] + (SB));                                              \
+        HR_MMA(CUR, 1, 0); fa[NX][1] = lds_read16(arel[TAP][1][KK] + (SB));                                              \
+        HR_MMA(CUR, 0, 1); fb[NX][0] = lds_read16_off<((TAP) % 3) * 8192>(bbase[KYR][KK]);                               \
+        HR_MMA(CUR, 1, 1); fb[NX][1] = lds_read16_off<((TAP) % 3) * 8192 + 2048>(bbase[KYR][KK]);                        \
+        HR_MMA(CUR, 0, 2); fb[NX][2] = lds_read16_off<((TAP) % 3) * 8192 + 4096>(bbase[KYR][KK]);                        \
+        HR_MMA(CUR, 1, 2); fb[NX][3] = lds_read16_off<((TAP) % 3) * 8192 + 6144>(bbase[KYR][KK]);                        \
+        HR_MMA(CUR, 0, 3);                                                                                              \
+        HR_MMA(CUR, 1, 3);                                                                                              \
+    }
+    // kernel row KY of the current (tile, chunk): six k-steps; NKY = (KY + 1) % 3, SBN = slab buffer of the row after this one
+#define HR_ROW(KY, NKY, SBN)                                                                                          \
+    {                                                                                                                  \
+        if ((KY) == 0) { HR_DRIP_READ(0) }                                                                              \
+        HR_KSTEP(0, 2, sb, (KY) * 3 + 1, KY, 0)                                                                         \
+        if ((KY) == 0) { HR_DRIP_STORE(0) }                                                                             \
+        w_pieces(NKY, 4, 6);                          /* the last two pieces of the next kernel row */                 \
+        if ((KY) == 1) { w_advance(); slab_pieces(7, HALO_MAX_ROUNDS); slab_advance(); }                                \
+        if ((KY) == 0) { HR_DRIP_READ(1) }                                                                              \
+        HR_KSTEP(1, 0, sb, (KY) * 3 + 1, KY, 1)                                                                         \
+        if ((KY) == 0) { HR_DRIP_STORE(1) HR_DRIP_READ(2) }                                                             \
+        HR_KSTEP(2, 1, sb, (KY) * 3 + 2, KY, 0)                                                                         \
+        if ((KY) == 0) { HR_DRIP_STORE(2) HR_DRIP_READ(3) }                                                             \
+        HR_KSTEP(0, 2, sb, (KY) * 3 + 2, KY, 1)                                                                         \
+        if ((KY) == 0) { HR_DRIP_STORE(3) d_on = false; }                                                               \
+        if ((KY) == 2 && last_chunk) set_rows(n_item < items ? n_item : c_item);                                       \
+        HSTAMP(4);                                                                                                     \
+        /* the next row's weights (and, before a new chunk, its slab) have landed for every wave; the row before this is free */ \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                               \
+        HSTAMP(5);                                                                                                     \
+        __builtin_amdgcn_s_barrier();                                                                                  \
+        asm volatile("" ::: "memory");                                                                                 \
+        HSTAMP(6);                                                                                                     \
+        HR_KSTEP(1, 0, SBN, (NKY) * 3, NKY, 0)                                                                          \
+        w_pieces(((KY) + 2) % 3, 0, 2);                                                                                 \
+        if ((KY) == 0) slab_pieces(0, 4);                                                                               \
+        HR_KSTEP(2, 1, SBN, (NKY) * 3, NKY, 1)                                                                          \
+        w_pieces(((KY) + 2) % 3, 2, 4);                                                                                 \
+        if ((KY) == 0) slab_pieces(4, 7);                                                                               \
+        HSTAMP(8);                                                                                                     \
+    }
+
+    // ---- prologue: first slab, kernel rows 0 and 1 (four of its six pieces), fragments of k-steps 0 and 1 -------------------
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    fa[0][0] = lds_read16(arel[0][0][0]); fa[0][1] = lds_read16(arel[0][1][0]);
+    fb[0][0] = lds_read16_off<0>(bbase[0][0]); fb[0][1] = lds_read16_off<2048>(bbase[0][0]);
+    fb[0][2] = lds_read16_off<4096>(bbase[0][0]); fb[0][3] = lds_read16_off<6144>(bbase[0][0]);
+    fa[1][0] = lds_read16(arel[0][0][1]); fa[1][1] = lds_read16(arel[0][1][1]);
+    fb[1][0] = lds_read16_off<0>(bbase[0][1]); fb[1][1] = lds_read16_off<2048>(bbase[0][1]);
+    fb[1][2] = lds_read16_off<4096>(bbase[0][1]); fb[1][3] = lds_read16_off<6144>(bbase[0][1]);
+
+#pragma unroll 1
+    for (;;) {
+        const bool last_chunk = c_chunk == nchunks - 1;
+        int n_item = c_item, n_chunk = c_chunk + 1;
+        if (n_chunk == nchunks) { n_chunk = 0; n_item += G; }
+        const unsigned sb = c_sbuf * slab_bytes, sbn = (c_sbuf ^ 1) * slab_bytes;
+        HR_ROW(0, 1, sb)
+        HR_ROW(1, 2, sb)
+        HR_ROW(2, 0, sbn)
+        if (last_chunk) {
+            // ---- epilogue of the tile (the next tile's first fragments are already in flight / in registers)
+            const int mtile = c_item / NT, ntile = c_item - mtile * NT;
+            const int g0 = mtile * TR;
+            const int npos = min(TR, NH - g0) * W;
+            if (!(p.h_abl & 4)) {
+                AT* const out = (AT*)p.out + ((size_t)g0 * W) * p.Cout + ntile * BN;
+                if (ACCUM) {                                              // data gradient added to the shortcut's: fp32 sum, rounded once
+#pragma unroll
+                    for (int a = 0; a < TM; ++a) {
+                        const int m = wave * WM + a * 16 + fr;
+                        if (m < npos) {
+#pragma unroll
+                            for (int b = 0; b < TN; ++b) {
+                                AT* o = out + (size_t)m * p.Cout + b * 16 + fq * 4;
+                                f32x4 v = acc[a][b];
+                                float4 e = Act<AT>::ld4(o);
+                                v[0] += e.x; v[1] += e.y; v[2] += e.z; v[3] += e.w;
+                                Act<AT>::st4(o, make_float4(v[0], v[1], v[2], v[3]));
+                            }
+                        }
+                    }
+                } else {
+                    // the accumulators hold 4 channels x 16 positions per register quad: stored directly that is eight 8-byte stores per
+                    // lane in 32-byte row segments.  Staged through LDS (16 positions x 128 B per fragment row block, 16-byte chunks
+                    // XOR-swizzled by position pair) every store instruction writes eight full 128-byte rows.
+                    char* const stg = (char*)red + wave * (DRIP ? 4096 : 2048);
+#pragma unroll
+                    for (int a = 0; a < TM; ++a) {
+#pragma unroll
+                        for (int b = 0; b < TN; ++b) {
+                            const f32x4 v = acc[a][b];
+                            AT h4[4] = {(AT)v[0], (AT)v[1], (AT)v[2], (AT)v[3]};
+                            *(uint2*)(stg + (DRIP ? a * 2048 : 0) + fr * 128 + (((b * 2 + (fq >> 1)) ^ ((fr >> 1) & 7)) << 4) + (fq & 1) * 8) =
+                                *(const uint2*)h4;
+                            {   // BatchNorm sums of what will be read back (unconditional: a branch here makes the compiler copy the
+                                // sum registers at every merge; a launch without statistics just does not write them)
+                                f32x4 r = {(float)h4[0], (float)h4[1], (float)h4[2], (float)h4[3]};
+                                if (wave * WM + a * 16 + fr >= npos) r = (f32x4){0.f, 0.f, 0.f, 0.f};
+                                cs[b] += r;
+                                cq[b] += r * r;
+                            }
+                        }
+                        if (!DRIP) {
+#pragma unroll
+                            for (int i2 = 0; i2 < 2; ++i2) {
+                                const int pos = i2 * 8 + (lane >> 3), ch = lane & 7;
+                                const uint4 q = *(const uint4*)(stg + pos * 128 + ((ch ^ ((pos >> 1) & 7)) << 4));
+                                const int m = wave * WM + a * 16 + pos;
+                                if (m < npos) *(uint4*)((char*)(out + (size_t)m * p.Cout) + ch * 16) = q;
+                            }
+                        }
+                    }
+                    if (DRIP) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staged (the asm reads of the drip do not wait for plain stores)
+                        d_on = true;
+                        d_npos = npos;
+                        d_ptr = (char*)(out + (size_t)d_m0 * p.Cout) + (lane & 7) * 16;
+                    }
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if (last_chunk) HSTAMP(10);
+        c_item = n_item; c_chunk = n_chunk; c_sbuf ^= 1;
+        if (c_item >= items) break;
+    }
+    // drain: the fragment reads issued for a kernel row that does not exist; the last tile's staged output
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (DRIP && d_on) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const v4i q = *(const v4i*)((const char*)red + wave * 4096 + (d >> 1) * 2048 + ((d & 1) * 8 + (lane >> 3)) * 128 +
+                                        (((lane & 7) ^ ((((d & 1) * 8 + (lane >> 3)) >> 1) & 7)) << 4));
+            if (d_m0 + d * 8 < d_npos) *(v4i*)(d_ptr + d * d_step) = q;
+        }
+    }
+    __syncthreads();                                                    // the staging tiles alias `red`, which the statistics use next
+    if (p.stats) halo_store_stats<TN, BN>(cs, cq, red, p.stats, p.Cout, blockIdx.x / NT, blockIdx.x % NT, wave, fr, fq, t, false);
+#ifdef HALO_STAMPS
+    if (wave == 0) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int i = lane; i < 255; i += 64) p.h_dbg[(size_t)blockIdx.x * 256 + i] = i < n_stamp ? stl[i] : 0;
+        if (lane == 0) p.h_dbg[(size_t)blockIdx.x * 256 + 255] = n_stamp;
+    }
+#endif
+#undef HR_ROW
+#undef HR_DRIP_READ
+#undef HR_DRIP_STORE
+#undef HR_KSTEP
+#undef HR_MMA
 }
 
 
@@ -1266,6 +1691,7 @@ struct ConvPlan {
     int bn;               // output-channel tile
     int halo;             // 0, or TM (4 / 2) of conv_halo2d_kernel: 2D 3x3 / 1 / pad 1, 16-bit storage, Cin % 64 == 0, Cout % 64 == 0
     int h_tr, h_rows, h_slab_bytes, h_nr, h_mtiles, h_dbuf;
+    int h_v5;             // conv_halo_rows_kernel (row-unit pipeline, one workgroup per CU) instead of conv_halo2d_kernel
     int h_grid;           // persistent workgroups of the halo launch (a multiple of the output-channel tiles)
     int h_wgrec;          // 1: one BatchNorm record per workgroup (h_grid / (Cout / 64) records), 0: one per row tile (h_mtiles)
     int stem;             // 1: conv_stem_kernel (2D, 4 stored input channels, stride 2, Cout 64, 16-bit storage); records = stem_grid
@@ -1303,7 +1729,7 @@ static int num_cus() {
 int tri_internal_num_cus() { return num_cus(); }                     // for conv_wgrad.hip (not part of the C ABI header)
 
 // geometry of conv_halo2d_kernel for row tiles of 64 * TM positions; false when the layer does not fit
-static bool halo_geometry(int B, int H, int W, int cout, int TM, ConvPlan* pl) {
+static bool halo_geometry(int B, int H, int W, int cin, int cout, int TM, ConvPlan* pl) {
     const int BM = 64 * TM, P = W + 2;
     if (W > BM) return false;
     const int TR = BM / W;
@@ -1326,6 +1752,20 @@ static bool halo_geometry(int B, int H, int W, int cout, int TM, ConvPlan* pl) {
         if (slots < NT) slots = NT;
         pl->h_grid = items < slots ? items : slots;
         pl->h_wgrec = items >= 4 * slots ? 1 : 0;
+        static int rows_kernel = -1;                                  // A/B switch: TRICOLO_HALO_ROWS=0 keeps conv_halo2d_kernel
+        if (rows_kernel < 0) { const char* e = getenv("TRICOLO_HALO_ROWS"); rows_kernel = e ? atoi(e) : 1; }
+        pl->h_v5 = 0;
+        // the row-unit pipeline wins where its one workgroup per CU is not short of bytes in flight: 64 input channels (resident filter
+        // bank, only slabs stream) and launches with at most one tile per CU (layer4 of the bench shape: 27 against 45 us); with
+        // several weight-streaming tiles per workgroup the three co-resident workgroups of conv_halo2d_kernel hide more latency
+        int g = num_cus() / NT * NT;
+        if (g < NT) g = NT;
+        if (rows_kernel && (cin == 64 || items <= g || rows_kernel == 2) && TM == 2 &&
+            2 * (size_t)slab + 3 * (size_t)HROWS_SLOT + 8192 <= 163840) {
+            pl->h_v5 = 1;
+            pl->h_grid = items < g ? items : g;
+            pl->h_wgrec = 1;                                          // one BatchNorm record per workgroup
+        }
     }
     return true;
 }
@@ -1390,10 +1830,10 @@ static ConvPlan conv_make_plan(int B, int ID, int IH, int IW, int cin, int OD, i
         // 128-position tiles: a ~25 KB slab + 24 KB ring lets three workgroups share a CU (the kernel is bound by instruction
         // issue and latency, not by operand bytes: occupancy matters more than the bigger tile's reuse)
         ConvPlan t2{};
-        const ConvPlan* pick = halo_geometry(B, IH, IW, cout, 2, &t2) ? &t2 : nullptr;
+        const ConvPlan* pick = halo_geometry(B, IH, IW, cin, cout, 2, &t2) ? &t2 : nullptr;
         if (pick) {
             pl.halo = pick->halo; pl.h_tr = pick->h_tr; pl.h_rows = pick->h_rows; pl.h_slab_bytes = pick->h_slab_bytes;
-            pl.h_nr = pick->h_nr; pl.h_mtiles = pick->h_mtiles; pl.h_dbuf = pick->h_dbuf; pl.h_grid = pick->h_grid; pl.h_wgrec = pick->h_wgrec;
+            pl.h_nr = pick->h_nr; pl.h_mtiles = pick->h_mtiles; pl.h_dbuf = pick->h_dbuf; pl.h_grid = pick->h_grid; pl.h_wgrec = pick->h_wgrec; pl.h_v5 = pick->h_v5;
             pl.bn = 64; pl.nunits = 9 * (cin / 64); pl.ksplit = 1; pl.per_split = pl.nunits;
             return pl;
         }
@@ -1442,13 +1882,42 @@ static int launch_dma(const ConvArgs& a, hipStream_t stream) {
     return tri_check_launch("tri_conv_splitk_finish");
 }
 
+#ifdef HALO_STAMPS
+static long long* g_halo_dbg = nullptr;
+#endif
 template <int TM, typename AT>
 static int launch_halo(ConvArgs& a, const ConvPlan& pl, hipStream_t stream) {
     a.h_tr = pl.h_tr; a.h_rows = pl.h_rows; a.h_slab_bytes = pl.h_slab_bytes; a.h_nr = pl.h_nr; a.h_mtiles = pl.h_mtiles;
     a.h_dbuf = pl.h_dbuf;
     { static int abl = -1; if (abl < 0) { const char* e = getenv("TRICOLO_HALO_ABL"); abl = e ? atoi(e) : 0; } a.h_abl = abl; }
     a.dP = make_fastdiv(a.IW + 2); a.dH2 = make_fastdiv(a.IH + 2);
+#ifdef HALO_STAMPS
+    a.h_dbg = g_halo_dbg;
+    const size_t smem = (size_t)pl.h_slab_bytes + (size_t)HALO_NR * 8192 + 2048 + 2048;
+#else
     const size_t smem = (size_t)pl.h_slab_bytes + (size_t)HALO_NR * 8192 + 2048;
+#endif
+    if (pl.h_v5) {
+#ifdef HALO_STAMPS
+        a.h_dbg = g_halo_dbg;
+        const bool drip = 2 * (size_t)pl.h_slab_bytes + 3 * (size_t)HROWS_SLOT + 16384 + 2048 <= 163840 && !a.accumulate;
+        const size_t smem5 = 2 * (size_t)pl.h_slab_bytes + 3 * (size_t)HROWS_SLOT + (drip ? 16384 : 8192) + 2048;
+#else
+        const bool drip = 2 * (size_t)pl.h_slab_bytes + 3 * (size_t)HROWS_SLOT + 16384 <= 163840 && !a.accumulate;
+        const size_t smem5 = 2 * (size_t)pl.h_slab_bytes + 3 * (size_t)HROWS_SLOT + (drip ? 16384 : 8192);
+#endif
+        static size_t attr5 = 0;
+        if (smem5 > attr5) {
+            hipFuncSetAttribute((const void*)conv_halo_rows_kernel<AT, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem5);
+            hipFuncSetAttribute((const void*)conv_halo_rows_kernel<AT, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem5);
+            hipFuncSetAttribute((const void*)conv_halo_rows_kernel<AT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem5);
+            attr5 = smem5;
+        }
+        if (a.accumulate) conv_halo_rows_kernel<AT, false, true><<<pl.h_grid, 256, smem5, stream>>>(a);
+        else if (drip) conv_halo_rows_kernel<AT, true, false><<<pl.h_grid, 256, smem5, stream>>>(a);
+        else conv_halo_rows_kernel<AT, false, false><<<pl.h_grid, 256, smem5, stream>>>(a);
+        return tri_check_launch("tri_conv(halo rows)");
+    }
     static size_t attr = 0;
     if (smem > attr) {
         hipFuncSetAttribute((const void*)conv_halo2d_kernel<TM, false, AT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -1572,7 +2041,7 @@ extern "C" int tri_conv_kernel_family(const TriConvDesc* d, int transposed, int 
                              : conv_make_plan(d->B, d->ID, d->IH, d->IW, d->Cin, d->OD, d->OH, d->OW, d->Cout, d->KD, d->KH, d->KW, d->stride,
                                               d->pad_d, d->pad_h, d->pad_w, split3);
     if (pl.stem && !transposed) return 4 | (64 << 8);
-    if (pl.halo) return 3 | (pl.halo << 8);
+    if (pl.halo) return (pl.h_v5 ? 5 : 3) | (pl.halo << 8);
     return (pl.dma ? 2 : 0) | (pl.bn << 8) | ((pl.ksplit > 1 || (pl.dma && tri_conv_kpad(d->KD * d->KH * d->KW, transposed ? d->Cout : d->Cin) / 64 > 128)) ? (1 << 16) : 0);
 }
 

@@ -81,6 +81,8 @@ def _igemm_symbol(g, transposed, split, t):
     fam, bn = code & 255, (code >> 8) & 255
     if fam == 4:
         return f"conv_stem_kernel<{g.kernel[1]}, {_TNAME[t.dtype]}>"
+    if fam == 5:
+        return f"conv_halo_rows_kernel<{_TNAME[t.dtype]}>"          # (store / accumulate variants under one name)
     if fam == 3:
         return f"conv_halo2d_kernel<{bn}, {_TNAME[t.dtype]}>"     # (both record variants under one name)
     if fam == 2:
