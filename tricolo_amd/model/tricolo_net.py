@@ -117,7 +117,10 @@ class TriCoLoNet(TriModule):
         # still starts late - the folding is not a pure function of the issue order - and the step time is the same.)
         # Eager steps are bound by the host's launch rate instead: there the short towers go first so that their kernels are
         # already queued on their streams while the host spends ~1.5 ms issuing the image tower (6.1 against 7.6 ms per step).
-        order = os.environ.get("TRICOLO_TOWER_ORDER") or ("itv" if torch.cuda.is_current_stream_capturing() else "tvi")
+        # Re-measured with the row-unit conv kernels (shorter layer1 / layer4, bench.py three times each): trimodal tvi 3.30 /
+        # itv 3.33-3.35 / vti 3.33-3.35 ms (config 5: 24.21 / 24.20); without a voxel tower (config 3) itv 4.67 / tvi 4.73.
+        capt_order = "tvi" if self.voxel_encoder is not None else "itv"
+        order = os.environ.get("TRICOLO_TOWER_ORDER") or (capt_order if torch.cuda.is_current_stream_capturing() else "tvi")
         s_text.wait_stream(main)
         vox = img = text = None
         vox_on_main = self.image_encoder is None
