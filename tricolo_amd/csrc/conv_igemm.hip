@@ -952,24 +952,33 @@ __global__ __launch_bounds__(256, WGREC ? 3 : 1) void conv_halo2d_kernel(const C
 // ================================================================================================ halo kernel, row-unit pipeline
 // Same tiles, slab and operand layouts as conv_halo2d_kernel, restructured around what its in-kernel stamps showed
 // (tools/probes/halo_probe.hip): per 8 KiB tap unit a wave spent ~130 cycles waiting for the weights, ~220 issuing the next two
-// DMA pieces and ~540 in the block of 16 MFMAs (256 cycles of matrix work) because every fragment read was exposed.  Here
+// DMA pieces and ~540 in the block of 16 MFMAs (256 cycles of matrix work): the compiler re-used four registers per operand and
+// waited for the LDS before every MFMA pair, the tap's fragment addresses were recomputed in front of the MFMAs, and the epilogue
+// spent ~4k cycles per tile in register copies around its branches.  Here
 //   * one ring slot is a kernel ROW of one 64-channel chunk (3 taps x 64 x 64 = 24 KiB): one barrier and one DMA wait per 48 MFMAs;
-//   * the fragments of k-step t + 2 are read (inline asm, three register sets) between the MFMAs of k-step t - across row units,
-//     chunks and tiles: the stream of row units of a workgroup is one software pipeline, the epilogue of a tile runs with the next
-//     tile's first fragments already in registers;
-//   * the next-but-one row unit's six weight pieces and the next chunk's (or tile's) slab pieces are issued in the k-steps right
-//     after the barrier that freed their buffers, four k-steps before the barrier that needs them (two slab buffers);
-//   * one workgroup per CU (148 KiB of LDS), BatchNorm sums carried in registers: one record per workgroup.
+//   * the fragments of k-step t + 2 are read (inline asm, three register sets) between the MFMAs of k-step t - across kernel rows,
+//     chunks and tiles: the stream of kernel rows of a workgroup is one software pipeline, the epilogue of a tile runs with the
+//     next tile's first fragments already in registers; every fragment address is a per-workgroup constant (no VALU in the k-steps);
+//   * the slab of the next (tile, chunk) is issued in the k-steps right after the barrier that freed its buffer (two slab buffers);
+//   * weights, three ways (NTL):
+//       NTL = 0  streamed: the row after the next one's six pieces are issued four k-steps before the barrier that needs them
+//                (launches with about one tile per workgroup: layer4 of the bench shape, 27 against 45 us);
+//       NTL >= 1 resident: the ring holds the three kernel rows of ONE 64-channel chunk while the workgroup runs that chunk for a
+//                group of up to NTL of its tiles, each with its own accumulators - a workgroup fetches every weight once per
+//                group instead of once per tile (a DMA piece costs the issuing wave ~115 cycles, and with one workgroup per CU
+//                nothing else runs meanwhile); with 64 input channels the ring IS the filter bank and is loaded once;
+//   * one workgroup per CU (<= 160 KiB of LDS), BatchNorm sums carried in registers: one record per workgroup.
 #define HROWS_SLOT (3 * 8192)
-// DRIP: the tile's output waits in a 4 KiB LDS tile per wave and leaves as one full-row store per k-step of the NEXT tile's first kernel
-// row: with every workgroup of the launch in step, stores issued in the epilogue all hit the memory system at once and the waves
-// sat ~4k cycles per tile in store issue (probe stamps).  Launches whose slabs leave no room for the 16 KiB (DRIP = false) store
-// from the epilogue through a 2 KiB tile per wave.
-template <typename AT, bool DRIP, bool ACCUM>
+// DRIP: the tile's output waits in a 4 KiB LDS tile per wave and leaves as one full-row store per k-step of the NEXT element's first
+// kernel row: with every workgroup of the launch in step, stores issued in the epilogue all hit the memory system at once.  Launches
+// whose slabs leave no room for the 16 KiB (DRIP = false) store from the epilogue through a 2 KiB tile per wave.
+template <typename AT, bool DRIP, bool ACCUM, int NTL>
 __global__ __launch_bounds__(256, 1) void conv_halo_rows_kernel(const ConvArgs p) {
     typedef Mma<typename OpOf<AT>::E> MM;
     typedef typename MM::v8 v8;
     constexpr int BN = 64, TN = 4, TM = 2, WM = 32, SLOT = HROWS_SLOT;
+    constexpr int NTLE = NTL < 1 ? 1 : NTL;                             // tiles per group
+    constexpr bool STREAM = NTL == 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int slab_bytes = p.h_slab_bytes;
     char* const ring = smem + 2 * slab_bytes;
@@ -987,13 +996,14 @@ __global__ __launch_bounds__(256, 1) void conv_halo_rows_kernel(const ConvArgs p
     const int items = p.h_mtiles * NT, G = gridDim.x;
     const int S = slab_bytes >> 12;
     const int zero_pix = p.h_rows * P;
-    const int sgn = p.transposed ? -1 : 1;                              // tap (ky, kx) reads the slab shifted by +-((ky - 1) P + kx - 1)
     const v4i in_rsrc = make_rsrc_words(p.in, p.in_bytes);
     const v4i w_rsrc = make_rsrc_words(p.w_hi, (unsigned)((size_t)p.Cout * p.Kpad * 2));
     const unsigned lds_slab0 = lds_addr(smem), lds_ring0 = lds_addr(ring);
     const unsigned dma_slab = lds_slab0 + wave * 1024, dma_ring = lds_ring0 + wave * 1024;
     const int whole = (TR % H == 0) ? 1 : 0;
     if ((int)blockIdx.x >= items) return;
+    const int n_my = (items - (int)blockIdx.x + G - 1) / G;             // tiles of this workgroup: items blockIdx.x + k G (one output-channel tile)
+    const bool w_once = !STREAM && nchunks == 1;                        // resident filter bank
 
     int woff[2];
 #pragma unroll
@@ -1001,34 +1011,33 @@ __global__ __launch_bounds__(256, 1) void conv_halo_rows_kernel(const ConvArgs p
         const int n = r * 32 + wave * 8 + (lane >> 3);
         woff[r] = (n * p.Kpad + (((lane & 7) ^ ((n >> 1) & 7)) << 3)) * 2;
     }
-    // ---- weight stream: one element per (tile, chunk); its three kernel rows go to ring slots 0, 1, 2 (slot == kernel row);
-    //      six 1 KiB pieces per wave and row
-    int w_item = blockIdx.x, w_chunk = 0;
-    const int w_nb = (blockIdx.x % NT) * BN * p.Kpad;                   // every tile of this workgroup has the same output-channel tile
-    auto w_pieces = [&](int ky, int j0, int j1) {
-        if (w_item < items) {
-            // the data gradient is the same correlation with the taps taken in reverse order (tap' = 8 - tap)
-            const int tap0 = p.transposed ? 8 - ky * 3 : ky * 3, tstep = p.transposed ? -1 : 1;
-            const int kb = (w_nb + w_chunk * 64) * 2;
-            const unsigned dst = dma_ring + ky * SLOT;
+    // ---- weights: kernel row ky of a chunk goes to ring slot ky; six 1 KiB pieces per wave and row
+    const int w_nb = (blockIdx.x % NT) * BN * p.Kpad;
+    auto w_row_pieces = [&](int chunk, int ky, int j0, int j1) {
+        // the data gradient is the same correlation with the taps taken in reverse order (tap' = 8 - tap)
+        const int tap0 = p.transposed ? 8 - ky * 3 : ky * 3, tstep = p.transposed ? -1 : 1;
+        const int kb = (w_nb + chunk * 64) * 2;
+        const unsigned dst = dma_ring + ky * SLOT;
 #pragma unroll
-            for (int j = 0; j < 6; ++j)
-                if (j >= j0 && j < j1)
-                    dma16_async(w_rsrc, dst + (j >> 1) * 8192 + (j & 1) * 4096, woff[j & 1] + kb + (tap0 + tstep * (j >> 1)) * p.Cin * 2);
-        }
+        for (int j = 0; j < 6; ++j)
+            if (j >= j0 && j < j1)
+                dma16_async(w_rsrc, dst + (j >> 1) * 8192 + (j & 1) * 4096, woff[j & 1] + kb + (tap0 + tstep * (j >> 1)) * p.Cin * 2);
+    };
+    // streamed mode: cursor over (tile, chunk) elements, three rows each
+    int w_k = 0, w_chunk = 0;                                           // tile index in this workgroup's list, chunk
+    auto w_pieces = [&](int ky, int j0, int j1) {
+        if (STREAM && w_k < n_my) w_row_pieces(w_chunk, ky, j0, j1);
     };
     auto w_advance = [&]() {
-        if (++w_chunk == nchunks) { w_chunk = 0; w_item += G; }
+        if (++w_chunk == nchunks) { w_chunk = 0; ++w_k; }
     };
-
     // issued first: the weight DMAs are in flight while the slab source table and the fragment addresses are computed
-    w_pieces(0, 0, 6);
-    if (nchunks == 1) {                                                 // 64 input channels: the three ring slots ARE the filter bank of this
-        w_pieces(1, 0, 6);                                              // workgroup's output-channel tile - loaded once, never streamed again
-        w_pieces(2, 0, 6);
-        w_item = items;
+    w_row_pieces(0, 0, 0, 6);
+    if (STREAM) {
+        w_row_pieces(0, 1, 0, 4);
     } else {
-        w_pieces(1, 0, 4);
+        w_row_pieces(0, 1, 0, 6);
+        w_row_pieces(0, 2, 0, 6);
     }
 
     // ---- geometry-only lane constants (as conv_halo2d_kernel) ----------------------------------------------------------
@@ -1054,23 +1063,13 @@ __global__ __launch_bounds__(256, 1) void conv_halo_rows_kernel(const ConvArgs p
             soff[r] = ok ? ((grel * W + sx - 1) * p.Cin + ((slot ^ ((sp >> 1) & 7)) << 3)) * 2 : -1;
         }
     }
-    int pixc[TM];
-#pragma unroll
-    for (int a = 0; a < TM; ++a) {
-        const unsigned pa = wave * WM + a * 16 + fr;
-        const int j = (int)fdiv(pa, p.dOW), x = (int)pa - j * W;
-        const int i = whole ? (int)fdiv((unsigned)j, p.dOH) : 0;
-        pixc[a] = (j + 1 + 2 * i) * P + x + 1;
-    }
-    unsigned boff[2];
-    boff[0] = fr * 128 + (((fq ^ (fr >> 1)) & 7) << 4);
-    boff[1] = boff[0] ^ 64;
-
-    // ---- slab stream: one element per (tile, chunk), alternating between the two slab buffers -------------------------------
-    int s_item = blockIdx.x, s_chunk = 0, s_buf = 0, s_cb = 0;
+    // ---- slab stream: one element per (group, chunk, tile of the group), alternating between the two slab buffers -------------
+    int s_g = 0, s_chunk = 0, s_tl = 0, s_buf = 0, s_cb = 0;
     unsigned s_kill = 0;
+    auto grp_n = [&](int g) { return min(NTLE, n_my - g); };
     auto slab_setup = [&]() {                                           // source constants of the element the cursor points at
-        const int g0_ = (s_item / NT) * TR;
+        const int item_ = (int)blockIdx.x + (s_g + s_tl) * G;
+        const int g0_ = (item_ / NT) * TR;
         int top_ok = 1, bot_ok = 1;
         if (!whole) {
             const int h0_ = g0_ - (int)fdiv((unsigned)g0_, p.dOH) * H;
@@ -1081,7 +1080,7 @@ __global__ __launch_bounds__(256, 1) void conv_halo_rows_kernel(const ConvArgs p
         s_cb = g0_ * W * p.Cin * 2 + s_chunk * 128;
     };
     auto slab_pieces = [&](int r0, int r1) {
-        if (s_item < items) {
+        if (s_g < n_my) {
             const unsigned dst = dma_slab + s_buf * slab_bytes;
 #pragma unroll
             for (int r = 0; r < HALO_MAX_ROUNDS; ++r)
@@ -1091,20 +1090,35 @@ __global__ __launch_bounds__(256, 1) void conv_halo_rows_kernel(const ConvArgs p
     };
     auto slab_advance = [&]() {
         s_buf ^= 1;
-        if (++s_chunk == nchunks) { s_chunk = 0; s_item += G; }
-        if (s_item < items) slab_setup();
+        if (++s_tl == grp_n(s_g)) {
+            s_tl = 0;
+            if (++s_chunk == nchunks) { s_chunk = 0; s_g += NTLE; }
+        }
+        if (s_g < n_my) slab_setup();
     };
     slab_setup();                                                       // the first slab, before the remaining constants
     slab_pieces(0, HALO_MAX_ROUNDS);
     slab_advance();
+
+    int pixc[TM];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+        const unsigned pa = wave * WM + a * 16 + fr;
+        const int j = (int)fdiv(pa, p.dOW), x = (int)pa - j * W;
+        const int i = whole ? (int)fdiv((unsigned)j, p.dOH) : 0;
+        pixc[a] = (j + 1 + 2 * i) * P + x + 1;
+    }
     // ---- fragment addresses: every tap's slab address of this lane's two fragment rows, both 64-byte halves (buffer 0; the
     //      other slab buffer is + slab_bytes), and the weight fragment bases of the three ring slots - no address arithmetic
     //      is left in the k-steps
     unsigned arel[9][TM][2], bbase[3][2];
+    {
+        const unsigned boff = fr * 128 + (((fq ^ (fr >> 1)) & 7) << 4);
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-        bbase[ky][0] = lds_ring0 + ky * SLOT + boff[0];
-        bbase[ky][1] = lds_ring0 + ky * SLOT + boff[1];
+        for (int ky = 0; ky < 3; ++ky) {
+            bbase[ky][0] = lds_ring0 + ky * SLOT + boff;
+            bbase[ky][1] = lds_ring0 + ky * SLOT + (boff ^ 64);
+        }
     }
     int cur_npos = -1;
     auto set_rows = [&](int item_) {                                    // rows past the end of the last tile read the zero pixel
@@ -1127,14 +1141,16 @@ __global__ __launch_bounds__(256, 1) void conv_halo_rows_kernel(const ConvArgs p
 
     // ---- fragments: three register sets, set of k-step t = t % 3 (six k-steps per kernel row) -----------------------------
     v4i fa[3][TM], fb[3][TN];
-    f32x4 acc[TM][TN], cs[TN], cq[TN];
+    f32x4 acc[NTLE][TM][TN], cs[TN], cq[TN];
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
         cs[b] = (f32x4){0.f, 0.f, 0.f, 0.f}; cq[b] = cs[b];
 #pragma unroll
-        for (int a = 0; a < TM; ++a) acc[a][b] = cs[b];
+        for (int q = 0; q < NTLE; ++q)
+#pragma unroll
+            for (int a = 0; a < TM; ++a) acc[q][a][b] = cs[b];
     }
-    int c_item = blockIdx.x, c_chunk = 0, c_sbuf = 0;
+    int c_g = 0, c_chunk = 0, c_sbuf = 0;
     // drip state: staged tile of the previous epilogue (rows m0 + 8 d, d = 0..3, 16 bytes per lane)
     const unsigned d_lds0 = lds_addr(red) + wave * 4096 + (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 4) & 3)) << 4);
     const unsigned d_lds1 = lds_addr(red) + wave * 4096 + (8 + (lane >> 3)) * 128 + (((lane & 7) ^ (4 + ((lane >> 4) & 3))) << 4);
@@ -1151,142 +1167,183 @@ __global__ __launch_bounds__(256, 1) void conv_halo_rows_kernel(const ConvArgs p
         if (d_m0 + (D) * 8 < d_npos) *(v4i*)(d_ptr + (D) * d_step) = d_q;                  \
     }
 
-#define HR_MMA(SET, A, B) acc[A][B] = MM::mma(__builtin_bit_cast(v8, fb[SET][B]), __builtin_bit_cast(v8, fa[SET][A]), acc[A][B])
+#define HR_MMA(TL, SET, A, B) acc[TL][A][B] = MM::mma(__builtin_bit_cast(v8, fb[SET][B]), __builtin_bit_cast(v8, fa[SET][A]), acc[TL][A][B])
     // k-step: wait for set CUR, then its eight MFMAs with the six reads of set NX between them (the fragments of the k-step after
     // the next: tap TAP, half KK of the 64 channels, slab buffer offset SB, ring slot KYR)
-#define HR_KSTEP(CUR, NX, SB, TAP, KYR, KK)                                                                           \
+#define HR_KSTEP(TL, CUR, NX, SB, TAP, KYR, KK)                                                                       \
     {                                                                                                                  \
         frag_wait<6>(fa[CUR], fb[CUR]);                                                                                \
-        HR_MMA(CUR, 0, 0); fa[NX][0] = lds_read16(arel[TAP][0][KK] + (SB));                                              \
-        HR_MMA(CUR, 1, 0); fa[NX][1] = lds_read16(arel[TAP][1][KK] + (SB));                                              \
-        HR_MMA(CUR, 0, 1); fb[NX][0] = lds_read16_off<((TAP) % 3) * 8192>(bbase[KYR][KK]);                               \
-        HR_MMA(CUR, 1, 1); fb[NX][1] = lds_read16_off<((TAP) % 3) * 8192 + 2048>(bbase[KYR][KK]);                        \
-        HR_MMA(CUR, 0, 2); fb[NX][2] = lds_read16_off<((TAP) % 3) * 8192 + 4096>(bbase[KYR][KK]);                        \
-        HR_MMA(CUR, 1, 2); fb[NX][3] = lds_read16_off<((TAP) % 3) * 8192 + 6144>(bbase[KYR][KK]);                        \
-        HR_MMA(CUR, 0, 3);                                                                                              \
-        HR_MMA(CUR, 1, 3);                                                                                              \
+        HR_MMA(TL, CUR, 0, 0); fa[NX][0] = lds_read16(arel[TAP][0][KK] + (SB));                                          \
+        HR_MMA(TL, CUR, 1, 0); fa[NX][1] = lds_read16(arel[TAP][1][KK] + (SB));                                          \
+        HR_MMA(TL, CUR, 0, 1); fb[NX][0] = lds_read16_off<((TAP) % 3) * 8192>(bbase[KYR][KK]);                           \
+        HR_MMA(TL, CUR, 1, 1); fb[NX][1] = lds_read16_off<((TAP) % 3) * 8192 + 2048>(bbase[KYR][KK]);                    \
+        HR_MMA(TL, CUR, 0, 2); fb[NX][2] = lds_read16_off<((TAP) % 3) * 8192 + 4096>(bbase[KYR][KK]);                    \
+        HR_MMA(TL, CUR, 1, 2); fb[NX][3] = lds_read16_off<((TAP) % 3) * 8192 + 6144>(bbase[KYR][KK]);                    \
+        HR_MMA(TL, CUR, 0, 3);                                                                                          \
+        HR_MMA(TL, CUR, 1, 3);                                                                                          \
     }
-    // kernel row KY of the current (tile, chunk): six k-steps; NKY = (KY + 1) % 3, SBN = slab buffer of the row after this one
-#define HR_ROW(KY, NKY, SBN)                                                                                          \
+    // kernel row KY of the current element: six k-steps; NKY = (KY + 1) % 3, SBN = slab buffer of the row after this one
+#define HR_ROW(TL, KY, NKY, SBN)                                                                                      \
     {                                                                                                                  \
         if ((KY) == 0) { HR_DRIP_READ(0) }                                                                              \
-        HR_KSTEP(0, 2, sb, (KY) * 3 + 1, KY, 0)                                                                         \
+        HR_KSTEP(TL, 0, 2, sb, (KY) * 3 + 1, KY, 0)                                                                     \
         if ((KY) == 0) { HR_DRIP_STORE(0) }                                                                             \
-        w_pieces(NKY, 4, 6);                          /* the last two pieces of the next kernel row */                 \
-        if ((KY) == 1) { w_advance(); slab_pieces(7, HALO_MAX_ROUNDS); slab_advance(); }                                \
+        w_pieces(NKY, 4, 6);                          /* streamed: the last two pieces of the next kernel row */        \
+        if ((KY) == 1) { if (STREAM) w_advance(); slab_pieces(7, HALO_MAX_ROUNDS); slab_advance(); }                    \
         if ((KY) == 0) { HR_DRIP_READ(1) }                                                                              \
-        HR_KSTEP(1, 0, sb, (KY) * 3 + 1, KY, 1)                                                                         \
+        HR_KSTEP(TL, 1, 0, sb, (KY) * 3 + 1, KY, 1)                                                                     \
         if ((KY) == 0) { HR_DRIP_STORE(1) HR_DRIP_READ(2) }                                                             \
-        HR_KSTEP(2, 1, sb, (KY) * 3 + 2, KY, 0)                                                                         \
+        HR_KSTEP(TL, 2, 1, sb, (KY) * 3 + 2, KY, 0)                                                                     \
         if ((KY) == 0) { HR_DRIP_STORE(2) HR_DRIP_READ(3) }                                                             \
-        HR_KSTEP(0, 2, sb, (KY) * 3 + 2, KY, 1)                                                                         \
+        HR_KSTEP(TL, 0, 2, sb, (KY) * 3 + 2, KY, 1)                                                                     \
         if ((KY) == 0) { HR_DRIP_STORE(3) d_on = false; }                                                               \
-        if ((KY) == 2 && last_chunk) set_rows(n_item < items ? n_item : c_item);                                       \
+        if ((KY) == 2) set_rows(n_item);                                                                               \
         HSTAMP(4);                                                                                                     \
-        /* the next row's weights (and, before a new chunk, its slab) have landed for every wave; the row before this is free */ \
+        /* the next row's weights (streamed) and, before a new element, its slab have landed for every wave; the row before this is free */ \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                               \
         HSTAMP(5);                                                                                                     \
         __builtin_amdgcn_s_barrier();                                                                                  \
         asm volatile("" ::: "memory");                                                                                 \
         HSTAMP(6);                                                                                                     \
-        HR_KSTEP(1, 0, SBN, (NKY) * 3, NKY, 0)                                                                          \
+        HR_KSTEP(TL, 1, 0, SBN, (NKY) * 3, NKY, 0)                                                                      \
         w_pieces(((KY) + 2) % 3, 0, 2);                                                                                 \
         if ((KY) == 0) slab_pieces(0, 4);                                                                               \
-        HR_KSTEP(2, 1, SBN, (NKY) * 3, NKY, 1)                                                                          \
+        HR_KSTEP(TL, 2, 1, SBN, (NKY) * 3, NKY, 1)                                                                      \
         w_pieces(((KY) + 2) % 3, 2, 4);                                                                                 \
         if ((KY) == 0) slab_pieces(4, 7);                                                                               \
         HSTAMP(8);                                                                                                     \
     }
+    // the first fragments of an element (k-steps 0 and 1 of its kernel row 0) from slab buffer offset SB
+#define HR_FIRST_READS(SB)                                                                                            \
+    {                                                                                                                  \
+        fa[0][0] = lds_read16(arel[0][0][0] + (SB)); fa[0][1] = lds_read16(arel[0][1][0] + (SB));                        \
+        fb[0][0] = lds_read16_off<0>(bbase[0][0]); fb[0][1] = lds_read16_off<2048>(bbase[0][0]);                        \
+        fb[0][2] = lds_read16_off<4096>(bbase[0][0]); fb[0][3] = lds_read16_off<6144>(bbase[0][0]);                     \
+        fa[1][0] = lds_read16(arel[0][0][1] + (SB)); fa[1][1] = lds_read16(arel[0][1][1] + (SB));                        \
+        fb[1][0] = lds_read16_off<0>(bbase[0][1]); fb[1][1] = lds_read16_off<2048>(bbase[0][1]);                        \
+        fb[1][2] = lds_read16_off<4096>(bbase[0][1]); fb[1][3] = lds_read16_off<6144>(bbase[0][1]);                     \
+    }
+    // element TL of the group: three kernel rows, then (after the last chunk) the tile's epilogue
+#define HR_ELEM(TL)                                                                                                   \
+    if ((TL) < NTLE && (TL) < ng) {                                                                                    \
+        const int c_item = (int)blockIdx.x + (c_g + (TL)) * G;                                                         \
+        /* the element after this one (its first fragments are read in kernel row 2): next tile of the group, else next (chunk, group) */ \
+        int n_item = c_item + G;                                                                                       \
+        if ((TL) + 1 >= ng) n_item = (int)blockIdx.x + (last_chunk ? c_g + NTLE : c_g) * G;                            \
+        if (n_item >= items) n_item = c_item;                                                                          \
+        const unsigned sb = c_sbuf * slab_bytes, sbn = (c_sbuf ^ 1) * slab_bytes;                                      \
+        HR_ROW(TL, 0, 1, sb)                                                                                            \
+        HR_ROW(TL, 1, 2, sb)                                                                                            \
+        HR_ROW(TL, 2, 0, sbn)                                                                                           \
+        c_sbuf ^= 1;                                                                                                   \
+        if (last_chunk) {                                                                                              \
+            epilogue(acc[TL], c_item);                                                                                 \
+            HSTAMP(10);                                                                                                \
+        }                                                                                                              \
+    }
 
-    // ---- prologue: first slab, kernel rows 0 and 1 (four of its six pieces), fragments of k-steps 0 and 1 -------------------
+    auto epilogue = [&](f32x4 (&ac)[TM][TN], int c_item) __attribute__((always_inline)) {
+        // ---- epilogue of the tile (the next element's first fragments are already in flight / in registers)
+        const int mtile = c_item / NT, ntile = c_item - mtile * NT;
+        const int g0 = mtile * TR;
+        const int npos = min(TR, NH - g0) * W;
+        if (!(p.h_abl & 4)) {
+            AT* const out = (AT*)p.out + ((size_t)g0 * W) * p.Cout + ntile * BN;
+            if (ACCUM) {                                                  // data gradient added to the shortcut's: fp32 sum, rounded once
+#pragma unroll
+                for (int a = 0; a < TM; ++a) {
+                    const int m = wave * WM + a * 16 + fr;
+                    if (m < npos) {
+#pragma unroll
+                        for (int b = 0; b < TN; ++b) {
+                            AT* o = out + (size_t)m * p.Cout + b * 16 + fq * 4;
+                            f32x4 v = ac[a][b];
+                            float4 e = Act<AT>::ld4(o);
+                            v[0] += e.x; v[1] += e.y; v[2] += e.z; v[3] += e.w;
+                            Act<AT>::st4(o, make_float4(v[0], v[1], v[2], v[3]));
+                        }
+                    }
+                }
+            } else {
+                // the accumulators hold 4 channels x 16 positions per register quad: stored directly that is eight 8-byte stores per
+                // lane in 32-byte row segments.  Staged through LDS (16 positions x 128 B per fragment row block, 16-byte chunks
+                // XOR-swizzled by position pair) every store instruction writes eight full 128-byte rows.
+                char* const stg = (char*)red + wave * (DRIP ? 4096 : 2048);   // (`red` itself is only used after the last tile)
+#pragma unroll
+                for (int a = 0; a < TM; ++a) {
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) {
+                        const f32x4 v = ac[a][b];
+                        AT h4[4] = {(AT)v[0], (AT)v[1], (AT)v[2], (AT)v[3]};
+                        *(uint2*)(stg + (DRIP ? a * 2048 : 0) + fr * 128 + (((b * 2 + (fq >> 1)) ^ ((fr >> 1) & 7)) << 4) + (fq & 1) * 8) =
+                            *(const uint2*)h4;
+                        {   // BatchNorm sums of what will be read back (unconditional: a branch here makes the compiler copy the
+                            // sum registers at every merge; a launch without statistics just does not write them)
+                            f32x4 r = {(float)h4[0], (float)h4[1], (float)h4[2], (float)h4[3]};
+                            if (wave * WM + a * 16 + fr >= npos) r = (f32x4){0.f, 0.f, 0.f, 0.f};
+                            cs[b] += r;
+                            cq[b] += r * r;
+                        }
+                    }
+                    if (!DRIP) {
+#pragma unroll
+                        for (int i2 = 0; i2 < 2; ++i2) {
+                            const int pos = i2 * 8 + (lane >> 3), ch = lane & 7;
+                            const uint4 q = *(const uint4*)(stg + pos * 128 + ((ch ^ ((pos >> 1) & 7)) << 4));
+                            const int m = wave * WM + a * 16 + pos;
+                            if (m < npos) *(uint4*)((char*)(out + (size_t)m * p.Cout) + ch * 16) = q;
+                        }
+                    }
+                }
+                if (DRIP) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staged (the asm reads of the drip do not wait for plain stores)
+                    d_on = true;
+                    d_npos = npos;
+                    d_ptr = (char*)(out + (size_t)d_m0 * p.Cout) + (lane & 7) * 16;
+                }
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b) ac[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+
+    HSTAMP(2);
+    // ---- prologue: the first slab and weights have been issued; fragments of k-steps 0 and 1 --------------------------------
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    fa[0][0] = lds_read16(arel[0][0][0]); fa[0][1] = lds_read16(arel[0][1][0]);
-    fb[0][0] = lds_read16_off<0>(bbase[0][0]); fb[0][1] = lds_read16_off<2048>(bbase[0][0]);
-    fb[0][2] = lds_read16_off<4096>(bbase[0][0]); fb[0][3] = lds_read16_off<6144>(bbase[0][0]);
-    fa[1][0] = lds_read16(arel[0][0][1]); fa[1][1] = lds_read16(arel[0][1][1]);
-    fb[1][0] = lds_read16_off<0>(bbase[0][1]); fb[1][1] = lds_read16_off<2048>(bbase[0][1]);
-    fb[1][2] = lds_read16_off<4096>(bbase[0][1]); fb[1][3] = lds_read16_off<6144>(bbase[0][1]);
+    HR_FIRST_READS(0u)
+    HSTAMP(3);
 
 #pragma unroll 1
-    for (;;) {
+    for (;;) {                                                          // one (group, chunk) per iteration
+        const int ng = grp_n(c_g);
         const bool last_chunk = c_chunk == nchunks - 1;
-        int n_item = c_item, n_chunk = c_chunk + 1;
-        if (n_chunk == nchunks) { n_chunk = 0; n_item += G; }
-        const unsigned sb = c_sbuf * slab_bytes, sbn = (c_sbuf ^ 1) * slab_bytes;
-        HR_ROW(0, 1, sb)
-        HR_ROW(1, 2, sb)
-        HR_ROW(2, 0, sbn)
-        if (last_chunk) {
-            // ---- epilogue of the tile (the next tile's first fragments are already in flight / in registers)
-            const int mtile = c_item / NT, ntile = c_item - mtile * NT;
-            const int g0 = mtile * TR;
-            const int npos = min(TR, NH - g0) * W;
-            if (!(p.h_abl & 4)) {
-                AT* const out = (AT*)p.out + ((size_t)g0 * W) * p.Cout + ntile * BN;
-                if (ACCUM) {                                              // data gradient added to the shortcut's: fp32 sum, rounded once
-#pragma unroll
-                    for (int a = 0; a < TM; ++a) {
-                        const int m = wave * WM + a * 16 + fr;
-                        if (m < npos) {
-#pragma unroll
-                            for (int b = 0; b < TN; ++b) {
-                                AT* o = out + (size_t)m * p.Cout + b * 16 + fq * 4;
-                                f32x4 v = acc[a][b];
-                                float4 e = Act<AT>::ld4(o);
-                                v[0] += e.x; v[1] += e.y; v[2] += e.z; v[3] += e.w;
-                                Act<AT>::st4(o, make_float4(v[0], v[1], v[2], v[3]));
-                            }
-                        }
-                    }
-                } else {
-                    // the accumulators hold 4 channels x 16 positions per register quad: stored directly that is eight 8-byte stores per
-                    // lane in 32-byte row segments.  Staged through LDS (16 positions x 128 B per fragment row block, 16-byte chunks
-                    // XOR-swizzled by position pair) every store instruction writes eight full 128-byte rows.
-                    char* const stg = (char*)red + wave * (DRIP ? 4096 : 2048);
-#pragma unroll
-                    for (int a = 0; a < TM; ++a) {
-#pragma unroll
-                        for (int b = 0; b < TN; ++b) {
-                            const f32x4 v = acc[a][b];
-                            AT h4[4] = {(AT)v[0], (AT)v[1], (AT)v[2], (AT)v[3]};
-                            *(uint2*)(stg + (DRIP ? a * 2048 : 0) + fr * 128 + (((b * 2 + (fq >> 1)) ^ ((fr >> 1) & 7)) << 4) + (fq & 1) * 8) =
-                                *(const uint2*)h4;
-                            {   // BatchNorm sums of what will be read back (unconditional: a branch here makes the compiler copy the
-                                // sum registers at every merge; a launch without statistics just does not write them)
-                                f32x4 r = {(float)h4[0], (float)h4[1], (float)h4[2], (float)h4[3]};
-                                if (wave * WM + a * 16 + fr >= npos) r = (f32x4){0.f, 0.f, 0.f, 0.f};
-                                cs[b] += r;
-                                cq[b] += r * r;
-                            }
-                        }
-                        if (!DRIP) {
-#pragma unroll
-                            for (int i2 = 0; i2 < 2; ++i2) {
-                                const int pos = i2 * 8 + (lane >> 3), ch = lane & 7;
-                                const uint4 q = *(const uint4*)(stg + pos * 128 + ((ch ^ ((pos >> 1) & 7)) << 4));
-                                const int m = wave * WM + a * 16 + pos;
-                                if (m < npos) *(uint4*)((char*)(out + (size_t)m * p.Cout) + ch * 16) = q;
-                            }
-                        }
-                    }
-                    if (DRIP) {
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staged (the asm reads of the drip do not wait for plain stores)
-                        d_on = true;
-                        d_npos = npos;
-                        d_ptr = (char*)(out + (size_t)d_m0 * p.Cout) + (lane & 7) * 16;
-                    }
-                }
-            }
-#pragma unroll
-            for (int a = 0; a < TM; ++a)
-#pragma unroll
-                for (int b = 0; b < TN; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        HR_ELEM(0)
+        HR_ELEM(1)
+        HR_ELEM(2)
+        HR_ELEM(3)
+        int n_g = c_g, n_chunk = c_chunk + 1;
+        if (n_chunk == nchunks) { n_chunk = 0; n_g += NTLE; }
+        if (n_g >= n_my) break;
+        if (!STREAM && !w_once) {
+            // the ring changes chunk: every wave is done with the old one (its last reads were waited for in the final k-steps; the
+            // fragments prefetched for the next element came from the OLD weights and are read again below)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            w_row_pieces(n_chunk, 0, 0, 6);
+            w_row_pieces(n_chunk, 1, 0, 6);
+            w_row_pieces(n_chunk, 2, 0, 6);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const unsigned sb0 = c_sbuf * slab_bytes;
+            HR_FIRST_READS(sb0)
         }
-        if (last_chunk) HSTAMP(10);
-        c_item = n_item; c_chunk = n_chunk; c_sbuf ^= 1;
-        if (c_item >= items) break;
+        c_g = n_g; c_chunk = n_chunk;
     }
     // drain: the fragment reads issued for a kernel row that does not exist; the last tile's staged output
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1300,6 +1357,7 @@ __global__ __launch_bounds__(256, 1) void conv_halo_rows_kernel(const ConvArgs p
     }
     __syncthreads();                                                    // the staging tiles alias `red`, which the statistics use next
     if (p.stats) halo_store_stats<TN, BN>(cs, cq, red, p.stats, p.Cout, blockIdx.x / NT, blockIdx.x % NT, wave, fr, fq, t, false);
+    HSTAMP(11);
 #ifdef HALO_STAMPS
     if (wave == 0) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1307,6 +1365,8 @@ __global__ __launch_bounds__(256, 1) void conv_halo_rows_kernel(const ConvArgs p
         if (lane == 0) p.h_dbg[(size_t)blockIdx.x * 256 + 255] = n_stamp;
     }
 #endif
+#undef HR_ELEM
+#undef HR_FIRST_READS
 #undef HR_ROW
 #undef HR_DRIP_READ
 #undef HR_DRIP_STORE
@@ -1755,13 +1815,9 @@ static bool halo_geometry(int B, int H, int W, int cin, int cout, int TM, ConvPl
         static int rows_kernel = -1;                                  // A/B switch: TRICOLO_HALO_ROWS=0 keeps conv_halo2d_kernel
         if (rows_kernel < 0) { const char* e = getenv("TRICOLO_HALO_ROWS"); rows_kernel = e ? atoi(e) : 1; }
         pl->h_v5 = 0;
-        // the row-unit pipeline wins where its one workgroup per CU is not short of bytes in flight: 64 input channels (resident filter
-        // bank, only slabs stream) and launches with at most one tile per CU (layer4 of the bench shape: 27 against 45 us); with
-        // several weight-streaming tiles per workgroup the three co-resident workgroups of conv_halo2d_kernel hide more latency
         int g = num_cus() / NT * NT;
         if (g < NT) g = NT;
-        if (rows_kernel && (cin == 64 || items <= g || rows_kernel == 2) && TM == 2 &&
-            2 * (size_t)slab + 3 * (size_t)HROWS_SLOT + 8192 <= 163840) {
+        if (rows_kernel && TM == 2 && 2 * (size_t)slab + 3 * (size_t)HROWS_SLOT + 8192 <= 163840) {
             pl->h_v5 = 1;
             pl->h_grid = items < g ? items : g;
             pl->h_wgrec = 1;                                          // one BatchNorm record per workgroup
@@ -1900,22 +1956,45 @@ static int launch_halo(ConvArgs& a, const ConvPlan& pl, hipStream_t stream) {
     if (pl.h_v5) {
 #ifdef HALO_STAMPS
         a.h_dbg = g_halo_dbg;
-        const bool drip = 2 * (size_t)pl.h_slab_bytes + 3 * (size_t)HROWS_SLOT + 16384 + 2048 <= 163840 && !a.accumulate;
-        const size_t smem5 = 2 * (size_t)pl.h_slab_bytes + 3 * (size_t)HROWS_SLOT + (drip ? 16384 : 8192) + 2048;
+        const size_t extra = 2048;
 #else
-        const bool drip = 2 * (size_t)pl.h_slab_bytes + 3 * (size_t)HROWS_SLOT + 16384 <= 163840 && !a.accumulate;
-        const size_t smem5 = 2 * (size_t)pl.h_slab_bytes + 3 * (size_t)HROWS_SLOT + (drip ? 16384 : 8192);
+        const size_t extra = 0;
 #endif
-        static size_t attr5 = 0;
-        if (smem5 > attr5) {
-            hipFuncSetAttribute((const void*)conv_halo_rows_kernel<AT, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem5);
-            hipFuncSetAttribute((const void*)conv_halo_rows_kernel<AT, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem5);
-            hipFuncSetAttribute((const void*)conv_halo_rows_kernel<AT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem5);
-            attr5 = smem5;
-        }
-        if (a.accumulate) conv_halo_rows_kernel<AT, false, true><<<pl.h_grid, 256, smem5, stream>>>(a);
-        else if (drip) conv_halo_rows_kernel<AT, true, false><<<pl.h_grid, 256, smem5, stream>>>(a);
-        else conv_halo_rows_kernel<AT, false, false><<<pl.h_grid, 256, smem5, stream>>>(a);
+        const bool drip = 2 * (size_t)pl.h_slab_bytes + 3 * (size_t)HROWS_SLOT + 16384 + extra <= 163840 && !a.accumulate;
+        const size_t smem5 = 2 * (size_t)pl.h_slab_bytes + 3 * (size_t)HROWS_SLOT + (drip ? 16384 : 8192) + extra;
+        // weights: resident filter bank (64 input channels: NTL 1) or streamed (NTL 0).  The kernel also runs groups of 2 / 4 tiles per
+        // resident chunk (NTL 2 / 4, TRICOLO_HALO_NTL): measured no better than streaming on any configuration (profiles/r2/NOTES), so
+        // those instantiations are only built with -DHALO_NTL_EXPERIMENT
+        int ntl = a.Cin == 64 ? 1 : 0;
+#ifdef HALO_NTL_EXPERIMENT
+        { static int f = -1; if (f < 0) { const char* e = getenv("TRICOLO_HALO_NTL"); f = e ? atoi(e) : 0; }
+          const int items = pl.h_mtiles * (a.Cout / 64), per_wg = (items + pl.h_grid - 1) / pl.h_grid;
+          if (f && a.Cin != 64 && per_wg > 1) ntl = per_wg == 2 ? 2 : 4; }
+#endif
+#define TRI_ROWS_LAUNCH(DRIP_, ACC_, NTL_)                                                                                          \
+        do {                                                                                                                        \
+            static size_t attr5 = 0;                                                                                                \
+            if (smem5 > attr5) {                                                                                                    \
+                hipFuncSetAttribute((const void*)conv_halo_rows_kernel<AT, DRIP_, ACC_, NTL_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    (int)smem5);                                                                                    \
+                attr5 = smem5;                                                                                                      \
+            }                                                                                                                       \
+            conv_halo_rows_kernel<AT, DRIP_, ACC_, NTL_><<<pl.h_grid, 256, smem5, stream>>>(a);                                      \
+        } while (0)
+#define TRI_ROWS_MODE(NTL_)                                                                                                         \
+        do {                                                                                                                        \
+            if (a.accumulate) TRI_ROWS_LAUNCH(false, true, NTL_);                                                                   \
+            else if (drip) TRI_ROWS_LAUNCH(true, false, NTL_);                                                                      \
+            else TRI_ROWS_LAUNCH(false, false, NTL_);                                                                               \
+        } while (0)
+        if (ntl == 0) TRI_ROWS_MODE(0);
+        else if (ntl == 1) TRI_ROWS_MODE(1);
+#ifdef HALO_NTL_EXPERIMENT
+        else if (ntl == 2) TRI_ROWS_MODE(2);
+        else TRI_ROWS_MODE(4);
+#endif
+#undef TRI_ROWS_MODE
+#undef TRI_ROWS_LAUNCH
         return tri_check_launch("tri_conv(halo rows)");
     }
     static size_t attr = 0;
