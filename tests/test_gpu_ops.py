@@ -1,6 +1,8 @@
 """GPU parity of every kernel family, called through the C ABI (tricolo_amd.ops -> libtricolo_hip.so), against
 plain PyTorch-CPU fp32 / float64 restatements of the same op.  Integer-valued inputs make the bf16 MFMA path exact,
 so layout / fragment-mapping mistakes show up as exact mismatches, not as tolerance noise."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -689,6 +691,22 @@ def test_conv_16bit_storage_integer_exact(case, store, prec):
         dx2 = ops.conv_dgrad(cl3(dy).to(DEV).to(store), g, ops.pack_weight(wp.to(DEV), g, prec, transposed=True),
                              out=base.clone().to(DEV).to(store), accumulate=True)
         assert torch.equal(dx2.cpu(), (cl3(xr.grad) + base).to(store))
+
+
+@pytest.mark.parametrize("rows", ["0", "2"])
+def test_halo_kernels_ab_switch(rows):
+    """TRICOLO_HALO_ROWS picks the kernel of the resolution-keeping 3x3 layers per plan (default: conv_halo_rows_kernel for 64 input
+    channels and for launches with at most one tile per workgroup, conv_halo2d_kernel otherwise).  The switch is read once per
+    process, so the two forced settings - conv_halo2d_kernel everywhere (0), the row-unit pipeline everywhere, including its
+    weight-streaming multi-tile mode (2) - run the halo geometries of the exactness test above in a child process."""
+    import subprocess
+    import sys
+    env = dict(os.environ, TRICOLO_HALO_ROWS=rows)
+    k = "test_conv_16bit_storage_integer_exact and (h_ or big_nosplit or c64_32) and f16"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", k, "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
 
 
 @pytest.mark.parametrize("store,prec", STORE16, ids=STORE16_IDS)

@@ -1047,6 +1047,8 @@ __global__ __launch_bounds__(256, 1) void conv_halo_rows_kernel(const ConvArgs p
         const int spix = wave * 8 + (lane >> 3), slot = lane & 7;
 #pragma unroll
         for (int r = 0; r < HALO_MAX_ROUNDS; ++r) {
+            soff[r] = -1;
+            if (r >= S) continue;                                       // (uniform: rounds past the slab are never issued)
             const int sp = r * 32 + spix;
             const int srow = (int)fdiv((unsigned)sp, p.dP), sx = sp - srow * P;
             bool ok = srow < p.h_rows && sx >= 1 && sx <= W;
@@ -1815,9 +1817,17 @@ static bool halo_geometry(int B, int H, int W, int cin, int cout, int TM, ConvPl
         static int rows_kernel = -1;                                  // A/B switch: TRICOLO_HALO_ROWS=0 keeps conv_halo2d_kernel
         if (rows_kernel < 0) { const char* e = getenv("TRICOLO_HALO_ROWS"); rows_kernel = e ? atoi(e) : 1; }
         pl->h_v5 = 0;
+        // where the row-unit pipeline runs (TRICOLO_HALO_ROWS: 0 nowhere, 2 everywhere it fits): 64 input channels (resident filter
+        // bank, only slabs stream: layer1 27 against 34 us) and launches with at most 1.5 tiles per workgroup (layer4 of the bench
+        // shape 27 against 45 us, layer3 29 / 27 against 30 / 28).  With more weight-streaming tiles per workgroup its one workgroup
+        // per CU pays every DMA piece in issue time and the three co-resident workgroups of conv_halo2d_kernel are faster (layer2
+        // 24 / 24 against 26 / 25 us; steps with the row kernel everywhere: config 4 / 5 3.30-3.32 / 24.16 ms against 3.28-3.29 / 24.01)
         int g = num_cus() / NT * NT;
         if (g < NT) g = NT;
-        if (rows_kernel && TM == 2 && 2 * (size_t)slab + 3 * (size_t)HROWS_SLOT + 8192 <= 163840) {
+        static int half_tiles = -1;                                   // tuning aid: TRICOLO_HALO_ROWS_HALFTILES (tiles per workgroup x 2)
+        if (half_tiles < 0) { const char* e = getenv("TRICOLO_HALO_ROWS_HALFTILES"); half_tiles = e ? atoi(e) : 3; }
+        if (rows_kernel && (cin == 64 || 2 * items <= half_tiles * g || rows_kernel == 2) && TM == 2 &&
+            2 * (size_t)slab + 3 * (size_t)HROWS_SLOT + 8192 <= 163840) {
             pl->h_v5 = 1;
             pl->h_grid = items < g ? items : g;
             pl->h_wgrec = 1;                                          // one BatchNorm record per workgroup
