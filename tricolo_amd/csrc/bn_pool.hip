@@ -596,7 +596,8 @@ __global__ __launch_bounds__(256) void stem_bwd_reduce_kernel(const T* __restric
     float4 sg = make_float4(0, 0, 0, 0), sgy = make_float4(0, 0, 0, 0);
     if (tc < C4 && tr < rpp) {
         const float4 s4 = rs[tc], b4 = rb[tc];
-        for (long r = r0 + tr; r < r1; r += rpp) {
+#pragma unroll 4
+        for (long r = r0 + tr; r < r1; r += rpp) {                          // (4 iterations at 64 channels: all 48 loads in flight at once)
             const int bw = (int)(r % Wo); const long q = r / Wo;
             const int bh = (int)(q % Ho), n = (int)(q / Ho);
             float4 g[4];
