@@ -340,6 +340,28 @@ def run_mode(a, precision, world, rank, device, want_voxel_roofline):
     return res, vox_roof, cfg
 
 
+def run_mode_in_child(a, mode):
+    """`bench.py --precision <mode> --modes '' --no-cpu-baseline` with this run's workload flags in a child process (a child, not an
+    exec: this process has initialised the GPU); returns the same per-mode object run_mode() does."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--precision", mode, "--modes", "", "--no-cpu-baseline", "--steps", str(a.steps),
+           "--warmup", str(a.warmup), "--config", str(a.config), "--per-gpu-batch", str(a.per_gpu_batch),
+           "--resident-batches", str(a.resident_batches), "--preroll", str(a.preroll)]
+    for flag, val in (("--voxel-size", a.voxel_size), ("--num-views", a.num_views), ("--image-size", a.image_size)):
+        if val is not None:
+            cmd += [flag, str(val)]
+    if a.no_graph:
+        cmd.append("--no-graph")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        raise RuntimeError(f"bench.py child for mode {mode} failed (rc {r.returncode}):\n{r.stderr[-2000:]}")
+    d = json.loads(lines[-1])
+    return {"value": d["value"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"], "hip_graph": d["config"]["hip_graph"],
+            "final_loss": d["config"]["final_loss"], "roofline": d["roofline"], "process": "child"}
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -396,7 +418,12 @@ def main():
     head, vox_roof, cfg = run_mode(a, a.precision, world, rank, device, want_voxel_roofline=True)
     modes = {}
     for m in extra:
-        modes[m], _, _ = run_mode(a, m, world, rank, device, want_voxel_roofline=False)
+        if world == 1 and not dist.is_initialized():
+            # each extra mode in a CHILD process of its own: a second mode timed in this process inherits the allocator / physical
+            # memory state the first one left (the fp32-storage parity mode ran 6.8-8.3 ms after an f16 leg, 6.8 ms on its own)
+            modes[m] = run_mode_in_child(a, m)
+        else:
+            modes[m], _, _ = run_mode(a, m, world, rank, device, want_voxel_roofline=False)
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:             # the CPU leg is an N = 1 artefact (task contract)

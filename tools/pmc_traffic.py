@@ -30,7 +30,7 @@ def demangle(names):
 
 
 def symbol(d):
-    m = re.match(r"conv_halo_rows_kernel<(\w+), \w+, \w+>", d)
+    m = re.match(r"conv_halo_rows_kernel<(\w+), \w+, \w+, \d+>", d)
     if m:
         return f"conv_halo_rows_kernel<{m.group(1)}>"
     m = re.match(r"conv_halo2d_kernel<(\d+), \w+, (\w+)>", d)

@@ -7,7 +7,7 @@ tag=${1:-r2}
 R=$PWD
 O=$R/gpurun_out
 mkdir -p $O
-python -m pytest tests -m gpu -q 2>&1 | tail -8 > $O/${tag}_gpu_tests.txt
+python -m pytest tests -m gpu -q > $O/${tag}_gpu_tests_full.txt 2>&1; grep -E "passed|failed|error" $O/${tag}_gpu_tests_full.txt | tail -5 > $O/${tag}_gpu_tests.txt
 python bench.py > $O/${tag}_bench_default.json 2> $O/${tag}_bench_default.err
 for c in 2 3 5; do python bench.py --config $c --modes "" --no-cpu-baseline > $O/${tag}_bench_cfg$c.json 2> $O/${tag}_bench_cfg$c.err; done
 for c in 4 2 3 5; do python tools/step_timeline.py --config $c > $O/${tag}_timeline_cfg$c.txt 2>/dev/null; done
@@ -18,6 +18,8 @@ done
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${tag}_pmc_fetch -- python3 $R/bench.py --steps 3 --warmup 2 --precision f16 --modes "" --no-cpu-baseline > $O/${tag}_pmc_fetch.json 2> $O/${tag}_pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${tag}_pmc_write -- python3 $R/bench.py --steps 3 --warmup 2 --precision f16 --modes "" --no-cpu-baseline > $O/${tag}_pmc_write.json 2> $O/${tag}_pmc_write.err
 cd $R
+python tools/pmc_traffic.py $O/${tag}_pmc_fetch $O/${tag}_pmc_write f16 > $O/${tag}_pmc_traffic_f16.json
+for p in f16 bf16; do python tools/conv_layers_bench.py --precision $p 2>&1 | grep -v amdgpu.ids > $O/${tag}_conv_layers_$p.txt; done
 # keep the merged-back payload small: kernel traces are large, the stats CSVs are what gets committed
 find $O/${tag}_prof_* -name "*kernel_trace.csv" -size +20M -delete
 ls -la $O | tail -30
