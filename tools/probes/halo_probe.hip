@@ -1,4 +1,8 @@
-// In-kernel phase stamps of conv_halo2d_kernel (wave 0 of every workgroup) on the four 3x3 layers of the bench shape.
+// In-kernel phase stamps of the halo kernels (conv_halo2d_kernel / conv_halo_rows_kernel, whichever the plan picks - force one with
+// TRICOLO_HALO_ROWS=0 / 2; wave 0 of every workgroup) on the four 3x3 layers of the bench shape.  Stamp ids (HSTAMP in conv_igemm.hip):
+// conv_halo2d_kernel 2 constants done, 3 slab issued, 4 slab landed, 5 unit's weights landed, 6 barrier, 7 next unit issued, 8 MFMAs,
+// 9 epilogue start, 10 stores issued, 11 tile done; conv_halo_rows_kernel 2 constants + first DMAs issued, 3 first fragments read,
+// per kernel row 4 k-steps 0-3, 5 DMA wait, 6 barrier, 8 k-steps 4-5 + DMA issue, 10 epilogue, 11 statistics written.
 // Build (cross-compiles here, runs on the GPU box):
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DHALO_STAMPS -Iinclude -o tools/probes/build/halo_probe tools/probes/halo_probe.hip tricolo_amd/csrc/misc.hip
 // Prints, per layer: kernel time, and for a few workgroups the cycles between consecutive stamps summed by phase.
@@ -7,8 +11,7 @@
 #include <map>
 #include <algorithm>
 
-static const char* kPhase[] = {"", "start", "consts", "slab issued", "slab landed", "weights landed", "barrier", "w issued", "mfma", "tile end",
-                               "stores issued", "stats done"};
+static const char* kPhase[] = {"", "start", "2", "3", "4", "5", "6", "7", "8", "9", "10", "11"};
 
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 192;                       // images = per-GPU batch 32 x 6 views

@@ -695,6 +695,13 @@ template <int N>
 __device__ __forceinline__ void frag_wait(v4i (&a)[2], v4i (&b)[4]) {
     asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N));
 }
+// In-kernel phase stamps of the halo kernels (-DHALO_STAMPS builds only: tools/probes/halo_probe.hip).  Wave 0 of every workgroup writes
+// (id << 48 | s_memtime) into a 2 KiB LDS area `stl` of the kernel and copies it to p.h_dbg at the end; ~150 cycles per stamp.
+#ifdef HALO_STAMPS
+#define HSTAMP(id) do { if (wave == 0 && n_stamp < 255) { const long long c_ = __builtin_readcyclecounter(); if (lane == 0) stl[n_stamp] = ((long long)(id) << 48) | (c_ & 0xFFFFFFFFFFFFll); ++n_stamp; } } while (0)
+#else
+#define HSTAMP(id) do { } while (0)
+#endif
 // WGREC: BatchNorm records per persistent workgroup (launches with many tiles per workgroup) instead of per tile
 template <int TM, bool WGREC, typename AT>
 __global__ __launch_bounds__(256, WGREC ? 3 : 1) void conv_halo2d_kernel(const ConvArgs p) {     // WGREC: <= 170 VGPRs (three workgroups per CU)
@@ -711,9 +718,6 @@ __global__ __launch_bounds__(256, WGREC ? 3 : 1) void conv_halo2d_kernel(const C
 #ifdef HALO_STAMPS
     int n_stamp = 0;
     long long* const stl = (long long*)(smem + p.h_slab_bytes + HALO_NR * 8192 + 2048);      // wave 0's stamps (2 KiB past `red`)
-#define HSTAMP(id) do { if (wave == 0 && n_stamp < 255) { const long long c_ = __builtin_readcyclecounter(); if (lane == 0) stl[n_stamp] = ((long long)(id) << 48) | (c_ & 0xFFFFFFFFFFFFll); ++n_stamp; } } while (0)
-#else
-#define HSTAMP(id) do { } while (0)
 #endif
     HSTAMP(1);
     const int H = p.IH, W = p.IW, P = W + 2, TR = p.h_tr, NH = p.B * H;
