@@ -28,7 +28,18 @@ struct WgradArgs {
     int KD, KH, KW, stride, pd, ph, pw;
     int Kpad, M, ntaps, cin_shift, steps_per_split, ntiles, nsplits;
     FastDiv dOW, dOH, dOD, dCin;
+#ifdef WGRAD_STAMPS
+    long long* dbg;              // tools/probes/wgrad_probe.hip: per-workgroup (id, cycle) stamps of wave 0
+#endif
 };
+// In-kernel phase stamps of conv_wgrad_dma_kernel (-DWGRAD_STAMPS builds only): wave 0 writes (id << 48 | s_memtime) into the last
+// 2 KiB of the workgroup's LDS and copies them to p.dbg at the end; ~150 cycles per stamp.
+#ifdef WGRAD_STAMPS
+static long long* g_wgrad_dbg = nullptr;
+#define WSTAMP(id) do { if (wave == 0 && n_stamp < 255) { const long long c_ = __builtin_readcyclecounter(); if (lane == 0) stl[n_stamp] = ((long long)(id) << 48) | (c_ & 0xFFFFFFFFFFFFll); ++n_stamp; } } while (0)
+#else
+#define WSTAMP(id) do { } while (0)
+#endif
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
@@ -328,6 +339,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs p) 
     int* lrow = (int*)lplan_mask + p.steps_per_split * KB;       // row list launches, see conv_wgrad_kernel
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+#ifdef WGRAD_STAMPS
+    int n_stamp = 0;
+    long long* const stl = (long long*)(smem + 2 * STAGE + 512 + p.steps_per_split * (p.row_count ? 768 : 512));
+#endif
+    WSTAMP(1);
     const int JT = (p.Kpad + BJ - 1) / BJ;
     const int ntiles = p.ntiles;
     int split, tile;
@@ -375,6 +391,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs p) 
         }
     }
     __syncthreads();
+    WSTAMP(2);                                                     // tap table + gather plan staged
 
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -473,19 +490,26 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs p) 
 
     int ks = next_live(ks_begin);
     int buf = 0;
+    WSTAMP(3);                                                     // lane constants
     if (ks < ks_end) {
         issue(ks, 0);
         while (ks < ks_end) {
             int nxt = next_live(ks + 1);
+            WSTAMP(4);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's DMAs of stage `buf` have landed
+            WSTAMP(5);                                                 // DMA wait
             __builtin_amdgcn_s_barrier();                                // ... everyone's have, and all reads of buf ^ 1 are done
             asm volatile("" ::: "memory");
+            WSTAMP(6);                                                 // barrier
             if (nxt < ks_end) issue(nxt, buf ^ 1);
+            WSTAMP(7);                                                 // next stage issued
             compute(buf);
+            WSTAMP(8);                                                 // 32 MFMAs
             buf ^= 1;
             ks = nxt;
         }
     }
+    WSTAMP(9);
 
     float* slab = p.slab + (size_t)split * p.Cout * p.Kpad;
 #pragma unroll
@@ -499,6 +523,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs p) 
                 if (j < p.Kpad) slab[(size_t)co * p.Kpad + j] = acc[a][b][r];
             }
         }
+    WSTAMP(10);                                                    // slab stored
+#ifdef WGRAD_STAMPS
+    if (wave == 0) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int i = lane; i < 255; i += 64) p.dbg[(size_t)blockIdx.x * 256 + i] = i < n_stamp ? stl[i] : 0;
+        if (lane == 0) p.dbg[(size_t)blockIdx.x * 256 + 255] = n_stamp;
+    }
+#endif
 }
 
 // ================================================================================================ stem weight gradient
@@ -993,12 +1025,19 @@ template <int BI, int BJ, typename E>
 static int launch_wgrad_dma(const WgradArgs& a, int tiles, int splits, hipStream_t stream) {
     constexpr int STAGE = 64 * (BI * 2 + BJ * 2);
     size_t smem = 2 * STAGE + 512 + (size_t)a.steps_per_split * (a.row_count ? 768 : 512);     // + the list's positions (4 B each)
+#ifdef WGRAD_STAMPS
+    smem += 2048;
+    WgradArgs b = a;
+    b.dbg = g_wgrad_dbg;
+#else
+    const WgradArgs& b = a;
+#endif
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel<BI, BJ, E>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE + 512 + 96 * 768);
+        hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel<BI, BJ, E>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE + 512 + 96 * 768 + 2048);
         attr_set = true;
     }
-    conv_wgrad_dma_kernel<BI, BJ, E><<<dim3(((splits + 7) / 8) * 8 * tiles), 256, smem, stream>>>(a);
+    conv_wgrad_dma_kernel<BI, BJ, E><<<dim3(((splits + 7) / 8) * 8 * tiles), 256, smem, stream>>>(b);
     return tri_check_launch("tri_conv_wgrad(dma)");
 }
 
