@@ -176,6 +176,12 @@ int tri_bn_relu_pool3d_fwd(const void* y, const float* scale, const float* shift
                            void* pooled, uint8_t* mask_out, int act_fmt, void* stream);
 int tri_pool3d_bwd_route(const void* y, const float* scale, const float* shift, const uint8_t* mask, const void* pooled,
                          const void* dpooled, int B, int D, int C, void* g, int act_fmt, void* stream);
+/* the same with the level's BatchNorm-backward sums folded in (sparse_cnn.py:12-35 backward: SparseMaxPool3d -> ReLU -> BatchNorm1d):
+ * partial [tri_pool3d_bwd_route_reduce_num_blocks][2][C] = per-workgroup sums of g and g * y over the active sites, what
+ * tri_bn_bwd_reduce would produce from a second pass; continue with tri_bn_bwd_finalize / tri_bn_bwd_apply.  C / 4 must divide 256. */
+int tri_pool3d_bwd_route_reduce_num_blocks(int B, int D, int C);
+int tri_pool3d_bwd_route_reduce(const void* y, const float* scale, const float* shift, const uint8_t* mask, const void* pooled,
+                                const void* dpooled, int B, int D, int C, void* g, float* partial, int act_fmt, void* stream);
 /* bn_scale / bn_shift (optional, [C]): pools relu(x * scale + shift), i.e. BatchNorm + ReLU + MaxPool2d of the ResNet stem in one pass */
 int tri_maxpool2d_fwd(const void* x, int N, int H, int W, int C, void* out, uint8_t* arg /* [N,Ho,Wo,C] winning tap, may be NULL */,
                       const float* bn_scale, const float* bn_shift, int act_fmt, void* stream);

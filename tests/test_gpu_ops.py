@@ -444,6 +444,14 @@ def test_voxel_bn_pool_forward_backward_matches_oracle():
     np.testing.assert_allclose(cf3(dy.cpu()).numpy(), yr.grad.numpy(), atol=3e-5)
     np.testing.assert_allclose(dgamma.cpu().numpy(), bn.weight.grad.numpy(), rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(dbeta.cpu().numpy(), bn.bias.grad.numpy(), rtol=1e-4, atol=1e-4)
+    # the fused form the tower uses (routing pass + BatchNorm-backward sums in one launch): same routed gradient, sums in another order
+    dy2, dgamma2, dbeta2 = ops.pool3d_bn_bwd(ycl, co, m8, pooled, cl3(dp).to(DEV), B, D, C, bn2.weight, cnt)
+    np.testing.assert_allclose(cf3(dy2.cpu()).numpy(), yr.grad.numpy(), atol=3e-5)
+    np.testing.assert_allclose(dgamma2.cpu().numpy(), dgamma.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(dbeta2.cpu().numpy(), dbeta.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    act = m8[:B * D ** 3].bool().cpu()
+    assert torch.equal(dy2.cpu().view(-1, C)[act], dy2.cpu().view(-1, C)[act])        # (finite everywhere it is defined)
+    np.testing.assert_allclose(dy2.cpu().view(-1, C)[act].numpy(), dy.cpu().view(-1, C)[act].numpy(), atol=2e-6)
 
 
 def test_maxpool2d_and_viewmax():

@@ -410,6 +410,73 @@ extern "C" int tri_pool3d_bwd_route(const void* y, const float* scale, const flo
     return tri_check_launch("tri_pool3d_bwd_route");
 }
 
+// The same routing with the BatchNorm-backward sums of the level folded in: every routed value and the y it belongs to are in
+// registers here, so the per-channel sums of g and g * y over the active sites (what tri_bn_bwd_reduce would re-read both tensors
+// for) leave as one [2][C] record per workgroup for tri_bn_bwd_finalize - one launch less per level on the voxel tower's backward.
+// Needs 256 % (C / 4) == 0 (a thread keeps its channel quad across the grid-stride loop).
+template <typename T>
+__global__ __launch_bounds__(256) void pool3d_bwd_route_reduce_kernel(const T* __restrict__ y, const float4* __restrict__ scale,
+                                                                      const float4* __restrict__ shift, const uint8_t* __restrict__ mask,
+                                                                      const T* __restrict__ pooled, const T* __restrict__ dpooled, int B, int D,
+                                                                      int C4, T* __restrict__ g, float* __restrict__ partial) {
+    __shared__ float sh[256][8];
+    const int Do = D >> 1;
+    const long total = (long)B * Do * Do * Do * C4;
+    const int c = threadIdx.x % C4;
+    const float4 s = scale[c], t = shift[c];
+    float4 sg = make_float4(0.f, 0.f, 0.f, 0.f), sgy = sg;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long pos = i / C4;
+        int ox = (int)(pos % Do); long r = pos / Do;
+        int oy = (int)(r % Do); r /= Do;
+        int oz = (int)(r % Do); int b = (int)(r / Do);
+        float4 pm = Act<T>::ld4(pooled + i * 4), dp = Act<T>::ld4(dpooled + i * 4);
+        bool dx = false, dy = false, dz = false, dw = false;      // already routed
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            long ip = (((long)b * D + (oz * 2 + (k >> 2))) * D + (oy * 2 + ((k >> 1) & 1))) * D + (ox * 2 + (k & 1));
+            if (!mask[ip]) continue;
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 v = Act<T>::ld4(y + (ip * C4 + c) * 4);
+            float zx = fmaxf(__fmaf_rn(v.x, s.x, t.x), 0.f), zy = fmaxf(__fmaf_rn(v.y, s.y, t.y), 0.f);
+            float zz = fmaxf(__fmaf_rn(v.z, s.z, t.z), 0.f), zw = fmaxf(__fmaf_rn(v.w, s.w, t.w), 0.f);
+            zx = Act<T>::rnd(zx); zy = Act<T>::rnd(zy); zz = Act<T>::rnd(zz); zw = Act<T>::rnd(zw);
+            if (!dx && zx == pm.x && zx > 0.f) { o.x = dp.x; dx = true; }
+            if (!dy && zy == pm.y && zy > 0.f) { o.y = dp.y; dy = true; }
+            if (!dz && zz == pm.z && zz > 0.f) { o.z = dp.z; dz = true; }
+            if (!dw && zw == pm.w && zw > 0.f) { o.w = dp.w; dw = true; }
+            Act<T>::st4(g + (ip * C4 + c) * 4, o);
+            sg.x += o.x; sg.y += o.y; sg.z += o.z; sg.w += o.w;
+            sgy.x += o.x * v.x; sgy.y += o.y * v.y; sgy.z += o.z * v.z; sgy.w += o.w * v.w;
+        }
+    }
+    float* p = sh[threadIdx.x];
+    p[0] = sg.x; p[1] = sg.y; p[2] = sg.z; p[3] = sg.w; p[4] = sgy.x; p[5] = sgy.y; p[6] = sgy.z; p[7] = sgy.w;
+    __syncthreads();
+    if ((int)threadIdx.x < C4) {
+        float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int r = threadIdx.x; r < 256; r += C4)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] += sh[r][k];
+        float* o = partial + (size_t)blockIdx.x * 2 * C4 * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { o[c * 4 + k] = a[k]; o[C4 * 4 + c * 4 + k] = a[4 + k]; }
+    }
+}
+extern "C" int tri_pool3d_bwd_route_reduce_num_blocks(int B, int D, int C) {
+    return ew_grid((long)B * (D / 2) * (D / 2) * (D / 2) * (C / 4));
+}
+// g as tri_pool3d_bwd_route; partial [tri_pool3d_bwd_route_reduce_num_blocks][2][C] = per-workgroup sums of g and g * y over the active
+// sites, the input of tri_bn_bwd_finalize (then tri_bn_bwd_apply with the same site mask).  C / 4 must divide 256.
+extern "C" int tri_pool3d_bwd_route_reduce(const void* y, const float* scale, const float* shift, const uint8_t* mask, const void* pooled,
+                                           const void* dpooled, int B, int D, int C, void* g, float* partial, int act_fmt, void* stream) {
+    if (C % 4 || C / 4 > 256 || 256 % (C / 4)) { tri_set_error("tri_pool3d_bwd_route_reduce: C / 4 must divide 256"); return TRI_ERR_ARG; }
+    const int nblk = tri_pool3d_bwd_route_reduce_num_blocks(B, D, C);
+    TRI_ACT_DISPATCH(act_fmt, pool3d_bwd_route_reduce_kernel<T><<<nblk, 256, 0, (hipStream_t)stream>>>(
+        (const T*)y, (const float4*)scale, (const float4*)shift, mask, (const T*)pooled, (const T*)dpooled, B, D, C / 4, (T*)g, partial));
+    return tri_check_launch("tri_pool3d_bwd_route_reduce");
+}
+
 // ----------------------------------------------------------------------------- ResNet stem: 3x3 / stride 2 / pad 1
 // Forward also records, per output element, WHICH of the 9 window taps won (first maximum in (kh,kw) scan order, the
 // torch.max_pool2d tie rule) as one byte; backward is then a gather over the <= 4 windows covering an input pixel:

@@ -51,6 +51,7 @@ class SparseCNNEncoder(TriModule):
         self.sparseModel = nn.ModuleDict(mods)
         self.spatial = (voxel_size // 32) ** 3
         self.mlp = nn.Sequential(nn.Linear(z_dim * self.spatial, out_dim), nn.ReLU(inplace=True), nn.Linear(out_dim, out_dim))
+        self.fuse_pool_reduce = True                            # see _backward_impl; TriCoLoNet clears it when an image tower runs beside this one
         self._geoms = {}
         self.__dict__["_packers"] = {}
         self.__dict__["_packed"] = {}
@@ -143,13 +144,18 @@ class SparseCNNEncoder(TriModule):
         dx = ops.cast_from_f32(dflat.contiguous(), ops.act_dtype(prec), gs)
         batch = ops.wgrad_batch(dz.device)                     # the five weight-gradient reduces in one launch at the end
         compact = os.environ.get("TRICOLO_VOXEL_COMPACT", "1") != "0"
+        # route + BatchNorm-backward sums in one launch when this tower is the step's longest chain (Bi(V): 1.314 -> 1.302 ms).  Beside
+        # an image tower the shorter voxel chain changes how the replayed graph folds its branches and the STEP gets slower (3.30 ->
+        # 3.33 ms, four A/B pairs on two boxes), so TriCoLoNet switches it off there; TRICOLO_POOL_REDUCE=0 / 1 overrides.
+        env = os.environ.get("TRICOLO_POOL_REDUCE")
+        fuse = self.fuse_pool_reduce if env is None else env == "1"
         for l in range(4, -1, -1):
             D, C = V >> l, self.chans[l + 1]
             g = self._geom(B, l)
             x, y, mask, count, co, pooled, rows, _ = saved["levels"][l]
             conv, bn = self.sparseModel[str(4 * l)], self.sparseModel[str(4 * l + 1)]
-            gz = ops.pool3d_bwd_route(y, co, mask, pooled, dx.contiguous(), B, D, C)
-            dy, dgamma, dbeta = ops.bn_bwd(y, gz, co, bn.weight, count_dev=count, row_mask=mask, out_scale=ugs)
+            dy, dgamma, dbeta = ops.pool3d_bn_bwd(y, co, mask, pooled, dx.contiguous(), B, D, C, bn.weight, count, out_scale=ugs,
+                                                  fused=fuse)
             if compact:                                          # contraction over the active sites only (row list of the level)
                 grads[3 * l] = ops.conv_wgrad(x, dy, g, conv.weight, prec, rows=rows, out_scale=ugs, batch=batch)
             else:

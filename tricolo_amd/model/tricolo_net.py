@@ -58,6 +58,8 @@ class TriCoLoNet(TriModule):
             self.image_encoder = _instantiate(getattr(cfg.model.modules, cfg.model.image_encoder), clip_model=clip_model)
         if cfg.model.voxel_encoder is not None:
             self.voxel_encoder = _instantiate(getattr(cfg.model.modules, cfg.model.voxel_encoder))
+            if self.image_encoder is not None and hasattr(self.voxel_encoder, "fuse_pool_reduce"):
+                self.voxel_encoder.fuse_pool_reduce = False      # a side tower here: see SparseCNNEncoder._backward_impl
         self.loss_fn = _instantiate(getattr(cfg.loss, cfg.loss.name))
         self.val_test_step_outputs = []
         self.overlap_towers = os.environ.get("TRICOLO_OVERLAP", "1") != "0"

@@ -496,6 +496,28 @@ def pool3d_bwd_route(y, co: BNCoeffs, mask, pooled, dpooled, B, D, C):
     return g
 
 
+def pool3d_bn_bwd(y, co: BNCoeffs, mask, pooled, dpooled, B, D, C, gamma, count_dev, out_scale: float = 1.0, fused: bool = True):
+    """Backward of BatchNorm1d -> ReLU -> SparseMaxPool3d of one voxel level: (dy, dgamma, dbeta).  fused: the routing pass also
+    produces the BatchNorm-backward sums (tri_pool3d_bwd_route_reduce), so the level costs route + finalize + apply instead of
+    route + reduce + finalize + apply; channel counts whose quads do not divide 256 take the unfused passes."""
+    if C % 4 or (C // 4) > 256 or 256 % (C // 4) or not fused:
+        gz = pool3d_bwd_route(y, co, mask, pooled, dpooled, B, D, C)
+        return bn_bwd(y, gz, co, gamma, count_dev=count_dev, row_mask=mask, out_scale=out_scale)
+    assert dpooled.dtype == y.dtype and pooled.dtype == y.dtype
+    g = torch.empty_like(y)
+    nblk = lib().tri_pool3d_bwd_route_reduce_num_blocks(B, D, C)
+    partial = torch.empty((nblk, 2, C), dtype=torch.float32, device=y.device)
+    check(lib().tri_pool3d_bwd_route_reduce(ptr(_act(y)), ptr(co.scale), ptr(co.shift), ptr(mask), ptr(pooled), ptr(_act(dpooled)), B, D, C,
+                                            ptr(g), ptr(partial), _abf(y), stream()), "tri_pool3d_bwd_route_reduce")
+    buf = torch.empty((5, C), dtype=torch.float32, device=y.device)
+    M = y.numel() // C
+    check(lib().tri_bn_bwd_finalize(ptr(partial), nblk, C, ptr(count_dev), 0, ptr(gamma), ptr(co.mean), ptr(co.invstd), ptr(buf[0]),
+                                    ptr(buf[1]), ptr(buf[2]), ptr(buf[3]), ptr(buf[4]), float(out_scale), stream()), "tri_bn_bwd_finalize")
+    check(lib().tri_bn_bwd_apply(ptr(y), ptr(g), ptr(buf[2]), ptr(buf[3]), ptr(buf[4]), ptr(mask), ptr(g), M, C, None, None, None, None,
+                                 _abf(y), stream()), "tri_bn_bwd_apply")
+    return g, buf[0], buf[1]
+
+
 def maxpool2d_fwd(x, want_arg=True, bn: BNCoeffs = None):
     """3x3/2/pad-1 max-pool; also returns the winning-tap byte map used by maxpool2d_bwd.
     With ``bn`` the pooled tensor is relu(x * scale + shift): BatchNorm + ReLU + MaxPool2d in one pass."""
