@@ -454,6 +454,20 @@ def test_voxel_bn_pool_forward_backward_matches_oracle():
     np.testing.assert_allclose(dy2.cpu().view(-1, C)[act].numpy(), dy.cpu().view(-1, C)[act].numpy(), atol=2e-6)
 
 
+@pytest.mark.parametrize("n,p", [(1, 1.0), (2047, 0.5), (2048, 0.0), (5 * 2048 + 3, 0.3), (1 << 20, 0.13), (1024 * 2048, 0.9), (1025 * 2048 + 17, 0.05)])
+def test_mask_compact_matches_nonzero(n, p):
+    """tri_mask_compact: positions of the non-zero mask bytes in ascending order + their count on the device - one block, block
+    boundaries, an empty mask, the largest list the fused scan takes (1,024 blocks) and the first size past it (separate scan)."""
+    g = torch.Generator().manual_seed(n % 1000)
+    m = (torch.rand(n, generator=g) < p).to(torch.uint8)
+    mpad = torch.zeros((n + 31) // 32 * 32, dtype=torch.uint8)
+    mpad[:n] = m
+    rows, count = ops.mask_compact(mpad.to(DEV), n)
+    ref = torch.nonzero(m).flatten().int()
+    assert int(count.item()) == ref.numel()
+    assert torch.equal(rows[:ref.numel()].cpu(), ref)
+
+
 def test_maxpool2d_and_viewmax():
     g = torch.Generator().manual_seed(7)
     N, H, W, C = 6, 10, 10, 64

@@ -166,12 +166,46 @@ __global__ __launch_bounds__(256) void mask_block_write_kernel(const uint8_t* __
     for (int k = 0; k < 8; ++k)
         if ((bits >> k) & 1ull) row_pos[off++] = (int)(base + k);
 }
+// mask_block_write_kernel with the scan folded in, for lists of at most 1,024 blocks (2 M sites): every block sums the counts of the
+// blocks before it itself (<= 4 KiB of L2-resident reads) and the last block also writes the total - two launches instead of three
+// on a chain of ~15 short launches per voxel level.
+__global__ __launch_bounds__(256) void mask_block_write_scan_kernel(const uint8_t* __restrict__ mask, long n, const int* __restrict__ block_count,
+                                                                    int* __restrict__ row_pos, int* __restrict__ count) {
+    __shared__ int ws[4], bs[4];
+    unsigned long long bits;
+    const long base = (long)blockIdx.x * CMP_SITES + threadIdx.x * 8;
+    const int c = (int)cmp_load8(mask, base, n, &bits);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int pre = 0;                                                     // counts of the blocks before this one, 256 threads striding
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) pre += block_count[b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) pre += __shfl_xor(pre, o);
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+    if (lane == 63) ws[wave] = incl;
+    if (lane == 0) bs[wave] = pre;
+    __syncthreads();
+    const int block_base = bs[0] + bs[1] + bs[2] + bs[3];
+    int off = block_base + incl - c;
+    for (int w = 0; w < wave; ++w) off += ws[w];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if ((bits >> k) & 1ull) row_pos[off++] = (int)(base + k);
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *count = block_base + ws[0] + ws[1] + ws[2] + ws[3];
+}
 extern "C" size_t tri_mask_compact_scratch(long n) { return (size_t)((n + CMP_SITES - 1) / CMP_SITES + 1) * sizeof(int); }
 extern "C" int tri_mask_compact(const uint8_t* mask, long n, int* row_pos, int* count, void* scratch, void* stream) {
     if (n < 1 || n >= ((long)1 << 31)) { tri_set_error("tri_mask_compact: 1 <= n < 2^31 sites"); return TRI_ERR_ARG; }
     hipStream_t s = (hipStream_t)stream;
     const int nb = (int)((n + CMP_SITES - 1) / CMP_SITES);
     mask_block_count_kernel<<<nb, 256, 0, s>>>(mask, n, (int*)scratch);
+    static int fused = -1;                                           // A/B switch: TRICOLO_MASK_SCAN_FUSED=0 keeps the separate scan launch
+    if (fused < 0) { const char* e = getenv("TRICOLO_MASK_SCAN_FUSED"); fused = (e && e[0] == '0') ? 0 : 1; }
+    if (fused && nb <= 1024) {
+        mask_block_write_scan_kernel<<<nb, 256, 0, s>>>(mask, n, (const int*)scratch, row_pos, count);
+        return tri_check_launch("tri_mask_compact");
+    }
     mask_scan_kernel<<<1, 1024, 0, s>>>((int*)scratch, nb, count);
     mask_block_write_kernel<<<nb, 256, 0, s>>>(mask, n, (const int*)scratch, row_pos);
     return tri_check_launch("tri_mask_compact");
