@@ -137,16 +137,19 @@ def voxel_fwd_roofline(net, batch, B, nrep=3):
     enc = net.voxel_encoder
     vox = batch["voxels"]
     ops.TIMER = ops.KernelTimer()
+    torch.cuda._sleep(int(20e6))
+    ovh = ops.TIMER.calibrate()                                        # event-pair cost of an empty launch (as in the step's roofline leg)
     saved = None
     for _ in range(nrep):
         torch.cuda._sleep(int(20e6))                                   # park the GPU: events bracket kernels, not launch gaps
         _, saved = enc._forward_impl(vox["locs"], vox["feats"], B, save=True)
     torch.cuda.synchronize()
-    recs = [(s, f, a.elapsed_time(b)) for (s, f, a, b) in ops.TIMER.records if s.startswith("conv_")]
+    raw = [(s, f, a.elapsed_time(b)) for (s, f, a, b) in ops.TIMER.records if s.startswith("conv_")]
+    recs = [(s, f, max(e - ovh, 0.25 * e)) for (s, f, e) in raw]
     ops.TIMER = None
     per = len(recs) // nrep                        # 5 SubMConv3d launches first, then (64^3: 8 head sites) mlp[0] on the conv path
     assert per >= 5 and per * nrep == len(recs), len(recs)
-    levels, tot_ms, tot_dense, tot_exec, tot_rows = [], 0.0, 0, 0, 0
+    levels, tot_ms, tot_raw, tot_dense, tot_exec, tot_rows = [], 0.0, 0.0, 0, 0, 0
     V = enc.voxel_size
     for l in range(5):
         x, y, mask, count, co, pooled, rows, used_rows = saved["levels"][l]
@@ -161,23 +164,33 @@ def voxel_fwd_roofline(net, batch, B, nrep=3):
         # executed row tiles: the compact row list packs the active sites into ceil(active / 128) tiles; split-K levels (site
         # mask instead of a list) still run every 128-site tile that holds an active site
         tiles = (active + 127) // 128 if used_rows else int(m.view(-1, 128).any(dim=1).sum().item())
+        exec_rows = tiles * 128
+        brick = recs[l][0].startswith("conv_vox")
+        if brick:                                      # brick kernels (conv_vox.hip) execute the 16-site x-runs that hold an active site
+            exec_rows = 16 * int(m.view(-1, 16).any(dim=1).sum().item())
+            tiles = (exec_rows + 127) // 128
         ms = sorted(recs[r * per + l][2] for r in range(nrep))[nrep // 2]
+        ms_raw = sorted(raw[r * per + l][2] for r in range(nrep))[nrep // 2]
         dense = 2 * M * 27 * cin * cout
-        execd = 2 * tiles * 128 * 27 * cin * cout
+        execd = 2 * exec_rows * 27 * cin * cout
         rowf = 2 * active * 27 * cin * cout
         e = x.element_size()
         cs = 4 if cin == 3 else cin
         # algorithmic HBM bytes: every needed input row once + every written output row once.  Over a compact row list only the
         # active sites' rows are written and (up to the 3^3 halo, counted as one extra shell = x2) read; a dense pass moves all M rows
-        hbm = (min(M, 2 * active) * cs + active * cout) * e if used_rows else M * (cs + cout) * e
+        hbm = (min(M, 2 * active) * cs + active * cout) * e if (used_rows or brick) else M * (cs + cout) * e
         levels.append({"level": l, "kernel": recs[l][0], "grid": D, "cin": cin, "cout": cout, "sites": M, "active_sites": active,
-                       "tiles": (M + 127) // 128, "executed_tiles": tiles, "compact_rows": bool(used_rows), "ms": round(ms, 4), "dense_tflops": round(dense / ms / 1e9, 1),
+                       "tiles": (M + 127) // 128, "executed_tiles": tiles, "executed_rows": exec_rows, "compact_rows": bool(used_rows), "ms": round(ms, 4),
+                       "ms_raw": round(ms_raw, 4), "dense_tflops": round(dense / ms / 1e9, 1),
                        "executed_tflops": round(execd / ms / 1e9, 1), "active_row_tflops": round(rowf / ms / 1e9, 1),
                        "algorithmic_hbm_gbs": round(hbm / ms / 1e6, 1)})
-        tot_ms += ms; tot_dense += dense; tot_exec += execd; tot_rows += rowf
+        tot_ms += ms; tot_raw += ms_raw; tot_dense += dense; tot_exec += execd; tot_rows += rowf
     l0 = levels[0]
     return {"bound": "mfma", "what": "five SubMConv3d forwards of the voxel tower, per-GPU batch %d, %d^3" % (B, V),
-            "ms": round(tot_ms, 4), "dense_flops": tot_dense, "executed_flops": tot_exec, "active_row_flops": tot_rows,
+            "ms": round(tot_ms, 4), "ms_raw": round(tot_raw, 4),
+            "timing": f"HIP events around each launch, median of {nrep}; the event-pair cost of an empty launch measured in the same leg "
+                      f"({ovh * 1e3:.1f} us) is subtracted per launch (ms_raw = unsubtracted)",
+            "dense_flops": tot_dense, "executed_flops": tot_exec, "active_row_flops": tot_rows,
             "achieved": round(tot_exec / tot_ms / 1e9, 2), "achieved_dense_equivalent": round(tot_dense / tot_ms / 1e9, 2),
             "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tot_exec / tot_ms / 1e9 / MFMA_PEAK_TFLOPS, 4),
             "frac_dense_equivalent": round(tot_dense / tot_ms / 1e9 / MFMA_PEAK_TFLOPS, 4),
@@ -272,7 +285,7 @@ def run_mode(a, precision, world, rank, device, want_voxel_roofline):
     elapsed = time.perf_counter() - t0
     final_loss = float(loss.item())
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -393,12 +406,58 @@ def parse_args(argv=None):
     return a
 
 
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment): start the N rank processes from here, as
+    CHILDREN of this process, which has not touched the GPU (a process that has must never exec another program on this pool).  Rank
+    0's stdout is passed through (its last line is the JSON line), the exit code is the worst of the ranks'; when one rank dies the
+    others - stuck in a rendezvous or a collective by then - are ended by PID."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc, live = 0, list(procs)
+    while live:
+        time.sleep(0.2)
+        for p_ in list(live):
+            code = p_.poll()
+            if code is None:
+                continue
+            live.remove(p_)
+            if code != 0:
+                rc = rc or code
+                for q in live:                       # our own children, by PID
+                    q.terminate()
+    return rc
+
+
 def main():
     a = parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a))                     # before anything in this process initialises the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher set WORLD_SIZE={world}")
+    # TRICOLO_DP_SHARE_GPU=1: every rank on cuda:0, collectives over gloo through host memory (parallel.py) - runs the N > 1 code path
+    # (rank-offset row slices, three graphs around the collectives) on a one-GPU box; a validation aid, never a measurement
+    share = os.environ.get("TRICOLO_DP_SHARE_GPU", "0") == "1"
+    ndev = torch.cuda.device_count()                 # (counting devices does not initialise the GPU)
+    if ndev == 0:
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if share:
+        local_rank = 0
+    if local_rank >= ndev:
+        raise SystemExit(f"bench.py --gpus {a.gpus}: rank {rank} needs device {local_rank} but this box has {ndev} GPU(s) "
+                         f"(need {a.gpus} devices; TRICOLO_DP_SHARE_GPU=1 runs all ranks on one GPU over gloo for validation)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -407,8 +466,10 @@ def main():
     if world > 1 or force_dist:
         if force_dist and "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=device)
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     if a.modes is None:
         extra = [m for m in ("bf16x3", "bf16", "f16") if m != a.precision] if world == 1 else []

@@ -57,3 +57,19 @@ def test_product_never_imports_oracle():
                         names = [node.module]
                     bad += [(f, n) for n in names if n.split(".")[0] == "oracle"]
     assert not bad, bad
+
+
+def test_bench_gpus_n_spawns_its_ranks_and_fails_cleanly_without_devices():
+    """`python bench.py --gpus 2` without a launcher starts two rank processes itself (before anything touches the GPU) and, on a box
+    that lacks the devices, every rank exits with a message instead of an assertion / a hang."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    import torch
+    if torch.cuda.device_count() == 0:
+        assert r.stderr.count("needs an MI355X") == 2, r.stderr[-2000:]          # one message per spawned rank
+    elif torch.cuda.device_count() == 1:
+        assert "need 2 devices" in r.stderr, r.stderr[-2000:]

@@ -951,3 +951,59 @@ def test_conv_wgrad_over_a_compact_row_list(name, store, prec):
         junk[(mask == 0).to(DEV)] = 7.0
         out2 = ops.conv_wgrad(xd, junk.view(dyd.shape), g, wp.to(DEV), prec, rows=rows)
         assert torch.equal(out2, ref)
+
+
+def _blob_mask(B, V, seed, p_empty=0.3):
+    """Site mask [B, V, V, V] of solid blobs (a box and an ellipsoid per sample, like the synthetic voxel grids), some samples empty:
+    whole bricks and whole x-runs without an active site, runs cut by a blob boundary, sites on the grid faces."""
+    g = torch.Generator().manual_seed(seed)
+    zz, yy, xx = torch.meshgrid(torch.arange(V), torch.arange(V), torch.arange(V), indexing="ij")
+    m = torch.zeros(B, V, V, V, dtype=torch.bool)
+    for b in range(B):
+        if b > 0 and torch.rand((), generator=g) < p_empty:
+            continue
+        lo = torch.randint(0, V // 2, (3,), generator=g)
+        hi = lo + torch.randint(2, V // 2 + 1, (3,), generator=g)
+        m[b] |= (zz >= lo[0]) & (zz < hi[0]) & (yy >= lo[1]) & (yy < hi[1]) & (xx >= lo[2]) & (xx < hi[2])
+        c = torch.randint(0, V, (3,), generator=g).float()
+        r = torch.randint(2, V // 3, (3,), generator=g).float()
+        m[b] |= ((zz - c[0]) / r[0]) ** 2 + ((yy - c[1]) / r[1]) ** 2 + ((xx - c[2]) / r[2]) ** 2 <= 1.0
+    m[0, 0, 0, 0] = True                                           # a corner site: every out-of-grid tap direction at once
+    m[0, V - 1, V - 1, V - 1] = True
+    return m
+
+
+@pytest.mark.parametrize("store,prec", STORE16, ids=STORE16_IDS)
+@pytest.mark.parametrize("B,V", [(3, 32), (2, 64)])
+def test_voxel_level0_brick_kernel(B, V, store, prec):
+    """conv_vox0_kernel (conv_vox.hip): level 0 of the voxel tower (sparse_cnn.py:12, 3 -> 32 channels) over the dense grid by the
+    site mask.  Integer data: every active row equals the masked dense convolution exactly, rows of inactive sites are not written,
+    the BatchNorm records (one per workgroup) sum to the column sums of the active rows; and without a mask it is the plain conv."""
+    case = ("vox0", B, (V, V, V), 3, 32, (3, 3, 3), 1, (1, 1, 1), "spconv")
+    x, w, wp, xcl, g = make_case(case, integer=True, seed=71)
+    assert g.brick(False, 2), "level-0 geometry should plan the brick kernel in the 16-bit modes"
+    m = _blob_mask(B, V, seed=73)
+    mf = m.float()
+    x = x * mf[:, None]                                             # submanifold invariant: inactive sites are exactly zero
+    xcl = xcl * mf[..., None]
+    ref = cl3(F.conv3d(x, w, padding=1)).to(store)
+    packed = ops.pack_weight(wp.to(DEV), g, prec)
+    M = B * V ** 3
+    mask = m.reshape(M).to(torch.uint8)
+    junk = torch.full((B, V, V, V, 32), 777.0, dtype=store, device=DEV)
+    out, stats = ops.conv_fwd(xcl.to(DEV).to(store), g, packed, row_mask=mask.to(DEV), want_stats=True, out=junk)
+    assert stats.shape[0] == g.num_mtiles[2]
+    o = out.cpu().reshape(M, 32)
+    act = mask.bool()
+    assert torch.equal(o[act], ref.reshape(M, 32)[act])
+    assert bool((o[~act] == 777.0).all()), "rows of inactive sites must not be written"
+    exact = ref.reshape(M, 32)[act].double()
+    st = stats.cpu().double().sum(0)
+    np.testing.assert_allclose(st[0].numpy(), exact.sum(0).numpy(), rtol=1e-6, atol=1e-2)
+    np.testing.assert_allclose(st[1].numpy(), (exact ** 2).sum(0).numpy(), rtol=1e-6, atol=1e-2)
+    if B * V ** 3 <= 3 * 32 ** 3:                                   # no mask: every site active (the dense convolution)
+        xd, _, _, xdcl, _ = make_case(case, integer=True, seed=79)
+        out2 = ops.conv_fwd(xdcl.to(DEV).to(store), g, packed)
+        assert torch.equal(out2.cpu(), cl3(F.conv3d(xd, w, padding=1)).to(store))
+    with pytest.raises(RuntimeError):                               # a compact row list is refused (the kernel walks the grid by the mask)
+        ops.conv_fwd(xcl.to(DEV).to(store), g, packed, rows=ops.mask_compact(mask.to(DEV), M))

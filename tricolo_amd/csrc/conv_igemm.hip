@@ -14,6 +14,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include "../../include/tricolo_hip.h"
+#include "conv_vox.h"
 
 struct ConvArgs {
     const void* in;            // activations: fp32 or bf16 (kernel template parameter AT)
@@ -1762,6 +1763,8 @@ struct ConvPlan {
     int h_wgrec;          // 1: one BatchNorm record per workgroup (h_grid / (Cout / 64) records), 0: one per row tile (h_mtiles)
     int stem;             // 1: conv_stem_kernel (2D, 4 stored input channels, stride 2, Cout 64, 16-bit storage); records = stem_grid
     int stem_grid;
+    int vox0;             // 1: conv_vox0_kernel (conv_vox.hip: level 0 of the voxel tower, 16-bit storage); records = vox0_grid
+    int vox0_grid;
     int dma;              // 1: LDS-DMA kernel (16-bit activation storage, Cin % 64 == 0), 64-wide k-steps
     int nunits;           // k-steps (32 wide, or 64 wide for the DMA kernel)
     int ksplit, per_split;
@@ -1888,6 +1891,13 @@ static ConvPlan conv_make_plan(int B, int ID, int IH, int IW, int cin, int OD, i
     if (split_mode == 2 && cin % 64 == 0 && cout % 64 == 0 && !dma_disabled()) pl.dma = 1;
     pl.bn = bn;
     {
+        TriVox0Geom vg;
+        if (split_mode == 2 && tri_internal_vox0_geometry(B, ID, IH, IW, cin, OD, OH, OW, cout, KD, KH, KW, stride, pd, ph, pw, &vg)) {
+            pl.vox0 = 1; pl.vox0_grid = vg.grid; pl.bn = 32; pl.nunits = 4; pl.ksplit = 1; pl.per_split = 4;
+            return pl;
+        }
+    }
+    {
         StemGeom sgm;
         if (split_mode == 2 && !stem_disabled() && ID == 1 && OD == 1 &&
             stem_geometry(B, IH, IW, cin, OH, OW, cout, KD, KH, KW, stride, pd, ph, pw, &sgm)) {
@@ -1930,10 +1940,24 @@ static ConvPlan conv_make_plan(int B, int ID, int IH, int IW, int cin, int OD, i
     return pl;
 }
 
-static int dma_stages() {                                       // tuning aid: TRICOLO_DMA_STAGES = 2 | 3
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("TRICOLO_DMA_STAGES"); v = (e && atoi(e) == 3) ? 3 : 2; }
-    return v;
+// Pipeline depth of conv_dma_kernel (stages of [128 x 64] + [BN x 64] operand tiles in LDS, NST - 1 of them in flight under the
+// MFMAs).  Launches that fill the GPU several times over run 2 stages x 3 workgroups per CU (profiles/r1/README.md: 2.01 vs 2.24 ms
+// over the ResNet layers); launches that cannot - the deep voxel levels over a compact row list, split-K layers, small data
+// gradients - are a chain of exposed DMA latencies with one k-step in flight (round 2: 1.0-1.15 us per k-step), so they take 4
+// stages (three k-steps in flight, one workgroup per CU).  TRICOLO_DMA_STAGES = 2 | 3 | 4 forces one depth everywhere,
+// TRICOLO_DMA_STAGES_ROWS the depth of the row-list launches.
+static int dma_stages_env(const char* name) {
+    const char* e = getenv(name);
+    int v = e ? atoi(e) : 0;
+    return (v >= 2 && v <= 4) ? v : 0;
+}
+static int dma_stages_for(const ConvArgs& a, int bn) {
+    static int forced = -1, rows = -1;
+    if (forced < 0) { forced = dma_stages_env("TRICOLO_DMA_STAGES"); rows = dma_stages_env("TRICOLO_DMA_STAGES_ROWS"); }
+    if (forced) return forced;
+    if (a.row_count) return rows ? rows : 4;
+    const long wgs = (long)((a.M + 127) / 128) * (a.Cout / bn) * a.ksplit;
+    return wgs <= 2L * num_cus() ? 4 : 2;
 }
 
 template <int BN, int NST, typename AT>
@@ -2052,8 +2076,11 @@ static int launch_stem(ConvArgs& a, hipStream_t stream) {
 
 template <typename AT>
 static int launch_dma_any(const ConvArgs& a, int bn, hipStream_t stream) {
-    if (dma_stages() == 2) return bn == 128 ? launch_dma<128, 2, AT>(a, stream) : launch_dma<64, 2, AT>(a, stream);
-    return bn == 128 ? launch_dma<128, 3, AT>(a, stream) : launch_dma<64, 3, AT>(a, stream);
+    switch (dma_stages_for(a, bn)) {
+        case 4: return bn == 128 ? launch_dma<128, 4, AT>(a, stream) : launch_dma<64, 4, AT>(a, stream);
+        case 3: return bn == 128 ? launch_dma<128, 3, AT>(a, stream) : launch_dma<64, 3, AT>(a, stream);
+        default: return bn == 128 ? launch_dma<128, 2, AT>(a, stream) : launch_dma<64, 2, AT>(a, stream);
+    }
 }
 
 static int conv_dispatch(ConvArgs& a, int act_fmt, void* workspace, size_t workspace_bytes, hipStream_t stream) {
@@ -2094,6 +2121,18 @@ static int conv_dispatch(ConvArgs& a, int act_fmt, void* workspace, size_t works
     } else if (a.row_pos && !(pl.dma && pl.ksplit == 1 && !a.row_mask && !a.stats && a.Kpad / 64 <= 128)) {
         a.row_pos = nullptr;          // a pure visiting-order hint: honoured by the DMA kernel without split-K, dropped elsewhere
     }
+    if (pl.vox0 && !a.transposed) {
+        // the brick kernel walks the dense grid by the SITE MASK (rows of inactive sites are neither computed nor written); its
+        // BatchNorm records are one per workgroup, which is what tri_conv_num_mtiles reports for this layer
+        if (a.row_count || a.bias || a.act != 0 || a.accumulate) {
+            tri_set_error("conv: this layer runs the brick kernel (tri_conv_kernel_family == 6): pass the site mask as row_mask, no row list, "
+                          "bias, activation or accumulate");
+            return TRI_ERR_ARG;
+        }
+        TriVox0Geom vg;
+        tri_internal_vox0_geometry(a.B, a.ID, a.IH, a.IW, a.Cin, a.OD, a.OH, a.OW, a.Cout, a.KD, a.KH, a.KW, a.stride, a.pd, a.ph, a.pw, &vg);
+        return tri_internal_vox0_launch(vg, a.B, a.in, a.w_hi, a.Kpad, a.out, a.row_mask, a.stats, act_fmt, stream);
+    }
     if (pl.stem && !a.transposed && !a.row_mask && !a.row_count && !a.bias && a.act == 0 && !a.accumulate) {
         a.row_pos = nullptr;
         return act_fmt == TRI_FMT_F16 ? launch_stem<f16_t>(a, stream) : launch_stem<bf16_t>(a, stream);
@@ -2123,6 +2162,7 @@ extern "C" int tri_conv_num_mtiles(const TriConvDesc* d, int split3) {
     ConvPlan pl = conv_make_plan(d->B, d->ID, d->IH, d->IW, d->Cin, d->OD, d->OH, d->OW, d->Cout, d->KD, d->KH, d->KW, d->stride, d->pad_d,
                                  d->pad_h, d->pad_w, split3);
     if (pl.stem) return pl.stem_grid;
+    if (pl.vox0) return pl.vox0_grid;
     if (pl.halo) return pl.h_wgrec ? pl.h_grid / (d->Cout / 64) : pl.h_mtiles;
     return pl.ksplit > 1 ? (int)((M + 31) / 32) : (int)((M + 127) / 128);
 }
@@ -2134,6 +2174,7 @@ extern "C" int tri_conv_kernel_family(const TriConvDesc* d, int transposed, int 
                              : conv_make_plan(d->B, d->ID, d->IH, d->IW, d->Cin, d->OD, d->OH, d->OW, d->Cout, d->KD, d->KH, d->KW, d->stride,
                                               d->pad_d, d->pad_h, d->pad_w, split3);
     if (pl.stem && !transposed) return 4 | (64 << 8);
+    if (pl.vox0 && !transposed) return 6 | (32 << 8);
     if (pl.halo) return (pl.h_v5 ? 5 : 3) | (pl.halo << 8);
     return (pl.dma ? 2 : 0) | (pl.bn << 8) | ((pl.ksplit > 1 || (pl.dma && tri_conv_kpad(d->KD * d->KH * d->KW, transposed ? d->Cout : d->Cin) / 64 > 128)) ? (1 << 16) : 0);
 }

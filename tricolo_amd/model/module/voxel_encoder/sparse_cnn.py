@@ -110,7 +110,8 @@ class SparseCNNEncoder(TriModule):
             g = self._geom(B, l)
             conv, bn = self.sparseModel[str(4 * l)], self.sparseModel[str(4 * l + 1)]
             packed = self._packed[(l, False)]
-            use_rows = compact and not g.splitk(False, ops._conv_mode(x, packed[1]))
+            mode = ops._conv_mode(x, packed[1])
+            use_rows = compact and not g.splitk(False, mode) and not g.brick(False, mode)      # brick kernels walk the grid by the mask
             sel = dict(rows=rows) if use_rows else dict(row_mask=mask)
             if train:
                 y, stats = ops.conv_fwd(x, g, packed, want_stats=True, **sel)

@@ -99,6 +99,8 @@ def _igemm_symbol(g, transposed, split, t):
     h16 = t.dtype != torch.float32
     code = g.kernel_family[(transposed, 1 if split else (2 if h16 else 0))]
     fam, bn = code & 255, (code >> 8) & 255
+    if fam == 6:
+        return f"conv_vox0_kernel<{_TNAME[t.dtype]}>"
     if fam == 4:
         return f"conv_stem_kernel<{g.kernel[1]}, {_TNAME[t.dtype]}>"
     if fam == 5:
@@ -106,7 +108,7 @@ def _igemm_symbol(g, transposed, split, t):
     if fam == 3:
         return f"conv_halo2d_kernel<{bn}, {_TNAME[t.dtype]}>"     # (both record variants under one name)
     if fam == 2:
-        return f"conv_dma_kernel<{bn}, {3 if os.environ.get('TRICOLO_DMA_STAGES') == '3' else 2}, {_TNAME[t.dtype]}>"
+        return f"conv_dma_kernel<{bn}, {_TNAME[t.dtype]}>"           # (pipeline depths 2 / 3 / 4 under one name)
     return f"conv_igemm_kernel<{bn}, {2 if split else 1}, {_TNAME[t.dtype]}>"
 
 
@@ -203,6 +205,11 @@ class ConvGeom:
             t = order.to(torch.int32).to(device)
             self._plans[("rowpos", device)] = t
         return t
+
+    def brick(self, transposed: bool, mode: int) -> bool:
+        """True when tri_conv_fwd runs this layer on a brick kernel of conv_vox.hip: such launches take the site mask as row_mask
+        (rows of inactive sites are then neither computed nor written), not a compact row list."""
+        return (self.kernel_family[(transposed, mode)] & 255) == 6
 
     def splitk(self, transposed: bool, mode: int) -> bool:
         """True when tri_conv_fwd / tri_conv_dgrad runs this layer split-K in plan `mode` (_conv_mode): such launches take

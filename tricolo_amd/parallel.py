@@ -29,12 +29,45 @@ def is_dist() -> bool:
     return dist.get_world_size() > 1 or os.environ.get("TRICOLO_FORCE_DIST", "0") == "1"
 
 
+def _host_staged(t: torch.Tensor) -> bool:
+    """Device tensors under the gloo backend (several ranks sharing ONE GPU in the tests, or a box without RCCL) cross the
+    process boundary through host memory; under "nccl" (= RCCL over xGMI) the collective takes the device buffer itself."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+class _Done:
+    """Handle of a collective that already completed (the host-staged path is synchronous)."""
+
+    def wait(self):
+        return True
+
+
+def all_gather_rows(out: torch.Tensor, x: torch.Tensor) -> None:
+    """out[world * rows, ...] = the ranks' x[rows, ...] in rank order (all_gather_into_tensor)."""
+    if _host_staged(x):
+        ho = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(ho, x.detach().cpu().contiguous())
+        out.copy_(ho)
+        return
+    dist.all_gather_into_tensor(out, x.contiguous())
+
+
+def all_reduce_sum(t: torch.Tensor, async_op: bool = False):
+    """In-place SUM all-reduce of a (flat, contiguous) tensor; returns a handle with wait() when async_op."""
+    if _host_staged(t):
+        h = t.detach().cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        t.copy_(h)
+        return _Done() if async_op else None
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=async_op)
+
+
 class _AllGatherRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
         world = dist.get_world_size()
         out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-        dist.all_gather_into_tensor(out, x.contiguous())
+        all_gather_rows(out, x)
         ctx.rows = x.shape[0]
         return out
 
@@ -67,7 +100,10 @@ def allreduce_gradients(params, op=None) -> None:
     if not grads:
         return
     flat = torch.cat([g.reshape(-1) for g in grads])
-    dist.all_reduce(flat, op=op or dist.ReduceOp.SUM)
+    if op is None or op == dist.ReduceOp.SUM:
+        all_reduce_sum(flat)
+    else:
+        dist.all_reduce(flat, op=op)
     off = 0
     for g in grads:
         n = g.numel()
@@ -78,7 +114,7 @@ def allreduce_gradients(params, op=None) -> None:
 def allreduce_flat(flat: torch.Tensor) -> None:
     """In-place SUM all-reduce of one flat gradient bucket (hook for FusedAdam.step(reduce_fn=...))."""
     if is_dist():
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        all_reduce_sum(flat)
 
 
 class BackwardSplit:
@@ -90,8 +126,8 @@ class BackwardSplit:
     to the part below (they get their gradients last).  Several gates may be open in one forward pass (stage 2 then runs
     from all cuts at once).  For TriCoLoNet on the HIP modules there are two: inside the image tower between layer2 and layer3
     (MVCNNEncoder installs it when it is given a split) and at the voxel tower's output (TriCoLoNet.forward).  Stage 1 = text
-    tower + image layer3-4 + heads (68 % of the gradient bytes, reduced while stage 2 runs); stage 2 = image stem + layer1-2
-    beside the whole voxel tower on its own stream - measured on one GPU, a single gate inside the image tower cost 0.43 ms per
+    tower + image layer3-4 + heads (68 % of the gradient bytes of Tri(I+V) at 32^3: 12.6 of 18.5 M parameters, reduced while stage 2
+    runs); stage 2 = image stem + layer1-2 (0.68 M) beside the whole voxel tower (5.2 M) on its own stream - measured on one GPU, a single gate inside the image tower cost 0.43 ms per
     step because the voxel tower's backward, no longer hidden under the image tower's, then bounded stage 1."""
 
     def __init__(self, net, late_params):
@@ -152,7 +188,12 @@ def _runs(params, order):
 
 
 def _pack(params, out):
-    torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params], out=out)
+    # every parameter of a bucket needs a gradient: the flat Adam kernel updates ALL of them (weight decay, moment decay), which is not
+    # what torch.optim.Adam does for a parameter without one - the same rule FusedAdam.step enforces on the single-bucket path
+    if any(p.grad is None for p in params):
+        raise RuntimeError("parallel: a parameter of the gradient bucket has no gradient (the packed-gradient path needs one for every "
+                           "parameter; freeze it with requires_grad_(False) instead)")
+    torch.cat([p.grad.reshape(-1) for p in params], out=out)
 
 
 def backward_stage1(root, grad_root, split: BackwardSplit):
@@ -186,12 +227,12 @@ def backward_overlapped(total, split: BackwardSplit, order, flat=None):
     for s, e, ps in early_runs:
         _pack(ps, flat[s:e])
         if is_dist():
-            handles.append(dist.all_reduce(flat[s:e], op=dist.ReduceOp.SUM, async_op=True))     # runs under stage 2
+            handles.append(all_reduce_sum(flat[s:e], async_op=True))                            # runs under stage 2
     backward_stage2(split)
     for s, e, ps in late_runs:
         _pack(ps, flat[s:e])
         if is_dist():
-            handles.append(dist.all_reduce(flat[s:e], op=dist.ReduceOp.SUM, async_op=True))
+            handles.append(all_reduce_sum(flat[s:e], async_op=True))
     for h in handles:
         h.wait()
     return flat
@@ -206,7 +247,9 @@ def dp_training_step(net, batch, optimizer=None, split: BackwardSplit | None = N
     losses = net._calculate_losses(out, "train_loss")
     if optimizer is not None:
         optimizer.zero_grad(set_to_none=True)
-    if split is not None and optimizer is not None and getattr(optimizer, "_flatten", False) and is_dist():
+    if split is not None and optimizer is not None and getattr(optimizer, "_flatten", False):
+        # the two-stage backward whenever a split is installed (its gate refuses a plain backward); in a world of one the buckets
+        # are simply not reduced
         optimizer.prepare()
         flat = backward_overlapped(losses["train_loss/total_loss"], split, optimizer._params)
         optimizer.apply_flat(flat)
@@ -233,7 +276,7 @@ class GraphedDPStep:
     With `split` (BackwardSplit.for_net) graph B is cut in two at the image tower's layer2 / layer3 boundary:
 
         graph B1  loss, backward of the text / voxel towers and of the image tower's upper half, pack of those gradients
-        eager     all_reduce(early ranges of the flat gradient, async)      <- 96 % of the bytes, runs UNDER graph B2
+        eager     all_reduce(early ranges of the flat gradient, async)      <- 68 % of the bytes (Tri 32^3), runs UNDER graph B2
         graph B2  backward of stem + layer1 + layer2, pack of the late range
         eager     all_reduce(late range, async); wait for both
 
@@ -296,14 +339,14 @@ class GraphedDPStep:
 
     def replay(self):
         self.gA.replay()
-        dist.all_gather_into_tensor(self.full, self.packed)
+        all_gather_rows(self.full, self.packed)
         self.gB.replay()
         if self.split is None:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            all_reduce_sum(self.flat)
         else:
-            hs = [dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, async_op=True) for s, e, _ in self.early_runs]
+            hs = [all_reduce_sum(self.flat[s:e], async_op=True) for s, e, _ in self.early_runs]
             self.gB2.replay()                                           # runs while the early ranges are being reduced
-            hs += [dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, async_op=True) for s, e, _ in self.late_runs]
+            hs += [all_reduce_sum(self.flat[s:e], async_op=True) for s, e, _ in self.late_runs]
             for h in hs:
                 h.wait()
         self.gC.replay()
