@@ -92,9 +92,13 @@ int tri_linear_small_bwd(const float* x, const float* dout, const float* y, cons
  * descriptor.  wgrad writes dw through element strides, i.e. directly in the reference's parameter layout. */
 /* split3: 0 = bf16 operands / fp32 activations, 1 = bf16x3 (hi + lo operands), 2 = 16-bit operands and activation storage (bf16 or f16) */
 int tri_conv_num_mtiles(const TriConvDesc* d, int split3);
+/* the same for a call that passes a compact row list (row_list = 1: row_pos + row_count): such launches are planned for the voxel
+ * grids' occupancy (<= 25 %), so a small level may run split-K over its list where the dense call would not */
+int tri_conv_num_records(const TriConvDesc* d, int split3, int row_list);
 /* kernel family tri_conv_fwd (transposed = 0) / tri_conv_dgrad (transposed = 1) dispatches for this layer and mode:
  * 0 conv_igemm_kernel (register-staged im2col), 2 conv_dma_kernel (LDS-DMA staging); bits 8.. hold the output-channel
- * tile width; bit 16 set = the layer runs split-K in this mode (compact row lists are refused, use row_mask).  For profilers. */
+ * tile width; bit 16 set = the dense call of the layer runs split-K in this mode; 4 conv_stem_kernel, 3 / 5 the halo kernels,
+ * 6 / 7 = a brick kernel of conv_vox.hip (voxel level 0 / 1; takes the site mask as row_mask, refuses a row list).  For profilers. */
 int tri_conv_kernel_family(const TriConvDesc* d, int transposed, int split3);
 /* same for tri_conv_wgrad: 0 conv_wgrad_kernel, 2 conv_wgrad_dma_kernel (taken when act_fmt != 0 and the layer qualifies) */
 int tri_conv_wgrad_kernel_family(const TriConvDesc* d, int act_fmt);
@@ -210,8 +214,7 @@ int tri_mask_count(const uint8_t* mask, long n, int* count, void* stream);
 int tri_debug_stamp(unsigned long long* slot, void* stream);
 /* active-site list of a submanifold level: row_pos[0 .. *count) = positions with mask != 0, ascending; *count = how many.
  * Hand row_pos + count to tri_conv_fwd / tri_conv_dgrad: they then compute (and write) ONLY those rows - executed work =
- * active work (spconv's rulebook idea on a dense index space).  Layers that run split-K (tri_conv_kernel_family bit 16)
- * take row_mask instead.  scratch: tri_mask_compact_scratch(n) bytes. */
+ * active work (spconv's rulebook idea on a dense index space).  Split-K layers take the list too (slab row = list row).  scratch: tri_mask_compact_scratch(n) bytes. */
 size_t tri_mask_compact_scratch(long n);
 int tri_mask_compact(const uint8_t* mask, long n, int* row_pos, int* count, void* scratch, void* stream);
 int tri_nchw3_to_nhwc4(const float* x, int N, int H, int W, void* out, int act_fmt, void* stream);
@@ -270,6 +273,8 @@ int tri_ntxent_multi_bwd(const float* const* z, int M, int B, int D, float tempe
                          size_t workspace_bytes, void* stream);
 
 /* ---- Adam (torch.optim.Adam as instantiated by config/config.yaml:50-53, tricolo_net.py:43-44) ------------------------ */
+/* `step` is a DEVICE int[2]: [0] the step counter (tri_adam_tick adds one), [1] the running count of gradient elements the update
+ * kernels skipped because they were inf / NaN (overflow guard of the f16 mode: such an element leaves p, m and v untouched). */
 int tri_adam_tick(int* step, void* stream);
 /* lr_dev (optional, DEVICE float): when not NULL the learning rate is read from it at run time, so a captured HIP graph
  * follows a schedule (LrDecayCallback of train.py) without re-capture; `lr` is used otherwise.  Bias corrections in double. */

@@ -212,6 +212,114 @@ def test_mvcnn_encoder_matches_reference(golden, tag, B, nv, S):
             np.testing.assert_allclose(s, g[f"{tag}/after/wsample/{name}"], rtol=1e-4, atol=1e-5, err_msg=name)
 
 
+def test_mvcnn_gradients_within_measured_conditioning(golden):
+    """The ResNet-18 tower's parameter gradients against FLOAT64 gradients of the reference wrapper, each tensor bounded by its own
+    measured conditioning (tests/golden/mvcnn_sens.npz, oracle/make_mvcnn_sensitivity.py: how far the float64 gradient itself moves
+    under a 1.5e-5 relative weight perturbation, the size of the split-bf16 operand error).  Round-3 finding: that perturbation moves
+    the float64 gradients by 4.4 % in L2 (median over tensors; ReLU masks of near-zero activations flip) while norms move 0.2 % - the
+    HIP path sits at the same 4 % (its forward is within 6e-5), so the element-wise pin of THIS fixture cannot be tighter than that;
+    the tight pin of the backward composition is test_mvcnn_backward_replay_with_forced_routing below.  Checked here: embeddings,
+    norms and probes within 3 x their sensitivity, and the 40 BatchNorm weight / bias gradients WHOLE within 3 x their L2
+    sensitivity (well-conditioned tensors such as layer4.1's biases are thereby pinned to ~1e-3)."""
+    g = golden("mvcnn_sens")
+    tag, B, nv, S = "v6s128", 8, 6, 128
+    m = MVCNNEncoder(512, 512, "resnet18", nv)
+    fill_module(m, prefix="image_encoder.")
+    m = m.to(DEV)
+    batch = syn.make_batch(B, voxel_size=None, num_views=nv, image_size=S, seed=syn.BASE_SEED + 3)
+    assert _sha(batch["images"]) == str(g[f"{tag}/input_sha"])
+    z = m(batch["images"].flatten(end_dim=1).to(DEV), batch)
+    np.testing.assert_allclose(z.detach().cpu().numpy(), g[f"{tag}/z64"], atol=EMB_TOL)
+    up = torch.randn((B, 512), generator=torch.Generator().manual_seed(13))
+    (z * up.to(DEV)).sum().backward()
+    bad, worst, worst_l2, nvec = [], 0.0, 0.0, 0
+    for name, p in m.named_parameters():
+        ref_n, ref_s = float(g[f"{tag}/gradnorm64/{name}"]), g[f"{tag}/gradsample64/{name}"]
+        sn, ss, sl = float(g[f"{tag}/sens_norm/{name}"]), float(g[f"{tag}/sens_sample/{name}"]), float(g[f"{tag}/sens_l2/{name}"])
+        bn, bs, bl = 3.0 * max(sn, 0.25 * sl) + 2e-4, 3.0 * ss + 2e-3, 3.0 * sl + 2e-4
+        n, smp = probe(p.grad.cpu())
+        rms = max(ref_n / np.sqrt(p.numel()), 1e-30)
+        dn, ds = abs(n - ref_n) / max(ref_n, 1e-30), float(np.abs(smp.astype(np.float64) - ref_s).max()) / rms
+        worst = max(worst, dn / bn, ds / bs)
+        if dn > bn or ds > bs:
+            bad.append((name, "norm/probe", dn, bn, ds, bs))
+        key = f"{tag}/grad64/{name}"
+        if key in g:                                                # whole vector stored: element-wise L2
+            ref_v = g[key]
+            dl = float(np.linalg.norm(p.grad.detach().double().cpu().numpy().reshape(-1) - ref_v) / max(np.linalg.norm(ref_v), 1e-300))
+            worst_l2 = max(worst_l2, dl / bl)
+            nvec += 1
+            if dl > bl:
+                bad.append((name, "L2", dl, bl))
+    _report("grads/mvcnn_conditioning", {"worst_ratio_to_bound_norm_probe": worst, "worst_ratio_to_bound_l2": worst_l2, "vectors_checked_whole": nvec})
+    assert nvec >= 40 and not bad, bad
+
+
+def test_mvcnn_backward_replay_with_forced_routing():
+    """A tight pin of the image tower's BACKWARD composition (the flat gradient bounds could not see a 1 % bug).
+    The ResNet's gradient is discontinuous in its activations - a ReLU mask or a view arg-max that flips under a 1e-5 forward
+    difference changes gradient elements by O(1), which is where this fixture's 4 % element-wise noise floor comes from.  Here the
+    float64 oracle is replayed with the ROUTING FORCED to the HIP forward's: every block ReLU multiplies by the mask of the HIP path's
+    own stored activations, the view max gathers the HIP path's arg-max view.  What is left is a smooth function of the weights, and
+    the HIP gradients of every trunk tensor above the stem must agree with it element-wise: relative L2 <= 2e-3 per tensor (measured
+    in profiles/r3/parity_report.json).  The stem's conv1 / bn1 are excluded (their ReLU + max-pool routing is inside a fused kernel
+    whose masks are not stored); the heads are included."""
+    from oracle import modules as om
+    B, nv, S = 8, 6, 128
+    batch = syn.make_batch(B, voxel_size=None, num_views=nv, image_size=S, seed=syn.BASE_SEED + 3)
+    up = torch.randn((B, 512), generator=torch.Generator().manual_seed(13))
+    m = MVCNNEncoder(512, 512, "resnet18", nv)
+    fill_module(m, prefix="image_encoder.")
+    m = m.to(DEV)
+    images = batch["images"].flatten(end_dim=1)
+    z = m(images.to(DEV), batch)
+    (z * up.to(DEV)).sum().backward()
+    with torch.no_grad():                                            # the same forward again, keeping its activations
+        _, saved = m._forward_impl(images.to(DEV), save=True)
+    blocks = saved["lower"]["blocks"] + saved["upper"]["blocks"]
+    masks = []
+    for sv in blocks:                                                # (x, y1, co1, g1, a1, y2, co2, g2, yd, cod, gd, out), channels-last
+        for tns in (sv[4], sv[-1]):
+            masks.append((tns[:, 0] > 0).permute(0, 3, 1, 2).cpu())  # -> [N, C, H, W] bool
+    arg = saved["upper"]["arg"].cpu().long()                         # [B, 512] winning view
+
+    class Forced(torch.nn.Module):
+        def __init__(self, it):
+            super().__init__()
+            self.it = it
+
+        def forward(self, x):
+            return x * next(self.it).to(x.dtype)
+
+    ref = om.MVCNNRef(512, 512, "resnet18", nv)
+    fill_module(ref, prefix="image_encoder.")
+    ref = ref.double()
+    it = iter(masks)
+    for li in (4, 5, 6, 7):
+        for blk in ref.net_1[li]:
+            blk.relu = Forced(it)                                    # called twice per block: after bn1, after the residual sum
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    y = ref.net_1(images.double())                                   # [N, 512, 1, 1]
+    y = y.view(B, nv, 512)
+    y = torch.gather(y, 1, arg.view(B, 1, 512)).view(B, 512)        # the HIP path's view instead of torch.max
+    zr = torch.nn.functional.normalize(ref.mlp(ref.net_2(y)), dim=1)
+    assert next(it, None) is None
+    np.testing.assert_allclose(z.detach().cpu().numpy(), zr.detach().numpy(), atol=EMB_TOL)
+    (zr * up.double()).sum().backward()
+    rg = dict(ref.named_parameters())
+    worst, bad = 0.0, []
+    for name, p in m.named_parameters():
+        if name in ("net_1.0.weight", "net_1.1.weight", "net_1.1.bias"):
+            continue
+        a = rg[name].grad
+        dl = float((p.grad.detach().double().cpu() - a).norm() / a.norm().clamp_min(1e-300))
+        worst = max(worst, dl)
+        if dl > 2e-3:
+            bad.append((name, dl))
+    _report("grads/mvcnn_forced_routing_replay", {"worst_rel_l2": worst})
+    assert not bad, bad
+
+
 def test_ntxent_module_autograd(golden):
     g = golden("ntxent")
     za = torch.from_numpy(g["b8/za"]).to(DEV).requires_grad_()
@@ -570,17 +678,29 @@ def test_config5_full_per_gpu_batch_properties(prec):
     ("config4", "BiGRUEncoder", "MVCNNEncoder", "SparseCNNEncoder", 32, 6, 128, 32),
 ], ids=["config2", "config3", "config4"])
 def test_full_per_gpu_batch_properties_and_mode_agreement(tag, text, image, voxel, V, nv, S, B):
-    """BASELINE configs 2-4 at their real per-GPU batch (the fixtures hold 8 samples): the f16 step against the bf16x3 step of the
-    same weights on the same batch - step-0 loss within the north star's 1e-3, embeddings within 5e-4 - plus the size-independent
-    properties of test_config5_full_per_gpu_batch_properties.  These sizes also take kernel variants the fixtures never reach
-    (per-workgroup BatchNorm records, the slab-based layer1 weight gradient of config 3, row-list launches with > 10^5 rows)."""
-    res = {}
-    for prec in ("bf16x3", "f16"):
+    """BASELINE configs 2-4 at their real per-GPU batch (the fixtures hold 8 samples).  Every precision mode - bf16x3, f16 and the
+    bf16 that BASELINE config 2 names - runs one step on the same weights and batch; its step-0 loss and embeddings are compared with
+    the fp32 CPU ORACLE's forward on that full-size batch (not only with another HIP mode): bf16x3 and f16 inside the north star's
+    1e-3 on the loss / 5e-4 on the unit-norm embeddings, bf16 inside its stated 1e-2 / 5e-3.  Plus the size-independent properties of
+    test_config5_full_per_gpu_batch_properties.  These sizes also take kernel variants the fixtures never reach (per-workgroup
+    BatchNorm records, the slab-based layer1 weight gradient of config 3, row-list launches with > 10^5 rows, the brick kernel)."""
+    from itertools import combinations
+    from oracle import modules as om
+    host_batch = syn.make_batch(B, voxel_size=V if voxel else None, num_views=nv if image else None, image_size=S, seed=syn.BASE_SEED + 61)
+    ref = om.TriCoLoRef(om.BiGRURef(syn.DEFAULT_VOCAB, 512), om.MVCNNRef(512, 512, "resnet18", nv) if image else None,
+                        om.SparseCNNRef(V, 32, 512, 512) if voxel else None)
+    fill_module(ref)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    with torch.no_grad():                                   # train-mode forward (batch statistics), fp32, no step
+        remb = ref(host_batch)
+        rtotal = float(sum(om.nt_xent_ref(remb[a], remb[b], 0.1, 0.25) for a, b in combinations(remb.keys(), 2)))
+    bounds = {"bf16x3": (1e-3, 5e-4), "f16": (1e-3, 5e-4), "bf16": (1e-2, 5e-3)}
+    res, rep = {}, {"loss_oracle_fp32": rtotal}
+    for prec in ("bf16x3", "f16", "bf16"):
         ops.set_default_precision(prec)
         torch.manual_seed(1234)
         net, cfg = _build_net(text, image, voxel, V, nv, S)
-        batch = syn.batch_to_device(syn.make_batch(B, voxel_size=V if voxel else None, num_views=nv if image else None, image_size=S,
-                                                   seed=syn.BASE_SEED + 61), DEV)
+        batch = syn.batch_to_device(host_batch, DEV)
         opt = net.configure_optimizers()
         emb = net(batch)
         for k, v in emb.items():
@@ -594,11 +714,17 @@ def test_full_per_gpu_batch_properties_and_mode_agreement(tag, text, image, voxe
         after = net._calculate_losses(net(batch), "train_loss")["train_loss/total_loss"].item()
         assert np.isfinite(after) and after < total.item()
         res[prec] = (total.item(), after, {k: v.detach().float().cpu() for k, v in emb.items()})
+        dl = abs(total.item() - rtotal)
+        de = max(float((res[prec][2][k] - remb[k]).abs().max()) for k in remb)
+        rep.update({f"loss_{prec}": total.item(), f"loss_abs_diff_vs_oracle_{prec}": dl, f"embedding_max_abs_diff_vs_oracle_{prec}": de,
+                    f"loss_after_1_step_{prec}": after})
+        _report(f"fullbatch/{tag}", rep)
+        assert dl < bounds[prec][0] and de < bounds[prec][1], (prec, dl, de)
         del net, opt
     dl = abs(res["f16"][0] - res["bf16x3"][0])
     de = max(float((res["f16"][2][k] - res["bf16x3"][2][k]).abs().max()) for k in res["f16"][2])
-    _report(f"fullbatch/{tag}", {"loss_bf16x3": res["bf16x3"][0], "loss_f16": res["f16"][0], "loss_abs_diff": dl, "embedding_max_abs_diff": de,
-                                 "loss_after_1_step_bf16x3": res["bf16x3"][1], "loss_after_1_step_f16": res["f16"][1]})
+    rep.update({"loss_abs_diff_f16_vs_bf16x3": dl, "embedding_max_abs_diff_f16_vs_bf16x3": de})
+    _report(f"fullbatch/{tag}", rep)
     assert dl < 1e-3 and de < 5e-4
 
 
@@ -620,12 +746,14 @@ def _heldout_batches(steps):
 @pytest.mark.parametrize("prec,bound", [("bf16x3", 0.2), ("f16", 0.2), ("bf16", 1.0)])
 def test_heldout_retrieval_rr1(golden, prec, bound):
     """North star: retrieval RR@1 within +-0.2 of the reference on the same held-out synthetic set (512 unseen shapes x
-    5 captions = 2,560 queries of a learnable factor space).  The reference side is the CPU oracle trained in the build container
-    (oracle/make_heldout_rr.py -> tests/golden/heldout_rr.npz); the HIP path is trained here from the same recipe weights on the
+    5 captions = 2,560 queries of a learnable factor space).  The reference side is the REAL reference TriCoLoNet (under the import
+    shims of oracle/make_golden.py) trained in the build container and scored by the REAL compute_metrics
+    (oracle/make_heldout_rr.py -> tests/golden/heldout_rr.npz, `source` = "reference"); the HIP path is trained here from the same recipe weights on the
     same batches in the same order, embedded in eval mode, and ranked by the device retrieval kernel through compute_metrics.
     0.2 points = 5 queries of 2,560.  The bf16 throughput mode is reported with its own stated bound."""
     from tricolo_amd.evaluation.eval_retrieval import compute_metrics
     g = golden("heldout_rr")
+    assert str(g["source"]) == "reference"
     cps = [int(c) for c in g["checkpoints"]]
     steps = int(os.environ.get("TRICOLO_HELDOUT_STEPS", cps[-1]))
     cps = [c for c in cps if c <= steps]

@@ -561,13 +561,45 @@ def test_adam_matches_torch_optim():
     p = torch.randn(10007, generator=g)
     pd, m, v = p.clone().to(DEV), torch.zeros(10007, device=DEV), torch.zeros(10007, device=DEV)
     pr, mr, vr = p.clone(), torch.zeros(10007), torch.zeros(10007)
-    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    step = torch.zeros(2, dtype=torch.int32, device=DEV)                     # [0] step counter, [1] skipped non-finite elements
     for s in range(1, 5):
         gr = torch.randn(10007, generator=g)
         ops.adam_tick(step)
         ops.adam_step(pd, gr.to(DEV), m, v, step, 3.5e-4, 0.9, 0.999, 1e-8, 1e-6)
         adam_step_explicit(pr, gr, mr, vr, s)
         np.testing.assert_allclose(pd.cpu().numpy(), pr.numpy(), atol=2e-7)
+    assert step.tolist() == [4, 0]
+
+
+def test_adam_skips_non_finite_gradient_elements():
+    """Overflow guard: a gradient element that is inf / NaN - an f16 activation-gradient overflow - must not reach the fp32
+    master weights or the Adam moments; the element is left alone, counted on the device, and everything else is updated as usual.
+    Both update kernels: the flat one and the in-place segment reader FusedAdam uses at N = 1."""
+    from tricolo_amd.optim import FusedAdam
+    gen = torch.Generator().manual_seed(5)
+    w = [torch.nn.Parameter(torch.randn(64, 32, generator=gen).to(DEV)), torch.nn.Parameter(torch.randn(128, generator=gen).to(DEV))]
+    ref = [p.detach().clone() for p in w]
+    opt = FusedAdam(w, lr=1e-2, weight_decay=1e-6)
+    opt.prepare()
+    for use_reduce in (False, True):                                          # segment kernel, then the packed (data-parallel) path
+        before = [p.detach().clone() for p in w]
+        grads = [torch.randn(p.shape, generator=gen).to(DEV) for p in w]
+        grads[0][3, 5] = float("inf")
+        grads[0][7, 0] = float("nan")
+        grads[1][100] = float("-inf")
+        for p, g_ in zip(w, grads):
+            p.grad = g_
+        opt.step(reduce_fn=(lambda flat: None) if use_reduce else None)
+        torch.cuda.synchronize()
+        for p, b_, g_ in zip(w, before, grads):
+            bad = ~torch.isfinite(g_)
+            assert torch.isfinite(p).all()
+            assert torch.equal(p.detach()[bad], b_[bad])                       # untouched
+            assert bool((p.detach()[~bad] != b_[~bad]).all())                  # everything else moved
+            st = opt.state[p]
+            assert torch.isfinite(st["exp_avg"]).all() and torch.isfinite(st["exp_avg_sq"]).all()
+    assert opt.nonfinite_skipped() == 6
+    assert int(opt.state_dict()["state"][0]["step"]) == 2
 
 
 @pytest.mark.parametrize("tag", ["b8", "b5", "b16_sym", "b1"])
@@ -1007,3 +1039,38 @@ def test_voxel_level0_brick_kernel(B, V, store, prec):
         assert torch.equal(out2.cpu(), cl3(F.conv3d(xd, w, padding=1)).to(store))
     with pytest.raises(RuntimeError):                               # a compact row list is refused (the kernel walks the grid by the mask)
         ops.conv_fwd(xcl.to(DEV).to(store), g, packed, rows=ops.mask_compact(mask.to(DEV), M))
+
+
+@pytest.mark.parametrize("store,prec", STORE16, ids=STORE16_IDS)
+@pytest.mark.parametrize("B,V", [(5, 16), (40, 16), (70, 16)])
+def test_voxel_level1_brick_kernel(B, V, store, prec):
+    """conv_vox1_kernel (conv_vox.hip): level 1 of the voxel tower (sparse_cnn.py:17, 32 -> 64 channels) - filter bank stationary in
+    registers, persistent workgroups over the grid's bricks (B = 40: several bricks per workgroup, more bricks than workgroups x 1).
+    Integer data: active rows equal the masked dense convolution exactly, rows of inactive sites stay unwritten, the per-workgroup
+    BatchNorm records sum to the column sums of the active rows; without a mask it is the plain convolution."""
+    case = ("vox1", B, (V, V, V), 32, 64, (3, 3, 3), 1, (1, 1, 1), "spconv")
+    x, w, wp, xcl, g = make_case(case, integer=True, seed=81)
+    assert g.brick(False, 2) and (g.kernel_family[(False, 2)] & 255) == 7
+    m = _blob_mask(B, V, seed=83)
+    mf = m.float()
+    x = x * mf[:, None]
+    xcl = xcl * mf[..., None]
+    ref = cl3(F.conv3d(x, w, padding=1)).to(store)
+    packed = ops.pack_weight(wp.to(DEV), g, prec)
+    M = B * V ** 3
+    mask = m.reshape(M).to(torch.uint8)
+    junk = torch.full((B, V, V, V, 64), 777.0, dtype=store, device=DEV)
+    out, stats = ops.conv_fwd(xcl.to(DEV).to(store), g, packed, row_mask=mask.to(DEV), want_stats=True, out=junk)
+    assert stats.shape[0] == g.num_mtiles[2]
+    o = out.cpu().reshape(M, 64)
+    act = mask.bool()
+    assert torch.equal(o[act], ref.reshape(M, 64)[act])
+    assert bool((o[~act] == 777.0).all()), "rows of inactive sites must not be written"
+    exact = ref.reshape(M, 64)[act].double()
+    st = stats.cpu().double().sum(0)
+    np.testing.assert_allclose(st[0].numpy(), exact.sum(0).numpy(), rtol=1e-6, atol=1e-2)
+    np.testing.assert_allclose(st[1].numpy(), (exact ** 2).sum(0).numpy(), rtol=1e-6, atol=1e-2)
+    if B <= 5:
+        xd, _, _, xdcl, _ = make_case(case, integer=True, seed=89)
+        out2 = ops.conv_fwd(xdcl.to(DEV).to(store), g, packed)
+        assert torch.equal(out2.cpu(), cl3(F.conv3d(xd, w, padding=1)).to(store))

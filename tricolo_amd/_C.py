@@ -50,6 +50,7 @@ SIGNATURES = {
     "tri_linear_small_wgrad": (I, [P, P, P, P, P, I, I, I, I, I, P]),
     "tri_linear_small_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "tri_conv_num_mtiles": (I, [DP, I]),
+    "tri_conv_num_records": (I, [DP, I, I]),
     "tri_conv_workspace": (Z, [DP, I]),
     "tri_conv_kernel_family": (I, [DP, I, I]),
     "tri_conv_wgrad_kernel_family": (I, [DP, I]),

@@ -480,7 +480,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs p) {
     // The per-axis OR of the rows' validity bits bounds the taps any row of the tile can use; k-steps of other taps are
     // dropped from this workgroup's step list (exactly the 5-8 of 9 taps whose parity cannot match for a one-class tile).
     __shared__ unsigned wave_axes[4];
-    __shared__ int live_steps[128], nlive_s;
+    __shared__ int live_steps[256], nlive_s;
     if (p.row_pos) {
         unsigned ax = rmask[0] | rmask[1] | rmask[2] | rmask[3];
         ax |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)ax, 0x128, 0xf, 0xf, false);
@@ -573,7 +573,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs p) {
                         }
                     }
                     const unsigned long long bal = __ballot(ok);
-                    if (ok && count + __popcll(bal & ((1ull << lane) - 1ull)) < 128)
+                    if (ok && count + __popcll(bal & ((1ull << lane) - 1ull)) < 256)
                         live_steps[count + __popcll(bal & ((1ull << lane) - 1ull))] = ks;
                     count += __popcll(bal);
                 }
@@ -1571,11 +1571,14 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const ConvArgs 
     const int chunk = blockIdx.x, m0 = chunk * 32, n = blockIdx.y * 64 + tc * 4;
     float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f), q4 = s4;
     const float4 bv = p.bias ? *(const float4*)(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    // compact row list: slab row m is LIST row m (position row_pos[m]); chunks past the end of the list only write their empty record
+    const int Meff = p.row_count ? min(*p.row_count, p.M) : p.M;
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
         int m = m0 + rl * 2 + rr;
-        if (m >= p.M) continue;
-        bool live = p.row_mask ? (p.row_mask[m] != 0) : true;
+        if (m >= Meff) continue;
+        const size_t pos = p.row_pos ? (size_t)p.row_pos[m] : (size_t)m;
+        bool live = p.row_mask ? (p.row_mask[pos] != 0) : true;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (live) {
             for (int z = 0; z < p.ksplit; ++z) {
@@ -1586,7 +1589,7 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const ConvArgs 
             if (p.act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             else if (p.act == 2) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
         }
-        AT* o = (AT*)p.out + (size_t)m * p.Cout + n;
+        AT* o = (AT*)p.out + pos * p.Cout + n;
         if (p.accumulate) { float4 e = Act<AT>::ld4(o); v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w; }
         Act<AT>::st4(o, v);
         if (sizeof(AT) == 2) v = make_float4(Act<AT>::rnd(v.x), Act<AT>::rnd(v.y), Act<AT>::rnd(v.z), Act<AT>::rnd(v.w));
@@ -1765,6 +1768,8 @@ struct ConvPlan {
     int stem_grid;
     int vox0;             // 1: conv_vox0_kernel (conv_vox.hip: level 0 of the voxel tower, 16-bit storage); records = vox0_grid
     int vox0_grid;
+    int vox1;             // 1: conv_vox1_kernel (level 1 of the voxel tower, 32 -> 64 channels, 16-bit storage); records = vox1_grid
+    int vox1_grid;
     int dma;              // 1: LDS-DMA kernel (16-bit activation storage, Cin % 64 == 0), 64-wide k-steps
     int nunits;           // k-steps (32 wide, or 64 wide for the DMA kernel)
     int ksplit, per_split;
@@ -1880,20 +1885,35 @@ static bool dma_disabled() {
 
 // split_mode: 0 bf16 operands / fp32 activations, 1 bf16x3 (hi + lo operands), 2 16-bit operands AND activation storage
 // (bf16 or f16: same kernels, same plans)
+// row_list: the launch walks a compact active-row list (voxel levels): the workgroups past ceil(count / 128) leave at once, so the
+// dense tile count overstates the launch.  The count lives on the device; the plan assumes the usual occupancy of the voxel grids
+// (<= 25 % at every level of the synthetic and ShapeNet-like shapes) when it sizes split-K - a denser list just runs more
+// workgroups than planned.
 static ConvPlan conv_make_plan(int B, int ID, int IH, int IW, int cin, int OD, int OH, int OW, int cout, int KD, int KH, int KW, int stride,
-                               int pd, int ph, int pw, int split_mode) {
+                               int pd, int ph, int pw, int split_mode, int row_list = 0) {
     ConvPlan pl{};
     long M = (long)B * OD * OH * OW;
     int ntaps = KD * KH * KW;
     int kpad = (ntaps * cin + 31) / 32 * 32;
     int bn = conv_bn(cout);
     int blocks = (int)((M + 127) / 128) * (cout / bn);
+    if (row_list) {
+        // measured occupancies of the voxel levels (synthetic shapes, 32^3 and 64^3 inputs): 13-18 % on 16^3 and finer grids, ~25 % at 8^3,
+        // ~45 % at 4^3, ~95 % at 2^3 (coarse levels fill up)
+        const int side = OD > OH ? (OD > OW ? OD : OW) : (OH > OW ? OH : OW);
+        blocks = side >= 8 ? (blocks + 3) / 4 : (side >= 4 ? (blocks + 1) / 2 : blocks);
+    }
     if (split_mode == 2 && cin % 64 == 0 && cout % 64 == 0 && !dma_disabled()) pl.dma = 1;
     pl.bn = bn;
     {
         TriVox0Geom vg;
         if (split_mode == 2 && tri_internal_vox0_geometry(B, ID, IH, IW, cin, OD, OH, OW, cout, KD, KH, KW, stride, pd, ph, pw, &vg)) {
             pl.vox0 = 1; pl.vox0_grid = vg.grid; pl.bn = 32; pl.nunits = 4; pl.ksplit = 1; pl.per_split = 4;
+            return pl;
+        }
+        TriVox1Geom v1;
+        if (split_mode == 2 && tri_internal_vox1_geometry(B, ID, IH, IW, cin, OD, OH, OW, cout, KD, KH, KW, stride, pd, ph, pw, &v1)) {
+            pl.vox1 = 1; pl.vox1_grid = v1.grid; pl.bn = 64; pl.nunits = 27; pl.ksplit = 1; pl.per_split = 27;
             return pl;
         }
     }
@@ -1935,6 +1955,11 @@ static ConvPlan conv_make_plan(int B, int ID, int IH, int IW, int cin, int OD, i
         if (ks > 32) ks = 32;
         if (ks < 1) ks = 1;
     }
+    if (row_list) {
+        // the fp32 slabs of a row-list launch are sized for the DENSE row count (the live count is a device value): keep them under 48 MB
+        const long per_split = M * cout * (long)sizeof(float);
+        while (ks > 1 && ks * per_split > (48L << 20)) --ks;
+    }
     pl.per_split = (pl.nunits + ks - 1) / ks;
     pl.ksplit = (pl.nunits + pl.per_split - 1) / pl.per_split;
     return pl;
@@ -1942,10 +1967,12 @@ static ConvPlan conv_make_plan(int B, int ID, int IH, int IW, int cin, int OD, i
 
 // Pipeline depth of conv_dma_kernel (stages of [128 x 64] + [BN x 64] operand tiles in LDS, NST - 1 of them in flight under the
 // MFMAs).  Launches that fill the GPU several times over run 2 stages x 3 workgroups per CU (profiles/r1/README.md: 2.01 vs 2.24 ms
-// over the ResNet layers); launches that cannot - the deep voxel levels over a compact row list, split-K layers, small data
-// gradients - are a chain of exposed DMA latencies with one k-step in flight (round 2: 1.0-1.15 us per k-step), so they take 4
-// stages (three k-steps in flight, one workgroup per CU).  TRICOLO_DMA_STAGES = 2 | 3 | 4 forces one depth everywhere,
-// TRICOLO_DMA_STAGES_ROWS the depth of the row-list launches.
+// over the ResNet layers).  Launches that cannot - the deep voxel levels over a compact row list, split-K layers, small data
+// gradients - are bound by the operand bytes a CU can pull per microsecond with few workgroups resident; a third stage keeps two
+// k-steps in flight and still fits TWO workgroups per CU with 64-wide tiles (72 KiB each), which matters as much: round 3 measured
+// 64^3 level 3 (268 live workgroups) at 56 / 47 / 85 us with 2 / 3 / 4 stages - four stages leave one workgroup per CU and the
+// launch a second, nearly empty round.  128-wide tiles (32 KiB stages) keep 2.  TRICOLO_DMA_STAGES = 2 | 3 | 4 forces one depth
+// everywhere, TRICOLO_DMA_STAGES_ROWS the depth of the row-list launches.
 static int dma_stages_env(const char* name) {
     const char* e = getenv(name);
     int v = e ? atoi(e) : 0;
@@ -1955,9 +1982,10 @@ static int dma_stages_for(const ConvArgs& a, int bn) {
     static int forced = -1, rows = -1;
     if (forced < 0) { forced = dma_stages_env("TRICOLO_DMA_STAGES"); rows = dma_stages_env("TRICOLO_DMA_STAGES_ROWS"); }
     if (forced) return forced;
-    if (a.row_count) return rows ? rows : 4;
+    if (a.row_count && rows) return rows;
     const long wgs = (long)((a.M + 127) / 128) * (a.Cout / bn) * a.ksplit;
-    return wgs <= 2L * num_cus() ? 4 : 2;
+    const bool small = a.row_count != nullptr || wgs <= 2L * num_cus();
+    return (small && bn == 64) ? 3 : 2;
 }
 
 template <int BN, int NST, typename AT>
@@ -2097,7 +2125,8 @@ static int conv_dispatch(ConvArgs& a, int act_fmt, void* workspace, size_t works
     a.in_bytes = (unsigned)in_bytes;
     const bool split = a.w_lo != nullptr;
     if (act_fmt && split) { tri_set_error("conv: 16-bit activation storage takes single operands (no lo part)"); return TRI_ERR_ARG; }
-    ConvPlan pl = conv_make_plan(a.B, a.ID, a.IH, a.IW, a.Cin, a.OD, a.OH, a.OW, a.Cout, a.KD, a.KH, a.KW, a.stride, a.pd, a.ph, a.pw, act_fmt ? 2 : (split ? 1 : 0));
+    ConvPlan pl = conv_make_plan(a.B, a.ID, a.IH, a.IW, a.Cin, a.OD, a.OH, a.OW, a.Cout, a.KD, a.KH, a.KW, a.stride, a.pd, a.ph, a.pw, act_fmt ? 2 : (split ? 1 : 0),
+                                 a.row_count ? 1 : 0);
     a.ksplit = pl.ksplit;
     a.steps_per_split = pl.per_split;
     a.nunits = pl.nunits;
@@ -2114,11 +2143,12 @@ static int conv_dispatch(ConvArgs& a, int act_fmt, void* workspace, size_t works
         // compact row list (row_pos[0 .. *row_count) are the rows to compute): not an order hint, it changes WHICH rows run, so
         // the kernel must honour it - any layer without split-K does (the split-K finish kernel walks positions, not the list)
         if (!a.row_pos) { tri_set_error("conv: row_count needs row_pos"); return TRI_ERR_ARG; }
-        if (pl.ksplit > 1 || (pl.dma && a.Kpad / 64 > 128)) {
-            tri_set_error("conv: this layer runs split-K - pass row_mask instead of a compact row list (tri_conv_kernel_family bit 16)");
-            return TRI_ERR_ARG;
+        if (a.row_mask) { tri_set_error("conv: pass either row_mask or a compact row list"); return TRI_ERR_ARG; }
+        if (pl.dma && a.Kpad / 64 > 256) {
+            tri_set_error("conv: more than 256 k-steps with a row list (the live-step table of conv_dma_kernel)");
+            return TRI_ERR_UNSUPPORTED;
         }
-    } else if (a.row_pos && !(pl.dma && pl.ksplit == 1 && !a.row_mask && !a.stats && a.Kpad / 64 <= 128)) {
+    } else if (a.row_pos && !(pl.dma && pl.ksplit == 1 && !a.row_mask && !a.stats && a.Kpad / 64 <= 256)) {
         a.row_pos = nullptr;          // a pure visiting-order hint: honoured by the DMA kernel without split-K, dropped elsewhere
     }
     if (pl.vox0 && !a.transposed) {
@@ -2132,6 +2162,16 @@ static int conv_dispatch(ConvArgs& a, int act_fmt, void* workspace, size_t works
         TriVox0Geom vg;
         tri_internal_vox0_geometry(a.B, a.ID, a.IH, a.IW, a.Cin, a.OD, a.OH, a.OW, a.Cout, a.KD, a.KH, a.KW, a.stride, a.pd, a.ph, a.pw, &vg);
         return tri_internal_vox0_launch(vg, a.B, a.in, a.w_hi, a.Kpad, a.out, a.row_mask, a.stats, act_fmt, stream);
+    }
+    if (pl.vox1 && !a.transposed) {
+        if (a.row_count || a.bias || a.act != 0 || a.accumulate) {
+            tri_set_error("conv: this layer runs the brick kernel (tri_conv_kernel_family == 7): pass the site mask as row_mask, no row list, "
+                          "bias, activation or accumulate");
+            return TRI_ERR_ARG;
+        }
+        TriVox1Geom v1;
+        tri_internal_vox1_geometry(a.B, a.ID, a.IH, a.IW, a.Cin, a.OD, a.OH, a.OW, a.Cout, a.KD, a.KH, a.KW, a.stride, a.pd, a.ph, a.pw, &v1);
+        return tri_internal_vox1_launch(v1, a.B, a.in, a.w_hi, a.out, a.row_mask, a.stats, act_fmt, stream);
     }
     if (pl.stem && !a.transposed && !a.row_mask && !a.row_count && !a.bias && a.act == 0 && !a.accumulate) {
         a.row_pos = nullptr;
@@ -2157,15 +2197,17 @@ extern "C" int tri_conv_kpad(int ntaps, int cin_stored) { return (ntaps * cin_st
 // number of [2][Cout] statistic records tri_conv_fwd writes for this layer: one per 128-row tile, or one per 32-row
 // chunk when the layer runs split-K (the finish kernel produces them).  tri_bn_finalize just sums all records.
 // split3: 0 bf16 operands / fp32 activations, 1 bf16x3 (hi + lo operands), 2 16-bit operands and activation storage.
-extern "C" int tri_conv_num_mtiles(const TriConvDesc* d, int split3) {
+extern "C" int tri_conv_num_records(const TriConvDesc* d, int split3, int row_list) {
     long M = (long)d->B * d->OD * d->OH * d->OW;
     ConvPlan pl = conv_make_plan(d->B, d->ID, d->IH, d->IW, d->Cin, d->OD, d->OH, d->OW, d->Cout, d->KD, d->KH, d->KW, d->stride, d->pad_d,
-                                 d->pad_h, d->pad_w, split3);
+                                 d->pad_h, d->pad_w, split3, row_list);
     if (pl.stem) return pl.stem_grid;
     if (pl.vox0) return pl.vox0_grid;
+    if (pl.vox1) return pl.vox1_grid;
     if (pl.halo) return pl.h_wgrec ? pl.h_grid / (d->Cout / 64) : pl.h_mtiles;
     return pl.ksplit > 1 ? (int)((M + 31) / 32) : (int)((M + 127) / 128);
 }
+extern "C" int tri_conv_num_mtiles(const TriConvDesc* d, int split3) { return tri_conv_num_records(d, split3, 0); }
 
 // kernel family the dispatch picks (for profilers): low byte 0 conv_igemm_kernel / 2 conv_dma_kernel, bits 8.. = channel tile
 extern "C" int tri_conv_kernel_family(const TriConvDesc* d, int transposed, int split3) {
@@ -2175,8 +2217,9 @@ extern "C" int tri_conv_kernel_family(const TriConvDesc* d, int transposed, int 
                                               d->pad_d, d->pad_h, d->pad_w, split3);
     if (pl.stem && !transposed) return 4 | (64 << 8);
     if (pl.vox0 && !transposed) return 6 | (32 << 8);
+    if (pl.vox1 && !transposed) return 7 | (64 << 8);
     if (pl.halo) return (pl.h_v5 ? 5 : 3) | (pl.halo << 8);
-    return (pl.dma ? 2 : 0) | (pl.bn << 8) | ((pl.ksplit > 1 || (pl.dma && tri_conv_kpad(d->KD * d->KH * d->KW, transposed ? d->Cout : d->Cin) / 64 > 128)) ? (1 << 16) : 0);
+    return (pl.dma ? 2 : 0) | (pl.bn << 8) | ((pl.ksplit > 1 || (pl.dma && tri_conv_kpad(d->KD * d->KH * d->KW, transposed ? d->Cout : d->Cin) / 64 > 256)) ? (1 << 16) : 0);
 }
 
 // out[B,OD,OH,OW,Cout] = conv(in[B,ID,IH,IW,Cin], W) (+bias, act 0 none / 1 relu / 2 tanh); rows with row_mask==0 are
@@ -2185,18 +2228,20 @@ extern "C" int tri_conv_kernel_family(const TriConvDesc* d, int transposed, int 
 // (0 when the layer already fills the GPU) and therefore REQUIRES.
 extern "C" size_t tri_conv_workspace(const TriConvDesc* d, int transposed) {
     size_t need = 0;
-    for (int mode = 0; mode < 3; ++mode) {
+    for (int mode = 0; mode < 6; ++mode) {                                   // three operand modes x (dense | compact row list)
         ConvPlan pl;
         long M;
         int cout;
+        const int rl = mode / 3;
+        if (rl && (d->KD != 3 || d->stride != 1)) continue;                  // row lists are a voxel-level (3D submanifold) thing
         if (transposed) {
             M = (long)d->B * d->ID * d->IH * d->IW; cout = d->Cin;
             pl = conv_make_plan(d->B, d->OD, d->OH, d->OW, d->Cout, d->ID, d->IH, d->IW, d->Cin, d->KD, d->KH, d->KW, d->stride, d->pad_d,
-                                d->pad_h, d->pad_w, mode);
+                                d->pad_h, d->pad_w, mode % 3, rl);
         } else {
             M = (long)d->B * d->OD * d->OH * d->OW; cout = d->Cout;
             pl = conv_make_plan(d->B, d->ID, d->IH, d->IW, d->Cin, d->OD, d->OH, d->OW, d->Cout, d->KD, d->KH, d->KW, d->stride, d->pad_d,
-                                d->pad_h, d->pad_w, mode);
+                                d->pad_h, d->pad_w, mode % 3, rl);
         }
         size_t n = pl.ksplit > 1 ? (size_t)pl.ksplit * M * cout * sizeof(float) : 0;
         if (n > need) need = n;

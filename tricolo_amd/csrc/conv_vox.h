@@ -4,10 +4,18 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-struct TriVox0Geom { int V, TY, nyb, pitch, plane, slab_bytes, vshift, grid; };
+struct TriVox0Geom { int V, TY, grid; };
 // true when the layer is level 0 of the voxel tower in a 16-bit storage mode (4 stored input channels, 32 outputs, 3x3x3 / 1 / pad 1 on a
 // 32^3 / 64^3 / 128^3 grid); g->grid = workgroups = BatchNorm records of the launch
 bool tri_internal_vox0_geometry(int B, int ID, int IH, int IW, int cin, int OD, int OH, int OW, int cout, int KD, int KH, int KW, int stride,
                                 int pd, int ph, int pw, TriVox0Geom* g);
 int tri_internal_vox0_launch(const TriVox0Geom& g, int B, const void* in, const void* w, int kpad, void* out, const uint8_t* mask, float* stats,
                              int act_fmt, hipStream_t stream);
+
+struct TriVox1Geom { int V, TY, nbricks, grid; };
+// level 1 of the voxel tower in a 16-bit storage mode (32 -> 64 channels, 3x3x3 / 1 / pad 1 on a 16^3 or 32^3 grid); g->grid = persistent
+// workgroups = BatchNorm records of the launch
+bool tri_internal_vox1_geometry(int B, int ID, int IH, int IW, int cin, int OD, int OH, int OW, int cout, int KD, int KH, int KW, int stride,
+                                int pd, int ph, int pw, TriVox1Geom* g);
+int tri_internal_vox1_launch(const TriVox1Geom& g, int B, const void* in, const void* w, void* out, const uint8_t* mask, float* stats, int act_fmt,
+                             hipStream_t stream);

@@ -8,35 +8,30 @@
 // counted in the BatchNorm sums.
 //
 // conv_vox0_kernel: level 0 (4 stored input channels = 8 B per site, 32 output channels).
-//   * brick = 2 z-planes x TY rows x all V columns = 128 runs (TY = 1024 / V); one brick per workgroup, workgroups of empty
-//     bricks leave after reading 2 KB of site mask; the dispatcher balances the rest (2-3 workgroups per CU overlap each other's
-//     slab fill, MFMAs and stores);
-//   * with four stored channels one MFMA k-step (32) is 8 taps; the 27 taps (+ 5 zero-weight slots) are ORDERED so that the two
-//     16-lane groups served by one LDS cycle of a ds_read_b64 read rows that are an odd number of row / plane pitches apart and
-//     both pitches are 128 mod 256 bytes: conflict-free fragment reads without a swizzle (derivation at VOX0_WTAP);
-//   * the whole filter bank (32 x 128 k) is 32 registers of MFMA A fragments, loaded once per workgroup, with the output channels
-//     permuted so that a lane ends up with 8 CONSECUTIVE channels of one site: one 16-byte store per lane, full 64-byte rows per
-//     4 lanes;
+//   * brick = 2 z-planes x TY rows x all V columns = 64 or 128 runs; one brick per workgroup, workgroups of empty bricks leave
+//     after reading <= 2 KB of site mask; the dispatcher balances the rest (4-5 workgroups per CU overlap each other's slab fill,
+//     MFMAs and stores);
+//   * with four stored channels one MFMA k-step (32) is 8 taps.  K-step (kd, p) holds the taps (kd, kh, kw) with kh = the lane's
+//     k-group fq (fq = 3: zero weights) and kw = 2 p, 2 p + 1 (kw = 3: zero weights): six k-steps, and the slab address of a
+//     lane's operand is  (run base: one VALU add per run) + (lane part fq * row pitch + site * 8) + an IMMEDIATE kd * plane pitch
+//     + kw * 8 - the fragment reads cost no address arithmetic (the first version ordered the taps by a table to fit four k-steps
+//     and spent ~100 instructions per run, 650 issue cycles against 128 of MFMA: in-kernel stamps, profiles/r3/NOTES_vox.md);
+//   * row pitch = 128 mod 256 bytes, so the two 16-lane groups that one LDS cycle of a ds_read_b64 serves (k-groups fq, fq + 1 =
+//     adjacent slab rows, 16 consecutive sites = 128 contiguous bytes each) hit disjoint banks: conflict-free without a swizzle;
+//   * the whole filter bank (32 x 6 k-steps) is 48 registers of MFMA A fragments, loaded once per workgroup under the mask test,
+//     with the output channels permuted so that a lane ends up with 8 CONSECUTIVE channels of one site: one 16-byte store per
+//     lane, full 64-byte rows per 4 lanes;
 //   * BatchNorm sums (of the values as stored) stay in registers over the workgroup's runs: one record per workgroup.
 #include "common.h"
 #include <stdlib.h>
 #include "conv_vox.h"
 
+int tri_internal_num_cus();                                                   // conv_igemm.hip
+
 template <int N>
 __device__ __forceinline__ float vox_row_ror(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, false));
 }
-
-// slot (k-step s, k-group fq, half e) = s * 8 + fq * 2 + e  ->  tap whose 4 channels fill elements 4 e .. 4 e + 3 of that lane's
-// fragment.  ds_read_b64 serves lanes 0-31 (fq 0, 1) and 32-63 (fq 2, 3) in one LDS cycle each; a 16-lane group reads 16
-// consecutive sites = 128 contiguous bytes = 32 banks, so the two groups of a cycle are conflict-free iff their addresses differ
-// by 128 mod 256 bytes.  Row pitch and plane pitch are both 128 mod 256, so that holds iff the two taps share kw and differ in
-// (kd + kh) parity.  Per kw there are 5 even and 4 odd (kd, kh): 4 even-odd pairs, the centre row left over - it and the five
-// unused slots are paired with zero-weight slots that read a valid (finite) site of the opposite parity.
-__device__ const signed char VOX0_WTAP[32] = {0, 6, 3, 9, 18, 24, 15, 21, 1, 7, 4, 10, 19, 25, 16, 22,
-                                              2, 8, 5, 11, 20, 26, 17, 23, 12, 13, -1, -1, 14, -1, -1, -1};     // weight tap (-1: zeros)
-__device__ const signed char VOX0_ATAP[32] = {0, 6, 3, 9, 18, 24, 15, 21, 1, 7, 4, 10, 19, 25, 16, 22,
-                                              2, 8, 5, 11, 20, 26, 17, 23, 12, 13, 3, 4, 14, 13, 5, 4};         // tap whose site is read
 
 struct Vox0Args {
     const void* in;            // [B, V, V, V, 4] 16-bit, zeros at inactive sites
@@ -44,138 +39,208 @@ struct Vox0Args {
     void* out;                 // [B, V, V, V, 32]; rows of inactive sites are not written
     const uint8_t* mask;       // [B * V^3] site mask, or NULL (every site active)
     float* stats;              // [grid][2][32] or NULL
-    int B, V, TY, nyb, Kpad;
-    int pitch, plane, slab_bytes, vshift;
+    int B, Kpad;
+    unsigned in_bytes;
+#ifdef VOX_PROBE
+    long long* dbg;            // [grid][8] stamps of wave 0
+    int abl;                   // timing probes (wrong results): 1 no MFMA, 2 no stores, 4 no slab loads, 8 no fragment reads, 16 prologue only
+#endif
+};
+#ifdef VOX_PROBE
+#define VOX_ABL(bit) (p.abl & (bit))
+#define VOX_STAMP(i) do { if (p.dbg && t == 0) p.dbg[(size_t)blockIdx.x * 8 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define VOX_STAMPV(i, v) do { if (p.dbg && t == 0) p.dbg[(size_t)blockIdx.x * 8 + (i)] = (long long)(v); } while (0)
+#else
+#define VOX_ABL(bit) 0
+#define VOX_STAMP(i)
+#define VOX_STAMPV(i, v)
+#endif
+
+template <int V, int TY>
+struct Vox0Cfg {
+    static constexpr int PITCH = V * 8 + 128;                                  // [16 B pad | V sites x 8 B | 112 B pad]: 128 mod 256
+    static constexpr int PLANE0 = (TY + 2) * PITCH;
+    static constexpr int PLANE = PLANE0 + ((((PLANE0 >> 7) & 1) == 0) ? 128 : 0);   // 128 mod 256 as well
+    static constexpr int SLAB = 4 * PLANE;
+    static constexpr int RPR = V / 16;                                         // runs per grid row
+    static constexpr int HALF = TY * RPR;                                      // runs per z-plane of the brick
+    static constexpr int RUNS = 2 * HALF;                                      // 64 or 128
+    static constexpr int NYB = V / TY;
+    static constexpr int CPR = V / 2;                                          // 16-byte chunks per row
+    static constexpr int ITEMS = (TY + 2) * CPR;                               // chunks per slab plane
+    static constexpr int MAXC = (4 * ITEMS + 255) / 256;
+    static constexpr int WROW = 264;                                           // filter-bank row pitch in LDS: 256 B + 8 (rows 2 banks apart)
+    static constexpr size_t SMEM = (size_t)SLAB + RUNS * 16 + 4 * 32 * 2 * sizeof(float) + 32 * WROW;
+    static_assert(RUNS == 64 || RUNS == 128, "a brick is one or two 64-run mask words");
+    static_assert(2 * PLANE + 24 < 65536, "fragment-read immediates");
 };
 
-template <typename AT>
-__global__ __launch_bounds__(256, 2) void conv_vox0_kernel(const Vox0Args p) {
+template <typename AT, int V, int TY>
+__global__ __launch_bounds__(256, 4) void conv_vox0_kernel(const Vox0Args p) {
+    typedef Vox0Cfg<V, TY> C;
     typedef typename OpOf<AT>::E E;
     typedef Mma<E> MM;
     typedef typename MM::v8 v8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), fr = lane & 15, fq = lane >> 4;
-    const int V = p.V, TY = p.TY;
-    int bid = blockIdx.x;
-    const int yb = bid % p.nyb;
-    bid /= p.nyb;
-    const int hz = V >> 1;
-    const int zp = bid % hz, b = bid / hz;
+    // brick of this workgroup.  Workgroups i, i + 256, ... land on the same CU when the whole grid is resident at once (32^3 at the
+    // bench batch: 1,024 workgroups, four per CU); in sample-major order those would be the SAME spatial brick of four samples - the
+    // dense centre bricks on some CUs, the empty corner bricks on others (stamps: workgroup lifetimes 6.5 us median, 14 us for the
+    // densest CU).  Rotating the spatial index by the sample number deals every CU a mix.
+    constexpr int PS = (V / 2) * C::NYB;                                       // bricks per sample
+    const int b = blockIdx.x / PS;
+    const int sp = (blockIdx.x % PS + b * (PS / 2 + 1)) % PS;
+    const int yb = sp % C::NYB, zp = sp / C::NYB;
     const int z0 = zp * 2, y0 = yb * TY;
     char* const slab = smem;
-    uint8_t* const lmask = (uint8_t*)(smem + p.slab_bytes);                    // [128 runs][16 sites]
-    float* const red = (float*)(lmask + 2048);                                 // [4 waves][32][2]
+    uint8_t* const lmask = (uint8_t*)(smem + C::SLAB);                         // [RUNS][16 sites]
+    float* const red = (float*)(lmask + C::RUNS * 16);                         // [4 waves][32][2]
+    char* const wbuf = (char*)(red + 256);                                     // [32 rows][WROW] packed filter bank
+    VOX_STAMP(0);
+    VOX_STAMPV(5, __builtin_amdgcn_s_memrealtime());
 
-    // ---- site mask of the brick: run r = (plane r >> 6, row (r & 63) >> vshift, x-run r & (V / 16 - 1)) is 16 contiguous bytes
-    if (t < 128) {
-        uint4 mv = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
-        if (p.mask) mv = *(const uint4*)(p.mask + ((size_t)(b * V + z0 + (t >> 6)) * V + y0) * V + (t & 63) * 16);
-        *(uint4*)(lmask + t * 16) = mv;
+    // ---- site mask of the brick: run r = (plane r / HALF, row (r % HALF) / RPR, x-run r % RPR) is 16 contiguous bytes
+    uint4 mv = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
+    if (t < C::RUNS && p.mask) mv = *(const uint4*)(p.mask + ((size_t)(b * V + z0 + t / C::HALF) * V + y0) * V + (t % C::HALF) * 16);
+
+    // ---- filter bank: 8 KB, two coalesced 16-byte loads per thread into LDS, in flight under the mask test (the first versions read the
+    // MFMA fragments straight from global memory: 24 eight-byte loads per wave scattered over 16 rows - ~400 L1 requests per wave, and
+    // with every workgroup of the launch doing it at once the texture path was busy for microseconds: 3.9 us until the mask test)
+    uint4 wld[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) wld[u] = *(const uint4*)((const char*)p.w + (size_t)(t + u * 256) * 16);
+    if (t < C::RUNS) *(uint4*)(lmask + t * 16) = mv;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int c = t + u * 256;                                             // 16-byte chunk c of the [32][128] bank: row c / 16
+        char* d = wbuf + (c >> 4) * C::WROW + (c & 15) * 16;
+        *(uint2*)d = make_uint2(wld[u].x, wld[u].y);
+        *(uint2*)(d + 8) = make_uint2(wld[u].z, wld[u].w);
     }
     __syncthreads();
-    const uint4 ma = *(const uint4*)(lmask + lane * 16), mb = *(const uint4*)(lmask + 1024 + lane * 16);
-    const unsigned long long m0 = __ballot((ma.x | ma.y | ma.z | ma.w) != 0u), m1 = __ballot((mb.x | mb.y | mb.z | mb.w) != 0u);
+    unsigned long long m0, m1 = 0ull;
+    {
+        const uint4 ma = *(const uint4*)(lmask + lane * 16);
+        m0 = __ballot((ma.x | ma.y | ma.z | ma.w) != 0u);
+        if (C::RUNS == 128) {
+            const uint4 mb = *(const uint4*)(lmask + 1024 + lane * 16);
+            m1 = __ballot((mb.x | mb.y | mb.z | mb.w) != 0u);
+        }
+    }
+    VOX_STAMP(1);
+    VOX_STAMPV(4, __popcll(m0) + __popcll(m1));
     if ((m0 | m1) == 0ull) {                                                   // empty brick (the same answer in every wave)
+        VOX_STAMPV(6, __builtin_amdgcn_s_memrealtime());
         if (p.stats && t < 64) p.stats[(size_t)blockIdx.x * 64 + t] = 0.f;
         return;
     }
 
-    // ---- filter bank -> registers.  A fragment (s, ct): row i = fr is output channel 8 (i >> 2) + 4 ct + (i & 3), so that the
-    // accumulator registers r = 0..3 of lane (fr, fq) are channels 8 fq + 4 ct + r of site fr
-    v8 wf[4][2];
+    // ---- slab: 4 planes x (TY + 2) rows x [16 B pad | V sites x 8 B | pad]; rows / planes outside the grid are out-of-range buffer
+    // offsets (zeros), so all loads of a thread are issued back to back
     {
-        const uint16_t* w = (const uint16_t*)p.w;
+        const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+        uint4 pre[C::MAXC];
+        int dst[C::MAXC];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int ta = VOX0_WTAP[s * 8 + fq * 2], tb = VOX0_WTAP[s * 8 + fq * 2 + 1];
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) {
-                const uint16_t* row = w + (size_t)(8 * (fr >> 2) + 4 * ct + (fr & 3)) * p.Kpad;
-                uint2 lo = make_uint2(0u, 0u), hi = make_uint2(0u, 0u);
-                if (ta >= 0) lo = *(const uint2*)(row + ta * 4);
-                if (tb >= 0) hi = *(const uint2*)(row + tb * 4);
-                wf[s][ct] = __builtin_bit_cast(v8, make_uint4(lo.x, lo.y, hi.x, hi.y));
-            }
-        }
-    }
-    // per-lane slab offsets of the two taps of every k-step (relative to the run's first site)
-    int coff[4][2];
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int tp = VOX0_ATAP[s * 8 + fq * 2 + e];
-            const int kw = tp % 3, kh = (tp / 3) % 3, kd = tp / 9;
-            coff[s][e] = (kd - 1) * p.plane + (kh - 1) * p.pitch + (kw - 1) * 8 + fr * 8;
-        }
-
-    // ---- slab: 4 planes x (TY + 2) rows x [16 B pad | V sites x 8 B | pad]; rows / planes outside the grid are zeros
-    {
-        const int cpr = V >> 1, cshift = p.vshift + 3;                         // 16-byte chunks per row (2 sites each)
-        const int items = (TY + 2) * cpr;                                      // per plane
-        constexpr int MAXC = 10;
-        uint4 pre[MAXC];
-        int dst[MAXC];
-#pragma unroll
-        for (int u = 0; u < MAXC; ++u) {
+        for (int u = 0; u < C::MAXC; ++u) {
             const int c = t + u * 256;
-            const int zz = (c >= items) + (c >= 2 * items) + (c >= 3 * items);
-            const int i = c - zz * items;
-            const int yy = i >> cshift, ch = i & (cpr - 1);
+            const int zz = (c >= C::ITEMS) + (c >= 2 * C::ITEMS) + (c >= 3 * C::ITEMS);
+            const int i = c - zz * C::ITEMS;
+            const int yy = i / C::CPR, ch = i % C::CPR;
             const int gz = z0 - 1 + zz, gy = y0 - 1 + yy;
-            const bool inside = c < 4 * items;
-            dst[u] = inside ? zz * p.plane + yy * p.pitch + 16 + ch * 16 : -1;
+            const bool inside = c < 4 * C::ITEMS;
+            dst[u] = inside ? zz * C::PLANE + yy * C::PITCH + 16 + ch * 16 : -1;
+            const bool ok = inside && (unsigned)gz < (unsigned)V && (unsigned)gy < (unsigned)V;
+            const unsigned voff = ok ? (unsigned)(((((b * V + gz) * V + gy) * V) + 2 * ch) * 8) : 0x80000000u;
             pre[u] = make_uint4(0u, 0u, 0u, 0u);
-            if (inside && (unsigned)gz < (unsigned)V && (unsigned)gy < (unsigned)V)
-                pre[u] = *(const uint4*)((const char*)p.in + ((((size_t)(b * V + gz) * V + gy) * V) + 2 * ch) * 8);
+            if (!VOX_ABL(4)) pre[u] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(irs, voff, 0, 0));
         }
         // the one-site x halo left and right of every row
-        const int nrows = 4 * (TY + 2);
-        if (t < nrows) {
-            const int zz = (t >= TY + 2) + (t >= 2 * (TY + 2)) + (t >= 3 * (TY + 2));
-            char* r = slab + zz * p.plane + (t - zz * (TY + 2)) * p.pitch;
+        if (t < 4 * (TY + 2)) {
+            const int zz = t / (TY + 2);
+            char* r = slab + zz * C::PLANE + (t - zz * (TY + 2)) * C::PITCH;
             *(uint2*)(r + 8) = make_uint2(0u, 0u);
             *(uint2*)(r + 16 + V * 8) = make_uint2(0u, 0u);
         }
 #pragma unroll
-        for (int u = 0; u < MAXC; ++u)
+        for (int u = 0; u < C::MAXC; ++u)
             if (dst[u] >= 0) *(uint4*)(slab + dst[u]) = pre[u];
     }
+    // A fragment (kd, p, ct): row i = fr is output channel 8 (i >> 2) + 4 ct + (i & 3), so that the accumulator registers r = 0..3 of
+    // lane (fr, fq) are channels 8 fq + 4 ct + r of site fr; elements 0-3 / 4-7 = the four channels of tap (kd, kh = fq, kw = 2 p) /
+    // (kd, fq, 2 p + 1); k-group 3 and kw = 3 are zeros
+    v8 wf[3][2][2];
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const char* row = wbuf + (8 * (fr >> 2) + 4 * ct + (fr & 3)) * C::WROW + ((kd * 3 + (fq == 3 ? 0 : fq)) * 3 + 2 * pp) * 8;
+                uint2 lo = *(const uint2*)row, hi = make_uint2(0u, 0u);
+                if (pp == 0) hi = *(const uint2*)(row + 8);
+                if (fq == 3) { lo = make_uint2(0u, 0u); hi = lo; }
+                wf[kd][pp][ct] = __builtin_bit_cast(v8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+            }
+
+    // ---- this wave's runs: the active runs whose ordinal (in run order) is the wave's number modulo 4
+    unsigned long long mine0, mine1 = 0ull;
+    {
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const int o0 = __popcll(m0 & below);
+        mine0 = __ballot(((m0 >> lane) & 1ull) && (o0 & 3) == wave);
+        if (C::RUNS == 128) {
+            const int o1 = __popcll(m0) + __popcll(m1 & below);
+            mine1 = __ballot(((m1 >> lane) & 1ull) && (o1 & 3) == wave);
+        }
+    }
+    // lane part of every fragment address: slab row kh = fq (the zero-weight k-group 3 re-reads row 1: finite data, and an odd
+    // number of row pitches away from k-group 2 it shares an LDS cycle with), site fr
+    const int lofs = (fq == 3 ? 1 : fq) * C::PITCH + fr * 8;
     __syncthreads();
 
-    // ---- runs: every wave walks the brick's active runs and takes those whose ordinal is its own modulo 4
+    VOX_STAMP(2);
+    if (VOX_ABL(16)) return;
     f32x4 cs0 = {0.f, 0.f, 0.f, 0.f}, cs1 = cs0, cq0 = cs0, cq1 = cs0;
-    const int xmask = (1 << p.vshift) - 1;
-    int ord = 0;
 #pragma unroll 1
-    for (int g = 0; g < 2; ++g) {
-        unsigned long long m = g ? m1 : m0;
+    for (int g = 0; g < (C::RUNS == 128 ? 2 : 1); ++g) {
+        unsigned long long m = g ? mine1 : mine0;
 #pragma unroll 1
         while (m) {
             const int bit = __builtin_ctzll(m);
             m &= m - 1;
-            if ((ord++ & 3) != wave) continue;
-            const int yl = bit >> p.vshift, xr = bit & xmask;
-            const char* sb = slab + (g + 1) * p.plane + (yl + 1) * p.pitch + 16 + xr * 128;
-            v8 bf[4];
+            const int r = g * 64 + bit;
+            const int zl = r / C::HALF, idx = r % C::HALF, yl = idx / C::RPR, xr = idx % C::RPR;
+            // operand of tap (kd, kh, kw) for site x0 + fr: slab plane zl + kd, row yl + kh, byte 16 + (x0 + fr + kw - 1) * 8
+            const char* sb = slab + (zl * C::PLANE + yl * C::PITCH + 8 + xr * 128) + lofs;
+            v8 bf[3][2];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const uint2 lo = *(const uint2*)(sb + coff[s][0]), hi = *(const uint2*)(sb + coff[s][1]);
-                bf[s] = __builtin_bit_cast(v8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+            for (int kd = 0; kd < 3; ++kd) {
+                uint2 t0 = make_uint2(bit, 0u), t1 = t0, t2 = t0;
+                if (!VOX_ABL(8)) {
+                    t0 = *(const uint2*)(sb + kd * C::PLANE);
+                    t1 = *(const uint2*)(sb + kd * C::PLANE + 8);
+                    t2 = *(const uint2*)(sb + kd * C::PLANE + 16);
+                }
+                bf[kd][0] = __builtin_bit_cast(v8, make_uint4(t0.x, t0.y, t1.x, t1.y));
+                bf[kd][1] = __builtin_bit_cast(v8, make_uint4(t2.x, t2.y, t2.x, t2.y));       // elements 4-7 meet zero weights (kw = 3)
             }
-            const int live = lmask[(g * 64 + bit) * 16 + fr];
+            const int live = lmask[r * 16 + fr];
             f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                a0 = MM::mma(wf[s][0], bf[s], a0);
-                a1 = MM::mma(wf[s][1], bf[s], a1);
-            }
+            for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp) {
+                    if (VOX_ABL(1)) { a0[0] += __builtin_bit_cast(float, ((uint4)__builtin_bit_cast(uint4, bf[kd][pp])).x); continue; }
+                    a0 = MM::mma(wf[kd][pp][0], bf[kd][pp], a0);
+                    a1 = MM::mma(wf[kd][pp][1], bf[kd][pp], a1);
+                }
             if (live) {
-                v8 o8;
-                o8[0] = (E)a0[0]; o8[1] = (E)a0[1]; o8[2] = (E)a0[2]; o8[3] = (E)a0[3];
-                o8[4] = (E)a1[0]; o8[5] = (E)a1[1]; o8[6] = (E)a1[2]; o8[7] = (E)a1[3];
-                const size_t site = ((size_t)(b * V + z0 + g) * V + y0 + yl) * V + xr * 16 + fr;
-                *(v8*)((AT*)p.out + site * 32 + fq * 8) = o8;
+                typedef E e4 __attribute__((ext_vector_type(4)));
+                const e4 h0 = __builtin_convertvector(a0, e4), h1 = __builtin_convertvector(a1, e4);     // packed conversions
+                const v8 o8 = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+                const size_t site = ((size_t)(b * V + z0 + zl) * V + y0 + yl) * V + xr * 16 + fr;
+                if (!VOX_ABL(2)) *(v8*)((AT*)p.out + site * 32 + fq * 8) = o8;
                 f32x4 r0 = {(float)o8[0], (float)o8[1], (float)o8[2], (float)o8[3]};
                 f32x4 r1 = {(float)o8[4], (float)o8[5], (float)o8[6], (float)o8[7]};
                 cs0 += r0; cq0 += r0 * r0;
@@ -184,6 +249,8 @@ __global__ __launch_bounds__(256, 2) void conv_vox0_kernel(const Vox0Args p) {
         }
     }
 
+    VOX_STAMP(3);
+    VOX_STAMPV(6, __builtin_amdgcn_s_memrealtime());
     if (p.stats) {                                                             // one record per workgroup
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
@@ -211,9 +278,208 @@ __global__ __launch_bounds__(256, 2) void conv_vox0_kernel(const Vox0Args p) {
     }
 }
 
+
+// ================================================================================================ level 1: 32 -> 64 channels
+// conv_vox1_kernel.  Level 1 through conv_igemm_kernel is a chain of exposed gather latencies (27 k-steps of one tap each, one
+// in flight): 23 us for 171 tiles at the bench shape, 93 us at 64^3 x 64.  Here the filter bank is STATIONARY IN REGISTERS: wave
+// w of a persistent workgroup holds the A fragments of output channels 16 w .. 16 w + 15 for all 27 taps (108 registers, loaded
+// once per workgroup), the workgroup walks its share of the grid's bricks (2 z-planes x TY rows x all columns = 16 runs of 16
+// sites), stages a brick + halo once in an LDS slab (64 B per site) and every wave forms the 27 taps of every active run from it:
+// one ds_read_b128 + one MFMA per tap and run, no address arithmetic (per-lane offset for kw = 0, 1, 2, immediates for kd, kh).
+//   * slab layout: site s of a row at byte s * 64, its 16-byte chunk q (8 channels) at position q ^ (2 * bit 2 of s).  For ANY 16
+//     consecutive sites the 16 lanes that one LDS cycle of a ds_read_b128 serves (k-groups a, a + 1 over four site quads) then hit
+//     16 distinct 16-byte bank slots - conflict-free for all three kw shifts (derivation in DESIGN.md section 5);
+//   * workgroup w takes bricks w, w + G, ... (order rotated by the sample number, see conv_vox0_kernel): their masks are fetched with
+//     one load per thread at the start, an empty brick then costs a 16-lane LDS read.  (Handing bricks out dynamically - an atomic
+//     counter + a memset node per launch - was measured and is slower at both sizes: 22.9 against 15.5 us at 32^3 x 32, 103 against
+//     119 us at 64^3 x 64, where conv_igemm_kernel takes 93: the kernel is planned for 16^3 level-1 grids only, i.e. 32^3 inputs);
+//   * two workgroups per CU (63 KB of LDS, < 256 registers): one fills its slab while the other one multiplies;
+//   * a lane ends up with 4 consecutive channels of a site (8-byte stores, 32-byte segments per wave, full 128-byte rows per
+//     workgroup); BatchNorm sums in registers across all bricks: one record per workgroup.
+struct Vox1Args {
+    const void* in;            // [B, V1, V1, V1, 32] 16-bit, zeros at inactive sites
+    const void* w;             // packed operand rows [64][864] (k = tap * 32 + channel)
+    void* out;                 // [B, V1, V1, V1, 64]; rows of inactive sites are not written
+    const uint8_t* mask;       // [B * V1^3] site mask, or NULL
+    float* stats;              // [grid][2][64] or NULL
+    int B, nbricks;
+    unsigned in_bytes;
+};
+
+template <int V1, int TY>
+struct Vox1Cfg {
+    static constexpr int XOFF = 4;                                             // zero / pad sites left of a row (multiple of 4)
+    static constexpr int PITCH = (V1 + 8) * 64;
+    static constexpr int PLANE = (TY + 2) * PITCH;
+    static constexpr int SLAB = 4 * PLANE;
+    static constexpr int RPR = V1 / 16;
+    static constexpr int HALF = TY * RPR;                                      // runs per z-plane of a brick
+    static constexpr int RUNS = 2 * HALF;
+    static constexpr int NYB = V1 / TY;
+    static constexpr int PS = (V1 / 2) * NYB;                                  // bricks per sample
+    static constexpr int CPR = V1 * 4;                                         // 16-byte chunks per row
+    static constexpr int ITEMS = (TY + 2) * CPR;                               // per plane
+    static constexpr int MAXC = (4 * ITEMS + 255) / 256;
+    static constexpr int NBMAX = 32;                                           // bricks whose masks a workgroup caches
+    static constexpr size_t SMEM = (size_t)SLAB + NBMAX * 256 + 4 * 16 * 2 * sizeof(float);
+    static_assert(RUNS == 16, "a brick is 16 runs (one 256-byte mask record)");
+    static_assert(2 * PLANE + 2 * PITCH + 4096 < 65536, "fragment-read immediates");
+};
+
+template <typename AT, int V1, int TY>
+__global__ __launch_bounds__(256, 2) void conv_vox1_kernel(const Vox1Args p) {
+    typedef Vox1Cfg<V1, TY> C;
+    typedef typename OpOf<AT>::E E;
+    typedef Mma<E> MM;
+    typedef typename MM::v8 v8;
+    constexpr int KPAD = 27 * 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = threadIdx.x, lane = t & 63, ct = __builtin_amdgcn_readfirstlane(t >> 6), fr = lane & 15, fq = lane >> 4;
+    char* const slab = smem;
+    uint8_t* const lmask = (uint8_t*)(smem + C::SLAB);                         // [NBMAX][16 runs][16 sites]
+    float* const red = (float*)(lmask + C::NBMAX * 256);                       // [4 waves][16][2]
+    const int G = gridDim.x, wg = blockIdx.x;
+    const int nmine = (p.nbricks - wg + G - 1) / G;                            // bricks wg, wg + G, ... (the launcher keeps this <= NBMAX)
+
+    // ---- filter bank of this wave's 16 output channels: 27 A fragments (row fr = channel 16 ct + fr, k = 8 fq .. 8 fq + 7 of the tap)
+    v8 wf[27];
+    {
+        const char* wrow = (const char*)p.w + ((size_t)(16 * ct + fr) * KPAD + fq * 8) * 2;
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) wf[tap] = __builtin_bit_cast(v8, *(const uint4*)(wrow + tap * 64));
+    }
+    auto brick_of = [&](int k, int& b, int& z0, int& y0) {
+        const int j = wg + k * G;
+        b = j / C::PS;
+        const int sp = (j % C::PS + b * (C::PS / 2 + 1)) % C::PS;
+        z0 = (sp / C::NYB) * 2;
+        y0 = (sp % C::NYB) * TY;
+    };
+    // per-lane slab offsets for kw = 0, 1, 2: site XOFF + fr + kw - 1 (+ the run's x0, a multiple of 16 sites: bit 2 unchanged)
+    int lofs[3];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+        const int sx = C::XOFF + fr + kw - 1;
+        lofs[kw] = sx * 64 + ((fq ^ (((sx >> 2) & 1) << 1)) << 4);
+    }
+    const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    f32x4 cs = {0.f, 0.f, 0.f, 0.f}, cq = cs;
+
+    // ---- site masks of all bricks of this workgroup: run r of a brick = 16 contiguous mask bytes
+    for (int i = t; i < nmine * 16; i += 256) {
+        const int k = i >> 4, r = i & 15;
+        int b, z0, y0;
+        brick_of(k, b, z0, y0);
+        const int zl = r / C::HALF, idx = r % C::HALF, yl = idx / C::RPR, xr = idx % C::RPR;
+        uint4 mv = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
+        if (p.mask) mv = *(const uint4*)(p.mask + ((size_t)(b * V1 + z0 + zl) * V1 + y0 + yl) * V1 + xr * 16);
+        *(uint4*)(lmask + k * 256 + r * 16) = mv;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int k = 0; k < nmine; ++k) {
+        unsigned rm;
+        {
+            const uint4 mv = *(const uint4*)(lmask + k * 256 + (lane & 15) * 16);
+            rm = (unsigned)(__ballot((mv.x | mv.y | mv.z | mv.w) != 0u) & 0xffffull);
+        }
+        if (rm == 0u) continue;                                                // empty brick: the same answer in every wave
+        int b, z0, y0;
+        brick_of(k, b, z0, y0);
+        __syncthreads();                                                       // every wave is done with the previous slab
+        {
+            uint4 pre[C::MAXC];
+            int dst[C::MAXC];
+#pragma unroll
+            for (int u = 0; u < C::MAXC; ++u) {
+                const int c = t + u * 256;
+                const int zz = (c >= C::ITEMS) + (c >= 2 * C::ITEMS) + (c >= 3 * C::ITEMS);
+                const int i = c - zz * C::ITEMS;
+                const int yy = i / C::CPR, cc = i % C::CPR;
+                const int sx = C::XOFF + (cc >> 2), q = cc & 3;
+                const int gz = z0 - 1 + zz, gy = y0 - 1 + yy;
+                const bool inside = c < 4 * C::ITEMS;
+                dst[u] = inside ? zz * C::PLANE + yy * C::PITCH + sx * 64 + ((q ^ (((sx >> 2) & 1) << 1)) << 4) : -1;
+                const bool ok = inside && (unsigned)gz < (unsigned)V1 && (unsigned)gy < (unsigned)V1;
+                const unsigned voff = ok ? (unsigned)((((b * V1 + gz) * V1 + gy) * V1) * 64 + cc * 16) : 0x80000000u;
+                pre[u] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(irs, voff, 0, 0));
+            }
+            // the zero site left and right of every row (4 chunks each)
+            for (int i = t; i < 4 * (TY + 2) * 8; i += 256) {
+                const int row = i >> 3, side = (i >> 2) & 1, q = i & 3;
+                const int zz = row / (TY + 2), yy = row - zz * (TY + 2);
+                const int sx = side ? C::XOFF + V1 : C::XOFF - 1;
+                *(uint4*)(slab + zz * C::PLANE + yy * C::PITCH + sx * 64 + q * 16) = make_uint4(0u, 0u, 0u, 0u);
+            }
+#pragma unroll
+            for (int u = 0; u < C::MAXC; ++u)
+                if (dst[u] >= 0) *(uint4*)(slab + dst[u]) = pre[u];
+        }
+        __syncthreads();
+
+#pragma unroll 1
+        while (rm) {
+            const int r = __builtin_ctz(rm);
+            rm &= rm - 1;
+            const int zl = r / C::HALF, idx = r % C::HALF, yl = idx / C::RPR, xr = idx % C::RPR;
+            const char* sb = slab + zl * C::PLANE + yl * C::PITCH + xr * 1024;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            // the nine fragments of a kd plane are read as one batch, the next plane's batch is issued before this plane's MFMAs: with
+            // reads only two taps ahead (the compiler's own schedule) every MFMA pair waited out an LDS latency
+            v8 bf[2][9];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) bf[0][j] = *(const v8*)(sb + lofs[j % 3] + (j / 3) * C::PITCH);
+#pragma unroll
+            for (int kd = 0; kd < 3; ++kd) {
+                if (kd < 2) {
+#pragma unroll
+                    for (int j = 0; j < 9; ++j) bf[(kd + 1) & 1][j] = *(const v8*)(sb + lofs[j % 3] + (kd + 1) * C::PLANE + (j / 3) * C::PITCH);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 9; ++j) acc = MM::mma(wf[kd * 9 + j], bf[kd & 1][j], acc);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const int live = lmask[k * 256 + r * 16 + fr];
+            if (live) {
+                typedef E e4 __attribute__((ext_vector_type(4)));
+                const e4 h = __builtin_convertvector(acc, e4);
+                const size_t site = ((size_t)(b * V1 + z0 + zl) * V1 + y0 + yl) * V1 + xr * 16 + fr;
+                *(e4*)((AT*)p.out + site * 64 + ct * 16 + fq * 4) = h;
+                const f32x4 rv = {(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+                cs += rv;
+                cq += rv * rv;
+            }
+        }
+    }
+
+    if (p.stats) {                                                             // one record per workgroup: wave ct owns channels 16 ct ..
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float s_ = cs[r], q_ = cq[r];
+            s_ += vox_row_ror<8>(s_); q_ += vox_row_ror<8>(q_);
+            s_ += vox_row_ror<4>(s_); q_ += vox_row_ror<4>(q_);
+            s_ += vox_row_ror<2>(s_); q_ += vox_row_ror<2>(q_);
+            s_ += vox_row_ror<1>(s_); q_ += vox_row_ror<1>(q_);
+            if (fr == 0) {
+                p.stats[(size_t)blockIdx.x * 128 + ct * 16 + fq * 4 + r] = s_;
+                p.stats[(size_t)blockIdx.x * 128 + 64 + ct * 16 + fq * 4 + r] = q_;
+            }
+        }
+    }
+}
+
 static bool vox_disabled(const char* name) {
     const char* e = getenv(name);
     return e && e[0] == '1';
+}
+
+// brick rows per workgroup: 32^3 -> 16 (64 runs), 64^3 -> 8 (64 runs; TRICOLO_VOX0_TY=16: 128 runs), 128^3 -> 8 (128 runs)
+static int vox0_ty(int V) {
+    static int env = -1;
+    if (env < 0) { const char* e = getenv("TRICOLO_VOX0_TY"); env = e ? atoi(e) : 0; }
+    if (V == 64 && env == 16) return 16;
+    return V == 32 ? 16 : 8;
 }
 
 bool tri_internal_vox0_geometry(int B, int ID, int IH, int IW, int cin, int OD, int OH, int OW, int cout, int KD, int KH, int KW, int stride,
@@ -224,33 +490,86 @@ bool tri_internal_vox0_geometry(int B, int ID, int IH, int IW, int cin, int OD, 
     const int V = ID;
     if (IH != V || IW != V || OD != V || OH != V || OW != V || (V != 32 && V != 64 && V != 128)) return false;
     if (cin != 4 || cout != 32 || KD != 3 || KH != 3 || KW != 3 || stride != 1 || pd != 1 || ph != 1 || pw != 1) return false;
-    if ((long)B * (V / 2) * 16 >= (1L << 31)) return false;
+    if ((long)B * V * V * V * 8 >= (1L << 31)) return false;                  // 32-bit buffer offsets
     g->V = V;
-    g->TY = 1024 / V;
-    g->nyb = V / g->TY;
-    g->pitch = V * 8 + 128;                                                   // 128 mod 256 for V = 32, 64, 128
-    g->plane = (g->TY + 2) * g->pitch;
-    if (((g->plane >> 7) & 1) == 0) g->plane += 128;                          // plane pitch 128 mod 256 too
-    g->slab_bytes = 4 * g->plane;
-    g->vshift = V == 32 ? 1 : (V == 64 ? 2 : 3);
-    g->grid = B * (V / 2) * g->nyb;
+    g->TY = vox0_ty(V);
+    g->grid = B * (V / 2) * (V / g->TY);
     return true;
+}
+
+template <typename AT, int V, int TY>
+static int vox0_launch_t(const Vox0Args& a, int grid, hipStream_t stream) {
+    typedef Vox0Cfg<V, TY> C;
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute((const void*)conv_vox0_kernel<AT, V, TY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::SMEM);
+        attr = true;
+    }
+    conv_vox0_kernel<AT, V, TY><<<grid, 256, C::SMEM, stream>>>(a);
+    return tri_check_launch("tri_conv(vox0)");
 }
 
 int tri_internal_vox0_launch(const TriVox0Geom& g, int B, const void* in, const void* w, int kpad, void* out, const uint8_t* mask, float* stats,
                              int act_fmt, hipStream_t stream) {
     Vox0Args a{};
     a.in = in; a.w = w; a.out = out; a.mask = mask; a.stats = stats;
-    a.B = B; a.V = g.V; a.TY = g.TY; a.nyb = g.nyb; a.Kpad = kpad;
-    a.pitch = g.pitch; a.plane = g.plane; a.slab_bytes = g.slab_bytes; a.vshift = g.vshift;
-    const size_t smem = (size_t)g.slab_bytes + 2048 + 4 * 32 * 2 * sizeof(float);
-    static size_t attr_f16 = 0, attr_bf16 = 0;
-    if (act_fmt == TRI_FMT_F16) {
-        if (smem > attr_f16) { hipFuncSetAttribute((const void*)conv_vox0_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr_f16 = smem; }
-        conv_vox0_kernel<f16_t><<<g.grid, 256, smem, stream>>>(a);
-    } else {
-        if (smem > attr_bf16) { hipFuncSetAttribute((const void*)conv_vox0_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr_bf16 = smem; }
-        conv_vox0_kernel<bf16_t><<<g.grid, 256, smem, stream>>>(a);
+    a.B = B; a.Kpad = kpad;
+    a.in_bytes = (unsigned)((size_t)B * g.V * g.V * g.V * 8);
+#ifdef VOX_PROBE
+    { const char* e = getenv("TRICOLO_VOX_ABL"); a.abl = e ? atoi(e) : 0; }
+    { const char* e = getenv("TRICOLO_VOX_DBG"); a.dbg = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
+#endif
+#define TRI_VOX0(V_, TY_)                                                                                          \
+    if (g.V == V_ && g.TY == TY_)                                                                                  \
+        return act_fmt == TRI_FMT_F16 ? vox0_launch_t<f16_t, V_, TY_>(a, g.grid, stream) : vox0_launch_t<bf16_t, V_, TY_>(a, g.grid, stream);
+    TRI_VOX0(32, 16)
+    TRI_VOX0(64, 8)
+    TRI_VOX0(64, 16)
+    TRI_VOX0(128, 8)
+#undef TRI_VOX0
+    tri_set_error("conv(vox0): brick shape not instantiated");
+    return TRI_ERR_UNSUPPORTED;
+}
+
+bool tri_internal_vox1_geometry(int B, int ID, int IH, int IW, int cin, int OD, int OH, int OW, int cout, int KD, int KH, int KW, int stride,
+                                int pd, int ph, int pw, TriVox1Geom* g) {
+    static int off = -1;
+    if (off < 0) off = vox_disabled("TRICOLO_NO_VOX1") ? 1 : 0;               // A/B switch: level 1 stays on conv_igemm_kernel
+    if (off) return false;
+    const int V = ID;
+    static int big = -1;                                                      // TRICOLO_VOX1_32=1: also 32^3 level-1 grids (64^3 inputs; slower than conv_igemm_kernel there)
+    if (big < 0) big = vox_disabled("TRICOLO_VOX1_32") ? 1 : 0;
+    if (IH != V || IW != V || OD != V || OH != V || OW != V || (V != 16 && !(V == 32 && big))) return false;
+    if (cin != 32 || cout != 64 || KD != 3 || KH != 3 || KW != 3 || stride != 1 || pd != 1 || ph != 1 || pw != 1) return false;
+    if ((long)B * V * V * V * 64 >= (1L << 31)) return false;                 // 32-bit buffer offsets
+    g->V = V;
+    g->TY = V == 16 ? 8 : 4;
+    g->nbricks = B * (V / 2) * (V / g->TY);
+    int grid = 2 * tri_internal_num_cus();                                    // persistent: two workgroups per CU
+    if (grid > g->nbricks) grid = g->nbricks;
+    if ((long)grid * 32 < g->nbricks) grid = (g->nbricks + 31) / 32;          // a workgroup caches the masks of <= 32 bricks
+    g->grid = grid;
+    return true;
+}
+
+template <typename AT, int V1, int TY>
+static int vox1_launch_t(const Vox1Args& a, int grid, hipStream_t stream) {
+    typedef Vox1Cfg<V1, TY> C;
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute((const void*)conv_vox1_kernel<AT, V1, TY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::SMEM);
+        attr = true;
     }
-    return tri_check_launch("tri_conv(vox0)");
+    conv_vox1_kernel<AT, V1, TY><<<grid, 256, C::SMEM, stream>>>(a);
+    return tri_check_launch("tri_conv(vox1)");
+}
+
+int tri_internal_vox1_launch(const TriVox1Geom& g, int B, const void* in, const void* w, void* out, const uint8_t* mask, float* stats, int act_fmt,
+                             hipStream_t stream) {
+    Vox1Args a{};
+    a.in = in; a.w = w; a.out = out; a.mask = mask; a.stats = stats;
+    a.B = B; a.nbricks = g.nbricks;
+    a.in_bytes = (unsigned)((size_t)B * g.V * g.V * g.V * 64);
+    if (g.V == 16) return act_fmt == TRI_FMT_F16 ? vox1_launch_t<f16_t, 16, 8>(a, g.grid, stream) : vox1_launch_t<bf16_t, 16, 8>(a, g.grid, stream);
+    return act_fmt == TRI_FMT_F16 ? vox1_launch_t<f16_t, 32, 4>(a, g.grid, stream) : vox1_launch_t<bf16_t, 32, 4>(a, g.grid, stream);
 }

@@ -486,20 +486,31 @@ __device__ __forceinline__ AdamCoef adam_coef(int t, float lr, const float* lr_d
     c.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
     return c;
 }
+// Overflow guard of the 16-bit modes: activation gradients are stored in f16 under a static 2^12 scale; should one
+// overflow, the inf / NaN reaches a parameter gradient.  An element whose gradient is not finite is NOT applied - its parameter and
+// both moments keep their values, so a non-finite value can never enter the fp32 master weights or the Adam state, also inside a
+// replayed HIP graph - and counted in step[1] (`step` is a device int[2]: [0] the step counter, [1] the running number of skipped
+// elements; FusedAdam.nonfinite_skipped() reads it).
+__device__ __forceinline__ void adam_note_bad(const int* step, int bad) {
+    if (bad) atomicAdd(const_cast<int*>(step) + 1, bad);
+}
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
                             const int* __restrict__ step, float lr, const float* __restrict__ lr_dev, float b1, float b2, float eps,
                             float wd, float gscale) {
     const AdamCoef co = adam_coef(*step, lr, lr_dev, b1, b2);
     const float step_size = co.step_size, inv_sqrt_bc2 = co.inv_sqrt_bc2;
+    int bad = 0;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         float pi = p[i];
         float gi = g[i] * gscale + wd * pi;
+        if (!__builtin_isfinite(gi)) { ++bad; continue; }          // overflow guard: p, m, v of that element stay (see adam_note_bad)
         float mi = b1 * m[i] + (1.f - b1) * gi;
         float vi = b2 * v[i] + (1.f - b2) * gi * gi;
         m[i] = mi;
         v[i] = vi;
         p[i] = pi - step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
     }
+    adam_note_bad(step, bad);
 }
 // Same update, gradients read in place from the per-parameter tensors autograd produced (segment table: device pointer and
 // flat start offset of every parameter, ascending) - no concatenation pass over the 74 MB of gradients first.  Four elements
@@ -516,6 +527,7 @@ __global__ __launch_bounds__(256) void adam_seg_kernel(float* __restrict__ p, co
     __syncthreads();
     const AdamCoef co = adam_coef(*step, lr, lr_dev, b1, b2);
     const float step_size = co.step_size, inv_sqrt_bc2 = co.inv_sqrt_bc2;
+    int bad = 0;
     for (long i4 = (long)blockIdx.x * blockDim.x + threadIdx.x; i4 < n4; i4 += (long)gridDim.x * blockDim.x) {
         const long i = i4 * 4;
         int lo = 0, hi = nseg - 1;                                  // last segment whose start is <= i
@@ -530,14 +542,17 @@ __global__ __launch_bounds__(256) void adam_seg_kernel(float* __restrict__ p, co
 #define ADAM1(P, G, M, V)                                   \
     {                                                       \
         const float gi = G * gscale + wd * P;               \
-        M = b1 * M + (1.f - b1) * gi;                       \
-        V = b2 * V + (1.f - b2) * gi * gi;                  \
-        P = P - step_size * M / (sqrtf(V) * inv_sqrt_bc2 + eps); \
+        if (__builtin_isfinite(gi)) {                       \
+            M = b1 * M + (1.f - b1) * gi;                   \
+            V = b2 * V + (1.f - b2) * gi * gi;              \
+            P = P - step_size * M / (sqrtf(V) * inv_sqrt_bc2 + eps); \
+        } else ++bad;                                       \
     }
         ADAM1(pv.x, gv.x, mv.x, vv.x) ADAM1(pv.y, gv.y, mv.y, vv.y) ADAM1(pv.z, gv.z, mv.z, vv.z) ADAM1(pv.w, gv.w, mv.w, vv.w)
 #undef ADAM1
         *(float4*)(p + i) = pv; *(float4*)(m + i) = mv; *(float4*)(v + i) = vv;
     }
+    adam_note_bad(step, bad);
 }
 extern "C" int tri_adam_step_segments(float* p, const void* grad_ptrs, const long* grad_starts, int nseg, float* m, float* v, long n,
                                       const int* step, float lr, const float* lr_dev, float b1, float b2, float eps, float wd, float gscale,

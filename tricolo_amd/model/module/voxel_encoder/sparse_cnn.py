@@ -111,7 +111,7 @@ class SparseCNNEncoder(TriModule):
             conv, bn = self.sparseModel[str(4 * l)], self.sparseModel[str(4 * l + 1)]
             packed = self._packed[(l, False)]
             mode = ops._conv_mode(x, packed[1])
-            use_rows = compact and not g.splitk(False, mode) and not g.brick(False, mode)      # brick kernels walk the grid by the mask
+            use_rows = compact and not g.brick(False, mode)      # brick kernels walk the grid by the mask; split-K levels take the list too
             sel = dict(rows=rows) if use_rows else dict(row_mask=mask)
             if train:
                 y, stats = ops.conv_fwd(x, g, packed, want_stats=True, **sel)
@@ -164,7 +164,7 @@ class SparseCNNEncoder(TriModule):
             grads[3 * l + 1], grads[3 * l + 2] = dgamma, dbeta
             if l > 0:
                 pt = self._packed[(l, True)]
-                if compact and not g.splitk(True, ops._conv_mode(dy, pt[1])):
+                if compact:
                     dx = ops.conv_dgrad(dy, g, pt, rows=rows)                   # only the active input sites are computed / written
                 else:
                     dx = ops.conv_dgrad(dy, g, pt, row_mask=mask)

@@ -101,6 +101,8 @@ def _igemm_symbol(g, transposed, split, t):
     fam, bn = code & 255, (code >> 8) & 255
     if fam == 6:
         return f"conv_vox0_kernel<{_TNAME[t.dtype]}>"
+    if fam == 7:
+        return f"conv_vox1_kernel<{_TNAME[t.dtype]}>"
     if fam == 4:
         return f"conv_stem_kernel<{g.kernel[1]}, {_TNAME[t.dtype]}>"
     if fam == 5:
@@ -179,6 +181,7 @@ class ConvGeom:
         self.M = B * OD * OH * OW
         self.M_in = B * ID * IH * IW
         self.num_mtiles = {m: lib().tri_conv_num_mtiles(_C.C.byref(self.desc), m) for m in (0, 1, 2)}     # by _conv_mode
+        self.num_records_rows = {m: lib().tri_conv_num_records(_C.C.byref(self.desc), m, 1) for m in (0, 1, 2)}   # calls with a row list
         self.kernel_family = {(tr, m): lib().tri_conv_kernel_family(_C.C.byref(self.desc), 1 if tr else 0, m)
                               for tr in (False, True) for m in (0, 1, 2)}
         self.wgrad_ws = lib().tri_conv_wgrad_workspace(_C.C.byref(self.desc))
@@ -209,7 +212,7 @@ class ConvGeom:
     def brick(self, transposed: bool, mode: int) -> bool:
         """True when tri_conv_fwd runs this layer on a brick kernel of conv_vox.hip: such launches take the site mask as row_mask
         (rows of inactive sites are then neither computed nor written), not a compact row list."""
-        return (self.kernel_family[(transposed, mode)] & 255) == 6
+        return (self.kernel_family[(transposed, mode)] & 255) in (6, 7)
 
     def splitk(self, transposed: bool, mode: int) -> bool:
         """True when tri_conv_fwd / tri_conv_dgrad runs this layer split-K in plan `mode` (_conv_mode): such launches take
@@ -301,7 +304,8 @@ def conv_fwd(x, g: ConvGeom, packed, row_mask=None, bias=None, act=0, want_stats
     if out is None:
         out = torch.empty((g.B, OD, OH, OW, g.cout), dtype=x.dtype, device=x.device)
     assert out.dtype == x.dtype
-    stats = torch.empty((g.num_mtiles[_conv_mode(x, lo)], 2, g.cout), dtype=torch.float32, device=x.device) if want_stats else None
+    nrec = (g.num_records_rows if rows else g.num_mtiles)[_conv_mode(x, lo)]
+    stats = torch.empty((nrec, 2, g.cout), dtype=torch.float32, device=x.device) if want_stats else None
     ws = _workspace(g.fwd_ws, x.device) if g.fwd_ws else None
     check(_timed(_igemm_symbol(g, False, lo is not None, x), g.flops,
                  lambda: lib().tri_conv_fwd(_C.C.byref(g.desc), ptr(_act(x)), ptr(hi), ptr(lo), ptr(out), ptr(row_mask), ptr(bias),

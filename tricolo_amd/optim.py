@@ -42,7 +42,7 @@ class FusedAdam(torch.optim.Optimizer):
                 raise RuntimeError("FusedAdam: fp32 master parameters expected")
         dev = params[0].device
         self._params = params
-        self._step_dev = torch.zeros((1,), dtype=torch.int32, device=dev)
+        self._step_dev = torch.zeros((2,), dtype=torch.int32, device=dev)        # [0] step counter, [1] skipped non-finite elements
         self._lr_dev = torch.zeros((1,), dtype=torch.float32, device=dev)
         self.sync_lr()
         if self._flatten:
@@ -87,6 +87,13 @@ class FusedAdam(torch.optim.Optimizer):
             sd, self._pending_state = self._pending_state, None
             self._restore(sd)
 
+    def nonfinite_skipped(self) -> int:
+        """Number of gradient elements the kernels refused so far because they were inf / NaN (f16 activation-gradient overflow guard:
+        such an element leaves its parameter and both moments untouched - csrc/misc.hip adam_note_bad).  Reads a device counter
+        (synchronises); 0 in a healthy run.  A training loop should look at it now and then and lower ops.F16_GRAD_SCALE / switch to
+        the bf16x3 mode when it grows."""
+        return 0 if self._step_dev is None else int(self._step_dev[1].item())
+
     def sync_lr(self):
         """Copy param_groups[0]['lr'] to the device scalar the kernels read.  Eager steps call it themselves; call it after
         changing the learning rate when the step is replayed from a HIP graph (it cannot run inside a capture)."""
@@ -108,7 +115,7 @@ class FusedAdam(torch.optim.Optimizer):
         under ``optimizer_states`` and ``trainer.fit(ckpt_path=...)`` restores, train.py:41-45)."""
         sd = super().state_dict()
         if self._step_dev is not None:
-            step = self._step_dev.to(torch.float32).reshape(())
+            step = self._step_dev[0].to(torch.float32).reshape(())
             # the packed per-parameter dicts ARE self.state's own and the moments are views of the flat buffers the kernels
             # update: hand out copies (an optimizer that load_state_dict()s this dict in the same process keeps the tensors)
             sd["state"] = {k: {"step": step.clone(), "exp_avg": v["exp_avg"].clone(), "exp_avg_sq": v["exp_avg_sq"].clone()}
@@ -131,7 +138,7 @@ class FusedAdam(torch.optim.Optimizer):
             if len(steps) > 1:
                 raise RuntimeError(f"FusedAdam keeps ONE step counter; the checkpoint holds different per-parameter steps {sorted(steps)}")
             if steps:
-                self._step_dev.fill_(steps.pop())
+                self._step_dev[0].fill_(steps.pop())
         for g, gs in zip(self.param_groups, sd["param_groups"]):
             for k, v in gs.items():
                 if k != "params":
