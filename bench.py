@@ -61,6 +61,16 @@ def workload_name(a):
     return f"BASELINE configs[{a.config - 1}] per-GPU shard: {kind} {towers}, fwd+bwd+Adam"
 
 
+def step_gflop_per_sample(a):
+    """Algorithmic FLOPs of one training step per sample (fwd + dgrad + wgrad ~ 3 x forward; BASELINE.md section 2 / SURVEY 8d)."""
+    fwd = 0.057 if a.text == "BiGRUEncoder" else 0.002
+    if a.voxel:
+        fwd += {32: 1.0192, 64: 8.1537}.get(a.voxel_size, 1.0192 * (a.voxel_size / 32) ** 3)
+    if a.image:
+        fwd += {128: 1.1843, 224: 3.628}.get(a.image_size, 1.1843 * (a.image_size / 128) ** 2) * a.num_views
+    return 3.0 * fwd
+
+
 def build_net(a, precision, device):
     from tricolo_amd import config as tcfg, ops
     from tricolo_amd.model.tricolo_net import TriCoLoNet
@@ -273,21 +283,27 @@ def run_mode(a, precision, world, rank, device, want_voxel_roofline):
         run(i)
     for i in range(a.warmup):
         loss = run(i)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        loss = run(i)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    # three back-to-back windows of EXACTLY K steps, each bracketed by barrier + synchronize, max over ranks per window; `value` is the
+    # MEDIAN window (a 66 ms region is at the mercy of one host hiccup), min / max beside it
+    windows = []
+    for w in range(a.windows):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            loss = run(w * a.steps + i)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([el], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el = float(tmax.item())
+        windows.append(el)
+    elapsed = sorted(windows)[len(windows) // 2]
     final_loss = float(loss.item())
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
 
     # ---- roofline leg: per-kernel HIP-event timing of eager steps, dominant kernel by time.  Rank 0 records; at N > 1
     # EVERY rank runs the steps (they contain the collectives - a rank-0-only step would wait for its peers forever).
@@ -298,7 +314,7 @@ def run_mode(a, precision, world, rank, device, want_voxel_roofline):
     # serialise the streams for this leg: a kernel's HIP-event duration must not include the other towers' kernels
     # sharing the GPU with it (the timed region above keeps towers on parallel streams)
     net.overlap_towers = False
-    for side_name in ("_side", "_side_ds"):
+    for side_name in ("_side", "_side_ds", "_side_prep"):
         if net.image_encoder is not None and getattr(net.image_encoder, side_name, None) is not None:
             getattr(net.image_encoder, side_name).enabled = False
     if rank == 0:
@@ -315,7 +331,15 @@ def run_mode(a, precision, world, rank, device, want_voxel_roofline):
         ev_ovh = ops.TIMER.overhead_ms
         ops.TIMER = None
         if agg:
-            sym, d = max(agg.items(), key=lambda kv: kv[1]["ms"])
+            # dominant kernel = the FAMILY (all template instantiations of one __global__ function: tile shapes, record / store variants,
+            # pipeline depths) with the most measured time; per-instantiation lines stay in all_kernels
+            fam = {}
+            for k, v in agg.items():
+                f = fam.setdefault(k.split("<")[0], {"launches": 0, "ms": 0.0, "ms_raw": 0.0, "flops": 0, "variants": []})
+                f["launches"] += v["launches"]; f["ms"] += v["ms"]; f["ms_raw"] += v["ms_raw"]; f["flops"] += v["flops"]
+                f["variants"].append(k)
+            fname, d = max(fam.items(), key=lambda kv: kv[1]["ms"])
+            sym = f"{fname}<*> ({len(d['variants'])} instantiation(s): {', '.join(sorted(d['variants']))})"
             tflops = d["flops"] / (d["ms"] * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": sym, "achieved": round(tflops, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(tflops / MFMA_PEAK_TFLOPS, 4), "traffic": None, "launches_per_step": d["launches"] // nprof,
@@ -325,22 +349,36 @@ def run_mode(a, precision, world, rank, device, want_voxel_roofline):
                               "compare avg_launch_ms with the rocprofv3 AverageNs of profiles/r2/kernel_stats_*.csv",
                     "flops_basis": "dense-equivalent 2*M*taps*Cin*Cout of this symbol's launches (executed FLOPs of the masked voxel "
                                    "launches: roofline_3dconv_fwd)",
+                    "families": {k: {"launches_per_step": v["launches"] // nprof, "ms_per_step": round(v["ms"] / nprof, 3),
+                                     "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in fam.items()},
                     "all_kernels": {k: {"launches_per_step": v["launches"] // nprof, "ms_per_step": round(v["ms"] / nprof, 3),
                                         "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in agg.items()}}
             # HBM bytes per launch of that kernel from the committed PMC passes over this same command (PMC cannot run inside
             # bench.py: separate `rocprofv3 --pmc` runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes)
-            rel = f"profiles/r2/pmc_traffic_{precision}.json"
-            try:
-                with open(os.path.join(REPO, rel)) as f:
-                    pmc = json.load(f)["kernels"].get(sym)
-                if pmc:
-                    roof["traffic"] = pmc["fetch_bytes_per_launch"] + pmc["write_bytes_per_launch"]
-                    roof["traffic_unit"] = f"fabric bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, mean over the step's launches; {rel})"
-            except Exception:                       # noqa: BLE001  no committed PMC pass for this mode: traffic stays null
-                pass
+            for rnd in ("r3", "r2"):
+                rel = f"profiles/{rnd}/pmc_traffic_{precision}.json"
+                try:
+                    with open(os.path.join(REPO, rel)) as f:
+                        doc = json.load(f)
+                    hit = {k: v for k, v in doc["kernels"].items() if k.split("<")[0] == fname}
+                    n = sum(v["dispatches"] for v in hit.values())
+                    if n:
+                        roof["traffic"] = int(sum((v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["dispatches"] for v in hit.values()) / n)
+                        roof["traffic_unit"] = (f"fabric bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, mean over the family's launches; {rel}; "
+                                                "PMC cannot run inside bench.py)")
+                        roof["step_hbm_bytes"] = doc.get("step_bytes")
+                        break
+                except Exception:                   # noqa: BLE001  no committed PMC pass for this mode: traffic stays null
+                    continue
         if want_voxel_roofline and net.voxel_encoder is not None and "locs" in batches[0]["voxels"]:
             vox_roof = voxel_fwd_roofline(net, batches[0], B)
+    gflop_per_sample = step_gflop_per_sample(a)
     res = {"value": round(B * world * a.steps / elapsed, 2), "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+           "ms_per_step_windows": {"median": round(elapsed / a.steps * 1e3, 3), "min": round(min(windows) / a.steps * 1e3, 3),
+                                   "max": round(max(windows) / a.steps * 1e3, 3), "windows": len(windows), "steps_per_window": a.steps},
+           "step_tflops": round(gflop_per_sample * B * world * a.steps / elapsed / 1e3, 1),
+           "step_tflops_note": f"algorithmic {gflop_per_sample:.2f} GFLOP per sample (3 x forward: SURVEY 8d / BASELINE.md section 2) over the median window; "
+                               f"{100 * gflop_per_sample * B * a.steps / elapsed / 1e3 / MFMA_PEAK_TFLOPS / 1:.1f} % of one GPU's dense 16-bit MFMA peak per GPU",
            "dtype": DTYPE_NOTE[precision], "hip_graph": graph_note if graphs is not None else (graph_note or False),
            "final_loss": round(final_loss, 5), "roofline": roof}
     del graphs, net, opt, batches
@@ -371,8 +409,9 @@ def run_mode_in_child(a, mode):
     if r.returncode != 0 or not lines:
         raise RuntimeError(f"bench.py child for mode {mode} failed (rc {r.returncode}):\n{r.stderr[-2000:]}")
     d = json.loads(lines[-1])
-    return {"value": d["value"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"], "hip_graph": d["config"]["hip_graph"],
-            "final_loss": d["config"]["final_loss"], "roofline": d["roofline"], "process": "child"}
+    return {"value": d["value"], "ms_per_step": d["ms_per_step"], "ms_per_step_windows": d.get("ms_per_step_windows"), "step_tflops": d.get("step_tflops"),
+            "dtype": d["dtype"], "hip_graph": d["config"]["hip_graph"], "final_loss": d["config"]["final_loss"], "roofline": d["roofline"],
+            "process": "child"}
 
 
 def parse_args(argv=None):
@@ -396,6 +435,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-budget-s", type=float, default=30.0)
     ap.add_argument("--resident-batches", type=int, default=2)
     ap.add_argument("--preroll", type=int, default=40)
+    ap.add_argument("--windows", type=int, default=3, help="timed windows of --steps steps each; value = the median window")
     a = ap.parse_args(argv)
     text, image, voxel, V, nv, S, pb = CONFIGS[a.config]
     a.text, a.image, a.voxel = text, image, voxel
@@ -500,7 +540,8 @@ def main():
         out = {
             "metric": "trimodal training samples/sec (32^3 voxel + 6-view)" if a.config == 4 else f"training samples/sec, BASELINE config {a.config}",
             "value": head["value"], "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": head["ms_per_step"], "ms_per_step_windows": head["ms_per_step_windows"], "step_tflops": head["step_tflops"],
+            "step_tflops_note": head["step_tflops_note"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": head["dtype"], "data": "synthetic",
             "config": {"workload": workload_name(a), "global_batch": gb, "per_gpu_batch": a.per_gpu_batch, "parallelism": f"dp{world}",
                        "precision_mode": a.precision, "hip_graph": head["hip_graph"], "final_loss": head["final_loss"],

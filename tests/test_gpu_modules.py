@@ -261,8 +261,8 @@ def test_mvcnn_backward_replay_with_forced_routing():
     difference changes gradient elements by O(1), which is where this fixture's 4 % element-wise noise floor comes from.  Here the
     float64 oracle is replayed with the ROUTING FORCED to the HIP forward's: every block ReLU multiplies by the mask of the HIP path's
     own stored activations, the view max gathers the HIP path's arg-max view.  What is left is a smooth function of the weights, and
-    the HIP gradients of every trunk tensor above the stem must agree with it element-wise: relative L2 <= 2e-3 per tensor (measured
-    in profiles/r3/parity_report.json).  The stem's conv1 / bn1 are excluded (their ReLU + max-pool routing is inside a fused kernel
+    the HIP gradients of every trunk tensor above the stem must agree with it element-wise: relative L2 <= 5e-4 per tensor (measured
+    6.4e-5, profiles/r3/parity_report.json).  The stem's conv1 / bn1 are excluded (their ReLU + max-pool routing is inside a fused kernel
     whose masks are not stored); the heads are included."""
     from oracle import modules as om
     B, nv, S = 8, 6, 128
@@ -314,7 +314,7 @@ def test_mvcnn_backward_replay_with_forced_routing():
         a = rg[name].grad
         dl = float((p.grad.detach().double().cpu() - a).norm() / a.norm().clamp_min(1e-300))
         worst = max(worst, dl)
-        if dl > 2e-3:
+        if dl > 5e-4:
             bad.append((name, dl))
     _report("grads/mvcnn_forced_routing_replay", {"worst_rel_l2": worst})
     assert not bad, bad

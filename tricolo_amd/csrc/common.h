@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -16,6 +17,18 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 #define TRI_ERR_UNSUPPORTED (-2)
 
 extern "C" void tri_set_error(const char* msg);
+// Ablation bits of the timing probes (no MFMA / no epilogue / no statistics ...: WRONG results, timing only).  Compiled in only with
+// -DTRI_PROBE_BUILD (tools/probes); the production library ignores TRICOLO_HALO_ABL, so an environment variable can never silently
+// corrupt gradients.
+static inline int tri_probe_ablation() {
+#ifdef TRI_PROBE_BUILD
+    static int abl = -1;
+    if (abl < 0) { const char* e = getenv("TRICOLO_HALO_ABL"); abl = e ? atoi(e) : 0; }
+    return abl;
+#else
+    return 0;
+#endif
+}
 int tri_check_launch(const char* what);
 
 // Unsigned division by a runtime constant (Granlund-Montgomery round-up form), valid for n < 2^31.

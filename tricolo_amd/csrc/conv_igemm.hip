@@ -2011,7 +2011,7 @@ template <int TM, typename AT>
 static int launch_halo(ConvArgs& a, const ConvPlan& pl, hipStream_t stream) {
     a.h_tr = pl.h_tr; a.h_rows = pl.h_rows; a.h_slab_bytes = pl.h_slab_bytes; a.h_nr = pl.h_nr; a.h_mtiles = pl.h_mtiles;
     a.h_dbuf = pl.h_dbuf;
-    { static int abl = -1; if (abl < 0) { const char* e = getenv("TRICOLO_HALO_ABL"); abl = e ? atoi(e) : 0; } a.h_abl = abl; }
+    a.h_abl = tri_probe_ablation();
     a.dP = make_fastdiv(a.IW + 2); a.dH2 = make_fastdiv(a.IH + 2);
 #ifdef HALO_STAMPS
     a.h_dbg = g_halo_dbg;
@@ -2077,7 +2077,7 @@ static int launch_halo(ConvArgs& a, const ConvPlan& pl, hipStream_t stream) {
 template <typename AT>
 static int launch_stem(ConvArgs& a, hipStream_t stream) {
     StemGeom sg;
-    { static int abl = -1; if (abl < 0) { const char* e = getenv("TRICOLO_HALO_ABL"); abl = e ? atoi(e) : 0; } a.h_abl = abl; }
+    a.h_abl = tri_probe_ablation();
     if (!stem_geometry(a.B, a.IH, a.IW, a.Cin, a.OH, a.OW, a.Cout, a.KD, a.KH, a.KW, a.stride, a.pd, a.ph, a.pw, &sg)) {
         tri_set_error("conv(stem): geometry changed between plan and launch"); return TRI_ERR_ARG;
     }

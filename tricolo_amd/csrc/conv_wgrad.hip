@@ -1072,7 +1072,7 @@ extern "C" int tri_conv_wgrad_partial(const TriConvDesc* d, const void* in, cons
             const size_t need = (size_t)grid * 64 * 576 * sizeof(float);
             if (workspace_bytes < need) { tri_set_error("wgrad(c64): workspace too small"); return TRI_ERR_ARG; }
             cg.in = in; cg.dout = dout; cg.slab = (float*)workspace;
-            { static int abl = -1; if (abl < 0) { const char* e = getenv("TRICOLO_HALO_ABL"); abl = e ? atoi(e) : 0; } cg.h_abl = abl; }
+            cg.h_abl = tri_probe_ablation();
             const size_t smem = (size_t)cg.TR * cg.W * 128 + (size_t)(cg.TR + 2) * (cg.W + 2) * 128;
             static bool attr = false;
             if (!attr) {
@@ -1101,7 +1101,7 @@ extern "C" int tri_conv_wgrad_partial(const TriConvDesc* d, const void* in, cons
             const size_t need = (size_t)grid * 64 * d->KH * 32 * sizeof(float);
             if (workspace_bytes < need) { tri_set_error("wgrad(stem): workspace too small"); return TRI_ERR_ARG; }
             sg.in = in; sg.dout = dout; sg.slab = (float*)workspace;
-            { static int abl = -1; if (abl < 0) { const char* e = getenv("TRICOLO_HALO_ABL"); abl = e ? atoi(e) : 0; } sg.h_abl = abl; }
+            sg.h_abl = tri_probe_ablation();
             const size_t smem = (size_t)sg.TH * sg.OW * 128 + (size_t)sg.slab_rows * sg.row_bytes;
             hipStream_t st = (hipStream_t)stream;
 #define TRI_SWG(KH_)                                                                                                           \

@@ -360,7 +360,10 @@ class WgradBatch:
 
     def __init__(self, device):
         self.device = device
-        self.chunks = WgradBatch._arenas.setdefault((device, torch.cuda.current_stream().cuda_stream), [])
+        # arenas of a HIP-graph capture are kept apart from the eager ones of the same stream id: a chunk allocated under capture lives
+        # in the graph's private pool and must only ever be touched by replays (torch hands stream ids out of a small pool, so an
+        # eager step could otherwise land on a capture's arena - ADVICE r2)
+        self.chunks = WgradBatch._arenas.setdefault((device, torch.cuda.current_stream().cuda_stream, torch.cuda.is_current_stream_capturing()), [])
         self.ci, self.off, self.descs = 0, 0, []
 
     def slab(self, nbytes: int) -> torch.Tensor:
@@ -373,7 +376,20 @@ class WgradBatch:
                     return t
                 self.ci, self.off = self.ci + 1, 0
             else:
-                self.chunks.append(torch.empty(max(nbytes, 128 << 20), dtype=torch.uint8, device=self.device))
+                self.chunks.append(torch.empty(max(nbytes, 16 << 20), dtype=torch.uint8, device=self.device))
+
+    @staticmethod
+    def reserve(device, nbytes: int):
+        """Make sure the current stream's arena holds at least nbytes (call eagerly, ahead of a capture)."""
+        chunks = WgradBatch._arenas.setdefault((device, torch.cuda.current_stream().cuda_stream, torch.cuda.is_current_stream_capturing()), [])
+        have = sum(c.numel() for c in chunks)
+        if have < nbytes:
+            chunks.append(torch.empty(max(nbytes - have, 16 << 20), dtype=torch.uint8, device=device))
+
+    @staticmethod
+    def release():
+        """Drop every arena (between runs / modes: the chunks are plain torch allocations)."""
+        WgradBatch._arenas.clear()
 
     def flush(self):
         n = len(self.descs)
@@ -837,6 +853,10 @@ def one(device) -> torch.Tensor:
     device = torch.device(device)
     t = _ONES.get(device)
     if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            # created inside a capture its fill kernel would only be RECORDED: an eager use before the first replay would read
+            # uninitialised memory.  FusedAdam.prepare() creates it ahead of any capture; anything else must call ops.one() eagerly first.
+            raise RuntimeError("ops.one(): first use inside a HIP-graph capture - call ops.one(device) (or FusedAdam.prepare()) before capturing")
         t = torch.ones((), dtype=torch.float32, device=device)
         _ONES[device] = t
     return t

@@ -43,6 +43,7 @@ class FusedAdam(torch.optim.Optimizer):
         dev = params[0].device
         self._params = params
         self._step_dev = torch.zeros((2,), dtype=torch.int32, device=dev)        # [0] step counter, [1] skipped non-finite elements
+        ops.one(dev)                                                             # the cached loss-gradient scalar: never first created inside a capture
         self._lr_dev = torch.zeros((1,), dtype=torch.float32, device=dev)
         self.sync_lr()
         if self._flatten:
