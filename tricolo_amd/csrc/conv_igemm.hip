@@ -1917,7 +1917,12 @@ static ConvPlan conv_make_plan(int B, int ID, int IH, int IW, int cin, int OD, i
         const int side = OD > OH ? (OD > OW ? OD : OW) : (OH > OW ? OH : OW);
         blocks = side >= 8 ? (blocks + 3) / 4 : (side >= 4 ? (blocks + 1) / 2 : blocks);
     }
-    if (split_mode == 2 && cin % 64 == 0 && cout % 64 == 0 && !dma_disabled()) pl.dma = 1;
+    // (round 3: 32-wide output tiles exist too - built for the data gradient of voxel level 1, 64 -> 32 channels, the slowest kernel of
+    // the voxel backward on the register-staged gather; measured no faster (config 2: 1.108 against 1.106 ms per step), so they are
+    // opt-in: TRICOLO_DMA32=1)
+    static int no32 = -1;
+    if (no32 < 0) { const char* e = getenv("TRICOLO_DMA32"); no32 = (e && e[0] == '1') ? 0 : 1; }
+    if (split_mode == 2 && cin % 64 == 0 && (cout % 64 == 0 || (cout % 32 == 0 && !no32)) && !dma_disabled()) pl.dma = 1;
     pl.bn = bn;
     {
         TriVox0Geom vg;
@@ -1939,7 +1944,7 @@ static ConvPlan conv_make_plan(int B, int ID, int IH, int IW, int cin, int OD, i
             return pl;
         }
     }
-    if (pl.dma && !halo_disabled() && KD == 1 && KH == 3 && KW == 3 && stride == 1 && pd == 0 && ph == 1 && pw == 1 && ID == 1 && OD == 1 &&
+    if (pl.dma && cout % 64 == 0 && !halo_disabled() && KD == 1 && KH == 3 && KW == 3 && stride == 1 && pd == 0 && ph == 1 && pw == 1 && ID == 1 && OD == 1 &&
         IH == OH && IW == OW && (long)B * IH * IW * cin * 2 < ((long)1 << 31)) {
         // 128-position tiles: a ~25 KB slab + 24 KB ring lets three workgroups share a CU (the kernel is bound by instruction
         // issue and latency, not by operand bytes: occupancy matters more than the bigger tile's reuse)
@@ -1999,7 +2004,7 @@ static int dma_stages_for(const ConvArgs& a, int bn) {
     if (a.row_count && rows) return rows;
     const long wgs = (long)((a.M + 127) / 128) * (a.Cout / bn) * a.ksplit;
     const bool small = a.row_count != nullptr || wgs <= 2L * num_cus();
-    return (small && bn == 64) ? 3 : 2;
+    return (small && bn <= 64) ? 3 : 2;
 }
 
 template <int BN, int NST, typename AT>
@@ -2118,7 +2123,9 @@ static int launch_stem(ConvArgs& a, hipStream_t stream) {
 
 template <typename AT>
 static int launch_dma_any(const ConvArgs& a, int bn, hipStream_t stream) {
-    switch (dma_stages_for(a, bn)) {
+    const int nst = dma_stages_for(a, bn);
+    if (bn == 32) return nst == 2 ? launch_dma<32, 2, AT>(a, stream) : launch_dma<32, 3, AT>(a, stream);
+    switch (nst) {
         case 4: return bn == 128 ? launch_dma<128, 4, AT>(a, stream) : launch_dma<64, 4, AT>(a, stream);
         case 3: return bn == 128 ? launch_dma<128, 3, AT>(a, stream) : launch_dma<64, 3, AT>(a, stream);
         default: return bn == 128 ? launch_dma<128, 2, AT>(a, stream) : launch_dma<64, 2, AT>(a, stream);
