@@ -151,3 +151,63 @@ def test_dp2_product_path_two_ranks_on_one_gpu(golden, tmp_path):
     assert float(r0["param_sum_graphed"]) == float(r1["param_sum_graphed"])
     for r in (r0, r1):
         assert float(r["param_maxdiff_graph_vs_eager"]) < 5e-3            # Adam's first steps are sign-like: bounded, not bitwise
+
+
+def _worker_sync(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle.recipe import fill_module
+    from tricolo_amd import config as tcfg, ops, parallel
+    from tricolo_amd.data import synthetic as syn
+    from tricolo_amd.model.tricolo_net import TriCoLoNet
+
+    ops.set_default_precision("bf16x3")
+    ops.set_sync_bn(True)
+    cfg = tcfg.compose(overrides=["data=synthetic", "model.text_encoder=BiGRUEncoder", "model.image_encoder=MVCNNEncoder",
+                                  "model.voxel_encoder=SparseCNNEncoder", "data.voxel_size=32", "data.num_views=6", "data.image_size=128",
+                                  "experiment_name=syncbn"])
+    net = TriCoLoNet(cfg)
+    fill_module(net)
+    net = net.to(dev)
+    opt = net.configure_optimizers()
+    full = syn.make_batch(8, voxel_size=32, num_views=6, image_size=128, seed=syn.BASE_SEED + 4)      # the batch of step_cfg4_tri.npz
+    shard = syn.batch_to_device(_shard(full, rank, 4), dev)
+    res = {"loss": []}
+    for step in range(3):
+        out = parallel.gather_embeddings(net(shard))
+        if step == 0:
+            for k, v in out.items():
+                res[f"emb/{k}"] = v.detach().cpu().numpy()
+        losses = net._calculate_losses(out, "train_loss")
+        opt.zero_grad(set_to_none=True)
+        losses["train_loss/total_loss"].backward()
+        opt.step(reduce_fn=parallel.allreduce_flat)
+        res["loss"].append(losses["train_loss/total_loss"].item())
+    res["loss"] = np.array(res["loss"])
+    res["running_mean_sum"] = float(sum(b.double().sum().item() for n, b in net.named_buffers() if n.endswith("running_mean")))
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_sync_bn_two_ranks_reproduce_the_single_process_global_batch(golden, tmp_path):
+    """SURVEY 8e "BatchNorm caveat": with ops.set_sync_bn(True) every BatchNorm uses global-batch statistics (one all-reduce of the
+    per-channel sums + count per layer, forward and backward), so TWO ranks with 4 samples each reproduce the reference's
+    SINGLE-process run on all 8 samples - tests/golden/step_cfg4_tri.npz, produced by the real TriCoLoNet: embeddings of the whole
+    batch, the step-0 loss and the losses after one and two Adam steps (gradient SUM over ranks = the global-batch gradient)."""
+    import torch.multiprocessing as mp
+    g = golden("step_cfg4_tri")
+    mp.spawn(_worker_sync, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (dict(np.load(tmp_path / f"rank{r}.npz")) for r in range(2))
+    np.testing.assert_array_equal(r0["loss"], r1["loss"])
+    assert float(r0["running_mean_sum"]) == float(r1["running_mean_sum"])            # both ranks track the same global statistics
+    for k in ("text_features", "image_features", "voxel_features"):
+        np.testing.assert_allclose(r0[f"emb/{k}"], g[f"emb/{k}"], atol=2e-4)
+    assert abs(float(r0["loss"][0]) - float(g["step0/total_loss"])) < 1e-3
+    assert abs(float(r0["loss"][1]) - float(g["step1/total_loss"])) < 1e-2            # (Adam's first steps amplify round-off: the bound of
+    assert abs(float(r0["loss"][2]) - float(g["step2/total_loss"])) < 1e-2            #  test_training_steps_match_reference)

@@ -449,7 +449,48 @@ class BNCoeffs:
         self.mean, self.invstd, self.scale, self.shift = buf[0], buf[1], buf[2], buf[3]
 
 
+# ---- optional synchronised BatchNorm (SURVEY 8e "BatchNorm caveat") ---------------------------------------------------------------
+# Default (like the reference under Lightning DDP without sync_batchnorm): per-rank statistics.  set_sync_bn(True) makes every
+# BatchNorm of the towers use GLOBAL-batch statistics - one SUM all-reduce of the per-channel (sum, sum of squares) record and of the
+# row count in the forward, one of the (sum g, sum g*y) record in the backward (the parameter gradients dgamma / dbeta stay the LOCAL
+# sums: the gradient all-reduce of the step adds the ranks up) - so N ranks reproduce the single-process run on the global batch
+# (tests/test_gpu_dp.py::test_sync_bn_two_ranks_reproduce_the_single_process_global_batch).  25 + 25 small collectives per step: a
+# parity mode, eager only (the collectives cannot sit inside a captured tower), never the benchmarked configuration.
+_SYNC_BN = False
+
+
+def set_sync_bn(flag: bool):
+    global _SYNC_BN
+    _SYNC_BN = bool(flag)
+
+
+def _sync_world() -> int:
+    if not _SYNC_BN:
+        return 1
+    import torch.distributed as dist
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def _sync_sum(t: torch.Tensor) -> torch.Tensor:
+    from .parallel import all_reduce_sum                  # (host-staged under gloo, RCCL under nccl)
+    if t.dtype == torch.int32:                             # gloo has no int32 SUM on every build: go through int64
+        u = t.to(torch.int64)
+        all_reduce_sum(u)
+        return u.to(torch.int32)
+    all_reduce_sum(t)
+    return t
+
+
 def bn_finalize(stats, C, gamma, beta, running_mean, running_var, nbt, count_dev=None, count_host=0, momentum=0.1, eps=1e-5):
+    world = _sync_world()
+    if world > 1:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("sync_bn: the BatchNorm collectives cannot be captured into a HIP graph - run the step eagerly")
+        stats = _sync_sum(stats.sum(0, keepdim=True).contiguous())
+        if count_dev is not None:
+            count_dev = _sync_sum(count_dev.clone())
+        else:
+            count_host = int(count_host) * world
     co = BNCoeffs(C, stats.device)
     check(lib().tri_bn_finalize(ptr(stats), stats.shape[0], C, ptr(count_dev), int(count_host), ptr(gamma), ptr(beta),
                                 ptr(running_mean), ptr(running_var), ptr(nbt), momentum, eps, ptr(co.mean), ptr(co.invstd),
@@ -479,6 +520,27 @@ def relu_bwd(dout, out, inplace=True):
     return g
 
 
+def _bn_bwd_finalize(partial, nblk, C, count_dev, count_host, gamma, co: "BNCoeffs", out_scale):
+    """tri_bn_bwd_finalize -> buf [5, C] = (dgamma, dbeta, c1, c2, c3).  Under sync_bn the apply coefficients come from the GLOBAL
+    (all-reduced) sums and row count, dgamma / dbeta from this rank's own sums."""
+    buf = torch.empty((5, C), dtype=torch.float32, device=partial.device)
+    check(lib().tri_bn_bwd_finalize(ptr(partial), nblk, C, ptr(count_dev), int(count_host), ptr(gamma), ptr(co.mean),
+                                    ptr(co.invstd), ptr(buf[0]), ptr(buf[1]), ptr(buf[2]), ptr(buf[3]), ptr(buf[4]), float(out_scale), stream()),
+          "tri_bn_bwd_finalize")
+    world = _sync_world()
+    if world > 1:
+        tot = _sync_sum(partial.sum(0, keepdim=True).contiguous())
+        if count_dev is not None:
+            count_dev = _sync_sum(count_dev.clone())
+        else:
+            count_host = int(count_host) * world
+        gbuf = torch.empty((5, C), dtype=torch.float32, device=partial.device)
+        check(lib().tri_bn_bwd_finalize(ptr(tot), 1, C, ptr(count_dev), int(count_host), ptr(gamma), ptr(co.mean), ptr(co.invstd), ptr(gbuf[0]),
+                                        ptr(gbuf[1]), ptr(gbuf[2]), ptr(gbuf[3]), ptr(gbuf[4]), float(out_scale), stream()), "tri_bn_bwd_finalize")
+        buf = torch.stack([buf[0], buf[1], gbuf[2], gbuf[3], gbuf[4]])
+    return buf
+
+
 def bn_bwd(y, g, co: BNCoeffs, gamma, count_dev=None, count_host=0, row_mask=None, inplace=True, relu=False, relu_out=None,
            g_masked=None, out_scale: float = 1.0):
     # row_mask: rows with 0 are never read by either pass (their y / g may be unwritten) and come out as zeros in dy
@@ -495,10 +557,7 @@ def bn_bwd(y, g, co: BNCoeffs, gamma, count_dev=None, count_host=0, row_mask=Non
     assert y.dtype == g.dtype
     check(lib().tri_bn_bwd_reduce(ptr(_act(y)), ptr(_act(g)), M, C, ptr(partial), ptr(rs), ptr(rb), ptr(relu_out), ptr(row_mask), _abf(y), stream()),
           "tri_bn_bwd_reduce")
-    buf = torch.empty((5, C), dtype=torch.float32, device=y.device)
-    check(lib().tri_bn_bwd_finalize(ptr(partial), nblk, C, ptr(count_dev), int(count_host), ptr(gamma), ptr(co.mean),
-                                    ptr(co.invstd), ptr(buf[0]), ptr(buf[1]), ptr(buf[2]), ptr(buf[3]), ptr(buf[4]), float(out_scale), stream()),
-          "tri_bn_bwd_finalize")
+    buf = _bn_bwd_finalize(partial, nblk, C, count_dev, count_host, gamma, co, out_scale)
     dy = g if inplace else torch.empty_like(g)
     check(lib().tri_bn_bwd_apply(ptr(y), ptr(g), ptr(buf[2]), ptr(buf[3]), ptr(buf[4]), ptr(row_mask), ptr(dy), M, C, ptr(rs), ptr(rb),
                                  ptr(relu_out), ptr(g_masked), _abf(y), stream()), "tri_bn_bwd_apply")
@@ -536,10 +595,8 @@ def pool3d_bn_bwd(y, co: BNCoeffs, mask, pooled, dpooled, B, D, C, gamma, count_
     partial = torch.empty((nblk, 2, C), dtype=torch.float32, device=y.device)
     check(lib().tri_pool3d_bwd_route_reduce(ptr(_act(y)), ptr(co.scale), ptr(co.shift), ptr(mask), ptr(pooled), ptr(_act(dpooled)), B, D, C,
                                             ptr(g), ptr(partial), _abf(y), stream()), "tri_pool3d_bwd_route_reduce")
-    buf = torch.empty((5, C), dtype=torch.float32, device=y.device)
     M = y.numel() // C
-    check(lib().tri_bn_bwd_finalize(ptr(partial), nblk, C, ptr(count_dev), 0, ptr(gamma), ptr(co.mean), ptr(co.invstd), ptr(buf[0]),
-                                    ptr(buf[1]), ptr(buf[2]), ptr(buf[3]), ptr(buf[4]), float(out_scale), stream()), "tri_bn_bwd_finalize")
+    buf = _bn_bwd_finalize(partial, nblk, C, count_dev, 0, gamma, co, out_scale)
     check(lib().tri_bn_bwd_apply(ptr(y), ptr(g), ptr(buf[2]), ptr(buf[3]), ptr(buf[4]), ptr(mask), ptr(g), M, C, None, None, None, None,
                                  _abf(y), stream()), "tri_bn_bwd_apply")
     return g, buf[0], buf[1]
@@ -565,9 +622,7 @@ def maxpool_bn_bwd(y, arg, dpool, co: "BNCoeffs", gamma, out_scale: float = 1.0)
     partial = torch.empty((nblk, 2, C), dtype=torch.float32, device=y.device)
     check(lib().tri_maxpool_bn_bwd_reduce(ptr(_act(y)), ptr(arg), ptr(_act(dpool)), N, H, W, C, ptr(partial), ptr(co.scale), ptr(co.shift),
                                           _abf(y), stream()), "tri_maxpool_bn_bwd_reduce")
-    buf = torch.empty((5, C), dtype=torch.float32, device=y.device)
-    check(lib().tri_bn_bwd_finalize(ptr(partial), nblk, C, None, N * H * W, ptr(gamma), ptr(co.mean), ptr(co.invstd), ptr(buf[0]),
-                                    ptr(buf[1]), ptr(buf[2]), ptr(buf[3]), ptr(buf[4]), float(out_scale), stream()), "tri_bn_bwd_finalize")
+    buf = _bn_bwd_finalize(partial, nblk, C, None, N * H * W, gamma, co, out_scale)
     dy = torch.empty_like(y)
     check(lib().tri_maxpool_bn_bwd_apply(ptr(y), ptr(arg), ptr(dpool), N, H, W, C, ptr(buf[2]), ptr(buf[3]), ptr(buf[4]), ptr(co.scale),
                                          ptr(co.shift), ptr(dy), _abf(y), stream()), "tri_maxpool_bn_bwd_apply")
