@@ -24,3 +24,4 @@ for p in f16 bf16; do python tools/conv_layers_bench.py --precision $p 2>&1 | gr
 # keep the merged-back payload small: kernel traces are large, the stats CSVs are what gets committed
 find $O/${tag}_prof_* -name "*kernel_trace.csv" -size +20M -delete
 ls -la $O | tail -30
+python -c "import __graft_entry__ as g; g.smoke()" > $O/${tag}_smoke.txt 2>&1; tail -3 $O/${tag}_smoke.txt
