@@ -1,5 +1,9 @@
 #!/usr/bin/env python
-"""In-kernel stamps of conv_vox0_kernel (library built with -DVOX_PROBE): per-workgroup shader-clock stamps of wave 0 at entry, after the
+"""In-kernel stamps of conv_vox0_kernel.  Needs a PROBE build of the library (the production build carries no stamp code):
+    cd tricolo_amd/csrc && hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-inline-asm -DVOX_PROBE -c conv_vox.hip -o conv_vox.o && \
+    hipcc -shared -fPIC --offload-arch=gfx950 *.o -o ../libtricolo_hip.so        (then `make -B conv_vox.o && make` restores production)
+TRICOLO_VOX_ABL=<bits> in such a build ablates the run loop (1 no MFMA, 2 no stores, 4 no slab loads, 8 no fragment reads, 16 prologue only).
+Output: per-workgroup shader-clock stamps of wave 0 at entry, after the
 mask test, after the slab fill and after the run loop, the number of active runs, and 100 MHz wall-clock start / end."""
 import os, sys
 import numpy as np

@@ -1911,11 +1911,14 @@ static ConvPlan conv_make_plan(int B, int ID, int IH, int IW, int cin, int OD, i
     int kpad = (ntaps * cin + 31) / 32 * 32;
     int bn = conv_bn(cout);
     int blocks = (int)((M + 127) / 128) * (cout / bn);
+    const int blocks_dense = blocks;                                          // the tile-width rule below keeps using the dense count
+    int occ_div = 1;
     if (row_list) {
         // measured occupancies of the voxel levels (synthetic shapes, 32^3 and 64^3 inputs): 13-18 % on 16^3 and finer grids, ~25 % at 8^3,
         // ~45 % at 4^3, ~95 % at 2^3 (coarse levels fill up)
         const int side = OD > OH ? (OD > OW ? OD : OW) : (OH > OW ? OH : OW);
-        blocks = side >= 8 ? (blocks + 3) / 4 : (side >= 4 ? (blocks + 1) / 2 : blocks);
+        occ_div = side >= 8 ? 4 : (side >= 4 ? 2 : 1);
+        blocks = (blocks + occ_div - 1) / occ_div;
     }
     // (round 3: 32-wide output tiles exist too - built for the data gradient of voxel level 1, 64 -> 32 channels, the slowest kernel of
     // the voxel backward on the register-staged gather; measured no faster (config 2: 1.108 against 1.106 ms per step), so they are
@@ -1962,7 +1965,9 @@ static ConvPlan conv_make_plan(int B, int ID, int IH, int IW, int cin, int OD, i
         // profiles/r1/README.md).  Wide tiles are kept for launches that fill the GPU several times over anyway.
         static int narrow = -1;
         if (narrow < 0) { const char* e = getenv("TRICOLO_DMA_BN64"); narrow = e ? atoi(e) : 1024; }
-        if (pl.dma && bn == 128 && blocks < narrow) { pl.bn = 64; blocks *= 2; }
+        // (decided on the DENSE tile count also for row-list launches: 64^3 level 2 - 2,048 dense tiles, 365 live - takes 42 us with
+        // 128-wide tiles against 54 with 64-wide ones; the occupancy discount is for the split-K decision only)
+        if (pl.dma && bn == 128 && blocks_dense < narrow) { pl.bn = 64; blocks *= 2; }
     }
     pl.nunits = pl.dma ? kpad / 64 : kpad / 32;
     int ks = 1;

@@ -10,8 +10,9 @@ the hard-coded 4096 (identical at 64^3, and makes the 32^3 configs of BASELINE.j
 MI355X design: the COO batch is scattered once into a dense channels-last grid + site mask; per level the active sites are
 listed in ascending order (tri_mask_compact) and every SubMConv3d / its data gradient is an implicit GEMM on MFMA over THAT
 row list - executed work = active work, rows of inactive sites are neither computed nor written and no consumer reads them
-(layers small enough to run split-K take the site mask instead: inactive 128-site tiles skipped, inactive rows zeroed);
-BatchNorm statistics come out of the conv epilogue; BN + ReLU + mask + 2^3 max-pool is one HBM pass.  Forward and backward
+(small deep levels run split-K over the list: slab row = list row).  In the 16-bit modes the two finest levels' forwards run the
+BRICK kernels of csrc/conv_vox.hip instead (dense grid + site mask, a brick + halo staged once in LDS, 16-site runs without an
+active site skipped); BatchNorm statistics come out of the conv epilogue; BN + ReLU + mask + 2^3 max-pool is one HBM pass.  Forward and backward
 of the whole tower are ONE autograd node, so a step costs a handful of Python calls and is HIP-graph capturable.
 """
 from __future__ import annotations
