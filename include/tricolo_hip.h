@@ -147,6 +147,29 @@ int tri_conv_wgrad_partial(const TriConvDesc* d, const void* in, const void* dou
                            int act_fmt, float out_scale, const int* row_pos, const int* row_count, TriWgradReduce* pending /* HOST, out */,
                            void* stream);
 int tri_wgrad_reduce_grouped(const TriWgradReduce* pending /* HOST array */, int n, void* stream);
+/* Several layers' partial kernels in ONE launch (16-bit activation storage, dense position ranges).  The launch's resident
+ * workgroups are shared by the jobs, so each layer is cut into fewer, longer splits than alone: the fp32 slab traffic of the step
+ * (splits x Cout x K per layer, written here and re-read by the reduce) shrinks by about the number of jobs.
+ * tri_conv_wgrad_group_info: family 0 = the layer is not groupable (use tri_conv_wgrad_partial), else jobs of equal family may share
+ * a launch; tiles = workgroups per split, steps = 64-position steps (the caller's budget: ~448 workgroups per launch).
+ * tri_conv_wgrad_partial_group: n <= TRI_WGRAD_JOBS_MAX jobs of one family; workspace sized by tri_conv_wgrad_workspace as before;
+ * pending[i] (HOST, out) is job i's reduce descriptor for tri_wgrad_reduce_grouped. */
+#define TRI_WGRAD_JOBS_MAX 6
+typedef struct TriWgradJob {
+    const TriConvDesc* d;
+    const void* in;
+    const void* dout;
+    const void* plan;
+    void* workspace;
+    size_t workspace_bytes;
+    float* dw;
+    long s_co, s_tap, s_ci;
+    int cin_real;
+    float out_scale;
+} TriWgradJob;
+int tri_conv_wgrad_group_info(const TriConvDesc* d, int act_fmt, int* family, int* tiles, int* steps);
+int tri_conv_wgrad_partial_group(const TriWgradJob* jobs /* HOST array */, int n, int act_fmt, TriWgradReduce* pending /* HOST array, out */,
+                                 void* stream);
 
 /* ---- BatchNorm (train-mode statistics, eps / momentum as torch.nn.BatchNorm1d/2d) ----------------------------------
  * Replaces nn.BatchNorm1d over active voxels (sparse_cnn.py:13,18,23,28,33; count from a device counter) and the 20

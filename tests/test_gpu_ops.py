@@ -838,7 +838,7 @@ def test_wgrad_grouped_reduce_is_bitwise_the_per_layer_reduce(store, prec):
     list is cut into two launches) against tri_conv_wgrad layer by layer: same partial kernels, same summation order."""
     names = ("vox_l0", "vox_l1", "stem7x7", "c3x3s1", "c3x3s2", "c1x1s2", "odd14", "linear", "vox_l3")
     cases = [c for c in CONV_CASES if c[0] in names]
-    batch = ops.WgradBatch(torch.device(DEV))
+    batch = ops.WgradBatch(torch.device(DEV), group_jobs=False)   # (shared partial launches cut the layers differently: next test)
     refs, outs = [], []
     for i in range(27):
         case = cases[i % len(cases)]
@@ -865,6 +865,51 @@ def test_wgrad_grouped_reduce_is_bitwise_the_per_layer_reduce(store, prec):
     b2.flush()
     assert len(b2.chunks) == n_chunks and b2.chunks is batch.chunks
     assert torch.equal(o, ops.conv_wgrad(xcl.to(DEV).to(store), dy.to(DEV).to(store), g, wp.to(DEV), prec))
+
+
+WGRAD_JOB_CASES = {
+    # family conv_wgrad_dma_kernel<64,128>: four long 64 -> 64 layers -> 35 steps per split (the plan ring refills) ...
+    "c64_ring": [("j", 48, (1, 32, 32), 64, 64, (1, 3, 3), 1, (0, 1, 1), "torch")] * 4,
+    # ... <128,128>: six layers of one shape (47 steps per split, ring), and a mixed group whose jobs get different split counts
+    "c128_ring": [("j", 96, (1, 16, 16), 128, 128, (1, 3, 3), 1, (0, 1, 1), "torch")] * 6,
+    "mixed": [("j", 6, (1, 16, 16), 128, 128, (1, 3, 3), 1, (0, 1, 1), "torch"), ("j", 6, (1, 16, 16), 128, 256, (1, 3, 3), 2, (0, 1, 1), "torch"),
+              ("j", 6, (1, 8, 8), 256, 256, (1, 3, 3), 1, (0, 1, 1), "torch"), ("j", 6, (1, 16, 16), 128, 256, (1, 1, 1), 2, (0, 0, 0), "torch"),
+              ("j", 5, (1, 4, 4), 512, 512, (1, 3, 3), 1, (0, 1, 1), "torch"), ("j", 5, (1, 4, 4), 512, 512, (1, 3, 3), 1, (0, 1, 1), "torch"),
+              ("j", 5, (1, 4, 4), 512, 512, (1, 3, 3), 1, (0, 1, 1), "torch"), ("j", 5, (1, 4, 4), 512, 512, (1, 3, 3), 1, (0, 1, 1), "torch"),
+              ("j", 7, (1, 32, 32), 64, 64, (1, 3, 3), 1, (0, 1, 1), "torch"), ("j", 3, (1, 8, 8), 64, 64, (1, 3, 3), 1, (0, 1, 1), "torch")],
+}
+
+
+@pytest.mark.parametrize("store,prec", STORE16, ids=STORE16_IDS)
+@pytest.mark.parametrize("group", list(WGRAD_JOB_CASES))
+def test_wgrad_jobs_share_one_partial_launch(group, store, prec):
+    """WgradBatch job queue -> tri_conv_wgrad_partial_group: several layers' partial kernels in ONE launch (fewer, longer splits per
+    layer; gather plan through the LDS ring beyond 16 steps per split), then the grouped reduce.  Integer data: every layer's dW is
+    exactly the reference's whatever the split; the queue launches when the family changes, the tile budget is full or 6 jobs wait."""
+    cases = WGRAD_JOB_CASES[group]
+    batch = ops.WgradBatch(torch.device(DEV), group_jobs=True)
+    outs, refs, launches, queued = [], [], 0, 0
+    for i, case in enumerate(cases):
+        x, w, wp, xcl, g = make_case(case, integer=True, seed=300 + i)
+        fam, tiles, steps = g.wgrad_group(ops._abf(torch.empty(0, dtype=store)))
+        assert fam in (1, 2) and tiles > 0 and steps == (g.B * int(np.prod(g.out_grid)) + 63) // 64
+        dy = ints((g.B, *g.out_grid, g.cout), -2, 2, 700 + i)
+        xr = x.clone().requires_grad_()
+        wr = w.clone().requires_grad_()
+        F.conv3d(xr, wr, stride=case[6], padding=case[7]).backward(cf3(dy))
+        refs.append(wr.grad)
+        before = len(batch.descs)
+        outs.append(ops.conv_wgrad(xcl.to(DEV).to(store), dy.to(DEV).to(store), g, wp.to(DEV), prec, out_scale=0.5 if i % 2 else 1.0, batch=batch))
+        launches += len(batch.descs) > before
+        queued = max(queued, len(batch.jobs))
+    assert queued > 1 and len(batch.jobs) + len(batch.descs) == len(cases)
+    batch.flush()
+    assert batch.jobs == [] and batch.descs == []
+    torch.cuda.synchronize()
+    if group == "mixed":
+        assert launches >= 2                                       # family changes (128 -> 64 rows of tiles) and the tile budget
+    for i, (o, r) in enumerate(zip(outs, refs)):
+        assert torch.equal(o.cpu(), r * (0.5 if i % 2 else 1.0)), f"job {i}: max abs diff {(o.cpu() - r).abs().max().item()}"
 
 
 @pytest.mark.parametrize("M,B,D,norm", [(3, 32, 512, True), (3, 5, 512, True), (2, 8, 512, True), (3, 300, 512, True), (3, 7, 64, False)],

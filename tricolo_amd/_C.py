@@ -31,6 +31,14 @@ class TriWgradReduce(C.Structure):
                [("out_scale", C.c_float), ("kw_real", C.c_int)]
 
 
+class TriWgradJob(C.Structure):
+    _fields_ = [("d", C.POINTER(TriConvDesc)), ("inp", C.c_void_p), ("dout", C.c_void_p), ("plan", C.c_void_p), ("workspace", C.c_void_p),
+                ("workspace_bytes", C.c_size_t), ("dw", C.c_void_p), ("s_co", C.c_long), ("s_tap", C.c_long), ("s_ci", C.c_long),
+                ("cin_real", C.c_int), ("out_scale", C.c_float)]
+
+
+TRI_WGRAD_JOBS_MAX = 6
+
 P, I, L, F, Z = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
 DP = C.POINTER(TriConvDesc)
 
@@ -62,6 +70,8 @@ SIGNATURES = {
     "tri_conv_wgrad": (I, [DP, P, P, P, P, P, Z, P, L, L, L, I, I, I, F, P, P, P]),
     "tri_conv_wgrad_partial": (I, [DP, P, P, P, P, P, Z, P, L, L, L, I, I, I, F, P, P, P, P]),
     "tri_wgrad_reduce_grouped": (I, [P, I, P]),
+    "tri_conv_wgrad_group_info": (I, [DP, I, P, P, P]),
+    "tri_conv_wgrad_partial_group": (I, [P, I, I, P, P]),
     "tri_bn_finalize": (I, [P, I, I, P, I, P, P, P, P, P, F, F, P, P, P, P, P]),
     "tri_bn_eval_coeffs": (I, [I, P, P, P, P, F, P, P, P, P, P]),
     "tri_bn_act": (I, [P, P, P, P, P, P, P, L, I, I, I, P]),

@@ -10,6 +10,7 @@
 // reproducible, no float atomics) straight into the reference's parameter layout.
 // Submanifold layers pass the output-site mask: 32-position steps with no active site are skipped.
 #include "common.h"
+#include <stdio.h>
 #include <stdlib.h>
 #include "../../include/tricolo_hip.h"
 
@@ -27,6 +28,7 @@ struct WgradArgs {
     int OD, OH, OW, Cout;
     int KD, KH, KW, stride, pd, ph, pw;
     int Kpad, M, ntaps, cin_shift, steps_per_split, ntiles, nsplits;
+    int plan_ring;               // conv_wgrad_dma_kernel: the gather plan is staged through a ring of 2 x 16 steps (any steps_per_split)
     FastDiv dOW, dOH, dOD, dCin;
 #ifdef WGRAD_STAMPS
     long long* dbg;              // tools/probes/wgrad_probe.hip: per-workgroup (id, cycle) stamps of wave 0
@@ -320,8 +322,22 @@ __device__ __forceinline__ int nat_sw(int row) {
     return NCH >= 8 ? ((row & 3) | (((row >> 3) & 1) << 2)) : (((row >> 1) & 1) | (((row >> 3) & 1) << 1));
 }
 
+// Several layers' weight gradients in ONE launch (tri_conv_wgrad_partial_group): the launch's ~448 resident workgroups are shared by
+// the jobs, so each layer is cut into a fraction of the splits it would get alone - the fp32 slab traffic (splits x Cout x K written
+// here, re-read by the reduce) shrinks by the number of jobs, and a workgroup's prologue / slab store is paid once per longer split.
+#define WGRAD_JOBS_MAX 6
+#define WGRAD_RING_STEPS 8                                         // plan ring: 2 chunks of this many 64-position steps (8 KB: two 128x128 workgroups per CU still fit)
+struct WgradJobs {
+    WgradArgs d[WGRAD_JOBS_MAX];
+    int first_block[WGRAD_JOBS_MAX + 1];
+    int n;
+};
 template <int BI, int BJ, typename E>
-__global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs p) {
+__global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradJobs jobs) {
+    int ji = 0;
+    while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.first_block[ji + 1]) ++ji;
+    const WgradArgs& p = jobs.d[ji];
+    const int bid = (int)blockIdx.x - jobs.first_block[ji];
     typedef Mma<E> MM;
     typedef typename MM::v8 v8;
     constexpr int KB = 64;
@@ -334,26 +350,29 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs p) 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* lut = (int*)(smem + 2 * STAGE);
     int* lut_off = lut + 64;
-    int* lplan_off = lut + 128;                                  // [steps_per_split * 64]
-    unsigned* lplan_mask = (unsigned*)lplan_off + p.steps_per_split * KB;
-    int* lrow = (int*)lplan_mask + p.steps_per_split * KB;       // row list launches, see conv_wgrad_kernel
+    constexpr int RING = 2 * WGRAD_RING_STEPS * KB;              // plan entries of the ring form
+    const int pcap = p.plan_ring ? RING : p.steps_per_split * KB;
+    const int pmask = p.plan_ring ? RING - 1 : 0x7fffffff;
+    int* lplan_off = lut + 128;                                  // [steps_per_split * 64], or the ring
+    unsigned* lplan_mask = (unsigned*)lplan_off + pcap;
+    int* lrow = (int*)lplan_mask + pcap;                         // row list launches, see conv_wgrad_kernel
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 #ifdef WGRAD_STAMPS
     int n_stamp = 0;
-    long long* const stl = (long long*)(smem + 2 * STAGE + 512 + p.steps_per_split * (p.row_count ? 768 : 512));
+    long long* const stl = (long long*)(smem + 2 * STAGE + 512 + pcap * (p.row_count ? 12 : 8));
 #endif
     WSTAMP(1);
     const int JT = (p.Kpad + BJ - 1) / BJ;
     const int ntiles = p.ntiles;
     int split, tile;
     if (p.nsplits >= 16) {                                       // XCD pinning, see conv_wgrad_kernel
-        const int grp = blockIdx.x / (8 * ntiles), rem = blockIdx.x - grp * 8 * ntiles;
+        const int grp = bid / (8 * ntiles), rem = bid - grp * 8 * ntiles;
         split = grp * 8 + (rem & 7);
         tile = rem >> 3;
     } else {
-        split = blockIdx.x / ntiles;
-        tile = blockIdx.x - split * ntiles;
+        split = bid / ntiles;
+        tile = bid - split * ntiles;
     }
     if (split >= p.nsplits) return;
     const int it = tile / JT, jt = tile - it * JT;
@@ -375,8 +394,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs p) 
         lut[t] = kd | (kh << 8) | (kw << 16);
         lut_off[t] = ((kd * p.IH + kh) * p.IW + kw) * p.Cin;
     }
+    const int mpad = (p.M + 31) & ~31;
     {
-        const int n = (ks_end - ks_begin) * KB, mpad = (p.M + 31) & ~31;
+        const int n = min((ks_end - ks_begin) * KB, pcap);         // ring form: the first two chunks
         for (int i = t; i < n; i += 256) {
             int m = ks_begin * KB + i;
             if (p.row_count) {
@@ -449,7 +469,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs p) 
         const unsigned xb = lds0 + buf * STAGE;
         const unsigned yb = xb + X_BYTES;
         if (p.row_count) {                                           // dOut rows through the list: one LDS lookup per instruction
-            const int* lr = lrow + (ks - ks_begin) * KB + xrow0;
+            const int* lr = lrow + (((ks - ks_begin) * KB) & pmask) + xrow0;
 #pragma unroll
             for (int i = 0; i < XNI; ++i) {
                 const int m = lr[4 * XRPI * i];
@@ -460,8 +480,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs p) 
 #pragma unroll
             for (int i = 0; i < XNI; ++i) dma16_async(xrsrc, xb + i * 4096, (int)(xbase + i * xstep));
         }
-        const int* po = lplan_off + (ks - ks_begin) * KB + yrow0;
-        const unsigned* pm = lplan_mask + (ks - ks_begin) * KB + yrow0;
+        const int* po = lplan_off + (((ks - ks_begin) * KB) & pmask) + yrow0;
+        const unsigned* pm = lplan_mask + (((ks - ks_begin) * KB) & pmask) + yrow0;
 #pragma unroll
         for (int i = 0; i < YNI; ++i) {
             int ro = po[4 * YRPI * i];
@@ -503,7 +523,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs p) 
             WSTAMP(6);                                                 // barrier
             if (nxt < ks_end) issue(nxt, buf ^ 1);
             WSTAMP(7);                                                 // next stage issued
+            // ring form: in the first step of chunk c (c >= 1) the plan of chunk c + 1 replaces chunk c - 1's (whose last step was
+            // issued two iterations ago); the loads fly under this step's MFMAs, the entries are first read 7 barriers from here
+            const int li = ks - ks_begin;
+            const bool refill = p.plan_ring && li >= WGRAD_RING_STEPS && (li & (WGRAD_RING_STEPS - 1)) == 0;
+            int rpo[RING / 512];
+            unsigned rpm[RING / 512];
+            if (refill) {
+                const int c1 = li / WGRAD_RING_STEPS + 1;
+#pragma unroll
+                for (int u = 0; u < RING / 512; ++u) {
+                    const int m = (ks_begin + c1 * WGRAD_RING_STEPS) * KB + t + 256 * u;
+                    rpo[u] = m < mpad ? p.plan_off[m] : 0;
+                    rpm[u] = m < mpad ? p.plan_mask[m] : 0u;
+                }
+            }
             compute(buf);
+            if (refill) {
+                const int slot = ((li / WGRAD_RING_STEPS + 1) & 1) * (RING / 2);
+#pragma unroll
+                for (int u = 0; u < RING / 512; ++u) { lplan_off[slot + t + 256 * u] = rpo[u]; lplan_mask[slot + t + 256 * u] = rpm[u]; }
+            }
             WSTAMP(8);                                                 // 32 MFMAs
             buf ^= 1;
             ks = nxt;
@@ -1021,24 +1061,46 @@ extern "C" int tri_conv_wgrad_kernel_family(const TriConvDesc* d, int act_fmt) {
     return dma ? 2 : 0;
 }
 
+static inline int wgrad_dma_blocks(const WgradArgs& a) {              // (16+ splits: padded to whole groups of 8 for the XCD pinning)
+    return a.nsplits >= 16 ? ((a.nsplits + 7) / 8) * 8 * a.ntiles : a.nsplits * a.ntiles;
+}
+static inline size_t wgrad_dma_plan_bytes(const WgradArgs& a) {       // gather plan (+ the row list's positions) in LDS
+    const size_t entries = a.plan_ring ? (size_t)2 * WGRAD_RING_STEPS * 64 : (size_t)a.steps_per_split * 64;
+    return entries * (a.row_count ? 12 : 8);
+}
 template <int BI, int BJ, typename E>
-static int launch_wgrad_dma(const WgradArgs& a, int tiles, int splits, hipStream_t stream) {
+static int launch_wgrad_dma_jobs(const WgradArgs* a, int n, hipStream_t stream) {
     constexpr int STAGE = 64 * (BI * 2 + BJ * 2);
-    size_t smem = 2 * STAGE + 512 + (size_t)a.steps_per_split * (a.row_count ? 768 : 512);     // + the list's positions (4 B each)
+    WgradJobs jobs{};
+    size_t plan_bytes = 0;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        jobs.d[i] = a[i];
+#ifdef WGRAD_STAMPS
+        jobs.d[i].dbg = g_wgrad_dbg;
+#endif
+        jobs.first_block[i] = blocks;
+        blocks += wgrad_dma_blocks(a[i]);
+        if (wgrad_dma_plan_bytes(a[i]) > plan_bytes) plan_bytes = wgrad_dma_plan_bytes(a[i]);
+    }
+    jobs.first_block[n] = blocks;
+    jobs.n = n;
+    size_t smem = 2 * STAGE + 512 + plan_bytes;
 #ifdef WGRAD_STAMPS
     smem += 2048;
-    WgradArgs b = a;
-    b.dbg = g_wgrad_dbg;
-#else
-    const WgradArgs& b = a;
 #endif
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel<BI, BJ, E>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE + 512 + 96 * 768 + 2048);
         attr_set = true;
     }
-    conv_wgrad_dma_kernel<BI, BJ, E><<<dim3(((splits + 7) / 8) * 8 * tiles), 256, smem, stream>>>(b);
+    conv_wgrad_dma_kernel<BI, BJ, E><<<dim3(blocks), 256, smem, stream>>>(jobs);
     return tri_check_launch("tri_conv_wgrad(dma)");
+}
+template <int BI, int BJ, typename E>
+static int launch_wgrad_dma(const WgradArgs& a, int tiles, int splits, hipStream_t stream) {
+    (void)tiles; (void)splits;
+    return launch_wgrad_dma_jobs<BI, BJ, E>(&a, 1, stream);
 }
 
 #define WGRAD_MAX_STEPS 96
@@ -1054,6 +1116,51 @@ static int launch_wgrad(const WgradArgs& a, int tiles, int splits, hipStream_t s
     }
     conv_wgrad_kernel<BI, BJ, NSPLIT, AT><<<dim3(((splits + 7) / 8) * 8 * tiles), 256, smem, stream>>>(a);
     return tri_check_launch("tri_conv_wgrad");
+}
+
+// the kernel arguments of one layer (conv_wgrad_kernel / conv_wgrad_dma_kernel) from its descriptor and split plan
+static int wgrad_fill_args(const TriConvDesc* d, const void* in, const void* dout, const uint8_t* row_mask, const void* plan, float* slab,
+                           const int* row_pos, const int* row_count, int split3, int act_fmt, int Kpad, int sps, int tiles, int splits,
+                           WgradArgs* out) {
+    WgradArgs a{};
+    a.in = in; a.dout = dout; a.row_mask = row_mask; a.slab = slab; a.row_pos = row_pos; a.row_count = row_count;
+    a.B = d->B; a.ID = d->ID; a.IH = d->IH; a.IW = d->IW; a.Cin = d->Cin;
+    a.OD = d->OD; a.OH = d->OH; a.OW = d->OW; a.Cout = d->Cout;
+    a.KD = d->KD; a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pd = d->pad_d; a.ph = d->pad_h; a.pw = d->pad_w;
+    a.ntaps = d->KD * d->KH * d->KW;
+    if (a.ntaps > 64) { tri_set_error("wgrad: more than 64 taps unsupported"); return TRI_ERR_UNSUPPORTED; }
+    a.Kpad = Kpad;
+    a.M = d->B * d->OD * d->OH * d->OW;
+    a.cin_shift = ilog2_exact(a.Cin);
+    a.steps_per_split = sps;
+    a.ntiles = tiles;
+    a.nsplits = splits;
+    size_t in_bytes = (size_t)a.B * a.ID * a.IH * a.IW * a.Cin * (act_fmt ? 2 : 4);
+    if (act_fmt && split3) { tri_set_error("wgrad: 16-bit activation storage takes single operands (no 3-product split)"); return TRI_ERR_ARG; }
+    if (!plan) { tri_set_error("wgrad: a gather plan from tri_conv_plan_build is required"); return TRI_ERR_ARG; }
+    if (in_bytes >= ((size_t)1 << 31)) { tri_set_error("wgrad: input tensor >= 2 GiB (32-bit buffer offsets)"); return TRI_ERR_UNSUPPORTED; }
+    {
+        long Mpad = ((long)a.M + 31) / 32 * 32;
+        a.plan_off = (const int*)plan;
+        a.plan_mask = (const unsigned*)plan + Mpad;
+        a.in_bytes = (unsigned)in_bytes;
+    }
+    a.dOW = make_fastdiv(a.OW); a.dOH = make_fastdiv(a.OH); a.dOD = make_fastdiv(a.OD); a.dCin = make_fastdiv(a.Cin);
+    *out = a;
+    return 0;
+}
+// reduce descriptor of a layer whose partial kernel wrote `splits` slabs [Cout][Kpad]
+static void wgrad_fill_pending(const TriConvDesc* d, const float* slab, int splits, int Kpad, float* dw, long s_co, long s_tap, long s_ci,
+                               int cin_real, float out_scale, TriWgradReduce* pending) {
+    const int ntaps = d->KD * d->KH * d->KW;
+    const long quads = (long)d->Cout * ((ntaps * d->Cin) >> 2);
+    int zlanes = 1;
+    while (zlanes < 64 && zlanes * 2 <= splits && quads * zlanes < 262144) zlanes *= 2;
+    const int kq = 256 / zlanes;
+    pending->slab = slab; pending->dw = dw; pending->s_co = s_co; pending->s_tap = s_tap; pending->s_ci = s_ci;
+    pending->splits = splits; pending->Cout = d->Cout; pending->Kpad = Kpad; pending->ntaps = ntaps; pending->cin_stored = d->Cin;
+    pending->cin_real = cin_real; pending->zlanes = zlanes; pending->nblocks = (int)((quads + kq - 1) / kq); pending->out_scale = out_scale;
+    pending->kw_real = 0;
 }
 
 // dw (addressed by element strides s_co / s_tap / s_ci, i.e. directly in the reference's parameter layout)
@@ -1137,29 +1244,10 @@ extern "C" int tri_conv_wgrad_partial(const TriConvDesc* d, const void* in, cons
     wgrad_plan(d, act_fmt, row_count != nullptr, &BI, &BJ, &tiles, &splits, &sps, &Kpad, &dma);
     if (workspace_bytes < (size_t)splits * d->Cout * Kpad * sizeof(float)) { tri_set_error("wgrad: workspace too small"); return TRI_ERR_ARG; }
     WgradArgs a{};
-    a.in = in; a.dout = dout; a.row_mask = row_mask; a.slab = (float*)workspace; a.row_pos = row_pos; a.row_count = row_count;
-    a.B = d->B; a.ID = d->ID; a.IH = d->IH; a.IW = d->IW; a.Cin = d->Cin;
-    a.OD = d->OD; a.OH = d->OH; a.OW = d->OW; a.Cout = d->Cout;
-    a.KD = d->KD; a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pd = d->pad_d; a.ph = d->pad_h; a.pw = d->pad_w;
-    a.ntaps = d->KD * d->KH * d->KW;
-    if (a.ntaps > 64) { tri_set_error("wgrad: more than 64 taps unsupported"); return TRI_ERR_UNSUPPORTED; }
-    a.Kpad = Kpad;
-    a.M = d->B * d->OD * d->OH * d->OW;
-    a.cin_shift = ilog2_exact(a.Cin);
-    a.steps_per_split = sps;
-    a.ntiles = tiles;
-    a.nsplits = splits;
-    size_t in_bytes = (size_t)a.B * a.ID * a.IH * a.IW * a.Cin * (act_fmt ? 2 : 4);
-    if (act_fmt && split3) { tri_set_error("wgrad: 16-bit activation storage takes single operands (no 3-product split)"); return TRI_ERR_ARG; }
-    if (!plan) { tri_set_error("wgrad: a gather plan from tri_conv_plan_build is required"); return TRI_ERR_ARG; }
-    if (in_bytes >= ((size_t)1 << 31)) { tri_set_error("wgrad: input tensor >= 2 GiB (32-bit buffer offsets)"); return TRI_ERR_UNSUPPORTED; }
     {
-        long Mpad = ((long)a.M + 31) / 32 * 32;
-        a.plan_off = (const int*)plan;
-        a.plan_mask = (const unsigned*)plan + Mpad;
-        a.in_bytes = (unsigned)in_bytes;
+        int rc = wgrad_fill_args(d, in, dout, row_mask, plan, (float*)workspace, row_pos, row_count, split3, act_fmt, Kpad, sps, tiles, splits, &a);
+        if (rc) return rc;
     }
-    a.dOW = make_fastdiv(a.OW); a.dOH = make_fastdiv(a.OH); a.dOD = make_fastdiv(a.OD); a.dCin = make_fastdiv(a.Cin);
     hipStream_t s = (hipStream_t)stream;
     int rc;
 #define TRI_WG(BI_, BJ_)                                                                                   \
@@ -1175,14 +1263,88 @@ extern "C" int tri_conv_wgrad_partial(const TriConvDesc* d, const void* in, cons
     else rc = TRI_WG(64, 128);
 #undef TRI_WG
     if (rc) return rc;
-    const long quads = (long)d->Cout * ((a.ntaps * d->Cin) >> 2);
-    int zlanes = 1;
-    while (zlanes < 64 && zlanes * 2 <= splits && quads * zlanes < 262144) zlanes *= 2;
-    const int kq = 256 / zlanes;
-    pending->slab = (const float*)workspace; pending->dw = dw; pending->s_co = s_co; pending->s_tap = s_tap; pending->s_ci = s_ci;
-    pending->splits = splits; pending->Cout = d->Cout; pending->Kpad = Kpad; pending->ntaps = a.ntaps; pending->cin_stored = d->Cin;
-    pending->cin_real = cin_real; pending->zlanes = zlanes; pending->nblocks = (int)((quads + kq - 1) / kq); pending->out_scale = out_scale;
+    wgrad_fill_pending(d, (const float*)workspace, splits, Kpad, dw, s_co, s_tap, s_ci, cin_real, out_scale, pending);
     return 0;
+}
+
+// ---- several layers in one launch
+// family of a layer for grouping: 0 = not groupable (tri_conv_wgrad_partial), 1 = conv_wgrad_dma_kernel<128,128>, 2 = <64,128>;
+// tiles = output tiles (workgroups per split), steps = 64-position steps of the contraction
+extern "C" int tri_conv_wgrad_group_info(const TriConvDesc* d, int act_fmt, int* family, int* tiles, int* steps) {
+    *family = 0; *tiles = 0; *steps = 0;
+    if (!act_fmt || d->Cin % 4 != 0 || d->Cout % 4 != 0) return 0;
+    {
+        C64WgradArgs cg; StemWgradArgs sg; int grid;
+        if (c64_wgrad_geometry(d, act_fmt, &cg, &grid) || stem_wgrad_geometry(d, act_fmt, &sg, &grid)) return 0;
+    }
+    int BI, BJ, t, splits, sps, Kpad, dma;
+    wgrad_plan(d, act_fmt, 0, &BI, &BJ, &t, &splits, &sps, &Kpad, &dma);
+    if (!dma) return 0;
+    *family = BI == 128 ? 1 : 2;
+    *tiles = t;
+    *steps = (int)(((long)d->B * d->OD * d->OH * d->OW + 63) / 64);
+    return 0;
+}
+static int wgrad_group_target(int family) {                     // resident workgroups a grouped launch is planned for
+    // 128x128 tiles (64 KB of stages + the plan ring: two workgroups per CU): all 512 slots; 64x128 tiles: 448 as for single launches
+    // (measured on the bench shape, profiles/r3/NOTES_wgrad.md).  TRICOLO_WGRAD_GROUP_BLOCKS="a,b" overrides (a: 128-row, b: 64-row tiles)
+    static int v[2] = {-1, -1};
+    if (v[0] < 0) {
+        v[0] = 512; v[1] = 448;
+        const char* e = getenv("TRICOLO_WGRAD_GROUP_BLOCKS");
+        if (e) { int a = 0, b = 0; const int k = sscanf(e, "%d,%d", &a, &b); if (k >= 1 && a > 0) v[0] = a; if (k >= 2 && b > 0) v[1] = b; }
+    }
+    return v[family == 1 ? 0 : 1];
+}
+// n <= TRI_WGRAD_JOBS_MAX layers of ONE family (tri_conv_wgrad_group_info), dense position ranges (no row mask / row list), 16-bit
+// activation storage.  Every job gets the splits that make all workgroups of the launch about equally long and never more than it
+// would get alone (so tri_conv_wgrad_workspace still bounds its slab); pending[i] receives job i's reduce descriptor.
+extern "C" int tri_conv_wgrad_partial_group(const TriWgradJob* jobs, int n, int act_fmt, TriWgradReduce* pending, void* stream) {
+    if (n < 1 || n > WGRAD_JOBS_MAX || !jobs || !pending) { tri_set_error("wgrad group: 1..TRI_WGRAD_JOBS_MAX jobs"); return TRI_ERR_ARG; }
+    static_assert(WGRAD_JOBS_MAX == TRI_WGRAD_JOBS_MAX, "header and kernel disagree");
+    WgradArgs a[WGRAD_JOBS_MAX];
+    int fam0 = 0, ind_sps[WGRAD_JOBS_MAX], tiles[WGRAD_JOBS_MAX], steps[WGRAD_JOBS_MAX], Kpads[WGRAD_JOBS_MAX];
+    long total = 0;
+    for (int i = 0; i < n; ++i) {
+        int fam;
+        tri_conv_wgrad_group_info(jobs[i].d, act_fmt, &fam, &tiles[i], &steps[i]);
+        if (!fam || (i && fam != fam0)) { tri_set_error("wgrad group: jobs must share one groupable kernel family"); return TRI_ERR_ARG; }
+        fam0 = fam;
+        int BI, BJ, t, splits, dma;
+        wgrad_plan(jobs[i].d, act_fmt, 0, &BI, &BJ, &t, &splits, &ind_sps[i], &Kpads[i], &dma);
+        total += (long)tiles[i] * steps[i];
+    }
+    // the smallest common split length whose workgroups (tiles x splits over the jobs) all fit the launch's resident slots at once;
+    // a job's own split length is then evened out (ceil(steps / splits)) and never shorter than the one it would get alone
+    const int target = wgrad_group_target(fam0);
+    int common = (int)((total + target - 1) / target);
+    if (common < 1) common = 1;
+    for (;; ++common) {
+        long wgs = 0;
+        for (int i = 0; i < n; ++i) {
+            const int sps = common > ind_sps[i] ? common : ind_sps[i];
+            wgs += (long)tiles[i] * ((steps[i] + sps - 1) / sps);
+        }
+        if (wgs <= target || common >= 4096) break;
+    }
+    for (int i = 0; i < n; ++i) {
+        int sps = n == 1 ? ind_sps[i] : (common > ind_sps[i] ? common : ind_sps[i]);
+        if (sps > steps[i]) sps = steps[i];
+        const int splits = (steps[i] + sps - 1) / sps;
+        if (n > 1) sps = (steps[i] + splits - 1) / splits;
+        const TriConvDesc* d = jobs[i].d;
+        if (jobs[i].workspace_bytes < (size_t)splits * d->Cout * Kpads[i] * sizeof(float)) { tri_set_error("wgrad group: workspace too small"); return TRI_ERR_ARG; }
+        if ((size_t)d->B * d->OD * d->OH * d->OW * d->Cout * 2 >= ((size_t)1 << 31)) { tri_set_error("wgrad: dOut tensor >= 2 GiB (32-bit buffer offsets)"); return TRI_ERR_UNSUPPORTED; }
+        int rc = wgrad_fill_args(d, jobs[i].in, jobs[i].dout, nullptr, jobs[i].plan, (float*)jobs[i].workspace, nullptr, nullptr, 0, act_fmt,
+                                 Kpads[i], sps, tiles[i], splits, &a[i]);
+        if (rc) return rc;
+        a[i].plan_ring = sps > 2 * WGRAD_RING_STEPS ? 1 : 0;
+        wgrad_fill_pending(d, (const float*)jobs[i].workspace, splits, Kpads[i], jobs[i].dw, jobs[i].s_co, jobs[i].s_tap, jobs[i].s_ci,
+                           jobs[i].cin_real, jobs[i].out_scale, &pending[i]);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (act_fmt == TRI_FMT_F16) return fam0 == 1 ? launch_wgrad_dma_jobs<128, 128, f16_t>(a, n, s) : launch_wgrad_dma_jobs<64, 128, f16_t>(a, n, s);
+    return fam0 == 1 ? launch_wgrad_dma_jobs<128, 128, bf16_t>(a, n, s) : launch_wgrad_dma_jobs<64, 128, bf16_t>(a, n, s);
 }
 
 extern "C" int tri_wgrad_reduce_grouped(const TriWgradReduce* pending, int n, void* stream) {

@@ -219,6 +219,16 @@ class ConvGeom:
         row_mask, not a compact row list."""
         return bool(self.kernel_family[(transposed, mode)] >> 16 & 1)
 
+    def wgrad_group(self, fmt: int):
+        """(family, tiles, steps) of this layer's weight gradient for WgradBatch.add_job (tri_conv_wgrad_group_info), cached."""
+        c = self.__dict__.setdefault("_wgrad_group", {})
+        if fmt not in c:
+            fam, tiles, steps = _C.C.c_int(), _C.C.c_int(), _C.C.c_int()
+            check(lib().tri_conv_wgrad_group_info(_C.C.byref(self.desc), fmt, _C.C.byref(fam), _C.C.byref(tiles), _C.C.byref(steps)),
+                  "tri_conv_wgrad_group_info")
+            c[fmt] = (fam.value, tiles.value, steps.value)
+        return c[fmt]
+
     def plan(self, device):
         """Gather plan (built once per geometry and device, reused by every step's wgrad)."""
         pl = self._plans.get(device)
@@ -348,6 +358,10 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
 
 
 _WGRAD_GROUPED = os.environ.get("TRICOLO_WGRAD_GROUPED", "1") != "0"     # A/B switch: one reduce launch per layer instead
+_WGRAD_JOBS = os.environ.get("TRICOLO_WGRAD_JOBS", "1") != "0"           # A/B switch: one partial launch per layer instead
+# output tiles (workgroups per split) one grouped partial launch takes, per kernel family (1: 128-row tiles, 2: 64-row tiles); the
+# library's split planner uses the same figures (TRICOLO_WGRAD_GROUP_BLOCKS)
+_WGRAD_JOB_TILES = dict(zip((1, 2), (int(v) for v in os.environ.get("TRICOLO_WGRAD_JOB_TILES", "512,448").split(","))))
 
 
 class WgradBatch:
@@ -355,16 +369,46 @@ class WgradBatch:
 
     Every conv_wgrad(..., batch=b) launches only the position-split partial kernel, into a slab of its own carved from a
     per-stream arena that persists across steps (so a captured HIP graph replays on the same memory); b.flush() sums all of
-    them in one launch.  The returned dw tensors hold garbage until then: flush before they leave the autograd Function."""
+    them in one launch.  The returned dw tensors hold garbage until then: flush before they leave the autograd Function.
+
+    Layers of one kernel family (tri_conv_wgrad_group_info) are not even launched one by one: their jobs wait here until a launch's
+    worth of output tiles (~448 workgroups) or TRI_WGRAD_JOBS_MAX of them are pending and then share ONE partial launch
+    (tri_conv_wgrad_partial_group) - each layer is cut into fewer, longer splits, so the fp32 slabs the reduce has to re-read
+    shrink by about the number of jobs.  The job keeps x / dout alive until that launch."""
     _arenas = {}
 
-    def __init__(self, device):
+    def __init__(self, device, group_jobs: bool | None = None):
         self.device = device
+        self.group_jobs = _WGRAD_JOBS if group_jobs is None else bool(group_jobs)
         # arenas of a HIP-graph capture are kept apart from the eager ones of the same stream id: a chunk allocated under capture lives
         # in the graph's private pool and must only ever be touched by replays (torch hands stream ids out of a small pool, so an
         # eager step could otherwise land on a capture's arena - ADVICE r2)
         self.chunks = WgradBatch._arenas.setdefault((device, torch.cuda.current_stream().cuda_stream, torch.cuda.is_current_stream_capturing()), [])
         self.ci, self.off, self.descs = 0, 0, []
+        self.jobs, self.job_tiles, self.job_family = [], 0, None
+
+    def add_job(self, family, tiles, job, keep, flops, sym):
+        """Queue one layer's partial kernel (see the class docstring); launches the pending group first when this one does not fit."""
+        if self.jobs and (family != self.job_family or self.job_tiles + tiles > _WGRAD_JOB_TILES[family] or len(self.jobs) == _C.TRI_WGRAD_JOBS_MAX):
+            self.launch_jobs()
+        self.jobs.append((job, keep, flops, sym))
+        self.job_tiles += tiles
+        self.job_family = family
+
+    def launch_jobs(self):
+        n = len(self.jobs)
+        if not n:
+            return
+        arr = (_C.TriWgradJob * n)(*[j[0] for j in self.jobs])
+        pend = (_C.TriWgradReduce * n)()
+        fmt = _abf(self.jobs[0][1][0])
+        check(_timed(self.jobs[0][3], sum(j[2] for j in self.jobs),
+                     lambda: lib().tri_conv_wgrad_partial_group(arr, n, fmt, pend, stream())), "tri_conv_wgrad_partial_group")
+        for i in range(n):
+            d = _C.TriWgradReduce()
+            _C.C.memmove(_C.C.byref(d), _C.C.byref(pend[i]), _C.C.sizeof(d))
+            self.descs.append(d)
+        self.jobs, self.job_tiles, self.job_family = [], 0, None
 
     def slab(self, nbytes: int) -> torch.Tensor:
         nbytes = (nbytes + 255) // 256 * 256
@@ -392,6 +436,7 @@ class WgradBatch:
         WgradBatch._arenas.clear()
 
     def flush(self):
+        self.launch_jobs()
         n = len(self.descs)
         if n:
             arr = (_C.TriWgradReduce * n)(*self.descs)
@@ -422,6 +467,14 @@ def conv_wgrad(x, dout, g: ConvGeom, like: torch.Tensor, precision: str, row_mas
         sym = f"conv_wgrad_dma_kernel<{bi}, {bj}, {_TNAME[x.dtype]}>"
     else:
         sym = f"conv_wgrad_kernel<{bi}, {bj}, {2 if s3 else 1}, {_TNAME[x.dtype]}>"
+    if batch is not None and batch.group_jobs and h16 and rows is None and row_mask is None:
+        fam, tiles, _ = g.wgrad_group(_abf(x))
+        if fam:
+            xa, da = _act(x), _act(dout)
+            job = _C.TriWgradJob(_C.C.pointer(g.desc), ptr(xa), ptr(da), ptr(plan), ptr(ws), ws.numel(), ptr(dw), s_co, s_tap, s_ci, g.cin,
+                                 float(out_scale))
+            batch.add_job(fam, tiles, job, (xa, da, ws, dw, plan), g.flops, sym)
+            return dw
     if batch is not None:
         desc = _C.TriWgradReduce()
         check(_timed(sym, g.flops,
