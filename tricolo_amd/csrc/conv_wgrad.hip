@@ -946,7 +946,10 @@ static void wgrad_plan(const TriConvDesc* d, int act_fmt, int rowlist, int* BI, 
     int ntaps = d->KD * d->KH * d->KW;
     *Kpad = (ntaps * d->Cin + 31) / 32 * 32;
     *BI = (d->Cout % 128 == 0 && *Kpad >= 128) ? 128 : 64;
-    int BJ = *BI == 128 ? 128 : (*Kpad <= 256 ? 256 : 128);
+    // 64-row tiles: K <= 256 is one 256-wide column tile of the register-staged kernel - unless the LDS-DMA kernel can take the
+    // layer (16-bit storage, 8-channel pieces): then 128-wide tiles (layer2's 1x1/2 shortcut: K = 64, 39 -> ~8 us at the bench shape)
+    const bool dma64 = act_fmt && d->Cin % 8 == 0 && d->Cout % 64 == 0 && !wgrad_dma_disabled();
+    int BJ = *BI == 128 ? 128 : ((*Kpad <= 256 && !dma64) ? 256 : 128);
     *BJ_out = BJ;
     int it = (d->Cout + *BI - 1) / *BI, jt = (*Kpad + BJ - 1) / BJ;
     *tiles = it * jt;

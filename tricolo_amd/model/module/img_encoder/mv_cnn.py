@@ -252,7 +252,8 @@ class MVCNNEncoder(TriModule):
                 with torch.cuda.stream(self._side_ds.fork(g, yd)):
                     dyd, gr[blk.downsample[1].weight], gr[blk.downsample[1].bias] = ops.bn_bwd(
                         yd, g, cod, blk.downsample[1].weight, count_host=gd.M, inplace=False, out_scale=ugs)
-                    gr[blk.downsample[0].weight] = ops.conv_wgrad(x, dyd, gd, blk.downsample[0].weight, prec, out_scale=ugs)
+                    if batch is None:
+                        gr[blk.downsample[0].weight] = ops.conv_wgrad(x, dyd, gd, blk.downsample[0].weight, prec, out_scale=ugs)
                     dx = ops.conv_dgrad(dyd, gd, self._packed[(id(blk.downsample[0]), True)])
             wgrad_async(a1, dy2, g2, blk.conv2.weight)
             da1 = ops.conv_dgrad(dy2, g2, self._packed[(id(blk.conv2), True)])
@@ -260,7 +261,11 @@ class MVCNNEncoder(TriModule):
             dy1, gr[blk.bn1.weight], gr[blk.bn1.bias] = ops.bn_bwd(y1, da1, co1, blk.bn1.weight, count_host=g1.M, relu=True, out_scale=ugs)
             wgrad_async(x, dy1, g1, blk.conv1.weight)
             if blk.downsample is not None:
-                self._side_ds.join(dx, gr[blk.downsample[0].weight], gr[blk.downsample[1].weight], gr[blk.downsample[1].bias])
+                if batch is None:
+                    self._side_ds.join(dx, gr[blk.downsample[0].weight], gr[blk.downsample[1].weight], gr[blk.downsample[1].bias])
+                else:                                                          # the shortcut's weight gradient joins the tower's job queue
+                    self._side_ds.join(dx, dyd, gr[blk.downsample[1].weight], gr[blk.downsample[1].bias])
+                    gr[blk.downsample[0].weight] = ops.conv_wgrad(x, dyd, gd, blk.downsample[0].weight, prec, out_scale=ugs, batch=batch)
             else:
                 dx = g                                                         # identity branch
             dx = ops.conv_dgrad(dy1, g1, self._packed[(id(blk.conv1), True)], out=dx, accumulate=True)

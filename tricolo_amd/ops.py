@@ -385,30 +385,37 @@ class WgradBatch:
         # eager step could otherwise land on a capture's arena - ADVICE r2)
         self.chunks = WgradBatch._arenas.setdefault((device, torch.cuda.current_stream().cuda_stream, torch.cuda.is_current_stream_capturing()), [])
         self.ci, self.off, self.descs = 0, 0, []
-        self.jobs, self.job_tiles, self.job_family = [], 0, None
+        self.queues = {}                                          # kernel family -> [pending jobs, their output tiles]
+
+    @property
+    def jobs(self):
+        return [j for q in self.queues.values() for j in q[0]]
 
     def add_job(self, family, tiles, job, keep, flops, sym):
-        """Queue one layer's partial kernel (see the class docstring); launches the pending group first when this one does not fit."""
-        if self.jobs and (family != self.job_family or self.job_tiles + tiles > _WGRAD_JOB_TILES[family] or len(self.jobs) == _C.TRI_WGRAD_JOBS_MAX):
-            self.launch_jobs()
-        self.jobs.append((job, keep, flops, sym))
-        self.job_tiles += tiles
-        self.job_family = family
+        """Queue one layer's partial kernel in its family's queue (see the class docstring); that queue is launched first when this
+        job does not fit beside what is pending."""
+        q = self.queues.setdefault(family, [[], 0])
+        if q[0] and (q[1] + tiles > _WGRAD_JOB_TILES[family] or len(q[0]) == _C.TRI_WGRAD_JOBS_MAX):
+            self.launch_jobs(family)
+            q = self.queues.setdefault(family, [[], 0])
+        q[0].append((job, keep, flops, sym))
+        q[1] += tiles
 
-    def launch_jobs(self):
-        n = len(self.jobs)
-        if not n:
-            return
-        arr = (_C.TriWgradJob * n)(*[j[0] for j in self.jobs])
-        pend = (_C.TriWgradReduce * n)()
-        fmt = _abf(self.jobs[0][1][0])
-        check(_timed(self.jobs[0][3], sum(j[2] for j in self.jobs),
-                     lambda: lib().tri_conv_wgrad_partial_group(arr, n, fmt, pend, stream())), "tri_conv_wgrad_partial_group")
-        for i in range(n):
-            d = _C.TriWgradReduce()
-            _C.C.memmove(_C.C.byref(d), _C.C.byref(pend[i]), _C.C.sizeof(d))
-            self.descs.append(d)
-        self.jobs, self.job_tiles, self.job_family = [], 0, None
+    def launch_jobs(self, family=None):
+        for fam in ([family] if family is not None else sorted(self.queues)):
+            pending = self.queues.pop(fam, [[], 0])[0]
+            n = len(pending)
+            if not n:
+                continue
+            arr = (_C.TriWgradJob * n)(*[j[0] for j in pending])
+            pend = (_C.TriWgradReduce * n)()
+            fmt = _abf(pending[0][1][0])
+            check(_timed(pending[0][3], sum(j[2] for j in pending),
+                         lambda: lib().tri_conv_wgrad_partial_group(arr, n, fmt, pend, stream())), "tri_conv_wgrad_partial_group")
+            for i in range(n):
+                d = _C.TriWgradReduce()
+                _C.C.memmove(_C.C.byref(d), _C.C.byref(pend[i]), _C.C.sizeof(d))
+                self.descs.append(d)
 
     def slab(self, nbytes: int) -> torch.Tensor:
         nbytes = (nbytes + 255) // 256 * 256
@@ -460,8 +467,8 @@ def conv_wgrad(x, dout, g: ConvGeom, like: torch.Tensor, precision: str, row_mas
     plan = g.plan(x.device)
     s_co, s_tap, s_ci = g.strides
     bi = 128 if (g.cout % 128 == 0 and g.kpad >= 128) else 64
-    bj = 128 if bi == 128 else (256 if g.kpad <= 256 else 128)
     h16 = x.dtype != torch.float32
+    bj = 128 if bi == 128 else (256 if (g.kpad <= 256 and not (h16 and g.wgrad_dma)) else 128)
     s3 = 1 if (split3(precision) and not h16) else 0          # fp32 tensors (heads, GRU) take the 3-product split in the f16 mode too
     if h16 and g.wgrad_dma:
         sym = f"conv_wgrad_dma_kernel<{bi}, {bj}, {_TNAME[x.dtype]}>"
