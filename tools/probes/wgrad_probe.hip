@@ -1,6 +1,7 @@
 // In-kernel phase stamps of conv_wgrad_dma_kernel (wave 0 of every workgroup) on the weight gradients of the bench shape's 3x3 layers.
 // Build (cross-compiles here, runs on the GPU box):
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DWGRAD_STAMPS -Iinclude -o tools/probes/build/wgrad_probe tools/probes/wgrad_probe.hip tricolo_amd/csrc/misc.hip tricolo_amd/csrc/conv_igemm.hip
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DWGRAD_STAMPS -Iinclude -o tools/probes/build/wgrad_probe tools/probes/wgrad_probe.hip tricolo_amd/csrc/misc.hip tricolo_amd/csrc/conv_igemm.hip tricolo_amd/csrc/conv_vox.hip
+// Usage: wgrad_probe [images = 192] [jobs = 1]
 // Stamp ids (WSTAMP in conv_wgrad.hip): 2 tap table + gather plan staged, 3 lane constants, then per 64-position step 4 loop top,
 // 5 DMA wait, 6 barrier, 7 next stage issued, 8 32 MFMAs; 9 loop done, 10 slab stored.
 #include "../../tricolo_amd/csrc/conv_wgrad.hip"
@@ -14,6 +15,7 @@ int main(int argc, char** argv) {
     hipMalloc(&g_wgrad_dbg, (size_t)4096 * 256 * 8);
     for (auto l : layers) {
         TriConvDesc d = {B, 1, l.hw, l.hw, l.c, 1, l.hw, l.hw, l.c, 1, 3, 3, 1, 0, 1, 1};
+        const int njobs = argc > 2 ? atoi(argv[2]) : 1;             // > 1: that many copies of the layer in ONE grouped launch
         const size_t M = (size_t)B * l.hw * l.hw, K = 9 * l.c;
         void *in, *dout, *plan, *ws; float* dw;
         hipMalloc(&in, M * l.c * 2); hipMalloc(&dout, M * l.c * 2); hipMalloc(&dw, K * l.c * 4);
@@ -21,13 +23,22 @@ int main(int argc, char** argv) {
         hipMalloc(&plan, tri_conv_plan_bytes(&d));
         tri_conv_plan_build(&d, plan, nullptr);
         const size_t wsb = tri_conv_wgrad_workspace(&d);
-        hipMalloc(&ws, wsb);
+        hipMalloc(&ws, wsb * njobs);
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         float best = 1e9f;
         for (int it = 0; it < 5; ++it) {
             hipMemset(g_wgrad_dbg, 0, (size_t)4096 * 256 * 8);
             hipEventRecord(e0, 0);
-            int rc = tri_conv_wgrad(&d, in, dout, nullptr, plan, ws, wsb, dw, (long)K, 1, 9, l.c, 0, TRI_FMT_F16, 1.0f, nullptr, nullptr, nullptr);
+            int rc;
+            if (njobs > 1) {
+                TriWgradJob jobs[TRI_WGRAD_JOBS_MAX];
+                TriWgradReduce pend[TRI_WGRAD_JOBS_MAX];
+                for (int j = 0; j < njobs; ++j) jobs[j] = TriWgradJob{&d, in, dout, plan, (char*)ws + j * wsb, wsb, dw, (long)K, 1, 9, l.c, 1.0f};
+                rc = tri_conv_wgrad_partial_group(jobs, njobs, TRI_FMT_F16, pend, nullptr);
+                if (!rc) rc = tri_wgrad_reduce_grouped(pend, njobs, nullptr);
+                if (it == 0) printf("   grouped x%d: splits %d per job\n", njobs, pend[0].splits);
+            } else
+            rc = tri_conv_wgrad(&d, in, dout, nullptr, plan, ws, wsb, dw, (long)K, 1, 9, l.c, 0, TRI_FMT_F16, 1.0f, nullptr, nullptr, nullptr);
             hipEventRecord(e1, 0); hipEventSynchronize(e1);
             if (rc) { printf("tri_conv_wgrad: %d %s\n", rc, tri_last_error()); return 1; }
             float ms; hipEventElapsedTime(&ms, e0, e1); best = std::min(best, ms);

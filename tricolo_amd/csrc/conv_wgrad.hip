@@ -332,8 +332,12 @@ struct WgradJobs {
     int first_block[WGRAD_JOBS_MAX + 1];
     int n;
 };
-template <int BI, int BJ, typename E>
-__global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradJobs jobs) {
+// NWI x NWJ waves, each a (BI / NWI) x (BJ / NWJ) = 64 x 64 (32 x 64 for 64-row tiles) block of the tile: 2 x 2 waves for the 128 x 128 and
+// 64 x 128 tiles (two, three workgroups per CU), 4 x 2 for the 256 x 128 tile of the grouped launches (one 512-thread workgroup per CU:
+// a third fewer operand bytes through the LDS-DMA path per FLOP, which is what bounds these kernels - profiles/r3/NOTES_wgrad.md).
+template <int BI, int BJ, typename E, int NWI = 2, int NWJ = 2>
+__global__ __launch_bounds__(NWI * NWJ * 64) void conv_wgrad_dma_kernel(const WgradJobs jobs) {
+    constexpr int NW = NWI * NWJ, NT = NW * 64;
     int ji = 0;
     while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.first_block[ji + 1]) ++ji;
     const WgradArgs& p = jobs.d[ji];
@@ -341,12 +345,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradJobs job
     typedef Mma<E> MM;
     typedef typename MM::v8 v8;
     constexpr int KB = 64;
-    constexpr int WI = BI / 2, WJ = BJ / 2, TM = WI / 16, TN = WJ / 16;
+    constexpr int WI = BI / NWI, WJ = BJ / NWJ, TM = WI / 16, TN = WJ / 16;
     constexpr int XROW = BI * 2, YROW = BJ * 2;
-    static_assert((XROW == 128 || XROW == 256) && (YROW == 128 || YROW == 256), "lane -> chunk map must not depend on the instruction");
     constexpr int X_BYTES = KB * XROW, Y_BYTES = KB * YROW, STAGE = X_BYTES + Y_BYTES;
     constexpr int XRPI = 1024 / XROW, YRPI = 1024 / YROW;        // tile rows per wave-instruction
-    constexpr int XNI = KB / (4 * XRPI), YNI = KB / (4 * YRPI);  // instructions per wave per step
+    constexpr int XNI = KB / (NW * XRPI), YNI = KB / (NW * YRPI);  // instructions per wave per step
+    // a lane's chunk swizzle depends on (row & 3) and bit 3 of its row: the rows of its successive instructions must differ by 16s
+    static_assert((NW * XRPI) % 16 == 0 && (NW * YRPI) % 16 == 0 && XNI >= 1 && YNI >= 1, "lane -> chunk map must not depend on the instruction");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* lut = (int*)(smem + 2 * STAGE);
     int* lut_off = lut + 64;
@@ -397,7 +402,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradJobs job
     const int mpad = (p.M + 31) & ~31;
     {
         const int n = min((ks_end - ks_begin) * KB, pcap);         // ring form: the first two chunks
-        for (int i = t; i < n; i += 256) {
+        for (int i = t; i < n; i += NT) {
             int m = ks_begin * KB + i;
             if (p.row_count) {
                 m = m < nrows ? p.row_pos[m] : -1;
@@ -419,14 +424,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradJobs job
 #pragma unroll
         for (int b = 0; b < TN; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int wi = wave >> 1, wj = wave & 1;
+    const int wi = wave / NWJ, wj = wave % NWJ;
     const int fr = lane & 15, fg = lane >> 4, fqq = fr >> 2, fp = fr & 3;
 
     // X (dOut) lane constants: row inside the instruction, 16-byte source chunk, byte offset of (row, chunk)
     const int xrow0 = wave * XRPI + lane / (XROW / 16), xs = lane % (XROW / 16);
     const int xchunk = ((((xs >> 1) ^ nat_sw<XROW>(xrow0)) & (XROW / 32 - 1)) << 1) | (xs & 1);
     const unsigned xoff = (unsigned)((xrow0 * p.Cout + i0 + xchunk * 8) * 2);
-    const unsigned xstep = (unsigned)(4 * XRPI * p.Cout * 2);   // bytes between the rows of consecutive instructions
+    const unsigned xstep = (unsigned)(NW * XRPI * p.Cout * 2);  // bytes between the rows of consecutive instructions
     // Y (input gather) lane constants
     const int yrow0 = wave * YRPI + lane / (YROW / 16), ys = lane % (YROW / 16);
     const int ychunk = ((((ys >> 1) ^ nat_sw<YROW>(yrow0)) & (YROW / 32 - 1)) << 1) | (ys & 1);
@@ -468,28 +473,36 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradJobs job
     auto issue = [&](int ks, int buf) {
         const unsigned xb = lds0 + buf * STAGE;
         const unsigned yb = xb + X_BYTES;
-        if (p.row_count) {                                           // dOut rows through the list: one LDS lookup per instruction
-            const int* lr = lrow + (((ks - ks_begin) * KB) & pmask) + xrow0;
+        // every LDS lookup of the step first (gather plan, row list), ONE wait, then the DMA pieces back to back: the pieces are
+        // asm volatile statements the compiler orders all memory accesses around, so a lookup placed between two of them costs a
+        // full LDS round trip per piece (measured: ~250 cycles per gathered piece, 1.3 k of a step's 2.9 k cycles)
+        const int pbase = ((ks - ks_begin) * KB) & pmask;
+        int ro[YNI];
+        unsigned rm[YNI];
+#pragma unroll
+        for (int i = 0; i < YNI; ++i) { ro[i] = lplan_off[pbase + yrow0 + NW * YRPI * i]; rm[i] = lplan_mask[pbase + yrow0 + NW * YRPI * i]; }
+        int xo[XNI];
+        if (p.row_count) {                                           // dOut rows through the list
 #pragma unroll
             for (int i = 0; i < XNI; ++i) {
-                const int m = lr[4 * XRPI * i];
-                dma16_async(xrsrc, xb + i * 4096, m >= 0 ? (int)((unsigned)(m * p.Cout + i0 + xchunk * 8) * 2u) : (int)0x80000000);
+                const int m = lrow[pbase + xrow0 + NW * XRPI * i];
+                xo[i] = m >= 0 ? (int)((unsigned)(m * p.Cout + i0 + xchunk * 8) * 2u) : (int)0x80000000;
             }
         } else {
             const unsigned xbase = xoff + (unsigned)(ks * KB) * (unsigned)(p.Cout * 2);
 #pragma unroll
-            for (int i = 0; i < XNI; ++i) dma16_async(xrsrc, xb + i * 4096, (int)(xbase + i * xstep));
+            for (int i = 0; i < XNI; ++i) xo[i] = (int)(xbase + i * xstep);
         }
-        const int* po = lplan_off + (((ks - ks_begin) * KB) & pmask) + yrow0;
-        const unsigned* pm = lplan_mask + (((ks - ks_begin) * KB) & pmask) + yrow0;
+        unsigned yo[YNI];
 #pragma unroll
         for (int i = 0; i < YNI; ++i) {
-            int ro = po[4 * YRPI * i];
-            unsigned rm = pm[4 * YRPI * i];
-            bool ok = y_tv && (((rm >> sx) & (rm >> sy) & (rm >> sz)) & 1u);
-            unsigned voff = ok ? (unsigned)(ro * 2 + y_toff) : 0x80000000u;
-            dma16_async(rsrc, yb + i * 4096, (int)voff);
+            const unsigned live = ((rm[i] >> sx) & (rm[i] >> sy) & (rm[i] >> sz)) & (y_tv ? 1u : 0u);
+            yo[i] = live ? (unsigned)(ro[i] * 2 + y_toff) : 0x80000000u;
         }
+#pragma unroll
+        for (int i = 0; i < XNI; ++i) dma16_async(xrsrc, xb + i * (NW * 1024), xo[i]);
+#pragma unroll
+        for (int i = 0; i < YNI; ++i) dma16_async(rsrc, yb + i * (NW * 1024), (int)yo[i]);
     };
     auto compute = [&](int buf) {
         const char* xb = smem + buf * STAGE;
@@ -527,13 +540,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradJobs job
             // issued two iterations ago); the loads fly under this step's MFMAs, the entries are first read 7 barriers from here
             const int li = ks - ks_begin;
             const bool refill = p.plan_ring && li >= WGRAD_RING_STEPS && (li & (WGRAD_RING_STEPS - 1)) == 0;
-            int rpo[RING / 512];
-            unsigned rpm[RING / 512];
+            constexpr int RPT = RING / 2 / NT;                         // plan entries of one chunk per thread
+            static_assert(RPT >= 1, "ring chunk smaller than the workgroup");
+            int rpo[RPT];
+            unsigned rpm[RPT];
             if (refill) {
                 const int c1 = li / WGRAD_RING_STEPS + 1;
 #pragma unroll
-                for (int u = 0; u < RING / 512; ++u) {
-                    const int m = (ks_begin + c1 * WGRAD_RING_STEPS) * KB + t + 256 * u;
+                for (int u = 0; u < RPT; ++u) {
+                    const int m = (ks_begin + c1 * WGRAD_RING_STEPS) * KB + t + NT * u;
                     rpo[u] = m < mpad ? p.plan_off[m] : 0;
                     rpm[u] = m < mpad ? p.plan_mask[m] : 0u;
                 }
@@ -542,7 +557,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradJobs job
             if (refill) {
                 const int slot = ((li / WGRAD_RING_STEPS + 1) & 1) * (RING / 2);
 #pragma unroll
-                for (int u = 0; u < RING / 512; ++u) { lplan_off[slot + t + 256 * u] = rpo[u]; lplan_mask[slot + t + 256 * u] = rpm[u]; }
+                for (int u = 0; u < RPT; ++u) { lplan_off[slot + t + NT * u] = rpo[u]; lplan_mask[slot + t + NT * u] = rpm[u]; }
             }
             WSTAMP(8);                                                 // 32 MFMAs
             buf ^= 1;
@@ -1071,7 +1086,7 @@ static inline size_t wgrad_dma_plan_bytes(const WgradArgs& a) {       // gather 
     const size_t entries = a.plan_ring ? (size_t)2 * WGRAD_RING_STEPS * 64 : (size_t)a.steps_per_split * 64;
     return entries * (a.row_count ? 12 : 8);
 }
-template <int BI, int BJ, typename E>
+template <int BI, int BJ, typename E, int NWI = 2, int NWJ = 2>
 static int launch_wgrad_dma_jobs(const WgradArgs* a, int n, hipStream_t stream) {
     constexpr int STAGE = 64 * (BI * 2 + BJ * 2);
     WgradJobs jobs{};
@@ -1094,10 +1109,11 @@ static int launch_wgrad_dma_jobs(const WgradArgs* a, int n, hipStream_t stream) 
 #endif
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel<BI, BJ, E>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE + 512 + 96 * 768 + 2048);
+        hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel<BI, BJ, E, NWI, NWJ>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            2 * STAGE + 512 + (NWI * NWJ > 4 ? 16 * 768 : 96 * 768) + 2048);
         attr_set = true;
     }
-    conv_wgrad_dma_kernel<BI, BJ, E><<<dim3(blocks), 256, smem, stream>>>(jobs);
+    conv_wgrad_dma_kernel<BI, BJ, E, NWI, NWJ><<<dim3(blocks), NWI * NWJ * 64, smem, stream>>>(jobs);
     return tri_check_launch("tri_conv_wgrad(dma)");
 }
 template <int BI, int BJ, typename E>
@@ -1270,6 +1286,32 @@ extern "C" int tri_conv_wgrad_partial(const TriConvDesc* d, const void* in, cons
     return 0;
 }
 
+// TRICOLO_WGRAD_WIDE=1: grouped jobs with Cout % 256 == 0 take 256 x 128 tiles (512-thread workgroups, one per CU).  Measured at the
+// bench shape: the launches themselves 0.286 -> 0.266 ms per step, the STEP 3.08 -> 3.12 ms (a 104 KB workgroup per CU leaves the
+// other towers' kernels no room beside it) - so it stays an experiment switch (profiles/r3/NOTES_wgrad.md).
+static bool wgrad_wide_tiles() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("TRICOLO_WGRAD_WIDE"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+static int wgrad_group_target(int family) {                     // resident workgroups a grouped launch is planned for
+    // 128x128 tiles (64 KB of stages + the plan ring: two workgroups per CU): all 512 slots; 64x128 tiles: 448 as for single launches
+    // (measured on the bench shape, profiles/r3/NOTES_wgrad.md).  TRICOLO_WGRAD_GROUP_BLOCKS="a,b" overrides (a: 128-row, b: 64-row tiles)
+    // 256x128 tiles: one 512-thread workgroup per CU.
+    static int v[3] = {-1, -1, -1};
+    if (v[0] < 0) {
+        v[0] = 512; v[1] = 448; v[2] = 256;
+        const char* e = getenv("TRICOLO_WGRAD_GROUP_BLOCKS");
+        if (e) {
+            int a = 0, b = 0, c = 0;
+            const int k = sscanf(e, "%d,%d,%d", &a, &b, &c);
+            if (k >= 1 && a > 0) v[0] = a;
+            if (k >= 2 && b > 0) v[1] = b;
+            if (k >= 3 && c > 0) v[2] = c;
+        }
+    }
+    return v[family >= 1 && family <= 3 ? family - 1 : 1];
+}
 // ---- several layers in one launch
 // family of a layer for grouping: 0 = not groupable (tri_conv_wgrad_partial), 1 = conv_wgrad_dma_kernel<128,128>, 2 = <64,128>;
 // tiles = output tiles (workgroups per split), steps = 64-position steps of the contraction
@@ -1284,20 +1326,13 @@ extern "C" int tri_conv_wgrad_group_info(const TriConvDesc* d, int act_fmt, int*
     wgrad_plan(d, act_fmt, 0, &BI, &BJ, &t, &splits, &sps, &Kpad, &dma);
     if (!dma) return 0;
     *family = BI == 128 ? 1 : 2;
+    if (BI == 128 && d->Cout % 256 == 0 && wgrad_wide_tiles()) {      // 256 x 128 tiles, 512-thread workgroups
+        *family = 3;
+        t = (d->Cout / 256) * ((Kpad + 127) / 128);
+    }
     *tiles = t;
     *steps = (int)(((long)d->B * d->OD * d->OH * d->OW + 63) / 64);
     return 0;
-}
-static int wgrad_group_target(int family) {                     // resident workgroups a grouped launch is planned for
-    // 128x128 tiles (64 KB of stages + the plan ring: two workgroups per CU): all 512 slots; 64x128 tiles: 448 as for single launches
-    // (measured on the bench shape, profiles/r3/NOTES_wgrad.md).  TRICOLO_WGRAD_GROUP_BLOCKS="a,b" overrides (a: 128-row, b: 64-row tiles)
-    static int v[2] = {-1, -1};
-    if (v[0] < 0) {
-        v[0] = 512; v[1] = 448;
-        const char* e = getenv("TRICOLO_WGRAD_GROUP_BLOCKS");
-        if (e) { int a = 0, b = 0; const int k = sscanf(e, "%d,%d", &a, &b); if (k >= 1 && a > 0) v[0] = a; if (k >= 2 && b > 0) v[1] = b; }
-    }
-    return v[family == 1 ? 0 : 1];
 }
 // n <= TRI_WGRAD_JOBS_MAX layers of ONE family (tri_conv_wgrad_group_info), dense position ranges (no row mask / row list), 16-bit
 // activation storage.  Every job gets the splits that make all workgroups of the launch about equally long and never more than it
@@ -1331,10 +1366,10 @@ extern "C" int tri_conv_wgrad_partial_group(const TriWgradJob* jobs, int n, int 
         if (wgs <= target || common >= 4096) break;
     }
     for (int i = 0; i < n; ++i) {
-        int sps = n == 1 ? ind_sps[i] : (common > ind_sps[i] ? common : ind_sps[i]);
+        int sps = (n == 1 && fam0 != 3) ? ind_sps[i] : (common > ind_sps[i] ? common : ind_sps[i]);
         if (sps > steps[i]) sps = steps[i];
         const int splits = (steps[i] + sps - 1) / sps;
-        if (n > 1) sps = (steps[i] + splits - 1) / splits;
+        if (n > 1 || fam0 == 3) sps = (steps[i] + splits - 1) / splits;
         const TriConvDesc* d = jobs[i].d;
         if (jobs[i].workspace_bytes < (size_t)splits * d->Cout * Kpads[i] * sizeof(float)) { tri_set_error("wgrad group: workspace too small"); return TRI_ERR_ARG; }
         if ((size_t)d->B * d->OD * d->OH * d->OW * d->Cout * 2 >= ((size_t)1 << 31)) { tri_set_error("wgrad: dOut tensor >= 2 GiB (32-bit buffer offsets)"); return TRI_ERR_UNSUPPORTED; }
@@ -1346,6 +1381,7 @@ extern "C" int tri_conv_wgrad_partial_group(const TriWgradJob* jobs, int n, int 
                            jobs[i].cin_real, jobs[i].out_scale, &pending[i]);
     }
     hipStream_t s = (hipStream_t)stream;
+    if (fam0 == 3) return act_fmt == TRI_FMT_F16 ? launch_wgrad_dma_jobs<256, 128, f16_t, 4, 2>(a, n, s) : launch_wgrad_dma_jobs<256, 128, bf16_t, 4, 2>(a, n, s);
     if (act_fmt == TRI_FMT_F16) return fam0 == 1 ? launch_wgrad_dma_jobs<128, 128, f16_t>(a, n, s) : launch_wgrad_dma_jobs<64, 128, f16_t>(a, n, s);
     return fam0 == 1 ? launch_wgrad_dma_jobs<128, 128, bf16_t>(a, n, s) : launch_wgrad_dma_jobs<64, 128, bf16_t>(a, n, s);
 }

@@ -359,9 +359,9 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
 
 _WGRAD_GROUPED = os.environ.get("TRICOLO_WGRAD_GROUPED", "1") != "0"     # A/B switch: one reduce launch per layer instead
 _WGRAD_JOBS = os.environ.get("TRICOLO_WGRAD_JOBS", "1") != "0"           # A/B switch: one partial launch per layer instead
-# output tiles (workgroups per split) one grouped partial launch takes, per kernel family (1: 128-row tiles, 2: 64-row tiles); the
+# output tiles (workgroups per split) one grouped partial launch takes, per kernel family (1: 128-row, 2: 64-row, 3: 256-row tiles); the
 # library's split planner uses the same figures (TRICOLO_WGRAD_GROUP_BLOCKS)
-_WGRAD_JOB_TILES = dict(zip((1, 2), (int(v) for v in os.environ.get("TRICOLO_WGRAD_JOB_TILES", "512,448").split(","))))
+_WGRAD_JOB_TILES = dict(zip((1, 2, 3), (int(v) for v in os.environ.get("TRICOLO_WGRAD_JOB_TILES", "512,448,256").split(","))))
 
 
 class WgradBatch:
