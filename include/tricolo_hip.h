@@ -167,6 +167,13 @@ typedef struct TriWgradJob {
     int cin_real;
     float out_scale;
 } TriWgradJob;
+/* Stem weight gradient fused with tri_maxpool_bn_bwd_apply (conv 7x7/2 -> BN -> ReLU -> MaxPool2d(3,2,1), mv_cnn.py:44): dW from the
+ * conv output y, the pool's winning-tap map / pooled gradient and the BatchNorm-backward coefficients; the gradient w.r.t. the conv
+ * output is never stored.  TRI_ERR_UNSUPPORTED when the layer does not run conv_stem_wgrad_kernel (then: apply + tri_conv_wgrad_partial). */
+int tri_conv_stem_wgrad_bn(const TriConvDesc* d, const void* in, const void* y, const uint8_t* arg, const void* dpool, const float* c1,
+                           const float* c2, const float* c3, const float* relu_scale, const float* relu_shift, void* workspace,
+                           size_t workspace_bytes, float* dw, long s_co, long s_tap, long s_ci, int cin_real, int act_fmt, float out_scale,
+                           TriWgradReduce* pending /* HOST, out */, void* stream);
 int tri_conv_wgrad_group_info(const TriConvDesc* d, int act_fmt, int* family, int* tiles, int* steps);
 int tri_conv_wgrad_partial_group(const TriWgradJob* jobs /* HOST array */, int n, int act_fmt, TriWgradReduce* pending /* HOST array, out */,
                                  void* stream);

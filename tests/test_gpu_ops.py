@@ -1000,6 +1000,38 @@ def test_stem_bn_backward_from_the_pooled_gradient(store):
         np.testing.assert_allclose(dg_b.cpu().numpy() * 2, gr.grad.numpy(), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("store,prec", STORE16, ids=STORE16_IDS)
+@pytest.mark.parametrize("N,HW,k", [(5, 64, 7), (3, 32, 7), (2, 32, 3)])
+def test_stem_weight_gradient_with_the_bn_apply_pass_folded_in(N, HW, k, store, prec):
+    """ops.maxpool_bn_bwd_wgrad (tri_conv_stem_wgrad_bn: conv_stem_wgrad_kernel forms dy while it stages its dOut tile) against
+    ops.maxpool_bn_bwd + ops.conv_wgrad on real-valued data: the staging computes exactly the values the apply pass stores (same routing
+    order, roundings and FMA chain), so dW, dgamma and dbeta are bit-identical.  Odd image counts, both stem kernel heights in use."""
+    case = ("stem", N, (1, HW, HW), 3, 64, (1, k, k), 2, (0, k // 2, k // 2), "torch")
+    x, w, wp, xcl, g = make_case(case, integer=False, seed=41)
+    gen = torch.Generator().manual_seed(43)
+    C, H, W = 64, HW // 2, HW // 2                                    # conv output grid
+    y = (torch.randn(N, 1, H, W, C, generator=gen) * 1.5 + 0.2).to(DEV).to(store)
+    gamma, beta = (torch.rand(C, generator=gen) + 0.5).to(DEV), (torch.randn(C, generator=gen) * 0.3).to(DEV)
+    M = N * H * W
+    yf = y.float().view(M, C)
+    stats = torch.stack([yf.double().sum(0).float(), (yf.double() ** 2).sum(0).float()]).view(1, 2, C)
+    co = ops.bn_finalize(stats, C, gamma, beta, None, None, None, count_host=M)
+    pooled, arg = ops.maxpool2d_fwd(y, want_arg=True, bn=co)
+    dpool = torch.randn(pooled.shape, generator=gen).to(DEV).to(store)
+    xd = xcl.to(DEV).to(store)
+    dy, dg_a, db_a = ops.maxpool_bn_bwd(y, arg, dpool, co, gamma, out_scale=0.5)
+    dw_a = ops.conv_wgrad(xd, dy, g, wp.to(DEV), prec, out_scale=0.5)
+    dw_b, dg_b, db_b = ops.maxpool_bn_bwd_wgrad(xd, y, arg, dpool, co, gamma, g, wp.to(DEV), prec, out_scale=0.5)
+    assert torch.equal(dg_a, dg_b) and torch.equal(db_a, db_b)
+    assert torch.equal(dw_a, dw_b), f"max abs diff {(dw_a - dw_b).abs().max().item()} of {dw_a.abs().max().item()}"
+    batch = ops.WgradBatch(torch.device(DEV))                          # and through a batch (deferred reduce)
+    dw_c, _, _ = ops.maxpool_bn_bwd_wgrad(xd, y, arg, dpool, co, gamma, g, wp.to(DEV), prec, out_scale=0.5, batch=batch)
+    batch.flush()
+    assert torch.equal(dw_a, dw_c)
+    ref = torch.nn.grad.conv2d_weight(x[:, :, 0].float(), w[:, :, 0].shape, cf3(dy.float().cpu())[:, :, 0], stride=2, padding=k // 2) * 0.5
+    np.testing.assert_allclose(dw_b.cpu()[:, :, 0].numpy(), ref.numpy(), rtol=2e-2, atol=2e-2 * float(ref.abs().max()))
+
+
 @pytest.mark.parametrize("store,prec", [(torch.float32, "bf16x3"), (torch.float16, "f16"), (torch.bfloat16, "bf16")], ids=["bf16x3", "f16", "bf16"])
 @pytest.mark.parametrize("name", ["vox_l0", "vox_l1", "vox_m64", "vox_l3"])
 def test_conv_wgrad_over_a_compact_row_list(name, store, prec):

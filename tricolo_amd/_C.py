@@ -38,6 +38,7 @@ class TriWgradJob(C.Structure):
 
 
 TRI_WGRAD_JOBS_MAX = 6
+TRI_ERR_ARG, TRI_ERR_UNSUPPORTED = -1, -2                   # common.h
 
 P, I, L, F, Z = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
 DP = C.POINTER(TriConvDesc)
@@ -70,6 +71,7 @@ SIGNATURES = {
     "tri_conv_wgrad": (I, [DP, P, P, P, P, P, Z, P, L, L, L, I, I, I, F, P, P, P]),
     "tri_conv_wgrad_partial": (I, [DP, P, P, P, P, P, Z, P, L, L, L, I, I, I, F, P, P, P, P]),
     "tri_wgrad_reduce_grouped": (I, [P, I, P]),
+    "tri_conv_stem_wgrad_bn": (I, [DP, P, P, P, P, P, P, P, P, P, P, Z, P, L, L, L, I, I, F, P, P]),
     "tri_conv_wgrad_group_info": (I, [DP, I, P, P, P]),
     "tri_conv_wgrad_partial_group": (I, [P, I, I, P, P]),
     "tri_bn_finalize": (I, [P, I, I, P, I, P, P, P, P, P, F, F, P, P, P, P, P]),

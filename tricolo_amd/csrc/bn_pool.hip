@@ -718,8 +718,11 @@ __global__ void stem_bwd_apply_kernel(const T* __restrict__ y, const uchar4* __r
             float4 gv = rnd4<T>(g[k]);
             gv.x = __fmaf_rn(yv.x, s4.x, b4.x) > 0.f ? gv.x : 0.f; gv.y = __fmaf_rn(yv.y, s4.y, b4.y) > 0.f ? gv.y : 0.f;
             gv.z = __fmaf_rn(yv.z, s4.z, b4.z) > 0.f ? gv.z : 0.f; gv.w = __fmaf_rn(yv.w, s4.w, b4.w) > 0.f ? gv.w : 0.f;
-            Act<T>::st4(dy + o, make_float4(a.x * gv.x + b.x + d.x * yv.x, a.y * gv.y + b.y + d.y * yv.y, a.z * gv.z + b.z + d.z * yv.z,
-                                            a.w * gv.w + b.w + d.w * yv.w));
+            // (explicit FMA chain: conv_stem_wgrad_kernel's BNF staging forms the same values, bit for bit - conv_wgrad.hip stem_dy8)
+            Act<T>::st4(dy + o, make_float4(fp32_rounded(__fmaf_rn(d.x, yv.x, __fmaf_rn(a.x, gv.x, b.x))),
+                                            fp32_rounded(__fmaf_rn(d.y, yv.y, __fmaf_rn(a.y, gv.y, b.y))),
+                                            fp32_rounded(__fmaf_rn(d.z, yv.z, __fmaf_rn(a.z, gv.z, b.z))),
+                                            fp32_rounded(__fmaf_rn(d.w, yv.w, __fmaf_rn(a.w, gv.w, b.w)))));
         }
     }
 }

@@ -81,6 +81,13 @@ __device__ __forceinline__ bf16x4 to_bf16x4(const float4& v) {
 #define TRI_FMT_BF16 1
 #define TRI_FMT_F16 2
 #endif
+// The fp32 value as a separately rounded result: without this the compiler may fold an fp32 FMA and the conversion to f16 that
+// follows into one v_fma_mixlo_f16 (ONE rounding of the exact result) in one kernel and not in another that forms the same value -
+// kernels that must agree bit for bit (tri_maxpool_bn_bwd_apply / conv_stem_wgrad_kernel's BNF staging) pin the double rounding.
+__device__ __forceinline__ float fp32_rounded(float x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
 template <typename T> struct Act;
 template <> struct Act<float> {
     static constexpr int BYTES = 4;

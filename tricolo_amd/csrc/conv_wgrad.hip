@@ -603,9 +603,78 @@ struct StemWgradArgs {
     const void* in; const void* dout; float* slab;
     int B, IH, IW, OH, OW, KW, ph, pw;
     int TH, slab_rows, row_bytes, groups, tiles_per_img, ntiles, h_abl;
+    // BNF instantiation (tri_conv_stem_wgrad_bn): dout is not read - the gradient w.r.t. the conv output is formed while the tile is
+    // staged, from the conv output y, the max-pool's winning-tap map / pooled gradient and the BatchNorm-backward coefficients
+    const void* y; const uint8_t* arg; const void* dpool;
+    const float *c1, *c2, *c3, *rs, *rb;
 };
+// dy of 8 channels (octet `piece`) of the 2x2 block (bh, bw) of stem output positions = what tri_maxpool_bn_bwd_apply stores there
+// (bn_pool.hip stem_route_2x2 + stem_bwd_apply_kernel: same routing and summation order, same rounding of the routed gradient, same
+// ReLU mask expression, same FMA chain), packed in the storage type: store(k, h, 4 channels) receives channels 4 h .. 4 h + 3 of
+// position (2 bh + k / 2, 2 bw + k % 2).  The block's pixels
+// can only have won in the four windows (bh..bh+1, bw..bw+1): 4 + 8 loads, all issued before the first use.
+// co = [5][64] floats in LDS: c1, c2, c3, relu scale, relu shift.
+template <typename AT, typename STORE>
+__device__ __forceinline__ void stem_dy_block(const StemWgradArgs& p, int img, int bh, int bw, int piece, const float* co, STORE&& store) {
+    const int Ho = p.OH >> 1, Wo = p.OW >> 1;
+    uint4 yr[4], dr[2][2];
+    uint2 ar[2][2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        yr[k] = *(const uint4*)((const AT*)p.y + (((size_t)img * p.OH + 2 * bh + (k >> 1)) * p.OW + 2 * bw + (k & 1)) * 64 + piece * 8);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            ar[u][v] = make_uint2(0xffffffffu, 0xffffffffu);
+            dr[u][v] = make_uint4(0u, 0u, 0u, 0u);
+            if (bh + u < Ho && bw + v < Wo) {
+                const size_t o = (((size_t)img * Ho + bh + u) * Wo + bw + v) * 64 + piece * 8;
+                ar[u][v] = *(const uint2*)(p.arg + o);
+                dr[u][v] = *(const uint4*)((const AT*)p.dpool + o);
+            }
+        }
+    // two halves of four channels, each stored before the next is formed (all eight at once do not fit the kernel's registers)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        AT res[4][4];
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            const int ch = h * 4 + c4;
+            float d[2][2];
+            unsigned a[2][2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    const AT* dp = (const AT*)&dr[u][v];
+                    d[u][v] = (float)dp[ch];
+                    a[u][v] = ((h ? ar[u][v].y : ar[u][v].x) >> (8 * c4)) & 255u;
+                }
+#define TRI_PK(U, V, TAP) (a[U][V] == (TAP) ? d[U][V] : 0.f)
+            float g[4];
+            g[0] = TRI_PK(0, 0, 4u);
+            g[1] = TRI_PK(0, 0, 5u) + TRI_PK(0, 1, 3u);
+            g[2] = TRI_PK(0, 0, 7u) + TRI_PK(1, 0, 1u);
+            g[3] = (TRI_PK(0, 0, 8u) + TRI_PK(0, 1, 6u)) + (TRI_PK(1, 0, 2u) + TRI_PK(1, 1, 0u));
+#undef TRI_PK
+            const float* cc = co + piece * 8 + ch;
+            const float k1 = cc[0], k2 = cc[64], k3 = cc[128], rs = cc[192], rb = cc[256];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float yv = (float)((const AT*)&yr[k])[ch];
+                float gv = Act<AT>::rnd(g[k]);
+                gv = __fmaf_rn(yv, rs, rb) > 0.f ? gv : 0.f;
+                res[k][c4] = (AT)fp32_rounded(__fmaf_rn(k3, yv, __fmaf_rn(k1, gv, k2)));
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) store(k, h, *(const uint2*)res[k]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
 #define STEM_WG_MAXG 8                                             // 32-position groups per tile (2 rows of <= 128 outputs)
-template <int KH, typename AT>
+template <int KH, typename AT, bool BNF = false>
 __global__ __launch_bounds__(256, 2) void conv_stem_wgrad_kernel(const StemWgradArgs p) {
     typedef Mma<typename OpOf<AT>::E> MM;
     typedef typename MM::v8 v8;
@@ -643,6 +712,11 @@ __global__ __launch_bounds__(256, 2) void conv_stem_wgrad_kernel(const StemWgrad
         x_loff[u] = srow * p.row_bytes + (2 * xp + p.pw) * 8;
     }
     for (int i = t * 16; i < slab_bytes; i += 256 * 16) *(uint4*)(slab + i) = make_uint4(0u, 0u, 0u, 0u);   // border chunks stay zero
+    float* const co = (float*)(slab + slab_bytes);                 // BNF: [5][64] BatchNorm-backward / ReLU coefficients
+    if (BNF) {
+        const float* src[5] = {p.c1, p.c2, p.c3, p.rs, p.rb};
+        for (int i = t; i < 5 * 64; i += 256) co[i] = src[i >> 6][i & 63];
+    }
 
     f32x4 acc[PPW][4];
 #pragma unroll
@@ -656,14 +730,25 @@ __global__ __launch_bounds__(256, 2) void conv_stem_wgrad_kernel(const StemWgrad
         {   // dOut tile: position row e / 8, 16-byte piece e % 8
             const char* ysrc = (const char*)p.dout + ((size_t)img * OH + oh0) * OW * 128;
             const int live = min(p.TH, OH - oh0) * OW;             // rows past the image: zeros
+            if (BNF) {                                             // one (2x2 position block, channel octet) per thread and pass; TH == 2
+                const int nitem = (OW >> 1) * 8;
+                for (int e = t; e < nitem; e += 256) {
+                    const int piece = e & 7, bw = e >> 3;
+                    stem_dy_block<AT>(p, img, oh0 >> 1, bw, piece, co, [&](int k, int h, uint2 v) {
+                        const int row = (k >> 1) * OW + 2 * bw + (k & 1);
+                        *(uint2*)(ytile + (row >> 5) * 4096 + nat_off<128>(row & 31, piece * 16 + h * 8)) = v;
+                    });
+                }
+            } else {
 #pragma unroll
-            for (int u = 0; u < YLD; ++u) {
-                const int e = t + u * 256;
-                const int row = e >> 3, piece = e & 7;
-                if (row < npos) {
-                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                    if (row < live) v = *(const uint4*)(ysrc + (size_t)row * 128 + piece * 16);
-                    *(uint4*)(ytile + (row >> 5) * 4096 + nat_off<128>(row & 31, piece * 16)) = v;
+                for (int u = 0; u < YLD; ++u) {
+                    const int e = t + u * 256;
+                    const int row = e >> 3, piece = e & 7;
+                    if (row < npos) {
+                        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                        if (row < live) v = *(const uint4*)(ysrc + (size_t)row * 128 + piece * 16);
+                        *(uint4*)(ytile + (row >> 5) * 4096 + nat_off<128>(row & 31, piece * 16)) = v;
+                    }
                 }
             }
             const int iy0 = oh0 * 2 - p.ph;
@@ -1182,6 +1267,65 @@ static void wgrad_fill_pending(const TriConvDesc* d, const float* slab, int spli
     pending->kw_real = 0;
 }
 
+// launch of conv_stem_wgrad_kernel (sg.y != NULL: the BNF instantiation) + the reduce descriptor of its per-workgroup slabs
+static int stem_wgrad_launch(const TriConvDesc* d, StemWgradArgs& sg, int grid, void* workspace, size_t workspace_bytes, float* dw, long s_co,
+                             long s_tap, long s_ci, int cin_real, int act_fmt, float out_scale, TriWgradReduce* pending, void* stream) {
+    const size_t need = (size_t)grid * 64 * d->KH * 32 * sizeof(float);
+    if (workspace_bytes < need) { tri_set_error("wgrad(stem): workspace too small"); return TRI_ERR_ARG; }
+    sg.slab = (float*)workspace;
+    sg.h_abl = tri_probe_ablation();
+    const bool bnf = sg.y != nullptr;
+    const size_t smem = (size_t)sg.TH * sg.OW * 128 + (size_t)sg.slab_rows * sg.row_bytes + (bnf ? 5 * 64 * sizeof(float) : 0);
+    hipStream_t st = (hipStream_t)stream;
+#define TRI_SWG1(KH_, T_, F_)                                                                                                  \
+    do {                                                                                                                       \
+        static bool attr = false;                                                                                              \
+        if (!attr) {                                                                                                           \
+            hipFuncSetAttribute((const void*)conv_stem_wgrad_kernel<KH_, T_, F_>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
+            attr = true;                                                                                                       \
+        }                                                                                                                      \
+        conv_stem_wgrad_kernel<KH_, T_, F_><<<grid, 256, smem, st>>>(sg);                                                      \
+    } while (0)
+#define TRI_SWG(KH_)                                                                                                           \
+    case KH_:                                                                                                                  \
+        if (act_fmt == TRI_FMT_F16) { if (bnf) TRI_SWG1(KH_, f16_t, true); else TRI_SWG1(KH_, f16_t, false); }                 \
+        else { if (bnf) TRI_SWG1(KH_, bf16_t, true); else TRI_SWG1(KH_, bf16_t, false); }                                      \
+        break;
+    switch (d->KH) { TRI_SWG(7) TRI_SWG(5) TRI_SWG(3) default: break; }
+#undef TRI_SWG
+#undef TRI_SWG1
+    int rc = tri_check_launch("tri_conv_wgrad(stem)");
+    if (rc) return rc;
+    const int ntaps_p = d->KH * 8;
+    const long quads = (long)64 * ntaps_p;
+    int zlanes = 1;
+    while (zlanes < 64 && zlanes * 2 <= grid && quads * zlanes < 262144) zlanes *= 2;
+    const int kq = 256 / zlanes;
+    pending->slab = (const float*)workspace; pending->dw = dw; pending->s_co = s_co; pending->s_tap = s_tap; pending->s_ci = s_ci;
+    pending->splits = grid; pending->Cout = 64; pending->Kpad = d->KH * 32; pending->ntaps = ntaps_p; pending->cin_stored = 4;
+    pending->cin_real = cin_real; pending->zlanes = zlanes; pending->nblocks = (int)((quads + kq - 1) / kq);
+    pending->out_scale = out_scale; pending->kw_real = d->KW;
+    return 0;
+}
+// Weight gradient of the stem conv straight from the BatchNorm-backward inputs (conv -> BN -> ReLU -> MaxPool2d(3, 2, 1), mv_cnn.py:44):
+// the gradient w.r.t. the conv output that tri_maxpool_bn_bwd_apply would store (and this kernel re-read) is formed while the dOut tile
+// is staged.  The stem has no data gradient, so that tensor (100 MB at the bench shape) is never materialised.  y [N,OH,OW,64] conv
+// output, arg / dpool [N,OH/2,OW/2,64] winning-tap map and pooled gradient, c1..c3 from tri_bn_bwd_finalize, relu_scale / relu_shift
+// the forward's BN coefficients.  TRI_ERR_UNSUPPORTED when the layer does not take conv_stem_wgrad_kernel (caller: apply + wgrad).
+extern "C" int tri_conv_stem_wgrad_bn(const TriConvDesc* d, const void* in, const void* y, const uint8_t* arg, const void* dpool, const float* c1,
+                                      const float* c2, const float* c3, const float* relu_scale, const float* relu_shift, void* workspace,
+                                      size_t workspace_bytes, float* dw, long s_co, long s_tap, long s_ci, int cin_real, int act_fmt,
+                                      float out_scale, TriWgradReduce* pending, void* stream) {
+    if (!pending) { tri_set_error("wgrad: pending descriptor is NULL"); return TRI_ERR_ARG; }
+    StemWgradArgs sg; int grid;
+    if (!stem_wgrad_geometry(d, act_fmt, &sg, &grid) || d->OH % 2 || d->OW % 2 || sg.TH != 2 || (sg.slab_rows * sg.row_bytes) % 16) {
+        tri_set_error("tri_conv_stem_wgrad_bn: not a stem-kernel layer with an even output grid"); return TRI_ERR_UNSUPPORTED;
+    }
+    sg.in = in; sg.dout = nullptr;
+    sg.y = y; sg.arg = arg; sg.dpool = dpool; sg.c1 = c1; sg.c2 = c2; sg.c3 = c3; sg.rs = relu_scale; sg.rb = relu_shift;
+    return stem_wgrad_launch(d, sg, grid, workspace, workspace_bytes, dw, s_co, s_tap, s_ci, cin_real, act_fmt, out_scale, pending, stream);
+}
+
 // dw (addressed by element strides s_co / s_tap / s_ci, i.e. directly in the reference's parameter layout)
 //   = sum over positions of dout x im2col(in).  row_mask (optional, per output position, buffer padded to a
 // multiple of 32 bytes) marks live positions; split3 != 0 selects the 3-product bf16 split mode.
@@ -1224,38 +1368,9 @@ extern "C" int tri_conv_wgrad_partial(const TriConvDesc* d, const void* in, cons
     {
         StemWgradArgs sg; int grid;
         if (!row_mask && !row_count && !split3 && stem_wgrad_geometry(d, act_fmt, &sg, &grid)) {
-            const size_t need = (size_t)grid * 64 * d->KH * 32 * sizeof(float);
-            if (workspace_bytes < need) { tri_set_error("wgrad(stem): workspace too small"); return TRI_ERR_ARG; }
-            sg.in = in; sg.dout = dout; sg.slab = (float*)workspace;
-            sg.h_abl = tri_probe_ablation();
-            const size_t smem = (size_t)sg.TH * sg.OW * 128 + (size_t)sg.slab_rows * sg.row_bytes;
-            hipStream_t st = (hipStream_t)stream;
-#define TRI_SWG(KH_)                                                                                                           \
-    case KH_: {                                                                                                                \
-        static bool attr = false;                                                                                              \
-        if (!attr) {                                                                                                           \
-            hipFuncSetAttribute((const void*)conv_stem_wgrad_kernel<KH_, f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);  \
-            hipFuncSetAttribute((const void*)conv_stem_wgrad_kernel<KH_, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
-            attr = true;                                                                                                       \
-        }                                                                                                                      \
-        if (act_fmt == TRI_FMT_F16) conv_stem_wgrad_kernel<KH_, f16_t><<<grid, 256, smem, st>>>(sg);                           \
-        else conv_stem_wgrad_kernel<KH_, bf16_t><<<grid, 256, smem, st>>>(sg);                                                 \
-        break;                                                                                                                 \
-    }
-            switch (d->KH) { TRI_SWG(7) TRI_SWG(5) TRI_SWG(3) default: break; }
-#undef TRI_SWG
-            int rc = tri_check_launch("tri_conv_wgrad(stem)");
-            if (rc) return rc;
-            const int ntaps_p = d->KH * 8;
-            const long quads = (long)64 * ntaps_p;
-            int zlanes = 1;
-            while (zlanes < 64 && zlanes * 2 <= grid && quads * zlanes < 262144) zlanes *= 2;
-            const int kq = 256 / zlanes;
-            pending->slab = (const float*)workspace; pending->dw = dw; pending->s_co = s_co; pending->s_tap = s_tap; pending->s_ci = s_ci;
-            pending->splits = grid; pending->Cout = 64; pending->Kpad = d->KH * 32; pending->ntaps = ntaps_p; pending->cin_stored = 4;
-            pending->cin_real = cin_real; pending->zlanes = zlanes; pending->nblocks = (int)((quads + kq - 1) / kq);
-            pending->out_scale = out_scale; pending->kw_real = d->KW;
-            return 0;
+            sg.in = in; sg.dout = dout;
+            sg.y = nullptr;
+            return stem_wgrad_launch(d, sg, grid, workspace, workspace_bytes, dw, s_co, s_tap, s_ci, cin_real, act_fmt, out_scale, pending, stream);
         }
     }
     if (d->Cin % 4 != 0 || d->Cout % 4 != 0) { tri_set_error("wgrad: channels must be multiples of 4"); return TRI_ERR_ARG; }

@@ -306,7 +306,15 @@ class MVCNNEncoder(TriModule):
         dout = self._backward_blocks(self._blocks()[:self.N_LOWER_BLOCKS], saved["blocks"], dout, gr, prec, ugs, batch)
         x0, y, co, g0, parg = saved["stem"]
         ops.stamp("image.bwd.layer1.end")
-        if y.shape[2] % 2 == 0 and y.shape[3] % 2 == 0 and os.environ.get("TRICOLO_STEM_FUSED", "1") != "0":
+        stem_mode = os.environ.get("TRICOLO_STEM_FUSED", "2")          # A/B: 0 three passes + max-pool backward, 1 BN passes from the pooled gradient
+        if y.shape[2] % 2 == 0 and y.shape[3] % 2 == 0 and stem_mode == "2":
+            # ... and the BatchNorm-backward apply pass inside the weight-gradient kernel's staging: the stem's dy is never stored
+            gr[self.net_1[0].weight], gr[self.net_1[1].weight], gr[self.net_1[1].bias] = ops.maxpool_bn_bwd_wgrad(
+                x0, y, parg, dout, co, self.net_1[1].weight, g0, self.net_1[0].weight, prec, out_scale=ugs, batch=batch)
+            if own and batch is not None:
+                batch.flush()
+            return [gr[p] for p in self._lower_params()]
+        if y.shape[2] % 2 == 0 and y.shape[3] % 2 == 0 and stem_mode != "0":
             # BatchNorm backward straight from the pooled gradient and the winning-tap map: no max-pool backward pass
             dy, gr[self.net_1[1].weight], gr[self.net_1[1].bias] = ops.maxpool_bn_bwd(y, parg, dout, co, self.net_1[1].weight, out_scale=ugs)
         else:

@@ -689,6 +689,42 @@ def maxpool_bn_bwd(y, arg, dpool, co: "BNCoeffs", gamma, out_scale: float = 1.0)
     return dy, buf[0], buf[1]
 
 
+def maxpool_bn_bwd_wgrad(x0, y, arg, dpool, co: "BNCoeffs", gamma, g: "ConvGeom", like, precision: str, out_scale: float = 1.0, batch=None):
+    """Stem backward in three launches: (dw, dgamma, dbeta) of conv -> BN -> ReLU -> MaxPool2d(3, 2, 1) (mv_cnn.py:44).  As maxpool_bn_bwd,
+    but the apply pass is folded into the weight-gradient kernel's operand staging (tri_conv_stem_wgrad_bn): the stem has no data
+    gradient, so the gradient w.r.t. the conv output - 100 MB written and re-read at the bench shape - is never stored.  Falls back to
+    maxpool_bn_bwd + conv_wgrad where the layer does not run the stem kernel."""
+    N, _, H, W, C = y.shape
+    h16 = y.dtype != torch.float32
+    if not (h16 and C == 64 and H % 2 == 0 and W % 2 == 0 and dpool.dtype == y.dtype and _sync_world() == 1):
+        dy, dgamma, dbeta = maxpool_bn_bwd(y, arg, dpool, co, gamma, out_scale=out_scale)
+        return conv_wgrad(x0, dy, g, like, precision, out_scale=out_scale, batch=batch), dgamma, dbeta
+    nblk = lib().tri_maxpool_bn_bwd_num_blocks(N, H, W)
+    partial = torch.empty((nblk, 2, C), dtype=torch.float32, device=y.device)
+    check(lib().tri_maxpool_bn_bwd_reduce(ptr(_act(y)), ptr(arg), ptr(_act(dpool)), N, H, W, C, ptr(partial), ptr(co.scale), ptr(co.shift),
+                                          _abf(y), stream()), "tri_maxpool_bn_bwd_reduce")
+    buf = _bn_bwd_finalize(partial, nblk, C, None, N * H * W, gamma, co, out_scale)
+    dw = torch.empty_like(like)
+    ws = batch.slab(g.wgrad_ws) if batch is not None else _workspace(g.wgrad_ws, y.device)
+    s_co, s_tap, s_ci = g.strides
+    desc = _C.TriWgradReduce()
+    rc = _timed(f"conv_stem_wgrad_kernel<{g.kernel[1]}, {_TNAME[y.dtype]}>", g.flops,
+                lambda: lib().tri_conv_stem_wgrad_bn(_C.C.byref(g.desc), ptr(_act(x0)), ptr(_act(y)), ptr(arg), ptr(_act(dpool)), ptr(buf[2]),
+                                                     ptr(buf[3]), ptr(buf[4]), ptr(co.scale), ptr(co.shift), ptr(ws), ws.numel(), ptr(dw), s_co,
+                                                     s_tap, s_ci, g.cin, _abf(y), float(out_scale), _C.C.byref(desc), stream()))
+    if rc == _C.TRI_ERR_UNSUPPORTED:                               # not a stem-kernel geometry: the two-pass form
+        dy = torch.empty_like(y)
+        check(lib().tri_maxpool_bn_bwd_apply(ptr(y), ptr(arg), ptr(dpool), N, H, W, C, ptr(buf[2]), ptr(buf[3]), ptr(buf[4]), ptr(co.scale),
+                                             ptr(co.shift), ptr(dy), _abf(y), stream()), "tri_maxpool_bn_bwd_apply")
+        return conv_wgrad(x0, dy, g, like, precision, out_scale=out_scale, batch=batch), buf[0], buf[1]
+    check(rc, "tri_conv_stem_wgrad_bn")
+    if batch is not None:
+        batch.descs.append(desc)
+    else:
+        check(lib().tri_wgrad_reduce_grouped(_C.C.byref(desc), 1, stream()), "tri_wgrad_reduce_grouped")
+    return dw, buf[0], buf[1]
+
+
 def maxpool2d_bwd(arg, dout, in_shape):
     N, _, H, W, C = in_shape
     dx = torch.empty(in_shape, dtype=dout.dtype, device=dout.device)
