@@ -147,12 +147,13 @@ int tri_conv_wgrad_partial(const TriConvDesc* d, const void* in, const void* dou
                            int act_fmt, float out_scale, const int* row_pos, const int* row_count, TriWgradReduce* pending /* HOST, out */,
                            void* stream);
 int tri_wgrad_reduce_grouped(const TriWgradReduce* pending /* HOST array */, int n, void* stream);
-/* Several layers' partial kernels in ONE launch (16-bit activation storage, dense position ranges).  The launch's resident
+/* Several layers' partial kernels in ONE launch (16-bit activation storage).  The launch's resident
  * workgroups are shared by the jobs, so each layer is cut into fewer, longer splits than alone: the fp32 slab traffic of the step
  * (splits x Cout x K per layer, written here and re-read by the reduce) shrinks by about the number of jobs.
  * tri_conv_wgrad_group_info: family 0 = the layer is not groupable (use tri_conv_wgrad_partial), else jobs of equal family may share
  * a launch; tiles = workgroups per split, steps = 64-position steps (the caller's budget: ~448 workgroups per launch).
- * tri_conv_wgrad_partial_group: n <= TRI_WGRAD_JOBS_MAX jobs of one family; workspace sized by tri_conv_wgrad_workspace as before;
+ * tri_conv_wgrad_partial_group: n <= TRI_WGRAD_JOBS_MAX jobs of one family (dense position ranges or compact row lists, no row mask);
+ * workspace sized by tri_conv_wgrad_workspace as before;
  * pending[i] (HOST, out) is job i's reduce descriptor for tri_wgrad_reduce_grouped. */
 #define TRI_WGRAD_JOBS_MAX 6
 typedef struct TriWgradJob {
@@ -166,6 +167,8 @@ typedef struct TriWgradJob {
     long s_co, s_tap, s_ci;
     int cin_real;
     float out_scale;
+    const int* row_pos;                /* optional compact list of the output positions to contract over (tri_mask_compact) ... */
+    const int* row_count;              /* ... and its device-side length, as tri_conv_wgrad_partial takes them */
 } TriWgradJob;
 /* Stem weight gradient fused with tri_maxpool_bn_bwd_apply (conv 7x7/2 -> BN -> ReLU -> MaxPool2d(3,2,1), mv_cnn.py:44): dW from the
  * conv output y, the pool's winning-tap map / pooled gradient and the BatchNorm-backward coefficients; the gradient w.r.t. the conv

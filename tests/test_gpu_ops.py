@@ -1063,6 +1063,38 @@ def test_conv_wgrad_over_a_compact_row_list(name, store, prec):
         assert torch.equal(out2, ref)
 
 
+@pytest.mark.parametrize("store,prec", STORE16, ids=STORE16_IDS)
+def test_wgrad_jobs_over_compact_row_lists(store, prec):
+    """Row-list layers (the voxel tower's levels 2-4 and a long level-1-like list) through the job queue: one grouped partial launch per
+    kernel family, each job contracting over its own compact list (device-side lengths, the plan ring refilled from the list for the
+    long one), against the masked single-layer call.  Integer data: exact whatever the split; an empty list gives a zero gradient."""
+    specs = [("l4", 40, (2, 2, 2), 256, 512, 0.9), ("l3", 40, (4, 4, 4), 128, 256, 0.45), ("l2", 40, (8, 8, 8), 64, 128, 0.25),
+             ("l2e", 3, (8, 8, 8), 64, 128, 0.0), ("long", 48, (16, 16, 16), 64, 128, 0.6), ("l1", 24, (16, 16, 16), 32, 64, 0.2)]
+    batch = ops.WgradBatch(torch.device(DEV), group_jobs=True)
+    outs, refs = [], []
+    for i, (name, B, grid, cin, cout, frac) in enumerate(specs):
+        case = (name, B, grid, cin, cout, (3, 3, 3), 1, (1, 1, 1), "spconv")
+        x, w, wp, xcl, g = make_case(case, integer=True, seed=400 + i)
+        M = g.M
+        gen = torch.Generator().manual_seed(450 + i)
+        mask = (torch.rand(M, generator=gen) < frac).to(torch.uint8)
+        mpad = torch.zeros((M + 31) // 32 * 32, dtype=torch.uint8)
+        mpad[:M] = mask
+        dy = (ints((M, cout), -2, 2, 470 + i) * mask[:, None].float()).sign()      # {-1, 0, 1}: sums stay exact over the long list
+        xd, dyd = xcl.sign().to(DEV).to(store), dy.view(B, *g.out_grid, cout).to(DEV).to(store)
+        refs.append(ops.conv_wgrad(xd, dyd, g, wp.to(DEV), prec, row_mask=mpad.to(DEV)))
+        rows = ops.mask_compact(mpad.to(DEV), M)
+        junk = dyd.clone().view(M, -1)
+        junk[(mask == 0).to(DEV)] = 7.0                              # rows of inactive sites are never visited
+        outs.append(ops.conv_wgrad(xd, junk.view(dyd.shape), g, wp.to(DEV), prec, rows=rows, batch=batch))
+    assert len(batch.jobs) + len(batch.descs) == len(specs) and len(batch.jobs) >= 2
+    batch.flush()
+    torch.cuda.synchronize()
+    for (name, *_), o, r in zip(specs, outs, refs):
+        assert torch.equal(o, r), f"{name}: max abs diff {(o - r).abs().max().item()}"
+    assert float(outs[3].abs().max()) == 0.0
+
+
 def _blob_mask(B, V, seed, p_empty=0.3):
     """Site mask [B, V, V, V] of solid blobs (a box and an ellipsoid per sample, like the synthetic voxel grids), some samples empty:
     whole bricks and whole x-runs without an active site, runs cut by a blob boundary, sites on the grid faces."""

@@ -34,7 +34,7 @@ class TriWgradReduce(C.Structure):
 class TriWgradJob(C.Structure):
     _fields_ = [("d", C.POINTER(TriConvDesc)), ("inp", C.c_void_p), ("dout", C.c_void_p), ("plan", C.c_void_p), ("workspace", C.c_void_p),
                 ("workspace_bytes", C.c_size_t), ("dw", C.c_void_p), ("s_co", C.c_long), ("s_tap", C.c_long), ("s_ci", C.c_long),
-                ("cin_real", C.c_int), ("out_scale", C.c_float)]
+                ("cin_real", C.c_int), ("out_scale", C.c_float), ("row_pos", C.c_void_p), ("row_count", C.c_void_p)]
 
 
 TRI_WGRAD_JOBS_MAX = 6

@@ -523,6 +523,11 @@ __global__ __launch_bounds__(NWI * NWJ * 64) void conv_wgrad_dma_kernel(const Wg
 
     int ks = next_live(ks_begin);
     int buf = 0;
+    constexpr int RPT = RING / 2 / NT;                             // plan entries of one ring chunk per thread
+    static_assert(RPT >= 1, "ring chunk smaller than the workgroup");
+    int rrow[RPT];                                                 // row-list launches: the next chunk's positions, fetched one step ahead of their plan entries
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) rrow[u] = -1;
     WSTAMP(3);                                                     // lane constants
     if (ks < ks_end) {
         issue(ks, 0);
@@ -536,28 +541,45 @@ __global__ __launch_bounds__(NWI * NWJ * 64) void conv_wgrad_dma_kernel(const Wg
             WSTAMP(6);                                                 // barrier
             if (nxt < ks_end) issue(nxt, buf ^ 1);
             WSTAMP(7);                                                 // next stage issued
-            // ring form: in the first step of chunk c (c >= 1) the plan of chunk c + 1 replaces chunk c - 1's (whose last step was
-            // issued two iterations ago); the loads fly under this step's MFMAs, the entries are first read 7 barriers from here
+            // ring form: in the first step(s) of chunk c (c >= 1) the plan of chunk c + 1 replaces chunk c - 1's (whose last step was
+            // issued two iterations ago); the loads fly under this step's MFMAs, the entries are first read 6-7 barriers from here
             const int li = ks - ks_begin;
-            const bool refill = p.plan_ring && li >= WGRAD_RING_STEPS && (li & (WGRAD_RING_STEPS - 1)) == 0;
-            constexpr int RPT = RING / 2 / NT;                         // plan entries of one chunk per thread
-            static_assert(RPT >= 1, "ring chunk smaller than the workgroup");
-            int rpo[RPT];
-            unsigned rpm[RPT];
-            if (refill) {
-                const int c1 = li / WGRAD_RING_STEPS + 1;
+            const int lph = li & (WGRAD_RING_STEPS - 1);
+            // row lists: the chunk's positions come from the list (step 0 of the chunk before), their plan entries one step later
+            const bool fetch_rows = p.plan_ring && p.row_count && li >= WGRAD_RING_STEPS && lph == 0;
+            const bool refill = p.plan_ring && li >= WGRAD_RING_STEPS && lph == (p.row_count ? 1 : 0);
+            const int c1 = li / WGRAD_RING_STEPS + 1;
+            if (fetch_rows) {
 #pragma unroll
                 for (int u = 0; u < RPT; ++u) {
                     const int m = (ks_begin + c1 * WGRAD_RING_STEPS) * KB + t + NT * u;
-                    rpo[u] = m < mpad ? p.plan_off[m] : 0;
-                    rpm[u] = m < mpad ? p.plan_mask[m] : 0u;
+                    rrow[u] = m < nrows ? p.row_pos[m] : -1;
+                }
+            }
+            int rpo[RPT];
+            unsigned rpm[RPT];
+            if (refill) {
+#pragma unroll
+                for (int u = 0; u < RPT; ++u) {
+                    if (p.row_count) {
+                        rpo[u] = rrow[u] >= 0 ? p.plan_off[rrow[u]] : 0;
+                        rpm[u] = rrow[u] >= 0 ? p.plan_mask[rrow[u]] : 0u;
+                    } else {
+                        const int m = (ks_begin + c1 * WGRAD_RING_STEPS) * KB + t + NT * u;
+                        rpo[u] = m < mpad ? p.plan_off[m] : 0;
+                        rpm[u] = m < mpad ? p.plan_mask[m] : 0u;
+                    }
                 }
             }
             compute(buf);
             if (refill) {
-                const int slot = ((li / WGRAD_RING_STEPS + 1) & 1) * (RING / 2);
+                const int slot = (c1 & 1) * (RING / 2);
 #pragma unroll
-                for (int u = 0; u < RPT; ++u) { lplan_off[slot + t + NT * u] = rpo[u]; lplan_mask[slot + t + NT * u] = rpm[u]; }
+                for (int u = 0; u < RPT; ++u) {
+                    lplan_off[slot + t + NT * u] = rpo[u];
+                    lplan_mask[slot + t + NT * u] = rpm[u];
+                    if (p.row_count) lrow[slot + t + NT * u] = rrow[u];
+                }
             }
             WSTAMP(8);                                                 // 32 MFMAs
             buf ^= 1;
@@ -1488,8 +1510,9 @@ extern "C" int tri_conv_wgrad_partial_group(const TriWgradJob* jobs, int n, int 
         const TriConvDesc* d = jobs[i].d;
         if (jobs[i].workspace_bytes < (size_t)splits * d->Cout * Kpads[i] * sizeof(float)) { tri_set_error("wgrad group: workspace too small"); return TRI_ERR_ARG; }
         if ((size_t)d->B * d->OD * d->OH * d->OW * d->Cout * 2 >= ((size_t)1 << 31)) { tri_set_error("wgrad: dOut tensor >= 2 GiB (32-bit buffer offsets)"); return TRI_ERR_UNSUPPORTED; }
-        int rc = wgrad_fill_args(d, jobs[i].in, jobs[i].dout, nullptr, jobs[i].plan, (float*)jobs[i].workspace, nullptr, nullptr, 0, act_fmt,
-                                 Kpads[i], sps, tiles[i], splits, &a[i]);
+        if ((jobs[i].row_pos == nullptr) != (jobs[i].row_count == nullptr)) { tri_set_error("wgrad group: row_pos and row_count go together"); return TRI_ERR_ARG; }
+        int rc = wgrad_fill_args(d, jobs[i].in, jobs[i].dout, nullptr, jobs[i].plan, (float*)jobs[i].workspace, jobs[i].row_pos, jobs[i].row_count,
+                                 0, act_fmt, Kpads[i], sps, tiles[i], splits, &a[i]);
         if (rc) return rc;
         a[i].plan_ring = sps > 2 * WGRAD_RING_STEPS ? 1 : 0;
         wgrad_fill_pending(d, (const float*)jobs[i].workspace, splits, Kpads[i], jobs[i].dw, jobs[i].s_co, jobs[i].s_tap, jobs[i].s_ci,

@@ -474,13 +474,13 @@ def conv_wgrad(x, dout, g: ConvGeom, like: torch.Tensor, precision: str, row_mas
         sym = f"conv_wgrad_dma_kernel<{bi}, {bj}, {_TNAME[x.dtype]}>"
     else:
         sym = f"conv_wgrad_kernel<{bi}, {bj}, {2 if s3 else 1}, {_TNAME[x.dtype]}>"
-    if batch is not None and batch.group_jobs and h16 and rows is None and row_mask is None:
+    if batch is not None and batch.group_jobs and h16 and row_mask is None:
         fam, tiles, _ = g.wgrad_group(_abf(x))
         if fam:
             xa, da = _act(x), _act(dout)
             job = _C.TriWgradJob(_C.C.pointer(g.desc), ptr(xa), ptr(da), ptr(plan), ptr(ws), ws.numel(), ptr(dw), s_co, s_tap, s_ci, g.cin,
-                                 float(out_scale))
-            batch.add_job(fam, tiles, job, (xa, da, ws, dw, plan), g.flops, sym)
+                                 float(out_scale), ptr(rows[0]) if rows else None, ptr(rows[1]) if rows else None)
+            batch.add_job(fam, tiles, job, (xa, da, ws, dw, plan, rows), g.flops, sym)
             return dw
     if batch is not None:
         desc = _C.TriWgradReduce()
