@@ -138,7 +138,8 @@ typedef struct TriWgradReduce {
     const float* slab;
     float* dw;
     long s_co, s_tap, s_ci;
-    int splits, Cout, Kpad, ntaps, cin_stored, cin_real, zlanes, nblocks;
+    int splits, Cout, Kpad, ntaps, cin_stored, cin_real, zlanes, nblocks;   /* zlanes 0: row form (one output channel per block, the
+                                                                               parameter row written as one contiguous run) */
     float out_scale;
     int kw_real;                       /* 0, or (stem kernel's slabs: kernel rows padded to 8 taps) the real kernel width */
 } TriWgradReduce;

@@ -979,10 +979,40 @@ __device__ __forceinline__ void wgrad_reduce_block(const float* __restrict__ sla
         }
     }
 }
+// Row form (descriptor zlanes == 0) for the torchvision parameter layout [co][ci][tap] (s_tap == 1, s_ci == ntaps) with several
+// taps: one output channel per block.  The slab row is in k = (tap, ci) order, the parameter row in (ci, tap) order: written straight
+// from the quads above, every store is four scattered floats, `ntaps` apart - PMC counted 230 MB of writes per step for 54 MB of
+// gradients (partial cache lines, written back more than once).  Here the summed row goes through LDS (tap-major, rows of cin + 1
+// floats: bank = (tap + ci) mod 32) and leaves as ONE contiguous run of K floats.  Splits are summed in order 0, 1, ...
+#define WGRAD_ROW_MAX 4640                                         // floats: 9 taps x (512 + 1)
+__device__ __forceinline__ void wgrad_reduce_row(const float* __restrict__ slab, int splits, int Cout, int Kpad, int ntaps, int cin,
+                                                 float* __restrict__ dw, long s_co, float out_scale, unsigned co, float* rowbuf) {
+    const int K = ntaps * cin, K4 = K >> 2;
+    const size_t zs = (size_t)Cout * Kpad;
+    const float* src = slab + (size_t)co * Kpad;
+    for (int q = threadIdx.x; q < K4; q += 256) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+        for (int z = 0; z < splits; ++z) {
+            const float4 v = *(const float4*)(src + z * zs + q * 4);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        const int k = q * 4, tap = k / cin, ci = k - tap * cin;     // cin % 4 == 0: the quad stays inside one tap
+        float* d = rowbuf + tap * (cin + 1) + ci;
+        d[0] = s.x * out_scale; d[1] = s.y * out_scale; d[2] = s.z * out_scale; d[3] = s.w * out_scale;
+    }
+    __syncthreads();
+    float* out = dw + (size_t)co * s_co;
+    for (int j = threadIdx.x; j < K; j += 256) {
+        const int ci = j / ntaps, tap = j - ci * ntaps;
+        out[j] = rowbuf[tap * (cin + 1) + ci];
+    }
+}
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, int Cout, int Kpad, int ntaps,
                                                            int cin_stored, int cin_real, float* __restrict__ dw, long s_co, long s_tap,
                                                            long s_ci, int zlanes, float out_scale) {
-    __shared__ float4 part[256];
+    __shared__ float4 part[WGRAD_ROW_MAX / 4];
+    if (zlanes == 0) { wgrad_reduce_row(slab, splits, Cout, Kpad, ntaps, cin_stored, dw, s_co, out_scale, blockIdx.x, (float*)part); return; }
     wgrad_reduce_block(slab, splits, Cout, Kpad, ntaps, cin_stored, cin_real, dw, s_co, s_tap, s_ci, zlanes, out_scale, blockIdx.x, part);
 }
 // Grouped form: the reduces of up to TRI_WGRAD_GROUP_MAX layers in ONE launch (their partial kernels ran earlier into per-layer
@@ -993,10 +1023,14 @@ struct WgradGroup {
     int first_block[TRI_WGRAD_GROUP_MAX + 1];
 };
 __global__ __launch_bounds__(256) void wgrad_reduce_grouped_kernel(const WgradGroup g, int n) {
-    __shared__ float4 part[256];
+    __shared__ float4 part[WGRAD_ROW_MAX / 4];
     int i = 0;
     while (i + 1 < n && (int)blockIdx.x >= g.first_block[i + 1]) ++i;
     const TriWgradReduce& r = g.d[i];
+    if (r.zlanes == 0) {
+        wgrad_reduce_row(r.slab, r.splits, r.Cout, r.Kpad, r.ntaps, r.cin_stored, r.dw, r.s_co, r.out_scale, blockIdx.x - g.first_block[i], (float*)part);
+        return;
+    }
     wgrad_reduce_block(r.slab, r.splits, r.Cout, r.Kpad, r.ntaps, r.cin_stored, r.cin_real, r.dw, r.s_co, r.s_tap, r.s_ci, r.zlanes,
                        r.out_scale, blockIdx.x - g.first_block[i], part, r.kw_real);
 }
@@ -1287,6 +1321,14 @@ static void wgrad_fill_pending(const TriConvDesc* d, const float* slab, int spli
     pending->splits = splits; pending->Cout = d->Cout; pending->Kpad = Kpad; pending->ntaps = ntaps; pending->cin_stored = d->Cin;
     pending->cin_real = cin_real; pending->zlanes = zlanes; pending->nblocks = (int)((quads + kq - 1) / kq); pending->out_scale = out_scale;
     pending->kw_real = 0;
+    // torchvision layout with several taps and not too many splits: the row form (wgrad_reduce_row), one output channel per block
+    static int rows = -1;
+    if (rows < 0) { const char* e = getenv("TRICOLO_WGRAD_REDUCE_ROWS"); rows = (e && e[0] == '0') ? 0 : 1; }
+    if (rows && ntaps > 1 && s_tap == 1 && s_ci == ntaps && s_co == (long)ntaps * d->Cin && cin_real == d->Cin && d->Cin % 4 == 0 &&
+        ntaps * (d->Cin + 1) <= WGRAD_ROW_MAX && splits <= 48) {
+        pending->zlanes = 0;
+        pending->nblocks = d->Cout;
+    }
 }
 
 // launch of conv_stem_wgrad_kernel (sg.y != NULL: the BNF instantiation) + the reduce descriptor of its per-workgroup slabs
@@ -1532,7 +1574,7 @@ extern "C" int tri_wgrad_reduce_grouped(const TriWgradReduce* pending, int n, vo
         int blocks = 0;
         for (int i = 0; i < m; ++i) {
             g.d[i] = pending[base + i];
-            if (g.d[i].nblocks <= 0 || g.d[i].zlanes <= 0 || 256 % g.d[i].zlanes) { tri_set_error("wgrad reduce: descriptor not filled by tri_conv_wgrad_partial"); return TRI_ERR_ARG; }
+            if (g.d[i].nblocks <= 0 || g.d[i].zlanes < 0 || (g.d[i].zlanes > 0 && 256 % g.d[i].zlanes)) { tri_set_error("wgrad reduce: descriptor not filled by tri_conv_wgrad_partial"); return TRI_ERR_ARG; }
             g.first_block[i] = blocks;
             blocks += g.d[i].nblocks;
         }
