@@ -141,7 +141,8 @@ typedef struct TriWgradReduce {
     int splits, Cout, Kpad, ntaps, cin_stored, cin_real, zlanes, nblocks;   /* zlanes 0: row form (one output channel per block, the
                                                                                parameter row written as one contiguous run) */
     float out_scale;
-    int kw_real;                       /* 0, or (stem kernel's slabs: kernel rows padded to 8 taps) the real kernel width */
+    int kw_real;                       /* 0, or (slabs whose kernel rows are padded to 2^kw_shift taps: stem 8, voxel level 0 4) the real kernel width */
+    int kw_shift;
 } TriWgradReduce;
 int tri_conv_wgrad_partial(const TriConvDesc* d, const void* in, const void* dout, const uint8_t* row_mask, const void* plan /* required */,
                            void* workspace, size_t workspace_bytes, float* dw, long s_co, long s_tap, long s_ci, int cin_real, int split3,

@@ -1152,6 +1152,41 @@ def test_voxel_level0_brick_kernel(B, V, store, prec):
 
 
 @pytest.mark.parametrize("store,prec", STORE16, ids=STORE16_IDS)
+@pytest.mark.parametrize("B,V", [(3, 32), (30, 32), (2, 64)])
+def test_voxel_level0_weight_gradient_brick_kernel(B, V, store, prec):
+    """conv_vox0_wgrad_kernel (conv_vox.hip): dW of level 0 (sparse_cnn.py:12, 3 -> 32 channels) contracted over the active sites of
+    the dense grid - both operands read transposed from LDS, kernel rows padded to 4 taps in the per-workgroup slabs (kw_shift = 2 in
+    the reduce).  Integer data: exactly the weight gradient of the masked dense convolution, whatever lies in dOut's inactive rows;
+    B = 30: more bricks than persistent workgroups x 1 ... x 2; with and without a WgradBatch; an all-inactive mask gives zeros."""
+    case = ("vox0", B, (V, V, V), 3, 32, (3, 3, 3), 1, (1, 1, 1), "spconv")
+    x, w, wp, xcl, g = make_case(case, integer=True, seed=171)
+    assert g.wgrad_brick
+    m = _blob_mask(B, V, seed=173)
+    mf = m.float()
+    x = (x * mf[:, None]).sign()
+    xcl = (xcl * mf[..., None]).sign()
+    M = B * V ** 3
+    mask = torch.zeros((M + 31) // 32 * 32, dtype=torch.uint8)
+    mask[:M] = m.reshape(M).to(torch.uint8)
+    dy = ints((B, V, V, V, 32), -1, 1, 175) * mf[..., None]
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    F.conv3d(xr, wr, padding=1).backward(cf3(dy))
+    ref = wr.grad.permute(0, 2, 3, 4, 1).contiguous()               # spconv layout [Cout, kd, kh, kw, Cin]
+    assert float(ref.abs().max()) < 2 ** 24
+    junk = dy.clone().view(M, 32)
+    junk[~m.reshape(M)] = 9.0                                       # rows of inactive sites are never read
+    xd, dyd = xcl.to(DEV).to(store), junk.view(B, V, V, V, 32).to(DEV).to(store)
+    out = ops.conv_wgrad(xd, dyd, g, wp.to(DEV), prec, row_mask=mask.to(DEV), out_scale=0.5)
+    assert torch.equal(out.cpu(), ref * 0.5), f"max abs diff {(out.cpu() - ref * 0.5).abs().max().item()}"
+    batch = ops.WgradBatch(torch.device(DEV))
+    out2 = ops.conv_wgrad(xd, dyd, g, wp.to(DEV), prec, row_mask=mask.to(DEV), batch=batch)
+    batch.flush()
+    assert torch.equal(out2.cpu(), ref)
+    out3 = ops.conv_wgrad(xd, dyd, g, wp.to(DEV), prec, row_mask=torch.zeros_like(mask).to(DEV))
+    assert float(out3.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("store,prec", STORE16, ids=STORE16_IDS)
 @pytest.mark.parametrize("B,V", [(5, 16), (40, 16), (70, 16)])
 def test_voxel_level1_brick_kernel(B, V, store, prec):
     """conv_vox1_kernel (conv_vox.hip): level 1 of the voxel tower (sparse_cnn.py:17, 32 -> 64 channels) - filter bank stationary in

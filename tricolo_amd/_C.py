@@ -28,7 +28,7 @@ class TriPrepDesc(C.Structure):
 class TriWgradReduce(C.Structure):
     _fields_ = [("slab", C.c_void_p), ("dw", C.c_void_p), ("s_co", C.c_long), ("s_tap", C.c_long), ("s_ci", C.c_long)] + \
                [(n, C.c_int) for n in ("splits", "Cout", "Kpad", "ntaps", "cin_stored", "cin_real", "zlanes", "nblocks")] + \
-               [("out_scale", C.c_float), ("kw_real", C.c_int)]
+               [("out_scale", C.c_float), ("kw_real", C.c_int), ("kw_shift", C.c_int)]
 
 
 class TriWgradJob(C.Structure):

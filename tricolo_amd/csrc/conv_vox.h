@@ -12,6 +12,11 @@ bool tri_internal_vox0_geometry(int B, int ID, int IH, int IW, int cin, int OD, 
 int tri_internal_vox0_launch(const TriVox0Geom& g, int B, const void* in, const void* w, int kpad, void* out, const uint8_t* mask, float* stats,
                              int act_fmt, hipStream_t stream);
 
+// level-0 weight gradient (conv_vox0_wgrad_kernel): persistent workgroups of the launch (0: switched off), each writes one fp32 slab [32][144]
+int tri_internal_vox0_wgrad_grid(const TriVox0Geom& g);
+int tri_internal_vox0_wgrad_launch(const TriVox0Geom& g, int grid, int B, const void* in, const void* dout, const uint8_t* mask, float* slab,
+                                   int act_fmt, hipStream_t stream);
+
 struct TriVox1Geom { int V, TY, nbricks, grid; };
 // level 1 of the voxel tower in a 16-bit storage mode (32 -> 64 channels, 3x3x3 / 1 / pad 1 on a 16^3 or 32^3 grid); g->grid = persistent
 // workgroups = BatchNorm records of the launch

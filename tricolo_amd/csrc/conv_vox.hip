@@ -279,6 +279,199 @@ __global__ __launch_bounds__(256, 4) void conv_vox0_kernel(const Vox0Args p) {
 }
 
 
+// ================================================================================================ level 0: weight gradient
+// conv_vox0_wgrad_kernel.  dW[co][kd, kh, kw, ci] = sum over active sites of dOut[site][co] * In[site + tap][ci] for level 0 (3 -> 32
+// channels, sparse_cnn.py:12-14).  Through conv_wgrad_kernel<64,256,1> this is an 8-byte gather per (site, tap) into tiles of which
+// three quarters are padding: 37-65 us at the bench shapes, the slowest MFMA kernel of the voxel tower's backward.  Here - the 3D
+// twin of conv_stem_wgrad_kernel - the brick's input sites are staged once in the forward kernel's LDS slab and BOTH operands are
+// read transposed (ds_read_b64_tr_b16: the contraction index is the SITE):
+//   * contraction groups of 32 x-consecutive sites (two runs); groups without an active site are skipped, dOut rows of inactive sites
+//     are zeroed while the group's [32 sites][32 channels] tile is staged in the wave's own 2 KB of LDS (they may never have been written);
+//   * the A fragments (dOut^T, two 16-channel tiles) come from that tile, the B fragment of kernel row (kd, kh) straight from the slab:
+//     row = site (8 B apart), 16 columns = the 4 channels of sites x - 1 .. x + 2, i.e. taps kw = 0, 1, 2 and one padding tap: 9 kernel
+//     rows x 2 channel tiles = 18 MFMAs per group against 22 transposed reads;
+//   * a persistent workgroup (bricks w, w + G, ...; same rotation as the forward kernel) keeps its 32 x 144 partial sums in registers
+//     (72 per lane) over all its bricks and groups; the four waves' sums are added in wave order through LDS and leave as ONE fp32 slab
+//     [32][9 rows x 4 taps x 4 channels] per workgroup, which tri_wgrad_reduce_grouped sums (kernel rows padded to 4 taps:
+//     TriWgradReduce.kw_real = 3, kw_shift = 2).
+struct Vox0WgradArgs {
+    const void* in;            // [B, V, V, V, 4] 16-bit, zeros at inactive sites
+    const void* dout;          // [B, V, V, V, 32]; rows of inactive sites are not read
+    const uint8_t* mask;       // [B * V^3] site mask, or NULL (every site active)
+    float* slab;               // [grid][32][144]
+    int B, nbricks;
+    unsigned in_bytes;
+};
+typedef short vox_s16x4 __attribute__((ext_vector_type(4)));
+typedef short vox_s16x8 __attribute__((ext_vector_type(8)));
+template <typename V8>
+__device__ __forceinline__ V8 vox_tr_frag(const char* lo_addr, const char* hi_addr) {
+    const vox_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((vox_s16x4 __attribute__((address_space(3)))*)lo_addr);
+    const vox_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((vox_s16x4 __attribute__((address_space(3)))*)hi_addr);
+    const vox_s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(V8, r);
+}
+template <typename AT, int V, int TY>
+__global__ __launch_bounds__(256, 3) void conv_vox0_wgrad_kernel(const Vox0WgradArgs p) {
+    typedef Vox0Cfg<V, TY> C;
+    typedef typename OpOf<AT>::E E;
+    typedef Mma<E> MM;
+    typedef typename MM::v8 v8;
+    constexpr int NG = C::RUNS / 2;                                            // 32-site groups per brick (32 or 64)
+    constexpr int PS = (V / 2) * C::NYB;                                       // bricks per sample
+    static_assert(C::SLAB >= 4 * 6 * 64 * 16, "the slab doubles as the cross-wave reduction buffer");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int fr = lane & 15, fg = lane >> 4, fqq = fr >> 2, fp = fr & 3;
+    char* const slab = smem;
+    uint8_t* const lmask = (uint8_t*)(smem + C::SLAB);                         // [RUNS][16 sites]
+    char* const ytile = (char*)(lmask + C::RUNS * 16) + wave * 2048;           // this wave's [32 sites][32 channels] dOut tile
+    const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+
+    f32x4 acc[9][2];
+#pragma unroll
+    for (int kk = 0; kk < 9; ++kk) { acc[kk][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[kk][1] = acc[kk][0]; }
+    // lane constants: dOut tile pieces this lane stages (site e >> 2, 16-byte part e & 3 for e = lane, lane + 64; the two 32-byte halves
+    // of a row swap places for rows 8-15 and 24-31, so the two 16-lane groups one LDS cycle serves hit disjoint banks) and fragment rows
+    int ysite[2], ydst[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int e = lane + 64 * u;
+        ysite[u] = e >> 2;
+        ydst[u] = (e >> 2) * 64 + (((((e >> 1) & 1) ^ ((e >> 5) & 1)) << 5) | ((e & 1) << 4));
+    }
+    const int arow_lo = 8 * fg + fqq, arow_hi = arow_lo + 4;
+    int aoff[2][2];                                                            // [channel tile][lo / hi row]
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        aoff[ct][0] = arow_lo * 64 + ((ct ^ ((arow_lo >> 3) & 1)) << 5) + fp * 8;
+        aoff[ct][1] = arow_hi * 64 + ((ct ^ ((arow_hi >> 3) & 1)) << 5) + fp * 8;
+    }
+    const int boff_lo = (arow_lo + fp) * 8, boff_hi = (arow_hi + fp) * 8;      // slab: site row + column quad
+
+#pragma unroll 1
+    for (int bi = blockIdx.x; bi < p.nbricks; bi += gridDim.x) {
+        const int b = bi / PS;
+        const int sp = (bi % PS + b * (PS / 2 + 1)) % PS;
+        const int yb = sp % C::NYB, zp = sp / C::NYB;
+        const int z0 = zp * 2, y0 = yb * TY;
+        __syncthreads();                                                       // the previous brick's reads of lmask / slab are done
+        {
+            uint4 mv = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
+            if (t < C::RUNS && p.mask) mv = *(const uint4*)(p.mask + ((size_t)(b * V + z0 + t / C::HALF) * V + y0) * V + (t % C::HALF) * 16);
+            if (t < C::RUNS) *(uint4*)(lmask + t * 16) = mv;
+        }
+        __syncthreads();
+        unsigned long long mg;                                                 // active groups of the brick
+        {
+            bool any = false;
+            if (lane < NG) {
+                const uint4 ma = *(const uint4*)(lmask + lane * 32), mb = *(const uint4*)(lmask + lane * 32 + 16);
+                any = (ma.x | ma.y | ma.z | ma.w | mb.x | mb.y | mb.z | mb.w) != 0u;
+            }
+            mg = __ballot(any);
+        }
+        if (mg == 0ull) continue;                                              // empty brick (the same answer in every wave)
+        {   // slab fill, as conv_vox0_kernel
+            uint4 pre[C::MAXC];
+            int dst[C::MAXC];
+#pragma unroll
+            for (int u = 0; u < C::MAXC; ++u) {
+                const int c = t + u * 256;
+                const int zz = (c >= C::ITEMS) + (c >= 2 * C::ITEMS) + (c >= 3 * C::ITEMS);
+                const int i = c - zz * C::ITEMS;
+                const int yy = i / C::CPR, ch = i % C::CPR;
+                const int gz = z0 - 1 + zz, gy = y0 - 1 + yy;
+                const bool inside = c < 4 * C::ITEMS;
+                dst[u] = inside ? zz * C::PLANE + yy * C::PITCH + 16 + ch * 16 : -1;
+                const bool ok = inside && (unsigned)gz < (unsigned)V && (unsigned)gy < (unsigned)V;
+                const unsigned voff = ok ? (unsigned)(((((b * V + gz) * V + gy) * V) + 2 * ch) * 8) : 0x80000000u;
+                pre[u] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(irs, voff, 0, 0));
+            }
+            if (t < 4 * (TY + 2)) {
+                const int zz = t / (TY + 2);
+                char* r = slab + zz * C::PLANE + (t - zz * (TY + 2)) * C::PITCH;
+                *(uint2*)(r + 8) = make_uint2(0u, 0u);
+                *(uint2*)(r + 16 + V * 8) = make_uint2(0u, 0u);
+            }
+#pragma unroll
+            for (int u = 0; u < C::MAXC; ++u)
+                if (dst[u] >= 0) *(uint4*)(slab + dst[u]) = pre[u];
+        }
+        // this wave's groups: the active ones whose ordinal is the wave's number modulo 4
+        unsigned long long mine;
+        {
+            const unsigned long long below = (1ull << lane) - 1ull;
+            mine = __ballot(((mg >> lane) & 1ull) && (__popcll(mg & below) & 3) == wave);
+        }
+        __syncthreads();                                                       // slab complete
+
+        auto ybase = [&](int gi) -> const char* {                              // first dOut row of group gi
+            const int r0 = 2 * gi, zl = r0 / C::HALF, idx = r0 % C::HALF, yl = idx / C::RPR, xr = idx % C::RPR;
+            return (const char*)p.dout + ((((size_t)(b * V + z0 + zl) * V + y0 + yl) * V) + xr * 16) * 64;
+        };
+        uint4 ld[2];
+        int cur = mine ? __builtin_ctzll(mine) : -1;
+        if (cur >= 0) {
+            mine &= mine - 1;
+            const char* src = ybase(cur);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) ld[u] = lmask[cur * 32 + ysite[u]] ? *(const uint4*)(src + (lane + 64 * u) * 16) : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll 1
+        while (cur >= 0) {
+            const int nxt = mine ? __builtin_ctzll(mine) : -1;
+            if (nxt >= 0) mine &= mine - 1;
+            __builtin_amdgcn_wave_barrier();                                   // the previous group's fragment reads are issued (in order per wave)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) *(uint4*)(ytile + ydst[u]) = ld[u];
+            if (nxt >= 0) {                                                    // the next group's rows fly under this group's MFMAs
+                const char* src = ybase(nxt);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) ld[u] = lmask[nxt * 32 + ysite[u]] ? *(const uint4*)(src + (lane + 64 * u) * 16) : make_uint4(0u, 0u, 0u, 0u);
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int r0 = 2 * cur, zl = r0 / C::HALF, idx = r0 % C::HALF, yl = idx / C::RPR, xr = idx % C::RPR;
+            const char* sb = slab + zl * C::PLANE + yl * C::PITCH + 8 + xr * 128;   // site x0 - 1 of slab row (zl, yl)
+            v8 af[2];
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) af[ct] = vox_tr_frag<v8>(ytile + aoff[ct][0], ytile + aoff[ct][1]);
+#pragma unroll
+            for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    const char* rb = sb + kd * C::PLANE + kh * C::PITCH;
+                    const v8 bf = vox_tr_frag<v8>(rb + boff_lo, rb + boff_hi);
+                    acc[kd * 3 + kh][0] = MM::mma(af[0], bf, acc[kd * 3 + kh][0]);
+                    acc[kd * 3 + kh][1] = MM::mma(af[1], bf, acc[kd * 3 + kh][1]);
+                }
+            cur = nxt;
+        }
+    }
+
+    // ---- the four waves' sums, added in wave order: three passes of 6 accumulator tiles through the (now idle) slab
+    f32x4* const red = (f32x4*)slab;                                           // [4 waves][6 tiles][64 lanes]
+    float* const out = p.slab + (size_t)blockIdx.x * 32 * 144;
+#pragma unroll
+    for (int pass = 0; pass < 3; ++pass) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) red[(wave * 6 + j * 2 + ct) * 64 + lane] = acc[pass * 3 + j][ct];
+        __syncthreads();
+        for (int e = t; e < 6 * 64; e += 256) {
+            const int tile = e >> 6, ln = e & 63;
+            f32x4 sum = red[(0 * 6 + tile) * 64 + ln];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) sum += red[(w * 6 + tile) * 64 + ln];
+            const int kk = pass * 3 + (tile >> 1), ct = tile & 1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(ct * 16 + (ln >> 4) * 4 + r) * 144 + kk * 16 + (ln & 15)] = sum[r];
+        }
+    }
+}
+
 // ================================================================================================ level 1: 32 -> 64 channels
 // conv_vox1_kernel.  Level 1 through conv_igemm_kernel is a chain of exposed gather latencies (27 k-steps of one tap each, one
 // in flight): 23 us for 171 tiles at the bench shape, 93 us at 64^3 x 64.  Here the filter bank is STATIONARY IN REGISTERS: wave
@@ -528,6 +721,44 @@ int tri_internal_vox0_launch(const TriVox0Geom& g, int B, const void* in, const 
     TRI_VOX0(128, 8)
 #undef TRI_VOX0
     tri_set_error("conv(vox0): brick shape not instantiated");
+    return TRI_ERR_UNSUPPORTED;
+}
+
+template <typename AT, int V, int TY>
+static int vox0_wgrad_launch_t(const Vox0WgradArgs& a, int grid, hipStream_t stream) {
+    typedef Vox0Cfg<V, TY> C;
+    constexpr size_t SMEM = (size_t)C::SLAB + C::RUNS * 16 + 4 * 2048;
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute((const void*)conv_vox0_wgrad_kernel<AT, V, TY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM);
+        attr = true;
+    }
+    conv_vox0_wgrad_kernel<AT, V, TY><<<grid, 256, SMEM, stream>>>(a);
+    return tri_check_launch("tri_conv_wgrad(vox0)");
+}
+// workgroups (= fp32 slabs [32][144]) of the level-0 weight-gradient kernel: persistent, three per CU
+int tri_internal_vox0_wgrad_grid(const TriVox0Geom& g) {
+    static int off = -1;
+    if (off < 0) off = vox_disabled("TRICOLO_NO_VOX0_WGRAD") ? 1 : 0;         // A/B switch: level 0 stays on conv_wgrad_kernel
+    if (off) return 0;
+    const int slots = 3 * tri_internal_num_cus();
+    return g.grid < slots ? g.grid : slots;
+}
+int tri_internal_vox0_wgrad_launch(const TriVox0Geom& g, int grid, int B, const void* in, const void* dout, const uint8_t* mask, float* slab,
+                                   int act_fmt, hipStream_t stream) {
+    Vox0WgradArgs a{};
+    a.in = in; a.dout = dout; a.mask = mask; a.slab = slab;
+    a.B = B; a.nbricks = g.grid;
+    a.in_bytes = (unsigned)((size_t)B * g.V * g.V * g.V * 8);
+#define TRI_VOX0W(V_, TY_)                                                                                         \
+    if (g.V == V_ && g.TY == TY_)                                                                                  \
+        return act_fmt == TRI_FMT_F16 ? vox0_wgrad_launch_t<f16_t, V_, TY_>(a, grid, stream) : vox0_wgrad_launch_t<bf16_t, V_, TY_>(a, grid, stream);
+    TRI_VOX0W(32, 16)
+    TRI_VOX0W(64, 8)
+    TRI_VOX0W(64, 16)
+    TRI_VOX0W(128, 8)
+#undef TRI_VOX0W
+    tri_set_error("conv_wgrad(vox0): brick shape not instantiated");
     return TRI_ERR_UNSUPPORTED;
 }
 

@@ -13,6 +13,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include "../../include/tricolo_hip.h"
+#include "conv_vox.h"
 
 struct WgradArgs {
     const void* in;              // activations / gradients: fp32 or bf16 (kernel template parameter AT)
@@ -937,7 +938,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_c64_kernel(const C64WgradAr
 // and a tiny dW (stem, voxel level 0) still put a few hundred thousand loads in flight.
 __device__ __forceinline__ void wgrad_reduce_block(const float* __restrict__ slab, int splits, int Cout, int Kpad, int ntaps, int cin_stored,
                                                    int cin_real, float* __restrict__ dw, long s_co, long s_tap, long s_ci, int zlanes,
-                                                   float out_scale, unsigned block, float4* part, int kw_real = 0) {
+                                                   float out_scale, unsigned block, float4* part, int kw_real = 0, int kw_shift = 3) {
     const int kq = 256 / zlanes;                                 // quads per block
     const int ql = threadIdx.x % kq, zl = threadIdx.x / kq;
     const int K4 = (ntaps * cin_stored) >> 2;
@@ -964,8 +965,8 @@ __device__ __forceinline__ void wgrad_reduce_block(const float* __restrict__ sla
         s.x *= out_scale; s.y *= out_scale; s.z *= out_scale; s.w *= out_scale;
         int tap = k / cin_stored;
         const int ci = k - tap * cin_stored;                         // cin_stored % 4 == 0: the quad stays inside one tap
-        if (kw_real) {                                               // stem slabs: kernel rows padded to 8 taps (conv_stem_wgrad_kernel)
-            const int kh = tap >> 3, kw = tap & 7;
+        if (kw_real) {                                               // kernel rows padded to 8 (stem) / 4 (voxel level 0) taps in the slabs
+            const int kh = tap >> kw_shift, kw = tap & ((1 << kw_shift) - 1);
             if (kw >= kw_real) return;
             tap = kh * kw_real + kw;
         }
@@ -1032,7 +1033,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_grouped_kernel(const WgradGr
         return;
     }
     wgrad_reduce_block(r.slab, r.splits, r.Cout, r.Kpad, r.ntaps, r.cin_stored, r.cin_real, r.dw, r.s_co, r.s_tap, r.s_ci, r.zlanes,
-                       r.out_scale, blockIdx.x - g.first_block[i], part, r.kw_real);
+                       r.out_scale, blockIdx.x - g.first_block[i], part, r.kw_real, r.kw_shift);
 }
 
 static int ilog2_exact(int v) {
@@ -1203,6 +1204,10 @@ extern "C" size_t tri_conv_wgrad_workspace(const TriConvDesc* d) {
         if (stem_wgrad_geometry(d, 1, &sg, &grid)) need = (size_t)grid * 64 * d->KH * 32 * sizeof(float);
         C64WgradArgs cg;
         if (c64_wgrad_geometry(d, 1, &cg, &grid)) need = (size_t)grid * 64 * 576 * sizeof(float);
+        TriVox0Geom vg;
+        if (tri_internal_vox0_geometry(d->B, d->ID, d->IH, d->IW, d->Cin, d->OD, d->OH, d->OW, d->Cout, d->KD, d->KH, d->KW, d->stride, d->pad_d,
+                                       d->pad_h, d->pad_w, &vg) && tri_internal_vox0_wgrad_grid(vg) > 0)
+            need = (size_t)tri_internal_vox0_wgrad_grid(vg) * 32 * 144 * sizeof(float);
     }
     for (int mode = 0; mode < 4; ++mode) {                        // fp32 / 16-bit storage x position range / row list
         int BI, BJ, tiles, splits, sps, Kpad, dma;
@@ -1215,6 +1220,12 @@ extern "C" size_t tri_conv_wgrad_workspace(const TriConvDesc* d) {
 
 // 0: conv_wgrad_kernel (register-staged), 2: conv_wgrad_dma_kernel (bf16 activation storage, LDS-DMA).  For profilers.
 extern "C" int tri_conv_wgrad_kernel_family(const TriConvDesc* d, int act_fmt) {
+    {
+        TriVox0Geom vg;
+        if (act_fmt && tri_internal_vox0_geometry(d->B, d->ID, d->IH, d->IW, d->Cin, d->OD, d->OH, d->OW, d->Cout, d->KD, d->KH, d->KW, d->stride,
+                                                  d->pad_d, d->pad_h, d->pad_w, &vg) && tri_internal_vox0_wgrad_grid(vg) > 0)
+            return 6;                                              // conv_vox0_wgrad_kernel when the call passes a site mask
+    }
     int BI, BJ, tiles, splits, sps, Kpad, dma;
     wgrad_plan(d, act_fmt, 0, &BI, &BJ, &tiles, &splits, &sps, &Kpad, &dma);
     return dma ? 2 : 0;
@@ -1320,7 +1331,7 @@ static void wgrad_fill_pending(const TriConvDesc* d, const float* slab, int spli
     pending->slab = slab; pending->dw = dw; pending->s_co = s_co; pending->s_tap = s_tap; pending->s_ci = s_ci;
     pending->splits = splits; pending->Cout = d->Cout; pending->Kpad = Kpad; pending->ntaps = ntaps; pending->cin_stored = d->Cin;
     pending->cin_real = cin_real; pending->zlanes = zlanes; pending->nblocks = (int)((quads + kq - 1) / kq); pending->out_scale = out_scale;
-    pending->kw_real = 0;
+    pending->kw_real = 0; pending->kw_shift = 0;
     // torchvision layout with several taps and not too many splits: the row form (wgrad_reduce_row), one output channel per block
     static int rows = -1;
     if (rows < 0) { const char* e = getenv("TRICOLO_WGRAD_REDUCE_ROWS"); rows = (e && e[0] == '0') ? 0 : 1; }
@@ -1368,7 +1379,7 @@ static int stem_wgrad_launch(const TriConvDesc* d, StemWgradArgs& sg, int grid, 
     pending->slab = (const float*)workspace; pending->dw = dw; pending->s_co = s_co; pending->s_tap = s_tap; pending->s_ci = s_ci;
     pending->splits = grid; pending->Cout = 64; pending->Kpad = d->KH * 32; pending->ntaps = ntaps_p; pending->cin_stored = 4;
     pending->cin_real = cin_real; pending->zlanes = zlanes; pending->nblocks = (int)((quads + kq - 1) / kq);
-    pending->out_scale = out_scale; pending->kw_real = d->KW;
+    pending->out_scale = out_scale; pending->kw_real = d->KW; pending->kw_shift = 3;
     return 0;
 }
 // Weight gradient of the stem conv straight from the BatchNorm-backward inputs (conv -> BN -> ReLU -> MaxPool2d(3, 2, 1), mv_cnn.py:44):
@@ -1425,7 +1436,27 @@ extern "C" int tri_conv_wgrad_partial(const TriConvDesc* d, const void* in, cons
             pending->slab = (const float*)workspace; pending->dw = dw; pending->s_co = s_co; pending->s_tap = s_tap; pending->s_ci = s_ci;
             pending->splits = grid; pending->Cout = 64; pending->Kpad = 576; pending->ntaps = 9; pending->cin_stored = 64;
             pending->cin_real = cin_real; pending->zlanes = zlanes; pending->nblocks = (int)((quads + kq - 1) / kq);
-            pending->out_scale = out_scale;
+            pending->out_scale = out_scale; pending->kw_shift = 0;
+            return 0;
+        }
+    }
+    {   // voxel level 0 over a site mask: conv_vox0_wgrad_kernel (conv_vox.hip)
+        TriVox0Geom vg; int grid;
+        if (row_mask && !row_count && !split3 && act_fmt &&
+            tri_internal_vox0_geometry(d->B, d->ID, d->IH, d->IW, d->Cin, d->OD, d->OH, d->OW, d->Cout, d->KD, d->KH, d->KW, d->stride, d->pad_d,
+                                       d->pad_h, d->pad_w, &vg) && (grid = tri_internal_vox0_wgrad_grid(vg)) > 0) {
+            const size_t need = (size_t)grid * 32 * 144 * sizeof(float);
+            if (workspace_bytes < need) { tri_set_error("wgrad(vox0): workspace too small"); return TRI_ERR_ARG; }
+            int rc = tri_internal_vox0_wgrad_launch(vg, grid, d->B, in, dout, row_mask, (float*)workspace, act_fmt, (hipStream_t)stream);
+            if (rc) return rc;
+            const long quads = (long)32 * 36;
+            int zlanes = 1;
+            while (zlanes < 64 && zlanes * 2 <= grid && quads * zlanes < 262144) zlanes *= 2;
+            const int kq = 256 / zlanes;
+            pending->slab = (const float*)workspace; pending->dw = dw; pending->s_co = s_co; pending->s_tap = s_tap; pending->s_ci = s_ci;
+            pending->splits = grid; pending->Cout = 32; pending->Kpad = 144; pending->ntaps = 36; pending->cin_stored = 4;
+            pending->cin_real = cin_real; pending->zlanes = zlanes; pending->nblocks = (int)((quads + kq - 1) / kq);
+            pending->out_scale = out_scale; pending->kw_real = 3; pending->kw_shift = 2;
             return 0;
         }
     }

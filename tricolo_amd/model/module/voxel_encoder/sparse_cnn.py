@@ -158,7 +158,8 @@ class SparseCNNEncoder(TriModule):
             conv, bn = self.sparseModel[str(4 * l)], self.sparseModel[str(4 * l + 1)]
             dy, dgamma, dbeta = ops.pool3d_bn_bwd(y, co, mask, pooled, dx.contiguous(), B, D, C, bn.weight, count, out_scale=ugs,
                                                   fused=fuse)
-            if compact:                                          # contraction over the active sites only (row list of the level)
+            if compact and not (g.wgrad_brick and dy.dtype != torch.float32):
+                # contraction over the active sites only (row list of the level)
                 grads[3 * l] = ops.conv_wgrad(x, dy, g, conv.weight, prec, rows=rows, out_scale=ugs, batch=batch)
             else:
                 grads[3 * l] = ops.conv_wgrad(x, dy, g, conv.weight, prec, row_mask=mask, out_scale=ugs, batch=batch)

@@ -185,7 +185,9 @@ class ConvGeom:
         self.kernel_family = {(tr, m): lib().tri_conv_kernel_family(_C.C.byref(self.desc), 1 if tr else 0, m)
                               for tr in (False, True) for m in (0, 1, 2)}
         self.wgrad_ws = lib().tri_conv_wgrad_workspace(_C.C.byref(self.desc))
-        self.wgrad_dma = lib().tri_conv_wgrad_kernel_family(_C.C.byref(self.desc), 1) == 2
+        fam = lib().tri_conv_wgrad_kernel_family(_C.C.byref(self.desc), 1)
+        self.wgrad_dma = fam == 2
+        self.wgrad_brick = fam == 6                               # conv_vox0_wgrad_kernel: needs the dense site mask (row_mask), not a row list
         self._plans = {}
         self.fwd_ws = lib().tri_conv_workspace(_C.C.byref(self.desc), 0)
         self.dgrad_ws = lib().tri_conv_workspace(_C.C.byref(self.desc), 1) if cin == cin_stored and cin % 32 == 0 else 0
@@ -470,7 +472,9 @@ def conv_wgrad(x, dout, g: ConvGeom, like: torch.Tensor, precision: str, row_mas
     h16 = x.dtype != torch.float32
     bj = 128 if bi == 128 else (256 if (g.kpad <= 256 and not (h16 and g.wgrad_dma)) else 128)
     s3 = 1 if (split3(precision) and not h16) else 0          # fp32 tensors (heads, GRU) take the 3-product split in the f16 mode too
-    if h16 and g.wgrad_dma:
+    if h16 and g.wgrad_brick and row_mask is not None:
+        sym = f"conv_vox0_wgrad_kernel<{_TNAME[x.dtype]}>"
+    elif h16 and g.wgrad_dma:
         sym = f"conv_wgrad_dma_kernel<{bi}, {bj}, {_TNAME[x.dtype]}>"
     else:
         sym = f"conv_wgrad_kernel<{bi}, {bj}, {2 if s3 else 1}, {_TNAME[x.dtype]}>"
