@@ -1185,10 +1185,11 @@ static bool c64_wgrad_geometry(const TriConvDesc* d, int act_fmt, C64WgradArgs* 
     if ((size_t)TR * W * 128 + (size_t)(TR + 2) * (W + 2) * 128 > 78 * 1024) return false;      // two workgroups per CU
     g->B = d->B; g->H = H; g->W = W; g->TR = TR; g->groups = TR * W / 32;
     g->tiles_per_img = H / TR; g->ntiles = d->B * g->tiles_per_img;
-    // 256-512 per-workgroup slabs of 147 KB: pays from ~6 row tiles per CU on (measured: per-GPU batch 64 of 6 x 128^2 5.03 -> 4.87 ms,
-    // 12 x 224^2 25.3 -> 24.6 ms; the bench shape's 3 tiles per CU 3.41 -> 3.44-3.48 ms, so it keeps conv_wgrad_dma_kernel)
+    // 256-512 per-workgroup slabs of 147 KB.  Round 2: paid from ~6 row tiles per CU on (per-GPU batch 64 of 6 x 128^2 5.03 -> 4.87 ms,
+    // 12 x 224^2 25.3 -> 24.6 ms).  Round 3, against layer1's four weight gradients in ONE grouped conv_wgrad_dma_kernel launch: 6 tiles
+    // per CU 4.43 (this kernel) against 4.36-4.38 ms (grouped), 42 tiles per CU 22.76 against 22.76 - so only the largest shapes keep it
     static int min_per_cu = -1;
-    if (min_per_cu < 0) { const char* e = getenv("TRICOLO_C64_MIN_TILES_PER_CU"); min_per_cu = e ? atoi(e) : 6; }
+    if (min_per_cu < 0) { const char* e = getenv("TRICOLO_C64_MIN_TILES_PER_CU"); min_per_cu = e ? atoi(e) : 12; }
     if (g->ntiles < min_per_cu * tri_internal_num_cus()) return false;
     static int per_cu = -1;
     if (per_cu < 0) { const char* e = getenv("TRICOLO_C64_WGS_PER_CU"); per_cu = e ? atoi(e) : 2; }
