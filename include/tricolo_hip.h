@@ -206,7 +206,10 @@ int tri_bn_bwd_finalize(const float* partial, int nblk, int C, const int* count_
                         void* stream);
 int tri_bn_bwd_apply(const void* y, const void* g, const float* c1, const float* c2, const float* c3, const uint8_t* row_mask,
                      void* dy, long M, int C, const float* relu_scale, const float* relu_shift, const void* relu_out,
-                     void* g_masked /* optional: receives g * (relu_out > 0), may alias g */, int act_fmt, void* stream);
+                     void* g_masked /* optional: receives g * (relu_out > 0), may alias g */,
+                     int keep_inactive /* 0: rows with row_mask == 0 come out as zeros (a data gradient gathers them); 1: they are left
+                                          untouched - for layers whose dy only feeds a weight gradient over the same mask (voxel level 0) */,
+                     int act_fmt, void* stream);
 
 /* ---- pooling -------------------------------------------------------------------------------------------------
  * BN + ReLU + mask + spconv.SparseMaxPool3d(2,2) fused (sparse_cnn.py:13-15 ...), its backward routing;

@@ -81,7 +81,7 @@ SIGNATURES = {
     "tri_bn_bwd_num_blocks": (I, [L]),
     "tri_bn_bwd_reduce": (I, [P, P, L, I, P, P, P, P, P, I, P]),
     "tri_bn_bwd_finalize": (I, [P, I, I, P, I, P, P, P, P, P, P, P, P, F, P]),
-    "tri_bn_bwd_apply": (I, [P, P, P, P, P, P, P, L, I, P, P, P, P, I, P]),
+    "tri_bn_bwd_apply": (I, [P, P, P, P, P, P, P, L, I, P, P, P, P, I, I, P]),
     "tri_bn_relu_pool3d_fwd": (I, [P, P, P, P, I, I, I, P, P, I, P]),
     "tri_pool3d_bwd_route": (I, [P, P, P, P, P, P, I, I, I, P, I, P]),
     "tri_pool3d_bwd_route_reduce_num_blocks": (I, [I, I, I]),

@@ -283,11 +283,13 @@ template <typename T, int MASK>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ y, const T* g, const float4* __restrict__ c1,
                                     const float4* __restrict__ c2, const float4* __restrict__ c3,
                                     const uint8_t* __restrict__ row_mask, T* dy, long total4, int C4,
-                                    const float4* __restrict__ rs, const float4* __restrict__ rb, const T* __restrict__ ro, T* gm) {
+                                    const float4* __restrict__ rs, const float4* __restrict__ rb, const T* __restrict__ ro, T* gm,
+                                    int keep_inactive) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
         long row = i / C4;
         int c = (int)(i - row * C4);
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (keep_inactive && row_mask && !row_mask[row]) continue;    // nobody reads dy there (a first layer: no data gradient): no zeros written
         if (!row_mask || row_mask[row]) {
             float4 yv = Act<T>::ld4(y + i * 4), gv = Act<T>::ld4(g + i * 4), a = c1[c], b = c2[c], d = c3[c];
             if (MASK == 1) {                                        // ReLU mask recomputed from y (see tri_bn_bwd_reduce)
@@ -308,12 +310,12 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ y, const T* g, const f
 }
 extern "C" int tri_bn_bwd_apply(const void* y, const void* g, const float* c1, const float* c2, const float* c3,
                                 const uint8_t* row_mask, void* dy, long M, int C, const float* relu_scale, const float* relu_shift,
-                                const void* relu_out, void* g_masked, int act_fmt, void* stream) {
+                                const void* relu_out, void* g_masked, int keep_inactive, int act_fmt, void* stream) {
     long total4 = M * (C / 4);
 #define TRI_BNA(MASK_)                                                                                                              \
     TRI_ACT_DISPATCH(act_fmt, bn_bwd_apply_kernel<T, MASK_><<<ew_grid(total4), 256, 0, (hipStream_t)stream>>>(                      \
         (const T*)y, (const T*)g, (const float4*)c1, (const float4*)c2, (const float4*)c3, row_mask, (T*)dy, total4, C / 4,          \
-        (const float4*)relu_scale, (const float4*)relu_shift, (const T*)relu_out, (T*)g_masked))
+        (const float4*)relu_scale, (const float4*)relu_shift, (const T*)relu_out, (T*)g_masked, keep_inactive))
     if (relu_out) TRI_BNA(2);
     else if (relu_scale) TRI_BNA(1);
     else TRI_BNA(0);

@@ -157,7 +157,9 @@ class SparseCNNEncoder(TriModule):
             x, y, mask, count, co, pooled, rows, _ = saved["levels"][l]
             conv, bn = self.sparseModel[str(4 * l)], self.sparseModel[str(4 * l + 1)]
             dy, dgamma, dbeta = ops.pool3d_bn_bwd(y, co, mask, pooled, dx.contiguous(), B, D, C, bn.weight, count, out_scale=ugs,
-                                                  fused=fuse)
+                                                  fused=fuse, keep_inactive=(l == 0 and (compact or g.wgrad_brick)))
+            # (level 0 has no data gradient that would gather dy at inactive sites; its weight gradient walks a row list or masks dOut
+            # rows itself - only the masked-tile form of conv_wgrad_kernel needs the zeros)
             if compact and not (g.wgrad_brick and dy.dtype != torch.float32):
                 # contraction over the active sites only (row list of the level)
                 grads[3 * l] = ops.conv_wgrad(x, dy, g, conv.weight, prec, rows=rows, out_scale=ugs, batch=batch)

@@ -606,7 +606,7 @@ def _bn_bwd_finalize(partial, nblk, C, count_dev, count_host, gamma, co: "BNCoef
 
 
 def bn_bwd(y, g, co: BNCoeffs, gamma, count_dev=None, count_host=0, row_mask=None, inplace=True, relu=False, relu_out=None,
-           g_masked=None, out_scale: float = 1.0):
+           g_masked=None, out_scale: float = 1.0, keep_inactive: bool = False):
     # row_mask: rows with 0 are never read by either pass (their y / g may be unwritten) and come out as zeros in dy
     """Returns (dy, dgamma, dbeta).  g = gradient w.r.t. the BN output (already activation-masked), or - with relu=True -
     w.r.t. relu(bn(y)): the ReLU mask is then recomputed from y inside the two passes (no separate relu_bwd pass), or -
@@ -624,7 +624,7 @@ def bn_bwd(y, g, co: BNCoeffs, gamma, count_dev=None, count_host=0, row_mask=Non
     buf = _bn_bwd_finalize(partial, nblk, C, count_dev, count_host, gamma, co, out_scale)
     dy = g if inplace else torch.empty_like(g)
     check(lib().tri_bn_bwd_apply(ptr(y), ptr(g), ptr(buf[2]), ptr(buf[3]), ptr(buf[4]), ptr(row_mask), ptr(dy), M, C, ptr(rs), ptr(rb),
-                                 ptr(relu_out), ptr(g_masked), _abf(y), stream()), "tri_bn_bwd_apply")
+                                 ptr(relu_out), ptr(g_masked), 1 if keep_inactive else 0, _abf(y), stream()), "tri_bn_bwd_apply")
     return dy, buf[0], buf[1]
 
 
@@ -646,13 +646,16 @@ def pool3d_bwd_route(y, co: BNCoeffs, mask, pooled, dpooled, B, D, C):
     return g
 
 
-def pool3d_bn_bwd(y, co: BNCoeffs, mask, pooled, dpooled, B, D, C, gamma, count_dev, out_scale: float = 1.0, fused: bool = True):
+def pool3d_bn_bwd(y, co: BNCoeffs, mask, pooled, dpooled, B, D, C, gamma, count_dev, out_scale: float = 1.0, fused: bool = True,
+                  keep_inactive: bool = False):
     """Backward of BatchNorm1d -> ReLU -> SparseMaxPool3d of one voxel level: (dy, dgamma, dbeta).  fused: the routing pass also
     produces the BatchNorm-backward sums (tri_pool3d_bwd_route_reduce), so the level costs route + finalize + apply instead of
-    route + reduce + finalize + apply; channel counts whose quads do not divide 256 take the unfused passes."""
+    route + reduce + finalize + apply; channel counts whose quads do not divide 256 take the unfused passes.  keep_inactive: dy rows
+    of inactive sites are left unwritten instead of zeroed (level 0: its dy only feeds the weight gradient over the same mask - at
+    13 % occupancy the zeros were 87 % of the pass's writes)."""
     if C % 4 or (C // 4) > 256 or 256 % (C // 4) or not fused:
         gz = pool3d_bwd_route(y, co, mask, pooled, dpooled, B, D, C)
-        return bn_bwd(y, gz, co, gamma, count_dev=count_dev, row_mask=mask, out_scale=out_scale)
+        return bn_bwd(y, gz, co, gamma, count_dev=count_dev, row_mask=mask, out_scale=out_scale, keep_inactive=keep_inactive)
     assert dpooled.dtype == y.dtype and pooled.dtype == y.dtype
     g = torch.empty_like(y)
     nblk = lib().tri_pool3d_bwd_route_reduce_num_blocks(B, D, C)
@@ -662,7 +665,7 @@ def pool3d_bn_bwd(y, co: BNCoeffs, mask, pooled, dpooled, B, D, C, gamma, count_
     M = y.numel() // C
     buf = _bn_bwd_finalize(partial, nblk, C, count_dev, 0, gamma, co, out_scale)
     check(lib().tri_bn_bwd_apply(ptr(y), ptr(g), ptr(buf[2]), ptr(buf[3]), ptr(buf[4]), ptr(mask), ptr(g), M, C, None, None, None, None,
-                                 _abf(y), stream()), "tri_bn_bwd_apply")
+                                 1 if keep_inactive else 0, _abf(y), stream()), "tri_bn_bwd_apply")
     return g, buf[0], buf[1]
 
 
