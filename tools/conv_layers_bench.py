@@ -83,7 +83,9 @@ def main():
     if args.only in ("", "linear"):
         layers.append(("gru_xproj", ops.ConvGeom(96 * args.batch, (1, 1, 1), 256, 256, 768, (1, 1, 1), 1, (0, 0, 0), (256, 1, 1)), None))
         layers.append(("mlp512", ops.ConvGeom(args.batch, (1, 1, 1), 512, 512, 512, (1, 1, 1), 1, (0, 0, 0), (512, 1, 1)), None))
-    print(f"{'layer':28s} {'M':>8s} {'K':>6s} {'N':>4s} | {'fwd ms':>8s} {'TF':>7s} | {'dgrad ms':>8s} {'TF':>7s} | {'wgrad ms':>8s} {'TF':>7s}")
+    # last column pair: the layer's weight gradient as the training step runs it - FOUR copies of the layer queued in a WgradBatch (one
+    # grouped partial launch per tile family + one grouped reduce), time per layer
+    print(f"{'layer':28s} {'M':>8s} {'K':>6s} {'N':>4s} | {'fwd ms':>8s} {'TF':>7s} | {'dgrad ms':>8s} {'TF':>7s} | {'wgrad ms':>8s} {'TF':>7s} | {'x4 grouped':>10s} {'TF':>7s}")
     tot = [0.0, 0.0, 0.0]
     for name, g, mask in layers:
         ID, IH, IW = g.in_grid
@@ -102,12 +104,20 @@ def main():
             packed_t = ops.pack_weight(w, g, prec, transposed=True)
             t_d = time_it(lambda: ops.conv_dgrad(dy, g, packed_t, row_mask=mask))
         t_w = time_it(lambda: ops.conv_wgrad(x, dy, g, w, prec, row_mask=mask))
+        t_g = float("nan")
+        if mask is None and x.dtype != torch.float32 and g.wgrad_group(ops._abf(x))[0]:
+            def grouped():
+                batch = ops.WgradBatch(dev)
+                for _ in range(4):
+                    ops.conv_wgrad(x, dy, g, w, prec, batch=batch)
+                batch.flush()
+            t_g = time_it(grouped) / 4
         fl = g.flops / 1e9
         mult = 3 if "x3" in name else 1
         tot[0] += t_f * mult
         tot[1] += (0 if t_d != t_d else t_d) * mult
         tot[2] += t_w * mult
-        print(f"{name:28s} {g.M:8d} {g.kpad:6d} {g.cout:4d} | {t_f:8.3f} {fl / t_f:7.1f} | {t_d:8.3f} {fl / t_d:7.1f} | {t_w:8.3f} {fl / t_w:7.1f}")
+        print(f"{name:28s} {g.M:8d} {g.kpad:6d} {g.cout:4d} | {t_f:8.3f} {fl / t_f:7.1f} | {t_d:8.3f} {fl / t_d:7.1f} | {t_w:8.3f} {fl / t_w:7.1f} | {t_g:10.3f} {fl / t_g:7.1f}")
     print(f"totals (x3 layers weighted): fwd {tot[0]:.3f} ms  dgrad {tot[1]:.3f} ms  wgrad {tot[2]:.3f} ms  sum {sum(tot):.3f} ms")
 
 
