@@ -452,6 +452,13 @@ def test_voxel_bn_pool_forward_backward_matches_oracle():
     act = m8[:B * D ** 3].bool().cpu()
     assert torch.equal(dy2.cpu().view(-1, C)[act], dy2.cpu().view(-1, C)[act])        # (finite everywhere it is defined)
     np.testing.assert_allclose(dy2.cpu().view(-1, C)[act].numpy(), dy.cpu().view(-1, C)[act].numpy(), atol=2e-6)
+    # keep_inactive (level 0: its dy only feeds the weight gradient over the same mask): active rows identical, inactive rows untouched
+    # - whatever pool3d_bwd_route left there - instead of zeroed
+    gz3 = ops.pool3d_bwd_route(ycl, co, m8, pooled, cl3(dp).to(DEV), B, D, C)
+    gz3.view(-1, C)[~act.to(DEV)] = 123.0
+    dy3, dgamma3, dbeta3 = ops.bn_bwd(ycl, gz3, co, bn2.weight, count_dev=cnt, row_mask=m8, keep_inactive=True)
+    assert torch.equal(dy3.cpu().view(-1, C)[act], dy.cpu().view(-1, C)[act]) and torch.equal(dgamma3, dgamma) and torch.equal(dbeta3, dbeta)
+    assert bool((dy3.cpu().view(-1, C)[~act] == 123.0).all()) and bool((dy.cpu().view(-1, C)[~act] == 0.0).all())
 
 
 @pytest.mark.parametrize("n,p", [(1, 1.0), (2047, 0.5), (2048, 0.0), (5 * 2048 + 3, 0.3), (1 << 20, 0.13), (1024 * 2048, 0.9), (1025 * 2048 + 17, 0.05)])
