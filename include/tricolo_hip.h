@@ -157,7 +157,7 @@ int tri_wgrad_reduce_grouped(const TriWgradReduce* pending /* HOST array */, int
  * tri_conv_wgrad_partial_group: n <= TRI_WGRAD_JOBS_MAX jobs of one family (dense position ranges or compact row lists, no row mask);
  * workspace sized by tri_conv_wgrad_workspace as before;
  * pending[i] (HOST, out) is job i's reduce descriptor for tri_wgrad_reduce_grouped. */
-#define TRI_WGRAD_JOBS_MAX 6
+#define TRI_WGRAD_JOBS_MAX 12
 typedef struct TriWgradJob {
     const TriConvDesc* d;
     const void* in;

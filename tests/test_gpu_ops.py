@@ -892,7 +892,7 @@ WGRAD_JOB_CASES = {
 def test_wgrad_jobs_share_one_partial_launch(group, store, prec):
     """WgradBatch job queue -> tri_conv_wgrad_partial_group: several layers' partial kernels in ONE launch (fewer, longer splits per
     layer; gather plan through the LDS ring beyond 16 steps per split), then the grouped reduce.  Integer data: every layer's dW is
-    exactly the reference's whatever the split; a family's queue launches when its tile budget is full or 6 jobs wait."""
+    exactly the reference's whatever the split; a family's queue launches when its tile budget is full or TRI_WGRAD_JOBS_MAX jobs wait."""
     cases = WGRAD_JOB_CASES[group]
     batch = ops.WgradBatch(torch.device(DEV), group_jobs=True)
     outs, refs, launches, queued = [], [], 0, 0
@@ -911,7 +911,7 @@ def test_wgrad_jobs_share_one_partial_launch(group, store, prec):
         queued = max(queued, len(batch.jobs))
     assert queued > 1 and len(batch.jobs) + len(batch.descs) == len(cases)
     if group == "mixed" and os.environ.get("TRICOLO_WGRAD_WIDE") != "1":
-        # six jobs / the tile budget launched the 128-row family once on the way; both families still hold jobs (one queue per family)
+        # the tile budget launched the 128-row family once on the way; both families still hold jobs (one queue per family)
         assert launches == 1 and sorted(batch.queues) == [1, 2]
     batch.flush()
     assert batch.jobs == [] and batch.descs == []

@@ -37,7 +37,7 @@ class TriWgradJob(C.Structure):
                 ("cin_real", C.c_int), ("out_scale", C.c_float), ("row_pos", C.c_void_p), ("row_count", C.c_void_p)]
 
 
-TRI_WGRAD_JOBS_MAX = 6
+TRI_WGRAD_JOBS_MAX = 12
 TRI_ERR_ARG, TRI_ERR_UNSUPPORTED = -1, -2                   # common.h
 
 P, I, L, F, Z = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t

@@ -326,7 +326,7 @@ __device__ __forceinline__ int nat_sw(int row) {
 // Several layers' weight gradients in ONE launch (tri_conv_wgrad_partial_group): the launch's ~448 resident workgroups are shared by
 // the jobs, so each layer is cut into a fraction of the splits it would get alone - the fp32 slab traffic (splits x Cout x K written
 // here, re-read by the reduce) shrinks by the number of jobs, and a workgroup's prologue / slab store is paid once per longer split.
-#define WGRAD_JOBS_MAX 6
+#define WGRAD_JOBS_MAX 12
 #define WGRAD_RING_STEPS 8                                         // plan ring: 2 chunks of this many 64-position steps (8 KB: two 128x128 workgroups per CU still fit)
 struct WgradJobs {
     WgradArgs d[WGRAD_JOBS_MAX];
