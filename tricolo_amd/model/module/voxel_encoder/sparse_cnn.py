@@ -147,8 +147,9 @@ class SparseCNNEncoder(TriModule):
         batch = ops.wgrad_batch(dz.device)                     # the five weight-gradient reduces in one launch at the end
         compact = os.environ.get("TRICOLO_VOXEL_COMPACT", "1") != "0"
         # route + BatchNorm-backward sums in one launch when this tower is the step's longest chain (Bi(V): 1.314 -> 1.302 ms).  Beside
-        # an image tower the shorter voxel chain changes how the replayed graph folds its branches and the STEP gets slower (3.30 ->
-        # 3.33 ms, four A/B pairs on two boxes), so TriCoLoNet switches it off there; TRICOLO_POOL_REDUCE=0 / 1 overrides.
+        # an image tower the shorter voxel chain changes how the replayed graph folds its branches and at 32^3 the STEP gets slower
+        # (round 2: 3.30 -> 3.33 ms, four pairs; round 3: 2.98-3.01 -> 3.04-3.05, three pairs) - TriCoLoNet switches it off there and
+        # keeps it for 64^3 grids (22.39 -> 21.87 ms beside 12 x 224^2 views); TRICOLO_POOL_REDUCE=0 / 1 overrides.
         env = os.environ.get("TRICOLO_POOL_REDUCE")
         fuse = self.fuse_pool_reduce if env is None else env == "1"
         for l in range(4, -1, -1):

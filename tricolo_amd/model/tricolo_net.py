@@ -59,7 +59,9 @@ class TriCoLoNet(TriModule):
         if cfg.model.voxel_encoder is not None:
             self.voxel_encoder = _instantiate(getattr(cfg.model.modules, cfg.model.voxel_encoder))
             if self.image_encoder is not None and hasattr(self.voxel_encoder, "fuse_pool_reduce"):
-                self.voxel_encoder.fuse_pool_reduce = False      # a side tower here: see SparseCNNEncoder._backward_impl
+                # a side tower here: see SparseCNNEncoder._backward_impl.  Beside an image tower the fused pass only pays on the big
+                # grids (64^3 x 64 + 12 x 224^2: 22.39 -> 21.87 ms; 32^3 x 32 + 6 x 128^2: 2.98-3.01 -> 3.04-3.05 ms, three pairs)
+                self.voxel_encoder.fuse_pool_reduce = getattr(self.voxel_encoder, "voxel_size", 32) >= 64
         self.loss_fn = _instantiate(getattr(cfg.loss, cfg.loss.name))
         self.val_test_step_outputs = []
         self.overlap_towers = os.environ.get("TRICOLO_OVERLAP", "1") != "0"
