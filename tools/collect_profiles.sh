@@ -8,7 +8,8 @@ cp $O/${tag}_bench_default.json $P/bench_default.json
 for c in 2 3 5; do cp $O/${tag}_bench_cfg$c.json $P/bench_config$c.json; done
 for c in 2 3 4 5; do cp $O/${tag}_timeline_cfg$c.txt $P/timeline_config$c.txt; done
 for p in f16 bf16x3; do
-  f=$(find $O/${tag}_prof_$p -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $P/kernel_stats_$p.csv
+  # (gpurun merges every call's files into gpurun_out/: take the newest run's stats, not the first name found)
+  f=$(find $O/${tag}_prof_$p -name "*kernel_stats.csv" -printf "%T@ %p\n" | sort -n | tail -1 | cut -d" " -f2); [ -n "$f" ] && cp $f $P/kernel_stats_$p.csv
   cp $O/${tag}_prof_$p.json $P/bench_under_rocprof_$p.json
 done
 cp $O/${tag}_pmc_traffic_f16.json $P/pmc_traffic_f16.json
