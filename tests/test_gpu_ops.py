@@ -705,6 +705,11 @@ BF16_CASES = [c for c in CONV_CASES if c[0] in ("vox_l0", "vox_l1", "vox_l3", "s
     ("stem_224", 1, (1, 56, 224), 3, 64, (1, 7, 7), 2, (0, 3, 3), "torch"),
     # 56-wide rows (two per tile, 112 of 128 positions used), four output-channel tiles, 7 tiles per CU
     ("h_56x4", 32, (1, 56, 56), 64, 256, (1, 3, 3), 1, (0, 1, 1), "torch"),
+    # conv_c64_kernel (64 -> 64 channels, filter bank in registers; also big_nosplit and c64_32 above): 16-wide images (8 rows per brick),
+    # 32-wide with 12 rows (3 bricks per image), more bricks than persistent workgroups (140 x 8 = 1,120)
+    ("c64k_16", 5, (1, 16, 16), 64, 64, (1, 3, 3), 1, (0, 1, 1), "torch"),
+    ("c64k_32x12", 3, (1, 12, 32), 64, 64, (1, 3, 3), 1, (0, 1, 1), "torch"),
+    ("c64k_many", 140, (1, 32, 32), 64, 64, (1, 3, 3), 1, (0, 1, 1), "torch"),
 ]
 
 
@@ -713,6 +718,8 @@ BF16_CASES = [c for c in CONV_CASES if c[0] in ("vox_l0", "vox_l1", "vox_l3", "s
 def test_conv_16bit_storage_integer_exact(case, store, prec):
     """The bf16 / f16 modes store activations in 16 bits: operands are exact, the fp32 accumulator is rounded once on store."""
     x, w, wp, xcl, g = make_case(case, integer=True, seed=51)
+    if case[0].startswith("c64k") or case[0] in ("big_nosplit", "c64_32"):
+        assert (g.kernel_family[(False, 2)] & 255) == 9 and (g.kernel_family[(True, 2)] & 255) == 9      # conv_c64_kernel, both directions
     ref = cl3(F.conv3d(x, w, stride=case[6], padding=case[7]))
     packed = ops.pack_weight(wp.to(DEV), g, prec)
     out = ops.conv_fwd(xcl.to(DEV).to(store), g, packed)

@@ -1,0 +1,267 @@
+// 64 -> 64 channel 3x3 / 1 / pad 1 convolution with the filter bank STATIONARY IN REGISTERS (16-bit storage modes, gfx950): layer1 of
+// the ResNet trunk (mv_cnn.py:44, torchvision BasicBlock 64 -> 64), forward and data gradient.
+//
+// conv_halo_rows_kernel keeps layer1's filter bank in LDS and every wave re-reads four weight fragments per k-step next to its two
+// activation fragments; at one wave per SIMD (372 registers) nothing covers the slab DMA pieces, the epilogue and the 7.4 k-cycle
+// prologue: a 128-position tile takes 5.4 k cycles for 2.3 k cycles of MFMA.  This kernel is the 2D twin of conv_vox1_kernel:
+//   * a persistent workgroup (two per CU) walks bricks of TY image rows x W columns = 8 runs of 16 pixels, stages a brick + one-pixel halo
+//     once in an LDS slab (128 B per pixel, 16-byte chunks XOR-swizzled by the pixel pair: conflict-free ds_read_b128 for all three kx);
+//   * wave (c, h) holds the A fragments of output channels 32 c .. 32 c + 31 for all 9 taps x 2 k-steps (36 fragments, 144 registers,
+//     loaded once per workgroup) and takes the runs of parity h: every activation fragment it reads feeds TWO MFMAs (the 1 : 1 form of
+//     conv_vox1_kernel is LDS-bound at half the matrix rate), no weight traffic at all after the prologue;
+//   * fragment addresses: per-lane offsets for (kx, k-step), immediates / one add for (ky, run);
+//   * forward: BatchNorm sums of the values as stored stay in registers over all bricks, one record per workgroup; data gradient: the
+//     same correlation over the transposed operand rows with the taps in reverse order, optionally added to what `out` holds (the
+//     shortcut's gradient), fp32 sum rounded once.
+#include "common.h"
+#include <stdlib.h>
+#include "conv_vox.h"
+
+int tri_internal_num_cus();                                                   // conv_igemm.hip
+
+template <int N>
+__device__ __forceinline__ float c64_row_ror(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, false));
+}
+
+struct ConvC64Args {
+    const void* in;            // [N, H, W, 64] 16-bit
+    const void* w;             // packed operand rows [64][576] (k = tap * 64 + channel); data gradient: the transposed rows
+    void* out;                 // [N, H, W, 64]
+    float* stats;              // [grid][2][64] or NULL
+    int N, H, nbricks, transposed, accumulate;
+    unsigned in_bytes;
+};
+
+template <int W, int TY>
+struct C64Cfg {
+    static constexpr int XOFF = 4;                                             // pad pixels left of a slab row
+    static constexpr int P = W + 16;                                           // pixels per slab row: a multiple of 16 (the swizzle then depends on x only)
+    static constexpr int PITCH = P * 128;
+    static constexpr int SLAB = (TY + 2) * PITCH;
+    static constexpr int RPR = W / 16;
+    static constexpr int RUNS = TY * RPR;
+    static constexpr int CPR = W * 8;                                          // 16-byte chunks per image row
+    static constexpr int ITEMS = (TY + 2) * CPR;
+    static constexpr int MAXC = (ITEMS + 255) / 256;
+    static constexpr int WROW = 9 * 64 * 2 + 16;                               // filter-bank row pitch while it is staged through LDS: 16 rows -> 16 distinct bank quads
+    static constexpr size_t SMEM = (size_t)SLAB > (size_t)64 * WROW ? (size_t)SLAB : (size_t)64 * WROW;
+    static_assert(RUNS == 8 || RUNS == 4, "a brick is 8 or 4 runs (half of them per wave pair)");
+    static_assert(2 * PITCH + 4096 < 65536, "fragment-read immediates");
+};
+
+template <typename AT, int W, int TY, bool ACCUM>
+__global__ __launch_bounds__(256, 2) void conv_c64_kernel(const ConvC64Args p) {
+    typedef C64Cfg<W, TY> C;
+    typedef typename OpOf<AT>::E E;
+    typedef Mma<E> MM;
+    typedef typename MM::v8 v8;
+    constexpr int KPAD = 9 * 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), fr = lane & 15, fq = lane >> 4;
+    const int c = wave & 1, h = wave >> 1;
+    char* const slab = smem;
+    const int G = gridDim.x, wg = blockIdx.x;
+    const int bpi = p.H / TY;                                                  // bricks per image
+
+    // ---- filter bank of this wave's 32 output channels: A fragment (tap, k-step, ct): row fr = channel 32 c + 16 ct + fr,
+    // k = 8 fq .. 8 fq + 7 of the k-step's 32 channels; the data gradient walks the taps backwards (tap' = 8 - tap)
+    // (staged through LDS with coalesced loads: read straight from global memory these are 36 scattered 16-byte loads per lane, and with
+    // every workgroup of the launch doing it at once the launch paid ~10 us before its first MFMA - the lesson of conv_vox0_kernel)
+    v8 wf[9][2][2];
+    {
+        constexpr int NCH = 64 * KPAD * 2 / 16;                                // 4,608 chunks of the [64][576] bank
+        uint4 wld[NCH / 256];
+#pragma unroll
+        for (int u = 0; u < NCH / 256; ++u) wld[u] = *(const uint4*)((const char*)p.w + (size_t)(t + u * 256) * 16);
+#pragma unroll
+        for (int u = 0; u < NCH / 256; ++u) {
+            const int ch = t + u * 256, row = ch / 72, col = ch - row * 72;    // 72 chunks per row
+            *(uint4*)(slab + row * C::WROW + col * 16) = wld[u];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const char* wrow = slab + (32 * c + 16 * ct + fr) * C::WROW + fq * 16;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int tw = p.transposed ? 8 - tap : tap;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) wf[tap][ks][ct] = *(const v8*)(wrow + (tw * 64 + ks * 32) * 2);
+            }
+        }
+        __syncthreads();                                                       // the slab takes the staging area over
+    }
+    // per-lane slab offsets for (kx, k-step): pixel XOFF + fr + kx - 1, chunk 4 ks + fq at its swizzled position
+    int lofs[3][2];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int sx = C::XOFF + fr + kx - 1;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) lofs[kx][ks] = sx * 128 + (((4 * ks + fq) ^ ((sx >> 1) & 7)) << 4);
+    }
+    const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    f32x4 cs[2], cq[2];
+    cs[0] = cs[1] = cq[0] = cq[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // the zero pixel left and right of every slab row (written once: the fill below never touches them)
+    for (int i = t; i < (TY + 2) * 16; i += 256) {
+        const int row = i >> 4, side = (i >> 3) & 1, q = i & 7;
+        const int sx = side ? C::XOFF + W : C::XOFF - 1;
+        *(uint4*)(slab + row * C::PITCH + sx * 128 + q * 16) = make_uint4(0u, 0u, 0u, 0u);
+    }
+
+#pragma unroll 1
+    for (int j = wg; j < p.nbricks; j += G) {
+        const int n = j / bpi, y0 = (j - n * bpi) * TY;
+        __syncthreads();                                                       // every wave is done with the previous slab
+        {
+            uint4 pre[C::MAXC];
+            int dst[C::MAXC];
+#pragma unroll
+            for (int u = 0; u < C::MAXC; ++u) {
+                const int i = t + u * 256;
+                const int yy = i / C::CPR, cc = i % C::CPR;
+                const int sx = C::XOFF + (cc >> 3), q = cc & 7;
+                const int gy = y0 - 1 + yy;
+                const bool inside = i < C::ITEMS;
+                dst[u] = inside ? yy * C::PITCH + sx * 128 + ((q ^ ((sx >> 1) & 7)) << 4) : -1;
+                const bool ok = inside && (unsigned)gy < (unsigned)p.H;
+                const unsigned voff = ok ? (unsigned)(((n * p.H + gy) * W) * 128 + cc * 16) : 0x80000000u;
+                pre[u] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(irs, voff, 0, 0));
+            }
+#pragma unroll
+            for (int u = 0; u < C::MAXC; ++u)
+                if (dst[u] >= 0) *(uint4*)(slab + dst[u]) = pre[u];
+        }
+        __syncthreads();
+
+#pragma unroll 1
+        for (int r = h; r < C::RUNS; r += 2) {
+            const int yl = r / C::RPR, xr = r % C::RPR;
+            const char* sb = slab + yl * C::PITCH + xr * 2048;
+            f32x4 acc[2];
+            acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            // the six fragments of a kernel row (3 kx x 2 k-steps) are read as one batch, the next row's batch is issued before this
+            // row's twelve MFMAs
+            v8 bf[2][6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) bf[0][i] = *(const v8*)(sb + lofs[i >> 1][i & 1]);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                if (ky < 2) {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) bf[(ky + 1) & 1][i] = *(const v8*)(sb + lofs[i >> 1][i & 1] + (ky + 1) * C::PITCH);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    acc[0] = MM::mma(wf[ky * 3 + (i >> 1)][i & 1][0], bf[ky & 1][i], acc[0]);
+                    acc[1] = MM::mma(wf[ky * 3 + (i >> 1)][i & 1][1], bf[ky & 1][i], acc[1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            typedef E e4 __attribute__((ext_vector_type(4)));
+            AT* const o = (AT*)p.out + (((size_t)(n * p.H + y0 + yl) * W) + xr * 16 + fr) * 64 + 32 * c + fq * 4;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                f32x4 v = acc[ct];
+                if (ACCUM) {
+                    const e4 e = *(const e4*)(o + 16 * ct);
+                    v[0] += (float)e[0]; v[1] += (float)e[1]; v[2] += (float)e[2]; v[3] += (float)e[3];
+                }
+                const e4 hh = __builtin_convertvector(v, e4);
+                *(e4*)(o + 16 * ct) = hh;
+                const f32x4 rv = {(float)hh[0], (float)hh[1], (float)hh[2], (float)hh[3]};
+                cs[ct] += rv;
+                cq[ct] += rv * rv;
+            }
+        }
+    }
+
+    if (p.stats) {                                                             // one record per workgroup: channels 32 c + 16 ct + 4 fq + r, both run parities
+        float* const red = (float*)slab;                                       // [4 waves][32 channels][2] (the slab is idle now)
+        __syncthreads();
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s_ = cs[ct][r], q_ = cq[ct][r];
+                s_ += c64_row_ror<8>(s_); q_ += c64_row_ror<8>(q_);
+                s_ += c64_row_ror<4>(s_); q_ += c64_row_ror<4>(q_);
+                s_ += c64_row_ror<2>(s_); q_ += c64_row_ror<2>(q_);
+                s_ += c64_row_ror<1>(s_); q_ += c64_row_ror<1>(q_);
+                if (fr == 0) {
+                    red[(wave * 32 + 16 * ct + 4 * fq + r) * 2 + 0] = s_;
+                    red[(wave * 32 + 16 * ct + 4 * fq + r) * 2 + 1] = q_;
+                }
+            }
+        __syncthreads();
+        if (t < 64) {                                                          // channel t = 32 c' + i: waves c' (h = 0) and c' + 2 (h = 1)
+            const int cw = t >> 5, i = t & 31;
+            const float s_ = red[(cw * 32 + i) * 2] + red[((cw + 2) * 32 + i) * 2];
+            const float q_ = red[(cw * 32 + i) * 2 + 1] + red[((cw + 2) * 32 + i) * 2 + 1];
+            p.stats[(size_t)blockIdx.x * 128 + t] = s_;
+            p.stats[(size_t)blockIdx.x * 128 + 64 + t] = q_;
+        }
+    }
+}
+
+static bool c64_disabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("TRICOLO_NO_C64_CONV"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+
+bool tri_internal_c64_geometry(int B, int ID, int IH, int IW, int cin, int OD, int OH, int OW, int cout, int KD, int KH, int KW, int stride,
+                               int pd, int ph, int pw, TriC64Geom* g) {
+    if (c64_disabled()) return false;
+    if (ID != 1 || OD != 1 || KD != 1 || KH != 3 || KW != 3 || stride != 1 || pd != 0 || ph != 1 || pw != 1) return false;
+    if (cin != 64 || cout != 64 || OH != IH || OW != IW) return false;
+    int ty;
+    if (IW == 32) ty = 4; else if (IW == 64) ty = 2; else if (IW == 16) ty = 8; else return false;
+    if ((long)B * IH * IW * 128 >= (1L << 31)) return false;                  // 32-bit buffer offsets
+    const int slots = 2 * tri_internal_num_cus();
+    // bricks of 8 runs when that gives every persistent workgroup >= 3 of them, else bricks of 4 (the bench shape: 768 bricks of 8 runs on
+    // 512 workgroups are 2 rounds for 1.5 rounds of work; 1,536 bricks of 4 runs are 3 each)
+    if (IH % ty || (long)B * (IH / ty) < 3L * slots) ty /= 2;
+    if (IH % ty) return false;
+    g->W = IW; g->TY = ty;
+    g->nbricks = B * (IH / ty);
+    g->grid = g->nbricks < slots ? g->nbricks : slots;
+    return true;
+}
+
+template <typename AT, int W, int TY, bool ACCUM>
+static int c64_launch_t(const ConvC64Args& a, int grid, hipStream_t stream) {
+    typedef C64Cfg<W, TY> C;
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute((const void*)conv_c64_kernel<AT, W, TY, ACCUM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::SMEM);
+        attr = true;
+    }
+    conv_c64_kernel<AT, W, TY, ACCUM><<<grid, 256, C::SMEM, stream>>>(a);
+    return tri_check_launch("tri_conv(c64)");
+}
+
+int tri_internal_c64_launch(const TriC64Geom& g, int B, int H, const void* in, const void* w, void* out, float* stats, int transposed,
+                            int accumulate, int act_fmt, hipStream_t stream) {
+    ConvC64Args a{};
+    a.in = in; a.w = w; a.out = out; a.stats = stats;
+    a.N = B; a.H = H; a.nbricks = g.nbricks; a.transposed = transposed; a.accumulate = accumulate;
+    a.in_bytes = (unsigned)((size_t)B * H * g.W * 128);
+#define TRI_C64(W_, TY_)                                                                                                   \
+    if (g.W == W_ && g.TY == TY_) {                                                                                        \
+        if (act_fmt == TRI_FMT_F16)                                                                                        \
+            return accumulate ? c64_launch_t<f16_t, W_, TY_, true>(a, g.grid, stream) : c64_launch_t<f16_t, W_, TY_, false>(a, g.grid, stream);   \
+        return accumulate ? c64_launch_t<bf16_t, W_, TY_, true>(a, g.grid, stream) : c64_launch_t<bf16_t, W_, TY_, false>(a, g.grid, stream);     \
+    }
+    TRI_C64(32, 4)
+    TRI_C64(32, 2)
+    TRI_C64(64, 2)
+    TRI_C64(64, 1)
+    TRI_C64(16, 8)
+    TRI_C64(16, 4)
+#undef TRI_C64
+    tri_set_error("conv(c64): brick shape not instantiated");
+    return TRI_ERR_UNSUPPORTED;
+}

@@ -1784,6 +1784,8 @@ struct ConvPlan {
     int vox0_grid;
     int vox1;             // 1: conv_vox1_kernel (level 1 of the voxel tower, 32 -> 64 channels, 16-bit storage); records = vox1_grid
     int vox1_grid;
+    int c64;              // 1: conv_c64_kernel (conv_c64.hip: 64 -> 64 channels, 2D 3x3 / 1 / pad 1, 16-bit storage); records = c64_grid
+    int c64_grid;
     int dma;              // 1: LDS-DMA kernel (16-bit activation storage, Cin % 64 == 0), 64-wide k-steps
     int nunits;           // k-steps (32 wide, or 64 wide for the DMA kernel)
     int ksplit, per_split;
@@ -1944,6 +1946,15 @@ static ConvPlan conv_make_plan(int B, int ID, int IH, int IW, int cin, int OD, i
         if (split_mode == 2 && !stem_disabled() && ID == 1 && OD == 1 &&
             stem_geometry(B, IH, IW, cin, OH, OW, cout, KD, KH, KW, stride, pd, ph, pw, &sgm)) {
             pl.stem = 1; pl.stem_grid = sgm.grid; pl.bn = 64; pl.nunits = KH; pl.ksplit = 1; pl.per_split = KH;
+            return pl;
+        }
+    }
+    {
+        TriC64Geom cg;
+        if (pl.dma && split_mode == 2 && tri_internal_c64_geometry(B, ID, IH, IW, cin, OD, OH, OW, cout, KD, KH, KW, stride, pd, ph, pw, &cg)) {
+            // 64 -> 64 channels: conv_c64_kernel (filter bank in registers; conv_c64.hip), forward and data gradient; a call with a
+            // row mask / bias / activation takes conv_dma_kernel (nunits etc. below are its plan)
+            pl.c64 = 1; pl.c64_grid = cg.grid; pl.bn = 64; pl.nunits = kpad / 64; pl.ksplit = 1; pl.per_split = pl.nunits;
             return pl;
         }
     }
@@ -2199,6 +2210,18 @@ static int conv_dispatch(ConvArgs& a, int act_fmt, void* workspace, size_t works
         tri_internal_vox1_geometry(a.B, a.ID, a.IH, a.IW, a.Cin, a.OD, a.OH, a.OW, a.Cout, a.KD, a.KH, a.KW, a.stride, a.pd, a.ph, a.pw, &v1);
         return tri_internal_vox1_launch(v1, a.B, a.in, a.w_hi, a.out, a.row_mask, a.stats, act_fmt, stream);
     }
+    if (pl.c64) {
+        if (!a.row_mask && !a.row_count && !a.bias && a.act == 0) {
+            TriC64Geom cg;
+            tri_internal_c64_geometry(a.B, a.ID, a.IH, a.IW, a.Cin, a.OD, a.OH, a.OW, a.Cout, a.KD, a.KH, a.KW, a.stride, a.pd, a.ph, a.pw, &cg);
+            return tri_internal_c64_launch(cg, a.B, a.IH, a.in, a.w_hi, a.out, a.stats, a.transposed, a.accumulate, act_fmt, stream);
+        }
+        if (a.stats) {                                                // (the record count of this layer is conv_c64_kernel's)
+            tri_set_error("conv: this layer runs conv_c64_kernel (tri_conv_kernel_family == 9): statistics only without row mask / bias / activation");
+            return TRI_ERR_ARG;
+        }
+        a.row_pos = a.row_count ? a.row_pos : nullptr;
+    }
     if (pl.stem && !a.transposed && !a.row_mask && !a.row_count && !a.bias && a.act == 0 && !a.accumulate) {
         a.row_pos = nullptr;
         return act_fmt == TRI_FMT_F16 ? launch_stem<f16_t>(a, stream) : launch_stem<bf16_t>(a, stream);
@@ -2230,6 +2253,7 @@ extern "C" int tri_conv_num_records(const TriConvDesc* d, int split3, int row_li
     if (pl.stem) return pl.stem_grid;
     if (pl.vox0) return pl.vox0_grid;
     if (pl.vox1) return pl.vox1_grid;
+    if (pl.c64) return pl.c64_grid;
     if (pl.halo) return pl.h_wgrec ? pl.h_grid / (d->Cout / 64) : pl.h_mtiles;
     return pl.ksplit > 1 ? (int)((M + 31) / 32) : (int)((M + 127) / 128);
 }
@@ -2244,6 +2268,7 @@ extern "C" int tri_conv_kernel_family(const TriConvDesc* d, int transposed, int 
     if (pl.stem && !transposed) return 4 | (64 << 8);
     if (pl.vox0 && !transposed) return 6 | (32 << 8);
     if (pl.vox1 && !transposed) return 7 | (64 << 8);
+    if (pl.c64) return 9 | (64 << 8);
     if (pl.halo) return (pl.h_v5 ? 5 : 3) | (pl.halo << 8);
     return (pl.dma ? 2 : 0) | (pl.bn << 8) | ((pl.ksplit > 1 || (pl.dma && tri_conv_kpad(d->KD * d->KH * d->KW, transposed ? d->Cout : d->Cin) / 64 > 256)) ? (1 << 16) : 0);
 }

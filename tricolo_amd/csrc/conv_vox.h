@@ -24,3 +24,11 @@ bool tri_internal_vox1_geometry(int B, int ID, int IH, int IW, int cin, int OD, 
                                 int pd, int ph, int pw, TriVox1Geom* g);
 int tri_internal_vox1_launch(const TriVox1Geom& g, int B, const void* in, const void* w, void* out, const uint8_t* mask, float* stats, int act_fmt,
                              hipStream_t stream);
+
+struct TriC64Geom { int W, TY, nbricks, grid; };
+// a 64 -> 64 channel 3x3 / 1 / pad 1 2D layer on 16- / 32- / 64-pixel-wide images in a 16-bit storage mode (layer1 of the ResNet trunk):
+// conv_c64_kernel (conv_c64.hip), forward and data gradient; g->grid = persistent workgroups = BatchNorm records of the launch
+bool tri_internal_c64_geometry(int B, int ID, int IH, int IW, int cin, int OD, int OH, int OW, int cout, int KD, int KH, int KW, int stride,
+                               int pd, int ph, int pw, TriC64Geom* g);
+int tri_internal_c64_launch(const TriC64Geom& g, int B, int H, const void* in, const void* w, void* out, float* stats, int transposed,
+                            int accumulate, int act_fmt, hipStream_t stream);

@@ -103,6 +103,8 @@ def _igemm_symbol(g, transposed, split, t):
         return f"conv_vox0_kernel<{_TNAME[t.dtype]}>"
     if fam == 7:
         return f"conv_vox1_kernel<{_TNAME[t.dtype]}>"
+    if fam == 9:
+        return f"conv_c64_kernel<{_TNAME[t.dtype]}>"                 # (forward / data gradient (+ accumulate) under one name)
     if fam == 4:
         return f"conv_stem_kernel<{g.kernel[1]}, {_TNAME[t.dtype]}>"
     if fam == 5:
