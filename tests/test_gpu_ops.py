@@ -718,7 +718,7 @@ BF16_CASES = [c for c in CONV_CASES if c[0] in ("vox_l0", "vox_l1", "vox_l3", "s
 def test_conv_16bit_storage_integer_exact(case, store, prec):
     """The bf16 / f16 modes store activations in 16 bits: operands are exact, the fp32 accumulator is rounded once on store."""
     x, w, wp, xcl, g = make_case(case, integer=True, seed=51)
-    if case[0].startswith("c64k") or case[0] in ("big_nosplit", "c64_32"):
+    if case[0].startswith("c64k") or case[0] in ("big_nosplit", "c64_32", "c64_56", "h_56"):
         assert (g.kernel_family[(False, 2)] & 255) == 9 and (g.kernel_family[(True, 2)] & 255) == 9      # conv_c64_kernel, both directions
     ref = cl3(F.conv3d(x, w, stride=case[6], padding=case[7]))
     packed = ops.pack_weight(wp.to(DEV), g, prec)

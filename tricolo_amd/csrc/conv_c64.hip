@@ -36,10 +36,10 @@ struct ConvC64Args {
 template <int W, int TY>
 struct C64Cfg {
     static constexpr int XOFF = 4;                                             // pad pixels left of a slab row
-    static constexpr int P = W + 16;                                           // pixels per slab row: a multiple of 16 (the swizzle then depends on x only)
+    static constexpr int RPR = (W + 15) / 16;                                  // runs per image row (56-wide rows: the last run is half used)
+    static constexpr int P = RPR * 16 + 16;                                    // pixels per slab row: a multiple of 16 (the swizzle then depends on x only)
     static constexpr int PITCH = P * 128;
     static constexpr int SLAB = (TY + 2) * PITCH;
-    static constexpr int RPR = W / 16;
     static constexpr int RUNS = TY * RPR;
     static constexpr int CPR = W * 8;                                          // 16-byte chunks per image row
     static constexpr int ITEMS = (TY + 2) * CPR;
@@ -104,9 +104,10 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const ConvC64Args p) {
     f32x4 cs[2], cq[2];
     cs[0] = cs[1] = cq[0] = cq[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // the zero pixel left and right of every slab row (written once: the fill below never touches them)
-    for (int i = t; i < (TY + 2) * 16; i += 256) {
-        const int row = i >> 4, side = (i >> 3) & 1, q = i & 7;
-        const int sx = side ? C::XOFF + W : C::XOFF - 1;
+    constexpr int NZ = C::RPR * 16 - W + 2;                                    // zero pixels per slab row: x = -1 and x = W .. 16 RPR (the half-used run reads them)
+    for (int i = t; i < (TY + 2) * NZ * 8; i += 256) {
+        const int row = i / (NZ * 8), rem = i - row * (NZ * 8), zp = rem >> 3, q = rem & 7;
+        const int sx = zp == 0 ? C::XOFF - 1 : C::XOFF + W + zp - 1;
         *(uint4*)(slab + row * C::PITCH + sx * 128 + q * 16) = make_uint4(0u, 0u, 0u, 0u);
     }
 
@@ -162,6 +163,7 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const ConvC64Args p) {
             }
             typedef E e4 __attribute__((ext_vector_type(4)));
             AT* const o = (AT*)p.out + (((size_t)(n * p.H + y0 + yl) * W) + xr * 16 + fr) * 64 + 32 * c + fq * 4;
+            if (W % 16 && xr * 16 + fr >= W) continue;                         // the unused half of a row's last run: nothing stored, nothing counted
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
                 f32x4 v = acc[ct];
@@ -218,7 +220,7 @@ bool tri_internal_c64_geometry(int B, int ID, int IH, int IW, int cin, int OD, i
     if (ID != 1 || OD != 1 || KD != 1 || KH != 3 || KW != 3 || stride != 1 || pd != 0 || ph != 1 || pw != 1) return false;
     if (cin != 64 || cout != 64 || OH != IH || OW != IW) return false;
     int ty;
-    if (IW == 32) ty = 4; else if (IW == 64) ty = 2; else if (IW == 16) ty = 8; else return false;
+    if (IW == 32) ty = 4; else if (IW == 64 || IW == 56) ty = 2; else if (IW == 16) ty = 8; else return false;
     if ((long)B * IH * IW * 128 >= (1L << 31)) return false;                  // 32-bit buffer offsets
     const int slots = 2 * tri_internal_num_cus();
     // bricks of 8 runs when that gives every persistent workgroup >= 3 of them, else bricks of 4 (the bench shape: 768 bricks of 8 runs on
@@ -259,6 +261,8 @@ int tri_internal_c64_launch(const TriC64Geom& g, int B, int H, const void* in, c
     TRI_C64(32, 2)
     TRI_C64(64, 2)
     TRI_C64(64, 1)
+    TRI_C64(56, 2)
+    TRI_C64(56, 1)
     TRI_C64(16, 8)
     TRI_C64(16, 4)
 #undef TRI_C64
