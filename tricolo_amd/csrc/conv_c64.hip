@@ -142,6 +142,11 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const ConvC64Args p) {
             const char* sb = slab + yl * C::PITCH + xr * 2048;
             f32x4 acc[2];
             acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            typedef E e4 __attribute__((ext_vector_type(4)));
+            AT* const o = (AT*)p.out + (((size_t)(n * p.H + y0 + yl) * W) + xr * 16 + fr) * 64 + 32 * c + fq * 4;
+            const bool valid = !(W % 16) || xr * 16 + fr < W;                  // (the unused half of a 56-wide row's last run)
+            e4 prev[2];                                                        // ACCUM: what `out` holds, requested before the MFMAs
+            if (ACCUM && valid) { prev[0] = *(const e4*)o; prev[1] = *(const e4*)(o + 16); }
             // the six fragments of a kernel row (3 kx x 2 k-steps) are read as one batch, the next row's batch is issued before this
             // row's twelve MFMAs
             v8 bf[2][6];
@@ -161,14 +166,12 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const ConvC64Args p) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            typedef E e4 __attribute__((ext_vector_type(4)));
-            AT* const o = (AT*)p.out + (((size_t)(n * p.H + y0 + yl) * W) + xr * 16 + fr) * 64 + 32 * c + fq * 4;
-            if (W % 16 && xr * 16 + fr >= W) continue;                         // the unused half of a row's last run: nothing stored, nothing counted
+            if (!valid) continue;                                              // nothing stored, nothing counted
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
                 f32x4 v = acc[ct];
                 if (ACCUM) {
-                    const e4 e = *(const e4*)(o + 16 * ct);
+                    const e4 e = prev[ct];
                     v[0] += (float)e[0]; v[1] += (float)e[1]; v[2] += (float)e[2]; v[3] += (float)e[3];
                 }
                 const e4 hh = __builtin_convertvector(v, e4);
