@@ -48,6 +48,39 @@ __global__ __launch_bounds__(256) void linear_small_fwd_kernel(const float* __re
     for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int kq = K >> 2;                                           // this wave's share of the contraction
     const float* wrow = w + (size_t)(n0 + fr) * K + wave * kq + fq * 8;
+    if (MT <= 2 && kq == 128) {
+        // the heads' shape (<= 32 rows, K = 512): all 24 loads of the wave first, then the arithmetic - the rolled loop below waits out
+        // one L2 round trip per 32-wide step and per row tile (most of the kernel's 8.5 us)
+        float4 wv[4][2], xv[4][2][2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            wv[q][0] = *(const float4*)(wrow + q * 32);
+            wv[q][1] = *(const float4*)(wrow + q * 32 + 4);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int m = j * 16 + fr;
+                const float* xr = x + (size_t)(m < M ? m : 0) * K + wave * kq + fq * 8 + q * 32;
+                xv[q][j][0] = *(const float4*)xr;
+                xv[q][j][1] = *(const float4*)(xr + 4);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bf16x8 ah, al;
+            split8(wv[q][0], wv[q][1], ah, al);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (j < MT) {
+                    const bool ok = j * 16 + fr < M;
+                    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    bf16x8 bh, bl;
+                    split8(ok ? xv[q][j][0] : z4, ok ? xv[q][j][1] : z4, bh, bl);
+                    acc[j] = mma3<NSPLIT>(ah, al, bh, bl, acc[j]);
+                }
+            }
+        }
+    } else
+#pragma unroll 4
     for (int k0 = 0; k0 < kq; k0 += 32) {
         bf16x8 ah, al;
         split8(*(const float4*)(wrow + k0), *(const float4*)(wrow + k0 + 4), ah, al);
@@ -97,6 +130,7 @@ __device__ __forceinline__ void linear_small_dgrad_body(const float* __restrict_
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nq = N >> 2;
+#pragma unroll 4
     for (int nb = wave * nq; nb < (wave + 1) * nq; nb += 32) {
         // A = W^T: row i = k0 + fr, contraction index n = nb + 8 fq + jj (16 lanes read 16 consecutive k of one W row)
         float av[8];
@@ -155,6 +189,7 @@ __device__ __forceinline__ void linear_small_wgrad_body(const float* __restrict_
     const int n0 = bx * 16, k0 = by * 64 + wave * 16;
     const int MS = (M + 31) >> 5;                                    // 32-row contraction steps (1 or 2)
     bf16x8 ah[2], al[2];
+    float gsum = 0.f;                                                // this lane's share of column n0 + fr: rows 8 fq .. 8 fq + 7 of both steps
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         float av[8];
@@ -168,18 +203,16 @@ __device__ __forceinline__ void linear_small_wgrad_body(const float* __restrict_
                 if (act) g = act_grad(g, yout[o], act);
             }
             av[jj] = g;
+            gsum += g;
         }
         split8(make_float4(av[0], av[1], av[2], av[3]), make_float4(av[4], av[5], av[6], av[7]), ah[s], al[s]);
     }
-    if (db && by == 0 && wave == 0) {                        // bias gradient from the same fragments' source
-        float s = 0.f;
-        if (lane < 16)
-            for (int m = 0; m < M; ++m) {
-                float g = dout[(size_t)m * N + n0 + lane];
-                if (act) g = act_grad(g, yout[(size_t)m * N + n0 + lane], act);
-                s += g;
-            }
-        if (lane < 16) db[n0 + lane] = s;
+    if (db && by == 0 && wave == 0) {
+        // bias gradient from the values the fragments were built from: the four k-groups of a column add up through two shuffles (a
+        // serial loop over the rows - one dependent load per row on 16 lanes - was the longest thing in the launch: ~20 us at 32 rows)
+        gsum += __shfl_xor(gsum, 16);
+        gsum += __shfl_xor(gsum, 32);
+        if (lane < 16) db[n0 + lane] = gsum;
     }
     if (k0 < K) {
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
