@@ -778,6 +778,7 @@ __global__ __launch_bounds__(256) void avgpool_viewmax_fwd_kernel(const T* __res
         for (int v = slot; v < V; v += 8) {
             const T* p = x + ((long)(b * V + v) * HW) * C + c;
             float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8                                                   // (rolled: one load round trip per pixel, 16 in a row for a 4x4 map)
             for (int k = 0; k < HW; ++k) {
                 const float4 e = Act<T>::ld4(p + (long)k * C);
                 s.x += e.x; s.y += e.y; s.z += e.z; s.w += e.w;

@@ -271,10 +271,12 @@ __global__ void ntxm_l2norm_kernel(const NtxMulti p) {
     if (row >= p.B) return;
     const float* x = p.z[m] + (long)row * p.D;
     float s = 0.f;
+#pragma unroll 8                                                   // (rolled loops wait out one load round trip per step: misc.hip l2norm kernels)
     for (int i = lane; i < p.D; i += 64) s += x[i] * x[i];
     s = wave_sum(s);
     float nrm = sqrtf(s);
     float inv = 1.0f / fmaxf(nrm, p.eps);
+#pragma unroll 8
     for (int i = lane; i < p.D; i += 64) p.zhat[m][(long)row * p.D + i] = x[i] * inv;
     if (lane == 0) p.nrm[m][row] = nrm;
 }
@@ -388,6 +390,7 @@ __global__ __launch_bounds__(256) void ntxm_grad_kernel(const NtxMulti p) {
                 float acc = 0.f;
                 const float* ot = other[k];
                 const float* wk = w + k * B;
+#pragma unroll 8                                                   // (same summation order; eight loads in flight instead of one)
                 for (int j = 0; j < B; ++j) acc = fmaf(wk[j], ot[(long)j * D + c], acc);
                 tot += acc;
             }
