@@ -1923,10 +1923,11 @@ static ConvPlan conv_make_plan(int B, int ID, int IH, int IW, int cin, int OD, i
         blocks = (blocks + occ_div - 1) / occ_div;
     }
     // (round 3: 32-wide output tiles exist too - built for the data gradient of voxel level 1, 64 -> 32 channels, the slowest kernel of
-    // the voxel backward on the register-staged gather; measured no faster (config 2: 1.108 against 1.106 ms per step), so they are
-    // opt-in: TRICOLO_DMA32=1)
+    // the voxel backward on the register-staged gather: 43-57 -> 24 us.  Config 2's step does not move (1.050-1.063 against 1.058-1.061 ms),
+    // config 4's - where the voxel backward is the tail since the image tower got shorter - gains 0.02 ms in three of three pairs
+    // (2.896-2.922 against 2.920-2.944): on by default, TRICOLO_DMA32=0 switches them off)
     static int no32 = -1;
-    if (no32 < 0) { const char* e = getenv("TRICOLO_DMA32"); no32 = (e && e[0] == '1') ? 0 : 1; }
+    if (no32 < 0) { const char* e = getenv("TRICOLO_DMA32"); no32 = (e && e[0] == '0') ? 1 : 0; }
     if (split_mode == 2 && cin % 64 == 0 && (cout % 64 == 0 || (cout % 32 == 0 && !no32)) && !dma_disabled()) pl.dma = 1;
     pl.bn = bn;
     {
