@@ -1633,6 +1633,24 @@ __device__ __forceinline__ void prep_store(bool f16, uint16_t* hi, bf16_t* lo, s
     if (lo) lo[idx] = (bf16_t)(v - (float)h);
 }
 
+// four consecutive packed elements (idx % 4 == 0): one 8-byte store per operand array instead of four 2-byte ones
+__device__ __forceinline__ void prep_store4(bool f16, uint16_t* hi, bf16_t* lo, size_t idx, float4 v) {
+    if (f16) {
+        f16x4 h;
+        h[0] = (f16_t)v.x; h[1] = (f16_t)v.y; h[2] = (f16_t)v.z; h[3] = (f16_t)v.w;
+        *(f16x4*)(hi + idx) = h;
+        return;
+    }
+    bf16x4 h;
+    h[0] = (bf16_t)v.x; h[1] = (bf16_t)v.y; h[2] = (bf16_t)v.z; h[3] = (bf16_t)v.w;
+    *(bf16x4*)(hi + idx) = h;
+    if (lo) {
+        bf16x4 l;
+        l[0] = (bf16_t)(v.x - (float)h[0]); l[1] = (bf16_t)(v.y - (float)h[1]); l[2] = (bf16_t)(v.z - (float)h[2]); l[3] = (bf16_t)(v.w - (float)h[3]);
+        *(bf16x4*)(lo + idx) = l;
+    }
+}
+
 // dst[row][tap * inner_pad + i] (bf16 hi / lo, zero padded to Kpad) from an fp32 tensor addressed by strides.
 // forward:  row = co, inner = ci;   dgrad: row = ci, inner = co  (same tensor, swapped strides).
 __global__ void weight_prep_kernel(const float* __restrict__ w, long s_row, long s_tap, long s_inner, int rows, int ntaps,
@@ -1662,13 +1680,25 @@ __global__ __launch_bounds__(256) void weight_prep_multi_kernel(const TriPrepDes
     const long span = (long)d.inner * nt;
     if (nt > 1 && d.s_tap == 1 && d.s_inner == nt && d.s_row == span && span <= 64 * 73 && d.inner == d.inner_pad) {
         // forward operand of a [Cout,Cin,taps] weight: one contiguous filter per row; dst[tap * Cin + ci] = src[ci * taps + tap]
+        const bool vec = (span & 3) == 0 && (d.inner_pad & 3) == 0 && (d.kpad & 3) == 0 && (((uintptr_t)d.w) & 15) == 0;
         for (int row = blockIdx.x; row < d.rows; row += gridDim.x) {
             const float* src = d.w + (size_t)row * d.s_row;
-            for (int e = t; e < span; e += 256) tile[e] = src[e];
-            __syncthreads();
-            for (int k = t; k < d.kpad; k += 256) {
-                const int tap = k / d.inner_pad, i = k - tap * d.inner_pad;
-                prep_store(f16, hi, lo, (size_t)row * d.kpad + k, tap < nt ? tile[i * nt + tap] : 0.f);
+            if (vec) {                                             // 16-byte loads, 8-byte stores (the element-wise form: 2-byte stores, 128 B per wave)
+                for (int e = t * 4; e < span; e += 1024) *(float4*)(tile + e) = *(const float4*)(src + e);
+                __syncthreads();
+                for (int k = t * 4; k < d.kpad; k += 1024) {
+                    const int tap = k / d.inner_pad, i = k - tap * d.inner_pad;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (tap < nt) v = make_float4(tile[i * nt + tap], tile[(i + 1) * nt + tap], tile[(i + 2) * nt + tap], tile[(i + 3) * nt + tap]);
+                    prep_store4(f16, hi, lo, (size_t)row * d.kpad + k, v);
+                }
+            } else {
+                for (int e = t; e < span; e += 256) tile[e] = src[e];
+                __syncthreads();
+                for (int k = t; k < d.kpad; k += 256) {
+                    const int tap = k / d.inner_pad, i = k - tap * d.inner_pad;
+                    prep_store(f16, hi, lo, (size_t)row * d.kpad + k, tap < nt ? tile[i * nt + tap] : 0.f);
+                }
             }
             __syncthreads();
         }
@@ -1698,6 +1728,15 @@ __global__ __launch_bounds__(256) void weight_prep_multi_kernel(const TriPrepDes
                 tile[il * ld + r] = v;
             }
             __syncthreads();
+            if ((d.inner & 3) == 0 && (d.inner_pad & 3) == 0 && (d.kpad & 3) == 0) {
+                for (int e = t; e < 16 * run; e += 256) {         // four inner indices per thread: 8-byte stores
+                    const int il = (e & 15) * 4, r = e >> 4;      // r = row_l * taps + tap (torch_t) or row_l (plane_t)
+                    const int row_l = torch_t ? r / nt : r, tap = torch_t ? r - row_l * nt : plane;
+                    if (row_l < rows_here && i0 + il < d.inner)
+                        prep_store4(f16, hi, lo, (size_t)(r0 + row_l) * d.kpad + (size_t)tap * d.inner_pad + i0 + il,
+                                    make_float4(tile[il * ld + r], tile[(il + 1) * ld + r], tile[(il + 2) * ld + r], tile[(il + 3) * ld + r]));
+                }
+            } else
             for (int e = t; e < 64 * run; e += 256) {
                 const int il = e & 63, r = e >> 6;                // r = row_l * taps + tap (torch_t) or row_l (plane_t)
                 const int row_l = torch_t ? r / nt : r, tap = torch_t ? r - row_l * nt : plane;
