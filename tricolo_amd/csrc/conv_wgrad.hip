@@ -336,6 +336,7 @@ struct WgradJobs {
 // NWI x NWJ waves, each a (BI / NWI) x (BJ / NWJ) = 64 x 64 (32 x 64 for 64-row tiles) block of the tile: 2 x 2 waves for the 128 x 128 and
 // 64 x 128 tiles (two, three workgroups per CU), 4 x 2 for the 256 x 128 tile of the grouped launches (one 512-thread workgroup per CU:
 // a third fewer operand bytes through the LDS-DMA path per FLOP, which is what bounds these kernels - profiles/r3/NOTES_wgrad.md).
+static_assert(sizeof(WgradJobs) <= 4096, "the job table travels in the kernel arguments (4 KB)");
 template <int BI, int BJ, typename E, int NWI = 2, int NWJ = 2>
 __global__ __launch_bounds__(NWI * NWJ * 64) void conv_wgrad_dma_kernel(const WgradJobs jobs) {
     constexpr int NW = NWI * NWJ, NT = NW * 64;
