@@ -117,6 +117,23 @@ int tri_conv_dgrad(const TriConvDesc* d, const void* dout, const void* wt_hi, co
                    const int* row_count /* optional DEVICE int: row_pos is a COMPACT list, only rows [0, *row_count) are computed
                                            (submanifold layers: the active sites, tri_mask_compact); other rows of din are NOT written */,
                    void* stream);
+/* Data gradient that also takes the BatchNorm-backward sums of the BatchNorm whose OUTPUT gradient it produces: din is the gradient
+ * w.r.t. relu(bn(y)) (relu_scale / relu_shift: the mask y * scale + shift > 0 is recomputed), w.r.t. relu(bn(y) + shortcut) whose
+ * saved output is relu_out (mask relu_out > 0), or w.r.t. bn(y) itself (neither).  partial[records][2][C] receives sum g', sum g' * y
+ * over the values AS STORED in din (g' = masked), the layout tri_bn_bwd_reduce writes and tri_bn_bwd_finalize sums: the separate
+ * reduce pass over din / y (module/img_encoder/mv_cnn.py:44 BasicBlock backward: one per BatchNorm2d) is not launched at all.
+ * tri_conv_dgrad_bn_records: number of records, or 0 when this layer's data-gradient kernel has no fused form (then call
+ * tri_conv_dgrad and tri_bn_bwd_reduce). */
+typedef struct TriConvBnSums {
+    const void* y;            /* [B, ID, IH, IW, Cin] the BatchNorm's input, storage format of din */
+    const float* relu_scale;  /* optional [Cin] */
+    const float* relu_shift;
+    const void* relu_out;     /* optional, shape of y */
+    float* partial;           /* out */
+} TriConvBnSums;
+int tri_conv_dgrad_bn_records(const TriConvDesc* d, int accumulate, int act_fmt);
+int tri_conv_dgrad_bn(const TriConvDesc* d, const void* dout, const void* wt_hi, const void* wt_lo, void* din, int accumulate,
+                      int act_fmt, void* workspace, size_t workspace_bytes, const int* row_pos, const TriConvBnSums* sums, void* stream);
 size_t tri_conv_wgrad_workspace(const TriConvDesc* d);
 /* gather plan of a layer geometry (origin offset + tap validity bits per output position): build once, reuse every step */
 size_t tri_conv_plan_bytes(const TriConvDesc* d);

@@ -759,6 +759,30 @@ def test_conv_16bit_storage_integer_exact(case, store, prec):
         dx2 = ops.conv_dgrad(cl3(dy).to(DEV).to(store), g, ops.pack_weight(wp.to(DEV), g, prec, transposed=True),
                              out=base.clone().to(DEV).to(store), accumulate=True)
         assert torch.equal(dx2.cpu(), (cl3(xr.grad) + base).to(store))
+        # the data gradient that also takes the BatchNorm-backward sums of the pass that would read it next (tri_conv_dgrad_bn): the two
+        # forms of a BasicBlock backward - relu(bn1(y)) behind conv2 (mask recomputed from y), relu(bn2(y) + x) behind the accumulated
+        # conv1 gradient (mask from the saved output); a layer whose kernel has no fused form answers (dx, None)
+        tp = ops.pack_weight(wp.to(DEV), g, prec, transposed=True)
+        yv = ints(tuple(cl3(xr.grad).shape), -3, 3, 67)
+        co = ops.BNCoeffs(case[3], DEV)
+        co.scale.copy_(torch.linspace(-1.0, 1.5, case[3])); co.shift.copy_(torch.linspace(0.75, -0.5, case[3]))
+        dx3, part = ops.conv_dgrad(cl3(dy).to(DEV).to(store), g, tp, bn_sums=(yv.to(DEV).to(store), co, None))
+        assert torch.equal(dx3.cpu(), cl3(xr.grad).to(store))
+        assert (part is not None) == ((g.kernel_family[(True, 2)] & 255) == 9 and case[2][2] <= 32)      # (conv_c64_kernel, 16- / 32-wide images)
+        if part is not None:
+            keep = (yv * co.scale.cpu() + co.shift.cpu() > 0).double()
+            gm = cl3(xr.grad).to(store).double() * keep
+            st = part.cpu().double().sum(0)
+            np.testing.assert_allclose(st[0].numpy(), gm.reshape(-1, case[3]).sum(0).numpy(), rtol=1e-6, atol=1e-2)
+            np.testing.assert_allclose(st[1].numpy(), (gm * yv.double()).reshape(-1, case[3]).sum(0).numpy(), rtol=1e-6, atol=1e-2)
+            ro = ints(tuple(yv.shape), -1, 2, 69)
+            dx4, part = ops.conv_dgrad(cl3(dy).to(DEV).to(store), g, tp, out=base.clone().to(DEV).to(store), accumulate=True,
+                                       bn_sums=(yv.to(DEV).to(store), None, ro.to(DEV).to(store)))
+            assert part is not None and torch.equal(dx4.cpu(), (cl3(xr.grad) + base).to(store))
+            gm = (cl3(xr.grad) + base).to(store).double() * (ro > 0).double()
+            st = part.cpu().double().sum(0)
+            np.testing.assert_allclose(st[0].numpy(), gm.reshape(-1, case[3]).sum(0).numpy(), rtol=1e-6, atol=1e-2)
+            np.testing.assert_allclose(st[1].numpy(), (gm * yv.double()).reshape(-1, case[3]).sum(0).numpy(), rtol=1e-6, atol=1e-2)
 
 
 @pytest.mark.parametrize("rows", ["0", "2"])

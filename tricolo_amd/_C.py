@@ -37,6 +37,10 @@ class TriWgradJob(C.Structure):
                 ("cin_real", C.c_int), ("out_scale", C.c_float), ("row_pos", C.c_void_p), ("row_count", C.c_void_p)]
 
 
+class TriConvBnSums(C.Structure):
+    _fields_ = [("y", C.c_void_p), ("relu_scale", C.c_void_p), ("relu_shift", C.c_void_p), ("relu_out", C.c_void_p), ("partial", C.c_void_p)]
+
+
 TRI_WGRAD_JOBS_MAX = 12
 TRI_ERR_ARG, TRI_ERR_UNSUPPORTED = -1, -2                   # common.h
 
@@ -65,6 +69,8 @@ SIGNATURES = {
     "tri_conv_wgrad_kernel_family": (I, [DP, I]),
     "tri_conv_fwd": (I, [DP, P, P, P, P, P, P, I, I, P, I, P, Z, P, P, P]),
     "tri_conv_dgrad": (I, [DP, P, P, P, P, P, I, I, P, Z, P, P, P]),
+    "tri_conv_dgrad_bn_records": (I, [DP, I, I]),
+    "tri_conv_dgrad_bn": (I, [DP, P, P, P, P, I, I, P, Z, P, C.POINTER(TriConvBnSums), P]),
     "tri_conv_wgrad_workspace": (Z, [DP]),
     "tri_conv_plan_bytes": (Z, [DP]),
     "tri_conv_plan_build": (I, [DP, P, P]),

@@ -15,6 +15,7 @@
 //     shortcut's gradient), fp32 sum rounded once.
 #include "common.h"
 #include <stdlib.h>
+#include "../../include/tricolo_hip.h"
 #include "conv_vox.h"
 
 int tri_internal_num_cus();                                                   // conv_igemm.hip
@@ -31,6 +32,13 @@ struct ConvC64Args {
     float* stats;              // [grid][2][64] or NULL
     int N, H, nbricks, transposed, accumulate;
     unsigned in_bytes;
+    // BatchNorm-backward sums of the NEXT pass over `out` taken here instead (data gradient; TriConvBnSums): the records then hold
+    // sum g', sum g' * y per channel with g' = the stored value where the ReLU mask passes (mode 1: y * scale + shift > 0, mode 2: ro > 0)
+    const void* bs_y;          // [N, H, W, 64] the BatchNorm's input, same storage as out
+    const void* bs_ro;         // mode 2: the saved block output
+    const float* bs_scale;     // mode 1: the forward's folded scale / shift
+    const float* bs_shift;
+    int bs_mode;               // 0 none (forward statistics: sum v, sum v^2)
 };
 
 template <int W, int TY>
@@ -50,7 +58,7 @@ struct C64Cfg {
     static_assert(2 * PITCH + 4096 < 65536, "fragment-read immediates");
 };
 
-template <typename AT, int W, int TY, bool ACCUM>
+template <typename AT, int W, int TY, bool ACCUM, bool BS>
 __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const ConvC64Args p) {
     typedef C64Cfg<W, TY> C;
     typedef typename OpOf<AT>::E E;
@@ -103,6 +111,10 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const ConvC64Args p) {
     const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
     f32x4 cs[2], cq[2];
     cs[0] = cs[1] = cq[0] = cq[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr int bsm = BS ? (ACCUM ? 2 : 1) : 0;                              // (the two forms the BasicBlock backward has: conv2's data
+                                                                               // gradient feeds relu(bn1), conv1's accumulated one relu(bn2 + x))
+    float* const bsc = (float*)(smem + C::SMEM);                               // mode 1: [2][64] scale / shift (kept out of the register file)
+    if (bsm == 1 && t < 128) bsc[t] = t < 64 ? p.bs_scale[t] : p.bs_shift[t - 64];
     // the zero pixel left and right of every slab row (written once: the fill below never touches them)
     constexpr int NZ = C::RPR * 16 - W + 2;                                    // zero pixels per slab row: x = -1 and x = W .. 16 RPR (the half-used run reads them)
     for (int i = t; i < (TY + 2) * NZ * 8; i += 256) {
@@ -143,10 +155,14 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const ConvC64Args p) {
             f32x4 acc[2];
             acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
             typedef E e4 __attribute__((ext_vector_type(4)));
-            AT* const o = (AT*)p.out + (((size_t)(n * p.H + y0 + yl) * W) + xr * 16 + fr) * 64 + 32 * c + fq * 4;
+            const size_t eo = (((size_t)(n * p.H + y0 + yl) * W) + xr * 16 + fr) * 64 + 32 * c + fq * 4;
+            AT* const o = (AT*)p.out + eo;
             const bool valid = !(W % 16) || xr * 16 + fr < W;                  // (the unused half of a 56-wide row's last run)
             e4 prev[2];                                                        // ACCUM: what `out` holds, requested before the MFMAs
             if (ACCUM && valid) { prev[0] = *(const e4*)o; prev[1] = *(const e4*)(o + 16); }
+            e4 bsy[2], bsr[2];                                                 // BatchNorm-backward sums: y (and the saved output), requested
+                                                                               // under the last kernel row's MFMAs (the registers of the
+                                                                               // finished row's fragments are free then)
             // the six fragments of a kernel row (3 kx x 2 k-steps) are read as one batch, the next row's batch is issued before this
             // row's twelve MFMAs
             v8 bf[2][6];
@@ -157,6 +173,10 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const ConvC64Args p) {
                 if (ky < 2) {
 #pragma unroll
                     for (int i = 0; i < 6; ++i) bf[(ky + 1) & 1][i] = *(const v8*)(sb + lofs[i >> 1][i & 1] + (ky + 1) * C::PITCH);
+                }
+                if (ky == 2 && bsm && valid) {
+                    bsy[0] = *(const e4*)((const AT*)p.bs_y + eo); bsy[1] = *(const e4*)((const AT*)p.bs_y + eo + 16);
+                    if (bsm == 2) { bsr[0] = *(const e4*)((const AT*)p.bs_ro + eo); bsr[1] = *(const e4*)((const AT*)p.bs_ro + eo + 16); }
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -176,9 +196,22 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const ConvC64Args p) {
                 }
                 const e4 hh = __builtin_convertvector(v, e4);
                 *(e4*)(o + 16 * ct) = hh;
-                const f32x4 rv = {(float)hh[0], (float)hh[1], (float)hh[2], (float)hh[3]};
-                cs[ct] += rv;
-                cq[ct] += rv * rv;
+                f32x4 rv = {(float)hh[0], (float)hh[1], (float)hh[2], (float)hh[3]};
+                if (bsm) {
+                    const f32x4 yv = {(float)bsy[ct][0], (float)bsy[ct][1], (float)bsy[ct][2], (float)bsy[ct][3]};
+                    f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc;
+                    if (bsm == 1) { sc = *(const f32x4*)(bsc + 32 * c + 16 * ct + 4 * fq); sh = *(const f32x4*)(bsc + 64 + 32 * c + 16 * ct + 4 * fq); }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool keep = bsm == 1 ? __fmaf_rn(yv[r], sc[r], sh[r]) > 0.f : (float)bsr[ct][r] > 0.f;
+                        rv[r] = keep ? rv[r] : 0.f;
+                    }
+                    cs[ct] += rv;
+                    cq[ct] += rv * yv;
+                } else {
+                    cs[ct] += rv;
+                    cq[ct] += rv * rv;
+                }
             }
         }
     }
@@ -236,30 +269,40 @@ bool tri_internal_c64_geometry(int B, int ID, int IH, int IW, int cin, int OD, i
     return true;
 }
 
-template <typename AT, int W, int TY, bool ACCUM>
+template <typename AT, int W, int TY, bool ACCUM, bool BS>
 static int c64_launch_t(const ConvC64Args& a, int grid, hipStream_t stream) {
     typedef C64Cfg<W, TY> C;
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute((const void*)conv_c64_kernel<AT, W, TY, ACCUM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::SMEM);
+        hipFuncSetAttribute((const void*)conv_c64_kernel<AT, W, TY, ACCUM, BS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::SMEM + 512);
         attr = true;
     }
-    conv_c64_kernel<AT, W, TY, ACCUM><<<grid, 256, C::SMEM, stream>>>(a);
+    conv_c64_kernel<AT, W, TY, ACCUM, BS><<<grid, 256, C::SMEM + 512, stream>>>(a);
     return tri_check_launch("tri_conv(c64)");
 }
 
 int tri_internal_c64_launch(const TriC64Geom& g, int B, int H, const void* in, const void* w, void* out, float* stats, int transposed,
-                            int accumulate, int act_fmt, hipStream_t stream) {
+                            int accumulate, int act_fmt, const TriConvBnSums* bs, hipStream_t stream) {
     ConvC64Args a{};
     a.in = in; a.w = w; a.out = out; a.stats = stats;
+    if (bs) {
+        a.bs_y = bs->y; a.bs_ro = bs->relu_out; a.bs_scale = bs->relu_scale; a.bs_shift = bs->relu_shift;
+        a.bs_mode = accumulate ? 2 : 1;
+        if (accumulate ? !bs->relu_out : !bs->relu_scale) {
+            tri_set_error("conv(c64): BatchNorm-backward sums come in two forms: relu_scale / relu_shift without accumulate, relu_out with it");
+            return TRI_ERR_UNSUPPORTED;
+        }
+    }
     a.N = B; a.H = H; a.nbricks = g.nbricks; a.transposed = transposed; a.accumulate = accumulate;
     a.in_bytes = (unsigned)((size_t)B * H * g.W * 128);
-#define TRI_C64(W_, TY_)                                                                                                   \
-    if (g.W == W_ && g.TY == TY_) {                                                                                        \
+#define TRI_C64_BS(W_, TY_, BS_)                                                                                           \
+    if (g.W == W_ && g.TY == TY_ && (bs != nullptr) == BS_) {                                                              \
         if (act_fmt == TRI_FMT_F16)                                                                                        \
-            return accumulate ? c64_launch_t<f16_t, W_, TY_, true>(a, g.grid, stream) : c64_launch_t<f16_t, W_, TY_, false>(a, g.grid, stream);   \
-        return accumulate ? c64_launch_t<bf16_t, W_, TY_, true>(a, g.grid, stream) : c64_launch_t<bf16_t, W_, TY_, false>(a, g.grid, stream);     \
+            return accumulate ? c64_launch_t<f16_t, W_, TY_, true, BS_>(a, g.grid, stream) : c64_launch_t<f16_t, W_, TY_, false, BS_>(a, g.grid, stream);   \
+        return accumulate ? c64_launch_t<bf16_t, W_, TY_, true, BS_>(a, g.grid, stream) : c64_launch_t<bf16_t, W_, TY_, false, BS_>(a, g.grid, stream);     \
     }
+    // (the sums forms only where they fit the register file: the 56- / 64-wide bricks spill with them and config 5 lost 0.2 ms)
+#define TRI_C64(W_, TY_) TRI_C64_BS(W_, TY_, false) if (W_ <= 32) { TRI_C64_BS(W_ <= 32 ? W_ : 32, W_ <= 32 ? TY_ : 4, true) }
     TRI_C64(32, 4)
     TRI_C64(32, 2)
     TRI_C64(64, 2)
@@ -268,7 +311,8 @@ int tri_internal_c64_launch(const TriC64Geom& g, int B, int H, const void* in, c
     TRI_C64(56, 1)
     TRI_C64(16, 8)
     TRI_C64(16, 4)
+#undef TRI_C64_BS
 #undef TRI_C64
-    tri_set_error("conv(c64): brick shape not instantiated");
+    tri_set_error("conv(c64): brick shape not instantiated (BatchNorm-backward sums: 16- and 32-wide images only)");
     return TRI_ERR_UNSUPPORTED;
 }

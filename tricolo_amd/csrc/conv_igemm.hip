@@ -2188,7 +2188,7 @@ static int launch_dma_any(const ConvArgs& a, int bn, hipStream_t stream) {
     }
 }
 
-static int conv_dispatch(ConvArgs& a, int act_fmt, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+static int conv_dispatch(ConvArgs& a, int act_fmt, void* workspace, size_t workspace_bytes, hipStream_t stream, const TriConvBnSums* bs = nullptr) {
     if (a.Cin % 4 != 0) { tri_set_error("conv: stored input channels must be a multiple of 4"); return TRI_ERR_ARG; }
     if (a.Cout % 32 != 0) { tri_set_error("conv: output channels must be a multiple of 32"); return TRI_ERR_ARG; }
     if (a.ntaps > 64) { tri_set_error("conv: more than 64 taps unsupported"); return TRI_ERR_UNSUPPORTED; }
@@ -2254,13 +2254,17 @@ static int conv_dispatch(ConvArgs& a, int act_fmt, void* workspace, size_t works
         if (!a.row_mask && !a.row_count && !a.bias && a.act == 0) {
             TriC64Geom cg;
             tri_internal_c64_geometry(a.B, a.ID, a.IH, a.IW, a.Cin, a.OD, a.OH, a.OW, a.Cout, a.KD, a.KH, a.KW, a.stride, a.pd, a.ph, a.pw, &cg);
-            return tri_internal_c64_launch(cg, a.B, a.IH, a.in, a.w_hi, a.out, a.stats, a.transposed, a.accumulate, act_fmt, stream);
+            return tri_internal_c64_launch(cg, a.B, a.IH, a.in, a.w_hi, a.out, bs ? bs->partial : a.stats, a.transposed, a.accumulate, act_fmt, bs, stream);
         }
         if (a.stats) {                                                // (the record count of this layer is conv_c64_kernel's)
             tri_set_error("conv: this layer runs conv_c64_kernel (tri_conv_kernel_family == 9): statistics only without row mask / bias / activation");
             return TRI_ERR_ARG;
         }
         a.row_pos = a.row_count ? a.row_pos : nullptr;
+    }
+    if (bs) {
+        tri_set_error("conv: this layer's data-gradient kernel takes no BatchNorm-backward sums (tri_conv_dgrad_bn_records == 0)");
+        return TRI_ERR_UNSUPPORTED;
     }
     if (pl.stem && !a.transposed && !a.row_mask && !a.row_count && !a.bias && a.act == 0 && !a.accumulate) {
         a.row_pos = nullptr;
@@ -2370,4 +2374,36 @@ extern "C" int tri_conv_dgrad(const TriConvDesc* d, const void* dout, const void
     a.ntaps = d->KD * d->KH * d->KW;
     a.M = d->B * d->ID * d->IH * d->IW;
     return conv_dispatch(a, act_fmt, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// Data gradient + the BatchNorm-backward sums of the pass that would read din next (include/tricolo_hip.h, TriConvBnSums)
+extern "C" int tri_conv_dgrad_bn_records(const TriConvDesc* d, int accumulate, int act_fmt) {
+    (void)accumulate;
+    if (act_fmt != TRI_FMT_BF16 && act_fmt != TRI_FMT_F16) return 0;
+    ConvPlan pl = conv_make_plan(d->B, d->OD, d->OH, d->OW, d->Cout, d->ID, d->IH, d->IW, d->Cin, d->KD, d->KH, d->KW, d->stride, d->pad_d,
+                                 d->pad_h, d->pad_w, 2, 0);
+    if (pl.c64 && d->IW <= 32) return pl.c64_grid;              // (conv_c64.hip: the sums forms exist for 16- and 32-wide images)
+    return 0;
+}
+extern "C" int tri_conv_dgrad_bn(const TriConvDesc* d, const void* dout, const void* wt_hi, const void* wt_lo, void* din, int accumulate,
+                                 int act_fmt, void* workspace, size_t workspace_bytes, const int* row_pos, const TriConvBnSums* sums,
+                                 void* stream) {
+    if (!sums || !sums->y || !sums->partial || (!sums->relu_scale != !sums->relu_shift) || (sums->relu_scale && sums->relu_out)) {
+        tri_set_error("tri_conv_dgrad_bn: sums needs y, partial and at most one of (relu_scale + relu_shift) / relu_out");
+        return TRI_ERR_ARG;
+    }
+    if (tri_conv_dgrad_bn_records(d, accumulate, act_fmt) == 0) {
+        tri_set_error("tri_conv_dgrad_bn: no fused form for this layer (tri_conv_dgrad_bn_records == 0)");
+        return TRI_ERR_UNSUPPORTED;
+    }
+    ConvArgs a{};
+    a.in = dout; a.w_hi = wt_hi; a.w_lo = wt_lo; a.out = din;
+    a.row_pos = row_pos;
+    a.B = d->B; a.ID = d->OD; a.IH = d->OH; a.IW = d->OW; a.Cin = d->Cout;
+    a.OD = d->ID; a.OH = d->IH; a.OW = d->IW; a.Cout = d->Cin;
+    a.KD = d->KD; a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pd = d->pad_d; a.ph = d->pad_h; a.pw = d->pad_w;
+    a.transposed = 1; a.act = 0; a.accumulate = accumulate;
+    a.ntaps = d->KD * d->KH * d->KW;
+    a.M = d->B * d->ID * d->IH * d->IW;
+    return conv_dispatch(a, act_fmt, workspace, workspace_bytes, (hipStream_t)stream, sums);
 }

@@ -30,5 +30,6 @@ struct TriC64Geom { int W, TY, nbricks, grid; };
 // conv_c64_kernel (conv_c64.hip), forward and data gradient; g->grid = persistent workgroups = BatchNorm records of the launch
 bool tri_internal_c64_geometry(int B, int ID, int IH, int IW, int cin, int OD, int OH, int OW, int cout, int KD, int KH, int KW, int stride,
                                int pd, int ph, int pw, TriC64Geom* g);
+struct TriConvBnSums;                                                         // include/tricolo_hip.h
 int tri_internal_c64_launch(const TriC64Geom& g, int B, int H, const void* in, const void* w, void* out, float* stats, int transposed,
-                            int accumulate, int act_fmt, hipStream_t stream);
+                            int accumulate, int act_fmt, const TriConvBnSums* bs, hipStream_t stream);

@@ -241,12 +241,14 @@ class MVCNNEncoder(TriModule):
             with torch.cuda.stream(side.fork(x, dy)):
                 gr[w] = ops.conv_wgrad(x, dy, g, w, prec, out_scale=ugs)
 
-        for blk, sv in zip(reversed(blocks), reversed(saved_blocks)):
+        dout_sums = None                       # BatchNorm-backward sums of bn2 taken by the data gradient that produced dout
+        for bi in range(len(blocks) - 1, -1, -1):
+            blk, sv = blocks[bi], saved_blocks[bi]
             x, y1, co1, g1, a1, y2, co2, g2, yd, cod, gd, out = sv
             # relu(bn2(y2) + residual) backward inside the BN passes; g = dout * (out > 0) (gradient of the pre-activation sum,
             # also the residual branch's gradient) is written by the apply pass in place of dout
             dy2, gr[blk.bn2.weight], gr[blk.bn2.bias] = ops.bn_bwd(y2, dout, co2, blk.bn2.weight, count_host=g2.M, inplace=False,
-                                                                   relu_out=out, g_masked=dout, out_scale=ugs)
+                                                                   relu_out=out, g_masked=dout, out_scale=ugs, partial=dout_sums)
             g = dout
             if blk.downsample is not None:                         # shortcut branch next to the conv2 / conv1 chain
                 with torch.cuda.stream(self._side_ds.fork(g, yd)):
@@ -256,9 +258,11 @@ class MVCNNEncoder(TriModule):
                         gr[blk.downsample[0].weight] = ops.conv_wgrad(x, dyd, gd, blk.downsample[0].weight, prec, out_scale=ugs)
                     dx = ops.conv_dgrad(dyd, gd, self._packed[(id(blk.downsample[0]), True)])
             wgrad_async(a1, dy2, g2, blk.conv2.weight)
-            da1 = ops.conv_dgrad(dy2, g2, self._packed[(id(blk.conv2), True)])
-            # relu(bn1(y1)) backward: the ReLU mask is recomputed from y1 inside the BN passes (no relu_bwd pass over a1)
-            dy1, gr[blk.bn1.weight], gr[blk.bn1.bias] = ops.bn_bwd(y1, da1, co1, blk.bn1.weight, count_host=g1.M, relu=True, out_scale=ugs)
+            # relu(bn1(y1)) backward: the ReLU mask is recomputed from y1 inside the BN passes (no relu_bwd pass over a1); where conv2's
+            # data-gradient kernel can, it takes bn1's sums in its epilogue (no reduce pass over da1 / y1)
+            da1, sums1 = ops.conv_dgrad(dy2, g2, self._packed[(id(blk.conv2), True)], bn_sums=(y1, co1, None))
+            dy1, gr[blk.bn1.weight], gr[blk.bn1.bias] = ops.bn_bwd(y1, da1, co1, blk.bn1.weight, count_host=g1.M, relu=True, out_scale=ugs,
+                                                                   partial=sums1)
             wgrad_async(x, dy1, g1, blk.conv1.weight)
             if blk.downsample is not None:
                 if batch is None:
@@ -268,7 +272,13 @@ class MVCNNEncoder(TriModule):
                     gr[blk.downsample[0].weight] = ops.conv_wgrad(x, dyd, gd, blk.downsample[0].weight, prec, out_scale=ugs, batch=batch)
             else:
                 dx = g                                                         # identity branch
-            dx = ops.conv_dgrad(dy1, g1, self._packed[(id(blk.conv1), True)], out=dx, accumulate=True)
+            # conv1's data gradient completes dx = the previous block's dout: that block's bn2 sums (mask: its saved output = this x)
+            if bi > 0:
+                prev = saved_blocks[bi - 1]
+                dx, dout_sums = ops.conv_dgrad(dy1, g1, self._packed[(id(blk.conv1), True)], out=dx, accumulate=True,
+                                               bn_sums=(prev[5], None, prev[11]))
+            else:
+                dx, dout_sums = ops.conv_dgrad(dy1, g1, self._packed[(id(blk.conv1), True)], out=dx, accumulate=True), None
             dout = dx
         side.join(*[v for v in gr.values() if v.dim() == 4])
         return dout

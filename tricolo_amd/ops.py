@@ -223,6 +223,14 @@ class ConvGeom:
         row_mask, not a compact row list."""
         return bool(self.kernel_family[(transposed, mode)] >> 16 & 1)
 
+    def dgrad_bn_records(self, accumulate: bool, fmt: int) -> int:
+        """Records tri_conv_dgrad_bn writes for this layer (0: its data-gradient kernel has no fused BatchNorm-backward sums), cached."""
+        c = self.__dict__.setdefault("_dgrad_bn", {})
+        k = (bool(accumulate), fmt)
+        if k not in c:
+            c[k] = int(lib().tri_conv_dgrad_bn_records(_C.C.byref(self.desc), 1 if accumulate else 0, fmt))
+        return c[k]
+
     def wgrad_group(self, fmt: int):
         """(family, tiles, steps) of this layer's weight gradient for WgradBatch.add_job (tri_conv_wgrad_group_info), cached."""
         c = self.__dict__.setdefault("_wgrad_group", {})
@@ -332,7 +340,13 @@ def conv_fwd(x, g: ConvGeom, packed, row_mask=None, bias=None, act=0, want_stats
 _ROW_ORDER = os.environ.get("TRICOLO_NO_ROW_ORDER", "0") != "1"      # A/B switch: parity-class row order for stride-2 data gradients
 
 
-def conv_dgrad(dout, g: ConvGeom, packed_t, row_mask=None, out=None, accumulate=False, rows=None):
+_DGRAD_BN = os.environ.get("TRICOLO_DGRAD_BN", "1") != "0"       # A/B switch: BatchNorm-backward sums as a pass of their own everywhere
+
+
+def conv_dgrad(dout, g: ConvGeom, packed_t, row_mask=None, out=None, accumulate=False, rows=None, bn_sums=None):
+    """Data gradient.  bn_sums = (y, BNCoeffs | None, relu_out | None): the caller's next pass over the result is the BatchNorm-backward
+    reduce of the BatchNorm that consumed y; where the layer's kernel can take those sums in its epilogue (tri_conv_dgrad_bn_records)
+    the call returns (din, partial) and bn_bwd(..., partial=partial) skips its reduce launch, otherwise (din, None)."""
     hi, lo = packed_t
     ID, IH, IW = g.in_grid
     if out is None:
@@ -342,6 +356,22 @@ def conv_dgrad(dout, g: ConvGeom, packed_t, row_mask=None, out=None, accumulate=
     rowpos = g.dgrad_row_order(dout.device) if (row_mask is None and rows is None and _ROW_ORDER) else None
     if rows is not None:
         rowpos = rows[0]
+    if bn_sums is not None:
+        y, co, relu_out = bn_sums
+        nrec = g.dgrad_bn_records(accumulate, _abf(dout)) if (_DGRAD_BN and row_mask is None and rows is None and lo is None
+                                                               and (relu_out is not None) == bool(accumulate)
+                                                               and (co is not None) != (relu_out is not None)) else 0
+        if nrec == 0:
+            return conv_dgrad(dout, g, packed_t, row_mask=row_mask, out=out, accumulate=accumulate, rows=rows), None
+        assert y.dtype == out.dtype and y.numel() == out.numel()
+        partial = torch.empty((nrec, 2, g.cin_stored), dtype=torch.float32, device=dout.device)
+        sums = _C.TriConvBnSums(ptr(y), ptr(co.scale) if co is not None else None, ptr(co.shift) if co is not None else None,
+                                ptr(relu_out), ptr(partial))
+        check(_timed(_igemm_symbol(g, True, False, dout), g.flops,
+                     lambda: lib().tri_conv_dgrad_bn(_C.C.byref(g.desc), ptr(_act(dout)), ptr(hi), None, ptr(out), 1 if accumulate else 0,
+                                                     _abf(dout), ptr(ws), ws.numel() if ws is not None else 0, ptr(rowpos),
+                                                     _C.C.byref(sums), stream())), "tri_conv_dgrad_bn")
+        return out, partial
     check(_timed(_igemm_symbol(g, True, lo is not None, dout), g.flops,
                  lambda: lib().tri_conv_dgrad(_C.C.byref(g.desc), ptr(_act(dout)), ptr(hi), ptr(lo), ptr(out), ptr(row_mask),
                                               1 if accumulate else 0, _abf(dout), ptr(ws), ws.numel() if ws is not None else 0,
@@ -608,7 +638,7 @@ def _bn_bwd_finalize(partial, nblk, C, count_dev, count_host, gamma, co: "BNCoef
 
 
 def bn_bwd(y, g, co: BNCoeffs, gamma, count_dev=None, count_host=0, row_mask=None, inplace=True, relu=False, relu_out=None,
-           g_masked=None, out_scale: float = 1.0, keep_inactive: bool = False):
+           g_masked=None, out_scale: float = 1.0, keep_inactive: bool = False, partial=None):
     # row_mask: rows with 0 are never read by either pass (their y / g may be unwritten) and come out as zeros in dy
     """Returns (dy, dgamma, dbeta).  g = gradient w.r.t. the BN output (already activation-masked), or - with relu=True -
     w.r.t. relu(bn(y)): the ReLU mask is then recomputed from y inside the two passes (no separate relu_bwd pass), or -
@@ -618,11 +648,15 @@ def bn_bwd(y, g, co: BNCoeffs, gamma, count_dev=None, count_host=0, row_mask=Non
     rs, rb = (co.scale, co.shift) if relu else (None, None)
     C = y.shape[-1]
     M = y.numel() // C
-    nblk = lib().tri_bn_bwd_num_blocks(M)
-    partial = torch.empty((nblk, 2, C), dtype=torch.float32, device=y.device)
     assert y.dtype == g.dtype
-    check(lib().tri_bn_bwd_reduce(ptr(_act(y)), ptr(_act(g)), M, C, ptr(partial), ptr(rs), ptr(rb), ptr(relu_out), ptr(row_mask), _abf(y), stream()),
-          "tri_bn_bwd_reduce")
+    if partial is not None:                          # the sums came out of the data gradient that produced g (conv_dgrad(bn_sums=...))
+        assert row_mask is None and partial.shape[1:] == (2, C)
+        nblk = partial.shape[0]
+    else:
+        nblk = lib().tri_bn_bwd_num_blocks(M)
+        partial = torch.empty((nblk, 2, C), dtype=torch.float32, device=y.device)
+        check(lib().tri_bn_bwd_reduce(ptr(_act(y)), ptr(_act(g)), M, C, ptr(partial), ptr(rs), ptr(rb), ptr(relu_out), ptr(row_mask), _abf(y), stream()),
+              "tri_bn_bwd_reduce")
     buf = _bn_bwd_finalize(partial, nblk, C, count_dev, count_host, gamma, co, out_scale)
     dy = g if inplace else torch.empty_like(g)
     check(lib().tri_bn_bwd_apply(ptr(y), ptr(g), ptr(buf[2]), ptr(buf[3]), ptr(buf[4]), ptr(row_mask), ptr(dy), M, C, ptr(rs), ptr(rb),
