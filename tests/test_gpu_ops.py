@@ -710,6 +710,11 @@ BF16_CASES = [c for c in CONV_CASES if c[0] in ("vox_l0", "vox_l1", "vox_l3", "s
     ("c64k_16", 5, (1, 16, 16), 64, 64, (1, 3, 3), 1, (0, 1, 1), "torch"),
     ("c64k_32x12", 3, (1, 12, 32), 64, 64, (1, 3, 3), 1, (0, 1, 1), "torch"),
     ("c64k_many", 140, (1, 32, 32), 64, 64, (1, 3, 3), 1, (0, 1, 1), "torch"),
+    # conv_s2d_kernel (data gradient of the 64 -> 128 channel 3x3 / 2 layer, four parity classes from one slab): 16- and 32-pixel dOut rows,
+    # more bricks than persistent workgroups (300 x 8 = 2,400 bricks of two rows)
+    ("s2d_16", 5, (1, 32, 32), 64, 128, (1, 3, 3), 2, (0, 1, 1), "torch"),
+    ("s2d_32", 2, (1, 64, 64), 64, 128, (1, 3, 3), 2, (0, 1, 1), "torch"),
+    ("s2d_many", 300, (1, 32, 32), 64, 128, (1, 3, 3), 2, (0, 1, 1), "torch"),
 ]
 
 
@@ -737,6 +742,20 @@ def test_conv_16bit_storage_integer_exact(case, store, prec):
     if case[3] != 3:
         dx = ops.conv_dgrad(cl3(dy).to(DEV).to(store), g, ops.pack_weight(wp.to(DEV), g, prec, transposed=True))
         assert torch.equal(dx.cpu(), cl3(xr.grad).to(store))
+    if case[0].startswith("s2d"):
+        assert (g.kernel_family[(True, 2)] & 255) == 10                  # conv_s2d_kernel
+        tp = ops.pack_weight(wp.to(DEV), g, prec, transposed=True)
+        base = ints(tuple(cl3(xr.grad).shape), -5, 5, 59)
+        dx2 = ops.conv_dgrad(cl3(dy).to(DEV).to(store), g, tp, out=base.clone().to(DEV).to(store), accumulate=True)
+        assert torch.equal(dx2.cpu(), (cl3(xr.grad) + base).to(store))
+        for ty in ("4", "8") if case[0] == "s2d_16" else (("4",) if case[0] == "s2d_32" else ()):     # the larger bricks (batches of hundreds)
+            os.environ["TRICOLO_S2D_TY"] = ty
+            try:
+                dx3 = ops.conv_dgrad(cl3(dy).to(DEV).to(store), g, tp)
+                dx4 = ops.conv_dgrad(cl3(dy).to(DEV).to(store), g, tp, out=base.clone().to(DEV).to(store), accumulate=True)
+            finally:
+                del os.environ["TRICOLO_S2D_TY"]
+            assert torch.equal(dx3.cpu(), cl3(xr.grad).to(store)) and torch.equal(dx4.cpu(), (cl3(xr.grad) + base).to(store))
     if case[0].startswith("stem"):
         # one BatchNorm record per persistent workgroup of conv_stem_kernel: their sum is the whole tensor's column sum
         assert (g.kernel_family[(False, 2)] & 255) == 4

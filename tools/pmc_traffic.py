@@ -45,9 +45,12 @@ def symbol(d):
     m = re.match(r"conv_stem_wgrad_kernel<(\d+), (\w+), \w+>", d)                  # (with / without the folded BatchNorm apply pass)
     if m:
         return f"conv_stem_wgrad_kernel<{m.group(1)}, {m.group(2)}>"
-    m = re.match(r"conv_c64_kernel<(\w+), \d+, \d+, \w+>", d)
+    m = re.match(r"conv_c64_kernel<(\w+), \d+, \d+, \w+, \w+>", d)             # (brick shape, accumulate, BatchNorm-backward sums)
     if m:
         return f"conv_c64_kernel<{m.group(1)}>"
+    m = re.match(r"conv_s2d_kernel<(\w+), \d+, \d+, \w+>", d)
+    if m:
+        return f"conv_s2d_kernel<{m.group(1)}>"
     m = re.match(r"conv_vox0_wgrad_kernel<(\w+), \d+, \d+>", d)
     if m:
         return f"conv_vox0_wgrad_kernel<{m.group(1)}>"

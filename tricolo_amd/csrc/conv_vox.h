@@ -30,6 +30,12 @@ struct TriC64Geom { int W, TY, nbricks, grid; };
 // conv_c64_kernel (conv_c64.hip), forward and data gradient; g->grid = persistent workgroups = BatchNorm records of the launch
 bool tri_internal_c64_geometry(int B, int ID, int IH, int IW, int cin, int OD, int OH, int OW, int cout, int KD, int KH, int KW, int stride,
                                int pd, int ph, int pw, TriC64Geom* g);
+// data gradient of a 64 -> 128 channel 3x3 / 2 / pad 1 2D layer (GEMM view: 128 -> 64 channels onto a grid twice as large), dOut rows of
+// 16 / 32 pixels, 16-bit storage: conv_s2d_kernel (conv_c64.hip)
+bool tri_internal_s2d_geometry(int B, int ID, int IH, int IW, int cin, int OD, int OH, int OW, int cout, int KD, int KH, int KW, int stride,
+                               int pd, int ph, int pw, TriC64Geom* g);
+int tri_internal_s2d_launch(const TriC64Geom& g, int B, int H, const void* in, const void* w, void* out, int accumulate, int act_fmt,
+                            hipStream_t stream);
 struct TriConvBnSums;                                                         // include/tricolo_hip.h
 int tri_internal_c64_launch(const TriC64Geom& g, int B, int H, const void* in, const void* w, void* out, float* stats, int transposed,
                             int accumulate, int act_fmt, const TriConvBnSums* bs, hipStream_t stream);
