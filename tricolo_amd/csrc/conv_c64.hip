@@ -126,6 +126,16 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const ConvC64Args p) {
 #pragma unroll 1
     for (int j = wg; j < p.nbricks; j += G) {
         const int n = j / bpi, y0 = (j - n * bpi) * TY;
+        // sums forms: the brick's y (and saved-output) tile is touched now, one 128-byte pixel per thread, so that the epilogue's loads -
+        // issued only under the last kernel row's MFMAs, the register file is full - find it in L2 instead of HBM (in the step y was
+        // written a whole forward ago: the exposed latency made the fused form as slow as the reduce pass it replaces)
+        unsigned warm = 0;
+        if (bsm) {
+            constexpr int LINES = TY * W;                                      // pixels of the brick (<= 128)
+            const size_t b0 = ((size_t)(n * p.H + y0) * W) * 64;
+            if (t < LINES) warm = *(const unsigned*)((const AT*)p.bs_y + b0 + (size_t)t * 64);
+            else if (bsm == 2 && t < 2 * LINES) warm = *(const unsigned*)((const AT*)p.bs_ro + b0 + (size_t)(t - LINES) * 64);
+        }
         __syncthreads();                                                       // every wave is done with the previous slab
         {
             uint4 pre[C::MAXC];
@@ -146,6 +156,7 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const ConvC64Args p) {
             for (int u = 0; u < C::MAXC; ++u)
                 if (dst[u] >= 0) *(uint4*)(slab + dst[u]) = pre[u];
         }
+        if (bsm) asm volatile("" :: "v"(warm));                                // (the touch only has to have been issued)
         __syncthreads();
 
 #pragma unroll 1

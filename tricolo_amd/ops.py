@@ -342,7 +342,11 @@ def conv_fwd(x, g: ConvGeom, packed, row_mask=None, bias=None, act=0, want_stats
 _ROW_ORDER = os.environ.get("TRICOLO_NO_ROW_ORDER", "0") != "1"      # A/B switch: parity-class row order for stride-2 data gradients
 
 
-_DGRAD_BN = os.environ.get("TRICOLO_DGRAD_BN", "1") != "0"       # A/B switch: BatchNorm-backward sums as a pass of their own everywhere
+# A/B switch: 0 = BatchNorm-backward sums as a pass of their own everywhere, 2 (default) = only the relu(bn1) form inside conv2's data
+# gradient, 1 = also the relu(bn2 + x) form inside the accumulated conv1 gradient (reads y AND the saved output cold: 40.0 us against
+# 38.3 us for data gradient + reduce pass, tools/dgrad_bn_bench.py; the relu(bn1) form 27.0 against 31.2)
+_DGRAD_BN_MODE = os.environ.get("TRICOLO_DGRAD_BN", "2")
+_DGRAD_BN = _DGRAD_BN_MODE != "0"
 
 
 def conv_dgrad(dout, g: ConvGeom, packed_t, row_mask=None, out=None, accumulate=False, rows=None, bn_sums=None):
@@ -360,7 +364,7 @@ def conv_dgrad(dout, g: ConvGeom, packed_t, row_mask=None, out=None, accumulate=
         rowpos = rows[0]
     if bn_sums is not None:
         y, co, relu_out = bn_sums
-        nrec = g.dgrad_bn_records(accumulate, _abf(dout)) if (_DGRAD_BN and row_mask is None and rows is None and lo is None
+        nrec = g.dgrad_bn_records(accumulate, _abf(dout)) if (_DGRAD_BN and not (accumulate and _DGRAD_BN_MODE == "2") and row_mask is None and rows is None and lo is None
                                                                and (relu_out is not None) == bool(accumulate)
                                                                and (co is not None) != (relu_out is not None)) else 0
         if nrec == 0:
