@@ -795,8 +795,12 @@ def test_conv_16bit_storage_integer_exact(case, store, prec):
             np.testing.assert_allclose(st[0].numpy(), gm.reshape(-1, case[3]).sum(0).numpy(), rtol=1e-6, atol=1e-2)
             np.testing.assert_allclose(st[1].numpy(), (gm * yv.double()).reshape(-1, case[3]).sum(0).numpy(), rtol=1e-6, atol=1e-2)
             ro = ints(tuple(yv.shape), -1, 2, 69)
-            dx4, part = ops.conv_dgrad(cl3(dy).to(DEV).to(store), g, tp, out=base.clone().to(DEV).to(store), accumulate=True,
-                                       bn_sums=(yv.to(DEV).to(store), None, ro.to(DEV).to(store)))
+            mode, ops._DGRAD_BN_MODE = ops._DGRAD_BN_MODE, "1"               # (the accumulated form is off by default: TRICOLO_DGRAD_BN=2)
+            try:
+                dx4, part = ops.conv_dgrad(cl3(dy).to(DEV).to(store), g, tp, out=base.clone().to(DEV).to(store), accumulate=True,
+                                           bn_sums=(yv.to(DEV).to(store), None, ro.to(DEV).to(store)))
+            finally:
+                ops._DGRAD_BN_MODE = mode
             assert part is not None and torch.equal(dx4.cpu(), (cl3(xr.grad) + base).to(store))
             gm = (cl3(xr.grad) + base).to(store).double() * (ro > 0).double()
             st = part.cpu().double().sum(0)
