@@ -11,6 +11,7 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 # conv_wgrad_c64_kernel is planned from 12 row tiles per CU on (conv_wgrad.hip c64_wgrad_geometry); the exactness cases c64_32 /
 # c64_56 of test_gpu_ops.py are sized for 6 (a CPU reference at 12 would be twice as long): the library reads the switch once per process
 os.environ.setdefault("TRICOLO_C64_MIN_TILES_PER_CU", "6")
+os.environ.setdefault("TRICOLO_S2F_CONV", "1")            # conv_s2f_kernel is opt-in (measured slower in the step): the tests keep it covered
 
 
 def pytest_configure(config):

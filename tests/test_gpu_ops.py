@@ -744,6 +744,22 @@ def test_conv_16bit_storage_integer_exact(case, store, prec):
         assert torch.equal(dx.cpu(), cl3(xr.grad).to(store))
     if case[0].startswith("s2d"):
         assert (g.kernel_family[(True, 2)] & 255) == 10                  # conv_s2d_kernel
+        # ... and the forward of the same layer on conv_s2f_kernel: BatchNorm records (one per persistent workgroup), the taller bricks
+        assert (g.kernel_family[(False, 2)] & 255) == 11
+        for ty in (None,) + ((("4",) if case[0] == "s2d_16" else ("1",)) if case[0] != "s2d_many" else ()):
+            if ty:
+                os.environ["TRICOLO_S2F_TY"] = ty
+            try:
+                g2 = make_case(case, integer=True, seed=51)[4] if ty else g      # (records of the forced brick height)
+                out2, stats = ops.conv_fwd(xcl.to(DEV).to(store), g2, packed, want_stats=True)
+            finally:
+                if ty:
+                    del os.environ["TRICOLO_S2F_TY"]
+            assert torch.equal(out2.cpu(), ref.to(store))
+            exact = ref.to(store).double().reshape(-1, case[4])
+            st = stats.cpu().double().sum(0)
+            np.testing.assert_allclose(st[0].numpy(), exact.sum(0).numpy(), rtol=1e-6, atol=1e-2)
+            np.testing.assert_allclose(st[1].numpy(), (exact ** 2).sum(0).numpy(), rtol=1e-6, atol=1e-2)
         tp = ops.pack_weight(wp.to(DEV), g, prec, transposed=True)
         base = ints(tuple(cl3(xr.grad).shape), -5, 5, 59)
         dx2 = ops.conv_dgrad(cl3(dy).to(DEV).to(store), g, tp, out=base.clone().to(DEV).to(store), accumulate=True)

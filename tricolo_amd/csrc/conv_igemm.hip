@@ -1825,6 +1825,7 @@ struct ConvPlan {
     int vox1_grid;
     int c64;              // 1: conv_c64_kernel (conv_c64.hip: 64 -> 64 channels, 2D 3x3 / 1 / pad 1, 16-bit storage); records = c64_grid
     int c64_grid;
+    int s2f, s2f_grid;    // 1: conv_s2f_kernel (conv_c64.hip: forward of the 64 -> 128 channel 3x3 / 2 layer); records = s2f_grid
     int s2d;              // 1: conv_s2d_kernel (conv_c64.hip: data gradient of a 64 -> 128 channel 3x3 / 2 layer, 16-bit storage)
     int dma;              // 1: LDS-DMA kernel (16-bit activation storage, Cin % 64 == 0), 64-wide k-steps
     int nunits;           // k-steps (32 wide, or 64 wide for the DMA kernel)
@@ -2004,6 +2005,9 @@ static ConvPlan conv_make_plan(int B, int ID, int IH, int IW, int cin, int OD, i
         // GEMM view of a data-gradient call (the output grid is twice the input grid: no forward layer looks like this)
         if (pl.dma && split_mode == 2 && tri_internal_s2d_geometry(B, ID, IH, IW, cin, OD, OH, OW, cout, KD, KH, KW, stride, pd, ph, pw, &sg))
             pl.s2d = 1;                                                        // (a call with a row mask / list takes conv_dma_kernel: its plan below)
+        if (pl.dma && split_mode == 2 && !row_list && tri_internal_s2f_geometry(B, ID, IH, IW, cin, OD, OH, OW, cout, KD, KH, KW, stride, pd, ph, pw, &sg)) {
+            pl.s2f = 1; pl.s2f_grid = sg.grid;                                 // (likewise; a call that wants statistics must qualify)
+        }
     }
     if (pl.dma && cout % 64 == 0 && !halo_disabled() && KD == 1 && KH == 3 && KW == 3 && stride == 1 && pd == 0 && ph == 1 && pw == 1 && ID == 1 && OD == 1 &&
         IH == OH && IW == OW && (long)B * IH * IW * cin * 2 < ((long)1 << 31)) {
@@ -2269,6 +2273,17 @@ static int conv_dispatch(ConvArgs& a, int act_fmt, void* workspace, size_t works
         }
         a.row_pos = a.row_count ? a.row_pos : nullptr;
     }
+    if (pl.s2f && !a.transposed) {
+        if (!a.row_mask && !a.row_count && !a.bias && a.act == 0 && !a.accumulate) {
+            TriC64Geom sg;
+            tri_internal_s2f_geometry(a.B, a.ID, a.IH, a.IW, a.Cin, a.OD, a.OH, a.OW, a.Cout, a.KD, a.KH, a.KW, a.stride, a.pd, a.ph, a.pw, &sg);
+            return tri_internal_s2f_launch(sg, a.B, a.OH, a.in, a.w_hi, a.out, a.stats, act_fmt, stream);
+        }
+        if (a.stats) {                                                // (the record count of this layer is conv_s2f_kernel's)
+            tri_set_error("conv: this layer runs conv_s2f_kernel (tri_conv_kernel_family == 11): statistics only without row mask / bias / activation / accumulate");
+            return TRI_ERR_ARG;
+        }
+    }
     if (pl.s2d && a.transposed && !bs && !a.row_mask && !a.row_count && !a.bias && a.act == 0 && !a.stats) {
         TriC64Geom sg;
         tri_internal_s2d_geometry(a.B, a.ID, a.IH, a.IW, a.Cin, a.OD, a.OH, a.OW, a.Cout, a.KD, a.KH, a.KW, a.stride, a.pd, a.ph, a.pw, &sg);
@@ -2310,6 +2325,7 @@ extern "C" int tri_conv_num_records(const TriConvDesc* d, int split3, int row_li
     if (pl.vox0) return pl.vox0_grid;
     if (pl.vox1) return pl.vox1_grid;
     if (pl.c64) return pl.c64_grid;
+    if (pl.s2f) return pl.s2f_grid;
     if (pl.halo) return pl.h_wgrec ? pl.h_grid / (d->Cout / 64) : pl.h_mtiles;
     return pl.ksplit > 1 ? (int)((M + 31) / 32) : (int)((M + 127) / 128);
 }
@@ -2326,6 +2342,7 @@ extern "C" int tri_conv_kernel_family(const TriConvDesc* d, int transposed, int 
     if (pl.vox1 && !transposed) return 7 | (64 << 8);
     if (pl.c64) return 9 | (64 << 8);
     if (pl.s2d && transposed) return 10 | (64 << 8);
+    if (pl.s2f && !transposed) return 11 | (128 << 8);
     if (pl.halo) return (pl.h_v5 ? 5 : 3) | (pl.halo << 8);
     return (pl.dma ? 2 : 0) | (pl.bn << 8) | ((pl.ksplit > 1 || (pl.dma && tri_conv_kpad(d->KD * d->KH * d->KW, transposed ? d->Cout : d->Cin) / 64 > 256)) ? (1 << 16) : 0);
 }

@@ -36,6 +36,12 @@ bool tri_internal_s2d_geometry(int B, int ID, int IH, int IW, int cin, int OD, i
                                int pd, int ph, int pw, TriC64Geom* g);
 int tri_internal_s2d_launch(const TriC64Geom& g, int B, int H, const void* in, const void* w, void* out, int accumulate, int act_fmt,
                             hipStream_t stream);
+// forward of the same layer (64 -> 128 channels, 3x3 / 2 / pad 1, output rows of 16 / 32 pixels): conv_s2f_kernel (conv_c64.hip);
+// g->grid = persistent workgroups = BatchNorm records of the launch
+bool tri_internal_s2f_geometry(int B, int ID, int IH, int IW, int cin, int OD, int OH, int OW, int cout, int KD, int KH, int KW, int stride,
+                               int pd, int ph, int pw, TriC64Geom* g);
+int tri_internal_s2f_launch(const TriC64Geom& g, int B, int OH, const void* in, const void* w, void* out, float* stats, int act_fmt,
+                            hipStream_t stream);
 struct TriConvBnSums;                                                         // include/tricolo_hip.h
 int tri_internal_c64_launch(const TriC64Geom& g, int B, int H, const void* in, const void* w, void* out, float* stats, int transposed,
                             int accumulate, int act_fmt, const TriConvBnSums* bs, hipStream_t stream);
