@@ -98,7 +98,9 @@ int tri_conv_num_records(const TriConvDesc* d, int split3, int row_list);
 /* kernel family tri_conv_fwd (transposed = 0) / tri_conv_dgrad (transposed = 1) dispatches for this layer and mode:
  * 0 conv_igemm_kernel (register-staged im2col), 2 conv_dma_kernel (LDS-DMA staging); bits 8.. hold the output-channel
  * tile width; bit 16 set = the dense call of the layer runs split-K in this mode; 4 conv_stem_kernel, 3 / 5 the halo kernels,
- * 6 / 7 = a brick kernel of conv_vox.hip (voxel level 0 / 1; takes the site mask as row_mask, refuses a row list).  For profilers. */
+ * 6 / 7 = a brick kernel of conv_vox.hip (voxel level 0 / 1; takes the site mask as row_mask, refuses a row list), 9 / 10 / 11 = the
+ * register-stationary filter-bank kernels of conv_c64.hip (9 conv_c64_kernel: 64 -> 64 channels 3x3 / 1, both directions; 10 conv_s2d_kernel:
+ * data gradient of the 64 -> 128 channel 3x3 / 2 layer; 11 conv_s2f_kernel: its forward, opt-in).  For profilers. */
 int tri_conv_kernel_family(const TriConvDesc* d, int transposed, int split3);
 /* same for tri_conv_wgrad: 0 conv_wgrad_kernel, 2 conv_wgrad_dma_kernel (taken when act_fmt != 0 and the layer qualifies) */
 int tri_conv_wgrad_kernel_family(const TriConvDesc* d, int act_fmt);
