@@ -872,23 +872,47 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_c64_kernel(const C64WgradAr
     for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
         const int img = tile / p.tiles_per_img, h0 = (tile - img * p.tiles_per_img) * TR;
         __syncthreads();                                           // the previous tile's reads (and the zero fill) are done
-        {   // dOut tile: position row e / 8, 16-byte piece e % 8
+        {   // dOut tile: position row e / 8, 16-byte piece e % 8.  Loads go out in batches of FB per thread and are stored afterwards: written
+            // as one load + one store per iteration, the ~18 iterations of a tile were 18 dependent round trips - ~18 us of latency in
+            // front of 2 us of MFMAs (the kernel ran no faster than the grouped conv_wgrad_dma_kernel launches at the bench shape)
+            constexpr int FB = 8;
             const char* ysrc = (const char*)p.dout + ((size_t)img * H + h0) * W * 128;
-            for (int e = t; e < npos * 8; e += 256) {
-                const int row = e >> 3, piece = e & 7;
-                *(uint4*)(ytile + (row >> 5) * 4096 + nat_off<128>(row & 31, piece * 16)) = *(const uint4*)(ysrc + (size_t)row * 128 + piece * 16);
+            const int ny = npos * 8;
+            for (int e0 = t; e0 < ny; e0 += 256 * FB) {
+                uint4 v[FB];
+#pragma unroll
+                for (int u = 0; u < FB; ++u) {
+                    const int e = e0 + u * 256;
+                    v[u] = make_uint4(0u, 0u, 0u, 0u);
+                    if (e < ny) v[u] = *(const uint4*)(ysrc + (size_t)e * 16);
+                }
+#pragma unroll
+                for (int u = 0; u < FB; ++u) {
+                    const int e = e0 + u * 256;
+                    const int row = e >> 3, piece = e & 7;
+                    if (e < ny) *(uint4*)(ytile + (row >> 5) * 4096 + nat_off<128>(row & 31, piece * 16)) = v[u];
+                }
             }
             // slab rows h0 - 1 .. h0 + TR (zeros outside the image), columns 1 .. W
-            const char* xsrc = (const char*)p.in + (size_t)img * H * W * 128;
+            const char* xsrc = (const char*)p.in + ((size_t)img * H + h0 - 1) * W * 128;     // (may point before the image: only valid rows are read)
             const int nchunk = (TR + 2) * W * 8;
-            for (int e = t; e < nchunk; e += 256) {
-                const int piece = e & 7, px = e >> 3;
-                const int srow = px / W, x = px - srow * W;
-                const int iy = h0 - 1 + srow;
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if ((unsigned)iy < (unsigned)H) v = *(const uint4*)(xsrc + ((size_t)iy * W + x) * 128 + piece * 16);
-                const int pix = srow * P + x + 1;
-                *(uint4*)(slab + pix * 128 + ((((piece >> 1) ^ (pix & 3)) << 5) | ((piece & 1) << 4))) = v;
+            for (int e0 = t; e0 < nchunk; e0 += 256 * FB) {
+                uint4 v[FB];
+#pragma unroll
+                for (int u = 0; u < FB; ++u) {
+                    const int e = e0 + u * 256;
+                    const int iy = h0 - 1 + (e >> 3) / W;
+                    v[u] = make_uint4(0u, 0u, 0u, 0u);
+                    if (e < nchunk && (unsigned)iy < (unsigned)H) v[u] = *(const uint4*)(xsrc + (ptrdiff_t)e * 16);
+                }
+#pragma unroll
+                for (int u = 0; u < FB; ++u) {
+                    const int e = e0 + u * 256;
+                    const int piece = e & 7, px = e >> 3;
+                    const int srow = px / W, x = px - srow * W;
+                    const int pix = srow * P + x + 1;
+                    if (e < nchunk) *(uint4*)(slab + pix * 128 + ((((piece >> 1) ^ (pix & 3)) << 5) | ((piece & 1) << 4))) = v[u];
+                }
             }
         }
         __syncthreads();
@@ -1188,9 +1212,12 @@ static bool c64_wgrad_geometry(const TriConvDesc* d, int act_fmt, C64WgradArgs* 
     g->tiles_per_img = H / TR; g->ntiles = d->B * g->tiles_per_img;
     // 256-512 per-workgroup slabs of 147 KB.  Round 2: paid from ~6 row tiles per CU on (per-GPU batch 64 of 6 x 128^2 5.03 -> 4.87 ms,
     // 12 x 224^2 25.3 -> 24.6 ms).  Round 3, against layer1's four weight gradients in ONE grouped conv_wgrad_dma_kernel launch: 6 tiles
-    // per CU 4.43 (this kernel) against 4.36-4.38 ms (grouped), 42 tiles per CU 22.76 against 22.76 - so only the largest shapes keep it
+    // per CU 4.43 (this kernel) against 4.36-4.38 ms (grouped), 42 tiles per CU 22.76 against 22.76 - so only the largest shapes kept it (12).
+    // End of round 3, with the tile loads going out in batches (see the fill above): 42 tiles per CU 21.45 -> 20.9 ms (21.8 without this
+    // kernel), 6 tiles per CU 4.10-4.12 against 4.14-4.15 ms (grouped) - back to 6; 3 tiles per CU (the bench shape) 2.95 against 2.81-2.84 ms:
+    // 512 workgroups x 147 KB of slabs per layer are what it costs there
     static int min_per_cu = -1;
-    if (min_per_cu < 0) { const char* e = getenv("TRICOLO_C64_MIN_TILES_PER_CU"); min_per_cu = e ? atoi(e) : 12; }
+    if (min_per_cu < 0) { const char* e = getenv("TRICOLO_C64_MIN_TILES_PER_CU"); min_per_cu = e ? atoi(e) : 6; }
     if (g->ntiles < min_per_cu * tri_internal_num_cus()) return false;
     static int per_cu = -1;
     if (per_cu < 0) { const char* e = getenv("TRICOLO_C64_WGS_PER_CU"); per_cu = e ? atoi(e) : 2; }
