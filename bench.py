@@ -220,6 +220,8 @@ def run_mode(a, precision, world, rank, device, want_voxel_roofline):
         opt.prepare()
     B = a.per_gpu_batch
     batches = make_batches(a, rank, device, a.resident_batches)
+    # initial parameters + BatchNorm buffers (restored before the timed windows)
+    snap = (opt._flat_p.clone(), [b.clone() for b in net.buffers()]) if getattr(opt, "_flat_p", None) is not None else None
     force_dist = os.environ.get("TRICOLO_FORCE_DIST", "0") == "1"
 
     # N > 1, TRICOLO_DP_OVERLAP=1: two-stage backward (parallel.BackwardSplit) - the all-reduce of the early two thirds of the
@@ -255,9 +257,10 @@ def run_mode(a, precision, world, rank, device, want_voxel_roofline):
                               else "3 graphs + eager collectives")
             else:
                 graphs = []
+                pool = torch.cuda.graph_pool_handle()            # one pool: the graphs replay one after the other and reuse each other's activations
                 for b in batches:
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
+                    with torch.cuda.graph(g, pool=pool):
                         loss_static = step(b)
                     graphs.append((g, loss_static))
                 graph_note = True
@@ -281,6 +284,13 @@ def run_mode(a, precision, world, rank, device, want_voxel_roofline):
     # clocks / caches settle over the first few dozen replays; pre-roll untimed steps so the W + K steps see the steady state
     for i in range(a.preroll if graphs is not None else 5):
         run(i)
+    # the timed steps are steps W .. W + 3K of a run from the INITIAL weights, not those of a net that has memorised its resident batches
+    # (after ~250 replays of two batches the routing the timed step saw - ReLU masks, view arg-max - was an over-fitted net's)
+    if snap is not None:
+        with torch.no_grad():
+            opt._flat_p.copy_(snap[0]); opt._flat_m.zero_(); opt._flat_v.zero_(); opt._step_dev.zero_()
+            for bufr, b0 in zip(net.buffers(), snap[1]):
+                bufr.copy_(b0)
     for i in range(a.warmup):
         loss = run(i)
     # three back-to-back windows of EXACTLY K steps, each bracketed by barrier + synchronize, max over ranks per window; `value` is the
@@ -304,6 +314,31 @@ def run_mode(a, precision, world, rank, device, want_voxel_roofline):
         windows.append(el)
     elapsed = sorted(windows)[len(windows) // 2]
     final_loss = float(loss.item())
+    nonfinite = ({"skipped_steps": opt.skipped_steps(), "skipped_elements": opt.nonfinite_skipped()} if hasattr(opt, "skipped_steps") else None)
+
+    # ---- data-parallel breakdown (N > 1, or TRICOLO_FORCE_DIST=1 in a world of one): the exposed time of the two exchange steps and
+    # of the three graph segments, HIP events on this rank's stream, median of 10 replays behind the timed windows; every rank reports
+    # (rank 0 gathers the lines) together with the number of ranks the RCCL communicator really spans.
+    dp_info = None
+    if dp_graph and graphs is not None:
+        seen = torch.ones((1,), dtype=torch.float32, device=device)
+        parallel.all_reduce_sum(seen)
+        evs = []
+        for i in range(10):
+            _, ev = graphs[i % len(graphs)].replay_timed()
+            evs.append(ev)
+        torch.cuda.synchronize()
+        ph = [parallel.GraphedDPStep.phase_ms(ev) for ev in evs]
+        med = {k: round(sorted(p_[k] for p_ in ph)[len(ph) // 2], 4) for k in ph[0]}
+        mine = {"rank": rank, "backend": dist.get_backend(), "ranks_seen": int(round(float(seen.item()))), "phase_ms_median": med,
+                "all_gather_bytes_per_rank": int(graphs[0].packed.numel() * 4), "all_reduce_bytes": int(graphs[0].flat.numel() * 4)}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        dp_info = {"what": "HIP events around the phases of GraphedDPStep.replay on each rank's stream (10 replays, median): all_gather / "
+                           "all_reduce are the EXPOSED times of the two RCCL collectives", "overlap_split": split is not None,
+                   "per_rank": gathered}
+        print(f"[bench] rank {rank}: {dist.get_backend()} ranks seen = {mine['ranks_seen']} (WORLD_SIZE {world}); exposed all-gather "
+              f"{med['all_gather']:.3f} ms, all-reduce {med['all_reduce']:.3f} ms", file=sys.stderr, flush=True)
 
     # ---- roofline leg: per-kernel HIP-event timing of eager steps, dominant kernel by time.  Rank 0 records; at N > 1
     # EVERY rank runs the steps (they contain the collectives - a rank-0-only step would wait for its peers forever).
@@ -335,8 +370,9 @@ def run_mode(a, precision, world, rank, device, want_voxel_roofline):
             # pipeline depths) with the most measured time; per-instantiation lines stay in all_kernels
             fam = {}
             for k, v in agg.items():
-                f = fam.setdefault(k.split("<")[0], {"launches": 0, "ms": 0.0, "ms_raw": 0.0, "flops": 0, "variants": []})
+                f = fam.setdefault(k.split("<")[0], {"launches": 0, "ms": 0.0, "ms_raw": 0.0, "flops": 0, "flops_dense": 0, "variants": []})
                 f["launches"] += v["launches"]; f["ms"] += v["ms"]; f["ms_raw"] += v["ms_raw"]; f["flops"] += v["flops"]
+                f["flops_dense"] += v["flops_dense"]
                 f["variants"].append(k)
             fname, d = max(fam.items(), key=lambda kv: kv[1]["ms"])
             sym = f"{fname}<*> ({len(d['variants'])} instantiation(s): {', '.join(sorted(d['variants']))})"
@@ -346,16 +382,18 @@ def run_mode(a, precision, world, rank, device, want_voxel_roofline):
                     "avg_launch_ms": round(d["ms"] / d["launches"], 4), "avg_launch_ms_raw": round(d["ms_raw"] / d["launches"], 4),
                     "timing": "HIP events around every launch of eager, stream-serialised steps; the event-pair overhead of an empty "
                               f"kernel measured in the same leg ({ev_ovh * 1e3:.1f} us) is subtracted per launch (raw value beside it); "
-                              "compare avg_launch_ms with the rocprofv3 AverageNs of profiles/r2/kernel_stats_*.csv",
-                    "flops_basis": "dense-equivalent 2*M*taps*Cin*Cout of this symbol's launches (executed FLOPs of the masked voxel "
-                                   "launches: roofline_3dconv_fwd)",
+                              "compare avg_launch_ms with the rocprofv3 AverageNs of the newest profiles/r*/kernel_stats_<mode>.csv",
+                    "flops_basis": "EXECUTED FLOPs: 2*M*taps*Cin*Cout of dense launches, 2*(active rows)*taps*Cin*Cout of launches over a compact "
+                                   "row list / site mask (device-side count read after the leg); achieved_dense_equivalent prices the same time "
+                                   "on every site",
+                    "achieved_dense_equivalent": round(d["flops_dense"] / (d["ms"] * 1e-3) / 1e12, 2),
                     "families": {k: {"launches_per_step": v["launches"] // nprof, "ms_per_step": round(v["ms"] / nprof, 3),
                                      "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in fam.items()},
                     "all_kernels": {k: {"launches_per_step": v["launches"] // nprof, "ms_per_step": round(v["ms"] / nprof, 3),
                                         "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in agg.items()}}
             # HBM bytes per launch of that kernel from the committed PMC passes over this same command (PMC cannot run inside
             # bench.py: separate `rocprofv3 --pmc` runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes)
-            for rnd in ("r3", "r2"):
+            for rnd in ("r4", "r3", "r2"):
                 rel = f"profiles/{rnd}/pmc_traffic_{precision}.json"
                 try:
                     with open(os.path.join(REPO, rel)) as f:
@@ -380,7 +418,7 @@ def run_mode(a, precision, world, rank, device, want_voxel_roofline):
            "step_tflops_note": f"algorithmic {gflop_per_sample:.2f} GFLOP per sample (3 x forward: SURVEY 8d / BASELINE.md section 2) over the median window; "
                                f"{100 * gflop_per_sample * B * a.steps / elapsed / 1e3 / MFMA_PEAK_TFLOPS / 1:.1f} % of one GPU's dense 16-bit MFMA peak per GPU",
            "dtype": DTYPE_NOTE[precision], "hip_graph": graph_note if graphs is not None else (graph_note or False),
-           "final_loss": round(final_loss, 5), "roofline": roof}
+           "final_loss": round(final_loss, 5), "nonfinite_guard": nonfinite, "data_parallel": dp_info, "roofline": roof}
     del graphs, net, opt, batches
     # per-stream scratch arenas of this mode's (now dead) streams: hand them back before the next mode allocates - a bf16x3 leg run
     # after an f16 leg in the same process was 15 % slower than on its own until they were released
@@ -411,7 +449,7 @@ def run_mode_in_child(a, mode):
     d = json.loads(lines[-1])
     return {"value": d["value"], "ms_per_step": d["ms_per_step"], "ms_per_step_windows": d.get("ms_per_step_windows"), "step_tflops": d.get("step_tflops"),
             "dtype": d["dtype"], "hip_graph": d["config"]["hip_graph"], "final_loss": d["config"]["final_loss"], "roofline": d["roofline"],
-            "process": "child"}
+            "nonfinite_guard": d.get("nonfinite_guard"), "process": "child"}
 
 
 def parse_args(argv=None):
@@ -433,7 +471,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--cpu-budget-s", type=float, default=30.0)
-    ap.add_argument("--resident-batches", type=int, default=2)
+    ap.add_argument("--resident-batches", type=int, default=8)
     ap.add_argument("--preroll", type=int, default=40)
     ap.add_argument("--windows", type=int, default=3, help="timed windows of --steps steps each; value = the median window")
     a = ap.parse_args(argv)
@@ -544,10 +582,13 @@ def main():
             "step_tflops_note": head["step_tflops_note"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": head["dtype"], "data": "synthetic",
             "config": {"workload": workload_name(a), "global_batch": gb, "per_gpu_batch": a.per_gpu_batch, "parallelism": f"dp{world}",
+                       "resident_batches": a.resident_batches,
+                       "switches": {k: v for k, v in sorted(os.environ.items()) if k.startswith("TRICOLO_")},   # every kernel / tile-rule switch that was set
                        "precision_mode": a.precision, "hip_graph": head["hip_graph"], "final_loss": head["final_loss"],
                        "parity": "f16 mode: step-0 losses and embeddings within 1e-3 of the fp32 reference on BASELINE configs 1,3,4,5 "
                                  "(tests/test_gpu_modules.py::test_f16_mode_meets_the_1e3_parity_bound); bf16x3: ~1e-5; bf16: outside 1e-3"},
             "roofline": head["roofline"], "modes": modes, "roofline_3dconv_fwd": vox_roof, "cpu_baseline": cpu,
+            "data_parallel": head.get("data_parallel"), "nonfinite_guard": head.get("nonfinite_guard"),
         }
     if dist.is_initialized():
         dist.barrier()

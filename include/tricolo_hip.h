@@ -330,8 +330,14 @@ int tri_ntxent_multi_bwd(const float* const* z, int M, int B, int D, float tempe
                          size_t workspace_bytes, void* stream);
 
 /* ---- Adam (torch.optim.Adam as instantiated by config/config.yaml:50-53, tricolo_net.py:43-44) ------------------------ */
-/* `step` is a DEVICE int[2]: [0] the step counter (tri_adam_tick adds one), [1] the running count of gradient elements the update
- * kernels skipped because they were inf / NaN (overflow guard of the f16 mode: such an element leaves p, m and v untouched). */
+/* `step` is a DEVICE int[4]: [0] optimizer steps applied (the t of the bias corrections; tri_adam_tick adds one), [1] the running count
+ * of gradient elements the update kernels skipped because they were inf / NaN (per-element fallback: such an element leaves p, m and v
+ * untouched), [2] attempt number of the last step whose gradient tri_adam_guard* found non-finite, [3] steps skipped whole.
+ * Per-step overflow guard of the 16-bit modes (torch.cuda.amp.GradScaler's rule, decided on the device so that it replays inside a HIP
+ * graph): call tri_adam_guard / tri_adam_guard_segments over the step's gradient BEFORE tri_adam_tick; when it finds an inf / NaN the
+ * tick counts a skipped step instead of an applied one and the update kernels return without touching p, m, v. */
+int tri_adam_guard(const float* g, long n, int* step, void* stream);
+int tri_adam_guard_segments(const void* grad_ptrs, const long* grad_starts, int nseg, long n, int* step, void* stream);
 int tri_adam_tick(int* step, void* stream);
 /* lr_dev (optional, DEVICE float): when not NULL the learning rate is read from it at run time, so a captured HIP graph
  * follows a schedule (LrDecayCallback of train.py) without re-capture; `lr` is used otherwise.  Bias corrections in double. */

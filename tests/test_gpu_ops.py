@@ -568,25 +568,26 @@ def test_adam_matches_torch_optim():
     p = torch.randn(10007, generator=g)
     pd, m, v = p.clone().to(DEV), torch.zeros(10007, device=DEV), torch.zeros(10007, device=DEV)
     pr, mr, vr = p.clone(), torch.zeros(10007), torch.zeros(10007)
-    step = torch.zeros(2, dtype=torch.int32, device=DEV)                     # [0] step counter, [1] skipped non-finite elements
+    step = torch.zeros(4, dtype=torch.int32, device=DEV)                     # [0] applied steps, [1] skipped elements, [2] flagged attempt, [3] skipped steps
     for s in range(1, 5):
         gr = torch.randn(10007, generator=g)
         ops.adam_tick(step)
         ops.adam_step(pd, gr.to(DEV), m, v, step, 3.5e-4, 0.9, 0.999, 1e-8, 1e-6)
         adam_step_explicit(pr, gr, mr, vr, s)
         np.testing.assert_allclose(pd.cpu().numpy(), pr.numpy(), atol=2e-7)
-    assert step.tolist() == [4, 0]
+    assert step.tolist() == [4, 0, 0, 0]
 
 
 def test_adam_skips_non_finite_gradient_elements():
     """Overflow guard: a gradient element that is inf / NaN - an f16 activation-gradient overflow - must not reach the fp32
     master weights or the Adam moments; the element is left alone, counted on the device, and everything else is updated as usual.
-    Both update kernels: the flat one and the in-place segment reader FusedAdam uses at N = 1."""
+    Both update kernels: the flat one and the in-place segment reader FusedAdam uses at N = 1.  This is the per-ELEMENT fallback of the
+    kernels (FusedAdam(guard=False)); the default per-step guard is test_adam_guard_skips_the_whole_step_on_a_non_finite_gradient."""
     from tricolo_amd.optim import FusedAdam
     gen = torch.Generator().manual_seed(5)
     w = [torch.nn.Parameter(torch.randn(64, 32, generator=gen).to(DEV)), torch.nn.Parameter(torch.randn(128, generator=gen).to(DEV))]
     ref = [p.detach().clone() for p in w]
-    opt = FusedAdam(w, lr=1e-2, weight_decay=1e-6)
+    opt = FusedAdam(w, lr=1e-2, weight_decay=1e-6, guard=False)
     opt.prepare()
     for use_reduce in (False, True):                                          # segment kernel, then the packed (data-parallel) path
         before = [p.detach().clone() for p in w]
@@ -605,8 +606,71 @@ def test_adam_skips_non_finite_gradient_elements():
             assert bool((p.detach()[~bad] != b_[~bad]).all())                  # everything else moved
             st = opt.state[p]
             assert torch.isfinite(st["exp_avg"]).all() and torch.isfinite(st["exp_avg_sq"]).all()
-    assert opt.nonfinite_skipped() == 6
+    assert opt.nonfinite_skipped() == 6 and opt.skipped_steps() == 0
     assert int(opt.state_dict()["state"][0]["step"]) == 2
+
+
+@pytest.mark.parametrize("path", ["segments", "flat", "per_param", "graph"])
+def test_adam_guard_skips_the_whole_step_on_a_non_finite_gradient(path):
+    """Per-step overflow guard: ONE inf / NaN anywhere in a step's gradient - an f16 activation-gradient
+    overflow poisons every gradient further down its tower - skips the whole optimizer step like torch.cuda.amp.GradScaler does:
+    parameters, both moments and the step counter keep their values, skipped_steps() counts it, and the following healthy step is the
+    step torch.optim.Adam would have taken had the bad one never happened.  All of FusedAdam's update paths: the in-place segment
+    reader (N = 1), the packed flat gradient (data-parallel), the per-parameter form, and the segment path replayed from a HIP graph
+    (the decision is taken on the device: the same captured graph applies one replay and skips the next)."""
+    from tricolo_amd.optim import FusedAdam
+    gen = torch.Generator().manual_seed(9)
+    shapes = [(64, 36), (128,), (3, 3, 8)]
+    init = [torch.randn(sh, generator=gen) for sh in shapes]
+    w = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+    wr = [torch.nn.Parameter(t.clone()) for t in init]
+    opt = FusedAdam(w, lr=1e-2, weight_decay=1e-6, flatten=path != "per_param")
+    ropt = torch.optim.Adam(wr, lr=1e-2, weight_decay=1e-6)
+    opt.prepare()
+    kw = dict(reduce_fn=(lambda flat: None)) if path == "flat" else {}
+    gbuf = [torch.zeros(sh, device=DEV) for sh in shapes]
+    for p, g_ in zip(w, gbuf):
+        p.grad = g_
+    graph = None
+    if path == "graph":
+        opt.step()                                                             # warm-up on zero gradients (applied to the reference too)
+        for p in wr:
+            p.grad = torch.zeros_like(p)
+        ropt.step()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            opt.step()
+    applied0 = 1 if path == "graph" else 0
+    plan = [False, True, False, True, True, False]                             # which steps carry a non-finite element
+    n_bad = 0
+    for i, bad in enumerate(plan):
+        grads = [torch.randn(sh, generator=gen) for sh in shapes]
+        before = [p.detach().clone() for p in w]
+        mom = [opt.state[p]["exp_avg"].clone() for p in w]
+        dirty = [g_.clone() for g_ in grads]
+        if bad:
+            dirty[i % 3].view(-1)[(7 * i) % dirty[i % 3].numel()] = float("inf") if i % 2 else float("nan")
+            n_bad += 1
+        for b_, g_ in zip(gbuf, dirty):
+            b_.copy_(g_)
+        if graph is not None:
+            graph.replay()
+        else:
+            opt.step(**kw)
+        torch.cuda.synchronize()
+        if bad:
+            for p, b_, m_ in zip(w, before, mom):
+                assert torch.equal(p.detach(), b_) and torch.equal(opt.state[p]["exp_avg"], m_)
+        else:
+            for p, g_ in zip(wr, grads):
+                p.grad = g_
+            ropt.step()
+            for p, r in zip(w, wr):
+                np.testing.assert_allclose(p.detach().cpu().numpy(), r.detach().numpy(), atol=3e-7)
+        assert opt.skipped_steps() == n_bad
+    assert int(opt.state_dict()["state"][0]["step"]) == applied0 + len(plan) - n_bad
+    assert opt.nonfinite_skipped() == 0                                        # the per-element fallback never saw a bad element
 
 
 @pytest.mark.parametrize("tag", ["b8", "b5", "b16_sym", "b1"])

@@ -125,6 +125,8 @@ SIGNATURES = {
     "tri_copy_segments": (I, [P, P, P, I, P]),
     "tri_gru_bias_grads": (I, [P, I, P, P, P, P, P]),
     "tri_adam_tick": (I, [P, P]),
+    "tri_adam_guard": (I, [P, L, P, P]),
+    "tri_adam_guard_segments": (I, [P, P, I, L, P, P]),
     "tri_adam_step": (I, [P, P, P, P, L, P, F, P, F, F, F, F, F, P]),
     "tri_adam_step_segments": (I, [P, P, P, I, P, P, L, P, F, P, F, F, F, F, F, P]),
 }

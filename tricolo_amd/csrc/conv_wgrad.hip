@@ -1573,9 +1573,12 @@ extern "C" int tri_conv_wgrad_group_info(const TriConvDesc* d, int act_fmt, int*
     *steps = (int)(((long)d->B * d->OD * d->OH * d->OW + 63) / 64);
     return 0;
 }
-// n <= TRI_WGRAD_JOBS_MAX layers of ONE family (tri_conv_wgrad_group_info), dense position ranges (no row mask / row list), 16-bit
-// activation storage.  Every job gets the splits that make all workgroups of the launch about equally long and never more than it
-// would get alone (so tri_conv_wgrad_workspace still bounds its slab); pending[i] receives job i's reduce descriptor.
+// n <= TRI_WGRAD_JOBS_MAX layers of ONE family (tri_conv_wgrad_group_info), each over its dense position range or over a compact row list
+// (row_pos / row_count; no row MASK), 16-bit activation storage.  Every job gets the splits that make all workgroups of the launch about
+// equally long and never more than it would get alone (so tri_conv_wgrad_workspace still bounds its slab); pending[i] receives job i's
+// reduce descriptor.  Row-list jobs are PLANNED for the dense position count (the list length lives on the device): a list that is
+// 15 % full leaves its splits correspondingly short - the kernel re-derives the steps per split from *row_count, so the result does not
+// depend on the plan, only the balance of the launch does (the contract is "correct for any occupancy, sized for a full list").
 extern "C" int tri_conv_wgrad_partial_group(const TriWgradJob* jobs, int n, int act_fmt, TriWgradReduce* pending, void* stream) {
     if (n < 1 || n > WGRAD_JOBS_MAX || !jobs || !pending) { tri_set_error("wgrad group: 1..TRI_WGRAD_JOBS_MAX jobs"); return TRI_ERR_ARG; }
     static_assert(WGRAD_JOBS_MAX == TRI_WGRAD_JOBS_MAX, "header and kernel disagree");

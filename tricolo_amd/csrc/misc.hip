@@ -488,10 +488,46 @@ extern "C" int tri_cast_to_f32(const void* src, float* dst, long n, int act_fmt,
 // ------------------------------------------------------------------------------------------------ fused Adam
 // torch.optim.Adam(lr, betas, eps, weight_decay) single-tensor update, L2-in-gradient (config.yaml:50-53,
 // tricolo_net.py:43-44).  `step` lives on the device (incremented by tri_adam_tick) so the launch is graph-replayable.
-__global__ void adam_tick_kernel(int* step) { *step += 1; }
+// `step` is a device int[4]: [0] optimizer steps APPLIED (the t of the bias corrections), [1] gradient elements skipped by the per-element
+// guard below, [2] the attempt number (applied + skipped steps + 1) of the last step whose gradient tri_adam_guard* found non-finite,
+// [3] steps skipped WHOLE for that reason.  Per-step guard (VERDICT r3 item 9 / ADVICE r3): one inf / NaN in an f16 activation gradient
+// poisons the BatchNorm-backward sums and through them every gradient further down that tower, so skipping the bad ELEMENTS trains
+// the healthy towers on while one tower stands still.  tri_adam_guard* scans the step's gradient once (before the tick); a bad
+// gradient makes tri_adam_tick count a skipped step instead of an applied one and the update kernels leave p, m and v untouched -
+// what torch.cuda.amp.GradScaler does with an overflowed step.  All device-side: the decision replays inside a captured HIP graph.
+__global__ void adam_tick_kernel(int* step) {
+    const int attempt = step[0] + step[3] + 1;
+    if (step[2] == attempt) step[3] += 1;                          // the guard flagged this attempt: nothing is applied
+    else step[0] += 1;
+}
 extern "C" int tri_adam_tick(int* step, void* stream) {
     adam_tick_kernel<<<1, 1, 0, (hipStream_t)stream>>>(step);
     return tri_check_launch("tri_adam_tick");
+}
+__device__ __forceinline__ bool adam_step_skipped(const int* step) { return step[2] == step[0] + step[3]; }   // (after the tick)
+__device__ __forceinline__ unsigned nonfinite_bits(const float4& v) {
+    const unsigned e = 0x7f800000u;
+    return (unsigned)((__builtin_bit_cast(unsigned, v.x) & e) == e) | (unsigned)((__builtin_bit_cast(unsigned, v.y) & e) == e) |
+           (unsigned)((__builtin_bit_cast(unsigned, v.z) & e) == e) | (unsigned)((__builtin_bit_cast(unsigned, v.w) & e) == e);
+}
+__global__ __launch_bounds__(256) void adam_guard_kernel(const float* __restrict__ g, long n, int* __restrict__ step) {
+    // scalar head up to the first 16-byte boundary, float4 body, scalar tail
+    long head = (long)(((16 - ((uintptr_t)g & 15)) & 15) >> 2);
+    if (head > n) head = n;
+    const long n4 = (n - head) >> 2, tail0 = head + n4 * 4;
+    const float4* body = (const float4*)(g + head);
+    unsigned bad = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) bad |= nonfinite_bits(body[i]);
+    if (blockIdx.x == 0) {
+        if ((long)threadIdx.x < head) bad |= (unsigned)!__builtin_isfinite(g[threadIdx.x]);
+        if ((long)threadIdx.x < n - tail0) bad |= (unsigned)!__builtin_isfinite(g[tail0 + threadIdx.x]);
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicMax(step + 2, step[0] + step[3] + 1);
+}
+extern "C" int tri_adam_guard(const float* g, long n, int* step, void* stream) {
+    if ((uintptr_t)g & 3) { tri_set_error("tri_adam_guard: gradient not 4-byte aligned"); return TRI_ERR_ARG; }
+    adam_guard_kernel<<<ew_grid(n / 4 + 1), 256, 0, (hipStream_t)stream>>>(g, n, step);
+    return tri_check_launch("tri_adam_guard");
 }
 // bias corrections as torch computes them (Python doubles): 1 - beta^t in double, then step_size / bias_correction2_sqrt
 struct AdamCoef { float step_size, inv_sqrt_bc2; };
@@ -506,14 +542,15 @@ __device__ __forceinline__ AdamCoef adam_coef(int t, float lr, const float* lr_d
 // Overflow guard of the 16-bit modes: activation gradients are stored in f16 under a static 2^12 scale; should one
 // overflow, the inf / NaN reaches a parameter gradient.  An element whose gradient is not finite is NOT applied - its parameter and
 // both moments keep their values, so a non-finite value can never enter the fp32 master weights or the Adam state, also inside a
-// replayed HIP graph - and counted in step[1] (`step` is a device int[2]: [0] the step counter, [1] the running number of skipped
-// elements; FusedAdam.nonfinite_skipped() reads it).
+// replayed HIP graph - and counted in step[1] (FusedAdam.nonfinite_skipped() reads it).  This per-ELEMENT guard is the fallback of
+// callers that do not run tri_adam_guard* first; with the guard pass a bad gradient skips the whole step (see adam_tick_kernel).
 __device__ __forceinline__ void adam_note_bad(const int* step, int bad) {
     if (bad) atomicAdd(const_cast<int*>(step) + 1, bad);
 }
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
                             const int* __restrict__ step, float lr, const float* __restrict__ lr_dev, float b1, float b2, float eps,
                             float wd, float gscale) {
+    if (adam_step_skipped(step)) return;
     const AdamCoef co = adam_coef(*step, lr, lr_dev, b1, b2);
     const float step_size = co.step_size, inv_sqrt_bc2 = co.inv_sqrt_bc2;
     int bad = 0;
@@ -540,6 +577,7 @@ __global__ __launch_bounds__(256) void adam_seg_kernel(float* __restrict__ p, co
                                                        float gscale) {
     __shared__ long sstart[ADAM_MAX_SEG];
     __shared__ const float* sptr[ADAM_MAX_SEG];
+    if (adam_step_skipped(step)) return;
     for (int i = threadIdx.x; i < nseg; i += 256) { sstart[i] = gstart[i]; sptr[i] = gptr[i]; }
     __syncthreads();
     const AdamCoef co = adam_coef(*step, lr, lr_dev, b1, b2);
@@ -570,6 +608,30 @@ __global__ __launch_bounds__(256) void adam_seg_kernel(float* __restrict__ p, co
         *(float4*)(p + i) = pv; *(float4*)(m + i) = mv; *(float4*)(v + i) = vv;
     }
     adam_note_bad(step, bad);
+}
+__global__ __launch_bounds__(256) void adam_guard_seg_kernel(const float* const* __restrict__ gptr, const long* __restrict__ gstart, int nseg,
+                                                             long n4, int* __restrict__ step) {
+    __shared__ long sstart[ADAM_MAX_SEG];
+    __shared__ const float* sptr[ADAM_MAX_SEG];
+    for (int i = threadIdx.x; i < nseg; i += 256) { sstart[i] = gstart[i]; sptr[i] = gptr[i]; }
+    __syncthreads();
+    unsigned bad = 0;
+    for (long i4 = (long)blockIdx.x * blockDim.x + threadIdx.x; i4 < n4; i4 += (long)gridDim.x * blockDim.x) {
+        const long i = i4 * 4;
+        int lo = 0, hi = nseg - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (sstart[mid] <= i) lo = mid; else hi = mid - 1;
+        }
+        const float* gs = sptr[lo];
+        if (gs) bad |= nonfinite_bits(*(const float4*)(gs + (i - sstart[lo])));
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicMax(step + 2, step[0] + step[3] + 1);
+}
+extern "C" int tri_adam_guard_segments(const void* grad_ptrs, const long* grad_starts, int nseg, long n, int* step, void* stream) {
+    if (nseg < 1 || nseg > ADAM_MAX_SEG || n % 4) { tri_set_error("tri_adam_guard_segments: 1..1024 segments, n % 4 == 0"); return TRI_ERR_ARG; }
+    adam_guard_seg_kernel<<<ew_grid(n / 4), 256, 0, (hipStream_t)stream>>>((const float* const*)grad_ptrs, grad_starts, nseg, n / 4, step);
+    return tri_check_launch("tri_adam_guard_segments");
 }
 extern "C" int tri_adam_step_segments(float* p, const void* grad_ptrs, const long* grad_starts, int nseg, float* m, float* v, long n,
                                       const int* step, float lr, const float* lr_dev, float b1, float b2, float eps, float wd, float gscale,

@@ -157,11 +157,14 @@ class SparseCNNEncoder(TriModule):
             g = self._geom(B, l)
             x, y, mask, count, co, pooled, rows, _ = saved["levels"][l]
             conv, bn = self.sparseModel[str(4 * l)], self.sparseModel[str(4 * l + 1)]
+            # level 0 has no data gradient that would gather dy at inactive sites; its weight gradient walks a row list (compact) or is
+            # the brick kernel, which masks dOut rows itself - only the masked-tile form of conv_wgrad_kernel needs the zeros.  The brick
+            # kernel exists for 16-bit storage only (g.wgrad_brick is geometry-only): the SAME predicate picks the kernel and the rows
+            # left unwritten, or fp32 storage with TRICOLO_VOXEL_COMPACT=0 would contract over uninitialised dy rows
+            brick_wgrad = g.wgrad_brick and y.dtype != torch.float32
             dy, dgamma, dbeta = ops.pool3d_bn_bwd(y, co, mask, pooled, dx.contiguous(), B, D, C, bn.weight, count, out_scale=ugs,
-                                                  fused=fuse, keep_inactive=(l == 0 and (compact or g.wgrad_brick)))
-            # (level 0 has no data gradient that would gather dy at inactive sites; its weight gradient walks a row list or masks dOut
-            # rows itself - only the masked-tile form of conv_wgrad_kernel needs the zeros)
-            if compact and not (g.wgrad_brick and dy.dtype != torch.float32):
+                                                  fused=fuse, keep_inactive=(l == 0 and (compact or brick_wgrad)))
+            if compact and not brick_wgrad:
                 # contraction over the active sites only (row list of the level)
                 grads[3 * l] = ops.conv_wgrad(x, dy, g, conv.weight, prec, rows=rows, out_scale=ugs, batch=batch)
             else:

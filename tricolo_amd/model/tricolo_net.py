@@ -68,6 +68,15 @@ class TriCoLoNet(TriModule):
         self.__dict__["dp_split"] = None            # parallel.BackwardSplit (data-parallel gradient overlap): gates the voxel output
         self.__dict__["_side_streams"] = None
 
+    def _apply(self, fn, *args, **kwargs):
+        """Every device move (.to / .cuda) also creates ops.one() - the cached loss-gradient scalar - on the parameters' device, eagerly:
+        a step first run INSIDE a HIP-graph capture (torch.optim, a custom capture without FusedAdam.prepare()) then finds it."""
+        out = super()._apply(fn, *args, **kwargs)
+        p = next(self.parameters(), None)
+        if p is not None and p.is_cuda and not torch.cuda.is_current_stream_capturing():
+            ops.one(p.device)
+        return out
+
     # Lightning supplies .hparams / log_dict / log / print when present; minimal stand-ins otherwise
     def __getattr__(self, name):
         if name == "hparams" and "_hparams_ns" in self.__dict__:

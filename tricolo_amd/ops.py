@@ -23,7 +23,7 @@ _FMT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}        # act_fmt 
 # positions they spread over (1e-6 .. 1e-5 per element in layer1 at batch 32 x 6 views), below f16's normal range
 # (6.1e-5): they are carried multiplied by 2^12 from the first 16-bit gradient tensor of a tower to the parameter-gradient
 # kernels, which multiply by 2^-12 (exact).  f16 max is 65504.
-F16_GRAD_SCALE = 4096.0
+F16_GRAD_SCALE = float(os.environ.get("TRICOLO_F16_GRAD_SCALE", "4096"))      # (a power of two: the un-scaling is exact)
 _default_precision = os.environ.get("TRICOLO_PRECISION", "bf16x3")
 
 
@@ -72,15 +72,20 @@ class KernelTimer:
         return r
 
     def summary(self):
+        """Per symbol: launches, summed event time (ms: the calibrated event-pair overhead subtracted per launch; ms_raw: as measured),
+        flops = EXECUTED FLOPs (launches over a compact row list or a site mask count their active rows - resolved here from the
+        device-side counts, after the synchronize), flops_dense = the dense-equivalent figure beside it."""
         torch.cuda.synchronize()
         agg = {}
         for sym, fl, a, b in self.records:
-            d = agg.setdefault(sym, {"launches": 0, "ms": 0.0, "flops": 0})
+            d = agg.setdefault(sym, {"launches": 0, "ms": 0.0, "flops": 0, "flops_dense": 0})
             d["launches"] += 1
             e = a.elapsed_time(b)
             d["ms_raw"] = d.get("ms_raw", 0.0) + e
             d["ms"] += max(e - self.overhead_ms, 0.25 * e)
-            d["flops"] += fl
+            ex, dense = fl() if callable(fl) else (fl, fl)
+            d["flops"] += ex
+            d["flops_dense"] += dense
         return agg
 
 
@@ -89,6 +94,34 @@ TIMER: KernelTimer | None = None
 
 def _timed(symbol, flops, fn):
     return TIMER.run(symbol, flops, fn) if TIMER is not None else fn()
+
+
+def _flops(g, rows=None, row_mask=None):
+    """FLOPs of one launch of layer g for the KernelTimer: dense 2*M*taps*Cin*Cout, or - for launches that contract / compute over a
+    compact row list or a site mask - a callable -> (executed, dense) with executed = 2 * active rows * taps * Cin * Cout, resolved at
+    summary time from the device-side count (masked launches are priced on executed FLOPs)."""
+    if TIMER is None or (rows is None and row_mask is None):
+        return g.flops
+    per_row = 2 * g.ntaps * g.cin * g.cout
+    n = g.M
+    if rows is not None:
+        cnt = rows[1]
+        return lambda: (per_row * min(int(cnt.item()), n), g.flops)
+    return lambda: (per_row * int(row_mask[:n].sum().item()), g.flops)
+
+
+def _flops_sum(items):
+    """Sum of _flops() values (numbers or callables) as one value of the same kind."""
+    if not any(callable(f) for f in items):
+        return sum(items)
+
+    def total():
+        ex = dn = 0
+        for f in items:
+            e, d = f() if callable(f) else (f, f)
+            ex, dn = ex + e, dn + d
+        return ex, dn
+    return total
 
 
 _TNAME = {torch.float32: "float", torch.bfloat16: "bf16", torch.float16: "f16"}
@@ -333,7 +366,7 @@ def conv_fwd(x, g: ConvGeom, packed, row_mask=None, bias=None, act=0, want_stats
     nrec = (g.num_records_rows if rows else g.num_mtiles)[_conv_mode(x, lo)]
     stats = torch.empty((nrec, 2, g.cout), dtype=torch.float32, device=x.device) if want_stats else None
     ws = _workspace(g.fwd_ws, x.device) if g.fwd_ws else None
-    check(_timed(_igemm_symbol(g, False, lo is not None, x), g.flops,
+    check(_timed(_igemm_symbol(g, False, lo is not None, x), _flops(g, rows, row_mask),
                  lambda: lib().tri_conv_fwd(_C.C.byref(g.desc), ptr(_act(x)), ptr(hi), ptr(lo), ptr(out), ptr(row_mask), ptr(bias),
                                             act, 1 if accumulate else 0, ptr(stats), _abf(x), ptr(ws),
                                             ws.numel() if ws is not None else 0, ptr(rows[0]) if rows else None,
@@ -380,7 +413,7 @@ def conv_dgrad(dout, g: ConvGeom, packed_t, row_mask=None, out=None, accumulate=
                                                      _abf(dout), ptr(ws), ws.numel() if ws is not None else 0, ptr(rowpos),
                                                      _C.C.byref(sums), stream())), "tri_conv_dgrad_bn")
         return out, partial
-    check(_timed(_igemm_symbol(g, True, lo is not None, dout), g.flops,
+    check(_timed(_igemm_symbol(g, True, lo is not None, dout), _flops(g, rows, row_mask),
                  lambda: lib().tri_conv_dgrad(_C.C.byref(g.desc), ptr(_act(dout)), ptr(hi), ptr(lo), ptr(out), ptr(row_mask),
                                               1 if accumulate else 0, _abf(dout), ptr(ws), ws.numel() if ws is not None else 0,
                                               ptr(rowpos), ptr(rows[1]) if rows else None, stream())), "tri_conv_dgrad")
@@ -452,7 +485,7 @@ class WgradBatch:
             arr = (_C.TriWgradJob * n)(*[j[0] for j in pending])
             pend = (_C.TriWgradReduce * n)()
             fmt = _abf(pending[0][1][0])
-            check(_timed(pending[0][3], sum(j[2] for j in pending),
+            check(_timed(pending[0][3], _flops_sum([j[2] for j in pending]),
                          lambda: lib().tri_conv_wgrad_partial_group(arr, n, fmt, pend, stream())), "tri_conv_wgrad_partial_group")
             for i in range(n):
                 d = _C.TriWgradReduce()
@@ -524,11 +557,11 @@ def conv_wgrad(x, dout, g: ConvGeom, like: torch.Tensor, precision: str, row_mas
             xa, da = _act(x), _act(dout)
             job = _C.TriWgradJob(_C.C.pointer(g.desc), ptr(xa), ptr(da), ptr(plan), ptr(ws), ws.numel(), ptr(dw), s_co, s_tap, s_ci, g.cin,
                                  float(out_scale), ptr(rows[0]) if rows else None, ptr(rows[1]) if rows else None)
-            batch.add_job(fam, tiles, job, (xa, da, ws, dw, plan, rows), g.flops, sym)
+            batch.add_job(fam, tiles, job, (xa, da, ws, dw, plan, rows), _flops(g, rows), sym)
             return dw
     if batch is not None:
         desc = _C.TriWgradReduce()
-        check(_timed(sym, g.flops,
+        check(_timed(sym, _flops(g, rows, row_mask),
                      lambda: lib().tri_conv_wgrad_partial(_C.C.byref(g.desc), ptr(_act(x)), ptr(_act(dout)), ptr(row_mask), ptr(plan),
                                                           ptr(ws), ws.numel(), ptr(dw), s_co, s_tap, s_ci, g.cin, s3, _abf(x),
                                                           float(out_scale), ptr(rows[0]) if rows else None,
@@ -536,7 +569,7 @@ def conv_wgrad(x, dout, g: ConvGeom, like: torch.Tensor, precision: str, row_mas
               "tri_conv_wgrad_partial")
         batch.descs.append(desc)
         return dw
-    check(_timed(sym, g.flops,
+    check(_timed(sym, _flops(g, rows, row_mask),
                  lambda: lib().tri_conv_wgrad(_C.C.byref(g.desc), ptr(_act(x)), ptr(_act(dout)), ptr(row_mask), ptr(plan), ptr(ws),
                                               ws.numel(), ptr(dw), s_co, s_tap, s_ci, g.cin, s3, _abf(x), float(out_scale),
                                               ptr(rows[0]) if rows else None, ptr(rows[1]) if rows else None, stream())),
@@ -756,6 +789,7 @@ def maxpool_bn_bwd_wgrad(x0, y, arg, dpool, co: "BNCoeffs", gamma, g: "ConvGeom"
                                           _abf(y), stream()), "tri_maxpool_bn_bwd_reduce")
     buf = _bn_bwd_finalize(partial, nblk, C, None, N * H * W, gamma, co, out_scale)
     dw = torch.empty_like(like)
+    mark = (batch.ci, batch.off) if batch is not None else None   # the arena cursor: an unsupported geometry hands its slab back
     ws = batch.slab(g.wgrad_ws) if batch is not None else _workspace(g.wgrad_ws, y.device)
     s_co, s_tap, s_ci = g.strides
     desc = _C.TriWgradReduce()
@@ -764,6 +798,8 @@ def maxpool_bn_bwd_wgrad(x0, y, arg, dpool, co: "BNCoeffs", gamma, g: "ConvGeom"
                                                      ptr(buf[3]), ptr(buf[4]), ptr(co.scale), ptr(co.shift), ptr(ws), ws.numel(), ptr(dw), s_co,
                                                      s_tap, s_ci, g.cin, _abf(y), float(out_scale), _C.C.byref(desc), stream()))
     if rc == _C.TRI_ERR_UNSUPPORTED:                               # not a stem-kernel geometry: the two-pass form
+        if batch is not None:
+            batch.ci, batch.off = mark                             # (nothing was launched into that slab: conv_wgrad below carves its own)
         dy = torch.empty_like(y)
         check(lib().tri_maxpool_bn_bwd_apply(ptr(y), ptr(arg), ptr(dpool), N, H, W, C, ptr(buf[2]), ptr(buf[3]), ptr(buf[4]), ptr(co.scale),
                                              ptr(co.shift), ptr(dy), _abf(y), stream()), "tri_maxpool_bn_bwd_apply")
@@ -1113,6 +1149,15 @@ def ntxent_fwd_bwd(za, zb, temperature, alpha, norm=True, want_grad=True):
 # ------------------------------------------------------------------------------------------------ Adam
 def adam_tick(step):
     check(lib().tri_adam_tick(ptr(step), stream()), "tri_adam_tick")
+
+
+def adam_guard(g, step):
+    """Per-step overflow guard over a flat gradient: flags the attempt in step[2] when g holds an inf / NaN (call before adam_tick)."""
+    check(lib().tri_adam_guard(ptr(_f32(g)), g.numel(), ptr(step), stream()), "tri_adam_guard")
+
+
+def adam_guard_segments(grad_ptrs, grad_starts, n, step):
+    check(lib().tri_adam_guard_segments(ptr(grad_ptrs), ptr(grad_starts), grad_starts.numel(), n, ptr(step), stream()), "tri_adam_guard_segments")
 
 
 def adam_step_segments(p, grad_ptrs, grad_starts, m, v, step, lr, b1, b2, eps, wd, gscale=1.0, lr_dev=None):

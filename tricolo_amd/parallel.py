@@ -337,6 +337,39 @@ class GraphedDPStep:
         with torch.cuda.graph(self.gC, **mode):
             optimizer.apply_flat(self.flat)
 
+    def replay_timed(self):
+        """One replay with HIP events between its phases on the current stream -> (loss, events); GraphedDPStep.phase_ms(events) after a
+        synchronize gives {phase: ms}.  A collective issued through torch.distributed runs on the process group's own stream; the
+        current stream waits for it when the (synchronous) call returns / at handle.wait(), so the event recorded behind it fires
+        when the collective has completed: `all_gather` and `all_reduce` are the EXPOSED times of the two exchange steps (bench.py
+        prints their medians per rank into the JSON line, so the first multi-GPU run yields the breakdown)."""
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+        ev[0].record()
+        self.gA.replay()
+        ev[1].record()
+        all_gather_rows(self.full, self.packed)
+        ev[2].record()
+        self.gB.replay()
+        if self.split is None:
+            ev[3].record()
+            all_reduce_sum(self.flat)
+        else:
+            hs = [all_reduce_sum(self.flat[s:e], async_op=True) for s, e, _ in self.early_runs]
+            self.gB2.replay()
+            ev[3].record()                                              # (the early ranges are being reduced under graph B2)
+            hs += [all_reduce_sum(self.flat[s:e], async_op=True) for s, e, _ in self.late_runs]
+            for h in hs:
+                h.wait()
+        ev[4].record()
+        self.gC.replay()
+        ev[5].record()
+        return self.loss, ev
+
+    @staticmethod
+    def phase_ms(ev):
+        names = ("towers_forward", "all_gather", "loss_backward_pack", "all_reduce", "adam")
+        return {n: ev[i].elapsed_time(ev[i + 1]) for i, n in enumerate(names)}
+
     def replay(self):
         self.gA.replay()
         all_gather_rows(self.full, self.packed)

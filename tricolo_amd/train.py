@@ -58,6 +58,12 @@ def fit(net, cfg, train_batches, val_batches=None, device="cuda", ckpt_path: str
             last, step = loss, step + 1
         rec = {"epoch": epoch, "global_step": step, "train_loss": float(last.item()) if last is not None else None,
                "lr": float(opt.param_groups[0]["lr"])}
+        if hasattr(opt, "skipped_steps"):                             # FusedAdam's overflow guard: one device read per epoch
+            rec["skipped_steps"], rec["skipped_elements"] = opt.skipped_steps(), opt.nonfinite_skipped()
+            seen = (history[-1].get("skipped_steps", 0) + history[-1].get("skipped_elements", 0)) if history else 0
+            if rec["skipped_steps"] + rec["skipped_elements"] > seen:
+                log(f"[tricolo_amd.train] WARNING: {rec['skipped_steps']} optimizer step(s) / {rec['skipped_elements']} gradient element(s) skipped so far "
+                    "because of inf / NaN gradients (f16 activation-gradient overflow?): lower ops.F16_GRAD_SCALE or train in bf16x3")
         lr = cosine_lr(cfg, epoch)
         if lr is not None:
             for g in opt.param_groups:
