@@ -1033,7 +1033,8 @@ def test_wgrad_jobs_share_one_partial_launch(group, store, prec):
     for i, case in enumerate(cases):
         x, w, wp, xcl, g = make_case(case, integer=True, seed=300 + i)
         fam, tiles, steps = g.wgrad_group(ops._abf(torch.empty(0, dtype=store)))
-        assert fam in (1, 2, 3) and tiles > 0 and steps == (g.B * int(np.prod(g.out_grid)) + 63) // 64   # (3: TRICOLO_WGRAD_WIDE=1 runs)
+        # (3: TRICOLO_WGRAD_WIDE=1 runs; 4 / 5: the kernel-row slab kernel takes the resolution-keeping 3x3 layers)
+        assert fam in (1, 2, 3, 4, 5) and tiles > 0 and steps == (g.B * int(np.prod(g.out_grid)) + 63) // 64
         dy = ints((g.B, *g.out_grid, g.cout), -2, 2, 700 + i)
         xr = x.clone().requires_grad_()
         wr = w.clone().requires_grad_()
@@ -1045,13 +1046,60 @@ def test_wgrad_jobs_share_one_partial_launch(group, store, prec):
         queued = max(queued, len(batch.jobs))
     assert queued > 1 and len(batch.jobs) + len(batch.descs) == len(cases)
     if group == "mixed" and os.environ.get("TRICOLO_WGRAD_WIDE") != "1":
-        # the tile budget launched the 128-row family once on the way; both families still hold jobs (one queue per family)
-        assert launches == 1 and sorted(batch.queues) == [1, 2]
+        if os.environ.get("TRICOLO_NO_KROW_WGRAD") == "1":
+            # the tile budget launched the 128-row family once on the way; both families still hold jobs (one queue per family)
+            assert launches == 1 and sorted(batch.queues) == [1, 2]
+        else:                                       # stride-2 / 1x1 layers on the im2col families, 3x3 / 1 layers on the kernel-row ones
+            assert sorted(batch.queues) == [1, 4, 5]
     batch.flush()
     assert batch.jobs == [] and batch.descs == []
     torch.cuda.synchronize()
     for i, (o, r) in enumerate(zip(outs, refs)):
         assert torch.equal(o.cpu(), r * (0.5 if i % 2 else 1.0)), f"job {i}: max abs diff {(o.cpu() - r).abs().max().item()}"
+
+
+KROW_CASES = [
+    # name, images, (1, H, W), cin, cout: every image width the kernel-row slab kernel takes, both tile heights (Cout % 128), several
+    # input-channel chunks, a last step that runs past the tensor, image heights that do not divide the rows of a step
+    ("k4_512", 13, (1, 4, 4), 512, 512),
+    ("k8_256", 9, (1, 8, 8), 256, 256),
+    ("k16_128", 7, (1, 16, 16), 128, 128),
+    ("k32_64", 5, (1, 32, 32), 64, 64),
+    ("k64_64_128", 2, (1, 64, 64), 64, 128),
+    ("k16_128_192", 3, (1, 8, 16), 128, 192),
+    ("k8_h6", 5, (1, 6, 8), 64, 64),
+    ("k32_long", 40, (1, 32, 32), 64, 64),
+]
+
+
+@pytest.mark.parametrize("store,prec", STORE16, ids=STORE16_IDS)
+@pytest.mark.parametrize("case", KROW_CASES, ids=[c[0] for c in KROW_CASES])
+def test_conv_wgrad_krow_integer_exact(case, store, prec):
+    """conv_wgrad_krow_kernel (one kernel row of taps per workgroup from one input slab): dW of every geometry it takes,
+    launched alone and as jobs of a shared launch (two copies with different data), bit-exact on integer data against torch's conv
+    backward.  TRICOLO_NO_KROW_WGRAD=1 is the A/B partner (conv_wgrad_dma_kernel)."""
+    name, N, grid, cin, cout = case
+    full = (name, N, grid, cin, cout, (1, 3, 3), 1, (0, 1, 1), "torch")
+    outs, refs = [], []
+    batch = ops.WgradBatch(torch.device(DEV), group_jobs=True)
+    for rep in range(2):
+        x, w, wp, xcl, g = make_case(full, integer=True, seed=40 + rep)
+        if os.environ.get("TRICOLO_NO_KROW_WGRAD") != "1":
+            assert g.wgrad_krow and g.wgrad_group(ops._abf(torch.empty(0, dtype=store)))[0] == (4 if cout % 128 == 0 else 5)
+        dy = ints((N, *grid, cout), -2, 2, 50 + rep)
+        wr = w.clone().requires_grad_()
+        F.conv3d(x, wr, padding=(0, 1, 1)).backward(cf3(dy))
+        refs.append(wr.grad)
+        xd, dyd = xcl.to(DEV).to(store), dy.to(DEV).to(store)
+        if rep == 0:
+            alone = ops.conv_wgrad(xd, dyd, g, wp.to(DEV), prec).cpu()
+            assert torch.equal(alone, wr.grad), f"alone: max abs diff {(alone - wr.grad).abs().max().item()}"
+        outs.append(ops.conv_wgrad(xd, dyd, g, wp.to(DEV), prec, out_scale=0.5 if rep else 1.0, batch=batch))
+    assert len(batch.jobs) == 2
+    batch.flush()
+    torch.cuda.synchronize()
+    for rep, (o, r) in enumerate(zip(outs, refs)):
+        assert torch.equal(o.cpu(), r * (0.5 if rep else 1.0)), f"job {rep}: max abs diff {(o.cpu() - r).abs().max().item()}"
 
 
 @pytest.mark.parametrize("M,B,D,norm", [(3, 32, 512, True), (3, 5, 512, True), (2, 8, 512, True), (3, 300, 512, True), (3, 7, 64, False)],

@@ -956,6 +956,192 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_c64_kernel(const C64WgradAr
     }
 }
 
+// ================================================================================================ kernel-row slab weight gradient
+// 3x3 / stride 1 / pad 1 layers with 16-bit storage, Cin % 64 == 0, Cout % 64 == 0, image width 4 / 8 / 16 / 32 / 64 (every resolution-keeping
+// 3x3 conv of the ResNet trunk at 6 x 128^2, mv_cnn.py:44).  conv_wgrad_dma_kernel treats the layer as an im2col GEMM: every 128-column tile
+// of K = (tap, ci) re-gathers its input rows (each input pixel is fetched once per TAP) and re-reads its dOut tile (once per column tile) -
+// PMC had the family move 3.6x its algorithmic bytes, and its waves spend as long issuing LDS-DMA pieces as multiplying (NOTES_wgrad.md).
+// Here one workgroup owns ONE KERNEL ROW: dW[co0 .. co0 + CO_T)[ky][kx = 0..2][ci0 .. ci0 + 64).  A step is 64 output positions =
+// 64 / W whole image rows; its operands are staged ONCE: the dOut tile [64][CO_T] (natural layout, nat_off swizzle) and the 64 / W input
+// rows the kernel row ky needs (input row y + ky - 1 of each output row y, zeros outside the image) as a slab of (W + 2)-pixel rows with
+// zero borders, 128 B (64 channels) per pixel.  The three taps kx are the same slab read shifted by one pixel, so per step the
+// workgroup moves CO_T * 128 + ~10 KB for 3 x 64 x CO_T x 64 MACs: 2.9x (CO_T = 128) / 2.2x (64) fewer LDS-DMA bytes - and pieces to
+// issue - per FLOP than the 128 x 128 im2col tile.  Both operands are read transposed (ds_read_b64_tr_b16): A from the dOut tile, B from
+// the slab, whose four 32-byte channel quarters are XOR-swizzled by pixel bits so that the 8 position rows of a half-wave read hit
+// 8 different bank groups for every tap shift (sw() below).  Waves 2 x 2: (CO_T / 2 channels) x (6 of the 12 (kx, quarter) column tiles).
+// Output: fp32 slabs [split][Cout][9 Cin] in the standard k order (tri_wgrad_reduce_grouped sums them), jobs of several layers per launch.
+struct KrowArgs {
+    const void* in; const void* dout; float* slab;
+    unsigned in_bytes, dout_bytes;
+    int NH, H, W, Cin, Cout, Kpad;
+    int rps, P, npiece;          // image rows per step, slab row pitch in pixels (W + 2), 1 KiB DMA pieces per slab (8 pixels each)
+    int nsteps, steps_per_split, nsplits, ntiles, ci_chunks;
+    FastDiv dH, dP, dW;
+};
+struct KrowJobs {
+    KrowArgs d[WGRAD_JOBS_MAX];
+    int first_block[WGRAD_JOBS_MAX + 1];
+    int n;
+};
+static_assert(sizeof(KrowJobs) <= 4096, "the job table travels in the kernel arguments (4 KB)");
+#define KROW_SLAB_PX 96                                            // rps * (W + 2) <= 96 (W = 4: 16 rows of 6 pixels)
+// quarter swizzle of slab pixel (row r, column xs): bit 0 separates pixels two apart, bit 1 the two position octets of a half-wave
+// (8 pixels apart in one row for W >= 16, the next row for W = 8, two rows on for W = 4)
+__device__ __forceinline__ int krow_sw(int r, int xs, int W) {
+    const int hb = W >= 16 ? (xs >> 3) & 1 : (W == 8 ? r & 1 : (r >> 1) & 1);
+    return ((xs >> 1) & 1) | (hb << 1);
+}
+template <int CO_T, typename E>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_krow_kernel(const KrowJobs jobs) {
+    typedef Mma<E> MM;
+    typedef typename MM::v8 v8;
+    constexpr int KB = 64;
+    constexpr int XROW = CO_T * 2, X_BYTES = KB * XROW;
+    constexpr int SLAB_BYTES = KROW_SLAB_PX * 128, STAGE = X_BYTES + SLAB_BYTES;
+    constexpr int XRPI = 1024 / XROW, XNI = KB / (4 * XRPI);       // dOut rows per wave-instruction, instructions per wave and step
+    constexpr int TM = CO_T / 32;                                  // 16-channel row tiles per wave
+    static_assert((4 * XRPI) % 16 == 0 && XNI >= 1, "lane -> chunk map must not depend on the instruction");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int ji = 0;
+    while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.first_block[ji + 1]) ++ji;
+    const KrowArgs& p = jobs.d[ji];
+    const int bid = (int)blockIdx.x - jobs.first_block[ji];
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int ntiles = p.ntiles;
+    int split, tile;
+    if (p.nsplits >= 16) {                                         // XCD pinning of the position splits, see conv_wgrad_kernel
+        const int grp = bid / (8 * ntiles), rem = bid - grp * 8 * ntiles;
+        split = grp * 8 + (rem & 7);
+        tile = rem >> 3;
+    } else {
+        split = bid / ntiles;
+        tile = bid - split * ntiles;
+    }
+    if (split >= p.nsplits) return;
+    // tile = ((co tile * ci_chunks) + ci chunk) * 3 + ky: the three kernel rows of one (co, ci) block are neighbours (same dOut tile,
+    // input rows one apart) and, with the mapping above, run on one XCD
+    const int ky = tile % 3, rest = tile / 3;
+    const int cic = rest % p.ci_chunks, cot = rest / p.ci_chunks;
+    const int co0 = cot * CO_T, ci0 = cic * 64;
+    const int ks_begin = split * p.steps_per_split, ks_end = min(p.nsteps, ks_begin + p.steps_per_split);
+    const int W = p.W, P = p.P, H = p.H, Cin = p.Cin, Cout = p.Cout;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int fr = lane & 15, fg = lane >> 4, fqq = fr >> 2, fp = fr & 3;
+
+    // ---- DMA lane constants.  dOut tile: as conv_wgrad_dma_kernel's X operand
+    const int xrow0 = wave * XRPI + lane / (XROW / 16), xsl = lane % (XROW / 16);
+    const int xchunk = ((((xsl >> 1) ^ nat_sw<XROW>(xrow0)) & (XROW / 32 - 1)) << 1) | (xsl & 1);
+    const unsigned xoff = (unsigned)((xrow0 * Cout + co0 + xchunk * 8) * 2);
+    const unsigned xstep = (unsigned)(4 * XRPI * Cout * 2);
+    const unsigned step_bytes = (unsigned)(p.rps * W) * (unsigned)(Cout * 2);   // dOut bytes between two steps
+    // slab: piece pi = wave + 4 i covers slab pixels 8 pi .. 8 pi + 7; this lane moves the 16-byte chunk (lane & 7) of pixel 8 pi + lane / 8
+    int s_r[3], s_col[3];                                          // slab row of the lane's pixel, byte offset inside an input row (< 0: zeros)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int pi = wave + 4 * i;
+        const int q = 8 * pi + (lane >> 3), c = lane & 7;
+        const int r = (int)fdiv((uint32_t)q, p.dP), xs = q - r * P;
+        const int cq = ((c >> 1) ^ krow_sw(r, xs, W)) & 3;
+        s_r[i] = r;
+        s_col[i] = (xs >= 1 && xs <= W && r < p.rps) ? ((xs - 1) * Cin + ci0 + cq * 16 + (c & 1) * 8) * 2 : -1;
+    }
+    // ---- B fragment addresses (per lane, the same for every step): position 32 h + 8 fg + 4 half + fqq of the step, column tile b
+    int boff[2][2][6];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int pos = 32 * h + 8 * fg + 4 * hf + fqq;
+            const int r = (int)fdiv((uint32_t)pos, p.dW), x = pos - r * W;
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                const int tt = 6 * wj + b, kx = tt >> 2, cq = tt & 3;
+                const int xs = x + kx;
+                boff[h][hf][b] = (r * P + xs) * 128 + (((cq ^ krow_sw(r, xs, W)) & 3) << 5) + fp * 8;
+            }
+        }
+
+    f32x4 acc[TM][6];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < 6; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const v4i rsrc = make_rsrc_words(p.in, p.in_bytes);
+    const v4i xrsrc = make_rsrc_words(p.dout, p.dout_bytes);         // rows past the tensor arrive as zeros
+    const unsigned lds0 = lds_addr(smem) + wave * 1024;
+    const int row_bytes = W * Cin * 2;
+
+    auto issue_x = [&](int ks, int buf) {
+        const unsigned xb = lds0 + buf * STAGE;
+        const unsigned xbase = xoff + (unsigned)ks * step_bytes;
+#pragma unroll
+        for (int i = 0; i < XNI; ++i) dma16_async(xrsrc, xb + i * 4096, (int)(xbase + i * xstep));
+    };
+    auto issue_slab = [&](int ks, int buf) {
+        const unsigned sb = lds0 + buf * STAGE + X_BYTES;
+        int vo[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int R = ks * p.rps + s_r[i];                       // global image row of this slab row's OUTPUT row
+            const int n = (int)fdiv((uint32_t)R, p.dH), yy = R - n * H + ky - 1;
+            const bool ok = s_col[i] >= 0 && R < p.NH && (unsigned)yy < (unsigned)H;
+            vo[i] = ok ? (R + ky - 1) * row_bytes + s_col[i] : (int)0x80000000;
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (wave + 4 * i < p.npiece) dma16_async(rsrc, sb + i * 4096, vo[i]);
+    };
+    auto compute = [&](int buf, int h) {
+        const char* xb = smem + buf * STAGE + h * 32 * XROW;
+        const char* sb = smem + buf * STAGE + X_BYTES;
+        v8 af[TM];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) af[a] = tr_frag<XROW, v8>(xb, wi * (CO_T / 2) + a * 16, fg, fqq, fp);
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(sb + boff[h][0][b]));
+            s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(sb + boff[h][1][b]));
+            typedef short s16x8 __attribute__((ext_vector_type(8)));
+            const s16x8 rr = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            const v8 bf = __builtin_bit_cast(v8, rr);
+#pragma unroll
+            for (int a = 0; a < TM; ++a) acc[a][b] = MM::mma(af[a], bf, acc[a][b]);
+        }
+    };
+
+    if (ks_begin < ks_end) {
+        issue_x(ks_begin, 0);
+        issue_slab(ks_begin, 0);
+        int buf = 0;
+        for (int ks = ks_begin; ks < ks_end; ++ks) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's pieces of stage `buf` have landed
+            __builtin_amdgcn_s_barrier();                                // ... everyone's have, and all reads of buf ^ 1 are done
+            asm volatile("" ::: "memory");
+            const bool more = ks + 1 < ks_end;
+            if (more) issue_x(ks + 1, buf ^ 1);                          // the next step's pieces go out between the two halves' MFMAs
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {                                // (unrolled: boff[h] is a compile-time index)
+                if (h == 1 && more) issue_slab(ks + 1, buf ^ 1);
+                compute(buf, h);
+            }
+            buf ^= 1;
+        }
+    }
+    float* slab = p.slab + (size_t)split * Cout * p.Kpad;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = co0 + wi * (CO_T / 2) + a * 16 + fg * 4 + r;
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                const int tt = 6 * wj + b, kx = tt >> 2, cq = tt & 3;
+                slab[(size_t)co * p.Kpad + (ky * 3 + kx) * Cin + ci0 + cq * 16 + fr] = acc[a][b][r];
+            }
+        }
+}
+
 // dw[co*s_co + tap*s_tap + ci*s_ci] = sum_split slab[split][co][tap*cin_stored + ci]   (ci < cin_real)
 // Each thread owns 4 consecutive k (one 16-byte load per split) of one co; a block is (256 / zlanes) such quads x zlanes
 // split lanes: lane z sums splits z, z + zlanes, ... and lane 0 adds the partials in a fixed order (bitwise
@@ -1226,6 +1412,81 @@ static bool c64_wgrad_geometry(const TriConvDesc* d, int act_fmt, C64WgradArgs* 
     return true;
 }
 
+static bool krow_wgrad_disabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("TRICOLO_NO_KROW_WGRAD"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+// geometry of conv_wgrad_krow_kernel (everything but pointers and the split plan); false when the layer does not qualify.
+// *co_t = 128 / 64 (rows per workgroup tile), *tiles = workgroups per position split, *steps = 64-position steps
+static bool krow_geometry(const TriConvDesc* d, int act_fmt, KrowArgs* g, int* co_t, int* tiles, int* steps) {
+    if (!act_fmt || krow_wgrad_disabled()) return false;
+    if (d->KD != 1 || d->ID != 1 || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad_d != 0 || d->pad_h != 1 || d->pad_w != 1) return false;
+    if (d->Cin % 64 || d->Cout % 64 || d->OH != d->IH || d->OW != d->IW) return false;
+    const int W = d->IW, H = d->IH;
+    if (W != 4 && W != 8 && W != 16 && W != 32 && W != 64) return false;
+    const size_t in_bytes = (size_t)d->B * H * W * d->Cin * 2, dout_bytes = (size_t)d->B * H * W * d->Cout * 2;
+    if (in_bytes >= ((size_t)1 << 31) || dout_bytes >= ((size_t)1 << 31)) return false;
+    KrowArgs a{};
+    a.in_bytes = (unsigned)in_bytes; a.dout_bytes = (unsigned)dout_bytes;
+    a.NH = d->B * H; a.H = H; a.W = W; a.Cin = d->Cin; a.Cout = d->Cout; a.Kpad = 9 * d->Cin;
+    a.rps = 64 / W; a.P = W + 2;
+    if (a.rps * a.P > KROW_SLAB_PX) return false;
+    a.npiece = (a.rps * a.P + 7) / 8;
+    a.nsteps = (a.NH + a.rps - 1) / a.rps;
+    a.ci_chunks = d->Cin / 64;
+    *co_t = d->Cout % 128 == 0 ? 128 : 64;
+    a.ntiles = (d->Cout / *co_t) * 3 * a.ci_chunks;
+    a.dH = make_fastdiv(H); a.dP = make_fastdiv(a.P); a.dW = make_fastdiv(W);
+    *g = a;
+    *tiles = a.ntiles;
+    *steps = a.nsteps;
+    return true;
+}
+#define KROW_TARGET_BLOCKS 512                                      // two workgroups per CU (56 / 40 KB of LDS, <= 256 registers)
+// split plan of a layer launched alone: one resident round of workgroups, at least 4 steps per split
+static void krow_plan_alone(int tiles, int steps, int* sps, int* splits) {
+    int s = KROW_TARGET_BLOCKS / tiles;
+    const int max_by_steps = steps / 4 > 0 ? steps / 4 : 1;
+    if (s > max_by_steps) s = max_by_steps;
+    if (s < 1) s = 1;
+    if (s > 1024) s = 1024;
+    *sps = (steps + s - 1) / s;
+    *splits = (steps + *sps - 1) / *sps;
+}
+static inline int krow_blocks(const KrowArgs& a) {
+    return a.nsplits >= 16 ? ((a.nsplits + 7) / 8) * 8 * a.ntiles : a.nsplits * a.ntiles;
+}
+// jobs of one tile height in ONE launch; block ranges are dealt longest split first so that the short jobs' workgroups fill in behind
+template <int CO_T, typename E>
+static int launch_krow_jobs(const KrowArgs* a, int n, hipStream_t stream) {
+    constexpr int STAGE = 64 * CO_T * 2 + KROW_SLAB_PX * 128;
+    KrowJobs jobs{};
+    int order[WGRAD_JOBS_MAX];
+    for (int i = 0; i < n; ++i) order[i] = i;
+    for (int i = 1; i < n; ++i)                                      // insertion sort by steps per split, descending (stable)
+        for (int j = i; j > 0 && a[order[j]].steps_per_split > a[order[j - 1]].steps_per_split; --j) { int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        jobs.d[i] = a[order[i]];
+        jobs.first_block[i] = blocks;
+        blocks += krow_blocks(a[order[i]]);
+    }
+    jobs.first_block[n] = blocks;
+    jobs.n = n;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)conv_wgrad_krow_kernel<CO_T, E>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
+        attr_set = true;
+    }
+    conv_wgrad_krow_kernel<CO_T, E><<<dim3(blocks), 256, 2 * STAGE, stream>>>(jobs);
+    return tri_check_launch("tri_conv_wgrad(krow)");
+}
+static int launch_krow(int co_t, int act_fmt, const KrowArgs* a, int n, hipStream_t s) {
+    if (act_fmt == TRI_FMT_F16) return co_t == 128 ? launch_krow_jobs<128, f16_t>(a, n, s) : launch_krow_jobs<64, f16_t>(a, n, s);
+    return co_t == 128 ? launch_krow_jobs<128, bf16_t>(a, n, s) : launch_krow_jobs<64, bf16_t>(a, n, s);
+}
+
 extern "C" size_t tri_conv_wgrad_workspace(const TriConvDesc* d) {
     size_t need = 0;
     {
@@ -1237,6 +1498,13 @@ extern "C" size_t tri_conv_wgrad_workspace(const TriConvDesc* d) {
         if (tri_internal_vox0_geometry(d->B, d->ID, d->IH, d->IW, d->Cin, d->OD, d->OH, d->OW, d->Cout, d->KD, d->KH, d->KW, d->stride, d->pad_d,
                                        d->pad_h, d->pad_w, &vg) && tri_internal_vox0_wgrad_grid(vg) > 0)
             need = (size_t)tri_internal_vox0_wgrad_grid(vg) * 32 * 144 * sizeof(float);
+        KrowArgs kg; int co_t, tiles, steps;
+        if (krow_geometry(d, 1, &kg, &co_t, &tiles, &steps)) {
+            int sps, splits;
+            krow_plan_alone(tiles, steps, &sps, &splits);
+            const size_t n = (size_t)splits * d->Cout * kg.Kpad * sizeof(float);
+            if (n > need) need = n;
+        }
     }
     for (int mode = 0; mode < 4; ++mode) {                        // fp32 / 16-bit storage x position range / row list
         int BI, BJ, tiles, splits, sps, Kpad, dma;
@@ -1254,6 +1522,10 @@ extern "C" int tri_conv_wgrad_kernel_family(const TriConvDesc* d, int act_fmt) {
         if (act_fmt && tri_internal_vox0_geometry(d->B, d->ID, d->IH, d->IW, d->Cin, d->OD, d->OH, d->OW, d->Cout, d->KD, d->KH, d->KW, d->stride,
                                                   d->pad_d, d->pad_h, d->pad_w, &vg) && tri_internal_vox0_wgrad_grid(vg) > 0)
             return 6;                                              // conv_vox0_wgrad_kernel when the call passes a site mask
+    }
+    {
+        C64WgradArgs cg; KrowArgs kg; int grid, co_t, tiles, steps;
+        if (!c64_wgrad_geometry(d, act_fmt, &cg, &grid) && krow_geometry(d, act_fmt, &kg, &co_t, &tiles, &steps)) return 7;   // conv_wgrad_krow_kernel
     }
     int BI, BJ, tiles, splits, sps, Kpad, dma;
     wgrad_plan(d, act_fmt, 0, &BI, &BJ, &tiles, &splits, &sps, &Kpad, &dma);
@@ -1498,6 +1770,19 @@ extern "C" int tri_conv_wgrad_partial(const TriConvDesc* d, const void* in, cons
         }
     }
     if (d->Cin % 4 != 0 || d->Cout % 4 != 0) { tri_set_error("wgrad: channels must be multiples of 4"); return TRI_ERR_ARG; }
+    {   // resolution-keeping 3x3 layers, 16-bit storage: conv_wgrad_krow_kernel
+        KrowArgs kg; int co_t, tiles, steps;
+        if (!row_mask && !row_count && !split3 && krow_geometry(d, act_fmt, &kg, &co_t, &tiles, &steps)) {
+            int sps, splits;
+            krow_plan_alone(tiles, steps, &sps, &splits);
+            if (workspace_bytes < (size_t)splits * d->Cout * kg.Kpad * sizeof(float)) { tri_set_error("wgrad(krow): workspace too small"); return TRI_ERR_ARG; }
+            kg.in = in; kg.dout = dout; kg.slab = (float*)workspace; kg.steps_per_split = sps; kg.nsplits = splits;
+            int rc = launch_krow(co_t, act_fmt, &kg, 1, (hipStream_t)stream);
+            if (rc) return rc;
+            wgrad_fill_pending(d, (const float*)workspace, splits, kg.Kpad, dw, s_co, s_tap, s_ci, cin_real, out_scale, pending);
+            return 0;
+        }
+    }
     int BI, BJ, tiles, splits, sps, Kpad, dma;
     wgrad_plan(d, act_fmt, row_count != nullptr, &BI, &BJ, &tiles, &splits, &sps, &Kpad, &dma);
     if (workspace_bytes < (size_t)splits * d->Cout * Kpad * sizeof(float)) { tri_set_error("wgrad: workspace too small"); return TRI_ERR_ARG; }
@@ -1537,22 +1822,21 @@ static int wgrad_group_target(int family) {                     // resident work
     // 128x128 tiles (64 KB of stages + the plan ring: two workgroups per CU): all 512 slots; 64x128 tiles: 448 as for single launches
     // (measured on the bench shape, profiles/r3/NOTES_wgrad.md).  TRICOLO_WGRAD_GROUP_BLOCKS="a,b" overrides (a: 128-row, b: 64-row tiles)
     // 256x128 tiles: one 512-thread workgroup per CU.
-    static int v[3] = {-1, -1, -1};
+    static int v[5] = {-1, -1, -1, -1, -1};
     if (v[0] < 0) {
-        v[0] = 512; v[1] = 448; v[2] = 256;
+        v[0] = 512; v[1] = 448; v[2] = 256; v[3] = KROW_TARGET_BLOCKS; v[4] = KROW_TARGET_BLOCKS;     // (4, 5: conv_wgrad_krow_kernel<128> / <64>)
         const char* e = getenv("TRICOLO_WGRAD_GROUP_BLOCKS");
         if (e) {
-            int a = 0, b = 0, c = 0;
-            const int k = sscanf(e, "%d,%d,%d", &a, &b, &c);
-            if (k >= 1 && a > 0) v[0] = a;
-            if (k >= 2 && b > 0) v[1] = b;
-            if (k >= 3 && c > 0) v[2] = c;
+            int a[5] = {0, 0, 0, 0, 0};
+            const int k = sscanf(e, "%d,%d,%d,%d,%d", &a[0], &a[1], &a[2], &a[3], &a[4]);
+            for (int i = 0; i < k && i < 5; ++i) if (a[i] > 0) v[i] = a[i];
         }
     }
-    return v[family >= 1 && family <= 3 ? family - 1 : 1];
+    return v[family >= 1 && family <= 5 ? family - 1 : 1];
 }
 // ---- several layers in one launch
-// family of a layer for grouping: 0 = not groupable (tri_conv_wgrad_partial), 1 = conv_wgrad_dma_kernel<128,128>, 2 = <64,128>;
+// family of a layer for grouping: 0 = not groupable (tri_conv_wgrad_partial), 1 = conv_wgrad_dma_kernel<128,128>, 2 = <64,128>, 3 = <256,128>
+// (TRICOLO_WGRAD_WIDE), 4 = conv_wgrad_krow_kernel<128>, 5 = conv_wgrad_krow_kernel<64>;
 // tiles = output tiles (workgroups per split), steps = 64-position steps of the contraction
 extern "C" int tri_conv_wgrad_group_info(const TriConvDesc* d, int act_fmt, int* family, int* tiles, int* steps) {
     *family = 0; *tiles = 0; *steps = 0;
@@ -1560,6 +1844,8 @@ extern "C" int tri_conv_wgrad_group_info(const TriConvDesc* d, int act_fmt, int*
     {
         C64WgradArgs cg; StemWgradArgs sg; int grid;
         if (c64_wgrad_geometry(d, act_fmt, &cg, &grid) || stem_wgrad_geometry(d, act_fmt, &sg, &grid)) return 0;
+        KrowArgs kg; int co_t;
+        if (krow_geometry(d, act_fmt, &kg, &co_t, tiles, steps)) { *family = co_t == 128 ? 4 : 5; return 0; }
     }
     int BI, BJ, t, splits, sps, Kpad, dma;
     wgrad_plan(d, act_fmt, 0, &BI, &BJ, &t, &splits, &sps, &Kpad, &dma);
@@ -1582,6 +1868,43 @@ extern "C" int tri_conv_wgrad_group_info(const TriConvDesc* d, int act_fmt, int*
 extern "C" int tri_conv_wgrad_partial_group(const TriWgradJob* jobs, int n, int act_fmt, TriWgradReduce* pending, void* stream) {
     if (n < 1 || n > WGRAD_JOBS_MAX || !jobs || !pending) { tri_set_error("wgrad group: 1..TRI_WGRAD_JOBS_MAX jobs"); return TRI_ERR_ARG; }
     static_assert(WGRAD_JOBS_MAX == TRI_WGRAD_JOBS_MAX, "header and kernel disagree");
+    {
+        int fam, t0, st0;
+        tri_conv_wgrad_group_info(jobs[0].d, act_fmt, &fam, &t0, &st0);
+        if (fam == 4 || fam == 5) {
+            // kernel-row jobs: every job is cut into splits of about the launch's mean workgroup length (total tile-steps / resident
+            // slots), never more splits than it would get alone; the launch may hold more workgroups than slots - they are dealt longest
+            // first and the short ones fill in behind (one resident round would leave the few-step layers' slots idle for most of it)
+            KrowArgs ka[WGRAD_JOBS_MAX];
+            int co_t0 = 0, tl[WGRAD_JOBS_MAX], st[WGRAD_JOBS_MAX];
+            long total = 0;
+            for (int i = 0; i < n; ++i) {
+                int co_t;
+                if (jobs[i].row_pos || jobs[i].row_count || !krow_geometry(jobs[i].d, act_fmt, &ka[i], &co_t, &tl[i], &st[i]) || (i && co_t != co_t0)) {
+                    tri_set_error("wgrad group: jobs must share one groupable kernel family"); return TRI_ERR_ARG;
+                }
+                co_t0 = co_t;
+                total += (long)tl[i] * st[i];
+            }
+            int common = (int)((total + wgrad_group_target(fam) - 1) / wgrad_group_target(fam));
+            if (common < 8) common = 8;
+            for (int i = 0; i < n; ++i) {
+                int sps_alone, splits_alone;
+                krow_plan_alone(tl[i], st[i], &sps_alone, &splits_alone);
+                int sps = n == 1 ? sps_alone : (common > sps_alone ? common : sps_alone);
+                if (sps > st[i]) sps = st[i];
+                const int splits = (st[i] + sps - 1) / sps;
+                sps = (st[i] + splits - 1) / splits;                 // evened out
+                const TriConvDesc* d = jobs[i].d;
+                if (jobs[i].workspace_bytes < (size_t)splits * d->Cout * ka[i].Kpad * sizeof(float)) { tri_set_error("wgrad group(krow): workspace too small"); return TRI_ERR_ARG; }
+                ka[i].in = jobs[i].in; ka[i].dout = jobs[i].dout; ka[i].slab = (float*)jobs[i].workspace;
+                ka[i].steps_per_split = sps; ka[i].nsplits = splits;
+                wgrad_fill_pending(d, (const float*)jobs[i].workspace, splits, ka[i].Kpad, jobs[i].dw, jobs[i].s_co, jobs[i].s_tap, jobs[i].s_ci,
+                                   jobs[i].cin_real, jobs[i].out_scale, &pending[i]);
+            }
+            return launch_krow(co_t0, act_fmt, ka, n, (hipStream_t)stream);
+        }
+    }
     WgradArgs a[WGRAD_JOBS_MAX];
     int fam0 = 0, ind_sps[WGRAD_JOBS_MAX], tiles[WGRAD_JOBS_MAX], steps[WGRAD_JOBS_MAX], Kpads[WGRAD_JOBS_MAX];
     long total = 0;

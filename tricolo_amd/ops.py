@@ -226,6 +226,7 @@ class ConvGeom:
         self.wgrad_ws = lib().tri_conv_wgrad_workspace(_C.C.byref(self.desc))
         fam = lib().tri_conv_wgrad_kernel_family(_C.C.byref(self.desc), 1)
         self.wgrad_dma = fam == 2
+        self.wgrad_krow = fam == 7                                # conv_wgrad_krow_kernel (resolution-keeping 3x3 layers, 16-bit storage, no row mask / list)
         self.wgrad_brick = fam == 6                               # conv_vox0_wgrad_kernel: needs the dense site mask (row_mask), not a row list
         self._plans = {}
         self.fwd_ws = lib().tri_conv_workspace(_C.C.byref(self.desc), 0)
@@ -436,7 +437,8 @@ _WGRAD_GROUPED = os.environ.get("TRICOLO_WGRAD_GROUPED", "1") != "0"     # A/B s
 _WGRAD_JOBS = os.environ.get("TRICOLO_WGRAD_JOBS", "1") != "0"           # A/B switch: one partial launch per layer instead
 # output tiles (workgroups per split) one grouped partial launch takes, per kernel family (1: 128-row, 2: 64-row, 3: 256-row tiles); the
 # library's split planner uses the same figures (TRICOLO_WGRAD_GROUP_BLOCKS)
-_WGRAD_JOB_TILES = dict(zip((1, 2, 3), (int(v) for v in os.environ.get("TRICOLO_WGRAD_JOB_TILES", "512,448,256").split(","))))
+# (4, 5: conv_wgrad_krow_kernel<128> / <64>; a krow launch may hold more workgroups than resident slots, the library deals them longest first)
+_WGRAD_JOB_TILES = dict(zip((1, 2, 3, 4, 5), [int(v) for v in os.environ.get("TRICOLO_WGRAD_JOB_TILES", "512,448,256,512,512").split(",")] + [512] * 5))
 
 
 class WgradBatch:
@@ -547,6 +549,8 @@ def conv_wgrad(x, dout, g: ConvGeom, like: torch.Tensor, precision: str, row_mas
     s3 = 1 if (split3(precision) and not h16) else 0          # fp32 tensors (heads, GRU) take the 3-product split in the f16 mode too
     if h16 and g.wgrad_brick and row_mask is not None:
         sym = f"conv_vox0_wgrad_kernel<{_TNAME[x.dtype]}>"
+    elif h16 and g.wgrad_krow and row_mask is None and rows is None:
+        sym = f"conv_wgrad_krow_kernel<{128 if g.cout % 128 == 0 else 64}, {_TNAME[x.dtype]}>"
     elif h16 and g.wgrad_dma:
         sym = f"conv_wgrad_dma_kernel<{bi}, {bj}, {_TNAME[x.dtype]}>"
     else:
