@@ -219,6 +219,13 @@ int tri_bn_bwd_num_blocks(long M);
 int tri_bn_bwd_reduce(const void* y, const void* g, long M, int C, float* partial, const float* relu_scale, const float* relu_shift,
                       const void* relu_out, const uint8_t* row_mask /* optional: rows with 0 are skipped (never read) */, int act_fmt,
                       void* stream);
+/* BatchNorm backward of a SMALL tensor (M <= 16,384 rows) in ONE launch: a workgroup owns 4 / 8 channels for all positions - sums,
+ * coefficients (double) and the apply pass without records or a finalize launch.  Arguments as tri_bn_bwd_reduce / _finalize / _apply
+ * (dy may alias g); TRI_ERR_UNSUPPORTED for other shapes. */
+int tri_bn_bwd_small(const void* y, const void* g, long M, int C, const int* count_dev, int count_host, const float* gamma,
+                     const float* mean, const float* invstd, const float* relu_scale, const float* relu_shift, const void* relu_out,
+                     void* g_masked, const uint8_t* row_mask, int keep_inactive, void* dy, float* dgamma, float* dbeta, float out_scale,
+                     int act_fmt, void* stream);
 int tri_bn_bwd_finalize(const float* partial, int nblk, int C, const int* count_dev, int count_host, const float* gamma,
                         const float* mean, const float* invstd, float* dgamma, float* dbeta, float* c1, float* c2, float* c3,
                         float out_scale /* dgamma, dbeta *= out_scale (g carries the f16 mode's gradient scale; dy keeps it) */,
@@ -295,7 +302,9 @@ int tri_cast_to_f32(const void* src, float* dst, long n, int act_fmt, void* stre
  * w_hh [2][384][128], b_hh [2][384].  Outputs: hs [2][L][B][128], gates [2][L][B][128][4] (r,z,n,hn per unit) saved for backward,
  * hfinal [B][256] = cat(forward final state, reverse final state) (bigru.py:18).  tri_gru_bwd returns the gate
  * pre-activation gradients dgi [L][B][768], dgh [2][L][B][384] and h_{t-1} rows hprev [2][L][B][128]; the weight
- * gradients are then plain GEMMs (tri_conv_wgrad with 1x1 geometry). */
+ * gradients are then plain GEMMs (tri_conv_wgrad with 1x1 geometry).
+ * split3: MFMA operand mode of the recurrence - 0 single bf16 products, 1 the 3-product bf16 hi/lo split (fp32-grade), 2 single f16
+ * products (the f16 mode; the backward carries its gate gradients through LDS times 2^12). */
 int tri_gru_fwd(const float* xproj, const float* w_hh, const float* b_hh, int B, int L, float* hs, float* gates, float* hfinal,
                 int split3, void* stream);
 int tri_gru_bwd(const float* dhfinal, const float* w_hh, const float* hs, const float* gates, int B, int L, float* dgi, float* dgh,

@@ -397,6 +397,75 @@ def test_bn_bwd_residual_relu_mask(dtype):
     assert torch.equal(d2, gz)                                      # the residual branch's gradient, written in place
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("M,C,mode", [(3072, 512, "plain"), (3072, 512, "relu"), (12288, 256, "relu_out"), (16384, 128, "rowmask"),
+                                      (2048, 256, "rowmask_keep"), (777, 64, "relu"), (256, 512, "rowmask"), (243, 512, "rowmask_keep")])
+def test_bn_bwd_small_matches_the_three_pass_form(monkeypatch, M, C, mode, dtype):
+    """tri_bn_bwd_small (one workgroup per 4 / 8 channels over all positions: sums, coefficients and apply in one launch - the deepest
+    voxel level in the product, every size it accepts here) against reduce + finalize + apply on the same tensors, every mask form, with a row mask and a
+    device-side count, fp32 and f16 storage.  Same arithmetic, different summation order: dy to 1e-5 of its scale (one f16 ulp for f16
+    storage), dgamma / dbeta to 1e-4."""
+    g = torch.Generator().manual_seed(M + C)
+    y = (torch.randn(M, C, generator=g) * 1.5 + 0.2).to(dtype).to(DEV)
+    gin = torch.randn(M, C, generator=g).to(dtype).to(DEV)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), (torch.randn(C, generator=g) * 0.3).to(DEV)
+    mask = cnt = None
+    rows = torch.ones(M, dtype=torch.bool)
+    if mode.startswith("rowmask"):
+        rows = torch.rand(M, generator=g) < 0.4
+        mask = torch.zeros((M + 31) // 32 * 32, dtype=torch.uint8)
+        mask[:M] = rows.to(torch.uint8)
+        mask = mask.to(DEV)
+        cnt = ops.mask_count(mask, M)
+        y[~rows.to(DEV)] = float("nan")                                # rows of inactive sites are never read
+        gin[~rows.to(DEV)] = float("nan")
+    yf = y.float()[rows.to(DEV)].double()
+    stats = torch.stack([yf.sum(0).float(), (yf ** 2).sum(0).float()]).view(1, 2, C)
+    co = ops.bn_finalize(stats, C, gamma, beta, None, None, None, count_dev=cnt, count_host=0 if cnt is not None else M)
+    kw = dict(count_dev=cnt, count_host=0 if cnt is not None else M, row_mask=mask, inplace=False, out_scale=0.5)
+    res = {}
+    real_small = ops.lib().tri_bn_bwd_small
+
+    def bn_bwd_forced_small(y_, g_, co_, gamma_, count_dev=None, count_host=0, row_mask=None, inplace=True, relu=False, relu_out=None,
+                            g_masked=None, out_scale=1.0, keep_inactive=False):
+        """ops.bn_bwd's small branch for ANY M <= 16,384 (the product takes it for M <= 512 only)."""
+        rs, rb = (co_.scale, co_.shift) if relu else (None, None)
+        dy = g_ if inplace else torch.empty_like(g_)
+        buf = torch.empty((2, C), dtype=torch.float32, device=DEV)
+        ops.check(real_small(ops.ptr(y_), ops.ptr(g_), M, C, ops.ptr(count_dev), int(count_host), ops.ptr(gamma_), ops.ptr(co_.mean),
+                             ops.ptr(co_.invstd), ops.ptr(rs), ops.ptr(rb), ops.ptr(relu_out), ops.ptr(g_masked), ops.ptr(row_mask),
+                             1 if keep_inactive else 0, ops.ptr(dy), ops.ptr(buf[0]), ops.ptr(buf[1]), float(out_scale), ops._abf(y_), ops.stream()),
+                  "tri_bn_bwd_small")
+        return dy, buf[0], buf[1]
+    for small in (True, False):
+        monkeypatch.setattr(ops, "_BN_SMALL", False)
+        bn_bwd = bn_bwd_forced_small if small else ops.bn_bwd
+        g_in = gin.clone()
+        if mode == "relu":
+            out = bn_bwd(y, g_in, co, gamma, relu=True, **kw)
+            extra = None
+        elif mode == "relu_out":
+            ro = (torch.randn(M, C, generator=torch.Generator().manual_seed(5)) > 0).to(dtype).to(DEV)
+            out = bn_bwd(y, g_in, co, gamma, relu_out=ro, g_masked=g_in, **kw)
+            extra = g_in
+        else:
+            out = bn_bwd(y, g_in, co, gamma, keep_inactive=mode == "rowmask_keep", **kw)
+            extra = None
+        res[small] = (out, extra)
+    (dy_s, dg_s, db_s), ex_s = res[True]
+    (dy_r, dg_r, db_r), ex_r = res[False]
+    live = rows.to(DEV)
+    scale = float(dy_r[live].float().abs().max())
+    tol = 1e-5 * scale if dtype == torch.float32 else 2e-3 * scale
+    assert float((dy_s[live].float() - dy_r[live].float()).abs().max()) <= tol
+    if mode == "rowmask":
+        assert bool((dy_s[~live] == 0).all())                          # inactive rows zeroed
+    np.testing.assert_allclose(dg_s.cpu().numpy(), dg_r.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(dg_r.abs().max()))
+    np.testing.assert_allclose(db_s.cpu().numpy(), db_r.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(db_r.abs().max()))
+    if ex_s is not None:
+        assert torch.equal(ex_s, ex_r)                                 # the masked gradient for the residual branch
+
+
 def test_voxel_bn_pool_forward_backward_matches_oracle():
     from oracle import spconv_dense as sp
     g = torch.Generator().manual_seed(5)
@@ -697,7 +766,7 @@ def test_ntxent_large_batch_against_float64():
     np.testing.assert_allclose(dzb.cpu().numpy(), db, atol=1e-6)
 
 
-@pytest.mark.parametrize("precision,tol", [("bf16x3", 2e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 2e-5), ("bf16", 2e-2), ("f16", 2e-3)])      # f16: single f16 products (ops.gru_mode)
 @pytest.mark.parametrize("B,L", [(8, 96), (19, 7)])
 def test_gru_recurrence_matches_explicit_equations(precision, tol, B, L):
     from oracle.modules import gru_explicit

@@ -38,7 +38,7 @@ def main():
     torch.cuda.current_stream().wait_stream(s)
     torch.cuda.synchronize()
     buf = torch.zeros((256,), dtype=torch.int64, device=device)
-    ops.TIMELINE = {"buf": buf, "names": []}
+    ops.TIMELINE = {"buf": buf, "names": [], "fine": os.environ.get("TRICOLO_FINE_STAMPS", "0") == "1"}   # fine: a stamp behind every unit of the image tower
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         step()

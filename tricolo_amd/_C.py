@@ -87,6 +87,7 @@ SIGNATURES = {
     "tri_bn_bwd_num_blocks": (I, [L]),
     "tri_bn_bwd_reduce": (I, [P, P, L, I, P, P, P, P, P, I, P]),
     "tri_bn_bwd_finalize": (I, [P, I, I, P, I, P, P, P, P, P, P, P, P, F, P]),
+    "tri_bn_bwd_small": (I, [P, P, L, I, P, I, P, P, P, P, P, P, P, P, I, P, P, P, F, I, P]),
     "tri_bn_bwd_apply": (I, [P, P, P, P, P, P, P, L, I, P, P, P, P, I, I, P]),
     "tri_bn_relu_pool3d_fwd": (I, [P, P, P, P, I, I, I, P, P, I, P]),
     "tri_pool3d_bwd_route": (I, [P, P, P, P, P, P, I, I, I, P, I, P]),
@@ -147,6 +148,45 @@ def lib():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
         _lib = l
+    return _lib
+
+
+class _TimedLib:
+    """Diagnostic proxy (tools/kernel_times.py): every tri_* call that takes a stream is bracketed by two HIP events on the current
+    stream; `records` collects (entry point, start, end).  Never installed by the product path."""
+
+    def __init__(self, real):
+        self._real, self.records = real, []
+
+    def __getattr__(self, name):
+        fn = getattr(self._real, name)
+        sig = SIGNATURES.get(name)
+        if sig is None or not name.startswith("tri_") or not sig[1] or sig[0] is not I or name in ("tri_last_error",):
+            return fn
+        if "workspace" in name or "num_" in name or "_info" in name or "kpad" in name or "family" in name or "bytes" in name or "supported" in name or "scratch" in name or "records" in name:
+            return fn
+
+        shape_args = {"tri_bn_bwd_reduce": (2, 3), "tri_bn_bwd_apply": (7, 8), "tri_bn_act": (7, 8), "tri_bn_finalize": (1, 2),
+                      "tri_bn_bwd_finalize": (1, 2), "tri_bn_bwd_small": (2, 3)}.get(name)
+
+        def timed(*a):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*a)
+            e1.record()
+            key = name if shape_args is None else f"{name}[{int(a[shape_args[0]])}x{int(a[shape_args[1]])}]"
+            self.records.append((key, e0, e1))
+            return rc
+        return timed
+
+
+def install_timing_proxy():
+    """Replace the library handle by a _TimedLib (diagnostics only); returns it."""
+    global _lib
+    real = lib()
+    if isinstance(real, _TimedLib):
+        return real
+    _lib = _TimedLib(real)
     return _lib
 
 

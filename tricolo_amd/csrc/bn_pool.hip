@@ -147,6 +147,9 @@ extern "C" int tri_relu_bwd(const void* dout, const void* out, void* g, long n, 
 // rows per block: 256 for large tensors, 64 for small ones (so that a 3,072-row layer still fills 48 CUs)
 // ... and at most ~2,048 workgroups (= records for bn_bwd_finalize: a 2.4 M-row layer of the 224^2 configurations had 9,408)
 static inline int bnb_rows(long M) {
+    // small tensors are latency, not bandwidth: 16-row blocks put a 3,072-row layer on 192 CUs instead of 48 (7.3 -> ~3 us, round 4)
+    if (M <= 16384) return 16;
+    if (M <= 32768) return 32;
     if (M < 65536) return 64;
     long rows = (M + 2047) / 2048;
     rows = (rows + 63) / 64 * 64;
@@ -321,6 +324,144 @@ extern "C" int tri_bn_bwd_apply(const void* y, const void* g, const float* c1, c
     else TRI_BNA(0);
 #undef TRI_BNA
     return tri_check_launch("tri_bn_bwd_apply");
+}
+
+// ---- BatchNorm backward of a TINY tensor in one launch (tri_bn_bwd_small)
+// The deepest voxel level holds a few hundred rows: its three passes (reduce on 4 workgroups: 22 us, finalize, apply, two launch
+// boundaries) are pure latency.  Here one workgroup owns CH channels for ALL M positions: pass 1 sums g and g * y over the positions (every load of the pass in flight at once), the coefficients are formed in
+// double by the workgroup itself, pass 2 re-reads y and g - L2 / L1 hits, the tensor was just read - and writes dy.  No records, no
+// finalize launch, no second kernel.  A position row is C * 2 bytes, of which a workgroup reads CH * 2: the 128-byte lines are shared
+// with the workgroups of the neighbouring channel groups, so groups are dealt to the XCDs in contiguous runs (block b: XCD b % 8 takes
+// groups [b % 8 * nblk / 8 ...)) - each XCD's L2 then fetches only its own columns of the tensor.
+// MEASURED (round 4, HIP events, eager): 256 x 512: 3.4 us against 22.4 + 1.4 + 1.7; but every wave load touches 64 cache lines for 16
+// bytes each, so it loses from ~1 k rows on (2,048 x 256: 13.1 against 9.8 + 1.4 + 1.6; 3,072 x 512: 32 against 11; 12,288 x 256: 89
+// against 11): ops.bn_bwd takes it for M <= 512 only.
+template <typename T, int MASK, int CH>
+__global__ __launch_bounds__(256) void bn_bwd_small_kernel(const T* __restrict__ y, const T* g, long M, int C, const int* __restrict__ count_dev,
+                                                           int count_host, const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ rs,
+                                                           const float* __restrict__ rb, const T* __restrict__ ro, T* gm,
+                                                           const uint8_t* __restrict__ row_mask, int keep_inactive, T* dy,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, float out_scale) {
+    constexpr int Q = CH / 4;                                        // float4 quads per position
+    __shared__ float red[4][2 * CH];
+    __shared__ float coef[3 * CH];
+    const int nblk = gridDim.x;
+    const int grp = (nblk % 8 == 0) ? (int)(blockIdx.x % 8) * (nblk / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    const int c0 = grp * CH;
+    const int t = threadIdx.x;
+    float4 s4[Q], b4[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        s4[q] = make_float4(0.f, 0.f, 0.f, 0.f); b4[q] = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (MASK == 1) { s4[q] = *(const float4*)(rs + c0 + 4 * q); b4[q] = *(const float4*)(rb + c0 + 4 * q); }
+    }
+    auto masked = [&](float4 gv, const float4& yv, const float4& ov, int q) -> float4 {
+        if (MASK == 1) {
+            gv.x = __fmaf_rn(yv.x, s4[q].x, b4[q].x) > 0.f ? gv.x : 0.f; gv.y = __fmaf_rn(yv.y, s4[q].y, b4[q].y) > 0.f ? gv.y : 0.f;
+            gv.z = __fmaf_rn(yv.z, s4[q].z, b4[q].z) > 0.f ? gv.z : 0.f; gv.w = __fmaf_rn(yv.w, s4[q].w, b4[q].w) > 0.f ? gv.w : 0.f;
+        }
+        if (MASK == 2) { gv.x = ov.x > 0.f ? gv.x : 0.f; gv.y = ov.y > 0.f ? gv.y : 0.f; gv.z = ov.z > 0.f ? gv.z : 0.f; gv.w = ov.w > 0.f ? gv.w : 0.f; }
+        return gv;
+    };
+    float4 sg[Q], sgy[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) sg[q] = sgy[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+    for (long r = t; r < M; r += 256) {
+        if (row_mask && !row_mask[r]) continue;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const long o = r * C + c0 + 4 * q;
+            const float4 yv = Act<T>::ld4(y + o);
+            float4 ov = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (MASK == 2) ov = Act<T>::ld4(ro + o);
+            const float4 gv = masked(Act<T>::ld4(g + o), yv, ov, q);
+            sg[q].x += gv.x; sg[q].y += gv.y; sg[q].z += gv.z; sg[q].w += gv.w;
+            sgy[q].x += gv.x * yv.x; sgy[q].y += gv.y * yv.y; sgy[q].z += gv.z * yv.z; sgy[q].w += gv.w * yv.w;
+        }
+    }
+    {   // wave sums, then the four waves through LDS
+        float v[2 * CH];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            v[4 * q] = sg[q].x; v[4 * q + 1] = sg[q].y; v[4 * q + 2] = sg[q].z; v[4 * q + 3] = sg[q].w;
+            v[CH + 4 * q] = sgy[q].x; v[CH + 4 * q + 1] = sgy[q].y; v[CH + 4 * q + 2] = sgy[q].z; v[CH + 4 * q + 3] = sgy[q].w;
+        }
+#pragma unroll
+        for (int k = 0; k < 2 * CH; ++k) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o);
+        }
+        if ((t & 63) == 0)
+#pragma unroll
+            for (int k = 0; k < 2 * CH; ++k) red[t >> 6][k] = v[k];
+    }
+    __syncthreads();
+    if (t < CH) {
+        const double s = ((double)red[0][t] + (double)red[1][t]) + ((double)red[2][t] + (double)red[3][t]);
+        const double q = ((double)red[0][CH + t] + (double)red[1][CH + t]) + ((double)red[2][CH + t] + (double)red[3][CH + t]);
+        const double n = (double)(count_dev ? *count_dev : count_host);
+        const int c = c0 + t;
+        if (n < 1.0) { dgamma[c] = 0.f; dbeta[c] = 0.f; coef[t] = 0.f; coef[CH + t] = 0.f; coef[2 * CH + t] = 0.f; }
+        else {                                                        // as bn_bwd_finalize_kernel
+            const double mu = mean[c], is = invstd[c], ga = gamma[c];
+            const double dbe = s, dga = is * (q - mu * s);
+            dgamma[c] = (float)(dga * (double)out_scale);
+            dbeta[c] = (float)(dbe * (double)out_scale);
+            const double k1 = ga * is, k3 = -ga * is * is * dga / n, k2 = -k1 * dbe / n - k3 * mu;
+            coef[t] = (float)k1; coef[CH + t] = (float)k2; coef[2 * CH + t] = (float)k3;
+        }
+    }
+    __syncthreads();
+    float4 k1[Q], k2[Q], k3[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        k1[q] = *(const float4*)(coef + 4 * q); k2[q] = *(const float4*)(coef + CH + 4 * q); k3[q] = *(const float4*)(coef + 2 * CH + 4 * q);
+    }
+#pragma unroll 4
+    for (long r = t; r < M; r += 256) {
+        const bool live = !row_mask || row_mask[r];
+        if (!live && keep_inactive) continue;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const long o = r * C + c0 + 4 * q;
+            float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live) {
+                const float4 yv = Act<T>::ld4(y + o);
+                float4 ov = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (MASK == 2) ov = Act<T>::ld4(ro + o);
+                const float4 gv = masked(Act<T>::ld4(g + o), yv, ov, q);
+                if (MASK == 2 && gm) Act<T>::st4(gm + o, gv);
+                out.x = k1[q].x * gv.x + k2[q].x + k3[q].x * yv.x; out.y = k1[q].y * gv.y + k2[q].y + k3[q].y * yv.y;
+                out.z = k1[q].z * gv.z + k2[q].z + k3[q].z * yv.z; out.w = k1[q].w * gv.w + k2[q].w + k3[q].w * yv.w;
+            }
+            Act<T>::st4(dy + o, out);
+        }
+    }
+}
+// The whole BatchNorm backward of a small layer: (dy, dgamma, dbeta) from y, g and the forward's mean / invstd; relu_scale / relu_shift,
+// relu_out, g_masked, row_mask, keep_inactive as in tri_bn_bwd_reduce / tri_bn_bwd_apply (dy may alias g; g_masked may alias g).
+// TRI_ERR_UNSUPPORTED for tensors it is not meant for (M > 16,384 rows or C % 8 != 0): the caller then runs the three passes.
+extern "C" int tri_bn_bwd_small(const void* y, const void* g, long M, int C, const int* count_dev, int count_host, const float* gamma,
+                                const float* mean, const float* invstd, const float* relu_scale, const float* relu_shift,
+                                const void* relu_out, void* g_masked, const uint8_t* row_mask, int keep_inactive, void* dy, float* dgamma,
+                                float* dbeta, float out_scale, int act_fmt, void* stream) {
+    if (M > 16384 || M < 1 || C % 8 || C < 64) { tri_set_error("tri_bn_bwd_small: M <= 16384 rows, C % 8 == 0, C >= 64"); return TRI_ERR_UNSUPPORTED; }
+    if (relu_scale && relu_out) { tri_set_error("tri_bn_bwd_small: give either relu_scale/shift or relu_out"); return TRI_ERR_ARG; }
+    const int ch = C / 8 >= 64 ? 8 : 4;                             // at least 64 workgroups where the channel count allows
+    hipStream_t st = (hipStream_t)stream;
+#define TRI_BNS1(MASK_, CH_)                                                                                                             \
+    TRI_ACT_DISPATCH(act_fmt, bn_bwd_small_kernel<T, MASK_, CH_><<<C / CH_, 256, 0, st>>>(                                               \
+        (const T*)y, (const T*)g, M, C, count_dev, count_host, gamma, mean, invstd, relu_scale, relu_shift, (const T*)relu_out,         \
+        (T*)g_masked, row_mask, keep_inactive, (T*)dy, dgamma, dbeta, out_scale))
+#define TRI_BNS(MASK_) do { if (ch == 8) TRI_BNS1(MASK_, 8); else TRI_BNS1(MASK_, 4); } while (0)
+    if (relu_out) TRI_BNS(2);
+    else if (relu_scale) TRI_BNS(1);
+    else TRI_BNS(0);
+#undef TRI_BNS
+#undef TRI_BNS1
+    return tri_check_launch("tri_bn_bwd_small");
 }
 
 // --------------------------------------------------------------------- voxel: BN + ReLU + mask + 2^3 max-pool

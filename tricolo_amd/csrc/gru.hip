@@ -26,7 +26,10 @@ __device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __builti
 // LDS image of a [16][ncols] bf16 matrix: 16-byte chunk c of row r stored at chunk (c ^ (r & 15))
 __device__ __forceinline__ int himg_off(int row, int chunk, int row_bytes) { return row * row_bytes + ((chunk ^ (row & 15)) << 4); }
 
-template <int NSPLIT>
+// E = MFMA operand type: bf16_t (NSPLIT 1: single products, 2: the 3-product hi/lo split) or f16_t (NSPLIT 1, the f16 mode: |h| < 1 and
+// |W_hh| < 0.1 sit comfortably in f16's range, 11 significand bits against bf16's 8 keep the final embedding within 4e-5 of float64 over
+// the 96 steps - bf16 single products: 2.5e-4 - at a third of the split mode's MFMAs, which are a step's longest serial part)
+template <int NSPLIT, typename E>
 __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ xproj,   // [L][B][768]
                                                       const float* __restrict__ w_hh,    // [2][384][128]
                                                       const float* __restrict__ b_hh,    // [2][384]
@@ -41,8 +44,10 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
     const int unit = 16 * w + fr;
     const float* W = w_hh + (size_t)dir * 384 * GRU_H;
 
+    typedef Mma<E> MM;
+    typedef typename MM::v8 v8;
     // W_hh fragments: B operand of D[row][unit] += h[row][k] * W[g*128 + unit][k]
-    bf16x8 wh[3][4], wl[3][4];
+    v8 wh[3][4], wl[3][4];
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
@@ -52,9 +57,9 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
             float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                bf16_t h = (bf16_t)v[j];
+                E h = (E)v[j];
                 wh[g][ks][j] = h;
-                if (NSPLIT == 2) wl[g][ks][j] = (bf16_t)(v[j] - (float)h);
+                if (NSPLIT == 2) wl[g][ks][j] = (E)(v[j] - (float)h);
             }
         }
     const float bhr = b_hh[dir * 384 + unit], bhz = b_hh[dir * 384 + 128 + unit], bhn = b_hh[dir * 384 + 256 + unit];
@@ -98,16 +103,16 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             int off = himg_off(fr, ks * 4 + fq, 256);
-            bf16x8 ah = *(const bf16x8*)(hb + off);
-            bf16x8 al;
-            if (NSPLIT == 2) al = *(const bf16x8*)(hb + 16 * 256 + off);
+            v8 ah = *(const v8*)(hb + off);
+            v8 al;
+            if (NSPLIT == 2) al = *(const v8*)(hb + 16 * 256 + off);
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
                 if (NSPLIT == 2) {
-                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wh[g][ks], acc[g], 0, 0, 0);
-                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wl[g][ks], acc[g], 0, 0, 0);
+                    acc[g] = MM::mma(al, wh[g][ks], acc[g]);
+                    acc[g] = MM::mma(ah, wl[g][ks], acc[g]);
                 }
-                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wh[g][ks], acc[g], 0, 0, 0);
+                acc[g] = MM::mma(ah, wh[g][ks], acc[g]);
             }
         }
         char* hn_buf = lds + (cur ^ 1) * (NSPLIT * 16 * 256);
@@ -125,11 +130,11 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
                 hs[o * GRU_H + unit] = hnew;
                 *(float4*)(gates + (o * GRU_H + unit) * 4) = make_float4(rg, zg, ng, ghn);      // one 16-byte store per (row, unit)
             }
-            // re-publish as bf16 (hi, lo): element (row, unit) -> chunk unit/8, byte (unit%8)*2
-            bf16_t hh = (bf16_t)hnew;
+            // re-publish as 16-bit (hi, lo): element (row, unit) -> chunk unit/8, byte (unit%8)*2
+            E hh = (E)hnew;
             int off = himg_off(row, unit >> 3, 256) + (unit & 7) * 2;
-            *(bf16_t*)(hn_buf + off) = hh;
-            if (NSPLIT == 2) *(bf16_t*)(hn_buf + 16 * 256 + off) = (bf16_t)(hnew - (float)hh);
+            *(E*)(hn_buf + off) = hh;
+            if (NSPLIT == 2) *(E*)(hn_buf + 16 * 256 + off) = (E)(hnew - (float)hh);
         }
         cur ^= 1;
         __syncthreads();
@@ -144,7 +149,9 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
 // Backward through time.  dhfinal [B][256] seeds dh; per step the lane-local cell backward produces the gate
 // pre-activation gradients dgi (w.r.t. x W_ih^T + b_ih) and dgh (w.r.t. h W_hh^T + b_hh), stores both for the batched
 // weight-gradient GEMMs, and dh_{t-1} = dh * z + dgh @ W_hh through MFMA (W_hh column fragments resident in registers).
-template <int NSPLIT>
+// (E = f16_t: the gate gradients go through LDS times 2^12 - they are 1e-2 .. 1e-7, f16's normal range ends at 6e-5 - and the MFMA
+//  result is multiplied by 2^-12: both exact)
+template <int NSPLIT, typename E>
 __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ dhfinal,  // [B][256]
                                                       const float* __restrict__ w_hh,     // [2][384][128]
                                                       const float* __restrict__ hs,       // [2][L][B][128]
@@ -161,16 +168,19 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
     const int unit = 16 * w + fr;
     const float* W = w_hh + (size_t)dir * 384 * GRU_H;
 
+    typedef Mma<E> MM;
+    typedef typename MM::v8 v8;
+    constexpr float GS = sizeof(E) == 2 && NSPLIT == 1 && __is_same(E, f16_t) ? 4096.f : 1.f;
     // B operand of D[row][unit] += dgh[row][k] * W[k][unit],  k over the 384 gate units
-    bf16x8 wh[12], wl[12];
+    v8 wh[12], wl[12];
 #pragma unroll
     for (int ks = 0; ks < 12; ++ks)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float v = W[(size_t)(ks * 32 + fq * 8 + j) * GRU_H + unit];
-            bf16_t hgh = (bf16_t)v;
+            E hgh = (E)v;
             wh[ks][j] = hgh;
-            if (NSPLIT == 2) wl[ks][j] = (bf16_t)(v - (float)hgh);
+            if (NSPLIT == 2) wl[ks][j] = (E)(v - (float)hgh);
         }
 
     float dh[4];
@@ -235,14 +245,14 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
                 hprev[o * GRU_H + unit] = hp;
                 sb[0] += dr_pre; sb[1] += dz_pre; sb[2] += dn_pre; sb[3] += dgn;
             }
-            float vals[3] = {dr_pre, dz_pre, dgn};
+            float vals[3] = {dr_pre * GS, dz_pre * GS, dgn * GS};
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
                 int col = g * GRU_H + unit;
-                bf16_t hh = (bf16_t)vals[g];
+                E hh = (E)vals[g];
                 int off = himg_off(row, col >> 3, 768) + (col & 7) * 2;
-                *(bf16_t*)(gb + off) = hh;
-                if (NSPLIT == 2) *(bf16_t*)(gb + 16 * 768 + off) = (bf16_t)(vals[g] - (float)hh);
+                *(E*)(gb + off) = hh;
+                if (NSPLIT == 2) *(E*)(gb + 16 * 768 + off) = (E)(vals[g] - (float)hh);
             }
         }
         __syncthreads();
@@ -250,16 +260,16 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
 #pragma unroll
         for (int ks = 0; ks < 12; ++ks) {
             int off = himg_off(fr, ks * 4 + fq, 768);
-            bf16x8 ah = *(const bf16x8*)(gb + off);
+            v8 ah = *(const v8*)(gb + off);
             if (NSPLIT == 2) {
-                bf16x8 al = *(const bf16x8*)(gb + 16 * 768 + off);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wh[ks], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wl[ks], acc, 0, 0, 0);
+                v8 al = *(const v8*)(gb + 16 * 768 + off);
+                acc = MM::mma(al, wh[ks], acc);
+                acc = MM::mma(ah, wl[ks], acc);
             }
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wh[ks], acc, 0, 0, 0);
+            acc = MM::mma(ah, wh[ks], acc);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dh[r] = dhz[r] + acc[r];
+        for (int r = 0; r < 4; ++r) dh[r] = dhz[r] + acc[r] * (1.f / GS);
         cur ^= 1;                                             // next step writes the other image: one barrier per step
     }
 #pragma unroll
@@ -275,8 +285,10 @@ extern "C" int tri_gru_fwd(const float* xproj, const float* w_hh, const float* b
                            float* hfinal, int split3, void* stream) {
     if (B < 1 || L < 1) { tri_set_error("tri_gru_fwd: B, L must be positive"); return TRI_ERR_ARG; }
     dim3 grid((B + 15) / 16, 2);
-    if (split3) gru_fwd_kernel<2><<<grid, 512, 0, (hipStream_t)stream>>>(xproj, w_hh, b_hh, B, L, hs, gates, hfinal);
-    else gru_fwd_kernel<1><<<grid, 512, 0, (hipStream_t)stream>>>(xproj, w_hh, b_hh, B, L, hs, gates, hfinal);
+    // split3: 0 single bf16 products, 1 the 3-product bf16 split, 2 single f16 products (the f16 mode)
+    if (split3 == 2) gru_fwd_kernel<1, f16_t><<<grid, 512, 0, (hipStream_t)stream>>>(xproj, w_hh, b_hh, B, L, hs, gates, hfinal);
+    else if (split3) gru_fwd_kernel<2, bf16_t><<<grid, 512, 0, (hipStream_t)stream>>>(xproj, w_hh, b_hh, B, L, hs, gates, hfinal);
+    else gru_fwd_kernel<1, bf16_t><<<grid, 512, 0, (hipStream_t)stream>>>(xproj, w_hh, b_hh, B, L, hs, gates, hfinal);
     return tri_check_launch("tri_gru_fwd");
 }
 
@@ -284,7 +296,8 @@ extern "C" int tri_gru_bwd(const float* dhfinal, const float* w_hh, const float*
                            float* dgh, float* hprev, float* dbias, int split3, void* stream) {
     if (B < 1 || L < 1) { tri_set_error("tri_gru_bwd: B, L must be positive"); return TRI_ERR_ARG; }
     dim3 grid((B + 15) / 16, 2);
-    if (split3) gru_bwd_kernel<2><<<grid, 512, 0, (hipStream_t)stream>>>(dhfinal, w_hh, hs, gates, B, L, dgi, dgh, hprev, dbias);
-    else gru_bwd_kernel<1><<<grid, 512, 0, (hipStream_t)stream>>>(dhfinal, w_hh, hs, gates, B, L, dgi, dgh, hprev, dbias);
+    if (split3 == 2) gru_bwd_kernel<1, f16_t><<<grid, 512, 0, (hipStream_t)stream>>>(dhfinal, w_hh, hs, gates, B, L, dgi, dgh, hprev, dbias);
+    else if (split3) gru_bwd_kernel<2, bf16_t><<<grid, 512, 0, (hipStream_t)stream>>>(dhfinal, w_hh, hs, gates, B, L, dgi, dgh, hprev, dbias);
+    else gru_bwd_kernel<1, bf16_t><<<grid, 512, 0, (hipStream_t)stream>>>(dhfinal, w_hh, hs, gates, B, L, dgi, dgh, hprev, dbias);
     return tri_check_launch("tri_gru_bwd");
 }

@@ -167,15 +167,24 @@ class MVCNNEncoder(TriModule):
         if ds:                                                 # 1x1/2 conv + BN of the shortcut: independent of conv1 / conv2
             with torch.cuda.stream(self._side_ds.fork(x)):
                 yd, cod, gd = self._conv_bn(x, blk.downsample[0], blk.downsample[1], prec, train)
+        fine = ops.TIMELINE is not None and ops.TIMELINE.get("fine")
         y1, co1, g1 = self._conv_bn(x, blk.conv1, blk.bn1, prec, train)
+        if fine:
+            ops.stamp(f"image.fwd.c{y1.shape[-1]}.conv1+fin")
         a1 = ops.bn_act(y1, co1, relu=True)
+        if fine:
+            ops.stamp(f"image.fwd.c{y1.shape[-1]}.act1")
         y2, co2, g2 = self._conv_bn(a1, blk.conv2, blk.bn2, prec, train)
+        if fine:
+            ops.stamp(f"image.fwd.c{y1.shape[-1]}.conv2+fin")
         if ds:
             self._side_ds.join(yd, cod.scale, cod.shift)
             out = ops.bn_act(y2, co2, relu=True, res=yd, res_co=cod)
         else:
             yd = cod = gd = None
             out = ops.bn_act(y2, co2, relu=True, res=x)
+        if fine:
+            ops.stamp(f"image.fwd.c{y1.shape[-1]}.act2")
         if save:
             store.append((x, y1, co1, g1, a1, y2, co2, g2, yd, cod, gd, out))
         return out
@@ -250,6 +259,10 @@ class MVCNNEncoder(TriModule):
             dy2, gr[blk.bn2.weight], gr[blk.bn2.bias] = ops.bn_bwd(y2, dout, co2, blk.bn2.weight, count_host=g2.M, inplace=False,
                                                                    relu_out=out, g_masked=dout, out_scale=ugs, partial=dout_sums)
             g = dout
+            fine = ops.TIMELINE is not None and ops.TIMELINE.get("fine")
+            tag = f"image.bwd.c{y2.shape[-1]}.b{bi}"
+            if fine:
+                ops.stamp(tag + ".bn2")
             if blk.downsample is not None:                         # shortcut branch next to the conv2 / conv1 chain
                 with torch.cuda.stream(self._side_ds.fork(g, yd)):
                     dyd, gr[blk.downsample[1].weight], gr[blk.downsample[1].bias] = ops.bn_bwd(
@@ -261,8 +274,12 @@ class MVCNNEncoder(TriModule):
             # relu(bn1(y1)) backward: the ReLU mask is recomputed from y1 inside the BN passes (no relu_bwd pass over a1); where conv2's
             # data-gradient kernel can, it takes bn1's sums in its epilogue (no reduce pass over da1 / y1)
             da1, sums1 = ops.conv_dgrad(dy2, g2, self._packed[(id(blk.conv2), True)], bn_sums=(y1, co1, None))
+            if fine:
+                ops.stamp(tag + ".dgrad2")
             dy1, gr[blk.bn1.weight], gr[blk.bn1.bias] = ops.bn_bwd(y1, da1, co1, blk.bn1.weight, count_host=g1.M, relu=True, out_scale=ugs,
                                                                    partial=sums1)
+            if fine:
+                ops.stamp(tag + ".bn1")
             wgrad_async(x, dy1, g1, blk.conv1.weight)
             if blk.downsample is not None:
                 if batch is None:
@@ -279,6 +296,8 @@ class MVCNNEncoder(TriModule):
                                                bn_sums=(prev[5], None, prev[11]))
             else:
                 dx, dout_sums = ops.conv_dgrad(dy1, g1, self._packed[(id(blk.conv1), True)], out=dx, accumulate=True), None
+            if fine:
+                ops.stamp(tag + ".dgrad1")
             dout = dx
         side.join(*[v for v in gr.values() if v.dim() == 4])
         return dout

@@ -682,6 +682,9 @@ def _bn_bwd_finalize(partial, nblk, C, count_dev, count_host, gamma, co: "BNCoef
     return buf
 
 
+_BN_SMALL = os.environ.get("TRICOLO_BN_SMALL", "1") != "0"          # A/B switch: 0 = the three-pass BatchNorm backward for every tensor size
+
+
 def bn_bwd(y, g, co: BNCoeffs, gamma, count_dev=None, count_host=0, row_mask=None, inplace=True, relu=False, relu_out=None,
            g_masked=None, out_scale: float = 1.0, keep_inactive: bool = False, partial=None):
     # row_mask: rows with 0 are never read by either pass (their y / g may be unwritten) and come out as zeros in dy
@@ -694,6 +697,15 @@ def bn_bwd(y, g, co: BNCoeffs, gamma, count_dev=None, count_host=0, row_mask=Non
     C = y.shape[-1]
     M = y.numel() // C
     assert y.dtype == g.dtype
+    if partial is None and _BN_SMALL and M <= 512 and C % 8 == 0 and C >= 64 and _sync_world() == 1:
+        # tiny tensors (deepest voxel level): sums, coefficients and the apply pass in ONE launch (tri_bn_bwd_small; slower than the
+        # three passes from ~1 k rows on - its loads are 16 bytes per cache line)
+        dy = g if inplace else torch.empty_like(g)
+        buf = torch.empty((2, C), dtype=torch.float32, device=y.device)
+        check(lib().tri_bn_bwd_small(ptr(_act(y)), ptr(_act(g)), M, C, ptr(count_dev), int(count_host), ptr(gamma), ptr(co.mean), ptr(co.invstd),
+                                     ptr(rs), ptr(rb), ptr(relu_out), ptr(g_masked), ptr(row_mask), 1 if keep_inactive else 0, ptr(dy), ptr(buf[0]),
+                                     ptr(buf[1]), float(out_scale), _abf(y), stream()), "tri_bn_bwd_small")
+        return dy, buf[0], buf[1]
     if partial is not None:                          # the sums came out of the data gradient that produced g (conv_dgrad(bn_sums=...))
         assert row_mask is None and partial.shape[1:] == (2, C)
         nblk = partial.shape[0]
@@ -1012,13 +1024,22 @@ def act_bwd(dout, out, act, inplace=True):
 
 
 # ------------------------------------------------------------------------------------------------ GRU recurrence
+def gru_mode(precision: str) -> int:
+    """Operand mode of the GRU recurrence (tri_gru_fwd / tri_gru_bwd `split3`): 1 = 3-product bf16 split (bf16x3), 0 = single bf16
+    products (bf16), 2 = single f16 products (f16 mode: z within 4e-5 of float64 over the 96 steps, a third of the split's MFMAs;
+    TRICOLO_GRU_F16=0 keeps the split there - the A/B partner)."""
+    if precision == "f16" and os.environ.get("TRICOLO_GRU_F16", "1") != "0":
+        return 2
+    return split3(precision)
+
+
 def gru_fwd(xproj, w_hh, b_hh, B, L, precision):
     dev = xproj.device
     hs = torch.empty((2, L, B, 128), dtype=torch.float32, device=dev)
     gates = torch.empty((2, L, B, 128, 4), dtype=torch.float32, device=dev)        # (r, z, n, hn) per unit: one 16-byte access
     hfinal = torch.empty((B, 256), dtype=torch.float32, device=dev)
     check(lib().tri_gru_fwd(ptr(_f32(xproj)), ptr(_f32(w_hh)), ptr(_f32(b_hh)), B, L, ptr(hs), ptr(gates), ptr(hfinal),
-                            split3(precision), stream()), "tri_gru_fwd")
+                            gru_mode(precision), stream()), "tri_gru_fwd")
     return hfinal, hs, gates
 
 
@@ -1029,7 +1050,7 @@ def gru_bwd(dhfinal, w_hh, hs, gates, B, L, precision):
     hprev = torch.empty((2, L * B, 128), dtype=torch.float32, device=dev)
     dbias = torch.empty(((B + 15) // 16, 2, 4, 128), dtype=torch.float32, device=dev)
     check(lib().tri_gru_bwd(ptr(_f32(dhfinal.contiguous())), ptr(_f32(w_hh)), ptr(hs), ptr(gates), B, L, ptr(dgi), ptr(dgh), ptr(hprev),
-                            ptr(dbias), split3(precision), stream()), "tri_gru_bwd")
+                            ptr(dbias), gru_mode(precision), stream()), "tri_gru_bwd")
     return dgi, dgh, hprev, dbias
 
 
