@@ -1102,8 +1102,8 @@ def test_wgrad_jobs_share_one_partial_launch(group, store, prec):
     for i, case in enumerate(cases):
         x, w, wp, xcl, g = make_case(case, integer=True, seed=300 + i)
         fam, tiles, steps = g.wgrad_group(ops._abf(torch.empty(0, dtype=store)))
-        # (3: TRICOLO_WGRAD_WIDE=1 runs; 4 / 5: the kernel-row slab kernel takes the resolution-keeping 3x3 layers)
-        assert fam in (1, 2, 3, 4, 5) and tiles > 0 and steps == (g.B * int(np.prod(g.out_grid)) + 63) // 64
+        # (3: TRICOLO_WGRAD_WIDE=1 runs; 4 / 5: the kernel-row slab kernel takes the resolution-keeping 3x3 layers, 6 / 7 the stride-2 ones)
+        assert fam in (1, 2, 3, 4, 5, 6, 7) and tiles > 0 and steps == (g.B * int(np.prod(g.out_grid)) + 63) // 64
         dy = ints((g.B, *g.out_grid, g.cout), -2, 2, 700 + i)
         xr = x.clone().requires_grad_()
         wr = w.clone().requires_grad_()
@@ -1119,7 +1119,7 @@ def test_wgrad_jobs_share_one_partial_launch(group, store, prec):
             # the tile budget launched the 128-row family once on the way; both families still hold jobs (one queue per family)
             assert launches == 1 and sorted(batch.queues) == [1, 2]
         else:                                       # stride-2 / 1x1 layers on the im2col families, 3x3 / 1 layers on the kernel-row ones
-            assert sorted(batch.queues) == [1, 4, 5]
+            assert sorted(batch.queues) == [1, 4, 5, 6]
     batch.flush()
     assert batch.jobs == [] and batch.descs == []
     torch.cuda.synchronize()
@@ -1138,6 +1138,18 @@ KROW_CASES = [
     ("k16_128_192", 3, (1, 8, 16), 128, 192),
     ("k8_h6", 5, (1, 6, 8), 64, 64),
     ("k32_long", 40, (1, 32, 32), 64, 64),
+    # widths that do not divide 64 (the 224^2 configuration: 56 / 28 / 14 / 7): steps of floor(64 / W) rows, dead tail of the tile
+    ("k56_64", 2, (1, 56, 56), 64, 64),
+    ("k28_128", 3, (1, 28, 28), 128, 128),
+    ("k14_256", 5, (1, 14, 14), 256, 256),
+    ("k7_512", 11, (1, 7, 7), 512, 512),
+    ("k12_h5", 3, (1, 5, 12), 64, 128),
+    # stride-2 form (first conv of layer2 / 3 / 4): grid = INPUT grid, de-interleaved slab rows
+    ("s2_k16_64_128", 5, (1, 32, 32), 64, 128, 2),
+    ("s2_k8_128_256", 7, (1, 16, 16), 128, 256, 2),
+    ("s2_k4_256_512", 13, (1, 8, 8), 256, 512, 2),
+    ("s2_k32_64_64", 2, (1, 64, 64), 64, 64, 2),
+    ("s2_k8_h6", 3, (1, 12, 16), 64, 128, 2),
 ]
 
 
@@ -1147,17 +1159,18 @@ def test_conv_wgrad_krow_integer_exact(case, store, prec):
     """conv_wgrad_krow_kernel (one kernel row of taps per workgroup from one input slab): dW of every geometry it takes,
     launched alone and as jobs of a shared launch (two copies with different data), bit-exact on integer data against torch's conv
     backward.  TRICOLO_NO_KROW_WGRAD=1 is the A/B partner (conv_wgrad_dma_kernel)."""
-    name, N, grid, cin, cout = case
-    full = (name, N, grid, cin, cout, (1, 3, 3), 1, (0, 1, 1), "torch")
+    name, N, grid, cin, cout = case[:5]
+    stride = case[5] if len(case) > 5 else 1
+    full = (name, N, grid, cin, cout, (1, 3, 3), stride, (0, 1, 1), "torch")
     outs, refs = [], []
     batch = ops.WgradBatch(torch.device(DEV), group_jobs=True)
     for rep in range(2):
         x, w, wp, xcl, g = make_case(full, integer=True, seed=40 + rep)
         if os.environ.get("TRICOLO_NO_KROW_WGRAD") != "1":
-            assert g.wgrad_krow and g.wgrad_group(ops._abf(torch.empty(0, dtype=store)))[0] == (4 if cout % 128 == 0 else 5)
-        dy = ints((N, *grid, cout), -2, 2, 50 + rep)
+            assert g.wgrad_krow and g.wgrad_group(ops._abf(torch.empty(0, dtype=store)))[0] == (4 if cout % 128 == 0 else 5) + (2 if stride == 2 else 0)
+        dy = ints((N, *g.out_grid, cout), -2, 2, 50 + rep)
         wr = w.clone().requires_grad_()
-        F.conv3d(x, wr, padding=(0, 1, 1)).backward(cf3(dy))
+        F.conv3d(x, wr, stride=stride, padding=(0, 1, 1)).backward(cf3(dy))
         refs.append(wr.grad)
         xd, dyd = xcl.to(DEV).to(store), dy.to(DEV).to(store)
         if rep == 0:

@@ -957,8 +957,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_c64_kernel(const C64WgradAr
 }
 
 // ================================================================================================ kernel-row slab weight gradient
-// 3x3 / stride 1 / pad 1 layers with 16-bit storage, Cin % 64 == 0, Cout % 64 == 0, image width 4 / 8 / 16 / 32 / 64 (every resolution-keeping
-// 3x3 conv of the ResNet trunk at 6 x 128^2, mv_cnn.py:44).  conv_wgrad_dma_kernel treats the layer as an im2col GEMM: every 128-column tile
+// 3x3 / stride 1 / pad 1 layers with 16-bit storage, Cin % 64 == 0, Cout % 64 == 0, image width 4 .. 64 (every resolution-keeping
+// 3x3 conv of the ResNet trunk, mv_cnn.py:44; widths that do not divide 64 - 56 / 28 / 14 / 7 at 224^2 - run steps of floor(64 / W) rows
+// with the tail of the 64-position tile zero: dOut rows out of range, their B rows parked on a zero border pixel).  conv_wgrad_dma_kernel treats the layer as an im2col GEMM: every 128-column tile
 // of K = (tap, ci) re-gathers its input rows (each input pixel is fetched once per TAP) and re-reads its dOut tile (once per column tile) -
 // PMC had the family move 3.6x its algorithmic bytes, and its waves spend as long issuing LDS-DMA pieces as multiplying (NOTES_wgrad.md).
 // Here one workgroup owns ONE KERNEL ROW: dW[co0 .. co0 + CO_T)[ky][kx = 0..2][ci0 .. ci0 + 64).  A step is 64 output positions =
@@ -973,8 +974,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_c64_kernel(const C64WgradAr
 struct KrowArgs {
     const void* in; const void* dout; float* slab;
     unsigned in_bytes, dout_bytes;
-    int NH, H, W, Cin, Cout, Kpad;
-    int rps, P, npiece;          // image rows per step, slab row pitch in pixels (W + 2), 1 KiB DMA pieces per slab (8 pixels each)
+    int NH, H, W, Cin, Cout, Kpad;   // NH = images x H; H, W = OUTPUT grid of an image
+    int Hin, Win;                    // input grid (= H, W for stride 1; 2 H, 2 W for the stride-2 form)
+    int rps, P, npiece;          // image rows per step, slab row pitch in pixels, 1 KiB DMA pieces per slab (8 pixels each)
     int nsteps, steps_per_split, nsplits, ntiles, ci_chunks;
     FastDiv dH, dP, dW;
 };
@@ -984,20 +986,28 @@ struct KrowJobs {
     int n;
 };
 static_assert(sizeof(KrowJobs) <= 4096, "the job table travels in the kernel arguments (4 KB)");
-#define KROW_SLAB_PX 96                                            // rps * (W + 2) <= 96 (W = 4: 16 rows of 6 pixels)
+#define KROW_SLAB_PX 96                                            // stride 1: rps * (W + 2) <= 96 (W = 4: 16 rows of 6 pixels)
+#define KROW_SLAB_PX_S2 160                                        // stride 2: rps * (2 W + 2) <= 160 (W = 4: 16 rows of 10 pixels)
+// Stride-2 form (the first conv of layer2 / 3 / 4, mv_cnn.py:44): output position (y, x) reads input row 2 y + ky - 1, column 2 x + kx - 1.
+// A slab row holds the WHOLE input row (2 W + 2 columns incl. the borders) DE-INTERLEAVED - even columns first, then the odd ones (the
+// DMA's per-lane source address does it for free) - so that tap kx is again the same plane read shifted: column 2 x + kx sits at plane
+// (kx & 1), index x + (kx >> 1), and the eight positions of a half-wave read eight CONSECUTIVE pixels exactly as at stride 1.
 // quarter swizzle of slab pixel (row r, column xs): bit 0 separates pixels two apart, bit 1 the two position octets of a half-wave
 // (8 pixels apart in one row for W >= 16, the next row for W = 8, two rows on for W = 4)
+// (widths that do not divide 64 - 56 / 28 / 14 / 7 of the 224^2 configuration - keep the rule of the next power of two: a read whose
+//  second octet wraps into the next image row then has some 2-way conflicts; any swizzle is CORRECT as long as fill and read agree)
 __device__ __forceinline__ int krow_sw(int r, int xs, int W) {
-    const int hb = W >= 16 ? (xs >> 3) & 1 : (W == 8 ? r & 1 : (r >> 1) & 1);
+    const int hb = W > 8 ? (xs >> 3) & 1 : (W > 4 ? r & 1 : (r >> 1) & 1);
     return ((xs >> 1) & 1) | (hb << 1);
 }
-template <int CO_T, typename E>
+template <int CO_T, typename E, int S = 1>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_krow_kernel(const KrowJobs jobs) {
     typedef Mma<E> MM;
     typedef typename MM::v8 v8;
     constexpr int KB = 64;
     constexpr int XROW = CO_T * 2, X_BYTES = KB * XROW;
-    constexpr int SLAB_BYTES = KROW_SLAB_PX * 128, STAGE = X_BYTES + SLAB_BYTES;
+    constexpr int SLAB_BYTES = (S == 1 ? KROW_SLAB_PX : KROW_SLAB_PX_S2) * 128, STAGE = X_BYTES + SLAB_BYTES;
+    constexpr int NSP = SLAB_BYTES / 4096;                         // slab pieces per wave (3 / 5)
     constexpr int XRPI = 1024 / XROW, XNI = KB / (4 * XRPI);       // dOut rows per wave-instruction, instructions per wave and step
     constexpr int TM = CO_T / 32;                                  // 16-channel row tiles per wave
     static_assert((4 * XRPI) % 16 == 0 && XNI >= 1, "lane -> chunk map must not depend on the instruction");
@@ -1035,15 +1045,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_krow_kernel(const KrowJobs 
     const unsigned xstep = (unsigned)(4 * XRPI * Cout * 2);
     const unsigned step_bytes = (unsigned)(p.rps * W) * (unsigned)(Cout * 2);   // dOut bytes between two steps
     // slab: piece pi = wave + 4 i covers slab pixels 8 pi .. 8 pi + 7; this lane moves the 16-byte chunk (lane & 7) of pixel 8 pi + lane / 8
-    int s_r[3], s_col[3];                                          // slab row of the lane's pixel, byte offset inside an input row (< 0: zeros)
+    int s_r[NSP], s_col[NSP];                                      // slab row of the lane's pixel, byte offset inside an input row (< 0: zeros)
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < NSP; ++i) {
         const int pi = wave + 4 * i;
         const int q = 8 * pi + (lane >> 3), c = lane & 7;
-        const int r = (int)fdiv((uint32_t)q, p.dP), xs = q - r * P;
+        const int r = (int)fdiv((uint32_t)q, p.dP), xs = q - r * P;  // LDS pixel xs of slab row r
         const int cq = ((c >> 1) ^ krow_sw(r, xs, W)) & 3;
+        // slab COLUMN of that pixel: itself at stride 1; de-interleaved at stride 2 (even columns first); input x = column - 1
+        const int col = S == 1 ? xs : (xs >= P / 2 ? 2 * (xs - P / 2) + 1 : 2 * xs);
         s_r[i] = r;
-        s_col[i] = (xs >= 1 && xs <= W && r < p.rps) ? ((xs - 1) * Cin + ci0 + cq * 16 + (c & 1) * 8) * 2 : -1;
+        s_col[i] = (col >= 1 && col <= p.Win && r < p.rps) ? ((col - 1) * Cin + ci0 + cq * 16 + (c & 1) * 8) * 2 : -1;
     }
     // ---- B fragment addresses (per lane, the same for every step): position 32 h + 8 fg + 4 half + fqq of the step, column tile b
     int boff[2][2][6];
@@ -1052,11 +1064,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_krow_kernel(const KrowJobs 
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
             const int pos = 32 * h + 8 * fg + 4 * hf + fqq;
-            const int r = (int)fdiv((uint32_t)pos, p.dW), x = pos - r * W;
+            const bool live = pos < p.rps * W;                       // dead tail of the tile (W does not divide 64): its dOut rows are zeros;
+            const int r = live ? (int)fdiv((uint32_t)pos, p.dW) : 0; // park its B rows on pixel 0, a zero border (0 x garbage could be a NaN)
+            const int x = live ? pos - r * W : 0;
 #pragma unroll
             for (int b = 0; b < 6; ++b) {
-                const int tt = 6 * wj + b, kx = tt >> 2, cq = tt & 3;
-                const int xs = x + kx;
+                const int tt = 6 * wj + b, kx = live ? tt >> 2 : 0, cq = tt & 3;
+                const int xs = S == 1 ? x + kx : (kx & 1) * (P / 2) + x + (kx >> 1);     // LDS pixel of slab column x + kx / 2 x + kx
                 boff[h][hf][b] = (r * P + xs) * 128 + (((cq ^ krow_sw(r, xs, W)) & 3) << 5) + fp * 8;
             }
         }
@@ -1070,26 +1084,28 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_krow_kernel(const KrowJobs 
     const v4i rsrc = make_rsrc_words(p.in, p.in_bytes);
     const v4i xrsrc = make_rsrc_words(p.dout, p.dout_bytes);         // rows past the tensor arrive as zeros
     const unsigned lds0 = lds_addr(smem) + wave * 1024;
-    const int row_bytes = W * Cin * 2;
+    const int row_bytes = p.Win * Cin * 2;                           // one INPUT image row
 
+    const int npos = p.rps * W;                                      // live positions of a step (64 when W divides 64)
     auto issue_x = [&](int ks, int buf) {
         const unsigned xb = lds0 + buf * STAGE;
         const unsigned xbase = xoff + (unsigned)ks * step_bytes;
 #pragma unroll
-        for (int i = 0; i < XNI; ++i) dma16_async(xrsrc, xb + i * 4096, (int)(xbase + i * xstep));
+        for (int i = 0; i < XNI; ++i)                                // tile rows past the step's positions: zeros (out-of-range fetch)
+            dma16_async(xrsrc, xb + i * 4096, xrow0 + 4 * XRPI * i < npos ? (int)(xbase + i * xstep) : (int)0x80000000);
     };
     auto issue_slab = [&](int ks, int buf) {
         const unsigned sb = lds0 + buf * STAGE + X_BYTES;
-        int vo[3];
+        int vo[NSP];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < NSP; ++i) {
             const int R = ks * p.rps + s_r[i];                       // global image row of this slab row's OUTPUT row
-            const int n = (int)fdiv((uint32_t)R, p.dH), yy = R - n * H + ky - 1;
-            const bool ok = s_col[i] >= 0 && R < p.NH && (unsigned)yy < (unsigned)H;
-            vo[i] = ok ? (R + ky - 1) * row_bytes + s_col[i] : (int)0x80000000;
+            const int n = (int)fdiv((uint32_t)R, p.dH), yy = S * (R - n * H) + ky - 1;        // input row inside image n
+            const bool ok = s_col[i] >= 0 && R < p.NH && (unsigned)yy < (unsigned)p.Hin;
+            vo[i] = ok ? (n * p.Hin + yy) * row_bytes + s_col[i] : (int)0x80000000;
         }
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < NSP; ++i)
             if (wave + 4 * i < p.npiece) dma16_async(rsrc, sb + i * 4096, vo[i]);
     };
     auto compute = [&](int buf, int h) {
@@ -1377,6 +1393,11 @@ static bool stem_wgrad_geometry(const TriConvDesc* d, int act_fmt, StemWgradArgs
     return true;
 }
 
+static bool krow_wgrad_disabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("TRICOLO_NO_KROW_WGRAD"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
 static bool c64_wgrad_disabled() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("TRICOLO_NO_C64_WGRAD"); v = (e && e[0] == '1') ? 1 : 0; }
@@ -1389,6 +1410,9 @@ static bool c64_wgrad_geometry(const TriConvDesc* d, int act_fmt, C64WgradArgs* 
     if (d->Cin != 64 || d->Cout != 64 || d->OH != d->IH || d->OW != d->IW) return false;
     if ((long)d->B * d->IH * d->IW * 128 >= ((long)1 << 31)) return false;
     const int H = d->IH, W = d->IW;
+    // round 4: widths that divide 64 go to conv_wgrad_krow_kernel<64> (config 3, 32-wide layer1: 3.975 against 4.032 ms per step); this
+    // kernel keeps the widths whose 64-position steps would carry a dead tail there (56-wide layer1 of 12 x 224^2: 20.39 against 20.66 ms)
+    if (64 % W == 0 && W >= 4 && !krow_wgrad_disabled()) return false;
     int TR = 0;
     for (int tr = 1; tr <= H; ++tr)                                  // most positions per tile: whole rows of one image, multiple of 32, <= 256
         if (H % tr == 0 && (tr * W) % 32 == 0 && tr * W <= 32 * C64_MAXG) TR = tr;
@@ -1412,26 +1436,23 @@ static bool c64_wgrad_geometry(const TriConvDesc* d, int act_fmt, C64WgradArgs* 
     return true;
 }
 
-static bool krow_wgrad_disabled() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("TRICOLO_NO_KROW_WGRAD"); v = (e && e[0] == '1') ? 1 : 0; }
-    return v == 1;
-}
 // geometry of conv_wgrad_krow_kernel (everything but pointers and the split plan); false when the layer does not qualify.
 // *co_t = 128 / 64 (rows per workgroup tile), *tiles = workgroups per position split, *steps = 64-position steps
 static bool krow_geometry(const TriConvDesc* d, int act_fmt, KrowArgs* g, int* co_t, int* tiles, int* steps) {
     if (!act_fmt || krow_wgrad_disabled()) return false;
-    if (d->KD != 1 || d->ID != 1 || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad_d != 0 || d->pad_h != 1 || d->pad_w != 1) return false;
-    if (d->Cin % 64 || d->Cout % 64 || d->OH != d->IH || d->OW != d->IW) return false;
-    const int W = d->IW, H = d->IH;
-    if (W != 4 && W != 8 && W != 16 && W != 32 && W != 64) return false;
-    const size_t in_bytes = (size_t)d->B * H * W * d->Cin * 2, dout_bytes = (size_t)d->B * H * W * d->Cout * 2;
+    if (d->KD != 1 || d->ID != 1 || d->KH != 3 || d->KW != 3 || (d->stride != 1 && d->stride != 2) || d->pad_d != 0 || d->pad_h != 1 || d->pad_w != 1) return false;
+    if (d->Cin % 64 || d->Cout % 64 || d->OH * d->stride != d->IH || d->OW * d->stride != d->IW) return false;
+    const int W = d->OW, H = d->OH;
+    if (W < 4 || W > 64) return false;
+    const size_t in_bytes = (size_t)d->B * d->IH * d->IW * d->Cin * 2, dout_bytes = (size_t)d->B * H * W * d->Cout * 2;
     if (in_bytes >= ((size_t)1 << 31) || dout_bytes >= ((size_t)1 << 31)) return false;
     KrowArgs a{};
     a.in_bytes = (unsigned)in_bytes; a.dout_bytes = (unsigned)dout_bytes;
     a.NH = d->B * H; a.H = H; a.W = W; a.Cin = d->Cin; a.Cout = d->Cout; a.Kpad = 9 * d->Cin;
-    a.rps = 64 / W; a.P = W + 2;
-    if (a.rps * a.P > KROW_SLAB_PX) return false;
+    a.Hin = d->IH; a.Win = d->IW;
+    a.rps = 64 / W;
+    a.P = d->stride == 1 ? ((W + 3) & ~1) : 2 * W + 2;               // even pitch: the bank half of a pixel is the parity of its index
+    if (a.rps * a.P > (d->stride == 1 ? KROW_SLAB_PX : KROW_SLAB_PX_S2)) return false;
     a.npiece = (a.rps * a.P + 7) / 8;
     a.nsteps = (a.NH + a.rps - 1) / a.rps;
     a.ci_chunks = d->Cin / 64;
@@ -1458,9 +1479,9 @@ static inline int krow_blocks(const KrowArgs& a) {
     return a.nsplits >= 16 ? ((a.nsplits + 7) / 8) * 8 * a.ntiles : a.nsplits * a.ntiles;
 }
 // jobs of one tile height in ONE launch; block ranges are dealt longest split first so that the short jobs' workgroups fill in behind
-template <int CO_T, typename E>
+template <int CO_T, typename E, int S>
 static int launch_krow_jobs(const KrowArgs* a, int n, hipStream_t stream) {
-    constexpr int STAGE = 64 * CO_T * 2 + KROW_SLAB_PX * 128;
+    constexpr int STAGE = 64 * CO_T * 2 + (S == 1 ? KROW_SLAB_PX : KROW_SLAB_PX_S2) * 128;
     KrowJobs jobs{};
     int order[WGRAD_JOBS_MAX];
     for (int i = 0; i < n; ++i) order[i] = i;
@@ -1476,15 +1497,22 @@ static int launch_krow_jobs(const KrowArgs* a, int n, hipStream_t stream) {
     jobs.n = n;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)conv_wgrad_krow_kernel<CO_T, E>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
+        hipFuncSetAttribute((const void*)conv_wgrad_krow_kernel<CO_T, E, S>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
         attr_set = true;
     }
-    conv_wgrad_krow_kernel<CO_T, E><<<dim3(blocks), 256, 2 * STAGE, stream>>>(jobs);
+    conv_wgrad_krow_kernel<CO_T, E, S><<<dim3(blocks), 256, 2 * STAGE, stream>>>(jobs);
     return tri_check_launch("tri_conv_wgrad(krow)");
 }
+// (stride-2 jobs go out in a launch of their own: the slab size is a template parameter; all jobs of a call share the stride)
 static int launch_krow(int co_t, int act_fmt, const KrowArgs* a, int n, hipStream_t s) {
-    if (act_fmt == TRI_FMT_F16) return co_t == 128 ? launch_krow_jobs<128, f16_t>(a, n, s) : launch_krow_jobs<64, f16_t>(a, n, s);
-    return co_t == 128 ? launch_krow_jobs<128, bf16_t>(a, n, s) : launch_krow_jobs<64, bf16_t>(a, n, s);
+    const bool s2 = a[0].Hin != a[0].H;
+    for (int i = 1; i < n; ++i)
+        if ((a[i].Hin != a[i].H) != s2) { tri_set_error("wgrad(krow): jobs of one launch must share the stride"); return TRI_ERR_ARG; }
+#define TRI_KR(S_)                                                                                                                      \
+    (act_fmt == TRI_FMT_F16 ? (co_t == 128 ? launch_krow_jobs<128, f16_t, S_>(a, n, s) : launch_krow_jobs<64, f16_t, S_>(a, n, s))      \
+                            : (co_t == 128 ? launch_krow_jobs<128, bf16_t, S_>(a, n, s) : launch_krow_jobs<64, bf16_t, S_>(a, n, s)))
+    return s2 ? TRI_KR(2) : TRI_KR(1);
+#undef TRI_KR
 }
 
 extern "C" size_t tri_conv_wgrad_workspace(const TriConvDesc* d) {
@@ -1822,21 +1850,23 @@ static int wgrad_group_target(int family) {                     // resident work
     // 128x128 tiles (64 KB of stages + the plan ring: two workgroups per CU): all 512 slots; 64x128 tiles: 448 as for single launches
     // (measured on the bench shape, profiles/r3/NOTES_wgrad.md).  TRICOLO_WGRAD_GROUP_BLOCKS="a,b" overrides (a: 128-row, b: 64-row tiles)
     // 256x128 tiles: one 512-thread workgroup per CU.
-    static int v[5] = {-1, -1, -1, -1, -1};
+    static int v[7] = {-1, -1, -1, -1, -1, -1, -1};
     if (v[0] < 0) {
-        v[0] = 512; v[1] = 448; v[2] = 256; v[3] = KROW_TARGET_BLOCKS; v[4] = KROW_TARGET_BLOCKS;     // (4, 5: conv_wgrad_krow_kernel<128> / <64>)
+        // 4 / 6: conv_wgrad_krow_kernel<128> (stride 1 / 2), two workgroups per CU; 5 / 7: <64>, three per CU (40 KB of LDS, 126 registers:
+        // layer1's four layers in one launch 592 -> 725 TF; the step does not move)
+        v[0] = 512; v[1] = 448; v[2] = 256; v[3] = KROW_TARGET_BLOCKS; v[4] = 768; v[5] = KROW_TARGET_BLOCKS; v[6] = KROW_TARGET_BLOCKS;
         const char* e = getenv("TRICOLO_WGRAD_GROUP_BLOCKS");
         if (e) {
-            int a[5] = {0, 0, 0, 0, 0};
-            const int k = sscanf(e, "%d,%d,%d,%d,%d", &a[0], &a[1], &a[2], &a[3], &a[4]);
-            for (int i = 0; i < k && i < 5; ++i) if (a[i] > 0) v[i] = a[i];
+            int a[7] = {0, 0, 0, 0, 0, 0, 0};
+            const int k = sscanf(e, "%d,%d,%d,%d,%d,%d,%d", &a[0], &a[1], &a[2], &a[3], &a[4], &a[5], &a[6]);
+            for (int i = 0; i < k && i < 7; ++i) if (a[i] > 0) v[i] = a[i];
         }
     }
-    return v[family >= 1 && family <= 5 ? family - 1 : 1];
+    return v[family >= 1 && family <= 7 ? family - 1 : 1];
 }
 // ---- several layers in one launch
 // family of a layer for grouping: 0 = not groupable (tri_conv_wgrad_partial), 1 = conv_wgrad_dma_kernel<128,128>, 2 = <64,128>, 3 = <256,128>
-// (TRICOLO_WGRAD_WIDE), 4 = conv_wgrad_krow_kernel<128>, 5 = conv_wgrad_krow_kernel<64>;
+// (TRICOLO_WGRAD_WIDE), 4 = conv_wgrad_krow_kernel<128>, 5 = conv_wgrad_krow_kernel<64>, 6 / 7 = their stride-2 forms;
 // tiles = output tiles (workgroups per split), steps = 64-position steps of the contraction
 extern "C" int tri_conv_wgrad_group_info(const TriConvDesc* d, int act_fmt, int* family, int* tiles, int* steps) {
     *family = 0; *tiles = 0; *steps = 0;
@@ -1845,7 +1875,7 @@ extern "C" int tri_conv_wgrad_group_info(const TriConvDesc* d, int act_fmt, int*
         C64WgradArgs cg; StemWgradArgs sg; int grid;
         if (c64_wgrad_geometry(d, act_fmt, &cg, &grid) || stem_wgrad_geometry(d, act_fmt, &sg, &grid)) return 0;
         KrowArgs kg; int co_t;
-        if (krow_geometry(d, act_fmt, &kg, &co_t, tiles, steps)) { *family = co_t == 128 ? 4 : 5; return 0; }
+        if (krow_geometry(d, act_fmt, &kg, &co_t, tiles, steps)) { *family = (co_t == 128 ? 4 : 5) + (d->stride == 2 ? 2 : 0); return 0; }
     }
     int BI, BJ, t, splits, sps, Kpad, dma;
     wgrad_plan(d, act_fmt, 0, &BI, &BJ, &t, &splits, &sps, &Kpad, &dma);
@@ -1871,7 +1901,7 @@ extern "C" int tri_conv_wgrad_partial_group(const TriWgradJob* jobs, int n, int 
     {
         int fam, t0, st0;
         tri_conv_wgrad_group_info(jobs[0].d, act_fmt, &fam, &t0, &st0);
-        if (fam == 4 || fam == 5) {
+        if (fam >= 4 && fam <= 7) {
             // kernel-row jobs: every job is cut into splits of about the launch's mean workgroup length (total tile-steps / resident
             // slots), never more splits than it would get alone; the launch may hold more workgroups than slots - they are dealt longest
             // first and the short ones fill in behind (one resident round would leave the few-step layers' slots idle for most of it)

@@ -438,7 +438,7 @@ _WGRAD_JOBS = os.environ.get("TRICOLO_WGRAD_JOBS", "1") != "0"           # A/B s
 # output tiles (workgroups per split) one grouped partial launch takes, per kernel family (1: 128-row, 2: 64-row, 3: 256-row tiles); the
 # library's split planner uses the same figures (TRICOLO_WGRAD_GROUP_BLOCKS)
 # (4, 5: conv_wgrad_krow_kernel<128> / <64>; a krow launch may hold more workgroups than resident slots, the library deals them longest first)
-_WGRAD_JOB_TILES = dict(zip((1, 2, 3, 4, 5), [int(v) for v in os.environ.get("TRICOLO_WGRAD_JOB_TILES", "512,448,256,512,512").split(",")] + [512] * 5))
+_WGRAD_JOB_TILES = dict(zip(range(1, 8), [int(v) for v in os.environ.get("TRICOLO_WGRAD_JOB_TILES", "512,448,256,512,512,512,512").split(",")] + [512] * 7))   # (6, 7: stride-2 krow)
 
 
 class WgradBatch:
