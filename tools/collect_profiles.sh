@@ -1,6 +1,6 @@
 #!/bin/bash
 # Copy what tools/profile_round.sh <tag> merged back into gpurun_out/ into the tracked profiles/<tag>/ (the judge reads profiles/).
-tag=${1:-r3}
+tag=${1:-r4}
 O=gpurun_out
 P=profiles/$tag
 mkdir -p $P
@@ -14,6 +14,7 @@ for p in f16 bf16x3; do
 done
 cp $O/${tag}_pmc_traffic_f16.json $P/pmc_traffic_f16.json
 cp $O/${tag}_voxel_fwd.txt $P/voxel_fwd.txt
+cp $O/${tag}_kernel_times.txt $P/kernel_times.txt
 for p in f16 bf16; do cp $O/${tag}_conv_layers_$p.txt $P/conv_layers_$p.txt; done
 cp $O/${tag}_gpu_tests.txt $P/gpu_tests.txt
 cp $O/parity_report.json $P/parity_report.json

@@ -42,6 +42,9 @@ def symbol(d):
     m = re.match(r"conv_wgrad_dma_kernel<(\d+), (\d+), (\w+), \d+, \d+>", d)     # (wave layout: 2 x 2 unless TRICOLO_WGRAD_WIDE=1)
     if m:
         return f"conv_wgrad_dma_kernel<{m.group(1)}, {m.group(2)}, {m.group(3)}>"
+    m = re.match(r"conv_wgrad_krow_kernel<(\d+), (\w+)(?:, \d+)?>", d)                # (stride-1 / stride-2 forms under one name)
+    if m:
+        return f"conv_wgrad_krow_kernel<{m.group(1)}, {m.group(2)}>"
     m = re.match(r"conv_stem_wgrad_kernel<(\d+), (\w+), \w+>", d)                  # (with / without the folded BatchNorm apply pass)
     if m:
         return f"conv_stem_wgrad_kernel<{m.group(1)}, {m.group(2)}>"

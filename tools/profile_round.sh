@@ -3,7 +3,7 @@
 # Writes gpurun_out/<tag>_*: the -m gpu test log, bench.py JSON lines (default run + configs 2/3/5), rocprofv3 kernel stats
 # for the f16 and bf16x3 modes, the two PMC passes (FETCH_SIZE / WRITE_SIZE in separate runs, MI355X_MICROARCH.md) and the
 # in-graph step timelines (tools/step_timeline.py).
-tag=${1:-r3}
+tag=${1:-r4}
 R=$PWD
 O=$R/gpurun_out
 mkdir -p $O
@@ -19,6 +19,7 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${tag}_pmc_fetch -- python3
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${tag}_pmc_write -- python3 $R/bench.py --steps 3 --warmup 2 --precision f16 --modes "" --no-cpu-baseline > $O/${tag}_pmc_write.json 2> $O/${tag}_pmc_write.err
 cd $R
 python tools/pmc_traffic.py $O/${tag}_pmc_fetch $O/${tag}_pmc_write f16 > $O/${tag}_pmc_traffic_f16.json
+python tools/kernel_times.py > $O/${tag}_kernel_times.txt 2>/dev/null
 python tools/voxel_fwd_bench.py --modes f16,bf16 --out $O/${tag}_voxel_fwd.txt --json $O/${tag}_voxel_fwd.json > /dev/null 2>&1
 for p in f16 bf16; do python tools/conv_layers_bench.py --precision $p 2>&1 | grep -v amdgpu.ids > $O/${tag}_conv_layers_$p.txt; done
 # keep the merged-back payload small: kernel traces are large, the stats CSVs are what gets committed
