@@ -242,6 +242,16 @@ int tri_bn_bwd_apply(const void* y, const void* g, const float* c1, const float*
  * nn.MaxPool2d(3,2,1) of the ResNet stem; AdaptiveAvgPool2d + torch.max over views (mv_cnn.py:29-31). */
 int tri_bn_relu_pool3d_fwd(const void* y, const float* scale, const float* shift, const uint8_t* mask, int B, int D, int C,
                            void* pooled, uint8_t* mask_out, int act_fmt, void* stream);
+/* Row-list forms of the voxel tower's backward passes (round 4): the routing pass over the ACTIVE pooled sites (out_pos / out_count = the
+ * next level's tri_mask_compact list) and the whole BatchNorm backward (reduce + finalize + apply, three launches) over the level's own
+ * list, rows outside the list neither read nor written (tri_bn_bwd_apply's keep_inactive contract).  Same values as the dense forms. */
+int tri_pool3d_bwd_route_rows(const void* y, const float* scale, const float* shift, const uint8_t* mask, const void* pooled,
+                              const void* dpooled, int B, int D, int C, void* g, const int* out_pos, const int* out_count, int act_fmt,
+                              void* stream);
+size_t tri_bn_bwd_rows_scratch(int C);
+int tri_bn_bwd_rows(const void* y, const void* g, int C, const int* row_pos, const int* row_count, long max_rows, const float* gamma,
+                    const float* mean, const float* invstd, void* dy, float* dgamma, float* dbeta, float out_scale, void* scratch,
+                    int act_fmt, void* stream);
 int tri_pool3d_bwd_route(const void* y, const float* scale, const float* shift, const uint8_t* mask, const void* pooled,
                          const void* dpooled, int B, int D, int C, void* g, int act_fmt, void* stream);
 /* the same with the level's BatchNorm-backward sums folded in (sparse_cnn.py:12-35 backward: SparseMaxPool3d -> ReLU -> BatchNorm1d):

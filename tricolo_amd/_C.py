@@ -91,6 +91,9 @@ SIGNATURES = {
     "tri_bn_bwd_apply": (I, [P, P, P, P, P, P, P, L, I, P, P, P, P, I, I, P]),
     "tri_bn_relu_pool3d_fwd": (I, [P, P, P, P, I, I, I, P, P, I, P]),
     "tri_pool3d_bwd_route": (I, [P, P, P, P, P, P, I, I, I, P, I, P]),
+    "tri_pool3d_bwd_route_rows": (I, [P, P, P, P, P, P, I, I, I, P, P, P, I, P]),
+    "tri_bn_bwd_rows_scratch": (C.c_size_t, [I]),
+    "tri_bn_bwd_rows": (I, [P, P, I, P, P, L, P, P, P, P, P, P, F, P, I, P]),
     "tri_pool3d_bwd_route_reduce_num_blocks": (I, [I, I, I]),
     "tri_pool3d_bwd_route_reduce": (I, [P, P, P, P, P, P, I, I, I, P, P, I, P]),
     "tri_maxpool2d_fwd": (I, [P, I, I, I, I, P, P, P, P, I, P]),

@@ -553,6 +553,124 @@ extern "C" int tri_pool3d_bwd_route(const void* y, const float* scale, const flo
     return tri_check_launch("tri_pool3d_bwd_route");
 }
 
+// Row-list forms (round 4).  At 13-16 % occupancy the dense passes of the two finest voxel levels spend most of their threads on
+// sites whose mask byte says "skip": these walk the compact lists tri_mask_compact already produced for the conv kernels instead.
+// tri_pool3d_bwd_route_rows: the routing pass over the ACTIVE pooled sites (the next level's row list) - same values, same rows written.
+template <typename T>
+__global__ void pool3d_bwd_route_rows_kernel(const T* __restrict__ y, const float4* __restrict__ scale, const float4* __restrict__ shift,
+                                             const uint8_t* __restrict__ mask, const T* __restrict__ pooled, const T* __restrict__ dpooled,
+                                             int D, int C4, T* __restrict__ g, const int* __restrict__ out_pos, const int* __restrict__ out_count) {
+    const int Do = D >> 1;
+    const long total = (long)(*out_count) * C4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        const long pos = out_pos[i / C4];
+        int ox = (int)(pos % Do); long r = pos / Do;
+        int oy = (int)(r % Do); r /= Do;
+        int oz = (int)(r % Do); int b = (int)(r / Do);
+        float4 s = scale[c], t = shift[c];
+        float4 pm = Act<T>::ld4(pooled + (pos * C4 + c) * 4), dp = Act<T>::ld4(dpooled + (pos * C4 + c) * 4);
+        bool dx = false, dy = false, dz = false, dw = false;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            long ip = (((long)b * D + (oz * 2 + (k >> 2))) * D + (oy * 2 + ((k >> 1) & 1))) * D + (ox * 2 + (k & 1));
+            if (!mask[ip]) continue;
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 v = Act<T>::ld4(y + (ip * C4 + c) * 4);
+            float zx = fmaxf(__fmaf_rn(v.x, s.x, t.x), 0.f), zy = fmaxf(__fmaf_rn(v.y, s.y, t.y), 0.f);
+            float zz = fmaxf(__fmaf_rn(v.z, s.z, t.z), 0.f), zw = fmaxf(__fmaf_rn(v.w, s.w, t.w), 0.f);
+            zx = Act<T>::rnd(zx); zy = Act<T>::rnd(zy); zz = Act<T>::rnd(zz); zw = Act<T>::rnd(zw);
+            if (!dx && zx == pm.x && zx > 0.f) { o.x = dp.x; dx = true; }
+            if (!dy && zy == pm.y && zy > 0.f) { o.y = dp.y; dy = true; }
+            if (!dz && zz == pm.z && zz > 0.f) { o.z = dp.z; dz = true; }
+            if (!dw && zw == pm.w && zw > 0.f) { o.w = dp.w; dw = true; }
+            Act<T>::st4(g + (ip * C4 + c) * 4, o);
+        }
+    }
+}
+extern "C" int tri_pool3d_bwd_route_rows(const void* y, const float* scale, const float* shift, const uint8_t* mask, const void* pooled,
+                                         const void* dpooled, int B, int D, int C, void* g, const int* out_pos, const int* out_count,
+                                         int act_fmt, void* stream) {
+    if (C % 4 || D % 2 || !out_pos || !out_count) { tri_set_error("tri_pool3d_bwd_route_rows: C%4, D%2, row list required"); return TRI_ERR_ARG; }
+    long worst = (long)B * (D / 2) * (D / 2) * (D / 2) * (C / 4);
+    int grid = ew_grid(worst / 4 + 1);                              // (sized for a quarter-full list; the loop is grid-strided)
+    TRI_ACT_DISPATCH(act_fmt, pool3d_bwd_route_rows_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>(
+        (const T*)y, (const float4*)scale, (const float4*)shift, mask, (const T*)pooled, (const T*)dpooled, D, C / 4, (T*)g, out_pos, out_count));
+    return tri_check_launch("tri_pool3d_bwd_route_rows");
+}
+// BatchNorm backward over a compact row list (g is final: no ReLU mask; rows outside the list are neither read nor written - the
+// keep_inactive contract of tri_bn_bwd_apply).  partial: [BNR_BLOCKS][2][C] scratch.
+#define BNR_BLOCKS 512
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_rows_kernel(const T* __restrict__ y, const T* __restrict__ g, int C, const int* __restrict__ row_pos,
+                                                                 const int* __restrict__ row_count, float* __restrict__ partial) {
+    extern __shared__ float sh[];                                    // [rpp][tpr][8]
+    const int C4 = C >> 2;
+    const int tpr = C4 < 256 ? C4 : 256, rpp = 256 / tpr, cpt = (C4 + tpr - 1) / tpr;
+    const int tc = threadIdx.x % tpr, tr = threadIdx.x / tpr;
+    const int n = *row_count;
+    for (int cc = 0; cc < cpt; ++cc) {
+        const int c4 = tc + cc * tpr;
+        float4 sg = make_float4(0, 0, 0, 0), sgy = make_float4(0, 0, 0, 0);
+        if (c4 < C4 && tr < rpp)
+#pragma unroll 4
+            for (int i = blockIdx.x * rpp + tr; i < n; i += gridDim.x * rpp) {
+                const long r = row_pos[i];
+                const float4 gv = Act<T>::ld4(g + r * C + c4 * 4), yv = Act<T>::ld4(y + r * C + c4 * 4);
+                sg.x += gv.x; sg.y += gv.y; sg.z += gv.z; sg.w += gv.w;
+                sgy.x += gv.x * yv.x; sgy.y += gv.y * yv.y; sgy.z += gv.z * yv.z; sgy.w += gv.w * yv.w;
+            }
+        __syncthreads();
+        if (c4 < C4 && tr < rpp) {
+            float* p = sh + ((size_t)tr * tpr + tc) * 8;
+            p[0] = sg.x; p[1] = sg.y; p[2] = sg.z; p[3] = sg.w; p[4] = sgy.x; p[5] = sgy.y; p[6] = sgy.z; p[7] = sgy.w;
+        }
+        __syncthreads();
+        if (tr == 0 && c4 < C4) {
+            float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int rr = 0; rr < rpp; ++rr) {
+                const float* p = sh + ((size_t)rr * tpr + tc) * 8;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a[k] += p[k];
+            }
+            float* o = partial + (size_t)blockIdx.x * 2 * C;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { o[c4 * 4 + k] = a[k]; o[C + c4 * 4 + k] = a[4 + k]; }
+        }
+    }
+}
+template <typename T>
+__global__ void bn_bwd_apply_rows_kernel(const T* __restrict__ y, const T* g, const float4* __restrict__ c1, const float4* __restrict__ c2,
+                                         const float4* __restrict__ c3, T* dy, int C4, const int* __restrict__ row_pos,
+                                         const int* __restrict__ row_count) {
+    const long total = (long)(*row_count) * C4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        const long o = ((long)row_pos[i / C4] * C4 + c) * 4;
+        const float4 yv = Act<T>::ld4(y + o), gv = Act<T>::ld4(g + o), a = c1[c], b = c2[c], d = c3[c];
+        Act<T>::st4(dy + o, make_float4(a.x * gv.x + b.x + d.x * yv.x, a.y * gv.y + b.y + d.y * yv.y, a.z * gv.z + b.z + d.z * yv.z,
+                                        a.w * gv.w + b.w + d.w * yv.w));
+    }
+}
+extern "C" size_t tri_bn_bwd_rows_scratch(int C) { return (size_t)BNR_BLOCKS * 2 * C * sizeof(float) + 3 * (size_t)C * sizeof(float); }
+// (dy, dgamma, dbeta) of a BatchNorm whose g, y and dy are only defined on the rows of the list; max_rows = capacity of the list
+extern "C" int tri_bn_bwd_rows(const void* y, const void* g, int C, const int* row_pos, const int* row_count, long max_rows, const float* gamma,
+                               const float* mean, const float* invstd, void* dy, float* dgamma, float* dbeta, float out_scale, void* scratch,
+                               int act_fmt, void* stream) {
+    if (C % 4 || !row_pos || !row_count || !scratch) { tri_set_error("tri_bn_bwd_rows: C % 4, row list and scratch required"); return TRI_ERR_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    float* partial = (float*)scratch;
+    float* co = partial + (size_t)BNR_BLOCKS * 2 * C;
+    const int C4 = C / 4, tpr = C4 < 256 ? C4 : 256, rpp = 256 / tpr;
+    const size_t smem = (size_t)rpp * tpr * 8 * sizeof(float);
+    TRI_ACT_DISPATCH(act_fmt, bn_bwd_reduce_rows_kernel<T><<<BNR_BLOCKS, 256, smem, st>>>((const T*)y, (const T*)g, C, row_pos, row_count, partial));
+    bn_bwd_finalize_kernel<<<C, 256, 0, st>>>(partial, BNR_BLOCKS, C, row_count, 0, gamma, mean, invstd, dgamma, dbeta, co, co + C, co + 2 * C, out_scale);
+    const int grid = ew_grid(max_rows * C4 / 4 + 1);
+    TRI_ACT_DISPATCH(act_fmt, bn_bwd_apply_rows_kernel<T><<<grid, 256, 0, st>>>((const T*)y, (const T*)g, (const float4*)co, (const float4*)(co + C),
+                                                                                 (const float4*)(co + 2 * C), (T*)dy, C4, row_pos, row_count));
+    return tri_check_launch("tri_bn_bwd_rows");
+}
+
 // The same routing with the BatchNorm-backward sums of the level folded in: every routed value and the y it belongs to are in
 // registers here, so the per-channel sums of g and g * y over the active sites (what tri_bn_bwd_reduce would re-read both tensors
 // for) leave as one [2][C] record per workgroup for tri_bn_bwd_finalize - one launch less per level on the voxel tower's backward.

@@ -1006,6 +1006,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_krow_kernel(const KrowJobs 
     typedef typename MM::v8 v8;
     constexpr int KB = 64;
     constexpr int XROW = CO_T * 2, X_BYTES = KB * XROW;
+    // S = 1 / 2: the stride of every job of the launch; S = 0: per job (p.Hin != p.H), the big slab for all - layer2 / 3 / 4's
+    // stride-2 first convs then ride in the launch of the stride-1 layers (a launch of their own cut them into 4-57 short splits:
+    // 53 MB of slabs for 21.7 GFLOP)
     constexpr int SLAB_BYTES = (S == 1 ? KROW_SLAB_PX : KROW_SLAB_PX_S2) * 128, STAGE = X_BYTES + SLAB_BYTES;
     constexpr int NSP = SLAB_BYTES / 4096;                         // slab pieces per wave (3 / 5)
     constexpr int XRPI = 1024 / XROW, XNI = KB / (4 * XRPI);       // dOut rows per wave-instruction, instructions per wave and step
@@ -1024,17 +1027,25 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_krow_kernel(const KrowJobs 
         split = grp * 8 + (rem & 7);
         tile = rem >> 3;
     } else {
-        split = bid / ntiles;
-        tile = bid - split * ntiles;
+        // few splits (layer3 / layer4: one to three): every XCD takes a CONTIGUOUS run of the (split, tile) list - the job's block range
+        // starts at a multiple of 8, so bid % 8 is the XCD - i.e. the tiles of one dOut channel tile and neighbouring input-channel
+        // chunks.  Dealt round-robin (the first version) every XCD streamed the whole dOut and input tensors of the layer through its
+        // 4 MB L2: PMC had the launch move 975 MB of fabric traffic per step for ~130 MB of operands (profiles/r4/README.md).
+        const int nb = p.nsplits * ntiles;
+        if (bid >= nb) return;
+        const int lid = xcd_remap(bid, nb);
+        split = lid / ntiles;
+        tile = lid - split * ntiles;
     }
     if (split >= p.nsplits) return;
     // tile = ((co tile * ci_chunks) + ci chunk) * 3 + ky: the three kernel rows of one (co, ci) block are neighbours (same dOut tile,
-    // input rows one apart) and, with the mapping above, run on one XCD
+    // input rows one apart) and, with the mappings above, run on one XCD
     const int ky = tile % 3, rest = tile / 3;
     const int cic = rest % p.ci_chunks, cot = rest / p.ci_chunks;
     const int co0 = cot * CO_T, ci0 = cic * 64;
     const int ks_begin = split * p.steps_per_split, ks_end = min(p.nsteps, ks_begin + p.steps_per_split);
     const int W = p.W, P = p.P, H = p.H, Cin = p.Cin, Cout = p.Cout;
+    const int st = S ? S : (p.Hin != p.H ? 2 : 1);                 // stride of this job
     const int wi = wave >> 1, wj = wave & 1;
     const int fr = lane & 15, fg = lane >> 4, fqq = fr >> 2, fp = fr & 3;
 
@@ -1053,7 +1064,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_krow_kernel(const KrowJobs 
         const int r = (int)fdiv((uint32_t)q, p.dP), xs = q - r * P;  // LDS pixel xs of slab row r
         const int cq = ((c >> 1) ^ krow_sw(r, xs, W)) & 3;
         // slab COLUMN of that pixel: itself at stride 1; de-interleaved at stride 2 (even columns first); input x = column - 1
-        const int col = S == 1 ? xs : (xs >= P / 2 ? 2 * (xs - P / 2) + 1 : 2 * xs);
+        const int col = st == 1 ? xs : (xs >= P / 2 ? 2 * (xs - P / 2) + 1 : 2 * xs);
         s_r[i] = r;
         s_col[i] = (col >= 1 && col <= p.Win && r < p.rps) ? ((col - 1) * Cin + ci0 + cq * 16 + (c & 1) * 8) * 2 : -1;
     }
@@ -1070,7 +1081,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_krow_kernel(const KrowJobs 
 #pragma unroll
             for (int b = 0; b < 6; ++b) {
                 const int tt = 6 * wj + b, kx = live ? tt >> 2 : 0, cq = tt & 3;
-                const int xs = S == 1 ? x + kx : (kx & 1) * (P / 2) + x + (kx >> 1);     // LDS pixel of slab column x + kx / 2 x + kx
+                const int xs = st == 1 ? x + kx : (kx & 1) * (P / 2) + x + (kx >> 1);    // LDS pixel of slab column x + kx / 2 x + kx
                 boff[h][hf][b] = (r * P + xs) * 128 + (((cq ^ krow_sw(r, xs, W)) & 3) << 5) + fp * 8;
             }
         }
@@ -1100,7 +1111,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_krow_kernel(const KrowJobs 
 #pragma unroll
         for (int i = 0; i < NSP; ++i) {
             const int R = ks * p.rps + s_r[i];                       // global image row of this slab row's OUTPUT row
-            const int n = (int)fdiv((uint32_t)R, p.dH), yy = S * (R - n * H) + ky - 1;        // input row inside image n
+            const int n = (int)fdiv((uint32_t)R, p.dH), yy = st * (R - n * H) + ky - 1;       // input row inside image n
             const bool ok = s_col[i] >= 0 && R < p.NH && (unsigned)yy < (unsigned)p.Hin;
             vo[i] = ok ? (n * p.Hin + yy) * row_bytes + s_col[i] : (int)0x80000000;
         }
@@ -1475,8 +1486,8 @@ static void krow_plan_alone(int tiles, int steps, int* sps, int* splits) {
     *sps = (steps + s - 1) / s;
     *splits = (steps + *sps - 1) / *sps;
 }
-static inline int krow_blocks(const KrowArgs& a) {
-    return a.nsplits >= 16 ? ((a.nsplits + 7) / 8) * 8 * a.ntiles : a.nsplits * a.ntiles;
+static inline int krow_blocks(const KrowArgs& a) {               // (a multiple of 8: the next job's range starts on XCD 0 again)
+    return a.nsplits >= 16 ? ((a.nsplits + 7) / 8) * 8 * a.ntiles : (a.nsplits * a.ntiles + 7) / 8 * 8;
 }
 // jobs of one tile height in ONE launch; block ranges are dealt longest split first so that the short jobs' workgroups fill in behind
 template <int CO_T, typename E, int S>
@@ -1503,11 +1514,17 @@ static int launch_krow_jobs(const KrowArgs* a, int n, hipStream_t stream) {
     conv_wgrad_krow_kernel<CO_T, E, S><<<dim3(blocks), 256, 2 * STAGE, stream>>>(jobs);
     return tri_check_launch("tri_conv_wgrad(krow)");
 }
-// (stride-2 jobs go out in a launch of their own: the slab size is a template parameter; all jobs of a call share the stride)
+// (the slab size is a template parameter: 1 = all jobs stride 1, 2 = all stride 2, 0 = mixed - per job, big slab)
 static int launch_krow(int co_t, int act_fmt, const KrowArgs* a, int n, hipStream_t s) {
-    const bool s2 = a[0].Hin != a[0].H;
-    for (int i = 1; i < n; ++i)
-        if ((a[i].Hin != a[i].H) != s2) { tri_set_error("wgrad(krow): jobs of one launch must share the stride"); return TRI_ERR_ARG; }
+    int n2 = 0;
+    for (int i = 0; i < n; ++i) n2 += a[i].Hin != a[i].H;
+    if (n2 && n2 != n) {
+#define TRI_KR0 (act_fmt == TRI_FMT_F16 ? (co_t == 128 ? launch_krow_jobs<128, f16_t, 0>(a, n, s) : launch_krow_jobs<64, f16_t, 0>(a, n, s))   \
+                                        : (co_t == 128 ? launch_krow_jobs<128, bf16_t, 0>(a, n, s) : launch_krow_jobs<64, bf16_t, 0>(a, n, s)))
+        return TRI_KR0;
+#undef TRI_KR0
+    }
+    const bool s2 = n2 > 0;
 #define TRI_KR(S_)                                                                                                                      \
     (act_fmt == TRI_FMT_F16 ? (co_t == 128 ? launch_krow_jobs<128, f16_t, S_>(a, n, s) : launch_krow_jobs<64, f16_t, S_>(a, n, s))      \
                             : (co_t == 128 ? launch_krow_jobs<128, bf16_t, S_>(a, n, s) : launch_krow_jobs<64, bf16_t, S_>(a, n, s)))
@@ -1866,7 +1883,7 @@ static int wgrad_group_target(int family) {                     // resident work
 }
 // ---- several layers in one launch
 // family of a layer for grouping: 0 = not groupable (tri_conv_wgrad_partial), 1 = conv_wgrad_dma_kernel<128,128>, 2 = <64,128>, 3 = <256,128>
-// (TRICOLO_WGRAD_WIDE), 4 = conv_wgrad_krow_kernel<128>, 5 = conv_wgrad_krow_kernel<64>, 6 / 7 = their stride-2 forms;
+// (TRICOLO_WGRAD_WIDE), 4 = conv_wgrad_krow_kernel<128> (stride 1 and 2 share launches), 5 = conv_wgrad_krow_kernel<64>, 7 = its stride-2 form;
 // tiles = output tiles (workgroups per split), steps = 64-position steps of the contraction
 extern "C" int tri_conv_wgrad_group_info(const TriConvDesc* d, int act_fmt, int* family, int* tiles, int* steps) {
     *family = 0; *tiles = 0; *steps = 0;
@@ -1875,7 +1892,7 @@ extern "C" int tri_conv_wgrad_group_info(const TriConvDesc* d, int act_fmt, int*
         C64WgradArgs cg; StemWgradArgs sg; int grid;
         if (c64_wgrad_geometry(d, act_fmt, &cg, &grid) || stem_wgrad_geometry(d, act_fmt, &sg, &grid)) return 0;
         KrowArgs kg; int co_t;
-        if (krow_geometry(d, act_fmt, &kg, &co_t, tiles, steps)) { *family = (co_t == 128 ? 4 : 5) + (d->stride == 2 ? 2 : 0); return 0; }
+        if (krow_geometry(d, act_fmt, &kg, &co_t, tiles, steps)) { *family = co_t == 128 ? 4 : (d->stride == 2 ? 7 : 5); return 0; }
     }
     int BI, BJ, t, splits, sps, Kpad, dma;
     wgrad_plan(d, act_fmt, 0, &BI, &BJ, &t, &splits, &sps, &Kpad, &dma);

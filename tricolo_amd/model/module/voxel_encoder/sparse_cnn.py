@@ -162,8 +162,9 @@ class SparseCNNEncoder(TriModule):
             # kernel exists for 16-bit storage only (g.wgrad_brick is geometry-only): the SAME predicate picks the kernel and the rows
             # left unwritten, or fp32 storage with TRICOLO_VOXEL_COMPACT=0 would contract over uninitialised dy rows
             brick_wgrad = g.wgrad_brick and y.dtype != torch.float32
+            rows_out = saved["levels"][l + 1][6] if l < 4 else None    # the pooled level's active-site list
             dy, dgamma, dbeta = ops.pool3d_bn_bwd(y, co, mask, pooled, dx.contiguous(), B, D, C, bn.weight, count, out_scale=ugs,
-                                                  fused=fuse, keep_inactive=(l == 0 and (compact or brick_wgrad)))
+                                                  fused=fuse, keep_inactive=(l == 0 and (compact or brick_wgrad)), rows=rows, rows_out=rows_out)
             if compact and not brick_wgrad:
                 # contraction over the active sites only (row list of the level)
                 grads[3 * l] = ops.conv_wgrad(x, dy, g, conv.weight, prec, rows=rows, out_scale=ugs, batch=batch)

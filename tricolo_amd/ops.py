@@ -739,13 +739,45 @@ def pool3d_bwd_route(y, co: BNCoeffs, mask, pooled, dpooled, B, D, C):
     return g
 
 
+_VOX_ROWS = os.environ.get("TRICOLO_VOX_BWD_ROWS", "1") != "0"      # A/B switch: 0 = the dense (mask-skipping) passes everywhere
+
+
+def pool3d_bwd_route_rows(y, co: BNCoeffs, mask, pooled, dpooled, B, D, C, rows_out):
+    """pool3d_bwd_route over the ACTIVE pooled sites only (rows_out = the next level's (row_pos, count))."""
+    g = torch.empty_like(y)
+    check(lib().tri_pool3d_bwd_route_rows(ptr(_act(y)), ptr(co.scale), ptr(co.shift), ptr(mask), ptr(pooled), ptr(_act(dpooled)), B, D, C,
+                                          ptr(g), ptr(rows_out[0]), ptr(rows_out[1]), _abf(y), stream()), "tri_pool3d_bwd_route_rows")
+    return g
+
+
+def bn_bwd_rows(y, g, co: BNCoeffs, gamma, rows, out_scale: float = 1.0):
+    """BatchNorm backward over a compact row list, in place on g: rows outside the list are neither read nor written."""
+    C = y.shape[-1]
+    scratch = torch.empty((lib().tri_bn_bwd_rows_scratch(C),), dtype=torch.uint8, device=y.device)
+    buf = torch.empty((2, C), dtype=torch.float32, device=y.device)
+    check(lib().tri_bn_bwd_rows(ptr(_act(y)), ptr(_act(g)), C, ptr(rows[0]), ptr(rows[1]), rows[0].numel(), ptr(gamma), ptr(co.mean),
+                                ptr(co.invstd), ptr(g), ptr(buf[0]), ptr(buf[1]), float(out_scale), ptr(scratch), _abf(y), stream()),
+          "tri_bn_bwd_rows")
+    return g, buf[0], buf[1]
+
+
 def pool3d_bn_bwd(y, co: BNCoeffs, mask, pooled, dpooled, B, D, C, gamma, count_dev, out_scale: float = 1.0, fused: bool = True,
-                  keep_inactive: bool = False):
+                  keep_inactive: bool = False, rows=None, rows_out=None):
     """Backward of BatchNorm1d -> ReLU -> SparseMaxPool3d of one voxel level: (dy, dgamma, dbeta).  fused: the routing pass also
     produces the BatchNorm-backward sums (tri_pool3d_bwd_route_reduce), so the level costs route + finalize + apply instead of
     route + reduce + finalize + apply; channel counts whose quads do not divide 256 take the unfused passes.  keep_inactive: dy rows
     of inactive sites are left unwritten instead of zeroed (level 0: its dy only feeds the weight gradient over the same mask - at
     13 % occupancy the zeros were 87 % of the pass's writes)."""
+    # rows / rows_out (round 4): (row_pos, count) of THIS level / of the pooled level.  The finest levels are 13-16 % occupied: the
+    # routing pass then walks the active pooled sites, and - where dy may stay unwritten at inactive sites (keep_inactive) - the whole
+    # BatchNorm backward walks this level's list
+    big = y.numel() // C > 16384
+    if _VOX_ROWS and big and _sync_world() == 1 and C % 4 == 0 and (rows_out is not None or (rows is not None and keep_inactive)):
+        gz = (pool3d_bwd_route_rows(y, co, mask, pooled, dpooled, B, D, C, rows_out) if rows_out is not None
+              else pool3d_bwd_route(y, co, mask, pooled, dpooled, B, D, C))
+        if rows is not None and keep_inactive:
+            return bn_bwd_rows(y, gz, co, gamma, rows, out_scale=out_scale)
+        return bn_bwd(y, gz, co, gamma, count_dev=count_dev, row_mask=mask, out_scale=out_scale, keep_inactive=keep_inactive)
     if C % 4 or (C // 4) > 256 or 256 % (C // 4) or not fused:
         gz = pool3d_bwd_route(y, co, mask, pooled, dpooled, B, D, C)
         return bn_bwd(y, gz, co, gamma, count_dev=count_dev, row_mask=mask, out_scale=out_scale, keep_inactive=keep_inactive)
