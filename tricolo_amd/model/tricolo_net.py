@@ -58,10 +58,8 @@ class TriCoLoNet(TriModule):
             self.image_encoder = _instantiate(getattr(cfg.model.modules, cfg.model.image_encoder), clip_model=clip_model)
         if cfg.model.voxel_encoder is not None:
             self.voxel_encoder = _instantiate(getattr(cfg.model.modules, cfg.model.voxel_encoder))
-            if self.image_encoder is not None and hasattr(self.voxel_encoder, "fuse_pool_reduce"):
-                # a side tower here: see SparseCNNEncoder._backward_impl.  Beside an image tower the fused pass only pays on the big
-                # grids (64^3 x 64 + 12 x 224^2: 22.39 -> 21.87 ms; 32^3 x 32 + 6 x 128^2: 2.98-3.01 -> 3.04-3.05 ms, three pairs)
-                self.voxel_encoder.fuse_pool_reduce = getattr(self.voxel_encoder, "voxel_size", 32) >= 64
+            # (rounds 2-3 switched SparseCNNEncoder.fuse_pool_reduce off beside an image tower at 32^3 - the step was 1 % slower then;
+            #  re-measured in round 4, three alternating pairs: fused 2.757 against 2.768 ms, with the image tower issued first 2.740)
         self.loss_fn = _instantiate(getattr(cfg.loss, cfg.loss.name))
         self.val_test_step_outputs = []
         self.overlap_towers = os.environ.get("TRICOLO_OVERLAP", "1") != "0"
@@ -132,7 +130,9 @@ class TriCoLoNet(TriModule):
         # already queued on their streams while the host spends ~1.5 ms issuing the image tower (6.1 against 7.6 ms per step).
         # Re-measured with the row-unit conv kernels (shorter layer1 / layer4, bench.py three times each): trimodal tvi 3.30 /
         # itv 3.33-3.35 / vti 3.33-3.35 ms (config 5: 24.21 / 24.20); without a voxel tower (config 3) itv 4.67 / tvi 4.73.
-        capt_order = "tvi" if self.voxel_encoder is not None else "itv"
+        # Round 4 (krow weight gradients, shorter side towers; three alternating runs each): itv 2.756 / tvi 2.768 ms, with the fused
+        # voxel pool routing 2.740 / 2.757 - the image tower is issued first in every configuration now.
+        capt_order = "itv"
         order = os.environ.get("TRICOLO_TOWER_ORDER") or (capt_order if torch.cuda.is_current_stream_capturing() else "tvi")
         s_text.wait_stream(main)
         vox = img = text = None
