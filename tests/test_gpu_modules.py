@@ -743,6 +743,40 @@ def test_config5_full_per_gpu_batch_properties(prec):
     assert np.isfinite(after) and after < total.item()
 
 
+@pytest.mark.timeout(900)
+def test_config5_voxel_tower_at_full_size_against_the_oracle_forward():
+    """the 64^3 x 64 kernel plans of the voxel tower - the level-0 brick kernel with 128-run bricks, level 1 on the
+    row-list kernel, 128-wide split-K tiles on levels 2-4 - were only ever checked by properties at that size; the oracle comparison
+    for 64^3 ran at batch 2, which plans differently.  Here the whole tower runs at config 5's real per-GPU batch and its embeddings are
+    compared with the fp32 CPU oracle's forward on the same 64 samples (train-mode BatchNorm over the whole batch; ~25 s of CPU conv3d):
+    bf16x3 within 2e-4, f16 within 1e-3 (the north star's bound) per element of the unit-norm rows, and the running statistics agree."""
+    from oracle.modules import SparseCNNRef
+    B, V = 64, 64
+    batch = syn.make_batch(B, voxel_size=V, num_views=None, seed=syn.BASE_SEED + 56)
+    ref = SparseCNNRef(V, 32, 512, 512)
+    fill_module(ref, prefix="voxel_encoder.")
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    with torch.no_grad():
+        zr = ref(batch["voxels"], B)
+    vox = {k: v.to(DEV) for k, v in batch["voxels"].items()}
+    out = {}
+    for prec, tol in (("bf16x3", EMB_TOL), ("f16", 1e-3)):
+        ops.set_default_precision(prec)
+        m = SparseCNNEncoder(V, 32, 512, 512)
+        fill_module(m, prefix="voxel_encoder.")
+        m = m.to(DEV)
+        with torch.no_grad():
+            m.train()
+            z = m(vox, B)
+        d = float((z.cpu() - zr).abs().max())
+        out[prec] = d
+        assert d <= tol, (prec, d)
+        for name, v in m.state_dict().items():
+            if "running_var" in name or "running_mean" in name:
+                np.testing.assert_allclose(v.cpu().numpy(), ref.state_dict()[name].numpy(), rtol=2e-3, atol=2e-4, err_msg=f"{prec} {name}")
+    _report("fullbatch/config5_voxel_tower_vs_oracle", {"max_abs_embedding_diff": out})
+
+
 @pytest.mark.parametrize("tag,text,image,voxel,V,nv,S,B", [
     ("config2", "BiGRUEncoder", None, "SparseCNNEncoder", 32, 6, 128, 64),
     ("config3", "BiGRUEncoder", "MVCNNEncoder", None, 32, 6, 128, 64),
