@@ -325,7 +325,12 @@ def run_mode(a, precision, world, rank, device, want_voxel_roofline):
     # of the three graph segments, HIP events on this rank's stream, median of 10 replays behind the timed windows; every rank reports
     # (rank 0 gathers the lines) together with the number of ranks the RCCL communicator really spans.
     dp_info = None
-    if dp_graph and graphs is not None:
+    have_graphs = dp_graph and graphs is not None
+    if dp_graph and world > 1:                       # the leg below holds collectives: every rank must take the same branch
+        ok = torch.tensor([1.0 if have_graphs else 0.0], dtype=torch.float32, device="cpu" if dist.get_backend() == "gloo" else device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        have_graphs = have_graphs and float(ok.item()) > 0.5
+    if have_graphs:
         seen = torch.ones((1,), dtype=torch.float32, device=device)
         parallel.all_reduce_sum(seen)
         evs = []
