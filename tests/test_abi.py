@@ -37,6 +37,19 @@ def test_host_helpers_without_gpu():
     g2 = ops.ConvGeom(12, (1, 128, 128), 3, 4, 64, (1, 7, 7), 2, (0, 3, 3), (147, 1, 49))
     assert g2.out_grid == (1, 64, 64) and g2.flops == 2 * 12 * 64 * 64 * 49 * 3 * 64
     assert g2.wgrad_ws > 0
+    # round 4: the kernel-row weight-gradient planner (host-side; the launch itself needs a GPU) - which family a layer's job joins,
+    # its tiles per position split and its 64-position steps
+    l1 = ops.ConvGeom(192, (1, 32, 32), 64, 64, 64, (1, 3, 3), 1, (0, 1, 1), (576, 1, 9))
+    assert l1.wgrad_krow and l1.wgrad_group(2) == (5, 3, 3072)                 # 64-row tiles: 3 kernel rows x 1 channel chunk
+    l4 = ops.ConvGeom(192, (1, 4, 4), 512, 512, 512, (1, 3, 3), 1, (0, 1, 1), (4608, 1, 9))
+    assert l4.wgrad_krow and l4.wgrad_group(2) == (4, 96, 48)                  # 4 channel tiles x 3 rows x 8 chunks
+    s2 = ops.ConvGeom(192, (1, 32, 32), 64, 64, 128, (1, 3, 3), 2, (0, 1, 1), (576, 1, 9))
+    assert s2.wgrad_krow and s2.wgrad_group(2) == (4, 3, 768)                  # stride 2 rides in the stride-1 launch
+    w56 = ops.ConvGeom(8, (1, 56, 56), 128, 128, 128, (1, 3, 3), 1, (0, 1, 1), (1152, 1, 9))
+    assert w56.wgrad_group(2) == (4, 6, 8 * 56)                                # one 56-position row per step
+    ds = ops.ConvGeom(192, (1, 32, 32), 64, 64, 128, (1, 1, 1), 2, (0, 0, 0), (64, 1, 1))
+    assert not ds.wgrad_krow and ds.wgrad_group(2)[0] in (1, 2)                # 1x1 shortcuts stay on the im2col family
+    assert l1.wgrad_group(0) == (0, 0, 0)                                      # fp32 storage: no grouped family
     import torch
     with pytest.raises(RuntimeError, match="no CPU"):
         _C.ptr(torch.zeros(3))
