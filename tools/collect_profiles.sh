@@ -13,6 +13,7 @@ for p in f16 bf16x3; do
   cp $O/${tag}_prof_$p.json $P/bench_under_rocprof_$p.json
 done
 cp $O/${tag}_pmc_traffic_f16.json $P/pmc_traffic_f16.json
+cp $O/${tag}_pmc_mfma_f16.json $P/pmc_mfma_f16.json
 cp $O/${tag}_voxel_fwd.txt $P/voxel_fwd.txt
 cp $O/${tag}_kernel_times.txt $P/kernel_times.txt
 for p in f16 bf16; do cp $O/${tag}_conv_layers_$p.txt $P/conv_layers_$p.txt; done

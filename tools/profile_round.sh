@@ -17,7 +17,9 @@ for p in f16 bf16x3; do
 done
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${tag}_pmc_fetch -- python3 $R/bench.py --steps 3 --warmup 2 --precision f16 --modes "" --no-cpu-baseline > $O/${tag}_pmc_fetch.json 2> $O/${tag}_pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${tag}_pmc_write -- python3 $R/bench.py --steps 3 --warmup 2 --precision f16 --modes "" --no-cpu-baseline > $O/${tag}_pmc_write.json 2> $O/${tag}_pmc_write.err
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/${tag}_pmc_mfma -- python3 $R/bench.py --steps 3 --warmup 2 --precision f16 --modes "" --no-cpu-baseline > /dev/null 2> $O/${tag}_pmc_mfma.err
 cd $R
+python tools/pmc_mfma.py $O/${tag}_pmc_mfma > $O/${tag}_pmc_mfma_f16.json
 python tools/pmc_traffic.py $O/${tag}_pmc_fetch $O/${tag}_pmc_write f16 > $O/${tag}_pmc_traffic_f16.json
 python tools/kernel_times.py > $O/${tag}_kernel_times.txt 2>/dev/null
 python tools/voxel_fwd_bench.py --modes f16,bf16 --out $O/${tag}_voxel_fwd.txt --json $O/${tag}_voxel_fwd.json > /dev/null 2>&1
