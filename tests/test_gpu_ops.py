@@ -864,6 +864,9 @@ BF16_CASES = [c for c in CONV_CASES if c[0] in ("vox_l0", "vox_l1", "vox_l3", "s
     ("h_many", 40, (1, 32, 32), 64, 64, (1, 3, 3), 1, (0, 1, 1), "torch"),
     # more tiles than CUs with four output-channel tiles and two channel chunks each (the weight stream crosses tile boundaries)
     ("h_320", 160, (1, 8, 8), 128, 256, (1, 3, 3), 1, (0, 1, 1), "torch"),
+    # 192-position tiles of conv_halo_rows_kernel (planned where they save a round of workgroups: h_320 above - 216 tiles with a partial
+    # last one instead of 320 - and layer3 of the bench shape: 256 tiles instead of 384, four channel chunks)
+    ("h_tm3", 192, (1, 8, 8), 256, 256, (1, 3, 3), 1, (0, 1, 1), "torch"),
     # conv_stem_kernel (4 stored input channels, stride 2, 64 output channels): stem7x7 above (32 x 32 -> 16 x 16, one tile per
     # image) and: several tiles per image with a partial last one (OH = 24, TH = 8), 3x3 and 5x5 kernels, a persistent workgroup
     # that walks many tiles (more tiles than CUs), 112-wide output rows (7 position tiles per row, TH = 2)
@@ -959,6 +962,8 @@ def test_conv_16bit_storage_integer_exact(case, store, prec):
         # accumulate epilogue the residual branch of a BasicBlock uses
         out2, stats = ops.conv_fwd(xcl.to(DEV).to(store), g, packed, want_stats=True)
         assert torch.equal(out2.cpu(), ref.to(store))
+        if case[0] in ("h_tm3", "h_320") and os.environ.get("TRICOLO_HALO_ROWS", "1") != "0" and os.environ.get("TRICOLO_HALO_TM3", "1") != "0":
+            assert (g.kernel_family[(False, 2)] >> 8) == 3 and stats.shape[0] == (64 if case[0] == "h_tm3" else 54)   # 192-position tiles, one record per workgroup
         exact = ref.to(store).double().reshape(-1, case[4])
         st = stats.cpu().double().sum(0)
         np.testing.assert_allclose(st[0].numpy(), exact.sum(0).numpy(), rtol=1e-6, atol=1e-2)
@@ -997,7 +1002,7 @@ def test_conv_16bit_storage_integer_exact(case, store, prec):
             np.testing.assert_allclose(st[1].numpy(), (gm * yv.double()).reshape(-1, case[3]).sum(0).numpy(), rtol=1e-6, atol=1e-2)
 
 
-@pytest.mark.parametrize("rows", ["0", "2"])
+@pytest.mark.parametrize("rows", ["0", "2", "2,tm2"])
 def test_halo_kernels_ab_switch(rows):
     """TRICOLO_HALO_ROWS picks the kernel of the resolution-keeping 3x3 layers per plan (default: conv_halo_rows_kernel for 64 input
     channels and for launches with at most one tile per workgroup, conv_halo2d_kernel otherwise).  The switch is read once per
@@ -1005,7 +1010,9 @@ def test_halo_kernels_ab_switch(rows):
     weight-streaming multi-tile mode (2) - run the halo geometries of the exactness test above in a child process."""
     import subprocess
     import sys
-    env = dict(os.environ, TRICOLO_HALO_ROWS=rows)
+    env = dict(os.environ, TRICOLO_HALO_ROWS=rows.split(",")[0])
+    if rows.endswith("tm2"):
+        env["TRICOLO_HALO_TM3"] = "0"                                 # 128-position tiles only (A/B partner of the 192-position tiles)
     k = "test_conv_16bit_storage_integer_exact and (h_ or big_nosplit or c64_32) and f16"
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", k, "-p", "no:cacheprovider"],
                        env=env, capture_output=True, text=True, timeout=900)

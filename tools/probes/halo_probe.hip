@@ -15,9 +15,13 @@ static const char* kPhase[] = {"", "start", "2", "3", "4", "5", "6", "7", "8", "
 
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 192;                       // images = per-GPU batch 32 x 6 views
+    const int first = argc > 2 ? atoi(argv[2]) : 0;                     // first layer probed (0 = 64 channels ... 3 = 512)
     struct L { int hw, c; } layers[] = {{32, 64}, {16, 128}, {8, 256}, {4, 512}};
+    setvbuf(stdout, nullptr, _IONBF, 0);
     hipMalloc(&g_halo_dbg, (size_t)4096 * 256 * 8);
+    int li = -1;
     for (auto l : layers) {
+        if (++li < first) continue;
         TriConvDesc d = {B, 1, l.hw, l.hw, l.c, 1, l.hw, l.hw, l.c, 1, 3, 3, 1, 0, 1, 1};
         const size_t M = (size_t)B * l.hw * l.hw, K = 9 * l.c;
         void *in, *w, *out; float* stats;

@@ -21,11 +21,18 @@ def main():
     which = int(sys.argv[sys.argv.index("--step") + 1]) if "--step" in sys.argv else -2
     files = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
     rows = []
+    cols = None
     for f in files:
         for r in csv.DictReader(open(f)):
+            cols = cols or list(r.keys())
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?")))
     rows.sort()
-    ends = [i for i, r in enumerate(rows) if r[2].startswith("adam_seg_kernel") or r[2].startswith("adam_kernel")]
+    ends = [i for i, r in enumerate(rows) if re.search(r"\badam_(seg_)?kernel", r[2])]
+    if len(ends) < 2:
+        raise SystemExit(f"{len(rows)} kernel rows, {len(ends)} Adam launches: no complete step in the trace")
+    print(f"# {len(rows)} kernel rows, {len(ends)} Adam launches; columns {cols}")
+    if "--shortest" in sys.argv:                         # the shortest complete step (a replayed one, not an eager warm-up step)
+        which = min(range(1, len(ends)), key=lambda i: rows[ends[i]][1] - rows[ends[i - 1] + 1][0])
     lo, hi = ends[which - 1] + 1, ends[which] + 1
     step = rows[lo:hi]
     t0 = step[0][0]

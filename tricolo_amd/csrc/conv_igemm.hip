@@ -696,6 +696,10 @@ template <int N>
 __device__ __forceinline__ void frag_wait(v4i (&a)[2], v4i (&b)[4]) {
     asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N));
 }
+template <int N>
+__device__ __forceinline__ void frag_wait(v4i (&a)[3], v4i (&b)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(%7)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N));
+}
 // In-kernel phase stamps of the halo kernels (-DHALO_STAMPS builds only: tools/probes/halo_probe.hip).  Wave 0 of every workgroup writes
 // (id << 48 | s_memtime) into a 2 KiB LDS area `stl` of the kernel and copies it to p.h_dbg at the end; ~150 cycles per stamp.
 #ifdef HALO_STAMPS
@@ -977,11 +981,15 @@ __global__ __launch_bounds__(256, WGREC ? 3 : 1) void conv_halo2d_kernel(const C
 // DRIP: the tile's output waits in a 4 KiB LDS tile per wave and leaves as one full-row store per k-step of the NEXT element's first
 // kernel row: with every workgroup of the launch in step, stores issued in the epilogue all hit the memory system at once.  Launches
 // whose slabs leave no room for the 16 KiB (DRIP = false) store from the epilogue through a 2 KiB tile per wave.
-template <typename AT, bool DRIP, bool ACCUM, int NTL>
+// TMT: 16-position fragments per wave (2: 128-position tiles; 3: 192-position tiles, streamed weights only, no drip - for launches
+// whose 128-position tiles need one more round of workgroups than the 192-position ones: layer3 of the bench shape, 384 tiles
+// on 256 CUs = two rounds, 256 tiles of 192 = one round of 1.5 x the MFMAs per barrier / DMA piece: 25.9 -> see DESIGN.md)
+template <typename AT, bool DRIP, bool ACCUM, int NTL, int TMT = 2>
 __global__ __launch_bounds__(256, 1) void conv_halo_rows_kernel(const ConvArgs p) {
     typedef Mma<typename OpOf<AT>::E> MM;
     typedef typename MM::v8 v8;
-    constexpr int BN = 64, TN = 4, TM = 2, WM = 32, SLOT = HROWS_SLOT;
+    constexpr int BN = 64, TN = 4, TM = TMT, WM = 16 * TMT, SLOT = HROWS_SLOT;
+    static_assert(TMT == 2 || (TMT == 3 && !DRIP && NTL == 0), "192-position tiles: streamed weights, epilogue stores");
     constexpr int NTLE = NTL < 1 ? 1 : NTL;                             // tiles per group
     constexpr bool STREAM = NTL == 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1031,7 +1039,9 @@ __global__ __launch_bounds__(256, 1) void conv_halo_rows_kernel(const ConvArgs p
     // streamed mode: cursor over (tile, chunk) elements, three rows each
     int w_k = 0, w_chunk = 0;                                           // tile index in this workgroup's list, chunk
     auto w_pieces = [&](int ky, int j0, int j1) {
+#ifndef HR_ABL_NODMA
         if (STREAM && w_k < n_my) w_row_pieces(w_chunk, ky, j0, j1);
+#endif
     };
     auto w_advance = [&]() {
         if (++w_chunk == nchunks) { w_chunk = 0; ++w_k; }
@@ -1086,8 +1096,9 @@ __global__ __launch_bounds__(256, 1) void conv_halo_rows_kernel(const ConvArgs p
         s_kill = (top_ok ? 0u : stop) | (bot_ok ? 0u : sbot);
         s_cb = g0_ * W * p.Cin * 2 + s_chunk * 128;
     };
+    bool slab_on = true;                                                // (probe builds switch the in-loop slab DMAs off)
     auto slab_pieces = [&](int r0, int r1) {
-        if (s_g < n_my) {
+        if (s_g < n_my && slab_on) {
             const unsigned dst = dma_slab + s_buf * slab_bytes;
 #pragma unroll
             for (int r = 0; r < HALO_MAX_ROUNDS; ++r)
@@ -1106,6 +1117,9 @@ __global__ __launch_bounds__(256, 1) void conv_halo_rows_kernel(const ConvArgs p
     slab_setup();                                                       // the first slab, before the remaining constants
     slab_pieces(0, HALO_MAX_ROUNDS);
     slab_advance();
+#ifdef HR_ABL_NODMA
+    slab_on = false;
+#endif
 
     int pixc[TM];
 #pragma unroll
@@ -1174,20 +1188,44 @@ __global__ __launch_bounds__(256, 1) void conv_halo_rows_kernel(const ConvArgs p
         if (d_m0 + (D) * 8 < d_npos) *(v4i*)(d_ptr + (D) * d_step) = d_q;                  \
     }
 
+#ifdef HR_ABL_NOMMA                                                     /* probe builds only (tools/probes/halo_probe.hip): timing ablations */
+#define HR_MMA(TL, SET, A, B) asm volatile("" : "+v"(acc[TL][A][B]) : "v"(fb[SET][B]), "v"(fa[SET][A]))
+#else
 #define HR_MMA(TL, SET, A, B) acc[TL][A][B] = MM::mma(__builtin_bit_cast(v8, fb[SET][B]), __builtin_bit_cast(v8, fa[SET][A]), acc[TL][A][B])
+#endif
+#ifdef HR_ABL_NOREAD
+#define HR_RD(dst, expr) asm volatile("" : "+v"(dst))
+#else
+#define HR_RD(dst, expr) dst = expr
+#endif
     // k-step: wait for set CUR, then its eight MFMAs with the six reads of set NX between them (the fragments of the k-step after
     // the next: tap TAP, half KK of the 64 channels, slab buffer offset SB, ring slot KYR)
 #define HR_KSTEP(TL, CUR, NX, SB, TAP, KYR, KK)                                                                       \
     {                                                                                                                  \
-        frag_wait<6>(fa[CUR], fb[CUR]);                                                                                \
-        HR_MMA(TL, CUR, 0, 0); fa[NX][0] = lds_read16(arel[TAP][0][KK] + (SB));                                          \
-        HR_MMA(TL, CUR, 1, 0); fa[NX][1] = lds_read16(arel[TAP][1][KK] + (SB));                                          \
-        HR_MMA(TL, CUR, 0, 1); fb[NX][0] = lds_read16_off<((TAP) % 3) * 8192>(bbase[KYR][KK]);                           \
-        HR_MMA(TL, CUR, 1, 1); fb[NX][1] = lds_read16_off<((TAP) % 3) * 8192 + 2048>(bbase[KYR][KK]);                    \
-        HR_MMA(TL, CUR, 0, 2); fb[NX][2] = lds_read16_off<((TAP) % 3) * 8192 + 4096>(bbase[KYR][KK]);                    \
-        HR_MMA(TL, CUR, 1, 2); fb[NX][3] = lds_read16_off<((TAP) % 3) * 8192 + 6144>(bbase[KYR][KK]);                    \
+        frag_wait<TM + TN>(fa[CUR], fb[CUR]);                                                                          \
+        if constexpr (TM == 2) {                                                                                       \
+        HR_MMA(TL, CUR, 0, 0); HR_RD(fa[NX][0], lds_read16(arel[TAP][0][KK] + (SB)));                                    \
+        HR_MMA(TL, CUR, 1, 0); HR_RD(fa[NX][1], lds_read16(arel[TAP][1][KK] + (SB)));                                    \
+        HR_MMA(TL, CUR, 0, 1); HR_RD(fb[NX][0], lds_read16_off<((TAP) % 3) * 8192>(bbase[KYR][KK]));                     \
+        HR_MMA(TL, CUR, 1, 1); HR_RD(fb[NX][1], lds_read16_off<((TAP) % 3) * 8192 + 2048>(bbase[KYR][KK]));              \
+        HR_MMA(TL, CUR, 0, 2); HR_RD(fb[NX][2], lds_read16_off<((TAP) % 3) * 8192 + 4096>(bbase[KYR][KK]));              \
+        HR_MMA(TL, CUR, 1, 2); HR_RD(fb[NX][3], lds_read16_off<((TAP) % 3) * 8192 + 6144>(bbase[KYR][KK]));              \
         HR_MMA(TL, CUR, 0, 3);                                                                                          \
         HR_MMA(TL, CUR, 1, 3);                                                                                          \
+        } else {                                  /* twelve MFMAs, seven reads */                                       \
+        HR_MMA(TL, CUR, 0, 0); HR_RD(fa[NX][0], lds_read16(arel[TAP][0][KK] + (SB)));                                    \
+        HR_MMA(TL, CUR, 1, 0); HR_RD(fa[NX][1], lds_read16(arel[TAP][1][KK] + (SB)));                                    \
+        HR_MMA(TL, CUR, TM - 1, 0); HR_RD(fa[NX][TM - 1], lds_read16(arel[TAP][TM - 1][KK] + (SB)));                     \
+        HR_MMA(TL, CUR, 0, 1); HR_RD(fb[NX][0], lds_read16_off<((TAP) % 3) * 8192>(bbase[KYR][KK]));                     \
+        HR_MMA(TL, CUR, 1, 1); HR_RD(fb[NX][1], lds_read16_off<((TAP) % 3) * 8192 + 2048>(bbase[KYR][KK]));              \
+        HR_MMA(TL, CUR, TM - 1, 1); HR_RD(fb[NX][2], lds_read16_off<((TAP) % 3) * 8192 + 4096>(bbase[KYR][KK]));         \
+        HR_MMA(TL, CUR, 0, 2); HR_RD(fb[NX][3], lds_read16_off<((TAP) % 3) * 8192 + 6144>(bbase[KYR][KK]));              \
+        HR_MMA(TL, CUR, 1, 2);                                                                                          \
+        HR_MMA(TL, CUR, TM - 1, 2);                                                                                     \
+        HR_MMA(TL, CUR, 0, 3);                                                                                          \
+        HR_MMA(TL, CUR, 1, 3);                                                                                          \
+        HR_MMA(TL, CUR, TM - 1, 3);                                                                                     \
+        }                                                                                                              \
     }
     // kernel row KY of the current element: six k-steps; NKY = (KY + 1) % 3, SBN = slab buffer of the row after this one
 #define HR_ROW(TL, KY, NKY, SBN)                                                                                      \
@@ -1223,10 +1261,13 @@ __global__ __launch_bounds__(256, 1) void conv_halo_rows_kernel(const ConvArgs p
     // the first fragments of an element (k-steps 0 and 1 of its kernel row 0) from slab buffer offset SB
 #define HR_FIRST_READS(SB)                                                                                            \
     {                                                                                                                  \
+        /* in k-step order: the first k-step waits for all but the TM + TN youngest reads */                           \
         fa[0][0] = lds_read16(arel[0][0][0] + (SB)); fa[0][1] = lds_read16(arel[0][1][0] + (SB));                        \
+        if constexpr (TM == 3) fa[0][TM - 1] = lds_read16(arel[0][TM - 1][0] + (SB));                                    \
         fb[0][0] = lds_read16_off<0>(bbase[0][0]); fb[0][1] = lds_read16_off<2048>(bbase[0][0]);                        \
         fb[0][2] = lds_read16_off<4096>(bbase[0][0]); fb[0][3] = lds_read16_off<6144>(bbase[0][0]);                     \
         fa[1][0] = lds_read16(arel[0][0][1] + (SB)); fa[1][1] = lds_read16(arel[0][1][1] + (SB));                        \
+        if constexpr (TM == 3) fa[1][TM - 1] = lds_read16(arel[0][TM - 1][1] + (SB));                                    \
         fb[1][0] = lds_read16_off<0>(bbase[0][1]); fb[1][1] = lds_read16_off<2048>(bbase[0][1]);                        \
         fb[1][2] = lds_read16_off<4096>(bbase[0][1]); fb[1][3] = lds_read16_off<6144>(bbase[0][1]);                     \
     }
@@ -1895,7 +1936,11 @@ static bool halo_geometry(int B, int H, int W, int cin, int cout, int TM, ConvPl
         if (g < NT) g = NT;
         static int half_tiles = -1;                                   // tuning aid: TRICOLO_HALO_ROWS_HALFTILES (tiles per workgroup x 2)
         if (half_tiles < 0) { const char* e = getenv("TRICOLO_HALO_ROWS_HALFTILES"); half_tiles = e ? atoi(e) : 3; }
-        if (rows_kernel && (cin == 64 || 2 * items <= half_tiles * g || rows_kernel == 2) && TM == 2 &&
+        // (round 4: with >= 256 input channels - four or more weight chunks per tile - the row-unit kernel also wins launches of several
+        //  rounds: 384 images of 8 x 8 x 256 47 -> 32 us, 768 images of 4 x 4 x 512 85 -> 65 us; TRICOLO_HALO_ROWS_DEEP=0 restores the tile rule)
+        static int deep = -1;
+        if (deep < 0) { const char* e = getenv("TRICOLO_HALO_ROWS_DEEP"); deep = (e && e[0] == '0') ? 0 : 1; }
+        if (rows_kernel && (cin == 64 || (deep && cin >= 256) || 2 * items <= half_tiles * g || rows_kernel == 2) && (TM == 2 || (TM == 3 && cin != 64)) &&
             2 * (size_t)slab + 3 * (size_t)HROWS_SLOT + 8192 <= 163840) {
             pl->h_v5 = 1;
             pl->h_grid = items < g ? items : g;
@@ -2013,8 +2058,19 @@ static ConvPlan conv_make_plan(int B, int ID, int IH, int IW, int cin, int OD, i
         IH == OH && IW == OW && (long)B * IH * IW * cin * 2 < ((long)1 << 31)) {
         // 128-position tiles: a ~25 KB slab + 24 KB ring lets three workgroups share a CU (the kernel is bound by instruction
         // issue and latency, not by operand bytes: occupancy matters more than the bigger tile's reuse)
-        ConvPlan t2{};
+        ConvPlan t2{}, t3{};
         const ConvPlan* pick = halo_geometry(B, IH, IW, cin, cout, 2, &t2) ? &t2 : nullptr;
+        // 192-position tiles on the row-unit kernel where they save a ROUND of workgroups: a tile of 1.5 x the positions costs ~1.2 x the
+        // time (1.5 x the MFMAs per barrier, weight piece and DMA wait), so they win when 1.2 x their rounds < the 128-position rounds
+        // (layer3 of the bench shape: 384 tiles on 256 CUs -> 256 tiles, 26.5 -> 19.7 us forward, 24.9 -> 18.1 us data gradient; 384 images:
+        // 768 tiles in three rounds -> 512 in two, 47 (conv_halo2d_kernel) -> 32 us; round 4, TRICOLO_HALO_TM3=0 switches them off)
+        static int tm3 = -1;
+        if (tm3 < 0) { const char* e = getenv("TRICOLO_HALO_TM3"); tm3 = (e && e[0] == '0') ? 0 : 1; }
+        if (pick && pick->h_v5 && tm3 && cin != 64 && halo_geometry(B, IH, IW, cin, cout, 3, &t3) && t3.h_v5) {
+            const int nt = cout / 64, g = t2.h_grid > t3.h_grid ? t2.h_grid : t3.h_grid;
+            const int r2 = (t2.h_mtiles * nt + g - 1) / g, r3 = (t3.h_mtiles * nt + g - 1) / g;
+            if (12 * r3 < 10 * r2) pick = &t3;
+        }
         if (pick) {
             pl.halo = pick->halo; pl.h_tr = pick->h_tr; pl.h_rows = pick->h_rows; pl.h_slab_bytes = pick->h_slab_bytes;
             pl.h_nr = pick->h_nr; pl.h_mtiles = pick->h_mtiles; pl.h_dbuf = pick->h_dbuf; pl.h_grid = pick->h_grid; pl.h_wgrec = pick->h_wgrec; pl.h_v5 = pick->h_v5;
@@ -2112,7 +2168,7 @@ static int launch_halo(ConvArgs& a, const ConvPlan& pl, hipStream_t stream) {
 #else
         const size_t extra = 0;
 #endif
-        const bool drip = 2 * (size_t)pl.h_slab_bytes + 3 * (size_t)HROWS_SLOT + 16384 + extra <= 163840 && !a.accumulate;
+        const bool drip = 2 * (size_t)pl.h_slab_bytes + 3 * (size_t)HROWS_SLOT + 16384 + extra <= 163840 && !a.accumulate && pl.halo != 3;
         const size_t smem5 = 2 * (size_t)pl.h_slab_bytes + 3 * (size_t)HROWS_SLOT + (drip ? 16384 : 8192) + extra;
         // weights: resident filter bank (64 input channels: NTL 1) or streamed (NTL 0).  The kernel also runs groups of 2 / 4 tiles per
         // resident chunk (NTL 2 / 4, TRICOLO_HALO_NTL): measured no better than streaming on any configuration (profiles/r2/NOTES), so
@@ -2123,15 +2179,15 @@ static int launch_halo(ConvArgs& a, const ConvPlan& pl, hipStream_t stream) {
           const int items = pl.h_mtiles * (a.Cout / 64), per_wg = (items + pl.h_grid - 1) / pl.h_grid;
           if (f && a.Cin != 64 && per_wg > 1) ntl = per_wg == 2 ? 2 : 4; }
 #endif
-#define TRI_ROWS_LAUNCH(DRIP_, ACC_, NTL_)                                                                                          \
+#define TRI_ROWS_LAUNCH(DRIP_, ACC_, NTL_, ...)                                                                                     \
         do {                                                                                                                        \
             static size_t attr5 = 0;                                                                                                \
             if (smem5 > attr5) {                                                                                                    \
-                hipFuncSetAttribute((const void*)conv_halo_rows_kernel<AT, DRIP_, ACC_, NTL_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                hipFuncSetAttribute((const void*)conv_halo_rows_kernel<AT, DRIP_, ACC_, NTL_, ##__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                     (int)smem5);                                                                                    \
                 attr5 = smem5;                                                                                                      \
             }                                                                                                                       \
-            conv_halo_rows_kernel<AT, DRIP_, ACC_, NTL_><<<pl.h_grid, 256, smem5, stream>>>(a);                                      \
+            conv_halo_rows_kernel<AT, DRIP_, ACC_, NTL_, ##__VA_ARGS__><<<pl.h_grid, 256, smem5, stream>>>(a);                       \
         } while (0)
 #define TRI_ROWS_MODE(NTL_)                                                                                                         \
         do {                                                                                                                        \
@@ -2139,7 +2195,11 @@ static int launch_halo(ConvArgs& a, const ConvPlan& pl, hipStream_t stream) {
             else if (drip) TRI_ROWS_LAUNCH(true, false, NTL_);                                                                      \
             else TRI_ROWS_LAUNCH(false, false, NTL_);                                                                               \
         } while (0)
-        if (ntl == 0) TRI_ROWS_MODE(0);
+        if (pl.halo == 3) {                                           // 192-position tiles (streamed weights, epilogue stores)
+            if (a.accumulate) TRI_ROWS_LAUNCH(false, true, 0, 3);
+            else TRI_ROWS_LAUNCH(false, false, 0, 3);
+        }
+        else if (ntl == 0) TRI_ROWS_MODE(0);
         else if (ntl == 1) TRI_ROWS_MODE(1);
 #ifdef HALO_NTL_EXPERIMENT
         else if (ntl == 2) TRI_ROWS_MODE(2);
