@@ -271,6 +271,14 @@ int tri_maxpool2d_bwd(const uint8_t* arg, const void* dout, int N, int H, int W,
 int tri_maxpool_bn_bwd_num_blocks(int N, int H, int W);
 int tri_maxpool_bn_bwd_reduce(const void* y, const uint8_t* arg, const void* dpool, int N, int H, int W, int C, float* partial,
                               const float* relu_scale, const float* relu_shift, int act_fmt, void* stream);
+/* round 4: the same [blocks][2][C] sums from the POOLED tensors (pooled = the forward's max-pool output, which the next layer keeps):
+ * sum(g) and sum(g y) are sums over windows, and an active window's winning activation is (pooled - shift) / scale; 50 MB instead of
+ * 137 MB read at the bench shape.  Windows whose recovered activation would be ill-conditioned (|pooled| > 64 |gamma|) read the
+ * stored y through the tap map.  16-bit storage, C % 8 == 0 and C / 8 a divisor of 256; else TRI_ERR_UNSUPPORTED. */
+int tri_maxpool_bn_bwd_pooled_num_blocks(int N, int H, int W);
+int tri_maxpool_bn_bwd_reduce_pooled(const void* pooled, const void* dpool, const void* y, const uint8_t* arg, int N, int H, int W, int C,
+                                     float* partial, const float* relu_scale, const float* relu_shift, const float* gamma, int act_fmt,
+                                     void* stream);
 int tri_maxpool_bn_bwd_apply(const void* y, const uint8_t* arg, const void* dpool, int N, int H, int W, int C, const float* c1,
                              const float* c2, const float* c3, const float* relu_scale, const float* relu_shift, void* dy, int act_fmt,
                              void* stream);

@@ -1318,6 +1318,52 @@ def test_stem_bn_backward_from_the_pooled_gradient(store):
         np.testing.assert_allclose(dg_b.cpu().numpy() * 2, gr.grad.numpy(), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("store", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+@pytest.mark.parametrize("tiny_gamma", [False, True], ids=["plain", "tiny_gamma"])
+def test_stem_bn_backward_sums_from_the_pooled_tensors(store, tiny_gamma):
+    """tri_maxpool_bn_bwd_reduce_pooled (sums of g and g * y over WINDOWS, the winning activation recovered from the pooled output as
+    (p - shift) / scale) against the sums taken from y and the tap map (tri_maxpool_bn_bwd_reduce) and against float64.  Integer data:
+    every window's recovered activation is exact, the sums are equal bit for bit.  Real data: dgamma / dbeta within the storage
+    type's rounding of the float64 sums.  tiny_gamma: channels with gamma = 0 or |shift| >> |gamma| take the stored y through the
+    tap map (the recovery would divide by ~0) and stay as accurate as the others."""
+    gen = torch.Generator().manual_seed(77)
+    N, C, H, W = 3, 64, 12, 20
+    M = N * H * W
+    for integer in (True, False):
+        y = (ints((N, H, W, C), -4, 4, 5) if integer else torch.randn(N, H, W, C, generator=gen) * 2 + 0.3)
+        gamma = (ints((C,), 1, 3, 6) if integer else torch.rand(C, generator=gen) + 0.5)
+        beta = (ints((C,), -2, 2, 7) if integer else torch.randn(C, generator=gen) * 0.3)
+        if tiny_gamma:
+            gamma[3], gamma[17], beta[17], gamma[40], beta[40] = 0.0, 1e-3, 1.5, -2e-4, 0.75
+        yd = y.view(N, 1, H, W, C).to(DEV).to(store)
+        yf = yd.float().view(M, C)
+        if integer and not tiny_gamma:       # mean 0 / variance 1 statistics make scale = gamma, shift = beta exactly: an exact recovery
+            co = ops.BNCoeffs(C, DEV)
+            co.scale.copy_(gamma); co.shift.copy_(beta); co.mean.zero_(); co.invstd.fill_(1.0)
+        else:
+            stats = torch.stack([yf.double().sum(0).float(), (yf.double() ** 2).sum(0).float()]).view(1, 2, C)
+            co = ops.bn_finalize(stats, C, gamma.to(DEV), beta.to(DEV), None, None, None, count_host=M)
+        pooled, arg = ops.maxpool2d_fwd(yd, want_arg=True, bn=co)
+        dpool = (ints(tuple(pooled.shape), -3, 3, 8) if integer else torch.randn(pooled.shape, generator=gen)).to(DEV).to(store)
+        part_a, _ = ops._maxpool_bn_bwd_sums(yd, arg, dpool, co, gamma.to(DEV), None)
+        part_b, nb = ops._maxpool_bn_bwd_sums(yd, arg, dpool, co, gamma.to(DEV), pooled)
+        assert nb == ops.lib().tri_maxpool_bn_bwd_pooled_num_blocks(N, H, W) and part_b.shape[0] == nb
+        sa, sb = part_a.double().sum(0).cpu(), part_b.double().sum(0).cpu()
+        if integer and not tiny_gamma:
+            assert torch.equal(sa, sb)
+            continue
+        # float64 reference of the two sums from the stored tensors
+        z = F.relu(yf.double().cpu() * co.scale.double().cpu() + co.shift.double().cpu()).view(N, H, W, C).permute(0, 3, 1, 2).requires_grad_()
+        F.max_pool2d(z, 3, 2, 1).backward(dpool.double().cpu().view(N, H // 2, W // 2, C).permute(0, 3, 1, 2))
+        gfull = (z.grad * (z.detach() > 0)).permute(0, 2, 3, 1).reshape(M, C)
+        ref = torch.stack([gfull.sum(0), (gfull * yf.double().cpu()).sum(0)])
+        scale_ = float(ref.abs().max())
+        eps = 2.0 ** -10 if store == torch.float16 else 2.0 ** -7
+        # (the y-based form rounds the routed gradient to the storage type per position: it is the looser of the two)
+        np.testing.assert_allclose(sb.numpy(), ref.numpy(), rtol=0, atol=eps * scale_)
+        np.testing.assert_allclose(sa.numpy(), ref.numpy(), rtol=0, atol=4 * eps * scale_)
+
+
 @pytest.mark.parametrize("store,prec", STORE16, ids=STORE16_IDS)
 @pytest.mark.parametrize("N,HW,k", [(5, 64, 7), (3, 32, 7), (2, 32, 3)])
 def test_stem_weight_gradient_with_the_bn_apply_pass_folded_in(N, HW, k, store, prec):

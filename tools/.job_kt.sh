@@ -1,0 +1,9 @@
+# usage: bash tools/.job_kt.sh <tag> <grep pattern> "<ENV_A>" "<ENV_B>" ...   (kernel_times.py under several environments)
+tag=$1; pat=$2; shift 2
+mkdir -p gpurun_out/kt
+out=gpurun_out/kt/$tag.txt; : > $out
+for e in "$@"; do
+  echo "== $e" >> $out
+  env $e python3 tools/kernel_times.py --modes "" --no-cpu-baseline 2>gpurun_out/kt/$tag.err | grep -E "$pat|entry-point" >> $out
+done
+cat $out

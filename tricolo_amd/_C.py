@@ -100,6 +100,8 @@ SIGNATURES = {
     "tri_maxpool2d_bwd": (I, [P, P, I, I, I, I, P, I, P]),
     "tri_maxpool_bn_bwd_num_blocks": (I, [I, I, I]),
     "tri_maxpool_bn_bwd_reduce": (I, [P, P, P, I, I, I, I, P, P, P, I, P]),
+    "tri_maxpool_bn_bwd_pooled_num_blocks": (I, [I, I, I]),
+    "tri_maxpool_bn_bwd_reduce_pooled": (I, [P, P, P, P, I, I, I, I, P, P, P, P, I, P]),
     "tri_maxpool_bn_bwd_apply": (I, [P, P, P, I, I, I, I, P, P, P, P, P, P, I, P]),
     "tri_avgpool_viewmax_fwd": (I, [P, I, I, I, I, P, P, I, P]),
     "tri_avgpool_viewmax_bwd": (I, [P, P, I, I, I, I, P, I, F, P]),

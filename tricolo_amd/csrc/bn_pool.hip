@@ -780,9 +780,95 @@ __global__ void maxpool2d_fwd_kernel(const T* __restrict__ x, int N, int H, int 
         if (arg) arg[i] = bi;
     }
 }
+// 16-bit storage, C % 8 == 0: one thread = one output position x EIGHT channels (16-byte loads of the nine taps, one 16-byte store of
+// the maxima, 8 bytes of the tap map); the 4-channel form above moves 8 bytes per load and ran at 3.3 TB/s on the stem's 100 MB tensor.
+// Same scan order and tie rule per channel.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2d_fwd8_kernel(const T* __restrict__ x, int N, int H, int W, int C8, T* __restrict__ out,
+                                                             uint2* __restrict__ arg, const float* __restrict__ scale, const float* __restrict__ shift) {
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    // One thread = POOL8_ROWS consecutive output rows of one (image, column, channel octet): output rows oh and oh + 1 share input row
+    // 2 oh + 1, which stays in registers (6 loads per output instead of 9, and no second fetch of the shared row by another workgroup /
+    // XCD: 152 MB of fabric reads per launch for the 100 MB tensor before).  (XCD-contiguous runs of workgroups - xcd_remap - with one
+    // output per thread: 41 -> 54 us, not kept.)
+    constexpr int G = 4;
+    const int Hg = (Ho + G - 1) / G;
+    const long total = (long)N * Hg * Wo * C8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C8);
+        long pos = i / C8;
+        const int ow = (int)(pos % Wo); long r = pos / Wo;
+        const int og = (int)(r % Hg); const int n = (int)(r / Hg);
+        float s8[8], b8[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s8[k] = 1.f; b8[k] = 0.f; }
+        if (scale) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { s8[k] = scale[c * 8 + k]; b8[k] = shift[c * 8 + k]; }
+        }
+        bool okw[3];
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) okw[kw] = (unsigned)(ow * 2 - 1 + kw) < (unsigned)W;
+        auto load_row = [&](int ih, uint4 (&d)[3]) {
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                d[kw] = make_uint4(0u, 0u, 0u, 0u);
+                if ((unsigned)ih < (unsigned)H && okw[kw]) d[kw] = *(const uint4*)(x + ((((long)n * H + ih) * W + ow * 2 - 1 + kw) * C8 + c) * 8);
+            }
+        };
+        uint4 row0[3], row1[3], row2[3];
+        const int oh0 = og * G;
+        load_row(oh0 * 2 - 1, row0);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int oh = oh0 + g;
+            if (oh >= Ho) break;
+            load_row(oh * 2, row1);
+            load_row(oh * 2 + 1, row2);
+            float best[8];
+            unsigned bi[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { best[k] = -INFINITY; bi[k] = 0u; }
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                if ((unsigned)(oh * 2 - 1 + kh) >= (unsigned)H) continue;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    if (!okw[kw]) continue;
+                    const uint4 q = kh == 0 ? row0[kw] : (kh == 1 ? row1[kw] : row2[kw]);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        float e = (float)((const T*)&q)[k];
+                        if (scale) e = fmaxf(__fmaf_rn(e, s8[k], b8[k]), 0.f);
+                        if (e > best[k]) { best[k] = e; bi[k] = (unsigned)(kh * 3 + kw); }
+                    }
+                }
+            }
+            uint4 o;
+            T* op = (T*)&o;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) op[k] = (T)best[k];
+            const long oi = (((long)n * Ho + oh) * Wo + ow) * C8 + c;
+            *(uint4*)(out + oi * 8) = o;
+            if (arg) arg[oi] = make_uint2(bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24), bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24));
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) row0[kw] = row2[kw];
+        }
+    }
+}
 // bn_scale / bn_shift (optional, [C]): pool relu(x * scale + shift) - the ResNet stem's BN + ReLU + max-pool in one pass
 extern "C" int tri_maxpool2d_fwd(const void* x, int N, int H, int W, int C, void* out, uint8_t* arg, const float* bn_scale,
                                  const float* bn_shift, int act_fmt, void* stream) {
+    static int pool8 = -1;                                         // A/B switch: TRICOLO_POOL8=0 keeps the 4-channel form
+    if (pool8 < 0) { const char* e = getenv("TRICOLO_POOL8"); pool8 = (e && e[0] == '0') ? 0 : 1; }
+    if (pool8 && act_fmt != TRI_FMT_F32 && C % 8 == 0) {
+        const long total8 = (long)N * (((H + 1) / 2 + 3) / 4) * ((W + 1) / 2) * (C / 8);   // (four output rows per thread)
+        if (act_fmt == TRI_FMT_F16)
+            maxpool2d_fwd8_kernel<f16_t><<<ew_grid(total8), 256, 0, (hipStream_t)stream>>>((const f16_t*)x, N, H, W, C / 8, (f16_t*)out, (uint2*)arg, bn_scale, bn_shift);
+        else
+            maxpool2d_fwd8_kernel<bf16_t><<<ew_grid(total8), 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, N, H, W, C / 8, (bf16_t*)out, (uint2*)arg, bn_scale, bn_shift);
+        return tri_check_launch("tri_maxpool2d_fwd");
+    }
     long total = (long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
     TRI_ACT_DISPATCH(act_fmt, maxpool2d_fwd_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)stream>>>((const T*)x, N, H, W, C / 4, (T*)out, (uchar4*)arg,
                                                                                                   (const float4*)bn_scale, (const float4*)bn_shift));
@@ -910,14 +996,19 @@ __device__ __forceinline__ void stem_route_2x2(const uchar4* __restrict__ arg, c
 template <typename T>
 __device__ __forceinline__ float4 rnd4(float4 v) { return make_float4(Act<T>::rnd(v.x), Act<T>::rnd(v.y), Act<T>::rnd(v.z), Act<T>::rnd(v.w)); }
 
-#define STEM_BLOCKS_PER_WG 64                                       // 2x2 blocks (256 positions) per workgroup, as bnb_rows of large tensors
+// 2x2 blocks (4 positions each) per workgroup: 64 as bnb_rows of large tensors; tuning aid TRICOLO_STEM_BLOCKS
+static int stem_blocks_per_wg() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("TRICOLO_STEM_BLOCKS"); v = (e && atoi(e) >= 32) ? atoi(e) : 64; }
+    return v;
+}
 // 16-bit storage, C % 8 == 0: one thread = one 2x2 block of positions x EIGHT channels - 16-byte loads of y and the pooled gradient,
 // 8-byte loads of the tap map (the 4-channel form below moves 8 / 4 bytes per load and ran at 2.1 TB/s on the stem's 100 MB tensor).
 // Same routing, rounding, mask and summation order per channel as the 4-channel form.
 template <typename T>
 __global__ __launch_bounds__(256) void stem_bwd_reduce8_kernel(const T* __restrict__ y, const uint8_t* __restrict__ arg, const T* __restrict__ dpool,
                                                                int N, int H, int W, int C, float* __restrict__ partial,
-                                                               const float* __restrict__ rs, const float* __restrict__ rb) {
+                                                               const float* __restrict__ rs, const float* __restrict__ rb, int STEM_BLOCKS_PER_WG) {
     extern __shared__ float sh[];                                  // [items_per_pass][C8][16]
     const int C8 = C >> 3, Ho = H >> 1, Wo = W >> 1;
     const int tpr = C8 < 256 ? C8 : 256, rpp = 256 / tpr;
@@ -1001,7 +1092,7 @@ __global__ __launch_bounds__(256) void stem_bwd_reduce8_kernel(const T* __restri
 template <typename T>
 __global__ __launch_bounds__(256) void stem_bwd_reduce_kernel(const T* __restrict__ y, const uchar4* __restrict__ arg, const T* __restrict__ dpool,
                                                               int N, int H, int W, int C, float* __restrict__ partial,
-                                                              const float4* __restrict__ rs, const float4* __restrict__ rb) {
+                                                              const float4* __restrict__ rs, const float4* __restrict__ rb, int STEM_BLOCKS_PER_WG) {
     extern __shared__ float sh[];                                  // [items_per_pass][C4][8]
     const int C4 = C >> 2, Ho = H >> 1, Wo = W >> 1;
     const int tpr = C4 < 256 ? C4 : 256, rpp = 256 / tpr;
@@ -1075,7 +1166,8 @@ __global__ void stem_bwd_apply_kernel(const T* __restrict__ y, const uchar4* __r
     }
 }
 extern "C" int tri_maxpool_bn_bwd_num_blocks(int N, int H, int W) {
-    return (int)(((long)N * (H / 2) * (W / 2) + STEM_BLOCKS_PER_WG - 1) / STEM_BLOCKS_PER_WG);
+    const int per = stem_blocks_per_wg();
+    return (int)(((long)N * (H / 2) * (W / 2) + per - 1) / per);
 }
 static int stem_args_ok(int H, int W, int C, const void* rs, const void* rb) {
     if (H % 2 || W % 2 || C % 4 || C / 4 > 256) { tri_set_error("tri_maxpool_bn_bwd: needs even H, W and C % 4 == 0, C <= 1024"); return 0; }
@@ -1093,17 +1185,137 @@ extern "C" int tri_maxpool_bn_bwd_reduce(const void* y, const uint8_t* arg, cons
         const size_t smem8 = (size_t)rpp8 * tpr8 * 16 * sizeof(float);
         if (act_fmt == TRI_FMT_F16)
             stem_bwd_reduce8_kernel<f16_t><<<nblk, 256, smem8, (hipStream_t)stream>>>((const f16_t*)y, arg, (const f16_t*)dpool, N, H, W, C, partial,
-                                                                                     relu_scale, relu_shift);
+                                                                                     relu_scale, relu_shift, stem_blocks_per_wg());
         else
             stem_bwd_reduce8_kernel<bf16_t><<<nblk, 256, smem8, (hipStream_t)stream>>>((const bf16_t*)y, arg, (const bf16_t*)dpool, N, H, W, C, partial,
-                                                                                      relu_scale, relu_shift);
+                                                                                      relu_scale, relu_shift, stem_blocks_per_wg());
         return tri_check_launch("tri_maxpool_bn_bwd_reduce");
     }
     const int C4 = C / 4, tpr = C4 < 256 ? C4 : 256, rpp = 256 / tpr;
     const size_t smem = (size_t)rpp * tpr * 8 * sizeof(float);
     TRI_ACT_DISPATCH(act_fmt, stem_bwd_reduce_kernel<T><<<nblk, 256, smem, (hipStream_t)stream>>>(
-        (const T*)y, (const uchar4*)arg, (const T*)dpool, N, H, W, C, partial, (const float4*)relu_scale, (const float4*)relu_shift));
+        (const T*)y, (const uchar4*)arg, (const T*)dpool, N, H, W, C, partial, (const float4*)relu_scale, (const float4*)relu_shift,
+        stem_blocks_per_wg()));
     return tri_check_launch("tri_maxpool_bn_bwd_reduce");
+}
+// ---- the same two sums from the POOLED tensors (round 4) -----------------------------------------------------------------------
+// g - the gradient of relu(bn(y)) - is the pooled gradient routed to each window's winning tap, so sum(g) and sum(g * y) are sums over
+// WINDOWS: sum_w dpool[w] [p[w] > 0] and sum_w dpool[w] [p[w] > 0] y[winner(w)], where p = maxpool(relu(bn(y))) is the tensor the next
+// layer kept anyway and, for an active window, y[winner] = (p - shift) / scale.  The pass then reads 2 x 25 MB of pooled-resolution
+// tensors instead of y (100 MB) + tap map + dpool: 45 -> ~12 us at the bench shape.  A window whose recovered y would be ill-conditioned
+// (|p| > 64 |gamma|: a channel with gamma ~ 0 and a large shift; never at initialisation) reads the winner's stored y through the tap
+// map instead, so every channel keeps the accuracy of the stored activations.  The routed gradient is no longer rounded to the
+// storage type per position (the reference's max-pool backward has no such rounding either).
+#define STEM_POOLED_PER_WG 256                                      // pooled positions per workgroup
+template <typename T>
+__global__ __launch_bounds__(256) void stem_bwd_reduce_pooled_kernel(const T* __restrict__ pooled, const T* __restrict__ dpool, const T* __restrict__ y,
+                                                                     const uint8_t* __restrict__ arg, int N, int H, int W, int C,
+                                                                     float* __restrict__ partial, const float* __restrict__ rs,
+                                                                     const float* __restrict__ rb, const float* __restrict__ gamma) {
+    extern __shared__ float sh[];                                  // [rows per pass][C8][16]
+    const int C8 = C >> 3, Ho = H >> 1, Wo = W >> 1;
+    const int tpr = C8 < 256 ? C8 : 256, rpp = 256 / tpr;
+    const int tc = threadIdx.x % tpr, tr = threadIdx.x / tpr;
+    const long nb = (long)N * Ho * Wo;
+    const long r0 = (long)blockIdx.x * STEM_POOLED_PER_WG, r1 = r0 + STEM_POOLED_PER_WG < nb ? r0 + STEM_POOLED_PER_WG : nb;
+    float sg[8], sgy[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sg[k] = 0.f; sgy[k] = 0.f; }
+    if (tc < C8 && tr < rpp) {
+        float s8[8], inv8[8], b8[8], lim8[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float s_ = rs[tc * 8 + k];
+            b8[k] = rb[tc * 8 + k];
+            s8[k] = s_ != 0.f ? s_ : 1.f;
+            inv8[k] = 1.0f / s8[k];
+            lim8[k] = s_ != 0.f ? 64.f * fabsf(gamma[tc * 8 + k]) : -1.f;        // |p| above this: the stored y
+        }
+        // four rows per pass, all eight loads issued before the first is used; branch-free per channel (the quotient by one
+        // reciprocal + one residual correction: exact whenever (p - shift) / scale is representable), ONE rare branch per row for
+        // the windows that must read the stored y
+        constexpr int U = 4;
+        for (long rb0 = r0 + tr; rb0 < r1; rb0 += (long)U * rpp) {
+            uint4 prs[U], drs[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const long r = rb0 + (long)u * rpp;
+                prs[u] = make_uint4(0u, 0u, 0u, 0u); drs[u] = prs[u];         // (p = 0: an inactive window)
+                if (r < r1) { prs[u] = *(const uint4*)(pooled + r * C + tc * 8); drs[u] = *(const uint4*)(dpool + r * C + tc * 8); }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint4 pr = prs[u], dr = drs[u];
+                float yv8[8], d8[8];
+                bool far = false;
+#pragma unroll
+                for (int ch = 0; ch < 8; ++ch) {
+                    const float pv = (float)((const T*)&pr)[ch];
+                    const float num = pv - b8[ch];
+                    float qv = num * inv8[ch];
+                    qv = __fmaf_rn(__fmaf_rn(-qv, s8[ch], num), inv8[ch], qv);
+                    yv8[ch] = qv;
+                    d8[ch] = pv > 0.f ? (float)((const T*)&dr)[ch] : 0.f;
+                    far = far || (pv > 0.f && pv > lim8[ch]);
+                }
+                if (far) {                                         // (rare) the winners' stored activations
+                    const long r = rb0 + (long)u * rpp;
+                    const int ow = (int)(r % Wo); const long q = r / Wo;
+                    const int oh = (int)(q % Ho), n = (int)(q / Ho);
+#pragma unroll
+                    for (int ch = 0; ch < 8; ++ch) {
+                        const float pv = (float)((const T*)&pr)[ch];
+                        if (pv > 0.f && pv > lim8[ch]) {
+                            const int tap = arg[r * C + tc * 8 + ch];
+                            yv8[ch] = (float)y[(((long)n * H + 2 * oh - 1 + tap / 3) * W + 2 * ow - 1 + tap % 3) * C + tc * 8 + ch];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int ch = 0; ch < 8; ++ch) { sg[ch] += d8[ch]; sgy[ch] += d8[ch] * yv8[ch]; }
+            }
+        }
+        float* q = sh + ((size_t)tr * tpr + tc) * 16;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { q[k] = sg[k]; q[8 + k] = sgy[k]; }
+    }
+    __syncthreads();
+    if (tr == 0 && tc < C8) {
+        float a[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a[k] = 0.f;
+        for (int rr = 0; rr < rpp; ++rr) {
+            const float* q = sh + ((size_t)rr * tpr + tc) * 16;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) a[k] += q[k];
+        }
+        float* o = partial + (size_t)blockIdx.x * 2 * C;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { o[tc * 8 + k] = a[k]; o[C + tc * 8 + k] = a[8 + k]; }
+    }
+}
+extern "C" int tri_maxpool_bn_bwd_pooled_num_blocks(int N, int H, int W) {
+    return (int)(((long)N * (H / 2) * (W / 2) + STEM_POOLED_PER_WG - 1) / STEM_POOLED_PER_WG);
+}
+// partial [tri_maxpool_bn_bwd_pooled_num_blocks][2][C]; 16-bit storage, C % 8 == 0, C / 8 a divisor of 256 (else TRI_ERR_UNSUPPORTED:
+// use tri_maxpool_bn_bwd_reduce).  pooled = the forward's max-pool output, gamma = the BatchNorm weight.
+extern "C" int tri_maxpool_bn_bwd_reduce_pooled(const void* pooled, const void* dpool, const void* y, const uint8_t* arg, int N, int H, int W, int C,
+                                                float* partial, const float* relu_scale, const float* relu_shift, const float* gamma,
+                                                int act_fmt, void* stream) {
+    if (!stem_args_ok(H, W, C, relu_scale, relu_shift)) return TRI_ERR_ARG;
+    if (act_fmt == TRI_FMT_F32 || C % 8 || 256 % (C / 8) || !gamma || !arg || !y) {
+        tri_set_error("tri_maxpool_bn_bwd_reduce_pooled: 16-bit storage with C / 8 a divisor of 256 only");
+        return TRI_ERR_UNSUPPORTED;
+    }
+    const int nblk = tri_maxpool_bn_bwd_pooled_num_blocks(N, H, W);
+    const size_t smem = (size_t)256 * 16 * sizeof(float);
+    if (act_fmt == TRI_FMT_F16)
+        stem_bwd_reduce_pooled_kernel<f16_t><<<nblk, 256, smem, (hipStream_t)stream>>>((const f16_t*)pooled, (const f16_t*)dpool, (const f16_t*)y, arg, N, H, W,
+                                                                                      C, partial, relu_scale, relu_shift, gamma);
+    else
+        stem_bwd_reduce_pooled_kernel<bf16_t><<<nblk, 256, smem, (hipStream_t)stream>>>((const bf16_t*)pooled, (const bf16_t*)dpool, (const bf16_t*)y, arg, N, H,
+                                                                                       W, C, partial, relu_scale, relu_shift, gamma);
+    return tri_check_launch("tri_maxpool_bn_bwd_reduce_pooled");
 }
 extern "C" int tri_maxpool_bn_bwd_apply(const void* y, const uint8_t* arg, const void* dpool, int N, int H, int W, int C, const float* c1,
                                         const float* c2, const float* c3, const float* relu_scale, const float* relu_shift, void* dy,

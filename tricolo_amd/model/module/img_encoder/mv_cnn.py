@@ -343,13 +343,15 @@ class MVCNNEncoder(TriModule):
         if y.shape[2] % 2 == 0 and y.shape[3] % 2 == 0 and stem_mode == "2":
             # ... and the BatchNorm-backward apply pass inside the weight-gradient kernel's staging: the stem's dy is never stored
             gr[self.net_1[0].weight], gr[self.net_1[1].weight], gr[self.net_1[1].bias] = ops.maxpool_bn_bwd_wgrad(
-                x0, y, parg, dout, co, self.net_1[1].weight, g0, self.net_1[0].weight, prec, out_scale=ugs, batch=batch)
+                x0, y, parg, dout, co, self.net_1[1].weight, g0, self.net_1[0].weight, prec, out_scale=ugs, batch=batch,
+                pooled=saved["blocks"][0][0])                      # (the max-pool output = the first block's saved input)
             if own and batch is not None:
                 batch.flush()
             return [gr[p] for p in self._lower_params()]
         if y.shape[2] % 2 == 0 and y.shape[3] % 2 == 0 and stem_mode != "0":
             # BatchNorm backward straight from the pooled gradient and the winning-tap map: no max-pool backward pass
-            dy, gr[self.net_1[1].weight], gr[self.net_1[1].bias] = ops.maxpool_bn_bwd(y, parg, dout, co, self.net_1[1].weight, out_scale=ugs)
+            dy, gr[self.net_1[1].weight], gr[self.net_1[1].bias] = ops.maxpool_bn_bwd(y, parg, dout, co, self.net_1[1].weight, out_scale=ugs,
+                                                                                      pooled=saved["blocks"][0][0])
         else:
             dzs = ops.maxpool2d_bwd(parg, dout, tuple(y.shape))
             dy, gr[self.net_1[1].weight], gr[self.net_1[1].bias] = ops.bn_bwd(y, dzs, co, self.net_1[1].weight, count_host=g0.M, relu=True,

@@ -805,15 +805,34 @@ def maxpool2d_fwd(x, want_arg=True, bn: BNCoeffs = None):
     return out, arg
 
 
-def maxpool_bn_bwd(y, arg, dpool, co: "BNCoeffs", gamma, out_scale: float = 1.0):
-    """Backward of relu(bn(y)) -> MaxPool2d(3, 2, 1) in the two BatchNorm passes (no max-pool backward pass, no 4x-sized gradient
-    tensor): (dy, dgamma, dbeta).  y [N,1,H,W,C], arg / dpool [N,1,H/2,W/2,C]; H, W even."""
+_STEM_POOLED = os.environ.get("TRICOLO_STEM_POOLED", "1") != "0"       # A/B switch: stem BatchNorm-backward sums from y + tap map (0)
+
+
+def _maxpool_bn_bwd_sums(y, arg, dpool, co: "BNCoeffs", gamma, pooled):
+    """-> (partial [blocks, 2, C], blocks): sums of g and g * y over the stem's conv output, g = gradient of relu(bn(y)) in front of
+    the max-pool.  With the forward's pooled output at hand (16-bit storage) the sums are taken over the pooled-resolution tensors."""
     N, _, H, W, C = y.shape
-    assert dpool.dtype == y.dtype and H % 2 == 0 and W % 2 == 0
+    if pooled is not None and _STEM_POOLED and y.dtype != torch.float32 and C % 8 == 0 and 256 % (C // 8) == 0:
+        assert pooled.dtype == y.dtype and pooled.numel() == dpool.numel()
+        nblk = lib().tri_maxpool_bn_bwd_pooled_num_blocks(N, H, W)
+        partial = torch.empty((nblk, 2, C), dtype=torch.float32, device=y.device)
+        check(lib().tri_maxpool_bn_bwd_reduce_pooled(ptr(_act(pooled)), ptr(_act(dpool)), ptr(_act(y)), ptr(arg), N, H, W, C, ptr(partial),
+                                                     ptr(co.scale), ptr(co.shift), ptr(_f32(gamma.detach())), _abf(y), stream()),
+              "tri_maxpool_bn_bwd_reduce_pooled")
+        return partial, nblk
     nblk = lib().tri_maxpool_bn_bwd_num_blocks(N, H, W)
     partial = torch.empty((nblk, 2, C), dtype=torch.float32, device=y.device)
     check(lib().tri_maxpool_bn_bwd_reduce(ptr(_act(y)), ptr(arg), ptr(_act(dpool)), N, H, W, C, ptr(partial), ptr(co.scale), ptr(co.shift),
                                           _abf(y), stream()), "tri_maxpool_bn_bwd_reduce")
+    return partial, nblk
+
+
+def maxpool_bn_bwd(y, arg, dpool, co: "BNCoeffs", gamma, out_scale: float = 1.0, pooled=None):
+    """Backward of relu(bn(y)) -> MaxPool2d(3, 2, 1) in the two BatchNorm passes (no max-pool backward pass, no 4x-sized gradient
+    tensor): (dy, dgamma, dbeta).  y [N,1,H,W,C], arg / dpool [N,1,H/2,W/2,C]; H, W even.  pooled: the forward's max-pool output."""
+    N, _, H, W, C = y.shape
+    assert dpool.dtype == y.dtype and H % 2 == 0 and W % 2 == 0
+    partial, nblk = _maxpool_bn_bwd_sums(y, arg, dpool, co, gamma, pooled)
     buf = _bn_bwd_finalize(partial, nblk, C, None, N * H * W, gamma, co, out_scale)
     dy = torch.empty_like(y)
     check(lib().tri_maxpool_bn_bwd_apply(ptr(y), ptr(arg), ptr(dpool), N, H, W, C, ptr(buf[2]), ptr(buf[3]), ptr(buf[4]), ptr(co.scale),
@@ -821,7 +840,8 @@ def maxpool_bn_bwd(y, arg, dpool, co: "BNCoeffs", gamma, out_scale: float = 1.0)
     return dy, buf[0], buf[1]
 
 
-def maxpool_bn_bwd_wgrad(x0, y, arg, dpool, co: "BNCoeffs", gamma, g: "ConvGeom", like, precision: str, out_scale: float = 1.0, batch=None):
+def maxpool_bn_bwd_wgrad(x0, y, arg, dpool, co: "BNCoeffs", gamma, g: "ConvGeom", like, precision: str, out_scale: float = 1.0, batch=None,
+                         pooled=None):
     """Stem backward in three launches: (dw, dgamma, dbeta) of conv -> BN -> ReLU -> MaxPool2d(3, 2, 1) (mv_cnn.py:44).  As maxpool_bn_bwd,
     but the apply pass is folded into the weight-gradient kernel's operand staging (tri_conv_stem_wgrad_bn): the stem has no data
     gradient, so the gradient w.r.t. the conv output - 100 MB written and re-read at the bench shape - is never stored.  Falls back to
@@ -829,12 +849,9 @@ def maxpool_bn_bwd_wgrad(x0, y, arg, dpool, co: "BNCoeffs", gamma, g: "ConvGeom"
     N, _, H, W, C = y.shape
     h16 = y.dtype != torch.float32
     if not (h16 and C == 64 and H % 2 == 0 and W % 2 == 0 and dpool.dtype == y.dtype and _sync_world() == 1):
-        dy, dgamma, dbeta = maxpool_bn_bwd(y, arg, dpool, co, gamma, out_scale=out_scale)
+        dy, dgamma, dbeta = maxpool_bn_bwd(y, arg, dpool, co, gamma, out_scale=out_scale, pooled=pooled)
         return conv_wgrad(x0, dy, g, like, precision, out_scale=out_scale, batch=batch), dgamma, dbeta
-    nblk = lib().tri_maxpool_bn_bwd_num_blocks(N, H, W)
-    partial = torch.empty((nblk, 2, C), dtype=torch.float32, device=y.device)
-    check(lib().tri_maxpool_bn_bwd_reduce(ptr(_act(y)), ptr(arg), ptr(_act(dpool)), N, H, W, C, ptr(partial), ptr(co.scale), ptr(co.shift),
-                                          _abf(y), stream()), "tri_maxpool_bn_bwd_reduce")
+    partial, nblk = _maxpool_bn_bwd_sums(y, arg, dpool, co, gamma, pooled)
     buf = _bn_bwd_finalize(partial, nblk, C, None, N * H * W, gamma, co, out_scale)
     dw = torch.empty_like(like)
     mark = (batch.ci, batch.off) if batch is not None else None   # the arena cursor: an unsupported geometry hands its slab back
