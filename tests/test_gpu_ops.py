@@ -867,6 +867,11 @@ BF16_CASES = [c for c in CONV_CASES if c[0] in ("vox_l0", "vox_l1", "vox_l3", "s
     # 192-position tiles of conv_halo_rows_kernel (planned where they save a round of workgroups: h_320 above - 216 tiles with a partial
     # last one instead of 320 - and layer3 of the bench shape: 256 tiles instead of 384, four channel chunks)
     ("h_tm3", 192, (1, 8, 8), 256, 256, (1, 3, 3), 1, (0, 1, 1), "torch"),
+    # conv_pw_kernel (1x1 / 2 shortcut convolutions; c1x1s2 above is the 64 -> 128 one): 128 -> 256 with a partial last row tile, 256 -> 512
+    # (data gradient: K = 512, four rounds of activation fragments), 64-wide output-channel tiles and the 128-wide ones of a launch that fills the GPU
+    ("pw_256", 7, (1, 16, 16), 128, 256, (1, 1, 1), 2, (0, 0, 0), "torch"),
+    ("pw_512", 5, (1, 8, 8), 256, 512, (1, 1, 1), 2, (0, 0, 0), "torch"),
+    ("pw_wide", 130, (1, 32, 32), 64, 128, (1, 1, 1), 2, (0, 0, 0), "torch"),
     # conv_stem_kernel (4 stored input channels, stride 2, 64 output channels): stem7x7 above (32 x 32 -> 16 x 16, one tile per
     # image) and: several tiles per image with a partial last one (OH = 24, TH = 8), 3x3 and 5x5 kernels, a persistent workgroup
     # that walks many tiles (more tiles than CUs), 112-wide output rows (7 position tiles per row, TH = 2)
@@ -948,6 +953,24 @@ def test_conv_16bit_storage_integer_exact(case, store, prec):
             finally:
                 del os.environ["TRICOLO_S2D_TY"]
             assert torch.equal(dx3.cpu(), cl3(xr.grad).to(store)) and torch.equal(dx4.cpu(), (cl3(xr.grad) + base).to(store))
+    if case[5] == (1, 1, 1) and case[6] == 2:
+        # conv_pw_kernel, both directions; BatchNorm records of the forward: one per 128-row tile
+        assert (g.kernel_family[(False, 2)] & 255) == 12 and (g.kernel_family[(True, 2)] & 255) == 12
+        out2, stats = ops.conv_fwd(xcl.to(DEV).to(store), g, packed, want_stats=True)
+        assert torch.equal(out2.cpu(), ref.to(store)) and stats.shape[0] == g.num_mtiles[2] == (ref.numel() // case[4] + 127) // 128
+        exact = ref.to(store).double().reshape(-1, case[4])
+        st = stats.cpu().double().sum(0)
+        np.testing.assert_allclose(st[0].numpy(), exact.sum(0).numpy(), rtol=1e-6, atol=1e-2)
+        np.testing.assert_allclose(st[1].numpy(), (exact ** 2).sum(0).numpy(), rtol=1e-6, atol=1e-2)
+        # the data gradient writes the whole dense tensor (zeros at the pixels the stride skips) over whatever was there
+        tp = ops.pack_weight(wp.to(DEV), g, prec, transposed=True)
+        dirty = torch.full(tuple(cl3(xr.grad).shape), 7.0).to(DEV).to(store)
+        dx2 = ops.conv_dgrad(cl3(dy).to(DEV).to(store), g, tp, out=dirty)
+        assert torch.equal(dx2.cpu(), cl3(xr.grad).to(store))
+        # accumulate form (not the kernel's): conv_dma_kernel takes it
+        base = ints(tuple(cl3(xr.grad).shape), -5, 5, 59)
+        dx3 = ops.conv_dgrad(cl3(dy).to(DEV).to(store), g, tp, out=base.clone().to(DEV).to(store), accumulate=True)
+        assert torch.equal(dx3.cpu(), (cl3(xr.grad) + base).to(store))
     if case[0].startswith("stem"):
         # one BatchNorm record per persistent workgroup of conv_stem_kernel: their sum is the whole tensor's column sum
         assert (g.kernel_family[(False, 2)] & 255) == 4

@@ -1868,6 +1868,7 @@ struct ConvPlan {
     int c64_grid;
     int s2f, s2f_grid;    // 1: conv_s2f_kernel (conv_c64.hip: forward of the 64 -> 128 channel 3x3 / 2 layer); records = s2f_grid
     int s2d;              // 1: conv_s2d_kernel (conv_c64.hip: data gradient of a 64 -> 128 channel 3x3 / 2 layer, 16-bit storage)
+    int pw, pw_tr;        // 1: conv_pw_kernel (conv_pw.hip: 1x1 / 2 shortcut convolution), pw_tr: the plan is the data gradient's; records = row tiles
     int dma;              // 1: LDS-DMA kernel (16-bit activation storage, Cin % 64 == 0), 64-wide k-steps
     int nunits;           // k-steps (32 wide, or 64 wide for the DMA kernel)
     int ksplit, per_split;
@@ -2033,6 +2034,15 @@ static ConvPlan conv_make_plan(int B, int ID, int IH, int IW, int cin, int OD, i
         if (split_mode == 2 && !stem_disabled() && ID == 1 && OD == 1 &&
             stem_geometry(B, IH, IW, cin, OH, OW, cout, KD, KH, KW, stride, pd, ph, pw, &sgm)) {
             pl.stem = 1; pl.stem_grid = sgm.grid; pl.bn = 64; pl.nunits = KH; pl.ksplit = 1; pl.per_split = KH;
+            return pl;
+        }
+    }
+    {
+        TriPwGeom pg;
+        if (pl.dma && split_mode == 2 && !row_list && tri_internal_pw_geometry(B, ID, IH, IW, cin, OD, OH, OW, cout, KD, KH, KW, stride, pd, ph, pw, &pg)) {
+            // 1x1 / 2 shortcut convolution: conv_pw_kernel; a call it does not take (row mask / bias / activation / accumulate) runs
+            // conv_dma_kernel without split-K (the fields below are its plan; same record count: one per 128-row tile)
+            pl.pw = 1; pl.pw_tr = pg.transposed; pl.bn = pg.bn; pl.nunits = kpad / 64; pl.ksplit = 1; pl.per_split = pl.nunits;
             return pl;
         }
     }
@@ -2361,6 +2371,11 @@ static int conv_dispatch(ConvArgs& a, int act_fmt, void* workspace, size_t works
         a.row_pos = nullptr;
         return act_fmt == TRI_FMT_F16 ? launch_halo<2, f16_t>(a, pl, stream) : launch_halo<2, bf16_t>(a, pl, stream);
     }
+    if (pl.pw && pl.pw_tr == (a.transposed ? 1 : 0) && !a.row_mask && !a.row_count && !a.bias && a.act == 0 && !a.accumulate) {
+        TriPwGeom pg;
+        tri_internal_pw_geometry(a.B, a.ID, a.IH, a.IW, a.Cin, a.OD, a.OH, a.OW, a.Cout, a.KD, a.KH, a.KW, a.stride, a.pd, a.ph, a.pw, &pg);
+        return tri_internal_pw_launch(pg, a.B, a.in, a.w_hi, a.Cin, a.Cout, a.Kpad, a.out, a.stats, a.transposed ? 1 : 0, act_fmt, stream);
+    }
     if (pl.dma) return act_fmt == TRI_FMT_F16 ? launch_dma_any<f16_t>(a, pl.bn, stream) : launch_dma_any<bf16_t>(a, pl.bn, stream);
 #define TRI_CONV(BN_)                                                                                     \
     (act_fmt == TRI_FMT_F16 ? launch_conv<BN_, 1, f16_t>(a, stream)                                       \
@@ -2404,6 +2419,7 @@ extern "C" int tri_conv_kernel_family(const TriConvDesc* d, int transposed, int 
     if (pl.s2d && transposed) return 10 | (64 << 8);
     if (pl.s2f && !transposed) return 11 | (128 << 8);
     if (pl.halo) return (pl.h_v5 ? 5 : 3) | (pl.halo << 8);
+    if (pl.pw) return 12 | (pl.bn << 8);
     return (pl.dma ? 2 : 0) | (pl.bn << 8) | ((pl.ksplit > 1 || (pl.dma && tri_conv_kpad(d->KD * d->KH * d->KW, transposed ? d->Cout : d->Cin) / 64 > 256)) ? (1 << 16) : 0);
 }
 

@@ -45,3 +45,11 @@ int tri_internal_s2f_launch(const TriC64Geom& g, int B, int OH, const void* in, 
 struct TriConvBnSums;                                                         // include/tricolo_hip.h
 int tri_internal_c64_launch(const TriC64Geom& g, int B, int H, const void* in, const void* w, void* out, float* stats, int transposed,
                             int accumulate, int act_fmt, const TriConvBnSums* bs, hipStream_t stream);
+
+// the 1x1 / stride-2 / pad-0 shortcut convolutions (64 | cin <= 512, 64 | cout, 16-bit storage): conv_pw_kernel (conv_pw.hip), forward
+// (BatchNorm records: one per 128-row tile) and data gradient (writes the dense dIn tensor, zeros included; no accumulate form)
+struct TriPwGeom { int bn, mtiles, GH, GW, transposed; };
+bool tri_internal_pw_geometry(int B, int ID, int IH, int IW, int cin, int OD, int OH, int OW, int cout, int KD, int KH, int KW, int stride,
+                              int pd, int ph, int pw, TriPwGeom* g);
+int tri_internal_pw_launch(const TriPwGeom& g, int B, const void* in, const void* w, int K, int N, int Kpad, void* out, float* stats, int transposed,
+                           int act_fmt, hipStream_t stream);

@@ -116,6 +116,9 @@ class TriCoLoNet(TriModule):
         if self._side_streams is None:
             self._side_streams = (torch.cuda.Stream(), torch.cuda.Stream())
         s_text, s_vox = self._side_streams
+        # (round 4: both side towers on ONE stream, text first, was measured too: the image forward ends at 0.84 ms instead of 0.94 -
+        #  nothing runs beside its first half - but the side stream's kernels queue behind the image tower's down-sample branch until
+        #  ~0.65 ms, the voxel forward ends at 1.17 ms and the step takes 2.87 ms against 2.64)
         # The heaviest tower runs on the caller's stream: the image tower, or - Bi(V) - the voxel tower; the others on side streams
         # forked at the start of the step.  ISSUE order matters under HIP-graph replay: the executor folds capture streams onto a
         # few internal streams and a branch issued later queues behind branches issued earlier - including another tower's side

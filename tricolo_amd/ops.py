@@ -142,6 +142,8 @@ def _igemm_symbol(g, transposed, split, t):
         return f"conv_s2d_kernel<{_TNAME[t.dtype]}>"
     if fam == 11:
         return f"conv_s2f_kernel<{_TNAME[t.dtype]}>"
+    if fam == 12:
+        return f"conv_pw_kernel<{bn}, {_TNAME[t.dtype]}>"                # (forward and data gradient under one name)
     if fam == 4:
         return f"conv_stem_kernel<{g.kernel[1]}, {_TNAME[t.dtype]}>"
     if fam == 5:
