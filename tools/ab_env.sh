@@ -1,4 +1,6 @@
-# usage: bash tools/.job_ab.sh <tag> "<ENV_A>" "<ENV_B>" [bench args...]   (alternating A/B pairs in one box)
+#!/bin/bash
+# Alternating A/B pairs of bench.py under two environments IN ONE BOX (boxes and processes differ by +-1.5 %: compare within a call only).
+# usage: bash tools/ab_env.sh <tag> "<ENV_A>" "<ENV_B>" [bench args...]   (alternating A/B pairs in one box)
 tag=$1; A=$2; B=$3; shift 3
 mkdir -p gpurun_out/ab
 out=gpurun_out/ab/$tag.txt; : > $out

@@ -1,4 +1,6 @@
-# usage: bash tools/.job_kt.sh <tag> <grep pattern> "<ENV_A>" "<ENV_B>" ...   (kernel_times.py under several environments)
+#!/bin/bash
+# tools/kernel_times.py (unprofiled per-entry-point times of eager steps) under several environments, filtered by a pattern.
+# usage: bash tools/kernel_times_env.sh <tag> <grep pattern> "<ENV_A>" "<ENV_B>" ...   (kernel_times.py under several environments)
 tag=$1; pat=$2; shift 2
 mkdir -p gpurun_out/kt
 out=gpurun_out/kt/$tag.txt; : > $out

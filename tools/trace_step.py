@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """One training step out of a rocprofv3 --kernel-trace CSV: every kernel of the LAST complete replayed step in start order with its
 start offset, duration, queue and the idle gap of its queue in front of it (the critical chain of the step reads off this list).
-    python tools/trace_step.py <dir with *_kernel_trace.csv> [--step -2]"""
+    rocprofv3 --kernel-trace --output-format csv -d <dir> -- python3 bench.py --modes "" --no-cpu-baseline --steps 10 --warmup 3 --windows 1
+    python tools/trace_step.py <dir with *_kernel_trace.csv> [--step -2 | --shortest]   (--shortest: a replayed step, not an eager warm-up one)"""
 import csv
 import glob
 import os
