@@ -23,17 +23,6 @@
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 
-// The per-step barrier orders the LDS image of h (or of the gate gradients) only.  __syncthreads() also waits for vmcnt(0): every one of
-// the 96 steps then waited for the input projections it had just prefetched for three steps later AND for its own global stores (h, the
-// saved gates, the gate gradients) to complete - a memory round trip per step, 1.15 us (forward) / 2.25 us (backward) against ~0.4 us of
-// MFMAs and gate math.  The loads are consumed by the lane that issued them (the compiler's counted vmcnt wait in front of the use),
-// nobody in the kernel reads the stores.
-__device__ __forceinline__ void gru_lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-
 // LDS image of a [16][ncols] bf16 matrix: 16-byte chunk c of row r stored at chunk (c ^ (r & 15))
 __device__ __forceinline__ int himg_off(int row, int chunk, int row_bytes) { return row * row_bytes + ((chunk ^ (row & 15)) << 4); }
 
@@ -148,7 +137,7 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
             if (NSPLIT == 2) *(E*)(hn_buf + 16 * 256 + off) = (E)(hnew - (float)hh);
         }
         cur ^= 1;
-        gru_lds_barrier();
+        __syncthreads();
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -266,7 +255,7 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
                 if (NSPLIT == 2) *(E*)(gb + 16 * 768 + off) = (E)(vals[g] - (float)hh);
             }
         }
-        gru_lds_barrier();
+        __syncthreads();
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 12; ++ks) {
