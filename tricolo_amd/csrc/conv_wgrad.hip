@@ -627,6 +627,7 @@ struct StemWgradArgs {
     const void* in; const void* dout; float* slab;
     int B, IH, IW, OH, OW, KW, ph, pw;
     int TH, slab_rows, row_bytes, groups, tiles_per_img, ntiles, h_abl;
+    int unpiped;                                                   // A/B switch TRICOLO_STEM_WGRAD_PIPE=0: the unpipelined tile loop
     // BNF instantiation (tri_conv_stem_wgrad_bn): dout is not read - the gradient w.r.t. the conv output is formed while the tile is
     // staged, from the conv output y, the max-pool's winning-tap map / pooled gradient and the BatchNorm-backward coefficients
     const void* y; const uint8_t* arg; const void* dpool;
@@ -638,11 +639,11 @@ struct StemWgradArgs {
 // position (2 bh + k / 2, 2 bw + k % 2).  The block's pixels
 // can only have won in the four windows (bh..bh+1, bw..bw+1): 4 + 8 loads, all issued before the first use.
 // co = [5][64] floats in LDS: c1, c2, c3, relu scale, relu shift.
-template <typename AT, typename STORE>
-__device__ __forceinline__ void stem_dy_block(const StemWgradArgs& p, int img, int bh, int bw, int piece, const float* co, STORE&& store) {
+__device__ __forceinline__ bool stem_wgrad_unpiped(const StemWgradArgs& p) { return p.unpiped != 0; }
+template <typename AT>
+__device__ __forceinline__ void stem_dy_load(const StemWgradArgs& p, int img, int bh, int bw, int piece, uint4 (&yr)[4], uint4 (&dr)[2][2],
+                                             uint2 (&ar)[2][2]) {
     const int Ho = p.OH >> 1, Wo = p.OW >> 1;
-    uint4 yr[4], dr[2][2];
-    uint2 ar[2][2];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         yr[k] = *(const uint4*)((const AT*)p.y + (((size_t)img * p.OH + 2 * bh + (k >> 1)) * p.OW + 2 * bw + (k & 1)) * 64 + piece * 8);
@@ -658,6 +659,10 @@ __device__ __forceinline__ void stem_dy_block(const StemWgradArgs& p, int img, i
                 dr[u][v] = *(const uint4*)((const AT*)p.dpool + o);
             }
         }
+}
+template <typename AT, typename STORE>
+__device__ __forceinline__ void stem_dy_form(const uint4 (&yr)[4], const uint4 (&dr)[2][2], const uint2 (&ar)[2][2], int piece, const float* co,
+                                             STORE&& store) {
     // two halves of four channels, each stored before the next is formed (all eight at once do not fit the kernel's registers)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -696,6 +701,13 @@ __device__ __forceinline__ void stem_dy_block(const StemWgradArgs& p, int img, i
         for (int k = 0; k < 4; ++k) store(k, h, *(const uint2*)res[k]);
         __builtin_amdgcn_sched_barrier(0);
     }
+}
+template <typename AT, typename STORE>
+__device__ __forceinline__ void stem_dy_block(const StemWgradArgs& p, int img, int bh, int bw, int piece, const float* co, STORE&& store) {
+    uint4 yr[4], dr[2][2];
+    uint2 ar[2][2];
+    stem_dy_load<AT>(p, img, bh, bw, piece, yr, dr, ar);
+    stem_dy_form<AT>(yr, dr, ar, piece, co, store);
 }
 #define STEM_WG_MAXG 8                                             // 32-position groups per tile (2 rows of <= 128 outputs)
 template <int KH, typename AT, bool BNF = false>
@@ -749,6 +761,73 @@ __global__ __launch_bounds__(256, 2) void conv_stem_wgrad_kernel(const StemWgrad
         for (int ct = 0; ct < 4; ++ct) acc[j][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // (round 4: XCD-contiguous runs of tiles - xcd_remap - would keep the input rows neighbouring tiles share in one L2; measured 74 -> 78 us)
+    const bool piped = BNF && (OW >> 1) * 8 <= 256 && !stem_wgrad_unpiped(p);
+    if (BNF && piped) {
+        // BNF with at most one (2x2 block, channel octet) item per thread (output rows of <= 64 positions): the NEXT tile's y / tap map / pooled
+        // gradient / input pixels are requested before this tile's MFMAs and formed into dy after them - the tile loop below waits out a
+        // memory round trip per tile with only the other resident workgroup to cover it.  LDS-only barriers: __syncthreads() would wait for
+        // the loads just issued.
+        const int nitem = (OW >> 1) * 8;
+        const int piece = t & 7, bw = t >> 3;
+        uint4 pyr[4], pdr[2][2], px[XLD];
+        uint2 par[2][2];
+        auto prefetch = [&](int tile_) {
+            const int img_ = tile_ / p.tiles_per_img, oh0_ = (tile_ - img_ * p.tiles_per_img) * p.TH;
+            if (t < nitem) stem_dy_load<AT>(p, img_, oh0_ >> 1, bw, piece, pyr, pdr, par);
+            const int iy0 = oh0_ * 2 - p.ph;
+            const char* xsrc = (const char*)p.in + ((size_t)img_ * IH + iy0) * IW * 8;
+#pragma unroll
+            for (int u = 0; u < XLD; ++u) {
+                px[u] = make_uint4(0u, 0u, 0u, 0u);
+                if (x_row[u] >= 0 && (unsigned)(iy0 + x_row[u]) < (unsigned)IH) px[u] = *(const uint4*)(xsrc + x_goff[u]);
+            }
+        };
+        auto lds_barrier = [&]() {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        };
+        int tile = blockIdx.x;
+        if (tile < p.ntiles) prefetch(tile);
+        for (; tile < p.ntiles; tile += gridDim.x) {
+            lds_barrier();                                         // the previous tile's reads (and the zero fill / coefficients) are done
+            if (t < nitem)
+                stem_dy_form<AT>(pyr, pdr, par, piece, co, [&](int k, int h, uint2 v) {
+                    const int row = (k >> 1) * OW + 2 * bw + (k & 1);
+                    *(uint2*)(ytile + (row >> 5) * 4096 + nat_off<128>(row & 31, piece * 16 + h * 8)) = v;
+                });
+#pragma unroll
+            for (int u = 0; u < XLD; ++u)
+                if (x_row[u] >= 0) {
+                    *(uint2*)(slab + x_loff[u]) = make_uint2(px[u].x, px[u].y);
+                    *(uint2*)(slab + x_loff[u] + 8) = make_uint2(px[u].z, px[u].w);
+                }
+            if (tile + (int)gridDim.x < p.ntiles) prefetch(tile + gridDim.x);
+            lds_barrier();
+#pragma unroll
+            for (int g = 0; g < STEM_WG_MAXG; ++g) {
+                if (g >= p.groups) break;
+                v8 af[4];
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) af[ct] = tr_frag<128, v8>(ytile + g * 4096, ct * 16, fg, fqq, fp);
+#pragma unroll
+                for (int j = 0; j < PPW; ++j) {
+                    const int pair = wave + 4 * j;                 // wave-uniform
+                    if (pair < NPAIR) {
+                        const int kh = pair >> 1, nt = pair & 1;
+                        const int o = kh * p.row_bytes + nt * 32;
+                        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(slab + poff[g][0] + o));
+                        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(slab + poff[g][1] + o));
+                        typedef short s16x8 __attribute__((ext_vector_type(8)));
+                        const s16x8 rr = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        const v8 bf = __builtin_bit_cast(v8, rr);
+#pragma unroll
+                        for (int ct = 0; ct < 4; ++ct) acc[j][ct] = MM::mma(af[ct], bf, acc[j][ct]);
+                    }
+                }
+            }
+        }
+    } else
     for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
         const int img = tile / p.tiles_per_img, oh0 = (tile - img * p.tiles_per_img) * p.TH;
         __syncthreads();                                           // the previous tile's reads (and the zero fill) are done
@@ -1696,6 +1775,7 @@ static int stem_wgrad_launch(const TriConvDesc* d, StemWgradArgs& sg, int grid, 
     if (workspace_bytes < need) { tri_set_error("wgrad(stem): workspace too small"); return TRI_ERR_ARG; }
     sg.slab = (float*)workspace;
     sg.h_abl = tri_probe_ablation();
+    { static int pipe = -1; if (pipe < 0) { const char* e = getenv("TRICOLO_STEM_WGRAD_PIPE"); pipe = (e && e[0] == '0') ? 0 : 1; } sg.unpiped = !pipe; }
     const bool bnf = sg.y != nullptr;
     const size_t smem = (size_t)sg.TH * sg.OW * 128 + (size_t)sg.slab_rows * sg.row_bytes + (bnf ? 5 * 64 * sizeof(float) : 0);
     hipStream_t st = (hipStream_t)stream;
