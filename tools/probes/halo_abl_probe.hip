@@ -1,7 +1,7 @@
 // Timing ablations of conv_halo_rows_kernel / conv_halo2d_kernel on the bench shape's 3x3 layers (results are WRONG in the ablated
 // builds: timing only).  Build one binary per variant:
 //   for v in BASE NOMMA NOREAD NODMA; do hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-inline-asm -DHR_ABL_$v -Iinclude \
-//       -o tools/probes/build/halo_abl_$v tools/probes/halo_abl_probe.hip tricolo_amd/csrc/{misc,conv_c64,conv_vox}.hip; done
+//       -o tools/probes/build/halo_abl_$v tools/probes/halo_abl_probe.hip tricolo_amd/csrc/{misc,conv_c64,conv_vox,conv_pw}.hip; done
 // Prints per layer the mean of 50 back-to-back launches (forward and data gradient).
 #include "../../tricolo_amd/csrc/conv_igemm.hip"
 #include <vector>

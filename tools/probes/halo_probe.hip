@@ -4,7 +4,8 @@
 // 9 epilogue start, 10 stores issued, 11 tile done; conv_halo_rows_kernel 2 constants + first DMAs issued, 3 first fragments read,
 // per kernel row 4 k-steps 0-3, 5 DMA wait, 6 barrier, 8 k-steps 4-5 + DMA issue, 10 epilogue, 11 statistics written.
 // Build (cross-compiles here, runs on the GPU box):
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DHALO_STAMPS -Iinclude -o tools/probes/build/halo_probe tools/probes/halo_probe.hip tricolo_amd/csrc/misc.hip
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DHALO_STAMPS -Iinclude -o tools/probes/build/halo_probe tools/probes/halo_probe.hip \
+//         tricolo_amd/csrc/{misc,conv_c64,conv_vox,conv_pw}.hip          (usage: halo_probe [images = 192] [first layer 0..3])
 // Prints, per layer: kernel time, and for a few workgroups the cycles between consecutive stamps summed by phase.
 #include "../../tricolo_amd/csrc/conv_igemm.hip"
 #include <vector>
@@ -18,6 +19,7 @@ int main(int argc, char** argv) {
     const int first = argc > 2 ? atoi(argv[2]) : 0;                     // first layer probed (0 = 64 channels ... 3 = 512)
     struct L { int hw, c; } layers[] = {{32, 64}, {16, 128}, {8, 256}, {4, 512}};
     setvbuf(stdout, nullptr, _IONBF, 0);
+    setenv("TRICOLO_HALO_TM3", "0", 0);                                 // the 192-position tiles use all 160 KB of LDS: no room for the stamp area
     hipMalloc(&g_halo_dbg, (size_t)4096 * 256 * 8);
     int li = -1;
     for (auto l : layers) {
