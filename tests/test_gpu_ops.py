@@ -1025,7 +1025,7 @@ def test_conv_16bit_storage_integer_exact(case, store, prec):
             np.testing.assert_allclose(st[1].numpy(), (gm * yv.double()).reshape(-1, case[3]).sum(0).numpy(), rtol=1e-6, atol=1e-2)
 
 
-@pytest.mark.parametrize("rows", ["0", "2", "2,tm2"])
+@pytest.mark.parametrize("rows", ["0", "2", "2,tm2", "2,tm2,noprod"])
 def test_halo_kernels_ab_switch(rows):
     """TRICOLO_HALO_ROWS picks the kernel of the resolution-keeping 3x3 layers per plan (default: conv_halo_rows_kernel for 64 input
     channels and for launches with at most one tile per workgroup, conv_halo2d_kernel otherwise).  The switch is read once per
@@ -1034,8 +1034,10 @@ def test_halo_kernels_ab_switch(rows):
     import subprocess
     import sys
     env = dict(os.environ, TRICOLO_HALO_ROWS=rows.split(",")[0])
-    if rows.endswith("tm2"):
+    if "tm2" in rows:
         env["TRICOLO_HALO_TM3"] = "0"                                 # 128-position tiles only (A/B partner of the 192-position tiles)
+    if "noprod" in rows:
+        env["TRICOLO_HALO_PROD"] = "0"                                # every wave issues its own DMA pieces (A/B partner of the producer waves)
     k = "test_conv_16bit_storage_integer_exact and (h_ or big_nosplit or c64_32) and f16"
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", k, "-p", "no:cacheprovider"],
                        env=env, capture_output=True, text=True, timeout=900)

@@ -984,12 +984,16 @@ __global__ __launch_bounds__(256, WGREC ? 3 : 1) void conv_halo2d_kernel(const C
 // TMT: 16-position fragments per wave (2: 128-position tiles; 3: 192-position tiles, streamed weights only, no drip - for launches
 // whose 128-position tiles need one more round of workgroups than the 192-position ones: layer3 of the bench shape, 384 tiles
 // on 256 CUs = two rounds, 256 tiles of 192 = one round of 1.5 x the MFMAs per barrier / DMA piece: 25.9 -> see DESIGN.md)
-template <typename AT, bool DRIP, bool ACCUM, int NTL, int TMT = 2>
-__global__ __launch_bounds__(256, 1) void conv_halo_rows_kernel(const ConvArgs p) {
+// PROD (round 4, streamed 128-position tiles only): 512 threads - waves 4..7 are PRODUCERS that issue every LDS-DMA piece of the
+// row schedule and wait for it (vmcnt) in front of the row barrier; waves 0..3 run the k-steps, fragment reads and the epilogue and never
+// touch the vector-memory path inside the loop (their part of the kernel must fit 256 registers: two waves per SIMD).
+template <typename AT, bool DRIP, bool ACCUM, int NTL, int TMT = 2, bool PROD = false>
+__global__ __launch_bounds__(PROD ? 512 : 256, 1) void conv_halo_rows_kernel(const ConvArgs p) {
     typedef Mma<typename OpOf<AT>::E> MM;
     typedef typename MM::v8 v8;
     constexpr int BN = 64, TN = 4, TM = TMT, WM = 16 * TMT, SLOT = HROWS_SLOT;
     static_assert(TMT == 2 || (TMT == 3 && !DRIP && NTL == 0), "192-position tiles: streamed weights, epilogue stores");
+    static_assert(!PROD || (TMT == 2 && NTL == 0), "producer waves: streamed 128-position tiles");
     constexpr int NTLE = NTL < 1 ? 1 : NTL;                             // tiles per group
     constexpr bool STREAM = NTL == 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -997,7 +1001,8 @@ __global__ __launch_bounds__(256, 1) void conv_halo_rows_kernel(const ConvArgs p
     char* const ring = smem + 2 * slab_bytes;
     float* const red = (float*)(ring + 3 * SLOT);
 
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = threadIdx.x & 255, lane = t & 63, wave = t >> 6;      // (producers: wave = the 1 KiB quarter of every piece they move)
+    const bool producer = PROD && threadIdx.x >= 256;
     const int fr = lane & 15, fq = lane >> 4;
 #ifdef HALO_STAMPS
     int n_stamp = 0;
@@ -1038,21 +1043,29 @@ __global__ __launch_bounds__(256, 1) void conv_halo_rows_kernel(const ConvArgs p
     };
     // streamed mode: cursor over (tile, chunk) elements, three rows each
     int w_k = 0, w_chunk = 0;                                           // tile index in this workgroup's list, chunk
-    auto w_pieces = [&](int ky, int j0, int j1) {
+    auto p_w_pieces = [&](int ky, int j0, int j1) {                      // (the issuing side: every wave, or the producer waves)
 #ifndef HR_ABL_NODMA
         if (STREAM && w_k < n_my) w_row_pieces(w_chunk, ky, j0, j1);
 #endif
     };
-    auto w_advance = [&]() {
+    auto w_pieces = [&](int ky, int j0, int j1) {                        // (as called from the k-step schedule)
+        if constexpr (!PROD) p_w_pieces(ky, j0, j1);
+    };
+    auto p_w_advance = [&]() {
         if (++w_chunk == nchunks) { w_chunk = 0; ++w_k; }
     };
+    auto w_advance = [&]() {
+        if constexpr (!PROD) p_w_advance();
+    };
     // issued first: the weight DMAs are in flight while the slab source table and the fragment addresses are computed
-    w_row_pieces(0, 0, 0, 6);
-    if (STREAM) {
-        w_row_pieces(0, 1, 0, 4);
-    } else {
-        w_row_pieces(0, 1, 0, 6);
-        w_row_pieces(0, 2, 0, 6);
+    if (!PROD || producer) {
+        w_row_pieces(0, 0, 0, 6);
+        if (STREAM) {
+            w_row_pieces(0, 1, 0, 4);
+        } else {
+            w_row_pieces(0, 1, 0, 6);
+            w_row_pieces(0, 2, 0, 6);
+        }
     }
 
     // ---- geometry-only lane constants (as conv_halo2d_kernel) ----------------------------------------------------------
@@ -1097,7 +1110,7 @@ __global__ __launch_bounds__(256, 1) void conv_halo_rows_kernel(const ConvArgs p
         s_cb = g0_ * W * p.Cin * 2 + s_chunk * 128;
     };
     bool slab_on = true;                                                // (probe builds switch the in-loop slab DMAs off)
-    auto slab_pieces = [&](int r0, int r1) {
+    auto p_slab_pieces = [&](int r0, int r1) {
         if (s_g < n_my && slab_on) {
             const unsigned dst = dma_slab + s_buf * slab_bytes;
 #pragma unroll
@@ -1106,7 +1119,7 @@ __global__ __launch_bounds__(256, 1) void conv_halo_rows_kernel(const ConvArgs p
                     dma16_async(in_rsrc, dst + r * 4096, (soff[r] == -1 || ((s_kill >> r) & 1u)) ? (int)0x80000000 : soff[r] + s_cb);
         }
     };
-    auto slab_advance = [&]() {
+    auto p_slab_advance = [&]() {
         s_buf ^= 1;
         if (++s_tl == grp_n(s_g)) {
             s_tl = 0;
@@ -1114,12 +1127,50 @@ __global__ __launch_bounds__(256, 1) void conv_halo_rows_kernel(const ConvArgs p
         }
         if (s_g < n_my) slab_setup();
     };
-    slab_setup();                                                       // the first slab, before the remaining constants
-    slab_pieces(0, HALO_MAX_ROUNDS);
-    slab_advance();
+    auto slab_pieces = [&](int r0, int r1) {
+        if constexpr (!PROD) p_slab_pieces(r0, r1);
+    };
+    auto slab_advance = [&]() {
+        if constexpr (!PROD) p_slab_advance();
+    };
+    if (!PROD || producer) {
+        slab_setup();                                                   // the first slab, before the remaining constants
+        p_slab_pieces(0, HALO_MAX_ROUNDS);
+        p_slab_advance();
+    }
 #ifdef HR_ABL_NODMA
     slab_on = false;
 #endif
+    if (PROD && producer) {
+        // ---- producer waves: the DMA side of the row schedule below, one barrier per kernel row -----------------------------------
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                   // (the consumers' prologue barrier)
+        asm volatile("" ::: "memory");
+        int c_g = 0, c_chunk = 0;
+#pragma unroll 1
+        for (;;) {
+#pragma unroll
+            for (int KY = 0; KY < 3; ++KY) {
+                const int NKY = (KY + 1) % 3, PKY = (KY + 2) % 3;
+                p_w_pieces(NKY, 4, 6);
+                if (KY == 1) { p_w_advance(); p_slab_pieces(7, HALO_MAX_ROUNDS); p_slab_advance(); }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                p_w_pieces(PKY, 0, 2);
+                if (KY == 0) p_slab_pieces(0, 4);
+                p_w_pieces(PKY, 2, 4);
+                if (KY == 0) p_slab_pieces(4, 7);
+            }
+            int n_g = c_g, n_chunk = c_chunk + 1;
+            if (n_chunk == nchunks) { n_chunk = 0; n_g += NTLE; }
+            if (n_g >= n_my) break;
+            c_g = n_g; c_chunk = n_chunk;
+        }
+        __syncthreads();                                                // (the consumers' barrier in front of the statistics)
+        if (p.stats) __syncthreads();                                   // (halo_store_stats)
+        return;
+    }
 
     int pixc[TM];
 #pragma unroll
@@ -1245,7 +1296,7 @@ __global__ __launch_bounds__(256, 1) void conv_halo_rows_kernel(const ConvArgs p
         if ((KY) == 2) set_rows(n_item);                                                                               \
         HSTAMP(4);                                                                                                     \
         /* the next row's weights (streamed) and, before a new element, its slab have landed for every wave; the row before this is free */ \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                               \
+        if constexpr (!PROD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                          \
         HSTAMP(5);                                                                                                     \
         __builtin_amdgcn_s_barrier();                                                                                  \
         asm volatile("" ::: "memory");                                                                                 \
@@ -1359,7 +1410,7 @@ __global__ __launch_bounds__(256, 1) void conv_halo_rows_kernel(const ConvArgs p
 
     HSTAMP(2);
     // ---- prologue: the first slab and weights have been issued; fragments of k-steps 0 and 1 --------------------------------
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (!PROD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     HR_FIRST_READS(0u)
@@ -2205,6 +2256,27 @@ static int launch_halo(ConvArgs& a, const ConvPlan& pl, hipStream_t stream) {
             else if (drip) TRI_ROWS_LAUNCH(true, false, NTL_);                                                                      \
             else TRI_ROWS_LAUNCH(false, false, NTL_);                                                                               \
         } while (0)
+        // producer waves for the streamed 128-position tiles (layer4 of the bench shape: 23.0 -> 20.5 us forward, 21.8 -> 19.1 us data gradient;
+        // config 3 3.771 -> 3.748 ms, three of three alternating pairs); TRICOLO_HALO_PROD=0 is the A/B partner
+        static int prod = -1;
+        if (prod < 0) { const char* e = getenv("TRICOLO_HALO_PROD"); prod = (e && e[0] == '0') ? 0 : 1; }
+        if (prod && pl.halo == 2 && ntl == 0) {
+#define TRI_ROWS_LAUNCH_P(DRIP_, ACC_)                                                                                              \
+        do {                                                                                                                        \
+            static size_t attrp = 0;                                                                                                \
+            if (smem5 > attrp) {                                                                                                    \
+                hipFuncSetAttribute((const void*)conv_halo_rows_kernel<AT, DRIP_, ACC_, 0, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    (int)smem5);                                                                                    \
+                attrp = smem5;                                                                                                      \
+            }                                                                                                                       \
+            conv_halo_rows_kernel<AT, DRIP_, ACC_, 0, 2, true><<<pl.h_grid, 512, smem5, stream>>>(a);                                \
+        } while (0)
+            if (a.accumulate) TRI_ROWS_LAUNCH_P(false, true);
+            else if (drip) TRI_ROWS_LAUNCH_P(true, false);
+            else TRI_ROWS_LAUNCH_P(false, false);
+#undef TRI_ROWS_LAUNCH_P
+            return tri_check_launch("tri_conv(halo rows, producer waves)");
+        }
         if (pl.halo == 3) {                                           // 192-position tiles (streamed weights, epilogue stores)
             if (a.accumulate) TRI_ROWS_LAUNCH(false, true, 0, 3);
             else TRI_ROWS_LAUNCH(false, false, 0, 3);
