@@ -1061,7 +1061,7 @@ __global__ __launch_bounds__(PROD ? 512 : 256, 1) void conv_halo_rows_kernel(con
     if (!PROD || producer) {
         w_row_pieces(0, 0, 0, 6);
         if (STREAM) {
-            w_row_pieces(0, 1, 0, 4);
+            w_row_pieces(0, 1, 0, PROD ? 6 : 4);
         } else {
             w_row_pieces(0, 1, 0, 6);
             w_row_pieces(0, 2, 0, 6);
@@ -1151,16 +1151,17 @@ __global__ __launch_bounds__(PROD ? 512 : 256, 1) void conv_halo_rows_kernel(con
         for (;;) {
 #pragma unroll
             for (int KY = 0; KY < 3; ++KY) {
-                const int NKY = (KY + 1) % 3, PKY = (KY + 2) % 3;
-                p_w_pieces(NKY, 4, 6);
-                if (KY == 1) { p_w_advance(); p_slab_pieces(7, HALO_MAX_ROUNDS); p_slab_advance(); }
+                // Everything this barrier promises the consumers was issued a whole kernel row ago (the consumers' own schedule issued
+                // the last two pieces of a row in the k-step before its barrier, to spread the issue cost over their MFMAs): all six
+                // pieces of the row after the next go out right after the barrier that frees their ring slot, the next element's whole
+                // slab after the barrier that frees its buffer.
+                const int PKY = (KY + 2) % 3;
+                if (KY == 1) p_w_advance();
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-                p_w_pieces(PKY, 0, 2);
-                if (KY == 0) p_slab_pieces(0, 4);
-                p_w_pieces(PKY, 2, 4);
-                if (KY == 0) p_slab_pieces(4, 7);
+                p_w_pieces(PKY, 0, 6);
+                if (KY == 0) { p_slab_pieces(0, HALO_MAX_ROUNDS); p_slab_advance(); }
             }
             int n_g = c_g, n_chunk = c_chunk + 1;
             if (n_chunk == nchunks) { n_chunk = 0; n_g += NTLE; }
