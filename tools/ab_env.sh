@@ -4,7 +4,7 @@
 tag=$1; A=$2; B=$3; shift 3
 mkdir -p gpurun_out/ab
 out=gpurun_out/ab/$tag.txt; : > $out
-for rep in 1 2 3; do
+for rep in $(seq 1 ${AB_REPS:-3}); do
   for v in A B; do
     if [ $v = A ]; then e="$A"; else e="$B"; fi
     line=$(env $e python3 bench.py --modes "" --no-cpu-baseline "$@" 2>gpurun_out/ab/$tag.err | tail -1)
