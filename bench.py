@@ -20,8 +20,8 @@ Precision modes, ALL timed by the same invocation at N = 1 (one JSON line):
 Each mode carries its own `roofline` (dominant conv kernel by measured time, HIP events on the launch stream).
 `roofline_3dconv_fwd`: the five SubMConv3d forwards of the voxel tower timed by HIP events, with dense AND executed FLOPs
 (active 128-site tiles counted on the device from the site masks) and level 0's HBM rate.
-`cpu_baseline`: the torch-CPU oracle on the host cores, 2 warm-up + >= 5 timed steps, for the bench workload at batch 8
-and for BASELINE config 1 (Bi(V), batch 8).
+`cpu_baseline`: the torch-CPU oracle on every usable host CPU (model string and core counts stated), 2 warm-up + >= 5 timed steps,
+for the bench workload at the per-GPU batch (halved until it fits the time budget) and for BASELINE config 1 (Bi(V), batch 8).
 """
 import argparse
 import gc
@@ -119,21 +119,65 @@ def oracle_step_time(text, image, voxel, V, nv, S, B, cfg, threads, warm, timed,
     return kept[len(kept) // 2], len(kept), max(0, min(warm, len(times) - len(kept)))
 
 
+def host_cpu_info():
+    """CPU model string, logical CPUs and physical cores of this box (the report states model and core count)."""
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name" and model == "unknown":
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif not k and phys is not None and core is not None:
+                cores.add((phys, core)); phys = core = None
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = os.cpu_count() or 1
+    return {"model": model, "logical_cpus": os.cpu_count() or 1, "physical_cores": len(cores) or None, "usable_cpus": usable}
+
+
 def cpu_baseline(a, cfg):
-    """The oracle timed on this box's host cores (SURVEY 8d protocol: 2 warm-up + >= 5 timed steps, median), on a bounded
-    sample: the bench workload at batch 8 and BASELINE config 1 (Bi(V) 32^3 + BiGRU, batch 8)."""
+    """The oracle timed on this box's host cores, to BASELINE.md section 3: torch.set_num_threads(os.cpu_count()) (--cpu-threads 0, the
+    default; `cores` = the threads used), 2 warm-up + >= 5 timed steps, median, on the SAME per-GPU batch as the GPU line when a step
+    fits the time budget (the batch is halved until 2 + 5 steps fit --cpu-budget-s, judged from one probe step), plus BASELINE
+    config 1 (Bi(V) 32^3 + BiGRU, batch 8).  A 16-thread leg of the bench workload at batch 8 - the protocol of rounds 1-4 - is kept
+    beside it for continuity (torch-CPU conv3d can degrade when a large host is oversubscribed)."""
     from tricolo_amd.data import synthetic as syn
-    threads = max(1, min(os.cpu_count() or 1, a.cpu_threads))     # torch-CPU conv3d degrades when oversubscribed
-    B = a.cpu_batch
+    info = host_cpu_info()
+    threads = a.cpu_threads if a.cpu_threads > 0 else info["usable_cpus"]
+    threads = max(1, min(info["usable_cpus"], threads))
+    name = workload_name(a).split(': ')[1]
+    B = a.cpu_batch or a.per_gpu_batch
+    # probe: one step at batch 4 sizes the batch (a step scales ~linearly in the batch)
+    probe, _, _ = oracle_step_time(a.text, a.image, a.voxel, a.voxel_size, a.num_views, a.image_size, min(4, B), cfg, threads, 1, 1, 5.0,
+                                   syn.BASE_SEED + 40)
+    per_sample = probe / min(4, B)
+    while B > 4 and per_sample * B * (2 + a.cpu_steps) > a.cpu_budget_s:
+        B //= 2
     med, n, w = oracle_step_time(a.text, a.image, a.voxel, a.voxel_size, a.num_views, a.image_size, B, cfg, threads, 2, a.cpu_steps,
                                  a.cpu_budget_s, syn.BASE_SEED + 40)
     out = {"value": round(B / med, 3), "unit": "samples/s", "cores": threads, "kind": "port",
-           "sample": f"{n} timed steps after {w} warm-up of the same {workload_name(a).split(': ')[1]} step at batch {B} on the "
-                     f"torch-CPU oracle ({threads} threads, median; the GPU line runs per-GPU batch {a.per_gpu_batch})"}
+           "cpu_model": info["model"], "host_logical_cpus": info["logical_cpus"], "host_physical_cores": info["physical_cores"],
+           "batch": B, "ms_per_step": round(med * 1e3, 1),
+           "sample": f"{n} timed steps after {w} warm-up of the same {name} step at batch {B} on the torch-CPU oracle "
+                     f"({threads} threads = every usable CPU of the host, median; the GPU line runs per-GPU batch {a.per_gpu_batch})"}
     med1, n1, w1 = oracle_step_time("BiGRUEncoder", None, "SparseCNNEncoder", 32, 6, 128, 8, cfg, threads, 2, a.cpu_steps,
-                                    a.cpu_budget_s, syn.BASE_SEED + 1)
-    out["config1"] = {"value": round(8 / med1, 3), "unit": "samples/s", "ms_per_step": round(med1 * 1e3, 2),
+                                    a.cpu_budget_s / 3, syn.BASE_SEED + 1)
+    out["config1"] = {"value": round(8 / med1, 3), "unit": "samples/s", "ms_per_step": round(med1 * 1e3, 2), "cores": threads,
                       "sample": f"BASELINE configs[0] Bi(V) 32^3 + BiGRU, batch 8: {n1} timed steps after {w1} warm-up, median"}
+    if threads > 16:
+        med2, n2, w2 = oracle_step_time(a.text, a.image, a.voxel, a.voxel_size, a.num_views, a.image_size, 8, cfg, 16, 1, 3,
+                                        a.cpu_budget_s / 3, syn.BASE_SEED + 40)
+        out["threads16_batch8"] = {"value": round(8 / med2, 3), "unit": "samples/s", "cores": 16,
+                                   "sample": f"the protocol of rounds 1-4 (16 threads, batch 8): {n2} timed steps after {w2} warm-up, median"}
     return out
 
 
@@ -479,9 +523,9 @@ def parse_args(argv=None):
     ap.add_argument("--image-size", type=int, default=None)
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-batch", type=int, default=0, help="batch of the CPU leg (0: the per-GPU batch, halved until 2 + 5 steps fit the budget)")
     ap.add_argument("--cpu-steps", type=int, default=5)
-    ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU leg (0: every usable CPU of the host, BASELINE.md section 3)")
     ap.add_argument("--cpu-budget-s", type=float, default=30.0)
     ap.add_argument("--resident-batches", type=int, default=8)
     ap.add_argument("--preroll", type=int, default=40)

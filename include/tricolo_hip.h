@@ -219,7 +219,8 @@ int tri_bn_bwd_num_blocks(long M);
 int tri_bn_bwd_reduce(const void* y, const void* g, long M, int C, float* partial, const float* relu_scale, const float* relu_shift,
                       const void* relu_out, const uint8_t* row_mask /* optional: rows with 0 are skipped (never read) */, int act_fmt,
                       void* stream);
-/* BatchNorm backward of a SMALL tensor (M <= 16,384 rows) in ONE launch: a workgroup owns 4 / 8 channels for all positions - sums,
+/* BatchNorm backward of a SMALL tensor (accepted up to M = 16,384 rows; the Python gate ops.bn_bwd uses it for M <= 512 only - from
+ * ~1 k rows on the three-pass form is faster: this kernel's loads are 16 bytes per cache line) in ONE launch: a workgroup owns 4 / 8 channels for all positions - sums,
  * coefficients (double) and the apply pass without records or a finalize launch.  Arguments as tri_bn_bwd_reduce / _finalize / _apply
  * (dy may alias g); TRI_ERR_UNSUPPORTED for other shapes. */
 int tri_bn_bwd_small(const void* y, const void* g, long M, int C, const int* count_dev, int count_host, const float* gamma,

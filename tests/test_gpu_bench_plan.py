@@ -1,0 +1,156 @@
+"""The conv kernels bench.py TIMES, checked on the geometries it times them on.
+
+The module-level parity tests run at reduced batch, and the dispatch (tri_conv_kernel_family) plans by geometry INCLUDING the batch:
+a layer can run one kernel in those tests and another in the bench.  Here every conv layer of the default bench workload (BASELINE
+config 4 per-GPU shard: 32 samples, 6 x 128^2 views -> 192 images; 32^3 voxel grids) is planned by the encoders' own geometry
+helpers (MVCNNEncoder._geom2d / SparseCNNEncoder._geom, i.e. exactly what TriCoLoNet plans in bench.py), on the default switch set
+(tests/conftest.py sets no TRICOLO_* variable), in the bench's precision mode (f16), and compared bit for bit with torch's CPU
+convolution on integer-valued data: forward + BatchNorm sums, data gradient (plain and accumulating) and weight gradient through the
+grouped job queue the training step uses."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tricolo_amd import ops
+from tricolo_amd.data import synthetic as syn
+from tricolo_amd.model.module.img_encoder.mv_cnn import MVCNNEncoder
+from tricolo_amd.model.module.voxel_encoder.sparse_cnn import SparseCNNEncoder
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+B_BENCH, NV, S, V = 32, 6, 128, 32          # bench.py defaults (BASELINE.json configs[3] per-GPU shard)
+STORE, PREC = torch.float16, "f16"
+
+
+def ints(shape, lo, hi, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(lo, hi + 1, shape, generator=g).to(torch.float32)
+
+
+def _image_layers():
+    """(name, conv module, N, H, W) of every conv of the trunk at the bench shape, in execution order, one entry per distinct geometry."""
+    enc = MVCNNEncoder(512, 512, "resnet18", NV)
+    N = B_BENCH * NV
+    out, seen = [], set()
+    h = w = S
+    out.append(("stem", enc, enc.net_1[0], N, h, w))
+    h = w = S // 4
+    for li, blk in enumerate(enc._blocks()):
+        s = blk.conv1.stride[0]
+        cands = [(f"b{li}.conv1", blk.conv1, h, w)]
+        if blk.downsample is not None:
+            cands.append((f"b{li}.ds", blk.downsample[0], h, w))
+        h, w = (h + 2 - 3) // s + 1, (w + 2 - 3) // s + 1
+        cands.append((f"b{li}.conv2", blk.conv2, h, w))
+        for name, conv, ch, cw in cands:
+            key = (conv.in_channels, conv.out_channels, conv.kernel_size, conv.stride, ch, cw)
+            if key not in seen:
+                seen.add(key)
+                out.append((name, enc, conv, N, ch, cw))
+    return out
+
+
+IMAGE_LAYERS = _image_layers()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("layer", IMAGE_LAYERS, ids=[l[0] for l in IMAGE_LAYERS])
+def test_image_tower_bench_geometry_integer_exact(layer):
+    name, enc, conv, N, H, W = layer
+    assert not any(k.startswith("TRICOLO_") and k not in ("TRICOLO_HELDOUT_STEPS",) for k in os.environ), \
+        "the bench-plan tests must run on the default switch set"
+    g = enc._geom2d(N, H, W, conv)                                   # the plan TriCoLoNet makes for this layer in bench.py
+    cin, cout, k, s, p = conv.in_channels, conv.out_channels, conv.kernel_size[0], conv.stride[0], conv.padding[0]
+    x = ints((N, cin, H, W), -3, 3, 301)
+    w = ints((cout, cin, k, k), -2, 2, 302)
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    y = F.conv2d(xr, wr, stride=s, padding=p)
+    dy = ints(tuple(y.shape), -2, 2, 303)
+    y.backward(dy)
+    ref = y.detach().permute(0, 2, 3, 1).contiguous()
+    xcl = x.permute(0, 2, 3, 1).contiguous()
+    if g.cin_stored != cin:
+        xcl = torch.cat([xcl, torch.zeros(*xcl.shape[:-1], g.cin_stored - cin)], dim=-1).contiguous()
+    xd = xcl.view(N, 1, H, W, g.cin_stored).to(DEV).to(STORE)
+    dyd = dy.permute(0, 2, 3, 1).contiguous().view(N, 1, *y.shape[2:], cout).to(DEV).to(STORE)
+    wd = w.to(DEV)
+    packed = ops.pack_weight(wd, g, PREC)
+    out, stats = ops.conv_fwd(xd, g, packed, want_stats=True)       # as MVCNNEncoder._conv_bn calls it in training
+    assert torch.equal(out.cpu().view(ref.shape), ref.to(STORE)), f"{name}: forward differs ({ops._igemm_symbol(g, False, False, xd)})"
+    exact = ref.to(STORE).double().reshape(-1, cout)
+    st = stats.cpu().double().sum(0)
+    np.testing.assert_allclose(st[0].numpy(), exact.sum(0).numpy(), rtol=1e-6, atol=1e-1)
+    np.testing.assert_allclose(st[1].numpy(), (exact ** 2).sum(0).numpy(), rtol=1e-6, atol=1e-1)
+    # weight gradient through the job queue (one grouped partial launch + one grouped reduce), as the tower's backward issues it
+    batch = ops.wgrad_batch(torch.device(DEV))
+    dw = ops.conv_wgrad(xd, dyd, g, wd, PREC, out_scale=0.5, batch=batch)
+    if batch is not None:
+        batch.flush()
+    assert torch.equal(dw.cpu(), wr.grad * 0.5), f"{name}: weight gradient differs"
+    if cin != g.cin_stored:
+        return                                                       # the stem has no data gradient
+    refdx = xr.grad.permute(0, 2, 3, 1).contiguous()
+    tp = ops.pack_weight(wd, g, PREC, transposed=True)
+    dx = ops.conv_dgrad(dyd, g, tp)
+    assert torch.equal(dx.cpu().view(refdx.shape), refdx.to(STORE)), f"{name}: data gradient differs ({ops._igemm_symbol(g, True, False, dyd)})"
+    base = ints(tuple(refdx.shape), -5, 5, 304)
+    dx2 = ops.conv_dgrad(dyd, g, tp, out=base.clone().view(N, 1, H, W, cin).to(DEV).to(STORE), accumulate=True)
+    assert torch.equal(dx2.cpu().view(refdx.shape), (refdx + base).to(STORE)), f"{name}: accumulating data gradient differs"
+
+
+def _voxel_masks(B, Vx, seed):
+    batch = syn.make_batch(B, voxel_size=Vx, num_views=None, seed=seed)
+    locs = batch["voxels"]["locs"].long()
+    m = torch.zeros(B, 1, Vx, Vx, Vx)
+    m[locs[:, 0], 0, locs[:, 1], locs[:, 2], locs[:, 3]] = 1
+    masks = []
+    for _ in range(5):
+        masks.append(m[:, 0].bool())
+        m = F.max_pool3d(m, 2)
+    return masks
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("B,Vx,levels", [(B_BENCH, V, (0, 1, 2, 3, 4)), (64, 32, (1, 2, 3, 4)), (64, 64, (2, 3, 4))],
+                         ids=["config4_32^3xB32", "config2_32^3xB64", "config5_64^3xB64_coarse"])
+def test_voxel_tower_bench_geometry_integer_exact(B, Vx, levels):
+    """The five SubMConv3d forwards on the synthetic occupancy of the bench batch, selected as SparseCNNEncoder._forward_impl selects
+    them (brick kernels by site mask, everything else over the compact active-row list): active rows equal the masked dense convolution
+    exactly, rows of inactive sites stay unwritten, the BatchNorm records sum to the active rows' column sums."""
+    enc = SparseCNNEncoder(Vx, 32, 512, 512)
+    masks = _voxel_masks(B, Vx, seed=20250718 + 4)
+    for l in levels:
+        D = Vx >> l
+        g = enc._geom(B, l)
+        cin, cout = enc.chans[l], enc.chans[l + 1]
+        m = masks[l]
+        mf = m.float()
+        x = ints((B, cin, D, D, D), -2, 2, 311 + l) * mf[:, None]
+        w = ints((cout, cin, 3, 3, 3), -2, 2, 321 + l)
+        ref = F.conv3d(x, w, padding=1).permute(0, 2, 3, 4, 1).contiguous().to(STORE)
+        xcl = x.permute(0, 2, 3, 4, 1).contiguous()
+        if g.cin_stored != cin:
+            xcl = torch.cat([xcl, torch.zeros(*xcl.shape[:-1], g.cin_stored - cin)], dim=-1).contiguous()
+        wp = w.permute(0, 2, 3, 4, 1).contiguous().to(DEV)
+        packed = ops.pack_weight(wp, g, PREC)
+        M = B * D ** 3
+        mask = torch.zeros((M + 31) // 32 * 32, dtype=torch.uint8)
+        mask[:M] = m.reshape(M).to(torch.uint8)
+        mask = mask.to(DEV)
+        xd = xcl.to(DEV).to(STORE)
+        use_rows = not g.brick(False, 2)
+        sel = dict(rows=ops.mask_compact(mask, M)) if use_rows else dict(row_mask=mask)
+        junk = torch.full((B, D, D, D, cout), 777.0, dtype=STORE, device=DEV)
+        out, stats = ops.conv_fwd(xd, g, packed, want_stats=True, out=junk, **sel)
+        o = out.cpu().reshape(M, cout)
+        act = m.reshape(M)
+        sym = ops._igemm_symbol(g, False, False, xd)
+        assert torch.equal(o[act], ref.reshape(M, cout)[act]), f"level {l} ({sym}): active rows differ"
+        assert bool((o[~act] == 777.0).all()), f"level {l} ({sym}): rows of inactive sites must not be written"
+        exact = ref.reshape(M, cout)[act].double()
+        st = stats.cpu().double().sum(0)
+        np.testing.assert_allclose(st[0].numpy(), exact.sum(0).numpy(), rtol=1e-6, atol=1e-1)
+        np.testing.assert_allclose(st[1].numpy(), (exact ** 2).sum(0).numpy(), rtol=1e-6, atol=1e-1)

@@ -1203,7 +1203,7 @@ extern "C" int tri_maxpool_bn_bwd_reduce(const void* y, const uint8_t* arg, cons
 // WINDOWS: sum_w dpool[w] [p[w] > 0] and sum_w dpool[w] [p[w] > 0] y[winner(w)], where p = maxpool(relu(bn(y))) is the tensor the next
 // layer kept anyway and, for an active window, y[winner] = (p - shift) / scale.  The pass then reads 2 x 25 MB of pooled-resolution
 // tensors instead of y (100 MB) + tap map + dpool: 45 -> ~12 us at the bench shape.  A window whose recovered y would be ill-conditioned
-// (|p| > 64 |gamma|: a channel with gamma ~ 0 and a large shift; never at initialisation) reads the winner's stored y through the tap
+// (|p| > 64 |gamma| for f16 storage, 8 |gamma| for bf16: a channel with gamma ~ 0 and a large shift; never at initialisation) reads the winner's stored y through the tap
 // map instead, so every channel keeps the accuracy of the stored activations.  The routed gradient is no longer rounded to the
 // storage type per position (the reference's max-pool backward has no such rounding either).
 #define STEM_POOLED_PER_WG 256                                      // pooled positions per workgroup
@@ -1229,7 +1229,11 @@ __global__ __launch_bounds__(256) void stem_bwd_reduce_pooled_kernel(const T* __
             b8[k] = rb[tc * 8 + k];
             s8[k] = s_ != 0.f ? s_ : 1.f;
             inv8[k] = 1.0f / s8[k];
-            lim8[k] = s_ != 0.f ? 64.f * fabsf(gamma[tc * 8 + k]) : -1.f;        // |p| above this: the stored y
+            // |p| above this: the stored y.  p is rounded to the storage type (relative error 2^-9 for bf16, 2^-11 for f16), so the recovered
+            // xhat = (p - shift) / scale is off by up to |p| / |gamma| rounding units: the threshold keeps that under 2^-6 of a standard
+            // deviation for both types (f16: 64 |gamma|, bf16: 8 |gamma| - ADVICE r4: 64 let trained-like bf16 channels with
+            // |beta / gamma| ~ 10 drift by 0.02 in xhat)
+            lim8[k] = s_ != 0.f ? (Act<T>::SIG_BITS <= 8 ? 8.f : 64.f) * fabsf(gamma[tc * 8 + k]) : -1.f;
         }
         // four rows per pass, all eight loads issued before the first is used; branch-free per channel (the quotient by one
         // reciprocal + one residual correction: exact whenever (p - shift) / scale is representable), ONE rare branch per row for

@@ -91,12 +91,14 @@ __device__ __forceinline__ float fp32_rounded(float x) {
 template <typename T> struct Act;
 template <> struct Act<float> {
     static constexpr int BYTES = 4;
+    static constexpr int SIG_BITS = 24;                                        // significand bits incl. the hidden one
     static __device__ __forceinline__ float4 ld4(const float* p) { return *(const float4*)p; }
     static __device__ __forceinline__ void st4(float* p, const float4& v) { *(float4*)p = v; }
     static __device__ __forceinline__ float rnd(float v) { return v; }           // value as it will be read back
 };
 template <> struct Act<bf16_t> {
     static constexpr int BYTES = 2;
+    static constexpr int SIG_BITS = 8;
     static __device__ __forceinline__ float4 ld4(const bf16_t* p) {
         bf16x4 r = *(const bf16x4*)p;
         return make_float4((float)r[0], (float)r[1], (float)r[2], (float)r[3]);
@@ -106,6 +108,7 @@ template <> struct Act<bf16_t> {
 };
 template <> struct Act<f16_t> {
     static constexpr int BYTES = 2;
+    static constexpr int SIG_BITS = 11;
     static __device__ __forceinline__ float4 ld4(const f16_t* p) {
         f16x4 r = *(const f16x4*)p;
         return make_float4((float)r[0], (float)r[1], (float)r[2], (float)r[3]);

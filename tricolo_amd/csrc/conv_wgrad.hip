@@ -1950,8 +1950,9 @@ static int wgrad_group_target(int family) {                     // resident work
     // 256x128 tiles: one 512-thread workgroup per CU.
     static int v[7] = {-1, -1, -1, -1, -1, -1, -1};
     if (v[0] < 0) {
-        // 4 / 6: conv_wgrad_krow_kernel<128> (stride 1 / 2), two workgroups per CU; 5 / 7: <64>, three per CU (40 KB of LDS, 126 registers:
-        // layer1's four layers in one launch 592 -> 725 TF; the step does not move)
+        // 4 / 6: conv_wgrad_krow_kernel<128> (stride 1 / 2), two workgroups per CU; 5: <64> stride 1, three per CU (768 slots: 40 KB of LDS,
+        // 126 registers - layer1's four layers in one launch 592 -> 725 TF; the step does not move); 7: <64> stride 2 (one layer of the
+        // trunk: it rides in the stride-1 launch, so its own target is the two-per-CU default)
         v[0] = 512; v[1] = 448; v[2] = 256; v[3] = KROW_TARGET_BLOCKS; v[4] = 768; v[5] = KROW_TARGET_BLOCKS; v[6] = KROW_TARGET_BLOCKS;
         const char* e = getenv("TRICOLO_WGRAD_GROUP_BLOCKS");
         if (e) {

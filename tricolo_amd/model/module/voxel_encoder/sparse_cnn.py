@@ -52,7 +52,7 @@ class SparseCNNEncoder(TriModule):
         self.sparseModel = nn.ModuleDict(mods)
         self.spatial = (voxel_size // 32) ** 3
         self.mlp = nn.Sequential(nn.Linear(z_dim * self.spatial, out_dim), nn.ReLU(inplace=True), nn.Linear(out_dim, out_dim))
-        self.fuse_pool_reduce = True                            # see _backward_impl; TriCoLoNet clears it when an image tower runs beside this one
+        self.fuse_pool_reduce = True                            # see _backward_impl (TRICOLO_POOL_REDUCE=0 / 1 overrides)
         self._geoms = {}
         self.__dict__["_packers"] = {}
         self.__dict__["_packed"] = {}
@@ -146,10 +146,11 @@ class SparseCNNEncoder(TriModule):
         dx = ops.cast_from_f32(dflat.contiguous(), ops.act_dtype(prec), gs)
         batch = ops.wgrad_batch(dz.device)                     # the five weight-gradient reduces in one launch at the end
         compact = os.environ.get("TRICOLO_VOXEL_COMPACT", "1") != "0"
-        # route + BatchNorm-backward sums in one launch when this tower is the step's longest chain (Bi(V): 1.314 -> 1.302 ms).  Beside
-        # an image tower the shorter voxel chain changes how the replayed graph folds its branches and at 32^3 the STEP gets slower
-        # (round 2: 3.30 -> 3.33 ms, four pairs; round 3: 2.98-3.01 -> 3.04-3.05, three pairs) - TriCoLoNet switches it off there and
-        # keeps it for 64^3 grids (22.39 -> 21.87 ms beside 12 x 224^2 views); TRICOLO_POOL_REDUCE=0 / 1 overrides.
+        # route + BatchNorm-backward sums in one launch (pool3d_bwd_route_reduce): Bi(V) 1.314 -> 1.302 ms.  Rounds 2-3 had TriCoLoNet switch
+        # it off beside an image tower at 32^3 (the shorter voxel chain made the replayed graph fold its branches differently: 3.30 -> 3.33 ms);
+        # since round 4 it stays on everywhere (tricolo_net.py).  The fused form calls finalize + apply itself, so the one-launch
+        # tri_bn_bwd_small (tensors of <= 512 rows) is reached through ops.bn_bwd only - by the image tower's smallest layers and by this
+        # tower with TRICOLO_POOL_REDUCE=0.
         env = os.environ.get("TRICOLO_POOL_REDUCE")
         fuse = self.fuse_pool_reduce if env is None else env == "1"
         for l in range(4, -1, -1):

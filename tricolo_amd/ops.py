@@ -10,6 +10,7 @@ current torch stream (so the calls can be captured into a HIP graph together wit
 """
 from __future__ import annotations
 
+import math
 import os
 
 import torch
@@ -24,6 +25,8 @@ _FMT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}        # act_fmt 
 # (6.1e-5): they are carried multiplied by 2^12 from the first 16-bit gradient tensor of a tower to the parameter-gradient
 # kernels, which multiply by 2^-12 (exact).  f16 max is 65504.
 F16_GRAD_SCALE = float(os.environ.get("TRICOLO_F16_GRAD_SCALE", "4096"))      # (a power of two: the un-scaling is exact)
+if not (F16_GRAD_SCALE >= 1.0 and math.frexp(F16_GRAD_SCALE)[0] == 0.5):
+    raise ValueError(f"TRICOLO_F16_GRAD_SCALE={F16_GRAD_SCALE!r}: must be a power of two >= 1 (the kernels divide it out exactly)")
 _default_precision = os.environ.get("TRICOLO_PRECISION", "bf16x3")
 
 

@@ -32,11 +32,16 @@ class FusedAdam(torch.optim.Optimizer):
         self._lr_host = None
         self._params = None
         self._pending_state = None
+        self._captures = 0
 
     # ------------------------------------------------------------------ state
-    def prepare(self):
-        """Allocate state (and flatten the parameters) ahead of the first step / HIP-graph capture."""
+    def prepare(self, captures: int = 0):
+        """Allocate state (and flatten the parameters) ahead of the first step / HIP-graph capture.  captures: number of HIP-graph
+        captures of the step the caller is going to make (each keeps one pinned gradient-pointer table; 32 are provided anyway)."""
+        self._captures = max(int(captures), getattr(self, "_captures", 0))
         if self._step_dev is not None:
+            while hasattr(self, "_seg_capture_pool") and len(self._seg_capture_pool) + len(self._seg_captured) < self._captures:
+                self._seg_capture_pool.append(torch.zeros((len(self._params),), dtype=torch.int64).pin_memory())
             return
         params = [p for g in self.param_groups for p in g["params"] if p.requires_grad]
         if not params:
@@ -78,7 +83,9 @@ class FusedAdam(torch.optim.Optimizer):
                 # buffer of its own that is never written again (the captured copy re-reads it on every replay)
                 self._seg_ring = [[torch.zeros((len(sizes),), dtype=torch.int64).pin_memory(), None] for _ in range(4)]
                 self._seg_ring_i = 0
-                self._seg_capture_pool = [torch.zeros((len(sizes),), dtype=torch.int64).pin_memory() for _ in range(8)]
+                # (bench.py captures one graph per resident batch - 8 by default -, tests and re-captures add more: 32 tables of a few KB;
+                #  prepare(captures=n) sizes it for a caller that knows better; an exhausted pool is reported, never silent)
+                self._seg_capture_pool = [torch.zeros((len(sizes),), dtype=torch.int64).pin_memory() for _ in range(max(32, self._captures))]
                 self._seg_captured = []
                 self._seg_ptr = torch.zeros((len(sizes),), dtype=torch.int64, device=dev)
                 self._seg_keep = None
@@ -152,6 +159,11 @@ class FusedAdam(torch.optim.Optimizer):
                 raise RuntimeError(f"FusedAdam keeps ONE step counter; the checkpoint holds different per-parameter steps {sorted(steps)}")
             if steps:
                 self._step_dev[0].fill_(steps.pop())
+            # the guard's record speaks in ATTEMPT numbers (applied + skipped): [2] = the attempt it flagged last (atomicMax), [3] = steps
+            # skipped whole.  Rewinding [0] alone would leave a stale flag above every attempt of the restored run until it catches up -
+            # those steps would fall back to the per-element guard, and the attempt that reaches the old flag would be skipped although
+            # its gradient is finite.  A restored optimizer starts a fresh record.
+            self._step_dev[1:].zero_()
         for g, gs in zip(self.param_groups, sd["param_groups"]):
             for k, v in gs.items():
                 if k != "params":
@@ -198,6 +210,12 @@ class FusedAdam(torch.optim.Optimizer):
         capturing = torch.cuda.is_current_stream_capturing()
         if capturing:
             if not self._seg_capture_pool:                           # (pinned memory cannot be allocated inside a capture)
+                if not getattr(self, "_pool_warned", False):
+                    import warnings
+                    warnings.warn("FusedAdam: no pinned gradient-pointer table left for this HIP-graph capture (more than "
+                                  f"{len(self._seg_captured)} captures); the capture records the packed-gradient path instead - "
+                                  "call prepare(captures=n) before capturing")
+                    self._pool_warned = True
                 return False
             host = self._seg_capture_pool.pop()
             host.copy_(torch.tensor(ptrs, dtype=torch.int64))

@@ -64,6 +64,11 @@ def fit(net, cfg, train_batches, val_batches=None, device="cuda", ckpt_path: str
             if rec["skipped_steps"] + rec["skipped_elements"] > seen:
                 log(f"[tricolo_amd.train] WARNING: {rec['skipped_steps']} optimizer step(s) / {rec['skipped_elements']} gradient element(s) skipped so far "
                     "because of inf / NaN gradients (f16 activation-gradient overflow?): lower ops.F16_GRAD_SCALE or train in bf16x3")
+            prev_sk, prev_step = (history[-1].get("skipped_steps", 0), history[-1]["global_step"]) if history else (0, 0)
+            if step > prev_step and rec["skipped_steps"] - prev_sk >= step - prev_step:
+                # the static scale does not back off like GradScaler: a persistent overflow would freeze the weights silently
+                raise RuntimeError(f"every optimizer step of epoch {epoch} was skipped for non-finite gradients: lower TRICOLO_F16_GRAD_SCALE "
+                                   "(a power of two) or train in bf16x3")
         lr = cosine_lr(cfg, epoch)
         if lr is not None:
             for g in opt.param_groups:
