@@ -1668,3 +1668,71 @@ def test_voxel_level1_brick_kernel(B, V, store, prec):
         xd, _, _, xdcl, _ = make_case(case, integer=True, seed=89)
         out2 = ops.conv_fwd(xdcl.to(DEV).to(store), g, packed)
         assert torch.equal(out2.cpu(), cl3(F.conv3d(xd, w, padding=1)).to(store))
+
+
+VOXG_CASES = [
+    # B, D, cin, cout: the bench shapes' levels 2-4 (32^3 x 32), config 2 (x 64), config 5's levels 3-4, small batches (fewer workgroups than
+    # CUs, partial last unit), odd batch sizes
+    (32, 8, 64, 128), (32, 4, 128, 256), (32, 2, 256, 512),
+    (64, 8, 64, 128), (64, 2, 256, 512),
+    (64, 8, 128, 256), (64, 4, 256, 512),
+    (3, 8, 64, 128), (5, 4, 128, 256), (7, 2, 256, 512), (1, 2, 64, 16),
+]
+
+
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("store,prec", STORE16, ids=STORE16_IDS)
+@pytest.mark.parametrize("B,D,cin,cout", VOXG_CASES, ids=[f"B{c[0]}_D{c[1]}_{c[2]}to{c[3]}" for c in VOXG_CASES])
+def test_voxel_coarse_grid_kernel(B, D, cin, cout, store, prec):
+    """conv_voxg_kernel (conv_voxg.hip): SubMConv3d on 2^3 / 4^3 / 8^3 grids (sparse_cnn.py:22-32) - a unit of whole samples staged in a
+    zero-padded LDS slab, the unit's active sites ranked in the kernel and gathered from the slab as MFMA rows, weights straight into
+    registers.  Integer data: active rows equal the masked dense convolution exactly, rows of inactive sites stay unwritten (and whatever
+    the input holds at inactive sites is ignored), the per-unit BatchNorm records sum to the active rows' column sums; the data gradient
+    (mirrored taps, transposed operand) equals autograd's at the active sites; every site active (512 rows per 8^3 sample: three passes)
+    is the plain convolution; an all-inactive mask writes nothing and zero statistics."""
+    case = ("voxg", B, (D, D, D), cin, cout, (3, 3, 3), 1, (1, 1, 1), "spconv")
+    x, w, wp, xcl, g = make_case(case, integer=True, seed=181)
+    assert g.brick(False, 2) and (g.kernel_family[(False, 2)] & 255) == 13 and (g.kernel_family[(True, 2)] & 255) == 13
+    m = _blob_mask(B, D, seed=183 + D, p_empty=0.15) if D > 2 else (torch.rand(B, D, D, D, generator=torch.Generator().manual_seed(7)) < 0.9)
+    mf = m.float()
+    M = B * D ** 3
+    mask = torch.zeros((M + 31) // 32 * 32, dtype=torch.uint8)
+    mask[:M] = m.reshape(M).to(torch.uint8)
+    act = m.reshape(M)
+    xm = x * mf[:, None]
+    ref = cl3(F.conv3d(xm, w, padding=1)).to(store).reshape(M, cout)
+    packed = ops.pack_weight(wp.to(DEV), g, prec)
+    dirty = xcl.clone().reshape(M, cin)
+    dirty[~act] = 5.0                                               # inactive input rows are never used, whatever they hold
+    junk = torch.full((B, D, D, D, cout), 777.0, dtype=store, device=DEV)
+    out, stats = ops.conv_fwd(dirty.view(B, D, D, D, cin).to(DEV).to(store), g, packed, row_mask=mask.to(DEV), want_stats=True, out=junk)
+    assert stats.shape[0] == g.num_mtiles[2]
+    o = out.cpu().reshape(M, cout)
+    assert torch.equal(o[act], ref[act]), f"max abs diff {(o[act].float() - ref[act].float()).abs().max().item()}"
+    assert bool((o[~act] == 777.0).all()), "rows of inactive sites must not be written"
+    exact = ref[act].double()
+    st = stats.cpu().double().sum(0)
+    np.testing.assert_allclose(st[0].numpy(), exact.sum(0).numpy(), rtol=1e-6, atol=1e-2)
+    np.testing.assert_allclose(st[1].numpy(), (exact ** 2).sum(0).numpy(), rtol=1e-6, atol=1e-2)
+    # data gradient at the active sites (what SparseCNNEncoder._backward_impl asks for)
+    dy = ints((B, D, D, D, cout), -2, 2, 185) * mf[..., None]
+    xr = xm.clone().requires_grad_()
+    F.conv3d(xr, w, padding=1).backward(cf3(dy))
+    refdx = cl3(xr.grad).to(store).reshape(M, cin)
+    dyd = dy.clone().reshape(M, cout)
+    dyd[~act] = -3.0
+    junk2 = torch.full((B, D, D, D, cin), 555.0, dtype=store, device=DEV)
+    dx = ops.conv_dgrad(dyd.view(B, D, D, D, cout).to(DEV).to(store), g, ops.pack_weight(wp.to(DEV), g, prec, transposed=True),
+                        row_mask=mask.to(DEV), out=junk2)
+    dxc = dx.cpu().reshape(M, cin)
+    assert torch.equal(dxc[act], refdx[act]) and bool((dxc[~act] == 555.0).all())
+    with pytest.raises(RuntimeError):                               # a compact row list is refused (the kernel walks the grid by the mask)
+        ops.conv_fwd(xcl.to(DEV).to(store), g, packed, rows=ops.mask_compact(mask.to(DEV), M))
+    if B <= 7:
+        out2, stats2 = ops.conv_fwd(xcl.to(DEV).to(store), g, packed, want_stats=True)      # no mask: every site active
+        full = cl3(F.conv3d(x, w, padding=1)).to(store)
+        assert torch.equal(out2.cpu(), full)
+        np.testing.assert_allclose(stats2.cpu().double().sum(0)[0].numpy(), full.double().reshape(M, cout).sum(0).numpy(), rtol=1e-6, atol=1e-2)
+        junk3 = torch.full((B, D, D, D, cout), 777.0, dtype=store, device=DEV)
+        out3, stats3 = ops.conv_fwd(xcl.to(DEV).to(store), g, packed, row_mask=torch.zeros_like(mask).to(DEV), want_stats=True, out=junk3)
+        assert bool((out3 == 777.0).all()) and float(stats3.abs().max()) == 0.0

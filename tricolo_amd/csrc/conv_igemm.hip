@@ -1916,6 +1916,8 @@ struct ConvPlan {
     int vox0_grid;
     int vox1;             // 1: conv_vox1_kernel (level 1 of the voxel tower, 32 -> 64 channels, 16-bit storage); records = vox1_grid
     int vox1_grid;
+    int voxg;             // 1: conv_voxg_kernel (conv_voxg.hip: SubMConv3d on 2^3 / 4^3 / 8^3 grids, forward and data gradient, 16-bit storage);
+    int voxg_units, voxg_ct, voxg_spu;        // records = units
     int c64;              // 1: conv_c64_kernel (conv_c64.hip: 64 -> 64 channels, 2D 3x3 / 1 / pad 1, 16-bit storage); records = c64_grid
     int c64_grid;
     int s2f, s2f_grid;    // 1: conv_s2f_kernel (conv_c64.hip: forward of the 64 -> 128 channel 3x3 / 2 layer); records = s2f_grid
@@ -2078,6 +2080,14 @@ static ConvPlan conv_make_plan(int B, int ID, int IH, int IW, int cin, int OD, i
         TriVox1Geom v1;
         if (split_mode == 2 && tri_internal_vox1_geometry(B, ID, IH, IW, cin, OD, OH, OW, cout, KD, KH, KW, stride, pd, ph, pw, &v1)) {
             pl.vox1 = 1; pl.vox1_grid = v1.grid; pl.bn = 64; pl.nunits = 27; pl.ksplit = 1; pl.per_split = 27;
+            return pl;
+        }
+        TriVoxgGeom vgg;
+        if (split_mode == 2 && tri_internal_voxg_geometry(B, ID, IH, IW, cin, OD, OH, OW, cout, KD, KH, KW, stride, pd, ph, pw, &vgg)) {
+            // coarse voxel grids: activations stationary in LDS, weights straight into MFMA registers (forward and data gradient;
+            // the launch walks the grid by the site mask, one BatchNorm record per unit of samples)
+            pl.voxg = 1; pl.voxg_units = vgg.nunits; pl.voxg_ct = vgg.ct; pl.voxg_spu = vgg.spu;
+            pl.bn = vgg.ct; pl.nunits = kpad / 32; pl.ksplit = 1; pl.per_split = pl.nunits;
             return pl;
         }
     }
@@ -2404,6 +2414,16 @@ static int conv_dispatch(ConvArgs& a, int act_fmt, void* workspace, size_t works
         tri_internal_vox1_geometry(a.B, a.ID, a.IH, a.IW, a.Cin, a.OD, a.OH, a.OW, a.Cout, a.KD, a.KH, a.KW, a.stride, a.pd, a.ph, a.pw, &v1);
         return tri_internal_vox1_launch(v1, a.B, a.in, a.w_hi, a.out, a.row_mask, a.stats, act_fmt, stream);
     }
+    if (pl.voxg) {
+        if (a.row_count || a.bias || a.act != 0 || a.accumulate) {
+            tri_set_error("conv: this layer runs conv_voxg_kernel (tri_conv_kernel_family == 13): pass the site mask as row_mask, no row list, "
+                          "bias, activation or accumulate");
+            return TRI_ERR_ARG;
+        }
+        TriVoxgGeom vgg;
+        tri_internal_voxg_geometry(a.B, a.ID, a.IH, a.IW, a.Cin, a.OD, a.OH, a.OW, a.Cout, a.KD, a.KH, a.KW, a.stride, a.pd, a.ph, a.pw, &vgg);
+        return tri_internal_voxg_launch(vgg, a.B, a.Cin, a.Cout, a.Kpad, a.in, a.w_hi, a.out, a.row_mask, a.stats, a.transposed, act_fmt, stream);
+    }
     if (pl.c64) {
         if (!a.row_mask && !a.row_count && !a.bias && a.act == 0) {
             TriC64Geom cg;
@@ -2472,6 +2492,7 @@ extern "C" int tri_conv_num_records(const TriConvDesc* d, int split3, int row_li
     if (pl.stem) return pl.stem_grid;
     if (pl.vox0) return pl.vox0_grid;
     if (pl.vox1) return pl.vox1_grid;
+    if (pl.voxg) return pl.voxg_units;
     if (pl.c64) return pl.c64_grid;
     if (pl.s2f) return pl.s2f_grid;
     if (pl.halo) return pl.h_wgrec ? pl.h_grid / (d->Cout / 64) : pl.h_mtiles;
@@ -2488,6 +2509,7 @@ extern "C" int tri_conv_kernel_family(const TriConvDesc* d, int transposed, int 
     if (pl.stem && !transposed) return 4 | (64 << 8);
     if (pl.vox0 && !transposed) return 6 | (32 << 8);
     if (pl.vox1 && !transposed) return 7 | (64 << 8);
+    if (pl.voxg) return 13 | (pl.voxg_ct << 8) | (pl.voxg_spu << 24);      // (bits 24..: samples per unit)
     if (pl.c64) return 9 | (64 << 8);
     if (pl.s2d && transposed) return 10 | (64 << 8);
     if (pl.s2f && !transposed) return 11 | (128 << 8);

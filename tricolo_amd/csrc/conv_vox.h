@@ -25,6 +25,15 @@ bool tri_internal_vox1_geometry(int B, int ID, int IH, int IW, int cin, int OD, 
 int tri_internal_vox1_launch(const TriVox1Geom& g, int B, const void* in, const void* w, void* out, const uint8_t* mask, float* stats, int act_fmt,
                              hipStream_t stream);
 
+// the SubMConv3d layers on the coarse grids (2^3 / 4^3 / 8^3 sites per sample, 64 | cin, 16 | cout, 16-bit storage): conv_voxg_kernel
+// (conv_voxg.hip), forward and data gradient over the SITE MASK; spu samples per unit, nunits units = BatchNorm records, ct output
+// channels per workgroup
+struct TriVoxgGeom { int D, spu, nunits, ct, grid, smem; };
+bool tri_internal_voxg_geometry(int B, int ID, int IH, int IW, int cin, int OD, int OH, int OW, int cout, int KD, int KH, int KW, int stride,
+                                int pd, int ph, int pw, TriVoxgGeom* g);
+int tri_internal_voxg_launch(const TriVoxgGeom& g, int B, int cin, int cout, int kpad, const void* in, const void* w, void* out, const uint8_t* mask,
+                             float* stats, int transposed, int act_fmt, hipStream_t stream);
+
 struct TriC64Geom { int W, TY, nbricks, grid; };
 // a 64 -> 64 channel 3x3 / 1 / pad 1 2D layer on 16- / 32- / 64-pixel-wide images in a 16-bit storage mode (layer1 of the ResNet trunk):
 // conv_c64_kernel (conv_c64.hip), forward and data gradient; g->grid = persistent workgroups = BatchNorm records of the launch

@@ -1,0 +1,426 @@
+// conv_voxg_kernel: the SubMConv3d layers of the COARSE voxel grids (2^3, 4^3, 8^3 sites per sample: levels 2-4 of the 32^3 tower,
+// levels 3-4 of the 64^3 tower; sparse_cnn.py:22-32) and their data gradients, 16-bit storage, gfx950.
+//
+// Through conv_dma_kernel these layers are im2col GEMMs over a compact row list: every site row crosses the L2 -> LDS path once per
+// tap (27 x), every 128 x 64 tile re-streams its weight panel through LDS, and the small ones (32^3 inputs: 245 .. 4,054 rows) run
+// split-K with a finish launch: 10 + 5 us per level at the bench shape, 47 / 50 us (324 / 270 TFLOP/s) for levels 3 / 4 of 64^3 x 64
+// - both bound by the bytes a CU can pull from L2 (~29 B/clk), at 43 FLOP per byte.  Here the ACTIVATIONS are stationary in LDS and
+// the WEIGHTS go straight from L2 into MFMA registers:
+//   * a workgroup owns a UNIT - `spu` whole samples of the dense grid (one 8^3 sample, 2-4 4^3 samples, 4-32 2^3 samples) - and CT
+//     output channels.  It reads the unit's site mask, ranks the active sites (ballot / popcount: no row list from outside) and
+//     stages the unit's sites, 32 input channels at a time, in a zero-PADDED slab: padded coordinate (z, y, x) of a (D+2) x (D+2) x
+//     (D+1) box per sample (row pitch D + 1: the right halo of a row is the left halo of the next), so the neighbour of a site under
+//     tap (kd, kh, kw) is the site ((kd * (D+2)) + kh) * (D+1) + kw further on - a CONSTANT, whatever the site: no validity masks,
+//     no coordinate arithmetic in the MFMA loop;
+//   * slab layout: the 64 bytes of a site's 32-channel chunk are split into two 32-byte halves kept in two planes
+//     ([half][site][32 B]).  Lane (fr, fq) of a 16-row B fragment reads 16 bytes at  half(fq >> 1) + site(fr) * 32 + (fq & 1) * 16:
+//     for 16 consecutive sites the 16 lanes of every ds_read_b128 service group land on 16 distinct 16-byte bank slots
+//     ((2 s + (fq & 1)) mod 16) - conflict-free WITHOUT a swizzle, so a tap is an address offset and nothing else;
+//   * the MFMA rows are the ACTIVE sites only (16 per tile, in raster order: mostly x-consecutive runs) - no padded or inactive row is
+//     multiplied (the round-3 slab attempt for these levels multiplied every padded site of a run and lost: NOTES_vox.md);
+//   * the four waves split the workgroup's (output-channel tile, k-step) space: WC waves along the channels (TN tiles of 16 each),
+//     WK waves along the taps (tap j of a chunk belongs to wave j mod WK; partial sums are added through LDS at the end).  Every
+//     weight fragment is needed by exactly ONE wave, so it is loaded from L2 straight into that wave's registers as an MFMA A
+//     fragment (16 rows x 64 B per instruction, groups of 7 taps, the next group in flight under the current group's MFMAs): no
+//     LDS traffic, no barrier per k-step - one barrier per 32-channel chunk (the slab is double-buffered: the next chunk's sites are
+//     requested before the current chunk's MFMAs and written to the other buffer after them);
+//   * units with more than 16 * NRT active sites run in passes (weights re-streamed per pass);
+//   * epilogue: partial sums of the WK waves added in LDS, rounded to the storage type, stored as 8-byte pieces (rows of inactive
+//     sites are never written), BatchNorm sums of the stored values: one [2][CT] slice of record `unit` per workgroup.
+// Bytes a CU pulls per FLOP: weights CT x K once per unit, slab once per (unit, channel tile): 120-250 FLOP per byte.
+#include "common.h"
+#include <stdlib.h>
+#include <type_traits>
+#include "conv_vox.h"
+
+int tri_internal_num_cus();                                                   // conv_igemm.hip
+
+struct VoxgArgs {
+    const void* in;            // [B, D, D, D, Cin] 16-bit (values at inactive sites are ignored)
+    const void* w;             // packed operand rows [Cout][Kpad], k = tap * Cin + channel
+    void* out;                 // [B, D, D, D, Cout]; rows of inactive sites are not written
+    const uint8_t* mask;       // [B * D^3] site mask, or NULL (every site active)
+    float* stats;              // [nunits][2][Cout] or NULL
+    int B, D, Cin, Cout, Kpad;
+    int spu, nunits;           // samples per unit, units
+    int mirror;                // 1: data gradient (tap (kd, kh, kw) reads the site at -(kd-1, kh-1, kw-1))
+    unsigned in_bytes, w_bytes;
+};
+
+template <int N>
+__device__ __forceinline__ float voxg_row_ror(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, false));
+}
+
+#define VOXG_MAXROWS 512                                                      // active sites of a unit (8^3 sample, all active)
+#define VOXG_G 7                                                              // taps per weight-fragment group
+
+// LDS: row tables + unit mask (VOXG_TAB bytes) | [2 slab buffers][2 halves][NS sites x 32 B]; the epilogue scratch aliases the slab
+#define VOXG_TAB (2 * VOXG_MAXROWS * 4 + 16 * 4 + 512 + 192)                  // 4,864: a multiple of 256
+struct VoxgGeom {
+    int P, RY, PZ, sample_sites, NS, half_bytes, buf_bytes;
+};
+__host__ __device__ inline VoxgGeom voxg_geom(int D, int spu) {
+    VoxgGeom g;
+    g.P = D + 1; g.RY = D + 2; g.PZ = D + 2;
+    g.sample_sites = g.PZ * g.RY * g.P;
+    g.NS = spu * g.sample_sites + g.P + 2;                                    // (+ the far corner of the last sample's last site)
+    g.half_bytes = (g.NS * 32 + 255) / 256 * 256 + 128;                       // 128 mod 256: the two halves of a site land on different banks when written
+    g.buf_bytes = 2 * g.half_bytes;
+    return g;
+}
+
+template <typename AT, int TN, int WC, int WK, int NRT>
+__global__ __launch_bounds__(256, 1) void conv_voxg_kernel(const VoxgArgs p) {
+    typedef typename OpOf<AT>::E E;
+    typedef Mma<E> MM;
+    typedef typename MM::v8 v8;
+    static_assert(WC * WK == 4, "four waves");
+    constexpr int CT = WC * TN * 16;                                          // output channels of a workgroup
+    constexpr int MAXL = 8;                                                   // 16-byte slab pieces per thread and chunk (512 sites x 4 / 256)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), fr = lane & 15, fq = lane >> 4;
+    const int wc = wave / WK, wk = wave - wc * WK;
+    const int D = p.D, D3 = D * D * D;
+    const VoxgGeom G = voxg_geom(D, p.spu);
+    char* const slab = smem + VOXG_TAB;
+    int* const row_lds = (int*)smem;                                          // [VOXG_MAXROWS] byte offset (site * 32) of the row's (-1,-1,-1) corner
+    int* const row_glob = row_lds + VOXG_MAXROWS;                             // [VOXG_MAXROWS] global site index
+    int* const wcnt = row_glob + VOXG_MAXROWS;                                // [8] per-(half, wave) counts of the ranking
+    uint8_t* const lmask = (uint8_t*)(wcnt + 16);                             // [512] site mask of the unit
+
+    // ---- workgroup -> (unit, channel tile): workgroups of one channel tile share an XCD (blockIdx % 8), so its weights stay in that L2
+    const int nct = p.Cout / CT;
+    int unit, ctile;
+    {
+        const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
+        if (nct >= 8) { const int q = nct >> 3; ctile = xcd + 8 * (j % q); unit = j / q; }
+        else { const int r = 8 / nct; ctile = xcd % nct; unit = xcd / nct + r * j; }
+    }
+    if (unit >= p.nunits) return;
+    const int b0 = unit * p.spu;
+    const int ns = min(p.spu, p.B - b0);                                      // samples of this unit
+    const int nsites = ns * D3;                                               // dense sites of this unit (<= 512)
+    const int n0 = ctile * CT;
+
+    // ---- weight fragments: wave (wc, wk) owns output channels n0 + (wc * TN + tn) * 16 + fr and the taps wk, wk + WK, ...
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+    unsigned wrow[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) wrow[tn] = (unsigned)(((n0 + (wc * TN + tn) * 16 + fr) * p.Kpad + fq * 8) * 2);
+    const int nchunks = p.Cin >> 5;
+    constexpr int TAPS_W = (27 - 1) / WK + 1;                                 // taps of wave wk = 0 (the others have TAPS_W or TAPS_W - 1)
+    constexpr int NGRP = (TAPS_W + VOXG_G - 1) / VOXG_G;                      // groups of 7 taps per chunk
+    const int mytaps = (27 - wk + WK - 1) / WK;
+    v8 wf[2][VOXG_G][TN];
+    auto load_group = [&](int set, int chunk, int grp) {
+#pragma unroll
+        for (int i = 0; i < VOXG_G; ++i) {
+            const int jt = grp * VOXG_G + i;                                  // index among this wave's taps
+            const int tap = wk + jt * WK;
+            const bool ok = jt < mytaps;
+            const unsigned koff = (unsigned)((tap * p.Cin + chunk * 32) * 2);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+                wf[set][i][tn] = __builtin_bit_cast(v8, __builtin_amdgcn_raw_buffer_load_b128(wrs, ok ? wrow[tn] + koff : 0x80000000u, 0, 0));
+        }
+    };
+    load_group(0, 0, 0);                                                      // in flight under the whole set-up
+
+    // ---- slab pieces of this thread: piece e = t + 256 u is the 16-byte quarter (e & 3) of dense site (e >> 2)
+    const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    unsigned src[MAXL];
+    int dst[MAXL];
+#pragma unroll
+    for (int u = 0; u < MAXL; ++u) {
+        const int e = t + 256 * u, s = e >> 2, q = e & 3;
+        const bool ok = s < nsites;
+        const int bl = s / D3, r = s - bl * D3;
+        const int z = r / (D * D), y = (r / D) % D, x = r % D;
+        const int sp = ((bl * G.PZ + z + 1) * G.RY + y + 1) * G.P + x + 1;    // padded site
+        dst[u] = ok ? (q >> 1) * G.half_bytes + sp * 32 + (q & 1) * 16 : -1;
+        src[u] = ok ? (unsigned)((((size_t)b0 * D3 + s) * p.Cin + q * 8) * 2) : 0x80000000u;
+    }
+    uint4 pre[MAXL];
+    auto slab_request = [&](int chunk) {
+#pragma unroll
+        for (int u = 0; u < MAXL; ++u)
+            pre[u] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(irs, src[u] == 0x80000000u ? src[u] : src[u] + chunk * 64, 0, 0));
+    };
+    slab_request(0);
+
+    // ---- site mask of the unit (two bytes per thread), zero fill of both slab buffers (the padding is never written again)
+    auto zero_fill = [&]() {
+        for (int i = t * 16; i < 2 * G.buf_bytes; i += 256 * 16) *(uint4*)(slab + i) = make_uint4(0u, 0u, 0u, 0u);
+    };
+    {
+        uint8_t m0 = 0, m1 = 0;
+        if (t < nsites) m0 = p.mask ? p.mask[(size_t)b0 * D3 + t] : 1;
+        if (t + 256 < nsites) m1 = p.mask ? p.mask[(size_t)b0 * D3 + t + 256] : 1;
+        zero_fill();
+        lmask[t] = m0; lmask[t + 256] = m1;
+        // rank of every active site in raster order: pass 0 = sites 0..255, pass 1 = sites 256..511
+        const unsigned long long b0m = __ballot(m0 != 0), b1m = __ballot(m1 != 0);
+        if (lane == 0) { wcnt[wave] = __popcll(b0m); wcnt[4 + wave] = __popcll(b1m); }
+        __syncthreads();
+        int base0 = 0, base1 = 0, tot0 = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) { base0 += wcnt[w]; base1 += wcnt[4 + w]; }
+            tot0 += wcnt[w];
+        }
+        const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int s = t + 256 * h;
+            if (h ? m1 : m0) {
+                const int rk = h ? tot0 + base1 + __popcll(b1m & below) : base0 + __popcll(b0m & below);
+                const int bl = s / D3, r = s - bl * D3;
+                const int z = r / (D * D), y = (r / D) % D, x = r % D;
+                row_lds[rk] = (((bl * G.PZ + z) * G.RY + y) * G.P + x) * 32;  // the (-1, -1, -1) corner of the site's neighbourhood
+                row_glob[rk] = b0 * D3 + s;
+            }
+        }
+    }
+    __syncthreads();                                                          // zero fill + tables + masks visible
+    int nrows = 0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) nrows += wcnt[w];
+    if (nrows == 0) {                                                         // nothing active in this unit (the same answer in every wave)
+        if (p.stats && t < 2 * CT) p.stats[((size_t)unit * 2 + t / CT) * p.Cout + n0 + t % CT] = 0.f;
+        return;
+    }
+    auto slab_commit = [&](int buf) {                                         // inactive sites contribute zeros whatever the tensor holds there
+        char* const base = slab + buf * G.buf_bytes;
+#pragma unroll
+        for (int u = 0; u < MAXL; ++u)
+            if (dst[u] >= 0) {
+                const bool on = lmask[(t + 256 * u) >> 2] != 0;
+                *(uint4*)(base + dst[u]) = on ? pre[u] : make_uint4(0u, 0u, 0u, 0u);
+            }
+    };
+
+    const int lane_part = (fq >> 1) * G.half_bytes + (fq & 1) * 16;
+    float cs[TN][4], cq[TN][4];                                               // BatchNorm sums of this wave's epilogue share
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { cs[tn][r] = 0.f; cq[tn][r] = 0.f; }
+
+    const int npass = (nrows + 16 * NRT - 1) / (16 * NRT);
+#pragma unroll 1
+    for (int pass = 0; pass < npass; ++pass) {
+        const int r0 = pass * 16 * NRT;
+        const int nrt = min(NRT, (nrows - r0 + 15) >> 4);
+        int lbase[NRT];
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt) {
+            const int r = r0 + rt * 16 + fr;
+            lbase[rt] = (r < nrows ? row_lds[r] : 0) + lane_part;             // rows past the end read padding (zeros)
+        }
+        f32x4 acc[NRT][TN];
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) acc[rt][tn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (pass > 0) {
+            // the previous pass's epilogue scratch lay over the slab: once every wave is done with it, the padding is zeroed again
+            slab_request(0);
+            load_group(0, 0, 0);
+            __syncthreads();
+            zero_fill();
+            __syncthreads();
+        }
+        slab_commit(0);
+        __syncthreads();
+
+        // one 32-channel chunk: NGRP groups of 7 taps.  The register set of a group's weight fragments alternates; two chunks per loop
+        // iteration keep that index a compile-time constant (an odd NGRP would otherwise make it a run-time one: scratch memory)
+        auto chunk_body = [&](auto S0, const int c) {
+            constexpr int s0 = decltype(S0)::value;
+            const char* const sb = slab + (c & 1) * G.buf_bytes;
+            if (c + 1 < nchunks) slab_request(c + 1);
+#pragma unroll
+            for (int g = 0; g < NGRP; ++g) {
+                const int set = (s0 + g) & 1;
+                // the next group's weight fragments fly under this group's MFMAs
+                if (g + 1 < NGRP) load_group(set ^ 1, c, g + 1);
+                else if (c + 1 < nchunks) load_group(set ^ 1, c + 1, 0);
+#pragma unroll
+                for (int i = 0; i < VOXG_G; ++i) {
+                    const int jt = g * VOXG_G + i;
+                    if (jt < mytaps) {
+                        const int tap = wk + jt * WK;
+                        int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+                        if (p.mirror) { kd = 2 - kd; kh = 2 - kh; kw = 2 - kw; }
+                        const int toff = ((kd * G.RY + kh) * G.P + kw) * 32;
+                        v8 bf[NRT];
+#pragma unroll
+                        for (int rt = 0; rt < NRT; ++rt)
+                            if (rt < nrt) bf[rt] = *(const v8*)(sb + lbase[rt] + toff);
+#pragma unroll
+                        for (int rt = 0; rt < NRT; ++rt)
+                            if (rt < nrt) {
+#pragma unroll
+                                for (int tn = 0; tn < TN; ++tn) acc[rt][tn] = MM::mma(wf[set][i][tn], bf[rt], acc[rt][tn]);
+                            }
+                    }
+                }
+            }
+            if (c + 1 < nchunks) {
+                slab_commit((c + 1) & 1);                                     // (that buffer was last read in chunk c - 1: every wave is past it)
+                __syncthreads();
+            }
+        };
+#pragma unroll 1
+        for (int c = 0; c < nchunks; c += 2) {                                // (Cin % 64 == 0: an even number of chunks)
+            chunk_body(std::integral_constant<int, 0>{}, c);
+            chunk_body(std::integral_constant<int, NGRP & 1>{}, c + 1);
+        }
+
+        // ---- partial sums of the WK tap shares: through LDS (the slab is idle now), tile (rt, tn) of channel column wc summed and
+        // finished by wave wk' = tile index mod WK of that column
+        __syncthreads();
+        f32x4* const red = (f32x4*)slab;                                      // [wave][rt][tn][64 lanes]
+        if (WK > 1) {
+#pragma unroll
+            for (int rt = 0; rt < NRT; ++rt)
+                if (rt < nrt) {
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) red[((wave * NRT + rt) * TN + tn) * 64 + lane] = acc[rt][tn];
+                }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                if (rt >= nrt || (WK > 1 && ((rt * TN + tn) % WK) != wk)) continue;
+                f32x4 v = acc[rt][tn];
+                if (WK > 1) {
+                    v = red[(((wc * WK) * NRT + rt) * TN + tn) * 64 + lane];
+#pragma unroll
+                    for (int w = 1; w < WK; ++w) v += red[(((wc * WK + w) * NRT + rt) * TN + tn) * 64 + lane];
+                }
+                const int r = r0 + rt * 16 + fr;
+                if (r < nrows) {
+                    typedef E e4 __attribute__((ext_vector_type(4)));
+                    const e4 h = __builtin_convertvector(v, e4);
+                    *(e4*)((AT*)p.out + (size_t)row_glob[r] * p.Cout + n0 + (wc * TN + tn) * 16 + fq * 4) = h;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { const float f = (float)h[q]; cs[tn][q] += f; cq[tn][q] += f * f; }
+                }
+            }
+    }
+
+    // ---- BatchNorm sums: over the 16 sites of a fragment row (DPP), then over the waves that finished tiles of the same channels
+    if (p.stats) {
+        __syncthreads();
+        float* const sred = (float*)slab;                                     // [wave][TN][16 channels][2]
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float s_ = cs[tn][q], q_ = cq[tn][q];
+                s_ += voxg_row_ror<8>(s_); q_ += voxg_row_ror<8>(q_);
+                s_ += voxg_row_ror<4>(s_); q_ += voxg_row_ror<4>(q_);
+                s_ += voxg_row_ror<2>(s_); q_ += voxg_row_ror<2>(q_);
+                s_ += voxg_row_ror<1>(s_); q_ += voxg_row_ror<1>(q_);
+                if (fr == 0) {
+                    sred[((wave * TN + tn) * 16 + fq * 4 + q) * 2 + 0] = s_;
+                    sred[((wave * TN + tn) * 16 + fq * 4 + q) * 2 + 1] = q_;
+                }
+            }
+        __syncthreads();
+        if (t < CT) {
+            const int cw = t / (TN * 16), rem = t - cw * TN * 16;             // channel column (wc), (tn, channel) inside it
+            float s_ = 0.f, q_ = 0.f;
+#pragma unroll
+            for (int w = 0; w < WK; ++w) {
+                s_ += sred[(((cw * WK + w) * TN) * 16 + rem) * 2 + 0];
+                q_ += sred[(((cw * WK + w) * TN) * 16 + rem) * 2 + 1];
+            }
+            p.stats[((size_t)unit * 2 + 0) * p.Cout + n0 + t] = s_;
+            p.stats[((size_t)unit * 2 + 1) * p.Cout + n0 + t] = q_;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ plan + launch
+static bool voxg_disabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("TRICOLO_NO_VOXG"); v = (e && e[0] == '1') ? 1 : 0; }      // A/B switch: these levels stay on conv_dma_kernel
+    return v == 1;
+}
+
+bool tri_internal_voxg_geometry(int B, int ID, int IH, int IW, int cin, int OD, int OH, int OW, int cout, int KD, int KH, int KW, int stride,
+                                int pd, int ph, int pw, TriVoxgGeom* g) {
+    if (voxg_disabled()) return false;
+    const int D = ID;
+    if (IH != D || IW != D || OD != D || OH != D || OW != D || (D != 2 && D != 4 && D != 8)) return false;
+    if (KD != 3 || KH != 3 || KW != 3 || stride != 1 || pd != 1 || ph != 1 || pw != 1) return false;
+    if (cin % 64 != 0 || cout % 16 != 0) return false;                        // (two 32-channel chunks per loop iteration)
+    if ((long)B * D * D * D * cin * 2 >= (1L << 31) || (long)cout * 27 * cin * 2 >= (1L << 31)) return false;   // 32-bit buffer offsets
+    const int D3 = D * D * D;
+    // samples per unit: about 128 active sites at the occupancies these grids have (25 % at 8^3, 45 % at 4^3, 95 % at 2^3), at most 512
+    // dense sites, halved while the launch would leave CUs without a workgroup of 16 output channels
+    const double occ = D == 8 ? 0.25 : (D == 4 ? 0.45 : 0.95);
+    int spu = 1;
+    while (2 * spu * D3 <= 512 && occ * 2 * spu * D3 <= 128.0 && 2 * spu <= B) spu *= 2;
+    const int cus = tri_internal_num_cus();
+    while (spu > 1 && (long)((B + spu - 1) / spu) * (cout / 16) < cus) spu /= 2;
+    const int nunits = (B + spu - 1) / spu;
+    // output channels per workgroup: as many as keep one workgroup per CU (fewer weight re-reads of the slab, fewer partial-sum waves)
+    int ct = 16;
+    while (ct < 128 && cout % (2 * ct) == 0 && (long)nunits * (cout / (2 * ct)) >= cus) ct *= 2;
+    static int force_ct = -1, force_spu = -1;                                 // tuning aids
+    if (force_ct < 0) { const char* e = getenv("TRICOLO_VOXG_CT"); force_ct = e ? atoi(e) : 0; }
+    if (force_spu < 0) { const char* e = getenv("TRICOLO_VOXG_SPU"); force_spu = e ? atoi(e) : 0; }
+    if (force_ct == 16 || force_ct == 32 || force_ct == 64 || force_ct == 128) { if (cout % force_ct == 0) ct = force_ct; }
+    if (force_spu > 0 && force_spu * D3 <= 512) { spu = force_spu; }
+    g->D = D; g->spu = spu; g->nunits = (B + spu - 1) / spu; g->ct = ct;
+    const int nct = cout / ct;
+    if (nct >= 8) { if (nct % 8) return false; g->grid = g->nunits * nct; }
+    else { if (8 % nct) return false; const int r = 8 / nct; g->grid = 8 * ((g->nunits + r - 1) / r); }
+    const VoxgGeom vg = voxg_geom(D, spu);
+    g->smem = VOXG_TAB + 2 * vg.buf_bytes;
+    if (g->smem > 160 * 1024) return false;
+    return true;
+}
+
+template <typename AT, int TN, int WC, int WK, int NRT>
+static int voxg_launch_t(const VoxgArgs& a, const TriVoxgGeom& g, hipStream_t stream) {
+    // the epilogue scratch (partial sums of every wave, statistics) aliases the slab buffers
+    const size_t need = (size_t)4 * NRT * TN * 64 * sizeof(f32x4);
+    const VoxgGeom vg = voxg_geom(g.D, g.spu);
+    size_t smem = g.smem;
+    if (need > (size_t)2 * vg.buf_bytes) smem += need - 2 * vg.buf_bytes;     // (tiny slabs: 2^3 grids)
+    if (smem > 160 * 1024) { tri_set_error("conv(voxg): LDS budget exceeded"); return TRI_ERR_UNSUPPORTED; }
+    static size_t attr = 0;
+    if (smem > attr) {
+        hipFuncSetAttribute((const void*)conv_voxg_kernel<AT, TN, WC, WK, NRT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = 160 * 1024;
+    }
+    conv_voxg_kernel<AT, TN, WC, WK, NRT><<<g.grid, 256, smem, stream>>>(a);
+    return tri_check_launch("tri_conv(voxg)");
+}
+
+int tri_internal_voxg_launch(const TriVoxgGeom& g, int B, int cin, int cout, int kpad, const void* in, const void* w, void* out, const uint8_t* mask,
+                             float* stats, int transposed, int act_fmt, hipStream_t stream) {
+    VoxgArgs a{};
+    a.in = in; a.w = w; a.out = out; a.mask = mask; a.stats = stats;
+    a.B = B; a.D = g.D; a.Cin = cin; a.Cout = cout; a.Kpad = kpad;
+    a.spu = g.spu; a.nunits = g.nunits; a.mirror = transposed ? 1 : 0;
+    a.in_bytes = (unsigned)((size_t)B * g.D * g.D * g.D * cin * 2);
+    a.w_bytes = (unsigned)((size_t)cout * kpad * 2);
+#define TRI_VOXG(CT_, TN_, WC_, WK_)                                                                                      \
+    if (g.ct == CT_)                                                                                                      \
+        return act_fmt == TRI_FMT_F16 ? voxg_launch_t<f16_t, TN_, WC_, WK_, 12>(a, g, stream) : voxg_launch_t<bf16_t, TN_, WC_, WK_, 12>(a, g, stream);
+    TRI_VOXG(16, 1, 1, 4)
+    TRI_VOXG(32, 2, 1, 4)
+    TRI_VOXG(64, 2, 2, 2)
+    TRI_VOXG(128, 2, 4, 1)
+#undef TRI_VOXG
+    tri_set_error("conv(voxg): channel tile not instantiated");
+    return TRI_ERR_UNSUPPORTED;
+}

@@ -174,9 +174,9 @@ class SparseCNNEncoder(TriModule):
             grads[3 * l + 1], grads[3 * l + 2] = dgamma, dbeta
             if l > 0:
                 pt = self._packed[(l, True)]
-                if compact:
+                if compact and not g.brick(True, ops._conv_mode(dy, pt[1])):
                     dx = ops.conv_dgrad(dy, g, pt, rows=rows)                   # only the active input sites are computed / written
-                else:
+                else:                                                          # (conv_voxg_kernel walks the coarse grids by the site mask)
                     dx = ops.conv_dgrad(dy, g, pt, row_mask=mask)
         if batch is not None:
             batch.flush()

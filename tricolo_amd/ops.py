@@ -139,6 +139,8 @@ def _igemm_symbol(g, transposed, split, t):
         return f"conv_vox0_kernel<{_TNAME[t.dtype]}>"
     if fam == 7:
         return f"conv_vox1_kernel<{_TNAME[t.dtype]}>"
+    if fam == 13:
+        return f"conv_voxg_kernel<{bn}, {_TNAME[t.dtype]}>"                # (forward and data gradient under one name)
     if fam == 9:
         return f"conv_c64_kernel<{_TNAME[t.dtype]}>"                 # (forward / data gradient (+ accumulate) under one name)
     if fam == 10:
@@ -257,9 +259,15 @@ class ConvGeom:
         return t
 
     def brick(self, transposed: bool, mode: int) -> bool:
-        """True when tri_conv_fwd runs this layer on a brick kernel of conv_vox.hip: such launches take the site mask as row_mask
-        (rows of inactive sites are then neither computed nor written), not a compact row list."""
-        return (self.kernel_family[(transposed, mode)] & 255) in (6, 7)
+        """True when tri_conv_fwd / tri_conv_dgrad runs this layer on a kernel that walks the dense grid by the SITE MASK (the brick kernels
+        of conv_vox.hip, conv_voxg_kernel on the coarse grids): such launches take the mask as row_mask (rows of inactive sites are then
+        neither computed nor written), not a compact row list."""
+        return (self.kernel_family[(transposed, mode)] & 255) in (6, 7, 13)
+
+    def voxg_spu(self, transposed: bool, mode: int) -> int:
+        """Samples per unit of conv_voxg_kernel for this layer (0: another kernel runs it)."""
+        code = self.kernel_family[(transposed, mode)]
+        return (code >> 24) & 127 if (code & 255) == 13 else 0
 
     def splitk(self, transposed: bool, mode: int) -> bool:
         """True when tri_conv_fwd / tri_conv_dgrad runs this layer split-K in plan `mode` (_conv_mode): such launches take
