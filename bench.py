@@ -232,7 +232,15 @@ def voxel_fwd_roofline(net, batch, B, nrep=3):
         tiles = (active + 127) // 128 if used_rows else int(m.view(-1, 128).any(dim=1).sum().item())
         exec_rows = tiles * 128
         brick = recs[l][0].startswith("conv_vox")
-        if brick:                                      # brick kernels (conv_vox.hip) execute the 16-site x-runs that hold an active site
+        spu = enc._geom(B, l).voxg_spu(False, 2) if recs[l][0].startswith("conv_voxg") else 0
+        if spu:                                        # conv_voxg_kernel: 16-row MFMA tiles over each unit's ranked active sites
+            per_unit = m[:M].view(B, -1).sum(dim=1).to(torch.int64)
+            if B % spu:
+                per_unit = torch.cat([per_unit, per_unit.new_zeros(spu - B % spu)])
+            per_unit = per_unit.view(-1, spu).sum(dim=1)
+            exec_rows = int((((per_unit + 15) // 16) * 16).sum().item())
+            tiles = (exec_rows + 127) // 128
+        elif brick:                                    # brick kernels (conv_vox.hip) execute the 16-site x-runs that hold an active site
             exec_rows = 16 * int(m.view(-1, 16).any(dim=1).sum().item())
             tiles = (exec_rows + 127) // 128
         ms = sorted(recs[r * per + l][2] for r in range(nrep))[nrep // 2]

@@ -1557,7 +1557,7 @@ def _blob_mask(B, V, seed, p_empty=0.3):
         hi = lo + torch.randint(2, V // 2 + 1, (3,), generator=g)
         m[b] |= (zz >= lo[0]) & (zz < hi[0]) & (yy >= lo[1]) & (yy < hi[1]) & (xx >= lo[2]) & (xx < hi[2])
         c = torch.randint(0, V, (3,), generator=g).float()
-        r = torch.randint(2, V // 3, (3,), generator=g).float()
+        r = torch.randint(2, max(V // 3, 3), (3,), generator=g).float()
         m[b] |= ((zz - c[0]) / r[0]) ** 2 + ((yy - c[1]) / r[1]) ** 2 + ((xx - c[2]) / r[2]) ** 2 <= 1.0
     m[0, 0, 0, 0] = True                                           # a corner site: every out-of-grid tap direction at once
     m[0, V - 1, V - 1, V - 1] = True
@@ -1676,7 +1676,7 @@ VOXG_CASES = [
     (32, 8, 64, 128), (32, 4, 128, 256), (32, 2, 256, 512),
     (64, 8, 64, 128), (64, 2, 256, 512),
     (64, 8, 128, 256), (64, 4, 256, 512),
-    (3, 8, 64, 128), (5, 4, 128, 256), (7, 2, 256, 512), (1, 2, 64, 16),
+    (3, 8, 64, 128), (5, 4, 128, 256), (7, 2, 256, 512), (1, 2, 64, 64),
 ]
 
 

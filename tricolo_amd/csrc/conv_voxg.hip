@@ -21,7 +21,7 @@
 //   * the four waves split the workgroup's (output-channel tile, k-step) space: WC waves along the channels (TN tiles of 16 each),
 //     WK waves along the taps (tap j of a chunk belongs to wave j mod WK; partial sums are added through LDS at the end).  Every
 //     weight fragment is needed by exactly ONE wave, so it is loaded from L2 straight into that wave's registers as an MFMA A
-//     fragment (16 rows x 64 B per instruction, groups of 7 taps, the next group in flight under the current group's MFMAs): no
+//     fragment (16 rows x 64 B per instruction) through a RING of 14-28 register fragments per wave that is refilled slot by slot: no
 //     LDS traffic, no barrier per k-step - one barrier per 32-channel chunk (the slab is double-buffered: the next chunk's sites are
 //     requested before the current chunk's MFMAs and written to the other buffer after them);
 //   * units with more than 16 * NRT active sites run in passes (weights re-streamed per pass);
@@ -45,7 +45,17 @@ struct VoxgArgs {
     int spu, nunits;           // samples per unit, units
     int mirror;                // 1: data gradient (tap (kd, kh, kw) reads the site at -(kd-1, kh-1, kw-1))
     unsigned in_bytes, w_bytes;
+#ifdef VOXG_PROBE
+    long long* dbg;            // [grid][8] stamps of wave 0 (tools/probes/voxg_stamps.py)
+#endif
 };
+#ifdef VOXG_PROBE
+#define VOXG_STAMP(i) do { if (p.dbg && t == 0) p.dbg[(size_t)blockIdx.x * 8 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define VOXG_STAMPV(i, v) do { if (p.dbg && t == 0) p.dbg[(size_t)blockIdx.x * 8 + (i)] = (long long)(v); } while (0)
+#else
+#define VOXG_STAMP(i)
+#define VOXG_STAMPV(i, v)
+#endif
 
 template <int N>
 __device__ __forceinline__ float voxg_row_ror(float v) {
@@ -53,7 +63,6 @@ __device__ __forceinline__ float voxg_row_ror(float v) {
 }
 
 #define VOXG_MAXROWS 512                                                      // active sites of a unit (8^3 sample, all active)
-#define VOXG_G 7                                                              // taps per weight-fragment group
 
 // LDS: row tables + unit mask (VOXG_TAB bytes) | [2 slab buffers][2 halves][NS sites x 32 B]; the epilogue scratch aliases the slab
 #define VOXG_TAB (2 * VOXG_MAXROWS * 4 + 16 * 4 + 512 + 192)                  // 4,864: a multiple of 256
@@ -70,7 +79,7 @@ __host__ __device__ inline VoxgGeom voxg_geom(int D, int spu) {
     return g;
 }
 
-template <typename AT, int TN, int WC, int WK, int NRT>
+template <typename AT, int TN, int WC, int WK, int NRT, int RING>
 __global__ __launch_bounds__(256, 1) void conv_voxg_kernel(const VoxgArgs p) {
     typedef typename OpOf<AT>::E E;
     typedef Mma<E> MM;
@@ -109,23 +118,32 @@ __global__ __launch_bounds__(256, 1) void conv_voxg_kernel(const VoxgArgs p) {
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) wrow[tn] = (unsigned)(((n0 + (wc * TN + tn) * 16 + fr) * p.Kpad + fq * 8) * 2);
     const int nchunks = p.Cin >> 5;
-    constexpr int TAPS_W = (27 - 1) / WK + 1;                                 // taps of wave wk = 0 (the others have TAPS_W or TAPS_W - 1)
-    constexpr int NGRP = (TAPS_W + VOXG_G - 1) / VOXG_G;                      // groups of 7 taps per chunk
-    const int mytaps = (27 - wk + WK - 1) / WK;
-    v8 wf[2][VOXG_G][TN];
-    auto load_group = [&](int set, int chunk, int grp) {
+    // A wave's k-steps run chunk-major: (chunk c, i) = tap wk + i * WK of input channels 32 c .. 32 c + 31, i < KPC (the last one of a chunk
+    // is a dummy for the waves that own one tap fewer).  Their A fragments live in a RING of registers: slot (c mod U) * KPC + i, reloaded
+    // with k-step (c + U, i) right behind the MFMAs that consumed it - RING fragments (x TN) are in flight per wave at any time, which
+    // is what streaming 100-450 KB of weights per workgroup at L2 latency takes (one group of 7 ahead, the first version, left the
+    // MFMAs waiting for every group: 18-30 us for levels that should take 6; the loop is unrolled over U chunks so that every slot index
+    // is a compile-time constant).
+    constexpr int KPC = (27 + WK - 1) / WK;                                   // k-steps per chunk and wave: 7 (WK = 4) or 14 (WK = 2)
+    constexpr int U = RING / KPC;                                             // chunks per unrolled loop body
+    static_assert(U * KPC == RING && U >= 1, "ring = whole chunks");
+    v8 wf[RING][TN];
+    auto load_slot = [&](const int slot, const int chunk, const int i) {
+        const int tap = wk + i * WK;
+        const bool ok = tap < 27 && chunk < nchunks;
+        const unsigned koff = (unsigned)((tap * p.Cin + chunk * 32) * 2);
 #pragma unroll
-        for (int i = 0; i < VOXG_G; ++i) {
-            const int jt = grp * VOXG_G + i;                                  // index among this wave's taps
-            const int tap = wk + jt * WK;
-            const bool ok = jt < mytaps;
-            const unsigned koff = (unsigned)((tap * p.Cin + chunk * 32) * 2);
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-                wf[set][i][tn] = __builtin_bit_cast(v8, __builtin_amdgcn_raw_buffer_load_b128(wrs, ok ? wrow[tn] + koff : 0x80000000u, 0, 0));
-        }
+        for (int tn = 0; tn < TN; ++tn)
+            wf[slot][tn] = __builtin_bit_cast(v8, __builtin_amdgcn_raw_buffer_load_b128(wrs, ok ? wrow[tn] + koff : 0x80000000u, 0, 0));
     };
-    load_group(0, 0, 0);                                                      // in flight under the whole set-up
+    auto load_ring = [&]() {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int i = 0; i < KPC; ++i) load_slot(u * KPC + i, u, i);
+    };
+    VOXG_STAMP(0);
+    load_ring();                                                              // in flight under the whole set-up
 
     // ---- slab pieces of this thread: piece e = t + 256 u is the 16-byte quarter (e & 3) of dense site (e >> 2)
     const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
@@ -186,6 +204,9 @@ __global__ __launch_bounds__(256, 1) void conv_voxg_kernel(const VoxgArgs p) {
     int nrows = 0;
 #pragma unroll
     for (int w = 0; w < 8; ++w) nrows += wcnt[w];
+    VOXG_STAMP(1);
+    VOXG_STAMPV(6, nrows);
+    VOXG_STAMPV(7, __builtin_amdgcn_s_memrealtime());
     if (nrows == 0) {                                                         // nothing active in this unit (the same answer in every wave)
         if (p.stats && t < 2 * CT) p.stats[((size_t)unit * 2 + t / CT) * p.Cout + n0 + t % CT] = 0.f;
         return;
@@ -226,7 +247,7 @@ __global__ __launch_bounds__(256, 1) void conv_voxg_kernel(const VoxgArgs p) {
         if (pass > 0) {
             // the previous pass's epilogue scratch lay over the slab: once every wave is done with it, the padding is zeroed again
             slab_request(0);
-            load_group(0, 0, 0);
+            load_ring();
             __syncthreads();
             zero_fill();
             __syncthreads();
@@ -234,49 +255,43 @@ __global__ __launch_bounds__(256, 1) void conv_voxg_kernel(const VoxgArgs p) {
         slab_commit(0);
         __syncthreads();
 
-        // one 32-channel chunk: NGRP groups of 7 taps.  The register set of a group's weight fragments alternates; two chunks per loop
-        // iteration keep that index a compile-time constant (an odd NGRP would otherwise make it a run-time one: scratch memory)
-        auto chunk_body = [&](auto S0, const int c) {
-            constexpr int s0 = decltype(S0)::value;
-            const char* const sb = slab + (c & 1) * G.buf_bytes;
-            if (c + 1 < nchunks) slab_request(c + 1);
+        VOXG_STAMP(2);
+#pragma unroll 1
+        for (int c0 = 0; c0 < nchunks; c0 += U) {
 #pragma unroll
-            for (int g = 0; g < NGRP; ++g) {
-                const int set = (s0 + g) & 1;
-                // the next group's weight fragments fly under this group's MFMAs
-                if (g + 1 < NGRP) load_group(set ^ 1, c, g + 1);
-                else if (c + 1 < nchunks) load_group(set ^ 1, c + 1, 0);
+            for (int u = 0; u < U; ++u) {
+                const int c = c0 + u;
+                if (c < nchunks) {                                            // (U = 4 with two chunks: the same answer in every wave)
+                    const char* const sb = slab + (c & 1) * G.buf_bytes;
+                    if (c + 1 < nchunks) slab_request(c + 1);
 #pragma unroll
-                for (int i = 0; i < VOXG_G; ++i) {
-                    const int jt = g * VOXG_G + i;
-                    if (jt < mytaps) {
-                        const int tap = wk + jt * WK;
-                        int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-                        if (p.mirror) { kd = 2 - kd; kh = 2 - kh; kw = 2 - kw; }
-                        const int toff = ((kd * G.RY + kh) * G.P + kw) * 32;
-                        v8 bf[NRT];
+                    for (int i = 0; i < KPC; ++i) {
+                        const int tap = wk + i * WK;
+                        if (tap < 27) {
+                            int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+                            if (p.mirror) { kd = 2 - kd; kh = 2 - kh; kw = 2 - kw; }
+                            const int toff = ((kd * G.RY + kh) * G.P + kw) * 32;
+                            v8 bf[NRT];
 #pragma unroll
-                        for (int rt = 0; rt < NRT; ++rt)
-                            if (rt < nrt) bf[rt] = *(const v8*)(sb + lbase[rt] + toff);
+                            for (int rt = 0; rt < NRT; ++rt)
+                                if (rt < nrt) bf[rt] = *(const v8*)(sb + lbase[rt] + toff);
 #pragma unroll
-                        for (int rt = 0; rt < NRT; ++rt)
-                            if (rt < nrt) {
+                            for (int rt = 0; rt < NRT; ++rt)
+                                if (rt < nrt) {
 #pragma unroll
-                                for (int tn = 0; tn < TN; ++tn) acc[rt][tn] = MM::mma(wf[set][i][tn], bf[rt], acc[rt][tn]);
-                            }
+                                    for (int tn = 0; tn < TN; ++tn) acc[rt][tn] = MM::mma(wf[u * KPC + i][tn], bf[rt], acc[rt][tn]);
+                                }
+                        }
+                        load_slot(u * KPC + i, c + U, i);                     // the slot's next tenant: the same tap of chunk c + U
+                    }
+                    if (c + 1 < nchunks) {
+                        slab_commit((c + 1) & 1);                             // (that buffer was last read in chunk c - 1: every wave is past it)
+                        __syncthreads();
                     }
                 }
             }
-            if (c + 1 < nchunks) {
-                slab_commit((c + 1) & 1);                                     // (that buffer was last read in chunk c - 1: every wave is past it)
-                __syncthreads();
-            }
-        };
-#pragma unroll 1
-        for (int c = 0; c < nchunks; c += 2) {                                // (Cin % 64 == 0: an even number of chunks)
-            chunk_body(std::integral_constant<int, 0>{}, c);
-            chunk_body(std::integral_constant<int, NGRP & 1>{}, c + 1);
         }
+        VOXG_STAMP(3);
 
         // ---- partial sums of the WK tap shares: through LDS (the slab is idle now), tile (rt, tn) of channel column wc summed and
         // finished by wave wk' = tile index mod WK of that column
@@ -313,6 +328,7 @@ __global__ __launch_bounds__(256, 1) void conv_voxg_kernel(const VoxgArgs p) {
             }
     }
 
+    VOXG_STAMP(4);
     // ---- BatchNorm sums: over the 16 sites of a fragment row (DPP), then over the waves that finished tiles of the same channels
     if (p.stats) {
         __syncthreads();
@@ -344,6 +360,7 @@ __global__ __launch_bounds__(256, 1) void conv_voxg_kernel(const VoxgArgs p) {
             p.stats[((size_t)unit * 2 + 1) * p.Cout + n0 + t] = q_;
         }
     }
+    VOXG_STAMP(5);
 }
 
 // ------------------------------------------------------------------------------------------------ plan + launch
@@ -372,11 +389,11 @@ bool tri_internal_voxg_geometry(int B, int ID, int IH, int IW, int cin, int OD, 
     const int nunits = (B + spu - 1) / spu;
     // output channels per workgroup: as many as keep one workgroup per CU (fewer weight re-reads of the slab, fewer partial-sum waves)
     int ct = 16;
-    while (ct < 128 && cout % (2 * ct) == 0 && (long)nunits * (cout / (2 * ct)) >= cus) ct *= 2;
+    while (ct < 64 && cout % (2 * ct) == 0 && (long)nunits * (cout / (2 * ct)) >= cus) ct *= 2;
     static int force_ct = -1, force_spu = -1;                                 // tuning aids
     if (force_ct < 0) { const char* e = getenv("TRICOLO_VOXG_CT"); force_ct = e ? atoi(e) : 0; }
     if (force_spu < 0) { const char* e = getenv("TRICOLO_VOXG_SPU"); force_spu = e ? atoi(e) : 0; }
-    if (force_ct == 16 || force_ct == 32 || force_ct == 64 || force_ct == 128) { if (cout % force_ct == 0) ct = force_ct; }
+    if (force_ct == 16 || force_ct == 32 || force_ct == 64) { if (cout % force_ct == 0) ct = force_ct; }
     if (force_spu > 0 && force_spu * D3 <= 512) { spu = force_spu; }
     g->D = D; g->spu = spu; g->nunits = (B + spu - 1) / spu; g->ct = ct;
     const int nct = cout / ct;
@@ -388,7 +405,7 @@ bool tri_internal_voxg_geometry(int B, int ID, int IH, int IW, int cin, int OD, 
     return true;
 }
 
-template <typename AT, int TN, int WC, int WK, int NRT>
+template <typename AT, int TN, int WC, int WK, int NRT, int RING>
 static int voxg_launch_t(const VoxgArgs& a, const TriVoxgGeom& g, hipStream_t stream) {
     // the epilogue scratch (partial sums of every wave, statistics) aliases the slab buffers
     const size_t need = (size_t)4 * NRT * TN * 64 * sizeof(f32x4);
@@ -398,10 +415,10 @@ static int voxg_launch_t(const VoxgArgs& a, const TriVoxgGeom& g, hipStream_t st
     if (smem > 160 * 1024) { tri_set_error("conv(voxg): LDS budget exceeded"); return TRI_ERR_UNSUPPORTED; }
     static size_t attr = 0;
     if (smem > attr) {
-        hipFuncSetAttribute((const void*)conv_voxg_kernel<AT, TN, WC, WK, NRT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)conv_voxg_kernel<AT, TN, WC, WK, NRT, RING>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = 160 * 1024;
     }
-    conv_voxg_kernel<AT, TN, WC, WK, NRT><<<g.grid, 256, smem, stream>>>(a);
+    conv_voxg_kernel<AT, TN, WC, WK, NRT, RING><<<g.grid, 256, smem, stream>>>(a);
     return tri_check_launch("tri_conv(voxg)");
 }
 
@@ -413,13 +430,16 @@ int tri_internal_voxg_launch(const TriVoxgGeom& g, int B, int cin, int cout, int
     a.spu = g.spu; a.nunits = g.nunits; a.mirror = transposed ? 1 : 0;
     a.in_bytes = (unsigned)((size_t)B * g.D * g.D * g.D * cin * 2);
     a.w_bytes = (unsigned)((size_t)cout * kpad * 2);
-#define TRI_VOXG(CT_, TN_, WC_, WK_)                                                                                      \
+#ifdef VOXG_PROBE
+    { const char* e = getenv("TRICOLO_VOXG_DBG"); a.dbg = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
+#endif
+#define TRI_VOXG(CT_, TN_, WC_, WK_, RING_)                                                                               \
     if (g.ct == CT_)                                                                                                      \
-        return act_fmt == TRI_FMT_F16 ? voxg_launch_t<f16_t, TN_, WC_, WK_, 12>(a, g, stream) : voxg_launch_t<bf16_t, TN_, WC_, WK_, 12>(a, g, stream);
-    TRI_VOXG(16, 1, 1, 4)
-    TRI_VOXG(32, 2, 1, 4)
-    TRI_VOXG(64, 2, 2, 2)
-    TRI_VOXG(128, 2, 4, 1)
+        return act_fmt == TRI_FMT_F16 ? voxg_launch_t<f16_t, TN_, WC_, WK_, 12, RING_>(a, g, stream)                      \
+                                      : voxg_launch_t<bf16_t, TN_, WC_, WK_, 12, RING_>(a, g, stream);
+    TRI_VOXG(16, 1, 1, 4, 28)
+    TRI_VOXG(32, 2, 1, 4, 14)
+    TRI_VOXG(64, 2, 2, 2, 14)
 #undef TRI_VOXG
     tri_set_error("conv(voxg): channel tile not instantiated");
     return TRI_ERR_UNSUPPORTED;
