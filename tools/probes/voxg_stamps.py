@@ -13,6 +13,7 @@ from tricolo_amd.data import synthetic as syn
 import torch.nn.functional as F
 
 dev = torch.device("cuda:0")
+print("ablation bits:", os.environ.get("TRICOLO_VOXG_ABL", "0"))
 for V, B in ((32, 32), (64, 64)):
     batch = syn.make_batch(B, voxel_size=V, num_views=None, seed=syn.BASE_SEED + 2)
     locs = batch["voxels"]["locs"].long()

@@ -41,7 +41,7 @@ struct VoxgArgs {
     void* out;                 // [B, D, D, D, Cout]; rows of inactive sites are not written
     const uint8_t* mask;       // [B * D^3] site mask, or NULL (every site active)
     float* stats;              // [nunits][2][Cout] or NULL
-    int B, D, Cin, Cout, Kpad;
+    int B, D, logD, Cin, Cout, Kpad;
     int spu, nunits;           // samples per unit, units
     int mirror;                // 1: data gradient (tap (kd, kh, kw) reads the site at -(kd-1, kh-1, kw-1))
     unsigned in_bytes, w_bytes;
@@ -86,17 +86,19 @@ __global__ __launch_bounds__(256, 1) void conv_voxg_kernel(const VoxgArgs p) {
     typedef typename MM::v8 v8;
     static_assert(WC * WK == 4, "four waves");
     constexpr int CT = WC * TN * 16;                                          // output channels of a workgroup
-    constexpr int MAXL = 8;                                                   // 16-byte slab pieces per thread and chunk (512 sites x 4 / 256)
+    // 16-byte slab pieces per thread and chunk: four per ACTIVE site, up to 4 per thread (256 rows) held in registers between their request
+    // (at the start of the previous chunk) and their LDS write (at its end); the rows past 256 of a very dense unit are copied in a plain
+    // loop at the chunk boundary.  The variants with NRT < 12 run units of at most 16 * NRT sites.
+    constexpr int MAXL = NRT == 12 ? 4 : (NRT * 16 * 4 + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), fr = lane & 15, fq = lane >> 4;
     const int wc = wave / WK, wk = wave - wc * WK;
-    const int D = p.D, D3 = D * D * D;
+    const int D = p.D, lD = p.logD, D3 = 1 << (3 * lD);
     const VoxgGeom G = voxg_geom(D, p.spu);
     char* const slab = smem + VOXG_TAB;
     int* const row_lds = (int*)smem;                                          // [VOXG_MAXROWS] byte offset (site * 32) of the row's (-1,-1,-1) corner
     int* const row_glob = row_lds + VOXG_MAXROWS;                             // [VOXG_MAXROWS] global site index
     int* const wcnt = row_glob + VOXG_MAXROWS;                                // [8] per-(half, wave) counts of the ranking
-    uint8_t* const lmask = (uint8_t*)(wcnt + 16);                             // [512] site mask of the unit
 
     // ---- workgroup -> (unit, channel tile): workgroups of one channel tile share an XCD (blockIdx % 8), so its weights stay in that L2
     const int nct = p.Cout / CT;
@@ -109,21 +111,25 @@ __global__ __launch_bounds__(256, 1) void conv_voxg_kernel(const VoxgArgs p) {
     if (unit >= p.nunits) return;
     const int b0 = unit * p.spu;
     const int ns = min(p.spu, p.B - b0);                                      // samples of this unit
-    const int nsites = ns * D3;                                               // dense sites of this unit (<= 512)
+    const int nsites = ns << (3 * lD);                                        // dense sites of this unit (<= 512)
     const int n0 = ctile * CT;
+    VOXG_STAMP(0);
+
+    // ---- site mask of the unit: two bytes per thread, requested first (everything below waits for it)
+    uint8_t m0 = 0, m1 = 0;
+    if (t < nsites) m0 = p.mask ? p.mask[((size_t)b0 << (3 * lD)) + t] : 1;
+    if (t + 256 < nsites) m1 = p.mask ? p.mask[((size_t)b0 << (3 * lD)) + t + 256] : 1;
 
     // ---- weight fragments: wave (wc, wk) owns output channels n0 + (wc * TN + tn) * 16 + fr and the taps wk, wk + WK, ...
+    // A wave's k-steps run chunk-major: (chunk c, i) = tap wk + i * WK of input channels 32 c .. 32 c + 31, i < KPC (the last one of a chunk
+    // is a dummy for the waves that own one tap fewer).  Their A fragments live in a RING of registers: slot (c mod U) * KPC + i, reloaded
+    // with k-step (c + U, i) right behind the MFMAs that consumed it - RING fragments (x TN) stay in flight per wave, requested from the
+    // first instruction of the kernel on (the loop is unrolled over U chunks so that every slot index is a compile-time constant).
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
     unsigned wrow[TN];
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) wrow[tn] = (unsigned)(((n0 + (wc * TN + tn) * 16 + fr) * p.Kpad + fq * 8) * 2);
     const int nchunks = p.Cin >> 5;
-    // A wave's k-steps run chunk-major: (chunk c, i) = tap wk + i * WK of input channels 32 c .. 32 c + 31, i < KPC (the last one of a chunk
-    // is a dummy for the waves that own one tap fewer).  Their A fragments live in a RING of registers: slot (c mod U) * KPC + i, reloaded
-    // with k-step (c + U, i) right behind the MFMAs that consumed it - RING fragments (x TN) are in flight per wave at any time, which
-    // is what streaming 100-450 KB of weights per workgroup at L2 latency takes (one group of 7 ahead, the first version, left the
-    // MFMAs waiting for every group: 18-30 us for levels that should take 6; the loop is unrolled over U chunks so that every slot index
-    // is a compile-time constant).
     constexpr int KPC = (27 + WK - 1) / WK;                                   // k-steps per chunk and wave: 7 (WK = 4) or 14 (WK = 2)
     constexpr int U = RING / KPC;                                             // chunks per unrolled loop body
     static_assert(U * KPC == RING && U >= 1, "ring = whole chunks");
@@ -142,42 +148,17 @@ __global__ __launch_bounds__(256, 1) void conv_voxg_kernel(const VoxgArgs p) {
 #pragma unroll
             for (int i = 0; i < KPC; ++i) load_slot(u * KPC + i, u, i);
     };
-    VOXG_STAMP(0);
     load_ring();                                                              // in flight under the whole set-up
 
-    // ---- slab pieces of this thread: piece e = t + 256 u is the 16-byte quarter (e & 3) of dense site (e >> 2)
-    const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
-    unsigned src[MAXL];
-    int dst[MAXL];
-#pragma unroll
-    for (int u = 0; u < MAXL; ++u) {
-        const int e = t + 256 * u, s = e >> 2, q = e & 3;
-        const bool ok = s < nsites;
-        const int bl = s / D3, r = s - bl * D3;
-        const int z = r / (D * D), y = (r / D) % D, x = r % D;
-        const int sp = ((bl * G.PZ + z + 1) * G.RY + y + 1) * G.P + x + 1;    // padded site
-        dst[u] = ok ? (q >> 1) * G.half_bytes + sp * 32 + (q & 1) * 16 : -1;
-        src[u] = ok ? (unsigned)((((size_t)b0 * D3 + s) * p.Cin + q * 8) * 2) : 0x80000000u;
-    }
-    uint4 pre[MAXL];
-    auto slab_request = [&](int chunk) {
-#pragma unroll
-        for (int u = 0; u < MAXL; ++u)
-            pre[u] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(irs, src[u] == 0x80000000u ? src[u] : src[u] + chunk * 64, 0, 0));
-    };
-    slab_request(0);
-
-    // ---- site mask of the unit (two bytes per thread), zero fill of both slab buffers (the padding is never written again)
+    // ---- zero fill of both slab buffers while the mask is on its way: only ACTIVE sites are ever written afterwards, so the padding
+    // and the inactive sites stay zero for every chunk (and whatever the tensor holds at inactive sites is never read)
     auto zero_fill = [&]() {
         for (int i = t * 16; i < 2 * G.buf_bytes; i += 256 * 16) *(uint4*)(slab + i) = make_uint4(0u, 0u, 0u, 0u);
     };
+    zero_fill();
+
+    // ---- rank of every active site in raster order (first half: sites 0..255, second half: 256..511) -> row tables
     {
-        uint8_t m0 = 0, m1 = 0;
-        if (t < nsites) m0 = p.mask ? p.mask[(size_t)b0 * D3 + t] : 1;
-        if (t + 256 < nsites) m1 = p.mask ? p.mask[(size_t)b0 * D3 + t + 256] : 1;
-        zero_fill();
-        lmask[t] = m0; lmask[t + 256] = m1;
-        // rank of every active site in raster order: pass 0 = sites 0..255, pass 1 = sites 256..511
         const unsigned long long b0m = __ballot(m0 != 0), b1m = __ballot(m1 != 0);
         if (lane == 0) { wcnt[wave] = __popcll(b0m); wcnt[4 + wave] = __popcll(b1m); }
         __syncthreads();
@@ -193,14 +174,14 @@ __global__ __launch_bounds__(256, 1) void conv_voxg_kernel(const VoxgArgs p) {
             const int s = t + 256 * h;
             if (h ? m1 : m0) {
                 const int rk = h ? tot0 + base1 + __popcll(b1m & below) : base0 + __popcll(b0m & below);
-                const int bl = s / D3, r = s - bl * D3;
-                const int z = r / (D * D), y = (r / D) % D, x = r % D;
+                const int bl = s >> (3 * lD), r = s & (D3 - 1);
+                const int z = r >> (2 * lD), y = (r >> lD) & (D - 1), x = r & (D - 1);
                 row_lds[rk] = (((bl * G.PZ + z) * G.RY + y) * G.P + x) * 32;  // the (-1, -1, -1) corner of the site's neighbourhood
-                row_glob[rk] = b0 * D3 + s;
+                row_glob[rk] = (b0 << (3 * lD)) + s;
             }
         }
     }
-    __syncthreads();                                                          // zero fill + tables + masks visible
+    __syncthreads();                                                          // zero fill + tables visible
     int nrows = 0;
 #pragma unroll
     for (int w = 0; w < 8; ++w) nrows += wcnt[w];
@@ -211,15 +192,41 @@ __global__ __launch_bounds__(256, 1) void conv_voxg_kernel(const VoxgArgs p) {
         if (p.stats && t < 2 * CT) p.stats[((size_t)unit * 2 + t / CT) * p.Cout + n0 + t % CT] = 0.f;
         return;
     }
-    auto slab_commit = [&](int buf) {                                         // inactive sites contribute zeros whatever the tensor holds there
+
+    // ---- slab pieces of this thread: piece e = t + 256 u is the 16-byte quarter (e & 3) of active row (e >> 2)
+    const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    const int centre = (G.RY * G.P + G.P + 1) * 32;
+    unsigned src[MAXL];
+    int dst[MAXL];
+#pragma unroll
+    for (int u = 0; u < MAXL; ++u) {
+        const int e = t + 256 * u, r = e >> 2, q = e & 3;
+        const bool ok = r < nrows;
+        dst[u] = ok ? row_lds[r] + centre + (q >> 1) * G.half_bytes + (q & 1) * 16 : -1;
+        src[u] = ok ? (unsigned)(((size_t)row_glob[r] * p.Cin + q * 8) * 2) : 0x80000000u;
+    }
+    uint4 pre[MAXL];
+    auto slab_request = [&](int chunk) {
+#pragma unroll
+        for (int u = 0; u < MAXL; ++u)
+            if (dst[u] >= 0) pre[u] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(irs, src[u] + chunk * 64, 0, 0));
+    };
+    auto slab_commit = [&](int buf, int chunk) {
         char* const base = slab + buf * G.buf_bytes;
 #pragma unroll
         for (int u = 0; u < MAXL; ++u)
-            if (dst[u] >= 0) {
-                const bool on = lmask[(t + 256 * u) >> 2] != 0;
-                *(uint4*)(base + dst[u]) = on ? pre[u] : make_uint4(0u, 0u, 0u, 0u);
+            if (dst[u] >= 0) *(uint4*)(base + dst[u]) = pre[u];
+        if (NRT == 12) {                                                      // rows 256 .. of a dense unit (rare): load and write at once
+#pragma unroll 1
+            for (int e = t + 256 * MAXL; e < 4 * nrows; e += 256) {
+                const int r = e >> 2, q = e & 3;
+                const uint4 v = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
+                    irs, (unsigned)(((size_t)row_glob[r] * p.Cin + q * 8) * 2) + chunk * 64, 0, 0));
+                *(uint4*)(base + row_lds[r] + centre + (q >> 1) * G.half_bytes + (q & 1) * 16) = v;
             }
+        }
     };
+    slab_request(0);
 
     const int lane_part = (fq >> 1) * G.half_bytes + (fq & 1) * 16;
     float cs[TN][4], cq[TN][4];                                               // BatchNorm sums of this wave's epilogue share
@@ -227,6 +234,14 @@ __global__ __launch_bounds__(256, 1) void conv_voxg_kernel(const VoxgArgs p) {
     for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { cs[tn][r] = 0.f; cq[tn][r] = 0.f; }
+    // slab offset of tap wk + i * WK (the mirrored tap for the data gradient); i is an unrolled loop index, so these are scalar values
+    // (a wave that owns one tap fewer runs a DUMMY last k-step of every chunk - zero weights, tap offset 0 - so that the loop is branch-free)
+    auto tap_off = [&](const int i) -> int {
+        const int tap = wk + i * WK;
+        int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+        if (p.mirror) { kd = 2 - kd; kh = 2 - kh; kw = 2 - kw; }
+        return tap < 27 ? ((kd * G.RY + kh) * G.P + kw) * 32 : 0;
+    };
 
     const int npass = (nrows + 16 * NRT - 1) / (16 * NRT);
 #pragma unroll 1
@@ -237,7 +252,7 @@ __global__ __launch_bounds__(256, 1) void conv_voxg_kernel(const VoxgArgs p) {
 #pragma unroll
         for (int rt = 0; rt < NRT; ++rt) {
             const int r = r0 + rt * 16 + fr;
-            lbase[rt] = (r < nrows ? row_lds[r] : 0) + lane_part;             // rows past the end read padding (zeros)
+            lbase[rt] = (r < nrows ? row_lds[r] : 0) + lane_part;             // rows past the end read the first sites of the slab: discarded
         }
         f32x4 acc[NRT][TN];
 #pragma unroll
@@ -245,52 +260,61 @@ __global__ __launch_bounds__(256, 1) void conv_voxg_kernel(const VoxgArgs p) {
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) acc[rt][tn] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (pass > 0) {
-            // the previous pass's epilogue scratch lay over the slab: once every wave is done with it, the padding is zeroed again
+            // the previous pass's epilogue scratch lay over the slab: once every wave is done with it, everything is zeroed again
             slab_request(0);
             load_ring();
             __syncthreads();
             zero_fill();
             __syncthreads();
         }
-        slab_commit(0);
+        slab_commit(0, 0);
         __syncthreads();
 
         VOXG_STAMP(2);
+        // The chunk loop, for a COMPILE-TIME number NT of row tiles: a run-time guard per tile made every tile a basic block, and at every
+        // join the compiler waited lgkmcnt(0) - each MFMA pair then waited out the LDS read issued just before it (stamps: 3.6 x the
+        // MFMA time).  NT is the pass's tile count rounded up to 4 / 6 / 8 / 10 / 12; the surplus tiles multiply rows past the end of the
+        // list (discarded), the loop body is branch-free and its fragment reads run one k-step ahead of the MFMAs.
+        auto chunk_loop = [&](auto NTc) {
+            constexpr int NT = decltype(NTc)::value < NRT ? decltype(NTc)::value : NRT;
 #pragma unroll 1
-        for (int c0 = 0; c0 < nchunks; c0 += U) {
+            for (int c0 = 0; c0 < nchunks; c0 += U) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int c = c0 + u;
-                if (c < nchunks) {                                            // (U = 4 with two chunks: the same answer in every wave)
-                    const char* const sb = slab + (c & 1) * G.buf_bytes;
-                    if (c + 1 < nchunks) slab_request(c + 1);
+                for (int u = 0; u < U; ++u) {
+                    const int c = c0 + u;
+                    if (c < nchunks) {                                        // (U = 4 with two chunks: the same answer in every wave)
+                        const char* const sb = slab + (c & 1) * G.buf_bytes;
+                        if (c + 1 < nchunks) slab_request(c + 1);
+                        v8 bf[NT];
+                        {
+                            const int toff = tap_off(0);
 #pragma unroll
-                    for (int i = 0; i < KPC; ++i) {
-                        const int tap = wk + i * WK;
-                        if (tap < 27) {
-                            int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-                            if (p.mirror) { kd = 2 - kd; kh = 2 - kh; kw = 2 - kw; }
-                            const int toff = ((kd * G.RY + kh) * G.P + kw) * 32;
-                            v8 bf[NRT];
-#pragma unroll
-                            for (int rt = 0; rt < NRT; ++rt)
-                                if (rt < nrt) bf[rt] = *(const v8*)(sb + lbase[rt] + toff);
-#pragma unroll
-                            for (int rt = 0; rt < NRT; ++rt)
-                                if (rt < nrt) {
-#pragma unroll
-                                    for (int tn = 0; tn < TN; ++tn) acc[rt][tn] = MM::mma(wf[u * KPC + i][tn], bf[rt], acc[rt][tn]);
-                                }
+                            for (int rt = 0; rt < NT; ++rt) bf[rt] = *(const v8*)(sb + lbase[rt] + toff);
                         }
-                        load_slot(u * KPC + i, c + U, i);                     // the slot's next tenant: the same tap of chunk c + U
-                    }
-                    if (c + 1 < nchunks) {
-                        slab_commit((c + 1) & 1);                             // (that buffer was last read in chunk c - 1: every wave is past it)
-                        __syncthreads();
+#pragma unroll
+                        for (int i = 0; i < KPC; ++i) {
+                            const int toff = i + 1 < KPC ? tap_off(i + 1) : 0;
+#pragma unroll
+                            for (int rt = 0; rt < NT; ++rt) {
+#pragma unroll
+                                for (int tn = 0; tn < TN; ++tn) acc[rt][tn] = MM::mma(wf[u * KPC + i][tn], bf[rt], acc[rt][tn]);
+                                if (i + 1 < KPC) bf[rt] = *(const v8*)(sb + lbase[rt] + toff);
+                            }
+                            load_slot(u * KPC + i, c + U, i);                 // the slot's next tenant: the same tap of chunk c + U
+                        }
+                        if (c + 1 < nchunks) {
+                            slab_commit((c + 1) & 1, c + 1);                  // (that buffer was last read in chunk c - 1: every wave is past it)
+                            __syncthreads();
+                        }
                     }
                 }
             }
-        }
+        };
+        if (NRT <= 4 || nrt <= 4) chunk_loop(std::integral_constant<int, 4>{});
+        else if (nrt <= 6) chunk_loop(std::integral_constant<int, 6>{});
+        else if (NRT <= 8 || nrt <= 8) chunk_loop(std::integral_constant<int, 8>{});
+        else if (nrt <= 10) chunk_loop(std::integral_constant<int, 10>{});
+        else chunk_loop(std::integral_constant<int, 12>{});
         VOXG_STAMP(3);
 
         // ---- partial sums of the WK tap shares: through LDS (the slab is idle now), tile (rt, tn) of channel column wc summed and
@@ -426,20 +450,29 @@ int tri_internal_voxg_launch(const TriVoxgGeom& g, int B, int cin, int cout, int
                              float* stats, int transposed, int act_fmt, hipStream_t stream) {
     VoxgArgs a{};
     a.in = in; a.w = w; a.out = out; a.mask = mask; a.stats = stats;
-    a.B = B; a.D = g.D; a.Cin = cin; a.Cout = cout; a.Kpad = kpad;
+    a.B = B; a.D = g.D; a.logD = g.D == 8 ? 3 : (g.D == 4 ? 2 : 1); a.Cin = cin; a.Cout = cout; a.Kpad = kpad;
     a.spu = g.spu; a.nunits = g.nunits; a.mirror = transposed ? 1 : 0;
     a.in_bytes = (unsigned)((size_t)B * g.D * g.D * g.D * cin * 2);
     a.w_bytes = (unsigned)((size_t)cout * kpad * 2);
 #ifdef VOXG_PROBE
     { const char* e = getenv("TRICOLO_VOXG_DBG"); a.dbg = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
 #endif
+    // row tiles per pass: the unit's dense sites bound its active rows (2^3 / 4^3 units of few samples need 2-8 tiles, never a second pass)
+    const int nsites = g.spu * g.D * g.D * g.D;
+    const int nrt = nsites <= 32 ? 2 : (nsites <= 64 ? 4 : (nsites <= 128 ? 8 : 12));
+#define TRI_VOXG_N(CT_, TN_, WC_, WK_, RING_, NRT_)                                                                       \
+    if (g.ct == CT_ && nrt == NRT_)                                                                                       \
+        return act_fmt == TRI_FMT_F16 ? voxg_launch_t<f16_t, TN_, WC_, WK_, NRT_, RING_>(a, g, stream)                    \
+                                      : voxg_launch_t<bf16_t, TN_, WC_, WK_, NRT_, RING_>(a, g, stream);
 #define TRI_VOXG(CT_, TN_, WC_, WK_, RING_)                                                                               \
-    if (g.ct == CT_)                                                                                                      \
-        return act_fmt == TRI_FMT_F16 ? voxg_launch_t<f16_t, TN_, WC_, WK_, 12, RING_>(a, g, stream)                      \
-                                      : voxg_launch_t<bf16_t, TN_, WC_, WK_, 12, RING_>(a, g, stream);
-    TRI_VOXG(16, 1, 1, 4, 28)
-    TRI_VOXG(32, 2, 1, 4, 14)
-    TRI_VOXG(64, 2, 2, 2, 14)
+    TRI_VOXG_N(CT_, TN_, WC_, WK_, RING_, 2) TRI_VOXG_N(CT_, TN_, WC_, WK_, RING_, 4)                                     \
+    TRI_VOXG_N(CT_, TN_, WC_, WK_, RING_, 12)
+    // (ring of 28 fragments for the 16-channel workgroups - four chunks of seven taps in flight; with 8 row tiles that variant spills, so
+    //  it keeps 14 like the two-tile waves)
+    TRI_VOXG(16, 1, 1, 4, 28) TRI_VOXG_N(16, 1, 1, 4, 14, 8)
+    TRI_VOXG(32, 2, 1, 4, 14) TRI_VOXG_N(32, 2, 1, 4, 14, 8)
+    TRI_VOXG(64, 2, 2, 2, 14) TRI_VOXG_N(64, 2, 2, 2, 14, 8)
+#undef TRI_VOXG_N
 #undef TRI_VOXG
     tri_set_error("conv(voxg): channel tile not instantiated");
     return TRI_ERR_UNSUPPORTED;
