@@ -42,7 +42,11 @@ typedef struct TriConvDesc {
  * (3-product split mode, fp32-grade accuracy).
  *   forward operand : rows = Cout, inner = Cin     dgrad operand : rows = Cin, inner = Cout (swap the strides)
  * Layouts: spconv SubMConv3d weight [Cout,kd,kh,kw,Cin] (sparse_cnn.py:12-32), torchvision conv [Cout,Cin,kh,kw]
- * (mv_cnn.py:44), nn.Linear [out,in]. */
+ * (mv_cnn.py:44), nn.Linear [out,in].
+ * frag != 0 (rows % 16 == 0): the same elements in MFMA-FRAGMENT-MAJOR order for the kernels that load their weight fragments straight
+ * into registers (tri_conv_kernel_family == 13): the [16 rows x 32 k] block (row tile rt, k-step ks) is 1 KiB at
+ * ((rt * kpad / 32) + ks) * 512 elements, element (r, k) of it at ((k % 32) / 8 * 16 + r % 16) * 8 + k % 8 - lane (r, k / 8) of a
+ * 16x16x32 A fragment reads its 8 elements as ONE contiguous 16-byte piece and a wave reads 1 KiB contiguously. */
 int tri_conv_kpad(int ntaps, int cin_stored);
 /* one packing job; tri_weight_prep_multi runs an array of them (DEVICE memory) in a single launch - one per tower and step */
 typedef struct TriPrepDesc {
@@ -51,10 +55,11 @@ typedef struct TriPrepDesc {
     void* lo;            /* NULL in the single-operand modes (bf16, f16) */
     long s_row, s_tap, s_inner;
     int rows, ntaps, inner, inner_pad, kpad, fmt;
+    int frag;            /* 1: fragment-major order (see above) */
 } TriPrepDesc;
 int tri_weight_prep_multi(const TriPrepDesc* descs_dev, int n, void* stream);
 int tri_weight_prep(const float* w, long s_row, long s_tap, long s_inner, int rows, int ntaps, int inner, int inner_pad,
-                    void* w_hi, void* w_lo, int fmt, void* stream);
+                    void* w_hi, void* w_lo, int fmt, int frag, void* stream);
 
 /* ---- token embedding (bigru.py:10,15) ------------------------------------------------------------------------------
  * fwd: emb[L,B,D] = W[tokens[B,L]] (already in the GRU's time-major order); bwd: dense dW[V,D], occurrences summed in

@@ -73,7 +73,7 @@ def make_case(case, integer, seed=0):
 def test_conv_fwd_integer_exact(case, precision):
     x, w, wp, xcl, g = make_case(case, integer=True)
     ref = cl3(F.conv3d(x, w, stride=case[6], padding=case[7]))
-    packed = ops.pack_weight(wp.to(DEV), g, precision)
+    packed = ops.pack_weight(wp.to(DEV), g, precision, storage=torch.float32)
     out = ops.conv_fwd(xcl.to(DEV), g, packed).cpu()
     assert out.shape == ref.shape
     assert torch.equal(out, ref), f"max abs diff {(out - ref).abs().max().item()}"
@@ -85,7 +85,7 @@ def test_conv_fwd_float_split_precision(case):
     ref = cl3(F.conv3d(x.double(), w.double(), stride=case[6], padding=case[7]))
     scale = ref.abs().max().item()
     out3 = ops.conv_fwd(xcl.to(DEV), g, ops.pack_weight(wp.to(DEV), g, "bf16x3")).cpu().double()
-    out1 = ops.conv_fwd(xcl.to(DEV), g, ops.pack_weight(wp.to(DEV), g, "bf16")).cpu().double()
+    out1 = ops.conv_fwd(xcl.to(DEV), g, ops.pack_weight(wp.to(DEV), g, "bf16", storage=torch.float32)).cpu().double()
     assert (out3 - ref).abs().max().item() < 2e-5 * scale          # fp32-grade
     assert (out1 - ref).abs().max().item() < 3e-2 * scale          # plain bf16 operands
 
@@ -122,7 +122,7 @@ def test_conv_fwd_mask_bias_act_stats():
     mask = (torch.rand(M, generator=gen) < 0.3).to(torch.uint8)
     mask[:256] = 0                                                  # two fully inactive 128-row tiles
     ref = cl3(F.conv3d(x, w, padding=1)).reshape(M, -1) * mask[:, None].float()
-    packed = ops.pack_weight(wp.to(DEV), g, "bf16")
+    packed = ops.pack_weight(wp.to(DEV), g, "bf16", storage=torch.float32)
     out, stats = ops.conv_fwd(xcl.to(DEV), g, packed, row_mask=mask.to(DEV), want_stats=True)
     out = out.cpu().reshape(M, -1)
     assert torch.equal(out, ref)
@@ -148,7 +148,7 @@ def test_conv_dgrad_integer_exact(case, precision):
     dy = ints(tuple(y.shape), -2, 2, 11)
     y.backward(dy)
     ref = cl3(xr.grad)
-    packed_t = ops.pack_weight(wp.to(DEV), g, precision, transposed=True)
+    packed_t = ops.pack_weight(wp.to(DEV), g, precision, transposed=True, storage=torch.float32)
     dx = ops.conv_dgrad(cl3(dy).to(DEV), g, packed_t).cpu()
     assert torch.equal(dx, ref), f"max abs diff {(dx - ref).abs().max().item()}"
     base = ints(tuple(ref.shape), -5, 5, 13)
@@ -184,7 +184,7 @@ def test_conv_dgrad_float_split_precision(case):
     ref = cl3(xr.grad)
     scale = ref.abs().max().item()
     dx3 = ops.conv_dgrad(cl3(dy).to(DEV), g, ops.pack_weight(wp.to(DEV), g, "bf16x3", transposed=True)).cpu().double()
-    dx1 = ops.conv_dgrad(cl3(dy).to(DEV), g, ops.pack_weight(wp.to(DEV), g, "bf16", transposed=True)).cpu().double()
+    dx1 = ops.conv_dgrad(cl3(dy).to(DEV), g, ops.pack_weight(wp.to(DEV), g, "bf16", transposed=True, storage=torch.float32)).cpu().double()
     assert (dx3 - ref).abs().max().item() < 2e-5 * scale
     assert (dx1 - ref).abs().max().item() < 3e-2 * scale
     assert (dx1 - ref).abs().max().item() > 1e-4 * scale          # the single-operand path really is the coarser one
@@ -1102,10 +1102,13 @@ def test_opt_in_kernels_child_process(switch):
 
 @pytest.mark.parametrize("store,prec", STORE16, ids=STORE16_IDS)
 def test_conv_16bit_storage_masked_stats(store, prec):
-    """Submanifold rule + BatchNorm partial sums through the LDS-DMA kernel (Cin = 64) and its split-K finish."""
-    case = ("vox_m", 2, (8, 8, 8), 64, 128, (3, 3, 3), 1, (1, 1, 1), "spconv")
+    """Submanifold rule + BatchNorm partial sums through the LDS-DMA kernel (Cin = 64) and its split-K finish: rows with a zero mask
+    byte are written as zeros whatever the input holds (a 6^3 grid: the 2^3 / 4^3 / 8^3 grids run conv_voxg_kernel, which has its
+    own test - test_voxel_coarse_grid_kernel)."""
+    case = ("vox_m", 3, (6, 6, 6), 64, 128, (3, 3, 3), 1, (1, 1, 1), "spconv")
     x, w, wp, xcl, g = make_case(case, integer=True, seed=61)
-    M = 2 * 512
+    assert (g.kernel_family[(False, 2)] & 255) == 2
+    M = 3 * 216
     gen = torch.Generator().manual_seed(9)
     mask = (torch.rand(M, generator=gen) < 0.3).to(torch.uint8)
     mask[:256] = 0                                                  # two fully inactive 128-row tiles
@@ -1121,11 +1124,11 @@ def test_conv_16bit_storage_masked_stats(store, prec):
     dy = ints((M, 128), -2, 2, 63) * mask[:, None].float()
     xr = x.clone().requires_grad_()
     wr = w.clone().requires_grad_()
-    F.conv3d(xr, wr, padding=1).backward(cf3(dy.view(2, 8, 8, 8, 128)))
-    dw = ops.conv_wgrad(xcl.to(DEV).to(store), dy.view(2, 8, 8, 8, 128).to(DEV).to(store), g, wp.to(DEV), prec,
+    F.conv3d(xr, wr, padding=1).backward(cf3(dy.view(3, 6, 6, 6, 128)))
+    dw = ops.conv_wgrad(xcl.to(DEV).to(store), dy.view(3, 6, 6, 6, 128).to(DEV).to(store), g, wp.to(DEV), prec,
                         row_mask=mask.to(DEV))                      # 64-position steps without an active site are skipped
     assert torch.equal(dw.cpu(), wr.grad.permute(0, 2, 3, 4, 1).contiguous())
-    dx = ops.conv_dgrad(dy.view(2, 8, 8, 8, 128).to(DEV).to(store), g, ops.pack_weight(wp.to(DEV), g, prec, transposed=True),
+    dx = ops.conv_dgrad(dy.view(3, 6, 6, 6, 128).to(DEV).to(store), g, ops.pack_weight(wp.to(DEV), g, prec, transposed=True),
                         row_mask=mask.to(DEV))
     assert torch.equal(dx.cpu().reshape(M, -1), (cl3(xr.grad).reshape(M, -1) * mask[:, None].float()).to(store))
 

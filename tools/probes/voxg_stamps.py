@@ -35,7 +35,7 @@ for V, B in ((32, 32), (64, 64)):
             w = torch.randn(cout, 3, 3, 3, cin, device=dev) * 0.05
             packed = ops.pack_weight(w, g, "f16")
             nwg = 4096
-            dbg = torch.zeros((nwg, 8), dtype=torch.int64, device=dev)
+            dbg = torch.zeros((nwg, 16), dtype=torch.int64, device=dev)
             os.environ["TRICOLO_VOXG_DBG"] = str(dbg.data_ptr())
             for _ in range(3):
                 dbg.zero_()
@@ -50,6 +50,11 @@ for V, B in ((32, 32), (64, 64)):
             names = ["setup (mask, rank, zero fill)", "first slab commit", "chunk loop", "epilogue", "statistics"]
             for nme, sg in zip(names, seg):
                 print(f"      {nme:32s} median {np.median(sg):8.0f}  p90 {np.percentile(sg, 90):8.0f}  max {sg.max():8.0f} cycles")
+            fine = [("entry -> mask requested", 0, 8), ("ring loads issued", 8, 9), ("zero fill issued", 9, 10), ("mask arrived (ballot)", 10, 11),
+                    ("rank barrier", 11, 12), ("tables + barrier", 12, 1)]
+            for nme, i0, i1 in fine:
+                sg = d[ne, i1] - d[ne, i0]
+                print(f"        . {nme:30s} median {np.median(sg):8.0f}  p90 {np.percentile(sg, 90):8.0f} cycles")
             tot = d[ne, 5] - d[ne, 0]
             print(f"      total                            median {np.median(tot):8.0f}  p90 {np.percentile(tot, 90):8.0f}  max {tot.max():8.0f} cycles;  start spread {(d[:, 7].max() - d[:, 7].min()) / 100.0:.2f} us")
         m = F.max_pool3d(m, 2)

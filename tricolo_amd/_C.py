@@ -22,7 +22,7 @@ class TriConvDesc(C.Structure):
 class TriPrepDesc(C.Structure):
     _fields_ = [("w", C.c_void_p), ("hi", C.c_void_p), ("lo", C.c_void_p), ("s_row", C.c_long), ("s_tap", C.c_long),
                 ("s_inner", C.c_long), ("rows", C.c_int), ("ntaps", C.c_int), ("inner", C.c_int), ("inner_pad", C.c_int),
-                ("kpad", C.c_int), ("fmt", C.c_int)]
+                ("kpad", C.c_int), ("fmt", C.c_int), ("frag", C.c_int)]
 
 
 class TriWgradReduce(C.Structure):
@@ -52,7 +52,7 @@ SIGNATURES = {
     "tri_version": (I, []),
     "tri_last_error": (C.c_char_p, []),
     "tri_conv_kpad": (I, [I, I]),
-    "tri_weight_prep": (I, [P, L, L, L, I, I, I, I, P, P, I, P]),
+    "tri_weight_prep": (I, [P, L, L, L, I, I, I, I, P, P, I, I, P]),
     "tri_weight_prep_multi": (I, [P, I, P]),
     "tri_embedding_fwd": (I, [P, P, I, I, I, P, P]),
     "tri_embedding_bwd": (I, [P, P, I, I, I, I, I, P, P]),

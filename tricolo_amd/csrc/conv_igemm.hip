@@ -1726,6 +1726,13 @@ __device__ __forceinline__ void prep_store(bool f16, uint16_t* hi, bf16_t* lo, s
     if (lo) lo[idx] = (bf16_t)(v - (float)h);
 }
 
+// index of packed element (row, k): row-major [rows][kpad], or (frag) MFMA-fragment-major - the [16 x 32] block (row / 16, k / 32) is
+// 512 contiguous elements, lane (row % 16, (k % 32) / 8) of an A fragment owns 8 contiguous ones (include/tricolo_hip.h)
+__device__ __forceinline__ size_t prep_index(bool frag, int row, int k, int kpad) {
+    if (!frag) return (size_t)row * kpad + k;
+    return ((size_t)(row >> 4) * (kpad >> 5) + (k >> 5)) * 512 + ((((k & 31) >> 3) * 16 + (row & 15)) << 3) + (k & 7);
+}
+
 // four consecutive packed elements (idx % 4 == 0): one 8-byte store per operand array instead of four 2-byte ones
 __device__ __forceinline__ void prep_store4(bool f16, uint16_t* hi, bf16_t* lo, size_t idx, float4 v) {
     if (f16) {
@@ -1747,7 +1754,7 @@ __device__ __forceinline__ void prep_store4(bool f16, uint16_t* hi, bf16_t* lo, 
 // dst[row][tap * inner_pad + i] (bf16 hi / lo, zero padded to Kpad) from an fp32 tensor addressed by strides.
 // forward:  row = co, inner = ci;   dgrad: row = ci, inner = co  (same tensor, swapped strides).
 __global__ void weight_prep_kernel(const float* __restrict__ w, long s_row, long s_tap, long s_inner, int rows, int ntaps,
-                                   int inner, int inner_pad, int Kpad, uint16_t* __restrict__ hi, bf16_t* __restrict__ lo, int f16) {
+                                   int inner, int inner_pad, int Kpad, uint16_t* __restrict__ hi, bf16_t* __restrict__ lo, int f16, int frag) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     long total = (long)rows * Kpad;
     if (idx >= total) return;
@@ -1755,7 +1762,7 @@ __global__ void weight_prep_kernel(const float* __restrict__ w, long s_row, long
     int tap = k / inner_pad, i = k - tap * inner_pad;
     float v = 0.f;
     if (tap < ntaps && i < inner) v = w[row * s_row + tap * s_tap + i * s_inner];
-    prep_store(f16 != 0, hi, lo, idx, v);
+    prep_store(f16 != 0, hi, lo, prep_index(frag != 0, row, k, Kpad), v);
 }
 
 // All layers of a tower in ONE launch: blockIdx.y selects the descriptor, blockIdx.x grid-strides over its work.
@@ -1768,7 +1775,7 @@ __global__ __launch_bounds__(256) void weight_prep_multi_kernel(const TriPrepDes
     const TriPrepDesc d = descs[blockIdx.y];
     uint16_t* hi = (uint16_t*)d.hi;
     bf16_t* lo = (bf16_t*)d.lo;
-    const bool f16 = d.fmt == TRI_FMT_F16;
+    const bool f16 = d.fmt == TRI_FMT_F16, frag = d.frag != 0;
     const int t = threadIdx.x, nt = d.ntaps;
     const long span = (long)d.inner * nt;
     if (nt > 1 && d.s_tap == 1 && d.s_inner == nt && d.s_row == span && span <= 64 * 73 && d.inner == d.inner_pad) {
@@ -1783,14 +1790,14 @@ __global__ __launch_bounds__(256) void weight_prep_multi_kernel(const TriPrepDes
                     const int tap = k / d.inner_pad, i = k - tap * d.inner_pad;
                     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (tap < nt) v = make_float4(tile[i * nt + tap], tile[(i + 1) * nt + tap], tile[(i + 2) * nt + tap], tile[(i + 3) * nt + tap]);
-                    prep_store4(f16, hi, lo, (size_t)row * d.kpad + k, v);
+                    prep_store4(f16, hi, lo, prep_index(frag, row, k, d.kpad), v);
                 }
             } else {
                 for (int e = t; e < span; e += 256) tile[e] = src[e];
                 __syncthreads();
                 for (int k = t; k < d.kpad; k += 256) {
                     const int tap = k / d.inner_pad, i = k - tap * d.inner_pad;
-                    prep_store(f16, hi, lo, (size_t)row * d.kpad + k, tap < nt ? tile[i * nt + tap] : 0.f);
+                    prep_store(f16, hi, lo, prep_index(frag, row, k, d.kpad), tap < nt ? tile[i * nt + tap] : 0.f);
                 }
             }
             __syncthreads();
@@ -1826,7 +1833,7 @@ __global__ __launch_bounds__(256) void weight_prep_multi_kernel(const TriPrepDes
                     const int il = (e & 15) * 4, r = e >> 4;      // r = row_l * taps + tap (torch_t) or row_l (plane_t)
                     const int row_l = torch_t ? r / nt : r, tap = torch_t ? r - row_l * nt : plane;
                     if (row_l < rows_here && i0 + il < d.inner)
-                        prep_store4(f16, hi, lo, (size_t)(r0 + row_l) * d.kpad + (size_t)tap * d.inner_pad + i0 + il,
+                        prep_store4(f16, hi, lo, prep_index(frag, r0 + row_l, tap * d.inner_pad + i0 + il, d.kpad),
                                     make_float4(tile[il * ld + r], tile[(il + 1) * ld + r], tile[(il + 2) * ld + r], tile[(il + 3) * ld + r]));
                 }
             } else
@@ -1834,7 +1841,7 @@ __global__ __launch_bounds__(256) void weight_prep_multi_kernel(const TriPrepDes
                 const int il = e & 63, r = e >> 6;                // r = row_l * taps + tap (torch_t) or row_l (plane_t)
                 const int row_l = torch_t ? r / nt : r, tap = torch_t ? r - row_l * nt : plane;
                 if (row_l < rows_here && i0 + il < d.inner)
-                    prep_store(f16, hi, lo, (size_t)(r0 + row_l) * d.kpad + (size_t)tap * d.inner_pad + i0 + il, tile[il * ld + r]);
+                    prep_store(f16, hi, lo, prep_index(frag, r0 + row_l, tap * d.inner_pad + i0 + il, d.kpad), tile[il * ld + r]);
             }
             __syncthreads();
         }
@@ -1843,7 +1850,7 @@ __global__ __launch_bounds__(256) void weight_prep_multi_kernel(const TriPrepDes
         if (padw > 0)
             for (long e = (long)blockIdx.x * 256 + t; e < (long)d.rows * padw; e += (long)gridDim.x * 256) {
                 const int row = (int)(e / padw), k = kused + (int)(e - (long)row * padw);
-                prep_store(f16, hi, lo, (size_t)row * d.kpad + k, 0.f);
+                prep_store(f16, hi, lo, prep_index(frag, row, k, d.kpad), 0.f);
             }
         return;
     }
@@ -1853,7 +1860,7 @@ __global__ __launch_bounds__(256) void weight_prep_multi_kernel(const TriPrepDes
         int tap = k / d.inner_pad, i = k - tap * d.inner_pad;
         float v = 0.f;
         if (tap < d.ntaps && i < d.inner) v = d.w[row * d.s_row + tap * d.s_tap + i * d.s_inner];
-        prep_store(f16, hi, lo, idx, v);
+        prep_store(f16, hi, lo, prep_index(frag, row, k, d.kpad), v);
     }
 }
 
@@ -1864,14 +1871,15 @@ extern "C" int tri_weight_prep_multi(const TriPrepDesc* descs_dev, int n, void* 
 }
 
 extern "C" int tri_weight_prep(const float* w, long s_row, long s_tap, long s_inner, int rows, int ntaps, int inner,
-                               int inner_pad, void* w_hi, void* w_lo, int fmt, void* stream) {
+                               int inner_pad, void* w_hi, void* w_lo, int fmt, int frag, void* stream) {
     if (fmt == TRI_FMT_F16 && w_lo) { tri_set_error("tri_weight_prep: the f16 operand format has no lo part"); return TRI_ERR_ARG; }
     if (inner_pad % 4 != 0 || inner > inner_pad) { tri_set_error("tri_weight_prep: inner_pad must be a multiple of 4 >= inner"); return TRI_ERR_ARG; }
+    if (frag && rows % 16 != 0) { tri_set_error("tri_weight_prep: the fragment-major order needs rows % 16 == 0"); return TRI_ERR_ARG; }
     int Kpad = (ntaps * inner_pad + 31) / 32 * 32;
     long total = (long)rows * Kpad;
     int blocks = (int)((total + 255) / 256);
     weight_prep_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(w, s_row, s_tap, s_inner, rows, ntaps, inner, inner_pad, Kpad,
-                                                                (uint16_t*)w_hi, (bf16_t*)w_lo, fmt == TRI_FMT_F16 ? 1 : 0);
+                                                                (uint16_t*)w_hi, (bf16_t*)w_lo, fmt == TRI_FMT_F16 ? 1 : 0, frag ? 1 : 0);
     return tri_check_launch("tri_weight_prep");
 }
 

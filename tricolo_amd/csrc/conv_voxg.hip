@@ -21,7 +21,8 @@
 //   * the four waves split the workgroup's (output-channel tile, k-step) space: WC waves along the channels (TN tiles of 16 each),
 //     WK waves along the taps (tap j of a chunk belongs to wave j mod WK; partial sums are added through LDS at the end).  Every
 //     weight fragment is needed by exactly ONE wave, so it is loaded from L2 straight into that wave's registers as an MFMA A
-//     fragment (16 rows x 64 B per instruction) through a RING of 14-28 register fragments per wave that is refilled slot by slot: no
+//     fragment (the packed operand is stored FRAGMENT-MAJOR, so a wave instruction reads 1 KiB contiguously: with row-major rows a
+//     fragment was 16 rows x 64 B and every load took the texture addresser ~150 cycles) through a RING of 14-28 register fragments per wave that is refilled slot by slot: no
 //     LDS traffic, no barrier per k-step - one barrier per 32-channel chunk (the slab is double-buffered: the next chunk's sites are
 //     requested before the current chunk's MFMAs and written to the other buffer after them);
 //   * units with more than 16 * NRT active sites run in passes (weights re-streamed per pass);
@@ -37,7 +38,7 @@ int tri_internal_num_cus();                                                   //
 
 struct VoxgArgs {
     const void* in;            // [B, D, D, D, Cin] 16-bit (values at inactive sites are ignored)
-    const void* w;             // packed operand rows [Cout][Kpad], k = tap * Cin + channel
+    const void* w;             // packed operand, FRAGMENT-MAJOR (tri_weight_prep frag = 1): [Cout / 16][Kpad / 32][64 lanes][8], k = tap * Cin + channel
     void* out;                 // [B, D, D, D, Cout]; rows of inactive sites are not written
     const uint8_t* mask;       // [B * D^3] site mask, or NULL (every site active)
     float* stats;              // [nunits][2][Cout] or NULL
@@ -46,12 +47,12 @@ struct VoxgArgs {
     int mirror;                // 1: data gradient (tap (kd, kh, kw) reads the site at -(kd-1, kh-1, kw-1))
     unsigned in_bytes, w_bytes;
 #ifdef VOXG_PROBE
-    long long* dbg;            // [grid][8] stamps of wave 0 (tools/probes/voxg_stamps.py)
+    long long* dbg;            // [grid][16] stamps of wave 0 (tools/probes/voxg_stamps.py)
 #endif
 };
 #ifdef VOXG_PROBE
-#define VOXG_STAMP(i) do { if (p.dbg && t == 0) p.dbg[(size_t)blockIdx.x * 8 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
-#define VOXG_STAMPV(i, v) do { if (p.dbg && t == 0) p.dbg[(size_t)blockIdx.x * 8 + (i)] = (long long)(v); } while (0)
+#define VOXG_STAMP(i) do { if (p.dbg && t == 0) p.dbg[(size_t)blockIdx.x * 16 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define VOXG_STAMPV(i, v) do { if (p.dbg && t == 0) p.dbg[(size_t)blockIdx.x * 16 + (i)] = (long long)(v); } while (0)
 #else
 #define VOXG_STAMP(i)
 #define VOXG_STAMPV(i, v)
@@ -128,7 +129,8 @@ __global__ __launch_bounds__(256, 1) void conv_voxg_kernel(const VoxgArgs p) {
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
     unsigned wrow[TN];
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) wrow[tn] = (unsigned)(((n0 + (wc * TN + tn) * 16 + fr) * p.Kpad + fq * 8) * 2);
+    for (int tn = 0; tn < TN; ++tn)                                            // fragment (channel tile, k-step ks) = 1 KiB at (tile * Kpad / 32 + ks) * 1024: lane * 16 inside
+        wrow[tn] = (unsigned)(((n0 >> 4) + wc * TN + tn) * (p.Kpad >> 5) * 1024 + lane * 16);
     const int nchunks = p.Cin >> 5;
     constexpr int KPC = (27 + WK - 1) / WK;                                   // k-steps per chunk and wave: 7 (WK = 4) or 14 (WK = 2)
     constexpr int U = RING / KPC;                                             // chunks per unrolled loop body
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(256, 1) void conv_voxg_kernel(const VoxgArgs p) {
     auto load_slot = [&](const int slot, const int chunk, const int i) {
         const int tap = wk + i * WK;
         const bool ok = tap < 27 && chunk < nchunks;
-        const unsigned koff = (unsigned)((tap * p.Cin + chunk * 32) * 2);
+        const unsigned koff = (unsigned)((tap * nchunks + chunk) * 1024);   // k-step index = (tap * Cin + 32 chunk) / 32
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn)
             wf[slot][tn] = __builtin_bit_cast(v8, __builtin_amdgcn_raw_buffer_load_b128(wrs, ok ? wrow[tn] + koff : 0x80000000u, 0, 0));
@@ -148,7 +150,9 @@ __global__ __launch_bounds__(256, 1) void conv_voxg_kernel(const VoxgArgs p) {
 #pragma unroll
             for (int i = 0; i < KPC; ++i) load_slot(u * KPC + i, u, i);
     };
+    VOXG_STAMP(8);
     load_ring();                                                              // in flight under the whole set-up
+    VOXG_STAMP(9);
 
     // ---- zero fill of both slab buffers while the mask is on its way: only ACTIVE sites are ever written afterwards, so the padding
     // and the inactive sites stay zero for every chunk (and whatever the tensor holds at inactive sites is never read)
@@ -156,12 +160,15 @@ __global__ __launch_bounds__(256, 1) void conv_voxg_kernel(const VoxgArgs p) {
         for (int i = t * 16; i < 2 * G.buf_bytes; i += 256 * 16) *(uint4*)(slab + i) = make_uint4(0u, 0u, 0u, 0u);
     };
     zero_fill();
+    VOXG_STAMP(10);
 
     // ---- rank of every active site in raster order (first half: sites 0..255, second half: 256..511) -> row tables
     {
         const unsigned long long b0m = __ballot(m0 != 0), b1m = __ballot(m1 != 0);
+        VOXG_STAMP(11);
         if (lane == 0) { wcnt[wave] = __popcll(b0m); wcnt[4 + wave] = __popcll(b1m); }
         __syncthreads();
+        VOXG_STAMP(12);
         int base0 = 0, base1 = 0, tot0 = 0;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {

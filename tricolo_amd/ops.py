@@ -264,6 +264,21 @@ class ConvGeom:
         neither computed nor written), not a compact row list."""
         return (self.kernel_family[(transposed, mode)] & 255) in (6, 7, 13)
 
+    def packed_frag(self, transposed: bool, precision: str, storage=None) -> int:
+        """1 when the kernel that consumes this layer's packed operand (forward / data gradient) reads it in MFMA-fragment-major order
+        (tri_weight_prep frag: conv_voxg_kernel loads its weight fragments straight into registers).  The plan mode follows the
+        activation storage the operand will meet (default: the precision mode's own)."""
+        storage = storage or act_dtype(precision)
+        mode = 1 if precision == "bf16x3" else (2 if storage != torch.float32 else 0)
+        return 1 if (self.kernel_family[(transposed, mode)] & 255) == 13 else 0
+
+    def check_packed(self, packed, transposed: bool, x):
+        """The packed operand must be in the order this call's kernel reads (see pack_weight's `storage`)."""
+        need = 1 if (self.kernel_family[(transposed, _conv_mode(x, packed[1]))] & 255) == 13 else 0
+        if getattr(packed[0], "tri_frag", 0) != need:
+            raise RuntimeError("conv: the packed operand was ordered for another plan (row-major vs fragment-major): pack it with "
+                               "pack_weight(..., storage=<dtype of the activations>)")
+
     def voxg_spu(self, transposed: bool, mode: int) -> int:
         """Samples per unit of conv_voxg_kernel for this layer (0: another kernel runs it)."""
         code = self.kernel_family[(transposed, mode)]
@@ -306,8 +321,10 @@ class ConvGeom:
         return 2 * self.M * self.ntaps * self.cin * self.cout
 
 
-def pack_weight(w: torch.Tensor, g: ConvGeom, precision: str, transposed: bool = False):
-    """fp32 parameter -> (hi, lo|None) bf16 MFMA operand rows.  transposed=True packs the dgrad operand."""
+def pack_weight(w: torch.Tensor, g: ConvGeom, precision: str, transposed: bool = False, storage=None):
+    """fp32 parameter -> (hi, lo|None) bf16 MFMA operand rows.  transposed=True packs the dgrad operand.  storage: dtype of the activation
+    tensors the operand will meet (default act_dtype(precision)) - it selects the plan mode and with it the operand ORDER (row-major, or
+    fragment-major for conv_voxg_kernel); conv_fwd / conv_dgrad refuse an operand packed for another plan."""
     s_co, s_tap, s_ci = g.strides
     if not transposed:
         rows, inner, inner_pad, kpad, s_row, s_inner = g.cout, g.cin, g.cin_stored, g.kpad, s_co, s_ci
@@ -317,8 +334,10 @@ def pack_weight(w: torch.Tensor, g: ConvGeom, precision: str, transposed: bool =
             raise RuntimeError("dgrad operand requested for a layer with padded input channels")
     hi = torch.empty((rows, kpad), dtype=torch.float16 if precision == "f16" else torch.bfloat16, device=w.device)
     lo = torch.empty_like(hi) if precision == "bf16x3" else None
-    check(lib().tri_weight_prep(ptr(_f32(w)), s_row, s_tap, s_inner, rows, g.ntaps, inner, inner_pad, ptr(hi), ptr(lo), _abf(hi), stream()),
-          "tri_weight_prep")
+    frag = g.packed_frag(transposed, precision, storage)
+    check(lib().tri_weight_prep(ptr(_f32(w)), s_row, s_tap, s_inner, rows, g.ntaps, inner, inner_pad, ptr(hi), ptr(lo), _abf(hi),
+                                frag, stream()), "tri_weight_prep")
+    hi.tri_frag = frag
     return hi, lo
 
 
@@ -355,6 +374,7 @@ class WeightPacker:
             d.w, d.hi, d.lo = w.data_ptr(), hi.data_ptr(), (lo.data_ptr() if lo is not None else None)
             d.s_row, d.s_tap, d.s_inner = s_row, s_tap, s_inner
             d.rows, d.ntaps, d.inner, d.inner_pad, d.kpad = rows, g.ntaps, inner, inner_pad, kpad
+            d.frag = hi.tri_frag = g.packed_frag(tr, precision)
         raw = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(device)
         snap = tuple(w.data_ptr() for (w, _, _) in self.entries.values())
         return raw, len(self.entries), bufs, snap
@@ -373,6 +393,7 @@ class WeightPacker:
 def conv_fwd(x, g: ConvGeom, packed, row_mask=None, bias=None, act=0, want_stats=False, out=None, accumulate=False, rows=None):
     """rows = (row_pos, count) from mask_compact: only those rows are computed and WRITTEN (submanifold layers; pass no row_mask)."""
     hi, lo = packed
+    g.check_packed(packed, False, x)
     OD, OH, OW = g.out_grid
     if out is None:
         out = torch.empty((g.B, OD, OH, OW, g.cout), dtype=x.dtype, device=x.device)
@@ -403,6 +424,7 @@ def conv_dgrad(dout, g: ConvGeom, packed_t, row_mask=None, out=None, accumulate=
     reduce of the BatchNorm that consumed y; where the layer's kernel can take those sums in its epilogue (tri_conv_dgrad_bn_records)
     the call returns (din, partial) and bn_bwd(..., partial=partial) skips its reduce launch, otherwise (din, None)."""
     hi, lo = packed_t
+    g.check_packed(packed_t, True, dout)
     ID, IH, IW = g.in_grid
     if out is None:
         out = torch.empty((g.B, ID, IH, IW, g.cin_stored), dtype=dout.dtype, device=dout.device)
