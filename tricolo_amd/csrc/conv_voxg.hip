@@ -150,16 +150,15 @@ __global__ __launch_bounds__(256, 1) void conv_voxg_kernel(const VoxgArgs p) {
 #pragma unroll
             for (int i = 0; i < KPC; ++i) load_slot(u * KPC + i, u, i);
     };
-    VOXG_STAMP(8);
-    load_ring();                                                              // in flight under the whole set-up
-    VOXG_STAMP(9);
-
-    // ---- zero fill of both slab buffers while the mask is on its way: only ACTIVE sites are ever written afterwards, so the padding
-    // and the inactive sites stay zero for every chunk (and whatever the tensor holds at inactive sites is never read)
-    auto zero_fill = [&]() {
-        for (int i = t * 16; i < 2 * G.buf_bytes; i += 256 * 16) *(uint4*)(slab + i) = make_uint4(0u, 0u, 0u, 0u);
+    // ---- zero fill of the slab buffers: only ACTIVE sites are ever written afterwards, so the padding and the inactive sites stay zero for
+    // every chunk (and whatever the tensor holds at inactive sites is never read).  Buffer 0 is cleared while the mask is on its way,
+    // buffer 1 while the first chunk's sites are (start-up order - stamps: with the weight ring requested first, its 112 KB occupied
+    // the texture path for 2 k cycles in front of the mask-dependent chain, and the first MFMA issued 10 k cycles into the kernel)
+    auto zero_fill = [&](int first, int count) {
+        for (int i = first * G.buf_bytes + t * 16; i < (first + count) * G.buf_bytes; i += 256 * 16) *(uint4*)(slab + i) = make_uint4(0u, 0u, 0u, 0u);
     };
-    zero_fill();
+    VOXG_STAMP(8);
+    zero_fill(0, 1);
     VOXG_STAMP(10);
 
     // ---- rank of every active site in raster order (first half: sites 0..255, second half: 256..511) -> row tables
@@ -234,6 +233,9 @@ __global__ __launch_bounds__(256, 1) void conv_voxg_kernel(const VoxgArgs p) {
         }
     };
     slab_request(0);
+    VOXG_STAMP(9);
+    load_ring();                                                              // (behind the first chunk's sites: the first MFMA needs those, and ring slot 0)
+    zero_fill(1, 1);
 
     const int lane_part = (fq >> 1) * G.half_bytes + (fq & 1) * 16;
     float cs[TN][4], cq[TN][4];                                               // BatchNorm sums of this wave's epilogue share
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(256, 1) void conv_voxg_kernel(const VoxgArgs p) {
             slab_request(0);
             load_ring();
             __syncthreads();
-            zero_fill();
+            zero_fill(0, 2);
             __syncthreads();
         }
         slab_commit(0, 0);
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(256, 1) void conv_voxg_kernel(const VoxgArgs p) {
         VOXG_STAMP(2);
         // The chunk loop, for a COMPILE-TIME number NT of row tiles: a run-time guard per tile made every tile a basic block, and at every
         // join the compiler waited lgkmcnt(0) - each MFMA pair then waited out the LDS read issued just before it (stamps: 3.6 x the
-        // MFMA time).  NT is the pass's tile count rounded up to 4 / 6 / 8 / 10 / 12; the surplus tiles multiply rows past the end of the
+        // MFMA time).  NT is the pass's tile count rounded up to 2 / 4 / 6 / 8 / 10 / 12; the surplus tiles multiply rows past the end of the
         // list (discarded), the loop body is branch-free and its fragment reads run one k-step ahead of the MFMAs.
         auto chunk_loop = [&](auto NTc) {
             constexpr int NT = decltype(NTc)::value < NRT ? decltype(NTc)::value : NRT;
@@ -317,15 +319,16 @@ __global__ __launch_bounds__(256, 1) void conv_voxg_kernel(const VoxgArgs p) {
                 }
             }
         };
-        if (NRT <= 4 || nrt <= 4) chunk_loop(std::integral_constant<int, 4>{});
+        if (NRT <= 2 || nrt <= 2) chunk_loop(std::integral_constant<int, 2>{});
+        else if (NRT <= 4 || nrt <= 4) chunk_loop(std::integral_constant<int, 4>{});
         else if (nrt <= 6) chunk_loop(std::integral_constant<int, 6>{});
         else if (NRT <= 8 || nrt <= 8) chunk_loop(std::integral_constant<int, 8>{});
         else if (nrt <= 10) chunk_loop(std::integral_constant<int, 10>{});
         else chunk_loop(std::integral_constant<int, 12>{});
         VOXG_STAMP(3);
 
-        // ---- partial sums of the WK tap shares: through LDS (the slab is idle now), tile (rt, tn) of channel column wc summed and
-        // finished by wave wk' = tile index mod WK of that column
+        // ---- partial sums of the WK tap shares: tile (rt, tn) of channel column wc is finished by the wave whose wk = tile index mod WK;
+        // the other waves of the column hand it their partial sums through LDS (the slab is idle now), added in wave order
         __syncthreads();
         f32x4* const red = (f32x4*)slab;                                      // [wave][rt][tn][64 lanes]
         if (WK > 1) {
@@ -333,7 +336,8 @@ __global__ __launch_bounds__(256, 1) void conv_voxg_kernel(const VoxgArgs p) {
             for (int rt = 0; rt < NRT; ++rt)
                 if (rt < nrt) {
 #pragma unroll
-                    for (int tn = 0; tn < TN; ++tn) red[((wave * NRT + rt) * TN + tn) * 64 + lane] = acc[rt][tn];
+                    for (int tn = 0; tn < TN; ++tn)
+                        if (((rt * TN + tn) % WK) != wk) red[((wave * NRT + rt) * TN + tn) * 64 + lane] = acc[rt][tn];
                 }
             __syncthreads();
         }
@@ -344,9 +348,11 @@ __global__ __launch_bounds__(256, 1) void conv_voxg_kernel(const VoxgArgs p) {
                 if (rt >= nrt || (WK > 1 && ((rt * TN + tn) % WK) != wk)) continue;
                 f32x4 v = acc[rt][tn];
                 if (WK > 1) {
-                    v = red[(((wc * WK) * NRT + rt) * TN + tn) * 64 + lane];
 #pragma unroll
-                    for (int w = 1; w < WK; ++w) v += red[(((wc * WK + w) * NRT + rt) * TN + tn) * 64 + lane];
+                    for (int w = 0; w < WK; ++w) {
+                        const f32x4 pw = w == wk ? acc[rt][tn] : red[(((wc * WK + w) * NRT + rt) * TN + tn) * 64 + lane];
+                        v = w == 0 ? pw : v + pw;
+                    }
                 }
                 const int r = r0 + rt * 16 + fr;
                 if (r < nrows) {
