@@ -36,11 +36,12 @@ def main():
             docs[f"{V}^3 B{B} {mode}"] = r
             rows.append(f"{V}^3 x B{B:<3d} {mode:5s} total {r['ms']:.4f} ms  dense {r['achieved_dense_equivalent']:7.1f} TF ({100 * r['frac_dense_equivalent']:.2f} %)  "
                         f"executed {r['achieved']:7.1f} TF ({100 * r['frac']:.2f} % of 2.5 PF)  active-row {r['active_row_flops'] / r['ms'] / 1e9:7.1f} TF  "
-                        f"L0 HBM {r['level0_hbm']['achieved']:.0f} GB/s")
+                        f"L0 HBM {r['level0_hbm']['achieved']:.0f} GB/s  | raw events {r['ms_raw']:.4f} ms ({100 * r['frac']:.2f} %), "
+                        f"back to back {r['ms_back_to_back']:.4f} ms ({100 * r['frac_back_to_back']:.2f} %)")
             for l in r["levels"]:
                 rows.append(f"    L{l['level']} {l['kernel']:34s} {l['grid']:3d}^3 {l['cin']:3d}->{l['cout']:3d}  active {l['active_sites']:8d}/{l['sites']:9d} sites, "
                             f"{l['executed_tiles']:6d}/{l['tiles']:6d} tiles{'*' if l['compact_rows'] else ' '}  {l['ms']:.4f} ms  dense {l['dense_tflops']:7.1f}  executed {l['executed_tflops']:7.1f}  "
-                            f"active-row {l['active_row_tflops']:6.1f} TF  {l['algorithmic_hbm_gbs']:7.1f} GB/s")
+                            f"active-row {l['active_row_tflops']:6.1f} TF  {l['algorithmic_hbm_gbs']:7.1f} GB/s  b2b {l['ms_back_to_back']:.4f} ms")
             del net
             torch.cuda.empty_cache()
     text = "\n".join(rows)
