@@ -240,6 +240,10 @@ def voxel_fwd_roofline(net, batch, B, nrep=3):
             per_unit = per_unit.view(-1, spu).sum(dim=1)
             exec_rows = int((((per_unit + 15) // 16) * 16).sum().item())
             tiles = (exec_rows + 127) // 128
+        elif recs[l][0].startswith("conv_voxb"):       # conv_voxb_kernel: 16-row tiles over each 2 x 4 x D brick's ranked active sites
+            mb = m[:M].view(B, D // 2, 2, D // 4, 4, D).permute(0, 1, 3, 2, 4, 5).reshape(-1, 8 * D).sum(dim=1).to(torch.int64)
+            exec_rows = int((((mb + 15) // 16) * 16).sum().item())
+            tiles = (exec_rows + 127) // 128
         elif brick:                                    # brick kernels (conv_vox.hip) execute the 16-site x-runs that hold an active site
             exec_rows = 16 * int(m.view(-1, 16).any(dim=1).sum().item())
             tiles = (exec_rows + 127) // 128

@@ -107,7 +107,8 @@ int tri_conv_num_records(const TriConvDesc* d, int split3, int row_list);
  * register-stationary filter-bank kernels of conv_c64.hip (9 conv_c64_kernel: 64 -> 64 channels 3x3 / 1, both directions; 10 conv_s2d_kernel:
  * data gradient of the 64 -> 128 channel 3x3 / 2 layer; 11 conv_s2f_kernel: its forward, opt-in), 12 conv_pw_kernel (1x1 / 2 shortcuts),
  * 13 conv_voxg_kernel (conv_voxg.hip: SubMConv3d on 2^3 / 4^3 / 8^3 grids, both directions; takes the site mask as row_mask, refuses a
- * row list; bits 8..15 = output channels per workgroup, bits 24.. = samples per unit = per BatchNorm record).  For profilers. */
+ * row list; bits 8..15 = output channels per workgroup, bits 24.. = samples per unit = per BatchNorm record), 14 conv_voxb_kernel (voxel
+ * level 1 on 16^3 / 32^3 grids, forward only; site mask as row_mask).  Families 13 / 14 read FRAGMENT-MAJOR packed operands.  For profilers. */
 int tri_conv_kernel_family(const TriConvDesc* d, int transposed, int split3);
 /* same for tri_conv_wgrad: 0 conv_wgrad_kernel, 2 conv_wgrad_dma_kernel (taken when act_fmt != 0 and the layer qualifies) */
 int tri_conv_wgrad_kernel_family(const TriConvDesc* d, int act_fmt);

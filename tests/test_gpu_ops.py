@@ -1085,19 +1085,26 @@ def test_halo_kernels_ab_switch(rows):
     assert " passed" in r.stdout and "failed" not in r.stdout
 
 
-@pytest.mark.parametrize("switch", ["s2f"])
+@pytest.mark.parametrize("switch", ["s2f", "vox1", "voxb32", "no_voxg"])
 def test_opt_in_kernels_child_process(switch):
     """Kernels that are NOT on the default switch set keep their exactness coverage through a child process that sets the switch in its
     own environment (the parent - like bench.py - runs with no TRICOLO_* variable set, tests/conftest.py): conv_s2f_kernel
-    (TRICOLO_S2F_CONV=1, forward of the 64 -> 128 channel 3x3 / 2 layer; the s2d_* geometries assert family 11 there)."""
+    (TRICOLO_S2F_CONV=1, forward of the 64 -> 128 channel 3x3 / 2 layer; the s2d_* geometries assert family 11 there); conv_vox1_kernel
+    (TRICOLO_NO_VOXB=1: the run-based level-1 brick kernel, A/B partner of conv_voxb_kernel); conv_voxb_kernel on 32^3 level-1 grids
+    (TRICOLO_VOXB_32=1; conv_igemm_kernel is faster there); the voxel tower's coarse levels on
+    conv_dma_kernel over compact row lists (TRICOLO_NO_VOXG=1, A/B partner of conv_voxg_kernel: the bench-geometry voxel test)."""
     import subprocess
     import sys
-    env = dict(os.environ, TRICOLO_S2F_CONV="1")
-    k = "test_conv_16bit_storage_integer_exact and s2d_"
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", k, "-p", "no:cacheprovider"],
-                       env=env, capture_output=True, text=True, timeout=900)
+    env, k, f = {"s2f": ({"TRICOLO_S2F_CONV": "1"}, "test_conv_16bit_storage_integer_exact and s2d_", __file__),
+                 "vox1": ({"TRICOLO_NO_VOXB": "1"}, "test_voxel_level1_brick_kernel", __file__),
+                 "voxb32": ({"TRICOLO_VOXB_32": "1"}, "test_voxel_level1_ranked_brick_kernel and 32-", __file__),
+                 "no_voxg": ({"TRICOLO_NO_VOXG": "1", "TRICOLO_NO_VOXB": "1", "TRICOLO_BENCH_PLAN_ANY_SWITCH": "1"},
+                             "test_voxel_tower_bench_geometry_integer_exact and config4",
+                             os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_gpu_bench_plan.py"))}[switch]
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(f), "-q", "-x", "-k", k, "-p", "no:cacheprovider"],
+                       env=dict(os.environ, **env), capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout and "failed" not in r.stdout
+    assert " passed" in r.stdout and "failed" not in r.stdout and "skipped" not in r.stdout.split("\n")[-2]
 
 
 @pytest.mark.parametrize("store,prec", STORE16, ids=STORE16_IDS)
@@ -1638,6 +1645,46 @@ def test_voxel_level0_weight_gradient_brick_kernel(B, V, store, prec):
     assert float(out3.abs().max()) == 0.0
 
 
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("store,prec", STORE16, ids=STORE16_IDS)
+@pytest.mark.parametrize("B,V", [(5, 16), (40, 16), (90, 16), (3, 32), (18, 32)])
+def test_voxel_level1_ranked_brick_kernel(B, V, store, prec):
+    """conv_voxb_kernel (conv_voxg.hip): level 1 of the voxel tower (sparse_cnn.py:17, 32 -> 64 channels) on 16^3 and 32^3 grids - bricks of
+    256 sites, the active interior sites ranked in the kernel as MFMA rows, the active region sites loaded into a zero-padded slab and
+    cleared again, filter bank stationary in registers, persistent workgroups (B = 40 / 18: several bricks per workgroup).  Integer data:
+    active rows equal the masked dense convolution exactly whatever the input holds at inactive sites, rows of inactive sites stay
+    unwritten, the per-workgroup BatchNorm records sum to the active rows' column sums; without a mask it is the plain convolution
+    (256 rows per brick: two passes of eight tiles)."""
+    if V == 32 and os.environ.get("TRICOLO_VOXB_32") != "1":
+        pytest.skip("32^3 level-1 grids run conv_igemm_kernel by default: conv_voxb_kernel there is covered by test_opt_in_kernels_child_process[voxb32]")
+    case = ("vox1", B, (V, V, V), 32, 64, (3, 3, 3), 1, (1, 1, 1), "spconv")
+    x, w, wp, xcl, g = make_case(case, integer=True, seed=81)
+    assert g.brick(False, 2) and (g.kernel_family[(False, 2)] & 255) == 14
+    m = _blob_mask(B, V, seed=83)
+    mf = m.float()
+    xm = x * mf[:, None]
+    ref = cl3(F.conv3d(xm, w, padding=1)).to(store)
+    packed = ops.pack_weight(wp.to(DEV), g, prec)
+    M = B * V ** 3
+    mask = m.reshape(M).to(torch.uint8)
+    act = mask.bool()
+    dirty = xcl.clone().reshape(M, 32)
+    dirty[~act] = 3.0                                               # never read
+    junk = torch.full((B, V, V, V, 64), 777.0, dtype=store, device=DEV)
+    out, stats = ops.conv_fwd(dirty.view(B, V, V, V, 32).to(DEV).to(store), g, packed, row_mask=mask.to(DEV), want_stats=True, out=junk)
+    assert stats.shape[0] == g.num_mtiles[2]
+    o = out.cpu().reshape(M, 64)
+    assert torch.equal(o[act], ref.reshape(M, 64)[act]), f"max abs diff {(o[act].float() - ref.reshape(M, 64)[act].float()).abs().max().item()}"
+    assert bool((o[~act] == 777.0).all()), "rows of inactive sites must not be written"
+    exact = ref.reshape(M, 64)[act].double()
+    st = stats.cpu().double().sum(0)
+    np.testing.assert_allclose(st[0].numpy(), exact.sum(0).numpy(), rtol=1e-6, atol=1e-2)
+    np.testing.assert_allclose(st[1].numpy(), (exact ** 2).sum(0).numpy(), rtol=1e-6, atol=1e-2)
+    if B <= 5:
+        out2 = ops.conv_fwd(xcl.to(DEV).to(store), g, packed)
+        assert torch.equal(out2.cpu(), cl3(F.conv3d(x, w, padding=1)).to(store))
+
+
 @pytest.mark.parametrize("store,prec", STORE16, ids=STORE16_IDS)
 @pytest.mark.parametrize("B,V", [(5, 16), (40, 16), (70, 16)])
 def test_voxel_level1_brick_kernel(B, V, store, prec):
@@ -1645,6 +1692,8 @@ def test_voxel_level1_brick_kernel(B, V, store, prec):
     registers, persistent workgroups over the grid's bricks (B = 40: several bricks per workgroup, more bricks than workgroups x 1).
     Integer data: active rows equal the masked dense convolution exactly, rows of inactive sites stay unwritten, the per-workgroup
     BatchNorm records sum to the column sums of the active rows; without a mask it is the plain convolution."""
+    if os.environ.get("TRICOLO_NO_VOXB") != "1":
+        pytest.skip("conv_vox1_kernel is the A/B partner of conv_voxb_kernel since round 5: covered by test_opt_in_kernels_child_process[vox1]")
     case = ("vox1", B, (V, V, V), 32, 64, (3, 3, 3), 1, (1, 1, 1), "spconv")
     x, w, wp, xcl, g = make_case(case, integer=True, seed=81)
     assert g.brick(False, 2) and (g.kernel_family[(False, 2)] & 255) == 7

@@ -1924,6 +1924,7 @@ struct ConvPlan {
     int vox0_grid;
     int vox1;             // 1: conv_vox1_kernel (level 1 of the voxel tower, 32 -> 64 channels, 16-bit storage); records = vox1_grid
     int vox1_grid;
+    int voxb, voxb_grid;  // 1: conv_voxb_kernel (conv_voxg.hip: level 1 of the voxel tower, ranked active rows over bricks); records = voxb_grid
     int voxg;             // 1: conv_voxg_kernel (conv_voxg.hip: SubMConv3d on 2^3 / 4^3 / 8^3 grids, forward and data gradient, 16-bit storage);
     int voxg_units, voxg_ct, voxg_spu;        // records = units
     int c64;              // 1: conv_c64_kernel (conv_c64.hip: 64 -> 64 channels, 2D 3x3 / 1 / pad 1, 16-bit storage); records = c64_grid
@@ -2083,6 +2084,11 @@ static ConvPlan conv_make_plan(int B, int ID, int IH, int IW, int cin, int OD, i
         TriVox0Geom vg;
         if (split_mode == 2 && tri_internal_vox0_geometry(B, ID, IH, IW, cin, OD, OH, OW, cout, KD, KH, KW, stride, pd, ph, pw, &vg)) {
             pl.vox0 = 1; pl.vox0_grid = vg.grid; pl.bn = 32; pl.nunits = 4; pl.ksplit = 1; pl.per_split = 4;
+            return pl;
+        }
+        TriVoxbGeom vb;
+        if (split_mode == 2 && tri_internal_voxb_geometry(B, ID, IH, IW, cin, OD, OH, OW, cout, KD, KH, KW, stride, pd, ph, pw, &vb)) {
+            pl.voxb = 1; pl.voxb_grid = vb.grid; pl.bn = 64; pl.nunits = 27; pl.ksplit = 1; pl.per_split = 27;
             return pl;
         }
         TriVox1Geom v1;
@@ -2412,6 +2418,16 @@ static int conv_dispatch(ConvArgs& a, int act_fmt, void* workspace, size_t works
         tri_internal_vox0_geometry(a.B, a.ID, a.IH, a.IW, a.Cin, a.OD, a.OH, a.OW, a.Cout, a.KD, a.KH, a.KW, a.stride, a.pd, a.ph, a.pw, &vg);
         return tri_internal_vox0_launch(vg, a.B, a.in, a.w_hi, a.Kpad, a.out, a.row_mask, a.stats, act_fmt, stream);
     }
+    if (pl.voxb && !a.transposed) {
+        if (a.row_count || a.bias || a.act != 0 || a.accumulate) {
+            tri_set_error("conv: this layer runs conv_voxb_kernel (tri_conv_kernel_family == 14): pass the site mask as row_mask, no row list, "
+                          "bias, activation or accumulate");
+            return TRI_ERR_ARG;
+        }
+        TriVoxbGeom vb;
+        tri_internal_voxb_geometry(a.B, a.ID, a.IH, a.IW, a.Cin, a.OD, a.OH, a.OW, a.Cout, a.KD, a.KH, a.KW, a.stride, a.pd, a.ph, a.pw, &vb);
+        return tri_internal_voxb_launch(vb, a.B, a.in, a.w_hi, a.out, a.row_mask, a.stats, act_fmt, stream);
+    }
     if (pl.vox1 && !a.transposed) {
         if (a.row_count || a.bias || a.act != 0 || a.accumulate) {
             tri_set_error("conv: this layer runs the brick kernel (tri_conv_kernel_family == 7): pass the site mask as row_mask, no row list, "
@@ -2499,6 +2515,7 @@ extern "C" int tri_conv_num_records(const TriConvDesc* d, int split3, int row_li
                                  d->pad_h, d->pad_w, split3, row_list);
     if (pl.stem) return pl.stem_grid;
     if (pl.vox0) return pl.vox0_grid;
+    if (pl.voxb) return pl.voxb_grid;
     if (pl.vox1) return pl.vox1_grid;
     if (pl.voxg) return pl.voxg_units;
     if (pl.c64) return pl.c64_grid;
@@ -2516,6 +2533,7 @@ extern "C" int tri_conv_kernel_family(const TriConvDesc* d, int transposed, int 
                                               d->pad_d, d->pad_h, d->pad_w, split3);
     if (pl.stem && !transposed) return 4 | (64 << 8);
     if (pl.vox0 && !transposed) return 6 | (32 << 8);
+    if (pl.voxb && !transposed) return 14 | (64 << 8);
     if (pl.vox1 && !transposed) return 7 | (64 << 8);
     if (pl.voxg) return 13 | (pl.voxg_ct << 8) | (pl.voxg_spu << 24);      // (bits 24..: samples per unit)
     if (pl.c64) return 9 | (64 << 8);

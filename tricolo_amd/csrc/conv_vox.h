@@ -34,6 +34,14 @@ bool tri_internal_voxg_geometry(int B, int ID, int IH, int IW, int cin, int OD, 
 int tri_internal_voxg_launch(const TriVoxgGeom& g, int B, int cin, int cout, int kpad, const void* in, const void* w, void* out, const uint8_t* mask,
                              float* stats, int transposed, int act_fmt, hipStream_t stream);
 
+// level 1 of the voxel tower (32 -> 64 channels on 16^3 / 32^3 grids, 16-bit storage): conv_voxb_kernel (conv_voxg.hip) - bricks of 256
+// sites, ranked active rows, filter bank stationary; forward only, over the SITE MASK; g->grid = persistent workgroups = BatchNorm records
+struct TriVoxbGeom { int D, nbricks, grid; };
+bool tri_internal_voxb_geometry(int B, int ID, int IH, int IW, int cin, int OD, int OH, int OW, int cout, int KD, int KH, int KW, int stride,
+                                int pd, int ph, int pw, TriVoxbGeom* g);
+int tri_internal_voxb_launch(const TriVoxbGeom& g, int B, const void* in, const void* w, void* out, const uint8_t* mask, float* stats, int act_fmt,
+                             hipStream_t stream);
+
 struct TriC64Geom { int W, TY, nbricks, grid; };
 // a 64 -> 64 channel 3x3 / 1 / pad 1 2D layer on 16- / 32- / 64-pixel-wide images in a 16-bit storage mode (layer1 of the ResNet trunk):
 // conv_c64_kernel (conv_c64.hip), forward and data gradient; g->grid = persistent workgroups = BatchNorm records of the launch

@@ -490,3 +490,332 @@ int tri_internal_voxg_launch(const TriVoxgGeom& g, int B, int cin, int cout, int
     tri_set_error("conv(voxg): channel tile not instantiated");
     return TRI_ERR_UNSUPPORTED;
 }
+
+// ================================================================================================ level 1: 32 -> 64 channels on 16^3 / 32^3 grids
+// conv_voxb_kernel.  Level 1 (sparse_cnn.py:17) has ONE 32-channel chunk and a filter bank of only 110 KB, but grids too large for a
+// whole-sample slab: through conv_vox1_kernel (16^3 grids: 16-site x-runs by the mask, 2.2 x the active rows multiplied, every wave
+// reading every B fragment: LDS-bound) it took 14.7 us at the bench shape, through conv_igemm_kernel (32^3 grids: im2col gather over the
+// row list, one tap per k-step, register-staged) 88-95 us at 64^3 x 64 - a chain of exposed gather latencies at 6 x the MFMA time.
+// Here conv_voxg_kernel's scheme runs over BRICKS of the grid with the filter bank stationary:
+//   * a brick = 2 z-planes x BY rows x all D columns (BY = 4: 128 sites at 16^3, 256 at 32^3); its REGION = the brick plus a one-site
+//     halo in z and y (4 x (BY + 2) rows; x needs none: the row pitch D + 1 supplies the zero column).  A persistent workgroup (two
+//     per CU: one ranks / loads while the other multiplies) walks bricks wg, wg + G, ...;
+//   * per brick: the region's site mask is ranked twice (ballot / popcount) - the active INTERIOR sites become the MFMA rows, all
+//     active REGION sites the slab's load list; only those sites are loaded (64 B each) into a zero-padded LDS slab in
+//     conv_voxg_kernel's two-half layout, and cleared again after the brick (the slab is zeroed once per workgroup);
+//   * wave w owns output channels 16 w .. 16 w + 15 and keeps their 27 A fragments in registers for the whole launch (fragment-major
+//     operand: 27 contiguous 1 KiB loads per wave); a brick's rows run in passes of up to 8 tiles of 16 rows, branch-free per tile
+//     count, B fragments read one tap ahead; no K split, so a lane's accumulators are final: 8-byte stores, BatchNorm sums in
+//     registers over all bricks, one record per workgroup (each wave writes its own 16 channels);
+//   * the next brick's mask bytes are requested before the current brick's MFMAs.
+struct VoxbArgs {
+    const void* in;            // [B, D, D, D, 32] 16-bit (values at inactive sites are never read)
+    const void* w;             // packed operand, fragment-major [4 tiles][27 k-steps][64 lanes][8]
+    void* out;                 // [B, D, D, D, 64]; rows of inactive sites are not written
+    const uint8_t* mask;       // [B * D^3] site mask, or NULL (every site active)
+    float* stats;              // [grid][2][64] or NULL
+    int B, nbricks;
+    unsigned in_bytes;
+#ifdef VOXG_PROBE
+    long long* dbg;            // [grid][16]: cycles per phase summed over the workgroup's bricks (wave 0)
+#endif
+};
+#ifdef VOXG_PROBE
+#define VOXB_T(i) do { if (t == 0) { const long long now_ = (long long)__builtin_amdgcn_s_memtime(); acc_t[i] += now_ - last_t; last_t = now_; } } while (0)
+#else
+#define VOXB_T(i)
+#endif
+
+template <int D>
+struct VoxbCfg {
+    static constexpr int BZ = 2, BY = D == 16 ? 4 : 128 / D;                  // interior sites: 128 (16^3 grids: more, better balanced bricks) / 256
+    static constexpr int RZ = BZ + 2, RY = BY + 2, P = D + 1;
+    static constexpr int NREG = RZ * RY * D;                                  // region sites (768 / 640)
+    static constexpr int ROUNDS = (NREG + 255) / 256;                         // ranking rounds (3)
+    static constexpr int NS = RZ * RY * P + P + 2;                            // padded slab sites
+    static constexpr int HALF = (NS * 32 + 255) / 256 * 256 + 128;
+    static constexpr int SLAB = 2 * HALF;
+    static constexpr int NYB = D / BY, PS = (D / BZ) * NYB;                   // bricks per sample
+    // LDS: [2 table sets: load_off[NREG], load_glob[NREG], row_lds[256], row_glob[256]] | counts | slab
+    static constexpr int NINT = BZ * BY * D;                                  // interior sites
+    static constexpr int TABSET = (2 * NREG + 2 * NINT) * 4;
+    static constexpr int CNT = 2 * TABSET;
+    static constexpr int SLAB0 = (CNT + 256 + 255) / 256 * 256;
+    static constexpr size_t SMEM = (size_t)SLAB0 + SLAB;
+};
+
+template <typename AT, int D>
+__global__ __launch_bounds__(256, 2) void conv_voxb_kernel(const VoxbArgs p) {
+    typedef VoxbCfg<D> C;
+    typedef typename OpOf<AT>::E E;
+    typedef Mma<E> MM;
+    typedef typename MM::v8 v8;
+    constexpr int NRT = 8, MAXL = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), fr = lane & 15, fq = lane >> 4;
+    char* const slab = smem + C::SLAB0;
+    int* const wcnt = (int*)(smem + C::CNT);                                  // [ROUNDS][4 waves][2]
+    const int G = gridDim.x, wg = blockIdx.x;
+
+    // ---- filter bank of this wave's 16 output channels: 27 contiguous fragment loads, kept for the whole launch
+    v8 wf[27];
+    {
+        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 4 * 27 * 1024, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < 27; ++k)
+            wf[k] = __builtin_bit_cast(v8, __builtin_amdgcn_raw_buffer_load_b128(wrs, (unsigned)((wave * 27 + k) * 1024 + lane * 16), 0, 0));
+    }
+    // ---- region site of this thread in each ranking round (constant over bricks): e = t + 256 j -> (zr, yr, x)
+    int rzy[C::ROUNDS], rx[C::ROUNDS];                                        // zr * 64 + yr, x  (-1: past the region)
+    int sp32[C::ROUNDS];                                                      // padded slab site * 32 (bytes inside a half)
+    bool inner[C::ROUNDS];
+#pragma unroll
+    for (int j = 0; j < C::ROUNDS; ++j) {
+        const int e = t + 256 * j;
+        const int rr = e / D, x = e % D, zr = rr / C::RY, yr = rr % C::RY;
+        const bool ok = e < C::NREG;
+        rzy[j] = ok ? zr * 64 + yr : -1;
+        rx[j] = x;
+        sp32[j] = ((zr * C::RY + yr) * C::P + x + 1) * 32;
+        inner[j] = ok && zr >= 1 && zr <= C::BZ && yr >= 1 && yr <= C::BY;
+    }
+    auto brick_of = [&](int j, int& b, int& z0, int& y0) {
+        b = j / C::PS;
+        const int sp = (j % C::PS + b * (C::PS / 2 + 1)) % C::PS;             // rotated by the sample (see conv_vox0_kernel)
+        z0 = (sp / C::NYB) * C::BZ;
+        y0 = (sp % C::NYB) * C::BY;
+    };
+    auto load_mask = [&](int j, uint8_t (&m)[C::ROUNDS], int (&gsite)[C::ROUNDS]) {
+        int b, z0, y0;
+        brick_of(j, b, z0, y0);
+#pragma unroll
+        for (int r = 0; r < C::ROUNDS; ++r) {
+            const int z = z0 - 1 + (rzy[r] >> 6), y = y0 - 1 + (rzy[r] & 63);
+            const bool ok = rzy[r] >= 0 && j < p.nbricks && (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)D;
+            gsite[r] = ((b * D + z) * D + y) * D + rx[r];
+            m[r] = ok ? (p.mask ? p.mask[gsite[r]] : (uint8_t)1) : (uint8_t)0;
+        }
+    };
+    // zero the slab once: afterwards a brick writes its active region sites and clears exactly those again
+    for (int i = t * 16; i < C::SLAB; i += 256 * 16) *(uint4*)(slab + i) = make_uint4(0u, 0u, 0u, 0u);
+
+    const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    const int lane_part = (fq >> 1) * C::HALF + (fq & 1) * 16;
+    const int centre = (C::RY * C::P + C::P + 1) * 32;                        // (the row tables hold the (-1,-1,-1) corner: site - centre)
+    f32x4 cs = {0.f, 0.f, 0.f, 0.f}, cq = cs;
+    uint8_t mk[C::ROUNDS];
+    int gs[C::ROUNDS];
+    load_mask(wg, mk, gs);
+    int nload_prev = 0;
+    int it = 0;
+#ifdef VOXG_PROBE
+    long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_t = (long long)__builtin_amdgcn_s_memtime();
+    const long long t_begin = last_t;
+    int n_nonempty = 0, n_rows = 0;
+#endif
+#pragma unroll 1
+    for (int j = wg; j < p.nbricks; j += G, ++it) {
+        int* const tab = (int*)(smem + (it & 1) * C::TABSET);
+        int* const load_off = tab, * const load_glob = tab + C::NREG, * const row_lds = tab + 2 * C::NREG, * const row_glob = row_lds + C::NINT;
+        int* const ptab = (int*)(smem + ((it & 1) ^ 1) * C::TABSET);          // the previous brick's load list
+        VOXB_T(7);
+        __syncthreads();                                                      // [S1] every wave is done with the previous brick's slab
+        VOXB_T(0);
+        // clear the previous brick's sites (its load list is still in the other table set)
+        for (int e = t; e < 4 * nload_prev; e += 256) {
+            const int r = e >> 2, q = e & 3;
+            *(uint4*)(slab + ptab[r] + (q >> 1) * C::HALF + (q & 1) * 16) = make_uint4(0u, 0u, 0u, 0u);
+        }
+        // rank: region sites -> load list, interior sites -> MFMA rows (raster order)
+        unsigned long long ball[C::ROUNDS], balr[C::ROUNDS];
+#pragma unroll
+        for (int r = 0; r < C::ROUNDS; ++r) {
+            ball[r] = __ballot(mk[r] != 0);
+            balr[r] = __ballot(mk[r] != 0 && inner[r]);
+            if (lane == 0) { wcnt[(r * 4 + wave) * 2] = __popcll(ball[r]); wcnt[(r * 4 + wave) * 2 + 1] = __popcll(balr[r]); }
+        }
+        VOXB_T(1);
+        __syncthreads();
+        VOXB_T(2);
+        int nload = 0, nrows = 0;
+        {
+            int basel[C::ROUNDS], baser[C::ROUNDS];
+#pragma unroll
+            for (int r = 0; r < C::ROUNDS; ++r)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    if (w == wave) { basel[r] = nload; baser[r] = nrows; }
+                    nload += wcnt[(r * 4 + w) * 2];
+                    nrows += wcnt[(r * 4 + w) * 2 + 1];
+                }
+            const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+            for (int r = 0; r < C::ROUNDS; ++r)
+                if (mk[r]) {
+                    const int kl = basel[r] + __popcll(ball[r] & below);
+                    load_off[kl] = sp32[r];
+                    load_glob[kl] = gs[r];
+                    if (inner[r]) {
+                        const int kr = baser[r] + __popcll(balr[r] & below);
+                        row_lds[kr] = sp32[r] - centre;
+                        row_glob[kr] = gs[r];
+                    }
+                }
+        }
+        __syncthreads();                                                      // [S2] tables visible; the clears are ordered before the slab writes below
+        VOXB_T(3);
+        // the next brick's mask bytes fly under this brick's loads and MFMAs
+        load_mask(j + G, mk, gs);
+        nload_prev = nload;
+        if (nrows > 0) {
+            // slab: 64 bytes of every active region site (four 16-byte pieces)
+            {
+                uint4 pre[MAXL];
+#pragma unroll
+                for (int u = 0; u < MAXL; ++u) {
+                    const int e = t + 256 * u;
+                    if (e < 4 * nload) pre[u] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(irs, (unsigned)(load_glob[e >> 2] * 64 + (e & 3) * 16), 0, 0));
+                }
+#pragma unroll
+                for (int u = 0; u < MAXL; ++u) {
+                    const int e = t + 256 * u;
+                    if (e < 4 * nload) *(uint4*)(slab + load_off[e >> 2] + ((e & 3) >> 1) * C::HALF + (e & 1) * 16) = pre[u];
+                }
+#pragma unroll 1
+                for (int e = t + 256 * MAXL; e < 4 * nload; e += 256) {
+                    const uint4 v = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(irs, (unsigned)(load_glob[e >> 2] * 64 + (e & 3) * 16), 0, 0));
+                    *(uint4*)(slab + load_off[e >> 2] + ((e & 3) >> 1) * C::HALF + (e & 1) * 16) = v;
+                }
+            }
+            __syncthreads();                                                  // [S3] slab complete
+            VOXB_T(4);
+#ifdef VOXG_PROBE
+            ++n_nonempty; n_rows += nrows;
+#endif
+#pragma unroll 1
+            for (int r0 = 0; r0 < nrows; r0 += 16 * NRT) {
+                const int nrt = min(NRT, (nrows - r0 + 15) >> 4);
+                auto pass = [&](auto NTc) {
+                    constexpr int NT = decltype(NTc)::value;
+                    int lbase[NT];
+                    f32x4 acc[NT];
+#pragma unroll
+                    for (int rt = 0; rt < NT; ++rt) {
+                        const int r = r0 + rt * 16 + fr;
+                        lbase[rt] = (r < nrows ? row_lds[r] : 0) + lane_part;
+                        acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    }
+                    v8 bf[NT];
+#pragma unroll
+                    for (int rt = 0; rt < NT; ++rt) bf[rt] = *(const v8*)(slab + lbase[rt]);
+#pragma unroll
+                    for (int k = 0; k < 27; ++k) {
+                        constexpr int dummy = 0;
+                        const int kn = k + 1;
+                        const int toff = ((kn / 9 * C::RY + (kn / 3) % 3) * C::P + kn % 3) * 32;
+#pragma unroll
+                        for (int rt = 0; rt < NT; ++rt) {
+                            acc[rt] = MM::mma(wf[k], bf[rt], acc[rt]);
+                            if (k + 1 < 27) bf[rt] = *(const v8*)(slab + lbase[rt] + toff);
+                        }
+                        (void)dummy;
+                    }
+#pragma unroll
+                    for (int rt = 0; rt < NT; ++rt) {
+                        const int r = r0 + rt * 16 + fr;
+                        if (r < nrows) {
+                            typedef E e4 __attribute__((ext_vector_type(4)));
+                            const e4 h = __builtin_convertvector(acc[rt], e4);
+                            *(e4*)((AT*)p.out + (size_t)row_glob[r] * 64 + wave * 16 + fq * 4) = h;
+                            const f32x4 rv = {(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+                            cs += rv;
+                            cq += rv * rv;
+                        }
+                    }
+                };
+                if (nrt <= 1) pass(std::integral_constant<int, 1>{});
+                else if (nrt <= 2) pass(std::integral_constant<int, 2>{});
+                else if (nrt <= 3) pass(std::integral_constant<int, 3>{});
+                else if (nrt <= 4) pass(std::integral_constant<int, 4>{});
+                else if (nrt <= 6) pass(std::integral_constant<int, 6>{});
+                else pass(std::integral_constant<int, 8>{});
+            }
+            VOXB_T(5);
+        }
+    }
+#ifdef VOXG_PROBE
+    if (p.dbg && t == 0) {
+        for (int i = 0; i < 8; ++i) p.dbg[(size_t)blockIdx.x * 16 + i] = acc_t[i];
+        p.dbg[(size_t)blockIdx.x * 16 + 8] = (long long)__builtin_amdgcn_s_memtime() - t_begin;
+        p.dbg[(size_t)blockIdx.x * 16 + 9] = n_nonempty;
+        p.dbg[(size_t)blockIdx.x * 16 + 10] = n_rows;
+        p.dbg[(size_t)blockIdx.x * 16 + 11] = it;
+    }
+#endif
+    if (p.stats) {                                                            // one record per workgroup: wave w owns channels 16 w ..
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float s_ = cs[r], q_ = cq[r];
+            s_ += voxg_row_ror<8>(s_); q_ += voxg_row_ror<8>(q_);
+            s_ += voxg_row_ror<4>(s_); q_ += voxg_row_ror<4>(q_);
+            s_ += voxg_row_ror<2>(s_); q_ += voxg_row_ror<2>(q_);
+            s_ += voxg_row_ror<1>(s_); q_ += voxg_row_ror<1>(q_);
+            if (fr == 0) {
+                p.stats[(size_t)blockIdx.x * 128 + wave * 16 + fq * 4 + r] = s_;
+                p.stats[(size_t)blockIdx.x * 128 + 64 + wave * 16 + fq * 4 + r] = q_;
+            }
+        }
+    }
+}
+
+static bool voxb_disabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("TRICOLO_NO_VOXB"); v = (e && e[0] == '1') ? 1 : 0; }      // A/B switch: level 1 stays on conv_vox1_kernel / conv_igemm_kernel
+    return v == 1;
+}
+
+bool tri_internal_voxb_geometry(int B, int ID, int IH, int IW, int cin, int OD, int OH, int OW, int cout, int KD, int KH, int KW, int stride,
+                                int pd, int ph, int pw, TriVoxbGeom* g) {
+    if (voxb_disabled()) return false;
+    const int D = ID;
+    // 16^3 grids (32^3 inputs) by default: 15.1 / 23.4 us against conv_vox1_kernel's 16.4 / 26.0 at batch 32 / 64.  On 32^3 grids (64^3
+    // inputs, 8,192 bricks, three quarters of them empty) the per-brick chain - mask, two rankings, tables, slab gather, three barriers,
+    // and a B-fragment read per MFMA with two workgroups sharing the LDS (stamps: 11 k cycles per non-empty brick against 2.6 k of
+    // MFMAs) - makes it 100 us against conv_igemm_kernel's 88: TRICOLO_VOXB_32=1 plans it there anyway (tests do, in a child process)
+    static int big = -1;
+    if (big < 0) { const char* e = getenv("TRICOLO_VOXB_32"); big = (e && e[0] == '1') ? 1 : 0; }
+    if (IH != D || IW != D || OD != D || OH != D || OW != D || (D != 16 && !(D == 32 && big))) return false;
+    if (cin != 32 || cout != 64 || KD != 3 || KH != 3 || KW != 3 || stride != 1 || pd != 1 || ph != 1 || pw != 1) return false;
+    if ((long)B * D * D * D * 64 >= (1L << 31)) return false;                 // 32-bit buffer offsets
+    g->D = D;
+    g->nbricks = B * (D / 2) * (D / (D == 16 ? 4 : 128 / D));
+    int grid = 2 * tri_internal_num_cus();                                    // persistent: two workgroups per CU
+    if (grid > g->nbricks) grid = g->nbricks;
+    g->grid = grid;
+    return true;
+}
+
+template <typename AT, int D>
+static int voxb_launch_t(const VoxbArgs& a, int grid, hipStream_t stream) {
+    typedef VoxbCfg<D> C;
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute((const void*)conv_voxb_kernel<AT, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::SMEM);
+        attr = true;
+    }
+    conv_voxb_kernel<AT, D><<<grid, 256, C::SMEM, stream>>>(a);
+    return tri_check_launch("tri_conv(voxb)");
+}
+
+int tri_internal_voxb_launch(const TriVoxbGeom& g, int B, const void* in, const void* w, void* out, const uint8_t* mask, float* stats, int act_fmt,
+                             hipStream_t stream) {
+    VoxbArgs a{};
+    a.in = in; a.w = w; a.out = out; a.mask = mask; a.stats = stats;
+    a.B = B; a.nbricks = g.nbricks;
+    a.in_bytes = (unsigned)((size_t)B * g.D * g.D * g.D * 64);
+#ifdef VOXG_PROBE
+    { const char* e = getenv("TRICOLO_VOXG_DBG"); a.dbg = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
+#endif
+    if (g.D == 16) return act_fmt == TRI_FMT_F16 ? voxb_launch_t<f16_t, 16>(a, g.grid, stream) : voxb_launch_t<bf16_t, 16>(a, g.grid, stream);
+    return act_fmt == TRI_FMT_F16 ? voxb_launch_t<f16_t, 32>(a, g.grid, stream) : voxb_launch_t<bf16_t, 32>(a, g.grid, stream);
+}

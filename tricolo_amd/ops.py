@@ -139,6 +139,8 @@ def _igemm_symbol(g, transposed, split, t):
         return f"conv_vox0_kernel<{_TNAME[t.dtype]}>"
     if fam == 7:
         return f"conv_vox1_kernel<{_TNAME[t.dtype]}>"
+    if fam == 14:
+        return f"conv_voxb_kernel<{_TNAME[t.dtype]}>"
     if fam == 13:
         return f"conv_voxg_kernel<{bn}, {_TNAME[t.dtype]}>"                # (forward and data gradient under one name)
     if fam == 9:
@@ -262,7 +264,7 @@ class ConvGeom:
         """True when tri_conv_fwd / tri_conv_dgrad runs this layer on a kernel that walks the dense grid by the SITE MASK (the brick kernels
         of conv_vox.hip, conv_voxg_kernel on the coarse grids): such launches take the mask as row_mask (rows of inactive sites are then
         neither computed nor written), not a compact row list."""
-        return (self.kernel_family[(transposed, mode)] & 255) in (6, 7, 13)
+        return (self.kernel_family[(transposed, mode)] & 255) in (6, 7, 13, 14)
 
     def packed_frag(self, transposed: bool, precision: str, storage=None) -> int:
         """1 when the kernel that consumes this layer's packed operand (forward / data gradient) reads it in MFMA-fragment-major order
@@ -270,11 +272,11 @@ class ConvGeom:
         activation storage the operand will meet (default: the precision mode's own)."""
         storage = storage or act_dtype(precision)
         mode = 1 if precision == "bf16x3" else (2 if storage != torch.float32 else 0)
-        return 1 if (self.kernel_family[(transposed, mode)] & 255) == 13 else 0
+        return 1 if (self.kernel_family[(transposed, mode)] & 255) in (13, 14) else 0
 
     def check_packed(self, packed, transposed: bool, x):
         """The packed operand must be in the order this call's kernel reads (see pack_weight's `storage`)."""
-        need = 1 if (self.kernel_family[(transposed, _conv_mode(x, packed[1]))] & 255) == 13 else 0
+        need = 1 if (self.kernel_family[(transposed, _conv_mode(x, packed[1]))] & 255) in (13, 14) else 0
         if getattr(packed[0], "tri_frag", 0) != need:
             raise RuntimeError("conv: the packed operand was ordered for another plan (row-major vs fragment-major): pack it with "
                                "pack_weight(..., storage=<dtype of the activations>)")
