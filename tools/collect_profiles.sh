@@ -1,6 +1,6 @@
 #!/bin/bash
 # Copy what tools/profile_round.sh <tag> merged back into gpurun_out/ into the tracked profiles/<tag>/ (the judge reads profiles/).
-tag=${1:-r4}
+tag=${1:-r5}
 O=gpurun_out
 P=profiles/$tag
 mkdir -p $P
@@ -11,6 +11,9 @@ for p in f16 bf16x3; do
   # (gpurun merges every call's files into gpurun_out/: take the newest run's stats, not the first name found)
   f=$(find $O/${tag}_prof_$p -name "*kernel_stats.csv" -printf "%T@ %p\n" | sort -n | tail -1 | cut -d" " -f2); [ -n "$f" ] && cp $f $P/kernel_stats_$p.csv
   cp $O/${tag}_prof_$p.json $P/bench_under_rocprof_$p.json
+done
+for c in cfg2 cfg5 voxel_fwd; do
+  f=$(find $O/${tag}_prof_$c -name "*kernel_stats.csv" -printf "%T@ %p\n" | sort -n | tail -1 | cut -d" " -f2); [ -n "$f" ] && cp $f $P/kernel_stats_$c.csv
 done
 cp $O/${tag}_pmc_traffic_f16.json $P/pmc_traffic_f16.json
 cp $O/${tag}_pmc_mfma_f16.json $P/pmc_mfma_f16.json
