@@ -238,11 +238,21 @@ def voxel_fwd_roofline(net, batch, B, nrep=3):
             if B % spu:
                 per_unit = torch.cat([per_unit, per_unit.new_zeros(spu - B % spu)])
             per_unit = per_unit.view(-1, spu).sum(dim=1)
-            exec_rows = int((((per_unit + 15) // 16) * 16).sum().item())
+            # what the kernel EXECUTES: passes of up to NRT tiles (NRT by the unit's dense sites), the last pass's tile count rounded up to
+            # the next instantiated loop (2 / 4 / 6 / 8 / 10 / 12, capped by NRT): conv_voxg.hip chunk_loop
+            nsites = spu * D ** 3
+            nrt_max = 2 if nsites <= 32 else (4 if nsites <= 64 else (8 if nsites <= 128 else 12))
+            tiles_u = (per_unit + 15) // 16
+            full, rest = tiles_u // nrt_max, tiles_u % nrt_max
+            rest_up = torch.where(rest > 0, torch.clamp(((rest + 1) // 2) * 2, max=nrt_max), rest)
+            exec_rows = int(((full * nrt_max + rest_up) * 16).sum().item())
             tiles = (exec_rows + 127) // 128
         elif recs[l][0].startswith("conv_voxb"):       # conv_voxb_kernel: 16-row tiles over each 2 x 4 x D brick's ranked active sites
             mb = m[:M].view(B, D // 2, 2, D // 4, 4, D).permute(0, 1, 3, 2, 4, 5).reshape(-1, 8 * D).sum(dim=1).to(torch.int64)
-            exec_rows = int((((mb + 15) // 16) * 16).sum().item())
+            tiles_b = (mb + 15) // 16                  # passes of 8 tiles, the last one on the next instantiated count (1 / 2 / 3 / 4 / 6 / 8)
+            full, rest = tiles_b // 8, tiles_b % 8
+            rest_up = torch.where(rest == 5, torch.full_like(rest, 6), torch.where(rest == 7, torch.full_like(rest, 8), rest))
+            exec_rows = int(((full * 8 + rest_up) * 16).sum().item())
             tiles = (exec_rows + 127) // 128
         elif brick:                                    # brick kernels (conv_vox.hip) execute the 16-site x-runs that hold an active site
             exec_rows = 16 * int(m.view(-1, 16).any(dim=1).sum().item())
@@ -302,6 +312,11 @@ def voxel_fwd_roofline(net, batch, B, nrep=3):
     return {"bound": "mfma", "what": "five SubMConv3d forwards of the voxel tower, per-GPU batch %d, %d^3" % (B, V),
             "ms_back_to_back": round(tot_b2b, 4),
             "achieved_back_to_back": round(tot_exec / tot_b2b / 1e9, 2), "frac_back_to_back": round(tot_exec / tot_b2b / 1e9 / MFMA_PEAK_TFLOPS, 4),
+            # constant work across kernel generations: the FLOPs of the active rows alone (what no kernel can skip).  `executed_flops` shrinks when a
+            # kernel stops multiplying inactive rows of a tile / run (round 5: level 1 executes 1.15 x its active rows instead of 2.2 x), so the
+            # executed-FLOP fraction can stay flat while the launches get faster; these two move only with time
+            "frac_active_rows_raw_events": round(tot_rows / tot_raw / 1e9 / MFMA_PEAK_TFLOPS, 4),
+            "frac_active_rows_back_to_back": round(tot_rows / tot_b2b / 1e9 / MFMA_PEAK_TFLOPS, 4),
             "timing_back_to_back": "each level's launch replayed 20 x back to back from a HIP graph between ONE event pair (kernel + launch boundary, "
                                    "no per-launch event cost); `frac` / `achieved` stay on the single-launch RAW event times as in round 4",
             "ms": round(tot_ms, 4), "ms_raw": round(tot_raw, 4),
