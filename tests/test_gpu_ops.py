@@ -1788,3 +1788,29 @@ def test_voxel_coarse_grid_kernel(B, D, cin, cout, store, prec):
         junk3 = torch.full((B, D, D, D, cout), 777.0, dtype=store, device=DEV)
         out3, stats3 = ops.conv_fwd(xcl.to(DEV).to(store), g, packed, row_mask=torch.zeros_like(mask).to(DEV), want_stats=True, out=junk3)
         assert bool((out3 == 777.0).all()) and float(stats3.abs().max()) == 0.0
+
+
+def test_packed_operand_order_is_checked():
+    """conv_voxg_kernel / conv_voxb_kernel read FRAGMENT-MAJOR packed operands, every other kernel row-major ones; the C entry points cannot
+    tell which order a buffer is in, so the Python layer tags the buffers (pack_weight's `storage` selects the plan mode) and conv_fwd /
+    conv_dgrad refuse an operand packed for another plan instead of computing garbage."""
+    case = ("voxg", 2, (4, 4, 4), 128, 256, (3, 3, 3), 1, (1, 1, 1), "spconv")
+    x, w, wp, xcl, g = make_case(case, integer=True, seed=5)
+    assert g.packed_frag(False, "f16") == 1 and g.packed_frag(False, "f16", storage=torch.float32) == 0 and g.packed_frag(False, "bf16x3") == 0
+    p16 = ops.pack_weight(wp.to(DEV), g, "f16")                      # fragment-major (16-bit storage -> conv_voxg_kernel)
+    p32 = ops.pack_weight(wp.to(DEV), g, "bf16", storage=torch.float32)      # row-major (fp32 storage -> conv_igemm_kernel)
+    assert p16[0].tri_frag == 1 and p32[0].tri_frag == 0
+    ref = cl3(F.conv3d(x, w, padding=1))
+    assert torch.equal(ops.conv_fwd(xcl.to(DEV), g, p32).cpu(), ref)
+    assert torch.equal(ops.conv_fwd(xcl.to(DEV).half(), g, p16).cpu(), ref.half())
+    with pytest.raises(RuntimeError, match="ordered for another plan"):
+        ops.conv_fwd(xcl.to(DEV), g, p16)
+    with pytest.raises(RuntimeError, match="ordered for another plan"):
+        ops.conv_fwd(xcl.to(DEV).half(), g, (p32[0].half(), None))
+    # the batched packer picks the same order as the single-layer call
+    packer = ops.WeightPacker()
+    packer.add("f", wp.to(DEV), g)
+    packer.add("t", wp.to(DEV), g, transposed=True)
+    bufs = packer.run("f16", torch.device(DEV))
+    assert bufs["f"][0].tri_frag == 1 and torch.equal(bufs["f"][0], p16[0])
+    assert torch.equal(bufs["t"][0], ops.pack_weight(wp.to(DEV), g, "f16", transposed=True)[0])
