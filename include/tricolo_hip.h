@@ -257,6 +257,16 @@ int tri_bn_relu_pool3d_fwd(const void* y, const float* scale, const float* shift
 int tri_pool3d_bwd_route_rows(const void* y, const float* scale, const float* shift, const uint8_t* mask, const void* pooled,
                               const void* dpooled, int B, int D, int C, void* g, const int* out_pos, const int* out_count, int act_fmt,
                               void* stream);
+/* (round 5) the routing walk with the level's BatchNorm-backward sums folded in, as tri_pool3d_bwd_route_reduce does for the dense walk:
+ * partial [tri_pool3d_bwd_route_rows_num_blocks][2][C] feeds tri_bn_bwd_finalize; the apply pass is then tri_bn_bwd_apply (site mask) or
+ * tri_bn_bwd_apply_rows (dy = c1 * g + c2 + c3 * y on the rows of the level's own list only; dy may alias g).  C / 4 must divide 256.
+ * All 2x2x2-window kernels need fewer than 2^31 sites and a 2-byte aligned mask (TRI_ERR_ARG otherwise). */
+int tri_pool3d_bwd_route_rows_num_blocks(int B, int D, int C);
+int tri_pool3d_bwd_route_rows_reduce(const void* y, const float* scale, const float* shift, const uint8_t* mask, const void* pooled,
+                                     const void* dpooled, int B, int D, int C, void* g, const int* out_pos, const int* out_count,
+                                     float* partial, int act_fmt, void* stream);
+int tri_bn_bwd_apply_rows(const void* y, const void* g, const float* c1, const float* c2, const float* c3, void* dy, int C,
+                          const int* row_pos, const int* row_count, long max_rows, int act_fmt, void* stream);
 size_t tri_bn_bwd_rows_scratch(int C);
 int tri_bn_bwd_rows(const void* y, const void* g, int C, const int* row_pos, const int* row_count, long max_rows, const float* gamma,
                     const float* mean, const float* invstd, void* dy, float* dgamma, float* dbeta, float out_scale, void* scratch,
@@ -308,6 +318,14 @@ int tri_debug_stamp(unsigned long long* slot, void* stream);
  * active work (spconv's rulebook idea on a dense index space).  Split-K layers take the list too (slab row = list row).  scratch: tri_mask_compact_scratch(n) bytes. */
 size_t tri_mask_compact_scratch(long n);
 int tri_mask_compact(const uint8_t* mask, long n, int* row_pos, int* count, void* scratch, void* stream);
+/* (round 5) the voxel tower's five site masks and five row lists up front: tri_mask_pyramid builds the masks of levels 1-4 (2x2x2 OR-pool,
+ * what tri_bn_relu_pool3d_fwd writes as mask_out level by level - that argument may now be NULL) from the level-0 mask of [B, V, V, V]
+ * grids in one launch (V % 16 == 0; masks[l - 1] holds B * (V >> l)^3 bytes rounded up to 32, padding zeroed); tri_mask_compact_multi is
+ * tri_mask_compact of up to 8 masks in two launches (each list <= 2,097,152 sites).  Same masks, same lists, same counts. */
+int tri_mask_pyramid(const uint8_t* mask0, int B, int V, uint8_t* const* masks, void* stream);
+size_t tri_mask_compact_multi_scratch(const long* n, int nlist);
+int tri_mask_compact_multi(const uint8_t* const* masks, const long* n, int nlist, int* const* rows, int* const* counts, void* scratch,
+                           void* stream);
 int tri_nchw3_to_nhwc4(const float* x, int N, int H, int W, void* out, int act_fmt, void* stream);
 /* u8 images [N,3,H,W] -> channels-last [N,H,W,4], (u8/255 - mean[c]) / std[c] as ToTensor + Normalize of
  * general_dataset.py:87-89; mean3 / std3 are HOST pointers to three floats. */

@@ -536,7 +536,7 @@ def test_voxel_backward_row_list_forms_match_the_dense_forms(dtype):
     list) against the dense, mask-skipping passes: the routed gradient bit for bit on every active row, dy on the active rows and
     dgamma / dbeta to fp32 summation-order accuracy, rows outside the list untouched."""
     g = torch.Generator().manual_seed(41)
-    B, D, C = 3, 16, 32
+    B, D, C = 5, 16, 32
     M = B * D ** 3
     mask = (torch.rand(B, D, D, D, generator=g) < 0.15)
     mask[1, :, 8:] = False
@@ -568,6 +568,18 @@ def test_voxel_backward_row_list_forms_match_the_dense_forms(dtype):
     assert bool((dy_b.view(M, C)[~act] == 123.0).all())
     np.testing.assert_allclose(dg_b.cpu().numpy(), dg_a.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(dg_a.abs().max()))
     np.testing.assert_allclose(db_b.cpu().numpy(), db_a.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(db_a.abs().max()))
+    # (round 5) the level as SparseCNNEncoder runs it: tri_pool3d_bwd_route_rows_reduce (routing walk + BatchNorm-backward sums) ->
+    # tri_bn_bwd_finalize -> tri_bn_bwd_apply_rows (level 0: keep_inactive + own row list) or tri_bn_bwd_apply (site mask)
+    assert M > 16384 and ops._ROUTE_RED
+    for keep, rws in ((True, rows), (False, None)):
+        ref_dy, ref_dg, ref_db = ops.bn_bwd(ycl, g_dense.clone(), co, gamma, count_dev=cnt, row_mask=m8, keep_inactive=keep, out_scale=0.5)
+        dy_c, dg_c, db_c = ops.pool3d_bn_bwd(ycl, co, m8, pooled, dp, B, D, C, gamma, cnt, out_scale=0.5, keep_inactive=keep, rows=rws,
+                                             rows_out=rows_out)
+        assert float((ref_dy.view(M, C)[act].float() - dy_c.view(M, C)[act].float()).abs().max()) <= (1e-5 if dtype == torch.float32 else 2e-3) * scale
+        if not keep:
+            assert bool((dy_c.view(M, C)[~act] == 0).all())
+        np.testing.assert_allclose(dg_c.cpu().numpy(), ref_dg.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(ref_dg.abs().max()))
+        np.testing.assert_allclose(db_c.cpu().numpy(), ref_db.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(ref_db.abs().max()))
 
 
 @pytest.mark.parametrize("n,p", [(1, 1.0), (2047, 0.5), (2048, 0.0), (5 * 2048 + 3, 0.3), (1 << 20, 0.13), (1024 * 2048, 0.9), (1025 * 2048 + 17, 0.05)])
@@ -582,6 +594,39 @@ def test_mask_compact_matches_nonzero(n, p):
     ref = torch.nonzero(m).flatten().int()
     assert int(count.item()) == ref.numel()
     assert torch.equal(rows[:ref.numel()].cpu(), ref)
+
+
+@pytest.mark.parametrize("B,V,p", [(3, 16, 0.02), (2, 32, 0.13), (1, 48, 0.001), (5, 16, 0.0)])
+def test_mask_pyramid_and_multi_list_compaction(B, V, p):
+    """tri_mask_pyramid (site masks of levels 1-4 = 2x2x2 OR-pool, level by level) against max_pool3d, padding bytes zeroed, and
+    tri_mask_compact_multi (all five lists in two launches) against nonzero() - what the voxel tower builds once per forward instead of a
+    mask write in every pooling pass and two compaction launches per level."""
+    g = torch.Generator().manual_seed(B * 100 + V)
+    m = (torch.rand(B, 1, V, V, V, generator=g) < p).float()
+    if p > 0:
+        m[0, 0, V - 1, V - 1, V - 1] = 1                                  # the last site of a grid
+    n0 = B * V ** 3
+    m0 = torch.zeros((n0 + 31) // 32 * 32, dtype=torch.uint8)
+    m0[:n0] = m.reshape(-1).to(torch.uint8)
+    m0 = m0.to(DEV)
+    outs = ops.mask_pyramid(m0, B, V)
+    ref, masks, ns = m, [m0], [n0]
+    for l in range(1, 5):
+        ref = F.max_pool3d(ref, 2)
+        n = B * (V >> l) ** 3
+        got = outs[l - 1].cpu()
+        assert got.numel() == (n + 31) // 32 * 32
+        assert torch.equal(got[:n], ref.reshape(-1).to(torch.uint8)), f"level {l}"
+        assert bool((got[n:] == 0).all()), f"level {l}: padding bytes must be zero"
+        masks.append(outs[l - 1])
+        ns.append(n)
+    lists = ops.mask_compact_multi(masks, ns)
+    for l, (rows, count) in enumerate(lists):
+        refrows = torch.nonzero(masks[l][:ns[l]].cpu()).flatten().int()
+        assert int(count.item()) == refrows.numel(), f"level {l}"
+        assert torch.equal(rows[:refrows.numel()].cpu(), refrows), f"level {l}"
+        one = ops.mask_compact(masks[l], ns[l])
+        assert int(one[1].item()) == refrows.numel() and torch.equal(one[0][:refrows.numel()], rows[:refrows.numel()])
 
 
 def test_maxpool2d_and_viewmax():

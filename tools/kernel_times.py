@@ -40,6 +40,13 @@ def main():
         torch.cuda._sleep(int(80e6))
         step()
     torch.cuda.synchronize()
+    if os.environ.get("KT_TRACE") == "1":                           # the calls of the LAST step in issue order (eager, one stream)
+        per = len(proxy.records) // nrep
+        acc = 0.0
+        for name, e0, e1 in proxy.records[-per:]:
+            d = max(e0.elapsed_time(e1) - ovh, 0.0)
+            acc += d
+            print(f"{acc * 1e3:9.1f} us  {d * 1e3:7.1f}  {name}")
     agg = {}
     for name, e0, e1 in proxy.records:
         d = agg.setdefault(name, [0, 0.0])

@@ -92,6 +92,9 @@ SIGNATURES = {
     "tri_bn_relu_pool3d_fwd": (I, [P, P, P, P, I, I, I, P, P, I, P]),
     "tri_pool3d_bwd_route": (I, [P, P, P, P, P, P, I, I, I, P, I, P]),
     "tri_pool3d_bwd_route_rows": (I, [P, P, P, P, P, P, I, I, I, P, P, P, I, P]),
+    "tri_pool3d_bwd_route_rows_num_blocks": (I, [I, I, I]),
+    "tri_pool3d_bwd_route_rows_reduce": (I, [P, P, P, P, P, P, I, I, I, P, P, P, P, I, P]),
+    "tri_bn_bwd_apply_rows": (I, [P, P, P, P, P, P, I, P, P, L, I, P]),
     "tri_bn_bwd_rows_scratch": (C.c_size_t, [I]),
     "tri_bn_bwd_rows": (I, [P, P, I, P, P, L, P, P, P, P, P, P, F, P, I, P]),
     "tri_pool3d_bwd_route_reduce_num_blocks": (I, [I, I, I]),
@@ -112,6 +115,9 @@ SIGNATURES = {
     "tri_debug_stamp": (I, [P, P]),
     "tri_mask_compact_scratch": (Z, [L]),
     "tri_mask_compact": (I, [P, L, P, P, P, P]),
+    "tri_mask_pyramid": (I, [P, I, I, P, P]),
+    "tri_mask_compact_multi_scratch": (Z, [P, I]),
+    "tri_mask_compact_multi": (I, [P, P, I, P, P, P, P]),
     "tri_nchw3_to_nhwc4": (I, [P, I, I, I, P, I, P]),
     "tri_l2norm_fwd": (I, [P, I, I, F, P, P, P]),
     "tri_l2norm_bwd": (I, [P, P, P, I, I, F, P, P]),

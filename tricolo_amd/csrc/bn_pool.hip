@@ -466,41 +466,74 @@ extern "C" int tri_bn_bwd_small(const void* y, const void* g, long M, int C, con
 
 // --------------------------------------------------------------------- voxel: BN + ReLU + mask + 2^3 max-pool
 // y [B,D,D,D,C] raw conv output, mask [B,D,D,D]; pooled [B,D/2,..,C], mask_out = OR of children
+// The 2x2x2 window of pooled site `pos`: offset of its first child in the level's site order, and one bit per child (d,h,w scan order,
+// bit k = child k active) from FOUR 2-byte mask loads.  All window kernels below read the mask this way and then issue the loads of the
+// active children TOGETHER (inactive children read row 0 of the tensor - one cached line - and are discarded by a select): the first
+// version tested mask[ip] child by child, which the compiler turned into sixteen dependent memory round trips per pooled site
+// (byte, branch, row, branch, ...; ~11 us per grid-stride iteration; profiles/r5/NOTES_voxel.md).
+struct PoolWin { unsigned base, bits; };
+static __device__ __forceinline__ PoolWin pool_window(const uint8_t* __restrict__ mask, unsigned pos, unsigned D) {
+    const unsigned Do = D >> 1;
+    const unsigned ox = pos % Do; unsigned r = pos / Do;
+    const unsigned oy = r % Do; r /= Do;
+    const unsigned oz = r % Do, b = r / Do;
+    PoolWin w;
+    w.base = ((b * D + oz * 2) * D + oy * 2) * D + ox * 2;
+    const unsigned m0 = *(const unsigned short*)(mask + w.base), m1 = *(const unsigned short*)(mask + w.base + D);
+    const unsigned m2 = *(const unsigned short*)(mask + w.base + D * D), m3 = *(const unsigned short*)(mask + w.base + D * D + D);
+    w.bits = ((m0 & 0xffu) ? 1u : 0u) | ((m0 >> 8) ? 2u : 0u) | ((m1 & 0xffu) ? 4u : 0u) | ((m1 >> 8) ? 8u : 0u) |
+             ((m2 & 0xffu) ? 16u : 0u) | ((m2 >> 8) ? 32u : 0u) | ((m3 & 0xffu) ? 64u : 0u) | ((m3 >> 8) ? 128u : 0u);
+    return w;
+}
+static __device__ __forceinline__ unsigned pool_child(unsigned base, unsigned D, int k) {
+    return base + (unsigned)(k >> 2) * D * D + (unsigned)((k >> 1) & 1) * D + (unsigned)(k & 1);
+}
 template <typename T>
 __global__ void bn_relu_pool3d_fwd_kernel(const T* __restrict__ y, const float4* __restrict__ scale, const float4* __restrict__ shift,
                                           const uint8_t* __restrict__ mask, int B, int D, int C4, T* __restrict__ pooled,
                                           uint8_t* __restrict__ mask_out) {
-    const int Do = D >> 1;
-    const long total = (long)B * Do * Do * Do * C4;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int c = (int)(i % C4);
-        long pos = i / C4;
-        int ox = (int)(pos % Do); long r = pos / Do;
-        int oy = (int)(r % Do); r /= Do;
-        int oz = (int)(r % Do); int b = (int)(r / Do);
-        float4 s = scale[c], t = shift[c];
+    const unsigned Do = D >> 1, npos = (unsigned)B * Do * Do * Do, total = npos * (unsigned)C4;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const unsigned c = i % (unsigned)C4, pos = i / (unsigned)C4;
+        const PoolWin w = pool_window(mask, pos, (unsigned)D);
         float4 best = make_float4(0.f, 0.f, 0.f, 0.f);
-        int any = 0;
+        if (w.bits) {                                  // (84 % of the finest level's windows are empty: their lanes issue no row loads)
+            const float4 s = scale[c], t = shift[c];
+            float4 v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            long ip = (((long)b * D + (oz * 2 + (k >> 2))) * D + (oy * 2 + ((k >> 1) & 1))) * D + (ox * 2 + (k & 1));
-            if (mask[ip]) {
-                any = 1;
-                float4 v = Act<T>::ld4(y + (ip * C4 + c) * 4);
-                best.x = fmaxf(best.x, __fmaf_rn(v.x, s.x, t.x)); best.y = fmaxf(best.y, __fmaf_rn(v.y, s.y, t.y));
-                best.z = fmaxf(best.z, __fmaf_rn(v.z, s.z, t.z)); best.w = fmaxf(best.w, __fmaf_rn(v.w, s.w, t.w));
+            for (int k = 0; k < 8; ++k) {
+                const size_t row = (w.bits >> k) & 1u ? pool_child(w.base, (unsigned)D, k) : 0;
+                v[k] = Act<T>::ld4(y + (row * C4 + c) * 4);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const bool on = (w.bits >> k) & 1u;
+                const float zx = fmaxf(best.x, __fmaf_rn(v[k].x, s.x, t.x)), zy = fmaxf(best.y, __fmaf_rn(v[k].y, s.y, t.y));
+                const float zz = fmaxf(best.z, __fmaf_rn(v[k].z, s.z, t.z)), zw = fmaxf(best.w, __fmaf_rn(v[k].w, s.w, t.w));
+                best.x = on ? zx : best.x; best.y = on ? zy : best.y; best.z = on ? zz : best.z; best.w = on ? zw : best.w;
             }
         }
-        Act<T>::st4(pooled + i * 4, best);             // best >= 0: ReLU folded into the max with the zero init
-        if (c == 0) mask_out[pos] = (uint8_t)any;
+        Act<T>::st4(pooled + (size_t)i * 4, best);     // best >= 0: ReLU folded into the max with the zero init
+        if (c == 0 && mask_out) mask_out[pos] = (uint8_t)(w.bits != 0);
     }
     // every site's byte is written above; the padding of mask_out (to 32 bytes) is zeroed here, so callers pre-fill nothing
-    const long npos = (long)B * Do * Do * Do, pad = (npos + 31) / 32 * 32;
-    if (blockIdx.x == 0 && npos + threadIdx.x < pad) mask_out[npos + threadIdx.x] = 0;
+    const unsigned pad = (npos + 31) / 32 * 32;
+    if (mask_out && blockIdx.x == 0 && npos + threadIdx.x < pad) mask_out[npos + threadIdx.x] = 0;
+}
+// the window kernels index sites and (site, channel quad) pairs with 32-bit integers and read the mask two bytes at a time
+static bool pool_args_ok(const char* who, const uint8_t* mask, int B, int D, int C) {
+    const long sites = (long)B * D * D * D;
+    if (C % 4 || D % 2 || sites >= (1L << 31) || sites / 8 * (C / 4) >= (1L << 31) || ((uintptr_t)mask & 1)) {
+        char msg[256];
+        snprintf(msg, sizeof msg, "%s: needs C %% 4 == 0, D %% 2 == 0, fewer than 2^31 sites and (pooled site, channel quad) pairs, and a 2-byte aligned mask", who);
+        tri_set_error(msg);
+        return false;
+    }
+    return true;
 }
 extern "C" int tri_bn_relu_pool3d_fwd(const void* y, const float* scale, const float* shift, const uint8_t* mask, int B, int D, int C,
                                       void* pooled, uint8_t* mask_out, int act_fmt, void* stream) {
-    if (C % 4 || D % 2) { tri_set_error("tri_bn_relu_pool3d_fwd: C%4 or D%2"); return TRI_ERR_ARG; }
+    if (!pool_args_ok("tri_bn_relu_pool3d_fwd", mask, B, D, C)) return TRI_ERR_ARG;
     long total = (long)B * (D / 2) * (D / 2) * (D / 2) * (C / 4);
     TRI_ACT_DISPATCH(act_fmt, bn_relu_pool3d_fwd_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(
         (const T*)y, (const float4*)scale, (const float4*)shift, mask, B, D, C / 4, (T*)pooled, mask_out));
@@ -511,42 +544,52 @@ extern "C" int tri_bn_relu_pool3d_fwd(const void* y, const float* scale, const f
 // torch.max_pool3d) whose post-ReLU value equals the pooled maximum and is > 0; zero elsewhere; rows of INACTIVE sites are
 // left unwritten (tri_bn_bwd_reduce / tri_bn_bwd_apply skip them by the same mask, the latter writes their zeros).
 // (with 16-bit storage the recomputed value is rounded like the stored maximum before the comparison)
+// Routing of one pooled (site, channel quad) to its window: the rows of the active children are loaded together (see pool_window), the
+// first-maximum rule is then evaluated in registers in scan order, and only active children are stored.  Returns through sg / sgy the
+// sums of the routed gradient and of gradient * y over the window (the BatchNorm-backward sums; ignored by callers that do not need them).
+template <typename T>
+static __device__ __forceinline__ void route_window(const T* __restrict__ y, const float4& s, const float4& t, const PoolWin& w, unsigned D,
+                                                    unsigned C4, unsigned c, const float4& pm, const float4& dp, T* __restrict__ g,
+                                                    float4& sg, float4& sgy) {
+    float4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const size_t row = (w.bits >> k) & 1u ? pool_child(w.base, D, k) : 0;
+        v[k] = Act<T>::ld4(y + (row * C4 + c) * 4);
+    }
+    bool dx = false, dy = false, dz = false, dw = false;          // already routed
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const bool on = (w.bits >> k) & 1u;
+        float zx = fmaxf(__fmaf_rn(v[k].x, s.x, t.x), 0.f), zy = fmaxf(__fmaf_rn(v[k].y, s.y, t.y), 0.f);
+        float zz = fmaxf(__fmaf_rn(v[k].z, s.z, t.z), 0.f), zw = fmaxf(__fmaf_rn(v[k].w, s.w, t.w), 0.f);
+        zx = Act<T>::rnd(zx); zy = Act<T>::rnd(zy); zz = Act<T>::rnd(zz); zw = Act<T>::rnd(zw);
+        const bool hx = on && !dx && zx == pm.x && zx > 0.f, hy = on && !dy && zy == pm.y && zy > 0.f;
+        const bool hz = on && !dz && zz == pm.z && zz > 0.f, hw = on && !dw && zw == pm.w && zw > 0.f;
+        dx |= hx; dy |= hy; dz |= hz; dw |= hw;
+        const float4 o = make_float4(hx ? dp.x : 0.f, hy ? dp.y : 0.f, hz ? dp.z : 0.f, hw ? dp.w : 0.f);
+        if (on) Act<T>::st4(g + ((size_t)pool_child(w.base, D, k) * C4 + c) * 4, o);
+        sg.x += o.x; sg.y += o.y; sg.z += o.z; sg.w += o.w;
+        sgy.x += hx ? o.x * v[k].x : 0.f; sgy.y += hy ? o.y * v[k].y : 0.f; sgy.z += hz ? o.z * v[k].z : 0.f; sgy.w += hw ? o.w * v[k].w : 0.f;
+    }
+}
 template <typename T>
 __global__ void pool3d_bwd_route_kernel(const T* __restrict__ y, const float4* __restrict__ scale, const float4* __restrict__ shift,
                                         const uint8_t* __restrict__ mask, const T* __restrict__ pooled,
                                         const T* __restrict__ dpooled, int B, int D, int C4, T* __restrict__ g) {
-    const int Do = D >> 1;
-    const long total = (long)B * Do * Do * Do * C4;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int c = (int)(i % C4);
-        long pos = i / C4;
-        int ox = (int)(pos % Do); long r = pos / Do;
-        int oy = (int)(r % Do); r /= Do;
-        int oz = (int)(r % Do); int b = (int)(r / Do);
-        float4 s = scale[c], t = shift[c];
-        float4 pm = Act<T>::ld4(pooled + i * 4), dp = Act<T>::ld4(dpooled + i * 4);
-        bool dx = false, dy = false, dz = false, dw = false;      // already routed
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            long ip = (((long)b * D + (oz * 2 + (k >> 2))) * D + (oy * 2 + ((k >> 1) & 1))) * D + (ox * 2 + (k & 1));
-            if (!mask[ip]) continue;                   // rows of inactive sites are never read (bn_bwd reduce / apply skip them)
-            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-            {
-                float4 v = Act<T>::ld4(y + (ip * C4 + c) * 4);
-                float zx = fmaxf(__fmaf_rn(v.x, s.x, t.x), 0.f), zy = fmaxf(__fmaf_rn(v.y, s.y, t.y), 0.f);
-                float zz = fmaxf(__fmaf_rn(v.z, s.z, t.z), 0.f), zw = fmaxf(__fmaf_rn(v.w, s.w, t.w), 0.f);
-                zx = Act<T>::rnd(zx); zy = Act<T>::rnd(zy); zz = Act<T>::rnd(zz); zw = Act<T>::rnd(zw);
-                if (!dx && zx == pm.x && zx > 0.f) { o.x = dp.x; dx = true; }
-                if (!dy && zy == pm.y && zy > 0.f) { o.y = dp.y; dy = true; }
-                if (!dz && zz == pm.z && zz > 0.f) { o.z = dp.z; dz = true; }
-                if (!dw && zw == pm.w && zw > 0.f) { o.w = dp.w; dw = true; }
-            }
-            Act<T>::st4(g + (ip * C4 + c) * 4, o);
-        }
+    const unsigned Do = D >> 1, total = (unsigned)B * Do * Do * Do * (unsigned)C4;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const unsigned c = i % (unsigned)C4, pos = i / (unsigned)C4;
+        const PoolWin w = pool_window(mask, pos, (unsigned)D);
+        if (!w.bits) continue;                         // rows of inactive sites are never read (bn_bwd reduce / apply skip them)
+        const float4 pm = Act<T>::ld4(pooled + (size_t)i * 4), dp = Act<T>::ld4(dpooled + (size_t)i * 4);
+        float4 sg = make_float4(0.f, 0.f, 0.f, 0.f), sgy = sg;
+        route_window<T>(y, scale[c], shift[c], w, (unsigned)D, (unsigned)C4, c, pm, dp, g, sg, sgy);
     }
 }
 extern "C" int tri_pool3d_bwd_route(const void* y, const float* scale, const float* shift, const uint8_t* mask, const void* pooled,
                                     const void* dpooled, int B, int D, int C, void* g, int act_fmt, void* stream) {
+    if (!pool_args_ok("tri_pool3d_bwd_route", mask, B, D, C)) return TRI_ERR_ARG;
     long total = (long)B * (D / 2) * (D / 2) * (D / 2) * (C / 4);
     TRI_ACT_DISPATCH(act_fmt, pool3d_bwd_route_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(
         (const T*)y, (const float4*)scale, (const float4*)shift, mask, (const T*)pooled, (const T*)dpooled, B, D, C / 4, (T*)g));
@@ -556,47 +599,67 @@ extern "C" int tri_pool3d_bwd_route(const void* y, const float* scale, const flo
 // Row-list forms (round 4).  At 13-16 % occupancy the dense passes of the two finest voxel levels spend most of their threads on
 // sites whose mask byte says "skip": these walk the compact lists tri_mask_compact already produced for the conv kernels instead.
 // tri_pool3d_bwd_route_rows: the routing pass over the ACTIVE pooled sites (the next level's row list) - same values, same rows written.
-template <typename T>
-__global__ void pool3d_bwd_route_rows_kernel(const T* __restrict__ y, const float4* __restrict__ scale, const float4* __restrict__ shift,
-                                             const uint8_t* __restrict__ mask, const T* __restrict__ pooled, const T* __restrict__ dpooled,
-                                             int D, int C4, T* __restrict__ g, const int* __restrict__ out_pos, const int* __restrict__ out_count) {
-    const int Do = D >> 1;
-    const long total = (long)(*out_count) * C4;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C4);
-        const long pos = out_pos[i / C4];
-        int ox = (int)(pos % Do); long r = pos / Do;
-        int oy = (int)(r % Do); r /= Do;
-        int oz = (int)(r % Do); int b = (int)(r / Do);
-        float4 s = scale[c], t = shift[c];
-        float4 pm = Act<T>::ld4(pooled + (pos * C4 + c) * 4), dp = Act<T>::ld4(dpooled + (pos * C4 + c) * 4);
-        bool dx = false, dy = false, dz = false, dw = false;
+// RED: the BatchNorm-backward sums of the level (sum g, sum g * y over the active sites = over the windows of the active pooled sites) leave
+// as one [2][C] record per workgroup, as tri_pool3d_bwd_route_reduce does for the dense walk: no separate reduce pass over y and g.
+// Needs 256 % C4 == 0 (a thread keeps its channel quad across the grid-stride loop).
+template <typename T, bool RED>
+__global__ __launch_bounds__(256) void pool3d_bwd_route_rows_kernel(const T* __restrict__ y, const float4* __restrict__ scale,
+                                                                    const float4* __restrict__ shift, const uint8_t* __restrict__ mask,
+                                                                    const T* __restrict__ pooled, const T* __restrict__ dpooled, int D, int C4,
+                                                                    T* __restrict__ g, const int* __restrict__ out_pos,
+                                                                    const int* __restrict__ out_count, float* __restrict__ partial) {
+    __shared__ float sh[RED ? 256 : 1][8];
+    const unsigned total = (unsigned)(*out_count) * (unsigned)C4;
+    float4 sg = make_float4(0.f, 0.f, 0.f, 0.f), sgy = sg;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const unsigned c = i % (unsigned)C4, pos = (unsigned)out_pos[i / (unsigned)C4];
+        const PoolWin w = pool_window(mask, pos, (unsigned)D);
+        const float4 pm = Act<T>::ld4(pooled + ((size_t)pos * C4 + c) * 4), dp = Act<T>::ld4(dpooled + ((size_t)pos * C4 + c) * 4);
+        route_window<T>(y, scale[c], shift[c], w, (unsigned)D, (unsigned)C4, c, pm, dp, g, sg, sgy);
+    }
+    if (RED) {
+        float* p = sh[threadIdx.x];
+        p[0] = sg.x; p[1] = sg.y; p[2] = sg.z; p[3] = sg.w; p[4] = sgy.x; p[5] = sgy.y; p[6] = sgy.z; p[7] = sgy.w;
+        __syncthreads();
+        if ((int)threadIdx.x < C4) {
+            const int c = threadIdx.x;
+            float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int r = threadIdx.x; r < 256; r += C4)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            long ip = (((long)b * D + (oz * 2 + (k >> 2))) * D + (oy * 2 + ((k >> 1) & 1))) * D + (ox * 2 + (k & 1));
-            if (!mask[ip]) continue;
-            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-            float4 v = Act<T>::ld4(y + (ip * C4 + c) * 4);
-            float zx = fmaxf(__fmaf_rn(v.x, s.x, t.x), 0.f), zy = fmaxf(__fmaf_rn(v.y, s.y, t.y), 0.f);
-            float zz = fmaxf(__fmaf_rn(v.z, s.z, t.z), 0.f), zw = fmaxf(__fmaf_rn(v.w, s.w, t.w), 0.f);
-            zx = Act<T>::rnd(zx); zy = Act<T>::rnd(zy); zz = Act<T>::rnd(zz); zw = Act<T>::rnd(zw);
-            if (!dx && zx == pm.x && zx > 0.f) { o.x = dp.x; dx = true; }
-            if (!dy && zy == pm.y && zy > 0.f) { o.y = dp.y; dy = true; }
-            if (!dz && zz == pm.z && zz > 0.f) { o.z = dp.z; dz = true; }
-            if (!dw && zw == pm.w && zw > 0.f) { o.w = dp.w; dw = true; }
-            Act<T>::st4(g + (ip * C4 + c) * 4, o);
+                for (int k = 0; k < 8; ++k) a[k] += sh[r][k];
+            float* o = partial + (size_t)blockIdx.x * 2 * C4 * 4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { o[c * 4 + k] = a[k]; o[C4 * 4 + c * 4 + k] = a[4 + k]; }
         }
     }
+}
+static int route_rows_grid(int B, int D, int C) {
+    long worst = (long)B * (D / 2) * (D / 2) * (D / 2) * (C / 4);
+    return ew_grid(worst / 4 + 1);                                  // (sized for a quarter-full list; the loop is grid-strided)
 }
 extern "C" int tri_pool3d_bwd_route_rows(const void* y, const float* scale, const float* shift, const uint8_t* mask, const void* pooled,
                                          const void* dpooled, int B, int D, int C, void* g, const int* out_pos, const int* out_count,
                                          int act_fmt, void* stream) {
-    if (C % 4 || D % 2 || !out_pos || !out_count) { tri_set_error("tri_pool3d_bwd_route_rows: C%4, D%2, row list required"); return TRI_ERR_ARG; }
-    long worst = (long)B * (D / 2) * (D / 2) * (D / 2) * (C / 4);
-    int grid = ew_grid(worst / 4 + 1);                              // (sized for a quarter-full list; the loop is grid-strided)
-    TRI_ACT_DISPATCH(act_fmt, pool3d_bwd_route_rows_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>(
-        (const T*)y, (const float4*)scale, (const float4*)shift, mask, (const T*)pooled, (const T*)dpooled, D, C / 4, (T*)g, out_pos, out_count));
+    if (!out_pos || !out_count) { tri_set_error("tri_pool3d_bwd_route_rows: row list required"); return TRI_ERR_ARG; }
+    if (!pool_args_ok("tri_pool3d_bwd_route_rows", mask, B, D, C)) return TRI_ERR_ARG;
+    TRI_ACT_DISPATCH(act_fmt, (pool3d_bwd_route_rows_kernel<T, false><<<route_rows_grid(B, D, C), 256, 0, (hipStream_t)stream>>>(
+        (const T*)y, (const float4*)scale, (const float4*)shift, mask, (const T*)pooled, (const T*)dpooled, D, C / 4, (T*)g, out_pos, out_count,
+        nullptr)));
     return tri_check_launch("tri_pool3d_bwd_route_rows");
+}
+// The same walk with the BatchNorm-backward sums folded in: partial [tri_pool3d_bwd_route_rows_num_blocks][2][C] is the input of
+// tri_bn_bwd_finalize (then tri_bn_bwd_apply with the site mask, or tri_bn_bwd_apply_rows with this level's own list).  C / 4 must divide 256.
+extern "C" int tri_pool3d_bwd_route_rows_num_blocks(int B, int D, int C) { return route_rows_grid(B, D, C); }
+extern "C" int tri_pool3d_bwd_route_rows_reduce(const void* y, const float* scale, const float* shift, const uint8_t* mask, const void* pooled,
+                                                const void* dpooled, int B, int D, int C, void* g, const int* out_pos, const int* out_count,
+                                                float* partial, int act_fmt, void* stream) {
+    if (!out_pos || !out_count || !partial) { tri_set_error("tri_pool3d_bwd_route_rows_reduce: row list and partial required"); return TRI_ERR_ARG; }
+    if (C % 4 || C / 4 > 256 || 256 % (C / 4)) { tri_set_error("tri_pool3d_bwd_route_rows_reduce: C / 4 must divide 256"); return TRI_ERR_ARG; }
+    if (!pool_args_ok("tri_pool3d_bwd_route_rows_reduce", mask, B, D, C)) return TRI_ERR_ARG;
+    TRI_ACT_DISPATCH(act_fmt, (pool3d_bwd_route_rows_kernel<T, true><<<route_rows_grid(B, D, C), 256, 0, (hipStream_t)stream>>>(
+        (const T*)y, (const float4*)scale, (const float4*)shift, mask, (const T*)pooled, (const T*)dpooled, D, C / 4, (T*)g, out_pos, out_count,
+        partial)));
+    return tri_check_launch("tri_pool3d_bwd_route_rows_reduce");
 }
 // BatchNorm backward over a compact row list (g is final: no ReLU mask; rows outside the list are neither read nor written - the
 // keep_inactive contract of tri_bn_bwd_apply).  partial: [BNR_BLOCKS][2][C] scratch.
@@ -671,6 +734,17 @@ extern "C" int tri_bn_bwd_rows(const void* y, const void* g, int C, const int* r
     return tri_check_launch("tri_bn_bwd_rows");
 }
 
+// dy = c1 * g + c2 + c3 * y on the rows of the list only (the third pass of tri_bn_bwd_rows on its own, for callers whose sums came
+// from tri_pool3d_bwd_route_rows_reduce); dy may alias g.
+extern "C" int tri_bn_bwd_apply_rows(const void* y, const void* g, const float* c1, const float* c2, const float* c3, void* dy, int C,
+                                     const int* row_pos, const int* row_count, long max_rows, int act_fmt, void* stream) {
+    if (C % 4 || !row_pos || !row_count) { tri_set_error("tri_bn_bwd_apply_rows: C % 4 and a row list required"); return TRI_ERR_ARG; }
+    const int C4 = C / 4, grid = ew_grid(max_rows * C4 / 4 + 1);
+    TRI_ACT_DISPATCH(act_fmt, bn_bwd_apply_rows_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)y, (const T*)g, (const float4*)c1,
+        (const float4*)c2, (const float4*)c3, (T*)dy, C4, row_pos, row_count));
+    return tri_check_launch("tri_bn_bwd_apply_rows");
+}
+
 // The same routing with the BatchNorm-backward sums of the level folded in: every routed value and the y it belongs to are in
 // registers here, so the per-channel sums of g and g * y over the active sites (what tri_bn_bwd_reduce would re-read both tensors
 // for) leave as one [2][C] record per workgroup for tri_bn_bwd_finalize - one launch less per level on the voxel tower's backward.
@@ -683,33 +757,14 @@ __global__ __launch_bounds__(256) void pool3d_bwd_route_reduce_kernel(const T* _
     __shared__ float sh[256][8];
     const int Do = D >> 1;
     const long total = (long)B * Do * Do * Do * C4;
-    const int c = threadIdx.x % C4;
+    const int c = threadIdx.x % C4;                                  // (256 % C4 == 0: the quad is the same on every grid-stride pass)
     const float4 s = scale[c], t = shift[c];
     float4 sg = make_float4(0.f, 0.f, 0.f, 0.f), sgy = sg;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        long pos = i / C4;
-        int ox = (int)(pos % Do); long r = pos / Do;
-        int oy = (int)(r % Do); r /= Do;
-        int oz = (int)(r % Do); int b = (int)(r / Do);
-        float4 pm = Act<T>::ld4(pooled + i * 4), dp = Act<T>::ld4(dpooled + i * 4);
-        bool dx = false, dy = false, dz = false, dw = false;      // already routed
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            long ip = (((long)b * D + (oz * 2 + (k >> 2))) * D + (oy * 2 + ((k >> 1) & 1))) * D + (ox * 2 + (k & 1));
-            if (!mask[ip]) continue;
-            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 v = Act<T>::ld4(y + (ip * C4 + c) * 4);
-            float zx = fmaxf(__fmaf_rn(v.x, s.x, t.x), 0.f), zy = fmaxf(__fmaf_rn(v.y, s.y, t.y), 0.f);
-            float zz = fmaxf(__fmaf_rn(v.z, s.z, t.z), 0.f), zw = fmaxf(__fmaf_rn(v.w, s.w, t.w), 0.f);
-            zx = Act<T>::rnd(zx); zy = Act<T>::rnd(zy); zz = Act<T>::rnd(zz); zw = Act<T>::rnd(zw);
-            if (!dx && zx == pm.x && zx > 0.f) { o.x = dp.x; dx = true; }
-            if (!dy && zy == pm.y && zy > 0.f) { o.y = dp.y; dy = true; }
-            if (!dz && zz == pm.z && zz > 0.f) { o.z = dp.z; dz = true; }
-            if (!dw && zw == pm.w && zw > 0.f) { o.w = dp.w; dw = true; }
-            Act<T>::st4(g + (ip * C4 + c) * 4, o);
-            sg.x += o.x; sg.y += o.y; sg.z += o.z; sg.w += o.w;
-            sgy.x += o.x * v.x; sgy.y += o.y * v.y; sgy.z += o.z * v.z; sgy.w += o.w * v.w;
-        }
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total; i += gridDim.x * blockDim.x) {
+        const PoolWin w = pool_window(mask, i / (unsigned)C4, (unsigned)D);
+        if (!w.bits) continue;
+        const float4 pm = Act<T>::ld4(pooled + (size_t)i * 4), dp = Act<T>::ld4(dpooled + (size_t)i * 4);
+        route_window<T>(y, s, t, w, (unsigned)D, (unsigned)C4, (unsigned)c, pm, dp, g, sg, sgy);
     }
     float* p = sh[threadIdx.x];
     p[0] = sg.x; p[1] = sg.y; p[2] = sg.z; p[3] = sg.w; p[4] = sgy.x; p[5] = sgy.y; p[6] = sgy.z; p[7] = sgy.w;
@@ -732,6 +787,7 @@ extern "C" int tri_pool3d_bwd_route_reduce_num_blocks(int B, int D, int C) {
 extern "C" int tri_pool3d_bwd_route_reduce(const void* y, const float* scale, const float* shift, const uint8_t* mask, const void* pooled,
                                            const void* dpooled, int B, int D, int C, void* g, float* partial, int act_fmt, void* stream) {
     if (C % 4 || C / 4 > 256 || 256 % (C / 4)) { tri_set_error("tri_pool3d_bwd_route_reduce: C / 4 must divide 256"); return TRI_ERR_ARG; }
+    if (!pool_args_ok("tri_pool3d_bwd_route_reduce", mask, B, D, C)) return TRI_ERR_ARG;
     const int nblk = tri_pool3d_bwd_route_reduce_num_blocks(B, D, C);
     TRI_ACT_DISPATCH(act_fmt, pool3d_bwd_route_reduce_kernel<T><<<nblk, 256, 0, (hipStream_t)stream>>>(
         (const T*)y, (const float4*)scale, (const float4*)shift, mask, (const T*)pooled, (const T*)dpooled, B, D, C / 4, (T*)g, partial));

@@ -211,6 +211,153 @@ extern "C" int tri_mask_compact(const uint8_t* mask, long n, int* row_pos, int* 
     return tri_check_launch("tri_mask_compact");
 }
 
+// (round 5) All site masks of the voxel tower and all their row lists up front.  The occupancy of level l + 1 is the 2x2x2 OR-pool of level l
+// and depends on nothing but the input grid, so the five masks and the five compact lists need not be produced level by level between the
+// convolutions (10 short launches on the tower's forward chain, ~3 us each as nodes of the replayed graph): one launch builds the masks of
+// levels 1-4 from level 0 (one workgroup per level-4 site = 16^3 level-0 sites), two launches compact all levels together.
+__global__ __launch_bounds__(512) void mask_pyramid_kernel(const uint8_t* __restrict__ m0, int B, int V, uint8_t* __restrict__ m1,
+                                                           uint8_t* __restrict__ m2, uint8_t* __restrict__ m3, uint8_t* __restrict__ m4) {
+    __shared__ uint8_t s1[512], s2[64], s3[8];
+    const int t = threadIdx.x, V1 = V >> 1, V2 = V >> 2, V3 = V >> 3, V4 = V >> 4;
+    int r = blockIdx.x;
+    const int cx = r % V4; r /= V4;
+    const int cy = r % V4; r /= V4;
+    const int cz = r % V4, b = r / V4;
+    {
+        const int z = cz * 8 + (t >> 6), y = cy * 8 + ((t >> 3) & 7), x = cx * 8 + (t & 7);
+        const size_t base = (((size_t)b * V + z * 2) * V + y * 2) * V + x * 2;
+        const unsigned any = *(const unsigned short*)(m0 + base) | *(const unsigned short*)(m0 + base + V) |
+                             *(const unsigned short*)(m0 + base + (size_t)V * V) | *(const unsigned short*)(m0 + base + (size_t)V * V + V);
+        const uint8_t v = any ? 1 : 0;
+        s1[t] = v;
+        m1[(((size_t)b * V1 + z) * V1 + y) * V1 + x] = v;
+    }
+    __syncthreads();
+    if (t < 64) {
+        const int lz = t >> 4, ly = (t >> 2) & 3, lx = t & 3;
+        unsigned any = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) any |= s1[((lz * 2 + (k >> 2)) * 8 + ly * 2 + ((k >> 1) & 1)) * 8 + lx * 2 + (k & 1)];
+        s2[t] = (uint8_t)any;
+        m2[(((size_t)b * V2 + cz * 4 + lz) * V2 + cy * 4 + ly) * V2 + cx * 4 + lx] = (uint8_t)any;
+    }
+    __syncthreads();
+    if (t < 8) {
+        const int lz = t >> 2, ly = (t >> 1) & 1, lx = t & 1;
+        unsigned any = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) any |= s2[((lz * 2 + (k >> 2)) * 4 + ly * 2 + ((k >> 1) & 1)) * 4 + lx * 2 + (k & 1)];
+        s3[t] = (uint8_t)any;
+        m3[(((size_t)b * V3 + cz * 2 + lz) * V3 + cy * 2 + ly) * V3 + cx * 2 + lx] = (uint8_t)any;
+    }
+    __syncthreads();
+    if (t == 0) {
+        unsigned any = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) any |= s3[k];
+        m4[(((size_t)b * V4 + cz) * V4 + cy) * V4 + cx] = (uint8_t)any;
+    }
+    if (blockIdx.x == 0 && t < 32) {                                // padding of every mask to 32 bytes (the brick kernels read whole dwords)
+        const size_t n[4] = {(size_t)B * V1 * V1 * V1, (size_t)B * V2 * V2 * V2, (size_t)B * V3 * V3 * V3, (size_t)B * V4 * V4 * V4};
+        uint8_t* m[4] = {m1, m2, m3, m4};
+#pragma unroll
+        for (int l = 0; l < 4; ++l)
+            if (n[l] + t < (n[l] + 31) / 32 * 32) m[l][n[l] + t] = 0;
+    }
+}
+// masks[0 .. 3] <- levels 1-4 of the level-0 mask of [B, V, V, V] grids; V % 16 == 0; every output holds its site count rounded up to 32 bytes
+extern "C" int tri_mask_pyramid(const uint8_t* mask0, int B, int V, uint8_t* const* masks, void* stream) {
+    if (B < 1 || V < 16 || V % 16 || ((uintptr_t)mask0 & 1)) { tri_set_error("tri_mask_pyramid: V must be a multiple of 16, mask 2-byte aligned"); return TRI_ERR_ARG; }
+    const long blocks = (long)B * (V / 16) * (V / 16) * (V / 16);
+    if (blocks >= (1L << 31)) { tri_set_error("tri_mask_pyramid: too many level-4 sites"); return TRI_ERR_ARG; }
+    mask_pyramid_kernel<<<(int)blocks, 512, 0, (hipStream_t)stream>>>(mask0, B, V, masks[0], masks[1], masks[2], masks[3]);
+    return tri_check_launch("tri_mask_pyramid");
+}
+#define CMP_MAX_LISTS 8
+struct CompactJobs {
+    const uint8_t* mask[CMP_MAX_LISTS];
+    long n[CMP_MAX_LISTS];
+    int* rows[CMP_MAX_LISTS];
+    int* count[CMP_MAX_LISTS];
+    int blk0[CMP_MAX_LISTS + 1];                                     // first block of every list in the launch
+    int nlist;
+};
+template <typename T, int N>
+static __device__ __forceinline__ T cmp_pick(const T (&a)[N], int l) {      // a[l] without a run-time index into the kernel-argument struct
+    T v = a[0];
+#pragma unroll
+    for (int i = 1; i < N; ++i) if (l == i) v = a[i];
+    return v;
+}
+static __device__ __forceinline__ int compact_list_of(const CompactJobs& j, int blk) {
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < CMP_MAX_LISTS; ++i) if (i < j.nlist && blk >= j.blk0[i]) l = i;
+    return l;
+}
+__global__ __launch_bounds__(256) void mask_multi_count_kernel(CompactJobs j, int* __restrict__ block_count) {
+    __shared__ int ws[4];
+    const int l = compact_list_of(j, blockIdx.x);
+    unsigned long long bits;
+    int c = (int)cmp_load8(cmp_pick(j.mask, l), (long)(blockIdx.x - cmp_pick(j.blk0, l)) * CMP_SITES + threadIdx.x * 8, cmp_pick(j.n, l), &bits);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_count[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+__global__ __launch_bounds__(256) void mask_multi_write_scan_kernel(CompactJobs j, const int* __restrict__ block_count) {
+    __shared__ int ws[4], bs[4];
+    const int l = compact_list_of(j, blockIdx.x), first = cmp_pick(j.blk0, l), lb = blockIdx.x - first;
+    unsigned long long bits;
+    const long base = (long)lb * CMP_SITES + threadIdx.x * 8;
+    const int c = (int)cmp_load8(cmp_pick(j.mask, l), base, cmp_pick(j.n, l), &bits);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int pre = 0;                                                     // counts of the list's blocks before this one (as mask_block_write_scan_kernel)
+    for (int b = threadIdx.x; b < lb; b += 256) pre += block_count[first + b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) pre += __shfl_xor(pre, o);
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+    if (lane == 63) ws[wave] = incl;
+    if (lane == 0) bs[wave] = pre;
+    __syncthreads();
+    const int block_base = bs[0] + bs[1] + bs[2] + bs[3];
+    int off = block_base + incl - c;
+    for (int w = 0; w < wave; ++w) off += ws[w];
+    int* __restrict__ row_pos = cmp_pick(j.rows, l);
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if ((bits >> k) & 1ull) row_pos[off++] = (int)(base + k);
+    if ((int)blockIdx.x == cmp_pick(j.blk0, l + 1) - 1 && threadIdx.x == 0) *cmp_pick(j.count, l) = block_base + ws[0] + ws[1] + ws[2] + ws[3];
+}
+// tri_mask_compact of up to 8 masks in two launches (every list at most 1,024 blocks = 2 M sites; larger ones go through tri_mask_compact).
+// scratch: tri_mask_compact_multi_scratch(n, nlist) bytes.  Same lists, same counts.
+extern "C" size_t tri_mask_compact_multi_scratch(const long* n, int nlist) {
+    size_t nb = 0;
+    for (int l = 0; l < nlist; ++l) nb += (size_t)((n[l] + CMP_SITES - 1) / CMP_SITES);
+    return (nb + 1) * sizeof(int);
+}
+extern "C" int tri_mask_compact_multi(const uint8_t* const* masks, const long* n, int nlist, int* const* rows, int* const* counts, void* scratch,
+                                      void* stream) {
+    if (nlist < 1 || nlist > CMP_MAX_LISTS) { tri_set_error("tri_mask_compact_multi: 1..8 lists"); return TRI_ERR_ARG; }
+    CompactJobs j;
+    int nb = 0;
+    for (int l = 0; l < nlist; ++l) {
+        const long b = (n[l] + CMP_SITES - 1) / CMP_SITES;
+        if (n[l] < 1 || b > 1024) { tri_set_error("tri_mask_compact_multi: every list needs 1 <= n <= 2,097,152 sites"); return TRI_ERR_ARG; }
+        j.mask[l] = masks[l]; j.n[l] = n[l]; j.rows[l] = rows[l]; j.count[l] = counts[l]; j.blk0[l] = nb;
+        nb += (int)b;
+    }
+    for (int l = nlist; l <= CMP_MAX_LISTS; ++l) j.blk0[l] = nb;
+    j.nlist = nlist;
+    hipStream_t s = (hipStream_t)stream;
+    mask_multi_count_kernel<<<nb, 256, 0, s>>>(j, (int*)scratch);
+    mask_multi_write_scan_kernel<<<nb, 256, 0, s>>>(j, (const int*)scratch);
+    return tri_check_launch("tri_mask_compact_multi");
+}
+
 // ------------------------------------------------------------------------------------------------ token embedding
 // emb[l][b][:] = W[tok[b][l]][:]   (bigru.py:15: embedding_layer(x).transpose(0, 1); padding row 0 of W is zero by init)
 __global__ void embedding_fwd_kernel(const int* __restrict__ tok, const float4* __restrict__ w, int B, int L, int D4,

@@ -18,7 +18,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .... import ops
-from ....layers import L2NormFn, LinearFn, TriModule, linear_bwd, linear_fwd, linear_geom, require_gpu
+from ....layers import L2NormFn, LinearFn, TriModule, linear_fwd, linear_geom, require_gpu
 
 
 class _BiGRUFn(torch.autograd.Function):
@@ -36,8 +36,13 @@ class _BiGRUFn(torch.autograd.Function):
         b_hh = buf[768 * I + 768 + 768 * 128:].view(2, 384)
         ops.copy_segments([(w_ih_f.contiguous(), w_ih[:384]), (w_ih_r.contiguous(), w_ih[384:]), (b_ih_f, b_ih[:384]), (b_ih_r, b_ih[384:]),
                            (w_hh_f.contiguous(), w_hh[0]), (w_hh_r.contiguous(), w_hh[1]), (b_hh_f, b_hh[0]), (b_hh_r, b_hh[1])])
+        fine = ops.TIMELINE is not None and ops.TIMELINE.get("fine")
         xproj = linear_fwd(x2d, w_ih, b_ih, 0, precision)               # [L*B, 768]
+        if fine:
+            ops.stamp("text.fwd.xproj.end")
         hfinal, hs, gates = ops.gru_fwd(xproj, w_hh, b_hh, B, L, precision)
+        if fine:
+            ops.stamp("text.fwd.gru.end")
         ctx.save_for_backward(x2d, w_ih, w_hh, hs, gates)
         ctx.dims, ctx.precision = (L, B, I), precision
         return hfinal
@@ -49,9 +54,22 @@ class _BiGRUFn(torch.autograd.Function):
         ops.stamp("text.bwd.gru.start")
         dgi, dgh, hprev, dbias = ops.gru_bwd(dhfinal, w_hh, hs, gates, B, L, prec)
         ops.stamp("text.bwd.gru.end")
-        dx, dw_ih, _ = linear_bwd(x2d, w_ih, None, dgi, 0, prec, need_dx=ctx.needs_input_grad[0], need_db=False)
-        g_hh = linear_geom(L * B, 128, 384)
-        dw_hh = [ops.conv_wgrad(hprev[d], dgh[d], g_hh, w_hh[d], prec) for d in range(2)]
+        # dx first (the embedding gradient waits for it), then the three weight gradients with ONE grouped reduce behind them (round 5:
+        # this tail ends the Bi(V) step's backward; a side stream for the weight gradients would have to be joined back into this
+        # tower's own side stream, and a join into a stream that is itself a forked branch crashes hipStreamEndCapture on this ROCm -
+        # tools/probes/graph_nested_fork.py)
+        hp = ops.head_precision(prec)
+        g_ih, g_hh = linear_geom(L * B, I, 768), linear_geom(L * B, 128, 384)
+        dgi = dgi.contiguous()
+        assert L * B > 64                                      # (the one-launch small-linear path is for the <= 64-row heads, never the projection)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv_dgrad(dgi, g_ih, ops.pack_weight(w_ih, g_ih, hp, transposed=True)).view(x2d.shape)
+        batch = ops.wgrad_batch(dgi.device)
+        dw_ih = ops.conv_wgrad(x2d, dgi, g_ih, w_ih, hp, batch=batch)
+        dw_hh = [ops.conv_wgrad(hprev[d], dgh[d], g_hh, w_hh[d], prec, batch=batch) for d in range(2)]
+        if batch is not None:
+            batch.flush()
         db_ih_f, db_hh_f, db_ih_r, db_hh_r = ops.gru_bias_grads(dbias)     # per-chunk (dr, dz, dn_input, dn_hidden) sums -> nn.GRU biases
         demb = dx.view(L, B, I) if dx is not None else None
         return (demb, dw_ih[:384], dw_hh[0], db_ih_f, db_hh_f, dw_ih[384:], dw_hh[1], db_ih_r, db_hh_r, None)
@@ -70,7 +88,10 @@ class _EmbeddingFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         (tok,) = ctx.saved_tensors
-        return None, ops.embedding_bwd(tok, dout, ctx.vocab, padding_idx=0)
+        dw = ops.embedding_bwd(tok, dout, ctx.vocab, padding_idx=0)
+        if ops.TIMELINE is not None and ops.TIMELINE.get("fine"):
+            ops.stamp("text.bwd.end")
+        return None, dw
 
 
 class BiGRUEncoder(TriModule):
@@ -84,6 +105,8 @@ class BiGRUEncoder(TriModule):
     def forward(self, x, data_dict=None):
         require_gpu(x, "BiGRUEncoder")
         prec = self.precision or ops.default_precision()
+        if ops.TIMELINE is not None and ops.TIMELINE.get("fine"):
+            ops.stamp("text.fwd.start")
         emb = _EmbeddingFn.apply(x, self.embedding_layer.weight)                                        # [L,B,256], bigru.py:15
         g = self.gru
         feat = _BiGRUFn.apply(emb, g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0, g.weight_ih_l0_reverse,

@@ -97,13 +97,28 @@ class SparseCNNEncoder(TriModule):
     # ------------------------------------------------------------------ forward / backward implementations
     def _forward_impl(self, locs, feats, B, save: bool):
         prec, V, train = self._prec(), self.voxel_size, self.training
+        if ops.TIMELINE is not None and ops.TIMELINE.get("fine"):
+            ops.stamp("voxel.fwd.start")
         self._packed = self._pack_all(B, prec, train and save, feats.device)
+        if ops.TIMELINE is not None and ops.TIMELINE.get("fine"):
+            ops.stamp("voxel.fwd.packed")
         if locs is None:                                        # feats = dense RGBA u8 grids [B,4,V,V,V] (SURVEY 8f-2 input)
             x, mask = ops.voxel_from_rgba(feats, dtype=ops.act_dtype(prec))
         else:
             x, mask = ops.voxel_scatter(locs, feats, B, V, dtype=ops.act_dtype(prec))
         compact = os.environ.get("TRICOLO_VOXEL_COMPACT", "1") != "0"        # A/B switch: mask-only (tile skipping) path
-        rows = ops.mask_compact(mask, B * V ** 3)                             # (active positions ascending, device count)
+        fine = ops.TIMELINE is not None and ops.TIMELINE.get("fine")         # tools/step_timeline.py with TRICOLO_FINE_STAMPS=1
+        if fine:
+            ops.stamp("voxel.fwd.scattered")
+        # (round 5) every level's site mask and row list up front, three launches (ops.mask_pyramid / mask_compact_multi) instead of two per
+        # level between the convolutions; TRICOLO_NO_MASK_PYRAMID=1 or V % 16 != 0: level by level as before
+        pyramid = V % 16 == 0 and os.environ.get("TRICOLO_NO_MASK_PYRAMID") != "1"
+        if pyramid:
+            masks = [mask] + ops.mask_pyramid(mask, B, V)
+            lists = ops.mask_compact_multi(masks, [B * (V >> l) ** 3 for l in range(5)])
+            rows = lists[0]
+        else:
+            rows = ops.mask_compact(mask, B * V ** 3)                         # (active positions ascending, device count)
         count = rows[1]
         saved = {"levels": [], "B": B}
         for l in range(5):
@@ -121,8 +136,16 @@ class SparseCNNEncoder(TriModule):
             else:
                 y = ops.conv_fwd(x, g, packed, **sel)
                 co = ops.bn_eval_coeffs(C, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
-            pooled, mask_out = ops.bn_relu_pool3d_fwd(y, co, mask, B, D, C)
-            rows_out = ops.mask_compact(mask_out, B * (D // 2) ** 3) if l < 4 else (None, None)
+            if fine:
+                ops.stamp(f"voxel.fwd.l{l}.conv+stats")
+            if pyramid:
+                pooled, _ = ops.bn_relu_pool3d_fwd(y, co, mask, B, D, C, want_mask=False)
+                mask_out, rows_out = (masks[l + 1], lists[l + 1]) if l < 4 else (None, (None, None))
+            else:
+                pooled, mask_out = ops.bn_relu_pool3d_fwd(y, co, mask, B, D, C)
+                rows_out = ops.mask_compact(mask_out, B * (D // 2) ** 3) if l < 4 else (None, None)
+            if fine:
+                ops.stamp(f"voxel.fwd.l{l}.pooled")
             if save:
                 saved["levels"].append((x, y, mask, count, co, pooled, rows, use_rows))
             x, mask, rows, count = pooled, mask_out, rows_out, rows_out[1]
@@ -172,6 +195,8 @@ class SparseCNNEncoder(TriModule):
             else:
                 grads[3 * l] = ops.conv_wgrad(x, dy, g, conv.weight, prec, row_mask=mask, out_scale=ugs, batch=batch)
             grads[3 * l + 1], grads[3 * l + 2] = dgamma, dbeta
+            if ops.TIMELINE is not None and ops.TIMELINE.get("fine"):
+                ops.stamp(f"voxel.bwd.l{l}.bn+wgrad_issue")
             if l > 0:
                 pt = self._packed[(l, True)]
                 if compact and not g.brick(True, ops._conv_mode(dy, pt[1])):

@@ -135,7 +135,9 @@ class TriCoLoNet(TriModule):
         # itv 3.33-3.35 / vti 3.33-3.35 ms (config 5: 24.21 / 24.20); without a voxel tower (config 3) itv 4.67 / tvi 4.73.
         # Round 4 (krow weight gradients, shorter side towers; three alternating runs each): itv 2.756 / tvi 2.768 ms, with the fused
         # voxel pool routing 2.740 / 2.757 - the image tower is issued first in every configuration now.
-        capt_order = "itv"
+        # Round 5, Bi(V) (no image tower, voxel tower on the caller's stream): the voxel forward is the critical chain there and, issued
+        # after the text tower, its first kernel queued 34 us behind the text tower's first four - "vt" 0.881 / 0.890 ms against 0.895 / 0.903.
+        capt_order = "itv" if self.image_encoder is not None else "vt"
         order = os.environ.get("TRICOLO_TOWER_ORDER") or (capt_order if torch.cuda.is_current_stream_capturing() else "tvi")
         s_text.wait_stream(main)
         vox = img = text = None

@@ -759,10 +759,11 @@ def bn_bwd(y, g, co: BNCoeffs, gamma, count_dev=None, count_host=0, row_mask=Non
 
 
 # ------------------------------------------------------------------------------------------------ pooling
-def bn_relu_pool3d_fwd(y, co: BNCoeffs, mask, B, D, C):
+def bn_relu_pool3d_fwd(y, co: BNCoeffs, mask, B, D, C, want_mask: bool = True):
+    """want_mask=False: the pooled level's site mask is not written (the caller has it from mask_pyramid); returns (pooled, None)."""
     Do = D // 2
     pooled = torch.empty((B, Do, Do, Do, C), dtype=y.dtype, device=y.device)
-    mask_out = torch.empty(((B * Do ** 3 + 31) // 32 * 32,), dtype=torch.uint8, device=y.device)     # every byte written by the kernel
+    mask_out = torch.empty(((B * Do ** 3 + 31) // 32 * 32,), dtype=torch.uint8, device=y.device) if want_mask else None   # every byte written by the kernel
     check(lib().tri_bn_relu_pool3d_fwd(ptr(_act(y)), ptr(co.scale), ptr(co.shift), ptr(mask), B, D, C, ptr(pooled), ptr(mask_out),
                                        _abf(y), stream()), "tri_bn_relu_pool3d_fwd")
     return pooled, mask_out
@@ -777,6 +778,7 @@ def pool3d_bwd_route(y, co: BNCoeffs, mask, pooled, dpooled, B, D, C):
 
 
 _VOX_ROWS = os.environ.get("TRICOLO_VOX_BWD_ROWS", "1") != "0"      # A/B switch: 0 = the dense (mask-skipping) passes everywhere
+_ROUTE_RED = os.environ.get("TRICOLO_NO_ROUTE_ROWS_REDUCE") != "1"    # A/B switch: 1 = separate reduce pass after the row-list routing walk (round 4)
 
 
 def pool3d_bwd_route_rows(y, co: BNCoeffs, mask, pooled, dpooled, B, D, C, rows_out):
@@ -809,6 +811,22 @@ def pool3d_bn_bwd(y, co: BNCoeffs, mask, pooled, dpooled, B, D, C, gamma, count_
     # routing pass then walks the active pooled sites, and - where dy may stay unwritten at inactive sites (keep_inactive) - the whole
     # BatchNorm backward walks this level's list
     big = y.numel() // C > 16384
+    if _VOX_ROWS and _ROUTE_RED and big and C % 4 == 0 and 256 % (C // 4) == 0 and rows_out is not None:
+        # (round 5) the routing walk over the active pooled sites also leaves the BatchNorm-backward sums: route + finalize + apply
+        g = torch.empty_like(y)
+        nblk = lib().tri_pool3d_bwd_route_rows_num_blocks(B, D, C)
+        partial = torch.empty((nblk, 2, C), dtype=torch.float32, device=y.device)
+        check(lib().tri_pool3d_bwd_route_rows_reduce(ptr(_act(y)), ptr(co.scale), ptr(co.shift), ptr(mask), ptr(pooled), ptr(_act(dpooled)),
+                                                     B, D, C, ptr(g), ptr(rows_out[0]), ptr(rows_out[1]), ptr(partial), _abf(y), stream()),
+              "tri_pool3d_bwd_route_rows_reduce")
+        buf = _bn_bwd_finalize(partial, nblk, C, count_dev, 0, gamma, co, out_scale)
+        if rows is not None and keep_inactive:
+            check(lib().tri_bn_bwd_apply_rows(ptr(y), ptr(g), ptr(buf[2]), ptr(buf[3]), ptr(buf[4]), ptr(g), C, ptr(rows[0]), ptr(rows[1]),
+                                              rows[0].numel(), _abf(y), stream()), "tri_bn_bwd_apply_rows")
+        else:
+            check(lib().tri_bn_bwd_apply(ptr(y), ptr(g), ptr(buf[2]), ptr(buf[3]), ptr(buf[4]), ptr(mask), ptr(g), y.numel() // C, C,
+                                         None, None, None, None, 1 if keep_inactive else 0, _abf(y), stream()), "tri_bn_bwd_apply")
+        return g, buf[0], buf[1]
     if _VOX_ROWS and big and _sync_world() == 1 and C % 4 == 0 and (rows_out is not None or (rows is not None and keep_inactive)):
         gz = (pool3d_bwd_route_rows(y, co, mask, pooled, dpooled, B, D, C, rows_out) if rows_out is not None
               else pool3d_bwd_route(y, co, mask, pooled, dpooled, B, D, C))
@@ -986,6 +1004,42 @@ def mask_compact(mask, n):
     scratch = torch.empty((lib().tri_mask_compact_scratch(n),), dtype=torch.uint8, device=mask.device)
     check(lib().tri_mask_compact(ptr(mask), n, ptr(row_pos), ptr(count), ptr(scratch), stream()), "tri_mask_compact")
     return row_pos, count
+
+
+def mask_pyramid(mask0, B, V):
+    """Site masks of voxel levels 1-4 (2x2x2 OR-pool of the level below) from the level-0 mask, one launch; V % 16 == 0."""
+    import ctypes
+    outs = [torch.empty(((B * (V >> l) ** 3 + 31) // 32 * 32,), dtype=torch.uint8, device=mask0.device) for l in range(1, 5)]
+    arr = (ctypes.c_void_p * 4)(*[o.data_ptr() for o in outs])
+    check(lib().tri_mask_pyramid(ptr(mask0), B, V, arr, stream()), "tri_mask_pyramid")
+    return outs
+
+
+MASK_MULTI_MAX = 1024 * 2048          # sites per list tri_mask_compact_multi takes (1,024 blocks: the scan is folded into the write pass)
+
+
+def mask_compact_multi(masks, ns):
+    """mask_compact of several masks in two launches: [(row_pos, count), ...].  Lists beyond MASK_MULTI_MAX sites go through mask_compact."""
+    import ctypes
+    out = [None] * len(masks)
+    small = [i for i, n in enumerate(ns) if n <= MASK_MULTI_MAX]
+    for i, n in enumerate(ns):
+        if n > MASK_MULTI_MAX:
+            out[i] = mask_compact(masks[i], n)
+    for s0 in range(0, len(small), 8):
+        grp = small[s0:s0 + 8]
+        dev = masks[grp[0]].device
+        rows = [torch.empty((ns[i],), dtype=torch.int32, device=dev) for i in grp]
+        counts = torch.empty((len(grp),), dtype=torch.int32, device=dev)
+        n_arr = (ctypes.c_long * len(grp))(*[ns[i] for i in grp])
+        scratch = torch.empty((lib().tri_mask_compact_multi_scratch(n_arr, len(grp)),), dtype=torch.uint8, device=dev)
+        m_arr = (ctypes.c_void_p * len(grp))(*[masks[i].data_ptr() for i in grp])
+        r_arr = (ctypes.c_void_p * len(grp))(*[r.data_ptr() for r in rows])
+        c_arr = (ctypes.c_void_p * len(grp))(*[counts[k:k + 1].data_ptr() for k in range(len(grp))])
+        check(lib().tri_mask_compact_multi(m_arr, n_arr, len(grp), r_arr, c_arr, ptr(scratch), stream()), "tri_mask_compact_multi")
+        for k, i in enumerate(grp):
+            out[i] = (rows[k], counts[k:k + 1])
+    return out
 
 
 def mask_count(mask, n):
