@@ -1804,6 +1804,20 @@ __global__ __launch_bounds__(256) void weight_prep_multi_kernel(const TriPrepDes
         }
         return;
     }
+    if (d.s_inner == 1 && d.s_tap == d.inner && d.s_row == span && d.inner == d.inner_pad && (span & 3) == 0 && (d.kpad & 3) == 0 &&
+        (((uintptr_t)d.w) & 15) == 0) {
+        // (round 5) the packed row IS the source row ([Cout][taps][Cin] spconv weights, forward operand; linear layers): a cast, four
+        // elements per thread, 16-byte loads and 8-byte stores in either order.  These operands took the element-wise loop below -
+        // 64-bit divisions and 2-byte stores per element, most of the voxel tower's 41 us packing launch.
+        const unsigned q4 = (unsigned)(d.kpad >> 2), total4 = (unsigned)d.rows * q4, used = (unsigned)span;
+        for (unsigned e = blockIdx.x * 256u + t; e < total4; e += gridDim.x * 256u) {
+            const unsigned row = e / q4, k = (e - row * q4) * 4u;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < used) v = *(const float4*)(d.w + (size_t)row * span + k);
+            prep_store4(f16, hi, lo, prep_index(frag, (int)row, (int)k, d.kpad), v);
+        }
+        return;
+    }
     const bool torch_t = nt > 1 && nt <= 9 && d.s_tap == 1 && d.s_row == nt && d.s_inner == (long)d.rows * nt;   // [inner][rows][taps]
     const bool plane_t = d.s_row == 1 && d.s_tap == d.rows && d.s_inner == (long)d.rows * nt;                   // [inner][taps][rows]
     if ((torch_t || plane_t) && d.inner == d.inner_pad) {
@@ -1866,7 +1880,9 @@ __global__ __launch_bounds__(256) void weight_prep_multi_kernel(const TriPrepDes
 
 extern "C" int tri_weight_prep_multi(const TriPrepDesc* descs_dev, int n, void* stream) {
     if (n <= 0) return TRI_OK;
-    weight_prep_multi_kernel<<<dim3(256, n), 256, 0, (hipStream_t)stream>>>(descs_dev);
+    static int gx = 0;                                               // workgroups per descriptor (tuning aid: TRICOLO_PREP_GRID)
+    if (!gx) { const char* e = getenv("TRICOLO_PREP_GRID"); gx = (e && atoi(e) > 0) ? atoi(e) : 512; }   // (256 -> 512: the three packing launches of a step 81 -> 68 us; 1024: 75)
+    weight_prep_multi_kernel<<<dim3(gx, n), 256, 0, (hipStream_t)stream>>>(descs_dev);
     return tri_check_launch("tri_weight_prep_multi");
 }
 
