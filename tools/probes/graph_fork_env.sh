@@ -1,5 +1,7 @@
+#!/bin/bash
+# tools/probes/graph_fork.py under runtime knobs (one per run): does any of them change the pace at which a replayed graph's nodes start?
 export FORK_QUICK=1
 echo "== default"; python tools/probes/graph_fork.py 2>&1 | grep order
-for kv in DEBUG_CLR_GRAPH_PACKET_CAPTURE=1 DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 DEBUG_HIP_GRAPH_BATCH_SIZE=1 DEBUG_HIP_GRAPH_BATCH_SIZE=16 DEBUG_HIP_GRAPH_BATCH_SIZE=256 DEBUG_HIP_FORCE_GRAPH_QUEUES=1 DEBUG_HIP_FORCE_GRAPH_QUEUES=4 HIP_FORCE_DEV_KERNARG=1 HIP_FORCE_DEV_KERNARG=0 DEBUG_HIP_KERNARG_COPY_OPT=0 AMD_DIRECT_DISPATCH=0 ROC_ACTIVE_WAIT_TIMEOUT=1000 DEBUG_HIP_DYNAMIC_QUEUES=0 GPU_MAX_HW_QUEUES=8; do
+for kv in "$@"; do
   echo "== $kv"; env $kv timeout 120 python tools/probes/graph_fork.py 2>&1 | grep -E "order|rror" | head -3
 done
