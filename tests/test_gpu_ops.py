@@ -629,6 +629,33 @@ def test_mask_pyramid_and_multi_list_compaction(B, V, p):
         assert int(one[1].item()) == refrows.numel() and torch.equal(one[0][:refrows.numel()], rows[:refrows.numel()])
 
 
+def test_window_kernels_and_multi_compaction_reject_what_they_cannot_index():
+    """The 2x2x2-window kernels read the site mask two bytes at a time and index with 32-bit integers; tri_mask_compact_multi folds the scan
+    into the write pass (<= 1,024 blocks per list): arguments outside that are errors, not wrong answers."""
+    import ctypes
+    B, D, C = 1, 4, 8
+    y = torch.zeros(B, D, D, D, C, device=DEV)
+    co = ops.bn_eval_coeffs(C, torch.ones(C, device=DEV), torch.zeros(C, device=DEV), torch.zeros(C, device=DEV), torch.ones(C, device=DEV))
+    buf = torch.zeros(B * D ** 3 + 64, dtype=torch.uint8, device=DEV)
+    with pytest.raises(RuntimeError, match="2-byte aligned mask"):
+        ops.bn_relu_pool3d_fwd(y, co, buf[1:], B, D, C)                          # odd mask address
+    with pytest.raises(RuntimeError, match="multiple of 16"):
+        ops.mask_pyramid(buf, 1, 8)
+    n = ops.MASK_MULTI_MAX + 2048                                                # one block too many for the fused scan
+    big = torch.zeros((n,), dtype=torch.uint8, device=DEV)
+    lib = ops.lib()
+    n_arr = (ctypes.c_long * 1)(n)
+    rows, cnt = torch.empty((n,), dtype=torch.int32, device=DEV), torch.empty((1,), dtype=torch.int32, device=DEV)
+    scratch = torch.empty((lib.tri_mask_compact_multi_scratch(n_arr, 1),), dtype=torch.uint8, device=DEV)
+    rc = lib.tri_mask_compact_multi((ctypes.c_void_p * 1)(big.data_ptr()), n_arr, 1, (ctypes.c_void_p * 1)(rows.data_ptr()),
+                                    (ctypes.c_void_p * 1)(cnt.data_ptr()), ops.ptr(scratch), ops.stream())
+    assert rc != 0
+    big[5] = 1
+    big[n - 1] = 1
+    (r2, c2), = ops.mask_compact_multi([big], [n])                               # the Python wrapper routes such a list through tri_mask_compact
+    assert int(c2.item()) == 2 and r2[:2].tolist() == [5, n - 1]
+
+
 def test_maxpool2d_and_viewmax():
     g = torch.Generator().manual_seed(7)
     N, H, W, C = 6, 10, 10, 64
