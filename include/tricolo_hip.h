@@ -44,7 +44,7 @@ typedef struct TriConvDesc {
  * Layouts: spconv SubMConv3d weight [Cout,kd,kh,kw,Cin] (sparse_cnn.py:12-32), torchvision conv [Cout,Cin,kh,kw]
  * (mv_cnn.py:44), nn.Linear [out,in].
  * frag != 0 (rows % 16 == 0): the same elements in MFMA-FRAGMENT-MAJOR order for the kernels that load their weight fragments straight
- * into registers (tri_conv_kernel_family == 13): the [16 rows x 32 k] block (row tile rt, k-step ks) is 1 KiB at
+ * into registers (tri_conv_kernel_family == 13 / 14 / 15): the [16 rows x 32 k] block (row tile rt, k-step ks) is 1 KiB at
  * ((rt * kpad / 32) + ks) * 512 elements, element (r, k) of it at ((k % 32) / 8 * 16 + r % 16) * 8 + k % 8 - lane (r, k / 8) of a
  * 16x16x32 A fragment reads its 8 elements as ONE contiguous 16-byte piece and a wave reads 1 KiB contiguously. */
 int tri_conv_kpad(int ntaps, int cin_stored);
@@ -108,7 +108,9 @@ int tri_conv_num_records(const TriConvDesc* d, int split3, int row_list);
  * data gradient of the 64 -> 128 channel 3x3 / 2 layer; 11 conv_s2f_kernel: its forward, opt-in), 12 conv_pw_kernel (1x1 / 2 shortcuts),
  * 13 conv_voxg_kernel (conv_voxg.hip: SubMConv3d on 2^3 / 4^3 / 8^3 grids, both directions; takes the site mask as row_mask, refuses a
  * row list; bits 8..15 = output channels per workgroup, bits 24.. = samples per unit = per BatchNorm record), 14 conv_voxb_kernel (voxel
- * level 1 on 16^3 / 32^3 grids, forward only; site mask as row_mask).  Families 13 / 14 read FRAGMENT-MAJOR packed operands.  For profilers. */
+ * level 1 on 16^3 / 32^3 grids, forward only; site mask as row_mask), 15 conv_s2g_kernel (conv_s2g.hip: forward of the 3x3 / 2 layers with >= 128 input
+ * channels - layer3 / layer4's opening convolutions; refuses row mask / list, bias, activation, accumulate; one BatchNorm record per unit of images).
+ * Families 13 / 14 / 15 read FRAGMENT-MAJOR packed operands.  For profilers. */
 int tri_conv_kernel_family(const TriConvDesc* d, int transposed, int split3);
 /* same for tri_conv_wgrad: 0 conv_wgrad_kernel, 2 conv_wgrad_dma_kernel (taken when act_fmt != 0 and the layer qualifies) */
 int tri_conv_wgrad_kernel_family(const TriConvDesc* d, int act_fmt);

@@ -1157,7 +1157,7 @@ def test_halo_kernels_ab_switch(rows):
     assert " passed" in r.stdout and "failed" not in r.stdout
 
 
-@pytest.mark.parametrize("switch", ["s2f", "vox1", "voxb32", "no_voxg"])
+@pytest.mark.parametrize("switch", ["s2f", "vox1", "voxb32", "no_voxg", "s2g_all", "no_s2g"])
 def test_opt_in_kernels_child_process(switch):
     """Kernels that are NOT on the default switch set keep their exactness coverage through a child process that sets the switch in its
     own environment (the parent - like bench.py - runs with no TRICOLO_* variable set, tests/conftest.py): conv_s2f_kernel
@@ -1170,6 +1170,11 @@ def test_opt_in_kernels_child_process(switch):
     env, k, f = {"s2f": ({"TRICOLO_S2F_CONV": "1"}, "test_conv_16bit_storage_integer_exact and s2d_", __file__),
                  "vox1": ({"TRICOLO_NO_VOXB": "1"}, "test_voxel_level1_brick_kernel", __file__),
                  "voxb32": ({"TRICOLO_VOXB_32": "1"}, "test_voxel_level1_ranked_brick_kernel and 32-", __file__),
+                 # conv_s2g_kernel's 12-fragment variant (16x16 maps: slower than conv_dma_kernel at the bench shape, not planned by default)
+                 "s2g_all": ({"TRICOLO_S2G_ALL": "1"}, "test_stride2_slab_kernel and 16x", __file__),
+                 # ... and its A/B partner: layer4's opening layer on conv_dma_kernel (the bench-geometry test of that layer)
+                 "no_s2g": ({"TRICOLO_NO_S2G": "1", "TRICOLO_BENCH_PLAN_ANY_SWITCH": "1"}, "test_image_tower_bench_geometry_integer_exact and b6.conv1",
+                            os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_gpu_bench_plan.py")),
                  "no_voxg": ({"TRICOLO_NO_VOXG": "1", "TRICOLO_NO_VOXB": "1", "TRICOLO_BENCH_PLAN_ANY_SWITCH": "1"},
                              "test_voxel_tower_bench_geometry_integer_exact and config4",
                              os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_gpu_bench_plan.py"))}[switch]
@@ -1886,3 +1891,49 @@ def test_packed_operand_order_is_checked():
     bufs = packer.run("f16", torch.device(DEV))
     assert bufs["f"][0].tri_frag == 1 and torch.equal(bufs["f"][0], p16[0])
     assert torch.equal(bufs["t"][0], ops.pack_weight(wp.to(DEV), g, "f16", transposed=True)[0])
+
+
+S2G_CASES = [  # (N, H, W, cin, cout): 3x3 / 2 / pad 1 layers conv_s2g_kernel takes by default (>= 128 input channels, <= 16 outputs per image)
+    (192, 8, 8, 256, 512),        # layer4[0].conv1 at the bench shape: units of 6 images = 96 rows, 256 workgroups
+    (384, 8, 8, 256, 512),        # config-3 batch
+    (7, 8, 8, 128, 64),           # a batch that does not fill its last unit; one channel tile
+    (5, 8, 4, 128, 128),          # a non-square map; units of 1-2 images after the halving (few images)
+    (2, 4, 4, 192, 64),           # 2x2 outputs per image, 6 chunks
+]
+S2G_ALL_CASES = [  # shapes only TRICOLO_S2G_ALL=1 plans (the 12-fragment variant: slower than conv_dma_kernel at the bench shape, kept for experiments)
+    (192, 16, 16, 128, 256),      # layer3[0].conv1 at the bench shape: units of 3 images = 192 rows
+    (7, 16, 16, 128, 64),
+    (3, 16, 8, 128, 128),
+]
+
+
+@pytest.mark.parametrize("case", S2G_CASES + S2G_ALL_CASES, ids=[f"{c[0]}x{c[1]}x{c[2]}_{c[3]}to{c[4]}" for c in S2G_CASES + S2G_ALL_CASES])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+def test_stride2_slab_kernel(case, dtype):
+    """conv_s2g_kernel (family 15): forward of the 3x3 / 2 layers that open layer3 / layer4 - space-to-depth LDS slab, weights straight into
+    MFMA registers (fragment-major operand), BatchNorm records per unit of images.  Integer-exact against F.conv2d, statistics against the
+    stored values; partial last units, every unit size the plan picks, both 16-bit storage types."""
+    N, H, W, cin, cout = case
+    if case in S2G_ALL_CASES and os.environ.get("TRICOLO_S2G_ALL") != "1":
+        pytest.skip("planned only with TRICOLO_S2G_ALL=1 (runs in test_opt_in_kernels_child_process)")
+    prec = "f16" if dtype == torch.float16 else "bf16"
+    g = ops.ConvGeom(N, (1, H, W), cin, cin, cout, (1, 3, 3), 2, (0, 1, 1), (cin * 9, 1, 9))
+    assert (g.kernel_family[(False, 2)] & 255) == 15, "plan: not conv_s2g_kernel"
+    assert (g.kernel_family[(True, 2)] & 255) != 15                            # the data gradient keeps its own kernels
+    x = ints((N, cin, H, W), -2, 2, 71)
+    w = ints((cout, cin, 3, 3), -2, 2, 72)
+    ref = F.conv2d(x, w, stride=2, padding=1).permute(0, 2, 3, 1).contiguous()
+    xd = x.permute(0, 2, 3, 1).contiguous().view(N, 1, H, W, cin).to(DEV).to(dtype)
+    packed = ops.pack_weight(w.to(DEV), g, prec)
+    assert packed[0].tri_frag == 1
+    junk = torch.full((N, 1, H // 2, W // 2, cout), 777.0, dtype=dtype, device=DEV)
+    out, stats = ops.conv_fwd(xd, g, packed, want_stats=True, out=junk)
+    assert torch.equal(out.cpu().view(ref.shape).float(), ref.to(dtype).float()), f"{ops._igemm_symbol(g, False, False, xd)}: forward differs"
+    exact = ref.to(dtype).double().reshape(-1, cout)
+    st = stats.cpu().double().sum(0)
+    np.testing.assert_allclose(st[0].numpy(), exact.sum(0).numpy(), rtol=1e-6, atol=1e-1)
+    np.testing.assert_allclose(st[1].numpy(), (exact ** 2).sum(0).numpy(), rtol=1e-6, atol=1e-1)
+    with pytest.raises(RuntimeError, match="conv_s2g_kernel"):                 # no bias / activation epilogue on this kernel
+        ops.conv_fwd(xd, g, packed, bias=torch.zeros(cout, device=DEV), act=1)
+    # fp32 activations (the bf16x3 parity mode) never take this kernel: row-major operand, generic plan
+    assert (g.kernel_family[(False, 1)] & 255) != 15 and (g.kernel_family[(False, 0)] & 255) != 15

@@ -1941,6 +1941,7 @@ struct ConvPlan {
     int vox1;             // 1: conv_vox1_kernel (level 1 of the voxel tower, 32 -> 64 channels, 16-bit storage); records = vox1_grid
     int vox1_grid;
     int voxb, voxb_grid;  // 1: conv_voxb_kernel (conv_voxg.hip: level 1 of the voxel tower, ranked active rows over bricks); records = voxb_grid
+    int s2g, s2g_units;   // 1: conv_s2g_kernel (conv_s2g.hip: forward of the 3x3 / 2 layers that open layer3 / layer4, 16-bit storage); records = s2g_units
     int voxg;             // 1: conv_voxg_kernel (conv_voxg.hip: SubMConv3d on 2^3 / 4^3 / 8^3 grids, forward and data gradient, 16-bit storage);
     int voxg_units, voxg_ct, voxg_spu;        // records = units
     int c64;              // 1: conv_c64_kernel (conv_c64.hip: 64 -> 64 channels, 2D 3x3 / 1 / pad 1, 16-bit storage); records = c64_grid
@@ -2144,6 +2145,15 @@ static ConvPlan conv_make_plan(int B, int ID, int IH, int IW, int cin, int OD, i
             // 64 -> 64 channels: conv_c64_kernel (filter bank in registers; conv_c64.hip), forward and data gradient; a call with a
             // row mask / bias / activation takes conv_dma_kernel (nunits etc. below are its plan)
             pl.c64 = 1; pl.c64_grid = cg.grid; pl.bn = 64; pl.nunits = kpad / 64; pl.ksplit = 1; pl.per_split = pl.nunits;
+            return pl;
+        }
+    }
+    {
+        TriS2gGeom g2;
+        if (pl.dma && split_mode == 2 && !row_list && tri_internal_s2g_geometry(B, ID, IH, IW, cin, OD, OH, OW, cout, KD, KH, KW, stride, pd, ph, pw, &g2)) {
+            // 3x3 / 2 layers with >= 128 input channels: conv_s2g_kernel (space-to-depth slab, weights straight into MFMA registers); a call with a
+            // row mask / list / bias / activation / accumulate is refused (the layer's operand is packed fragment-major)
+            pl.s2g = 1; pl.s2g_units = g2.nunits; pl.bn = 64; pl.nunits = kpad / 32; pl.ksplit = 1; pl.per_split = pl.nunits;
             return pl;
         }
     }
@@ -2476,6 +2486,16 @@ static int conv_dispatch(ConvArgs& a, int act_fmt, void* workspace, size_t works
         }
         a.row_pos = a.row_count ? a.row_pos : nullptr;
     }
+    if (pl.s2g) {
+        if (a.transposed || a.row_mask || a.row_count || a.bias || a.act != 0 || a.accumulate) {
+            tri_set_error("conv: this layer runs conv_s2g_kernel (tri_conv_kernel_family == 15): forward only, no row mask / list, bias, activation "
+                          "or accumulate");
+            return TRI_ERR_ARG;
+        }
+        TriS2gGeom g2;
+        tri_internal_s2g_geometry(a.B, a.ID, a.IH, a.IW, a.Cin, a.OD, a.OH, a.OW, a.Cout, a.KD, a.KH, a.KW, a.stride, a.pd, a.ph, a.pw, &g2);
+        return tri_internal_s2g_launch(g2, a.B, a.IH, a.IW, a.Cin, a.Cout, a.Kpad, a.in, a.w_hi, a.out, a.stats, act_fmt, stream);
+    }
     if (pl.s2f && !a.transposed) {
         if (!a.row_mask && !a.row_count && !a.bias && a.act == 0 && !a.accumulate) {
             TriC64Geom sg;
@@ -2536,6 +2556,7 @@ extern "C" int tri_conv_num_records(const TriConvDesc* d, int split3, int row_li
     if (pl.voxg) return pl.voxg_units;
     if (pl.c64) return pl.c64_grid;
     if (pl.s2f) return pl.s2f_grid;
+    if (pl.s2g) return pl.s2g_units;
     if (pl.halo) return pl.h_wgrec ? pl.h_grid / (d->Cout / 64) : pl.h_mtiles;
     return pl.ksplit > 1 ? (int)((M + 31) / 32) : (int)((M + 127) / 128);
 }
@@ -2555,6 +2576,7 @@ extern "C" int tri_conv_kernel_family(const TriConvDesc* d, int transposed, int 
     if (pl.c64) return 9 | (64 << 8);
     if (pl.s2d && transposed) return 10 | (64 << 8);
     if (pl.s2f && !transposed) return 11 | (128 << 8);
+    if (pl.s2g && !transposed) return 15 | (64 << 8);
     if (pl.halo) return (pl.h_v5 ? 5 : 3) | (pl.halo << 8);
     if (pl.pw) return 12 | (pl.bn << 8);
     return (pl.dma ? 2 : 0) | (pl.bn << 8) | ((pl.ksplit > 1 || (pl.dma && tri_conv_kpad(d->KD * d->KH * d->KW, transposed ? d->Cout : d->Cin) / 64 > 256)) ? (1 << 16) : 0);

@@ -42,6 +42,14 @@ bool tri_internal_voxb_geometry(int B, int ID, int IH, int IW, int cin, int OD, 
 int tri_internal_voxb_launch(const TriVoxbGeom& g, int B, const void* in, const void* w, void* out, const uint8_t* mask, float* stats, int act_fmt,
                              hipStream_t stream);
 
+// the 3x3 / stride 2 / pad 1 layers that open layer3 / layer4 of the ResNet trunk (Cin >= 128, Cin % 64 == 0, Cout % 64 == 0, <= 192 output
+// positions per image, 16-bit storage): conv_s2g_kernel (conv_s2g.hip), forward only; units of whole images, g->nunits BatchNorm records
+struct TriS2gGeom { int ipu, nunits, nrt, PW, PS, NSP, HB, grid, smem; };
+bool tri_internal_s2g_geometry(int B, int ID, int IH, int IW, int cin, int OD, int OH, int OW, int cout, int KD, int KH, int KW, int stride,
+                               int pd, int ph, int pw, TriS2gGeom* g);
+int tri_internal_s2g_launch(const TriS2gGeom& g, int B, int IH, int IW, int cin, int cout, int kpad, const void* in, const void* w, void* out,
+                            float* stats, int act_fmt, hipStream_t stream);
+
 struct TriC64Geom { int W, TY, nbricks, grid; };
 // a 64 -> 64 channel 3x3 / 1 / pad 1 2D layer on 16- / 32- / 64-pixel-wide images in a 16-bit storage mode (layer1 of the ResNet trunk):
 // conv_c64_kernel (conv_c64.hip), forward and data gradient; g->grid = persistent workgroups = BatchNorm records of the launch

@@ -149,6 +149,8 @@ def _igemm_symbol(g, transposed, split, t):
         return f"conv_s2d_kernel<{_TNAME[t.dtype]}>"
     if fam == 11:
         return f"conv_s2f_kernel<{_TNAME[t.dtype]}>"
+    if fam == 15:
+        return f"conv_s2g_kernel<{_TNAME[t.dtype]}>"
     if fam == 12:
         return f"conv_pw_kernel<{bn}, {_TNAME[t.dtype]}>"                # (forward and data gradient under one name)
     if fam == 4:
@@ -204,6 +206,9 @@ def grad_scale(precision: str) -> float:
 def _conv_mode(x, lo) -> int:
     """Plan index of the conv entry points: 0 bf16 operands / fp32 storage, 1 bf16x3, 2 16-bit storage."""
     return 1 if lo is not None else (2 if x.dtype != torch.float32 else 0)
+
+
+_FRAG_FAMILIES = (13, 14, 15)        # kernel families that read the packed operand fragment-major: conv_voxg / conv_voxb / conv_s2g
 
 
 class ConvGeom:
@@ -272,11 +277,11 @@ class ConvGeom:
         activation storage the operand will meet (default: the precision mode's own)."""
         storage = storage or act_dtype(precision)
         mode = 1 if precision == "bf16x3" else (2 if storage != torch.float32 else 0)
-        return 1 if (self.kernel_family[(transposed, mode)] & 255) in (13, 14) else 0
+        return 1 if (self.kernel_family[(transposed, mode)] & 255) in _FRAG_FAMILIES else 0
 
     def check_packed(self, packed, transposed: bool, x):
         """The packed operand must be in the order this call's kernel reads (see pack_weight's `storage`)."""
-        need = 1 if (self.kernel_family[(transposed, _conv_mode(x, packed[1]))] & 255) in (13, 14) else 0
+        need = 1 if (self.kernel_family[(transposed, _conv_mode(x, packed[1]))] & 255) in _FRAG_FAMILIES else 0
         if getattr(packed[0], "tri_frag", 0) != need:
             raise RuntimeError("conv: the packed operand was ordered for another plan (row-major vs fragment-major): pack it with "
                                "pack_weight(..., storage=<dtype of the activations>)")
