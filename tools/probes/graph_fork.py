@@ -66,6 +66,14 @@ def run(NA, dA, NB, dB, order="AB", clock_mhz=2400.0):
 
 if __name__ == "__main__":
     torch.cuda.set_device(0)
+    if os.environ.get("FORK_SHARED") == "1":           # is node release a shared serial resource?  chain A alone, then beside an equal chain B
+        run(200, 1.0, 1, 1.0, "AB")
+        run(200, 1.0, 200, 1.0, "AB")
+        run(200, 1.0, 200, 1.0, "BA")
+        run(100, 5.0, 1, 1.0, "AB")
+        run(100, 5.0, 200, 1.0, "AB")
+        run(100, 5.0, 200, 1.0, "BA")
+        sys.exit(0)
     if os.environ.get("FORK_QUICK") == "1":
         run(50, 5.0, 10, 5.0, "AB")
         run(200, 1.0, 10, 5.0, "AB")
