@@ -977,6 +977,11 @@ BF16_CASES = [c for c in CONV_CASES if c[0] in ("vox_l0", "vox_l1", "vox_l3", "s
     # 192-position tiles of conv_halo_rows_kernel (planned where they save a round of workgroups: h_320 above - 216 tiles with a partial
     # last one instead of 320 - and layer3 of the bench shape: 256 tiles instead of 384, four channel chunks)
     ("h_tm3", 192, (1, 8, 8), 256, 256, (1, 3, 3), 1, (0, 1, 1), "torch"),
+    # (round 5) layer3 / layer4 at 224 x 224 inputs: 14 x 14 and 7 x 7 maps, whose rows do not fill a 128- / 192-position tile - conv_dma_kernel
+    # (halo tiles of 7 rows / two-three whole images, 77 % of a tile's positions, were measured: same step time, not kept)
+    ("h_14x256", 24, (1, 14, 14), 256, 256, (1, 3, 3), 1, (0, 1, 1), "torch"),
+    ("h_7x512", 50, (1, 7, 7), 512, 512, (1, 3, 3), 1, (0, 1, 1), "torch"),
+    ("h_7x256", 5, (1, 7, 7), 256, 64, (1, 3, 3), 1, (0, 1, 1), "torch"),
     # conv_pw_kernel (1x1 / 2 shortcut convolutions; c1x1s2 above is the 64 -> 128 one): 128 -> 256 with a partial last row tile, 256 -> 512
     # (data gradient: K = 512, four rounds of activation fragments), 64-wide output-channel tiles and the 128-wide ones of a launch that fills the GPU
     ("pw_256", 7, (1, 16, 16), 128, 256, (1, 1, 1), 2, (0, 0, 0), "torch"),
