@@ -2199,10 +2199,17 @@ static ConvPlan conv_make_plan(int B, int ID, int IH, int IW, int cin, int OD, i
         // 128-wide tiles against 54 with 64-wide ones; the occupancy discount is for the split-K decision only)
         if (pl.dma && bn == 128 && blocks_dense < narrow) { pl.bn = 64; blocks *= 2; }
     }
+    // (round 5) dense layers with a short K on the register-staged kernel (fp32 storage: the GRU's input projection, 3,072 x 256 x 768 at the
+    // bench shape): 64-wide tiles that fill the GPU once instead of 128-wide tiles split over K with a finish launch (two launches, a
+    // 19 MB round trip of partial sums for 8 k-steps of work)
+    static int lin64 = -1;
+    if (lin64 < 0) { const char* e = getenv("TRICOLO_LINEAR_BN64"); lin64 = (e && e[0] == '0') ? 0 : 1; }
+    const bool short_linear = lin64 && !pl.dma && !row_list && ntaps == 1 && kpad <= 256 && cout % 64 == 0;
+    if (short_linear && bn == 128 && blocks < num_cus() && 2 * blocks >= num_cus()) { pl.bn = 64; blocks *= 2; }
     pl.nunits = pl.dma ? kpad / 64 : kpad / 32;
     int ks = 1;
     int min_per = pl.dma ? 2 : 4;                                              // at least this many units per split
-    if (blocks < 384 && pl.nunits >= 2 * min_per && cout % 64 == 0) {
+    if (blocks < 384 && pl.nunits >= 2 * min_per && cout % 64 == 0 && !(short_linear && blocks >= num_cus())) {
         const int target = conv_target_blocks() ? conv_target_blocks() : (split_mode == 2 ? 256 : 768);
         ks = (target + blocks - 1) / blocks;
         if (ks > pl.nunits / min_per) ks = pl.nunits / min_per;
@@ -2534,7 +2541,7 @@ static int conv_dispatch(ConvArgs& a, int act_fmt, void* workspace, size_t works
     (act_fmt == TRI_FMT_F16 ? launch_conv<BN_, 1, f16_t>(a, stream)                                       \
      : act_fmt == TRI_FMT_BF16 ? launch_conv<BN_, 1, bf16_t>(a, stream)                                   \
      : (split ? launch_conv<BN_, 2, float>(a, stream) : launch_conv<BN_, 1, float>(a, stream)))
-    if (a.Cout % 128 == 0) return TRI_CONV(128);
+    if (a.Cout % 128 == 0 && pl.bn != 64) return TRI_CONV(128);
     if (a.Cout % 64 == 0) return TRI_CONV(64);
     return TRI_CONV(32);
 #undef TRI_CONV
