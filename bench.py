@@ -527,8 +527,11 @@ def run_mode(a, precision, world, rank, device, want_voxel_roofline):
                                         "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in agg.items()}}
             # HBM bytes per launch of that kernel from the committed PMC passes over this same command (PMC cannot run inside
             # bench.py: separate `rocprofv3 --pmc` runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes)
-            for rnd in ("r4", "r3", "r2"):
-                rel = f"profiles/{rnd}/pmc_traffic_{precision}.json"
+            import glob
+            pmc_docs = sorted(glob.glob(os.path.join(REPO, "profiles", "r*", f"pmc_traffic_{precision}.json")),
+                              key=lambda f: int("".join(c for c in os.path.basename(os.path.dirname(f)) if c.isdigit()) or 0), reverse=True)
+            for path in pmc_docs:                    # newest round first
+                rel = os.path.relpath(path, REPO)
                 try:
                     with open(os.path.join(REPO, rel)) as f:
                         doc = json.load(f)
@@ -586,6 +589,29 @@ def run_mode_in_child(a, mode):
             "nonfinite_guard": d.get("nonfinite_guard"), "process": "child"}
 
 
+def voxel_fwd_config5_in_child():
+    """The five SubMConv3d forwards at BASELINE config 5's per-GPU shape (64^3 grids, batch 64) - the shape where north_star's "40 % of
+    the MFMA roofline on the 3D-conv forward" is not below five launch latencies - timed by tools/voxel_fwd_bench.py in a child process
+    (its own allocator state; ~20 s).  Same object as `roofline_3dconv_fwd`; the PRIMARY figure is `frac_active_rows_raw_events`:
+    FLOPs of the active rows alone (constant across kernel generations) over the raw single-launch event times."""
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        js = os.path.join(d, "v.json")
+        cmd = [sys.executable, os.path.join(REPO, "tools", "voxel_fwd_bench.py"), "--modes", "f16", "--shapes", "64x64", "--json", js]
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        if r.returncode != 0 or not os.path.exists(js):
+            raise RuntimeError(f"voxel_fwd_bench.py child failed (rc {r.returncode}):\n{r.stderr[-1500:]}")
+        with open(js) as f:
+            doc = json.load(f)
+    res = next(iter(doc.values()))
+    res["primary"] = "frac_active_rows_raw_events"
+    res["frac_executed_raw_events"] = res["frac"]
+    res["process"] = "child (tools/voxel_fwd_bench.py --modes f16 --shapes 64x64)"
+    return res
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -601,6 +627,7 @@ def parse_args(argv=None):
     ap.add_argument("--image-size", type=int, default=None)
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-voxel-config5", action="store_true", help="skip the child leg that times the 3D-conv forwards at 64^3 x 64")
     ap.add_argument("--cpu-batch", type=int, default=0, help="batch of the CPU leg (0: the per-GPU batch, halved until 2 + 5 steps fit the budget)")
     ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU leg (0: the fastest of 16 / 32 / 64 / physical cores / all CPUs, probed)")
@@ -707,6 +734,13 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline:             # the CPU leg is an N = 1 artefact (task contract)
         cpu = cpu_baseline(a, cfg)
 
+    vox5 = None
+    if rank == 0 and world == 1 and a.config == 4 and not a.no_voxel_config5 and not a.no_cpu_baseline:
+        try:                                                            # (default line only: A/B runs pass --no-cpu-baseline)
+            vox5 = voxel_fwd_config5_in_child()
+        except Exception as e:                                         # noqa: BLE001  reported, never fatal for the headline
+            vox5 = {"error": str(e)[-500:]}
+
     if rank == 0:
         gb = a.per_gpu_batch * world
         out = {
@@ -719,11 +753,22 @@ def main():
                        "resident_batches": a.resident_batches,
                        "switches": {k: v for k, v in sorted(os.environ.items()) if k.startswith("TRICOLO_")},   # every kernel / tile-rule switch that was set
                        "precision_mode": a.precision, "hip_graph": head["hip_graph"], "final_loss": head["final_loss"],
+                       "roofline_3dconv_fwd_primary": "frac_active_rows_raw_events (FLOPs of the active rows over the raw single-launch event times; "
+                                                      "`frac` = executed FLOPs on the same times)",
                        "parity": "f16 mode: step-0 losses and embeddings within 1e-3 of the fp32 reference on BASELINE configs 1,3,4,5 "
                                  "(tests/test_gpu_modules.py::test_f16_mode_meets_the_1e3_parity_bound); bf16x3: ~1e-5; bf16: outside 1e-3"},
-            "roofline": head["roofline"], "modes": modes, "roofline_3dconv_fwd": vox_roof, "cpu_baseline": cpu,
+            "roofline": head["roofline"], "modes": modes, "roofline_3dconv_fwd": vox_roof, "roofline_3dconv_fwd_config5": vox5, "cpu_baseline": cpu,
             "data_parallel": head.get("data_parallel"), "nonfinite_guard": head.get("nonfinite_guard"),
         }
+        for m, d_ in modes.items():                                   # flat copies: the driver keeps top-level keys
+            out[f"value_{m}"] = d_["value"]
+            out[f"ms_per_step_{m}"] = d_["ms_per_step"]
+        if vox_roof:
+            vox_roof["primary"] = "frac_active_rows_raw_events"
+            out["frac_3dconv_fwd"] = vox_roof["frac_active_rows_raw_events"]
+        if vox5 and "error" not in vox5:
+            out["frac_3dconv_fwd_config5"] = vox5["frac_active_rows_raw_events"]
+            out["frac_3dconv_fwd_config5_executed"] = vox5["frac"]
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

@@ -103,9 +103,9 @@ int tri_conv_num_records(const TriConvDesc* d, int split3, int row_list);
 /* kernel family tri_conv_fwd (transposed = 0) / tri_conv_dgrad (transposed = 1) dispatches for this layer and mode:
  * 0 conv_igemm_kernel (register-staged im2col), 2 conv_dma_kernel (LDS-DMA staging); bits 8.. hold the output-channel
  * tile width; bit 16 set = the dense call of the layer runs split-K in this mode; 4 conv_stem_kernel, 3 / 5 the halo kernels,
- * 6 / 7 = a brick kernel of conv_vox.hip (voxel level 0 / 1; takes the site mask as row_mask, refuses a row list), 9 / 10 / 11 = the
+ * 6 = the brick kernel of conv_vox.hip (voxel level 0; takes the site mask as row_mask, refuses a row list), 9 / 10 = the
  * register-stationary filter-bank kernels of conv_c64.hip (9 conv_c64_kernel: 64 -> 64 channels 3x3 / 1, both directions; 10 conv_s2d_kernel:
- * data gradient of the 64 -> 128 channel 3x3 / 2 layer; 11 conv_s2f_kernel: its forward, opt-in), 12 conv_pw_kernel (1x1 / 2 shortcuts),
+ * data gradient of the 64 -> 128 channel 3x3 / 2 layer), 12 conv_pw_kernel (1x1 / 2 shortcuts; 7 and 11 were A/B partners dropped in round 6),
  * 13 conv_voxg_kernel (conv_voxg.hip: SubMConv3d on 2^3 / 4^3 / 8^3 grids, both directions; takes the site mask as row_mask, refuses a
  * row list; bits 8..15 = output channels per workgroup, bits 24.. = samples per unit = per BatchNorm record), 14 conv_voxb_kernel (voxel
  * level 1 on 16^3 / 32^3 grids, forward only; site mask as row_mask), 15 conv_s2g_kernel (conv_s2g.hip: forward of the 3x3 / 2 layers with >= 128 input

@@ -9,7 +9,7 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 GOLDEN = os.path.join(REPO, "tests", "golden")
 # The GPU tests run on the DEFAULT switch set - the binary path bench.py times: no TRICOLO_* variable is set
-# here.  Opt-in kernels (conv_s2f_kernel) and forced plans are covered by child-process runs (test_opt_in_kernels_child_process,
+# here.  Opt-in and forced plans are covered by child-process runs (test_opt_in_kernels_child_process,
 # test_halo_kernels_ab_switch in test_gpu_ops.py), each of which sets its switches in the child's environment only.
 
 

@@ -1040,24 +1040,14 @@ def test_conv_16bit_storage_integer_exact(case, store, prec):
         assert torch.equal(dx.cpu(), cl3(xr.grad).to(store))
     if case[0].startswith("s2d"):
         assert (g.kernel_family[(True, 2)] & 255) == 10                  # conv_s2d_kernel
-        # ... and the forward of the same layer: conv_dma_kernel on the default switch set (what bench.py times); with TRICOLO_S2F_CONV=1
-        # (test_opt_in_kernels_child_process) conv_s2f_kernel: BatchNorm records (one per persistent workgroup), the taller bricks
-        s2f = os.environ.get("TRICOLO_S2F_CONV") == "1"
-        assert (g.kernel_family[(False, 2)] & 255) == (11 if s2f else 2)
-        for ty in (None,) + (((("4",) if case[0] == "s2d_16" else ("1",)) if case[0] != "s2d_many" else ()) if s2f else ()):
-            if ty:
-                os.environ["TRICOLO_S2F_TY"] = ty
-            try:
-                g2 = make_case(case, integer=True, seed=51)[4] if ty else g      # (records of the forced brick height)
-                out2, stats = ops.conv_fwd(xcl.to(DEV).to(store), g2, packed, want_stats=True)
-            finally:
-                if ty:
-                    del os.environ["TRICOLO_S2F_TY"]
-            assert torch.equal(out2.cpu(), ref.to(store))
-            exact = ref.to(store).double().reshape(-1, case[4])
-            st = stats.cpu().double().sum(0)
-            np.testing.assert_allclose(st[0].numpy(), exact.sum(0).numpy(), rtol=1e-6, atol=1e-2)
-            np.testing.assert_allclose(st[1].numpy(), (exact ** 2).sum(0).numpy(), rtol=1e-6, atol=1e-2)
+        # ... and the forward of the same layer: conv_dma_kernel (what bench.py times; the opt-in conv_s2f_kernel was dropped in round 6)
+        assert (g.kernel_family[(False, 2)] & 255) == 2
+        out2, stats = ops.conv_fwd(xcl.to(DEV).to(store), g, packed, want_stats=True)
+        assert torch.equal(out2.cpu(), ref.to(store))
+        exact = ref.to(store).double().reshape(-1, case[4])
+        st = stats.cpu().double().sum(0)
+        np.testing.assert_allclose(st[0].numpy(), exact.sum(0).numpy(), rtol=1e-6, atol=1e-2)
+        np.testing.assert_allclose(st[1].numpy(), (exact ** 2).sum(0).numpy(), rtol=1e-6, atol=1e-2)
         tp = ops.pack_weight(wp.to(DEV), g, prec, transposed=True)
         base = ints(tuple(cl3(xr.grad).shape), -5, 5, 59)
         dx2 = ops.conv_dgrad(cl3(dy).to(DEV).to(store), g, tp, out=base.clone().to(DEV).to(store), accumulate=True)
@@ -1162,22 +1152,18 @@ def test_halo_kernels_ab_switch(rows):
     assert " passed" in r.stdout and "failed" not in r.stdout
 
 
-@pytest.mark.parametrize("switch", ["s2f", "vox1", "voxb32", "no_voxg", "s2g_all", "no_s2g"])
+@pytest.mark.parametrize("switch", ["voxb32", "no_voxg", "no_s2g"])
 def test_opt_in_kernels_child_process(switch):
-    """Kernels that are NOT on the default switch set keep their exactness coverage through a child process that sets the switch in its
-    own environment (the parent - like bench.py - runs with no TRICOLO_* variable set, tests/conftest.py): conv_s2f_kernel
-    (TRICOLO_S2F_CONV=1, forward of the 64 -> 128 channel 3x3 / 2 layer; the s2d_* geometries assert family 11 there); conv_vox1_kernel
-    (TRICOLO_NO_VOXB=1: the run-based level-1 brick kernel, A/B partner of conv_voxb_kernel); conv_voxb_kernel on 32^3 level-1 grids
-    (TRICOLO_VOXB_32=1; conv_igemm_kernel is faster there); the voxel tower's coarse levels on
-    conv_dma_kernel over compact row lists (TRICOLO_NO_VOXG=1, A/B partner of conv_voxg_kernel: the bench-geometry voxel test)."""
+    """Plans that are NOT on the default switch set keep their exactness coverage through a child process that sets the switch in its
+    own environment (the parent - like bench.py - runs with no TRICOLO_* variable set, tests/conftest.py): conv_voxb_kernel on 32^3
+    level-1 grids (TRICOLO_VOXB_32=1; conv_igemm_kernel is faster there); the voxel tower's coarse levels on conv_dma_kernel over compact
+    row lists (TRICOLO_NO_VOXG=1, A/B partner of conv_voxg_kernel: the bench-geometry voxel test); layer4's opening layer on
+    conv_dma_kernel (TRICOLO_NO_S2G=1).  Round 6 dropped the kernels that had lost their A/B for good (conv_vox1_kernel,
+    conv_s2f_kernel, conv_s2g_kernel's 12-fragment variant) together with their switches."""
     import subprocess
     import sys
-    env, k, f = {"s2f": ({"TRICOLO_S2F_CONV": "1"}, "test_conv_16bit_storage_integer_exact and s2d_", __file__),
-                 "vox1": ({"TRICOLO_NO_VOXB": "1"}, "test_voxel_level1_brick_kernel", __file__),
-                 "voxb32": ({"TRICOLO_VOXB_32": "1"}, "test_voxel_level1_ranked_brick_kernel and 32-", __file__),
-                 # conv_s2g_kernel's 12-fragment variant (16x16 maps: slower than conv_dma_kernel at the bench shape, not planned by default)
-                 "s2g_all": ({"TRICOLO_S2G_ALL": "1"}, "test_stride2_slab_kernel and 16x", __file__),
-                 # ... and its A/B partner: layer4's opening layer on conv_dma_kernel (the bench-geometry test of that layer)
+    env, k, f = {"voxb32": ({"TRICOLO_VOXB_32": "1"}, "test_voxel_level1_ranked_brick_kernel and 32-", __file__),
+                 # conv_s2g_kernel's A/B partner: layer4's opening layer on conv_dma_kernel (the bench-geometry test of that layer)
                  "no_s2g": ({"TRICOLO_NO_S2G": "1", "TRICOLO_BENCH_PLAN_ANY_SWITCH": "1"}, "test_image_tower_bench_geometry_integer_exact and b6.conv1",
                             os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_gpu_bench_plan.py")),
                  "no_voxg": ({"TRICOLO_NO_VOXG": "1", "TRICOLO_NO_VOXB": "1", "TRICOLO_BENCH_PLAN_ANY_SWITCH": "1"},
@@ -1767,43 +1753,6 @@ def test_voxel_level1_ranked_brick_kernel(B, V, store, prec):
         assert torch.equal(out2.cpu(), cl3(F.conv3d(x, w, padding=1)).to(store))
 
 
-@pytest.mark.parametrize("store,prec", STORE16, ids=STORE16_IDS)
-@pytest.mark.parametrize("B,V", [(5, 16), (40, 16), (70, 16)])
-def test_voxel_level1_brick_kernel(B, V, store, prec):
-    """conv_vox1_kernel (conv_vox.hip): level 1 of the voxel tower (sparse_cnn.py:17, 32 -> 64 channels) - filter bank stationary in
-    registers, persistent workgroups over the grid's bricks (B = 40: several bricks per workgroup, more bricks than workgroups x 1).
-    Integer data: active rows equal the masked dense convolution exactly, rows of inactive sites stay unwritten, the per-workgroup
-    BatchNorm records sum to the column sums of the active rows; without a mask it is the plain convolution."""
-    if os.environ.get("TRICOLO_NO_VOXB") != "1":
-        pytest.skip("conv_vox1_kernel is the A/B partner of conv_voxb_kernel since round 5: covered by test_opt_in_kernels_child_process[vox1]")
-    case = ("vox1", B, (V, V, V), 32, 64, (3, 3, 3), 1, (1, 1, 1), "spconv")
-    x, w, wp, xcl, g = make_case(case, integer=True, seed=81)
-    assert g.brick(False, 2) and (g.kernel_family[(False, 2)] & 255) == 7
-    m = _blob_mask(B, V, seed=83)
-    mf = m.float()
-    x = x * mf[:, None]
-    xcl = xcl * mf[..., None]
-    ref = cl3(F.conv3d(x, w, padding=1)).to(store)
-    packed = ops.pack_weight(wp.to(DEV), g, prec)
-    M = B * V ** 3
-    mask = m.reshape(M).to(torch.uint8)
-    junk = torch.full((B, V, V, V, 64), 777.0, dtype=store, device=DEV)
-    out, stats = ops.conv_fwd(xcl.to(DEV).to(store), g, packed, row_mask=mask.to(DEV), want_stats=True, out=junk)
-    assert stats.shape[0] == g.num_mtiles[2]
-    o = out.cpu().reshape(M, 64)
-    act = mask.bool()
-    assert torch.equal(o[act], ref.reshape(M, 64)[act])
-    assert bool((o[~act] == 777.0).all()), "rows of inactive sites must not be written"
-    exact = ref.reshape(M, 64)[act].double()
-    st = stats.cpu().double().sum(0)
-    np.testing.assert_allclose(st[0].numpy(), exact.sum(0).numpy(), rtol=1e-6, atol=1e-2)
-    np.testing.assert_allclose(st[1].numpy(), (exact ** 2).sum(0).numpy(), rtol=1e-6, atol=1e-2)
-    if B <= 5:
-        xd, _, _, xdcl, _ = make_case(case, integer=True, seed=89)
-        out2 = ops.conv_fwd(xdcl.to(DEV).to(store), g, packed)
-        assert torch.equal(out2.cpu(), cl3(F.conv3d(xd, w, padding=1)).to(store))
-
-
 VOXG_CASES = [
     # B, D, cin, cout: the bench shapes' levels 2-4 (32^3 x 32), config 2 (x 64), config 5's levels 3-4, small batches (fewer workgroups than
     # CUs, partial last unit), odd batch sizes
@@ -1905,22 +1854,15 @@ S2G_CASES = [  # (N, H, W, cin, cout): 3x3 / 2 / pad 1 layers conv_s2g_kernel ta
     (5, 8, 4, 128, 128),          # a non-square map; units of 1-2 images after the halving (few images)
     (2, 4, 4, 192, 64),           # 2x2 outputs per image, 6 chunks
 ]
-S2G_ALL_CASES = [  # shapes only TRICOLO_S2G_ALL=1 plans (the 12-fragment variant: slower than conv_dma_kernel at the bench shape, kept for experiments)
-    (192, 16, 16, 128, 256),      # layer3[0].conv1 at the bench shape: units of 3 images = 192 rows
-    (7, 16, 16, 128, 64),
-    (3, 16, 8, 128, 128),
-]
 
 
-@pytest.mark.parametrize("case", S2G_CASES + S2G_ALL_CASES, ids=[f"{c[0]}x{c[1]}x{c[2]}_{c[3]}to{c[4]}" for c in S2G_CASES + S2G_ALL_CASES])
+@pytest.mark.parametrize("case", S2G_CASES, ids=[f"{c[0]}x{c[1]}x{c[2]}_{c[3]}to{c[4]}" for c in S2G_CASES])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
 def test_stride2_slab_kernel(case, dtype):
     """conv_s2g_kernel (family 15): forward of the 3x3 / 2 layers that open layer3 / layer4 - space-to-depth LDS slab, weights straight into
     MFMA registers (fragment-major operand), BatchNorm records per unit of images.  Integer-exact against F.conv2d, statistics against the
     stored values; partial last units, every unit size the plan picks, both 16-bit storage types."""
     N, H, W, cin, cout = case
-    if case in S2G_ALL_CASES and os.environ.get("TRICOLO_S2G_ALL") != "1":
-        pytest.skip("planned only with TRICOLO_S2G_ALL=1 (runs in test_opt_in_kernels_child_process)")
     prec = "f16" if dtype == torch.float16 else "bf16"
     g = ops.ConvGeom(N, (1, H, W), cin, cin, cout, (1, 3, 3), 2, (0, 1, 1), (cin * 9, 1, 9))
     assert (g.kernel_family[(False, 2)] & 255) == 15, "plan: not conv_s2g_kernel"

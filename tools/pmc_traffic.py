@@ -54,9 +54,6 @@ def symbol(d):
     m = re.match(r"conv_s2d_kernel<(\w+), \d+, \d+, \w+>", d)
     if m:
         return f"conv_s2d_kernel<{m.group(1)}>"
-    m = re.match(r"conv_s2f_kernel<(\w+), \d+, \d+>", d)
-    if m:
-        return f"conv_s2f_kernel<{m.group(1)}>"
     m = re.match(r"conv_vox0_wgrad_kernel<(\w+), \d+, \d+>", d)
     if m:
         return f"conv_vox0_wgrad_kernel<{m.group(1)}>"

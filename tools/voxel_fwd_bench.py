@@ -23,10 +23,11 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--json", default="")
     ap.add_argument("--modes", default="f16,bf16")
+    ap.add_argument("--shapes", default="32x32,32x64,64x64", help="comma list of <voxel grid>x<batch>")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     rows, docs = [], {}
-    for V, B in ((32, 32), (32, 64), (64, 64)):
+    for V, B in [tuple(int(v) for v in sh.split("x")) for sh in a.shapes.split(",")]:
         batch = syn.batch_to_device(syn.make_batch(B, voxel_size=V, num_views=None, seed=syn.BASE_SEED + 2), dev)
         for mode in a.modes.split(","):
             args = types.SimpleNamespace(text="BiGRUEncoder", image=None, voxel="SparseCNNEncoder", voxel_size=V, num_views=6, image_size=128)

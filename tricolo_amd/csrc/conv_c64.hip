@@ -3,7 +3,7 @@
 //
 // conv_halo_rows_kernel keeps layer1's filter bank in LDS and every wave re-reads four weight fragments per k-step next to its two
 // activation fragments; at one wave per SIMD (372 registers) nothing covers the slab DMA pieces, the epilogue and the 7.4 k-cycle
-// prologue: a 128-position tile takes 5.4 k cycles for 2.3 k cycles of MFMA.  This kernel is the 2D twin of conv_vox1_kernel:
+// prologue: a 128-position tile takes 5.4 k cycles for 2.3 k cycles of MFMA.  This kernel is the 2D twin of round 3's conv_vox1_kernel (voxel level 1; dropped in round 6 for conv_voxb_kernel):
 //   * a persistent workgroup (two per CU) walks bricks of TY image rows x W columns = 8 runs of 16 pixels, stages a brick + one-pixel halo
 //     once in an LDS slab (128 B per pixel, 16-byte chunks XOR-swizzled by the pixel pair: conflict-free ds_read_b128 for all three kx);
 //   * wave (c, h) holds the A fragments of output channels 32 c .. 32 c + 31 for all 9 taps x 2 k-steps (36 fragments, 144 registers,
@@ -561,238 +561,5 @@ int tri_internal_s2d_launch(const TriC64Geom& g, int B, int H, const void* in, c
     TRI_S2D(32, 2)
 #undef TRI_S2D
     tri_set_error("conv(s2d): brick shape not instantiated");
-    return TRI_ERR_UNSUPPORTED;
-}
-
-// ------------------------------------------------------------------------------------------------------------------------------------
-// Forward of the same layer (64 -> 128 channels, 3x3 / 2 / pad 1: layer2's first conv): conv_dma_kernel ran it as 384 tiles of 128
-// positions that re-gather their input rows per tap (18 us, 400 TF at the bench shape, and worse beside the other towers' kernels).
-// conv_c64_kernel's scheme with stride-2 fragment addresses:
-//   * a persistent workgroup (two per CU) walks bricks of TY output rows = 2 TY + 1 input rows, staged once in LDS (128 B per pixel,
-//     the same swizzle: a run's 16 lanes read pixels 2 fr + kx - 1, again 8 distinct chunk positions per 8 lanes);
-//   * wave w holds the A fragments of output channels 32 w .. 32 w + 31 for all 9 taps x 2 k-steps (36 fragments, 144 registers, staged
-//     through LDS in two halves of 64 filter rows) and takes every run of 16 output pixels: 18 activation fragments feed 36 MFMAs;
-//   * BatchNorm sums of the values as stored stay in registers over all bricks (a wave owns its channels: no cross-wave sum), one record
-//     per workgroup.
-struct ConvS2fArgs {
-    const void* in;            // [N, 2 H, 2 W, 64] 16-bit
-    const void* w;             // packed operand rows [128][576] (k = tap * 64 + channel)
-    void* out;                 // [N, H, W, 128]
-    float* stats;              // [grid][2][128] or NULL
-    int N, H, nbricks;         // H = OUTPUT rows per image
-    unsigned in_bytes;
-};
-
-template <int W, int TY>
-struct S2fCfg {
-    static constexpr int XOFF = 2;                                             // pad pixels left of a slab row (input x = -1 sits at XOFF - 1)
-    static constexpr int RPR = W / 16;                                         // runs per output row
-    static constexpr int IW = 2 * W;                                           // input pixels per row
-    static constexpr int P = IW + 16;                                          // pixels per slab row (a multiple of 16)
-    static constexpr int PITCH = P * 128;
-    static constexpr int ROWS = 2 * TY + 1;
-    static constexpr int SLAB = ROWS * PITCH;
-    static constexpr int CPR = IW * 8;                                         // 16-byte chunks per input row
-    static constexpr int ITEMS = ROWS * CPR;
-    static constexpr int MAXC = (ITEMS + 255) / 256;
-    static constexpr int WROW = 9 * 64 * 2 + 16;
-    static constexpr size_t SMEM = (size_t)SLAB > (size_t)64 * WROW ? (size_t)SLAB : (size_t)64 * WROW;
-    static_assert(W % 16 == 0, "whole runs");
-    static_assert(2 * PITCH + 8192 < 65536, "fragment-read immediates");
-};
-
-template <typename AT, int W, int TY>
-__global__ __launch_bounds__(256, 2) void conv_s2f_kernel(const ConvS2fArgs p) {
-    typedef S2fCfg<W, TY> C;
-    typedef typename OpOf<AT>::E E;
-    typedef Mma<E> MM;
-    typedef typename MM::v8 v8;
-    constexpr int KPAD = 9 * 64;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), fr = lane & 15, fq = lane >> 4;
-    char* const slab = smem;
-    const int G = gridDim.x, wg = blockIdx.x;
-    const int bpi = p.H / TY;                                                  // bricks per image
-
-    // ---- filter bank: 64 filter rows at a time through LDS (coalesced loads); waves 0 / 1 own rows of the first half, 2 / 3 of the second
-    v8 wf[9][2][2];
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        constexpr int NCH = 64 * KPAD * 2 / 16;                                // 4,608 chunks
-        if (half) __syncthreads();
-#pragma unroll
-        for (int u = 0; u < NCH / 256; ++u) {
-            const int ch = t + u * 256, row = ch / 72, col = ch - row * 72;
-            *(uint4*)(slab + row * C::WROW + col * 16) = *(const uint4*)((const char*)p.w + ((size_t)(half * 64 + row) * KPAD) * 2 + col * 16);
-        }
-        __syncthreads();
-        if ((wave >> 1) == half) {
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) {
-                const char* wrow = slab + (32 * (wave & 1) + 16 * ct + fr) * C::WROW + fq * 16;
-#pragma unroll
-                for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) wf[tap][ks][ct] = *(const v8*)(wrow + (tap * 64 + ks * 32) * 2);
-            }
-        }
-    }
-    __syncthreads();                                                           // the slab takes the staging area over
-    // per-lane slab offsets for (kx, k-step): input pixel 2 fr + kx - 1 at slab pixel XOFF + that, chunk 4 ks + fq at its swizzled position
-    int lofs[3][2];
-#pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-        const int sx = C::XOFF + 2 * fr + kx - 1;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) lofs[kx][ks] = sx * 128 + (((4 * ks + fq) ^ ((sx >> 1) & 7)) << 4);
-    }
-    const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
-    f32x4 cs[2], cq[2];
-    cs[0] = cs[1] = cq[0] = cq[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // the zero pixel left of every slab row (input x = -1; written once: the fill never touches it)
-    for (int i = t; i < C::ROWS * 8; i += 256) {
-        const int row = i >> 3, q = i & 7;
-        *(uint4*)(slab + row * C::PITCH + (C::XOFF - 1) * 128 + q * 16) = make_uint4(0u, 0u, 0u, 0u);
-    }
-
-#pragma unroll 1
-    for (int j = wg; j < p.nbricks; j += G) {
-        const int n = j / bpi, y0 = (j - n * bpi) * TY;
-        __syncthreads();                                                       // every wave is done with the previous slab
-        {
-            uint4 pre[C::MAXC];
-            int dst[C::MAXC];
-#pragma unroll
-            for (int u = 0; u < C::MAXC; ++u) {
-                const int i = t + u * 256;
-                const int yy = i / C::CPR, cc = i % C::CPR;
-                const int sx = C::XOFF + (cc >> 3), q = cc & 7;
-                const int gy = 2 * y0 - 1 + yy;
-                const bool inside = i < C::ITEMS;
-                dst[u] = inside ? yy * C::PITCH + sx * 128 + ((q ^ ((sx >> 1) & 7)) << 4) : -1;
-                const bool ok = inside && gy >= 0;                             // (the row above the image: zeros; 2 H - 1 is the last one read)
-                const unsigned voff = ok ? (unsigned)(((n * 2 * p.H + gy) * C::IW) * 128 + cc * 16) : 0x80000000u;
-                pre[u] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(irs, voff, 0, 0));
-            }
-#pragma unroll
-            for (int u = 0; u < C::MAXC; ++u)
-                if (dst[u] >= 0) *(uint4*)(slab + dst[u]) = pre[u];
-        }
-        __syncthreads();
-
-#pragma unroll 1
-        for (int r = 0; r < TY * C::RPR; ++r) {
-            const int yl = r / C::RPR, xr = r % C::RPR;
-            const char* sb = slab + (2 * yl) * C::PITCH + xr * (32 * 128);     // a run spans 32 input pixels
-            f32x4 acc[2];
-            acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            typedef E e4 __attribute__((ext_vector_type(4)));
-            AT* const o = (AT*)p.out + (((size_t)(n * p.H + y0 + yl) * W) + xr * 16 + fr) * 128 + 32 * wave + fq * 4;
-            v8 bf[2][6];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) bf[0][i] = *(const v8*)(sb + lofs[i >> 1][i & 1]);
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                if (ky < 2) {
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) bf[(ky + 1) & 1][i] = *(const v8*)(sb + lofs[i >> 1][i & 1] + (ky + 1) * C::PITCH);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < 6; ++i) {
-                    acc[0] = MM::mma(wf[ky * 3 + (i >> 1)][i & 1][0], bf[ky & 1][i], acc[0]);
-                    acc[1] = MM::mma(wf[ky * 3 + (i >> 1)][i & 1][1], bf[ky & 1][i], acc[1]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) {
-                const e4 hh = __builtin_convertvector(acc[ct], e4);
-                *(e4*)(o + 16 * ct) = hh;
-                const f32x4 rv = {(float)hh[0], (float)hh[1], (float)hh[2], (float)hh[3]};
-                cs[ct] += rv;
-                cq[ct] += rv * rv;
-            }
-        }
-    }
-
-    if (p.stats) {                                                             // one record per workgroup; channel 32 wave + 16 ct + 4 fq + r
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float s_ = cs[ct][r], q_ = cq[ct][r];
-                s_ += c64_row_ror<8>(s_); q_ += c64_row_ror<8>(q_);
-                s_ += c64_row_ror<4>(s_); q_ += c64_row_ror<4>(q_);
-                s_ += c64_row_ror<2>(s_); q_ += c64_row_ror<2>(q_);
-                s_ += c64_row_ror<1>(s_); q_ += c64_row_ror<1>(q_);
-                if (fr == 0) {
-                    const int ch = 32 * wave + 16 * ct + 4 * fq + r;
-                    p.stats[(size_t)blockIdx.x * 256 + ch] = s_;
-                    p.stats[(size_t)blockIdx.x * 256 + 128 + ch] = q_;
-                }
-            }
-    }
-}
-
-// OPT-IN (TRICOLO_S2F_CONV=1): 18.0 -> 17.0 us in isolation (436 TF: five input rows of 32 pixels are staged per two output rows, and every
-// workgroup stages the 147 KB filter bank), but the step is 25 us SLOWER with it in five of five A/B pairs (2.849 against 2.823 ms mean) -
-// the tests keep it covered (tests/conftest.py switches it on).
-static bool s2f_disabled() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("TRICOLO_S2F_CONV"); v = (e && e[0] == '1') ? 0 : 1; }
-    return v == 1;
-}
-
-bool tri_internal_s2f_geometry(int B, int ID, int IH, int IW, int cin, int OD, int OH, int OW, int cout, int KD, int KH, int KW, int stride,
-                               int pd, int ph, int pw, TriC64Geom* g) {
-    if (s2f_disabled()) return false;
-    if (ID != 1 || OD != 1 || KD != 1 || KH != 3 || KW != 3 || stride != 2 || pd != 0 || ph != 1 || pw != 1) return false;
-    if (cin != 64 || cout != 128 || IH != 2 * OH || IW != 2 * OW) return false;
-    if (OW != 16 && OW != 32) return false;
-    if ((long)B * IH * IW * 128 >= (1L << 31) || (long)B * OH * OW * 256 >= (1L << 31)) return false;
-    const int slots = 2 * tri_internal_num_cus();
-    int ty = OW == 16 ? 4 : 2;
-    while (ty > 1 && (OH % ty || (long)B * (OH / ty) < 3L * slots)) ty /= 2;   // >= 3 bricks per persistent workgroup where the batch allows
-    if (ty == 1 && OW == 32) ty = 1;
-    if (ty == 1 && OW == 16) ty = 2;
-    if (const char* e = getenv("TRICOLO_S2F_TY")) {                            // tests: the taller bricks without a batch of hundreds
-        const int v = atoi(e);
-        if ((v == 1 && OW == 32) || v == 2 || (v == 4 && OW == 16)) if (OH % v == 0) ty = v;
-    }
-    if (OH % ty) return false;
-    g->W = OW; g->TY = ty;
-    g->nbricks = B * (OH / ty);
-    g->grid = g->nbricks < slots ? g->nbricks : slots;
-    return true;
-}
-
-template <typename AT, int W, int TY>
-static int s2f_launch_t(const ConvS2fArgs& a, int grid, hipStream_t stream) {
-    typedef S2fCfg<W, TY> C;
-    static bool attr = false;
-    if (!attr) {
-        hipFuncSetAttribute((const void*)conv_s2f_kernel<AT, W, TY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::SMEM);
-        attr = true;
-    }
-    conv_s2f_kernel<AT, W, TY><<<grid, 256, C::SMEM, stream>>>(a);
-    return tri_check_launch("tri_conv(s2f)");
-}
-
-int tri_internal_s2f_launch(const TriC64Geom& g, int B, int OH, const void* in, const void* w, void* out, float* stats, int act_fmt,
-                            hipStream_t stream) {
-    ConvS2fArgs a{};
-    a.in = in; a.w = w; a.out = out; a.stats = stats;
-    a.N = B; a.H = OH; a.nbricks = g.nbricks;
-    a.in_bytes = (unsigned)((size_t)B * 2 * OH * 2 * g.W * 128);
-#define TRI_S2F(W_, TY_)                                                                                                   \
-    if (g.W == W_ && g.TY == TY_)                                                                                          \
-        return act_fmt == TRI_FMT_F16 ? s2f_launch_t<f16_t, W_, TY_>(a, g.grid, stream) : s2f_launch_t<bf16_t, W_, TY_>(a, g.grid, stream);
-    TRI_S2F(16, 4)
-    TRI_S2F(16, 2)
-    TRI_S2F(32, 2)
-    TRI_S2F(32, 1)
-#undef TRI_S2F
-    tri_set_error("conv(s2f): brick shape not instantiated");
     return TRI_ERR_UNSUPPORTED;
 }

@@ -37,6 +37,7 @@ struct ConvArgs {
     int h_tr, h_rows, h_slab_bytes, h_nr, h_mtiles;    // halo kernel: image rows per tile, slab rows, slab bytes, ring slots, row tiles
     int h_dbuf;
     int h_abl;                                          // tuning aid (TRICOLO_HALO_ABL): ablation bits, 0 in production
+    int h_xcg, h_touch;                                 // conv_halo_rows_kernel: channel tiles per XCD block (0: linear tile order); L2 warm-up of the weights
 #ifdef HALO_STAMPS
     long long* h_dbg;                                   // tools/probes/halo_probe.hip: per-workgroup (id, cycle) stamps of wave 0
 #endif
@@ -1019,8 +1020,18 @@ __global__ __launch_bounds__(PROD ? 512 : 256, 1) void conv_halo_rows_kernel(con
     const unsigned lds_slab0 = lds_addr(smem), lds_ring0 = lds_addr(ring);
     const unsigned dma_slab = lds_slab0 + wave * 1024, dma_ring = lds_ring0 + wave * 1024;
     const int whole = (TR % H == 0) ? 1 : 0;
-    if ((int)blockIdx.x >= items) return;
-    const int n_my = (items - (int)blockIdx.x + G - 1) / G;             // tiles of this workgroup: items blockIdx.x + k G (one output-channel tile)
+    // XCD-aware tile order (round 6, launches with one tile per workgroup and h_xcg set by the host): hardware workgroup b runs on XCD b % 8,
+    // and in linear order the NT channel tiles of a row tile land on NT different XCDs - every XCD streamed a quarter of layer3's rows through
+    // its L2 for ONE channel tile (PMC: 27.9 MB fetched for 7.5 MB of operands), every XCD all of layer4's rows.  Here XCD x owns a block of
+    // (h_xcg channel tiles) x (row tiles): cg = NT for layer3 (rows fetched once, the 1.2 MB of weights by every XCD), 2 for layer4.
+    int bid = blockIdx.x;
+    if (p.h_xcg) {
+        const int cg = p.h_xcg, x = bid & 7, s = bid >> 3, ngrp = NT / cg;
+        const int cgi = x % ngrp, rgi = x / ngrp;
+        bid = (rgi * ((G >> 3) / cg) + s / cg) * NT + cgi * cg + s % cg;
+    }
+    if (bid >= items) return;
+    const int n_my = (items - bid + G - 1) / G;             // tiles of this workgroup: items bid + k G (one output-channel tile)
     const bool w_once = !STREAM && nchunks == 1;                        // resident filter bank
 
     int woff[2];
@@ -1030,7 +1041,7 @@ __global__ __launch_bounds__(PROD ? 512 : 256, 1) void conv_halo_rows_kernel(con
         woff[r] = (n * p.Kpad + (((lane & 7) ^ ((n >> 1) & 7)) << 3)) * 2;
     }
     // ---- weights: kernel row ky of a chunk goes to ring slot ky; six 1 KiB pieces per wave and row
-    const int w_nb = (blockIdx.x % NT) * BN * p.Kpad;
+    const int w_nb = (bid % NT) * BN * p.Kpad;
     auto w_row_pieces = [&](int chunk, int ky, int j0, int j1) {
         // the data gradient is the same correlation with the taps taken in reverse order (tap' = 8 - tap)
         const int tap0 = p.transposed ? 8 - ky * 3 : ky * 3, tstep = p.transposed ? -1 : 1;
@@ -1068,6 +1079,19 @@ __global__ __launch_bounds__(PROD ? 512 : 256, 1) void conv_halo_rows_kernel(con
         }
     }
 
+    // L2 warm-up (round 6): in the training step every launch finds its weights cold (packed at the start of the step, megabytes of
+    // activations ago) and the ring runs one kernel row ahead - far less than a trip to HBM.  The workgroups of an XCD share the weight rows
+    // of the XCD's channel tiles: each touches its 1 / n of them (one dword per 128-byte line and lane, right behind the first pieces), so
+    // the XCD's L2 holds the whole slice by the time the prologue (~3 us) is over.  Waited for with the first pieces (vmcnt(0) below).
+    int touch0 = 0, touch1 = 0;
+    if (p.h_xcg > 0 && p.h_touch && (!PROD || producer)) {
+        const int cg = p.h_xcg, n = G >> 3, s = (int)blockIdx.x >> 3;
+        const int lines = cg * BN * p.Kpad / 64, per = (lines + n - 1) / n;      // 128-byte lines of the XCD's cg channel tiles; this workgroup's share
+        const int l0 = (bid % NT / cg * cg) * BN * p.Kpad / 64 + s * per;
+        if (t < per) touch0 = touch_line(w_rsrc, (l0 + t) * 128);
+        if (t + 256 < per) touch1 = touch_line(w_rsrc, (l0 + t + 256) * 128);
+    }
+
     // ---- geometry-only lane constants (as conv_halo2d_kernel) ----------------------------------------------------------
     int soff[HALO_MAX_ROUNDS];
     unsigned stop = 0, sbot = 0;
@@ -1098,7 +1122,7 @@ __global__ __launch_bounds__(PROD ? 512 : 256, 1) void conv_halo_rows_kernel(con
     unsigned s_kill = 0;
     auto grp_n = [&](int g) { return min(NTLE, n_my - g); };
     auto slab_setup = [&]() {                                           // source constants of the element the cursor points at
-        const int item_ = (int)blockIdx.x + (s_g + s_tl) * G;
+        const int item_ = bid + (s_g + s_tl) * G;
         const int g0_ = (item_ / NT) * TR;
         int top_ok = 1, bot_ok = 1;
         if (!whole) {
@@ -1144,6 +1168,7 @@ __global__ __launch_bounds__(PROD ? 512 : 256, 1) void conv_halo_rows_kernel(con
     if (PROD && producer) {
         // ---- producer waves: the DMA side of the row schedule below, one barrier per kernel row -----------------------------------
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("" :: "v"(touch0), "v"(touch1));                   // (the warm-up loads' destination registers are free from here)
         __builtin_amdgcn_s_barrier();                                   // (the consumers' prologue barrier)
         asm volatile("" ::: "memory");
         int c_g = 0, c_chunk = 0;
@@ -1210,7 +1235,7 @@ __global__ __launch_bounds__(PROD ? 512 : 256, 1) void conv_halo_rows_kernel(con
             }
         }
     };
-    set_rows(blockIdx.x);
+    set_rows(bid);
 
     // ---- fragments: three register sets, set of k-step t = t % 3 (six k-steps per kernel row) -----------------------------
     v4i fa[3][TM], fb[3][TN];
@@ -1326,10 +1351,10 @@ __global__ __launch_bounds__(PROD ? 512 : 256, 1) void conv_halo_rows_kernel(con
     // element TL of the group: three kernel rows, then (after the last chunk) the tile's epilogue
 #define HR_ELEM(TL)                                                                                                   \
     if ((TL) < NTLE && (TL) < ng) {                                                                                    \
-        const int c_item = (int)blockIdx.x + (c_g + (TL)) * G;                                                         \
+        const int c_item = bid + (c_g + (TL)) * G;                                                         \
         /* the element after this one (its first fragments are read in kernel row 2): next tile of the group, else next (chunk, group) */ \
         int n_item = c_item + G;                                                                                       \
-        if ((TL) + 1 >= ng) n_item = (int)blockIdx.x + (last_chunk ? c_g + NTLE : c_g) * G;                            \
+        if ((TL) + 1 >= ng) n_item = bid + (last_chunk ? c_g + NTLE : c_g) * G;                            \
         if (n_item >= items) n_item = c_item;                                                                          \
         const unsigned sb = c_sbuf * slab_bytes, sbn = (c_sbuf ^ 1) * slab_bytes;                                      \
         HR_ROW(TL, 0, 1, sb)                                                                                            \
@@ -1412,6 +1437,7 @@ __global__ __launch_bounds__(PROD ? 512 : 256, 1) void conv_halo_rows_kernel(con
     HSTAMP(2);
     // ---- prologue: the first slab and weights have been issued; fragments of k-steps 0 and 1 --------------------------------
     if constexpr (!PROD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (!PROD) asm volatile("" :: "v"(touch0), "v"(touch1));
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     HR_FIRST_READS(0u)
@@ -1456,7 +1482,7 @@ __global__ __launch_bounds__(PROD ? 512 : 256, 1) void conv_halo_rows_kernel(con
         }
     }
     __syncthreads();                                                    // the staging tiles alias `red`, which the statistics use next
-    if (p.stats) halo_store_stats<TN, BN>(cs, cq, red, p.stats, p.Cout, blockIdx.x / NT, blockIdx.x % NT, wave, fr, fq, t, false);
+    if (p.stats) halo_store_stats<TN, BN>(cs, cq, red, p.stats, p.Cout, bid / NT, bid % NT, wave, fr, fq, t, false);
     HSTAMP(11);
 #ifdef HALO_STAMPS
     if (wave == 0) {
@@ -1938,15 +1964,12 @@ struct ConvPlan {
     int stem_grid;
     int vox0;             // 1: conv_vox0_kernel (conv_vox.hip: level 0 of the voxel tower, 16-bit storage); records = vox0_grid
     int vox0_grid;
-    int vox1;             // 1: conv_vox1_kernel (level 1 of the voxel tower, 32 -> 64 channels, 16-bit storage); records = vox1_grid
-    int vox1_grid;
     int voxb, voxb_grid;  // 1: conv_voxb_kernel (conv_voxg.hip: level 1 of the voxel tower, ranked active rows over bricks); records = voxb_grid
     int s2g, s2g_units;   // 1: conv_s2g_kernel (conv_s2g.hip: forward of the 3x3 / 2 layers that open layer3 / layer4, 16-bit storage); records = s2g_units
     int voxg;             // 1: conv_voxg_kernel (conv_voxg.hip: SubMConv3d on 2^3 / 4^3 / 8^3 grids, forward and data gradient, 16-bit storage);
     int voxg_units, voxg_ct, voxg_spu;        // records = units
     int c64;              // 1: conv_c64_kernel (conv_c64.hip: 64 -> 64 channels, 2D 3x3 / 1 / pad 1, 16-bit storage); records = c64_grid
     int c64_grid;
-    int s2f, s2f_grid;    // 1: conv_s2f_kernel (conv_c64.hip: forward of the 64 -> 128 channel 3x3 / 2 layer); records = s2f_grid
     int s2d;              // 1: conv_s2d_kernel (conv_c64.hip: data gradient of a 64 -> 128 channel 3x3 / 2 layer, 16-bit storage)
     int pw, pw_tr;        // 1: conv_pw_kernel (conv_pw.hip: 1x1 / 2 shortcut convolution), pw_tr: the plan is the data gradient's; records = row tiles
     int dma;              // 1: LDS-DMA kernel (16-bit activation storage, Cin % 64 == 0), 64-wide k-steps
@@ -2108,11 +2131,6 @@ static ConvPlan conv_make_plan(int B, int ID, int IH, int IW, int cin, int OD, i
             pl.voxb = 1; pl.voxb_grid = vb.grid; pl.bn = 64; pl.nunits = 27; pl.ksplit = 1; pl.per_split = 27;
             return pl;
         }
-        TriVox1Geom v1;
-        if (split_mode == 2 && tri_internal_vox1_geometry(B, ID, IH, IW, cin, OD, OH, OW, cout, KD, KH, KW, stride, pd, ph, pw, &v1)) {
-            pl.vox1 = 1; pl.vox1_grid = v1.grid; pl.bn = 64; pl.nunits = 27; pl.ksplit = 1; pl.per_split = 27;
-            return pl;
-        }
         TriVoxgGeom vgg;
         if (split_mode == 2 && tri_internal_voxg_geometry(B, ID, IH, IW, cin, OD, OH, OW, cout, KD, KH, KW, stride, pd, ph, pw, &vgg)) {
             // coarse voxel grids: activations stationary in LDS, weights straight into MFMA registers (forward and data gradient;
@@ -2150,9 +2168,11 @@ static ConvPlan conv_make_plan(int B, int ID, int IH, int IW, int cin, int OD, i
     }
     {
         TriS2gGeom g2;
-        if (pl.dma && split_mode == 2 && !row_list && tri_internal_s2g_geometry(B, ID, IH, IW, cin, OD, OH, OW, cout, KD, KH, KW, stride, pd, ph, pw, &g2)) {
+        if (pl.dma && split_mode == 2 && tri_internal_s2g_geometry(B, ID, IH, IW, cin, OD, OH, OW, cout, KD, KH, KW, stride, pd, ph, pw, &g2)) {
             // 3x3 / 2 layers with >= 128 input channels: conv_s2g_kernel (space-to-depth slab, weights straight into MFMA registers); a call with a
-            // row mask / list / bias / activation / accumulate is refused (the layer's operand is packed fragment-major)
+            // row mask / list / bias / activation / accumulate is refused (the layer's operand is packed fragment-major).  Planned whether or
+            // not the call carries a row list: the family query packs the operand without knowing, so a row-list call must reach
+            // conv_dispatch's refusal instead of reading the fragment-major operand row-major in conv_dma_kernel
             pl.s2g = 1; pl.s2g_units = g2.nunits; pl.bn = 64; pl.nunits = kpad / 32; pl.ksplit = 1; pl.per_split = pl.nunits;
             return pl;
         }
@@ -2162,9 +2182,6 @@ static ConvPlan conv_make_plan(int B, int ID, int IH, int IW, int cin, int OD, i
         // GEMM view of a data-gradient call (the output grid is twice the input grid: no forward layer looks like this)
         if (pl.dma && split_mode == 2 && tri_internal_s2d_geometry(B, ID, IH, IW, cin, OD, OH, OW, cout, KD, KH, KW, stride, pd, ph, pw, &sg))
             pl.s2d = 1;                                                        // (a call with a row mask / list takes conv_dma_kernel: its plan below)
-        if (pl.dma && split_mode == 2 && !row_list && tri_internal_s2f_geometry(B, ID, IH, IW, cin, OD, OH, OW, cout, KD, KH, KW, stride, pd, ph, pw, &sg)) {
-            pl.s2f = 1; pl.s2f_grid = sg.grid;                                 // (likewise; a call that wants statistics must qualify)
-        }
     }
     if (pl.dma && cout % 64 == 0 && !halo_disabled() && KD == 1 && KH == 3 && KW == 3 && stride == 1 && pd == 0 && ph == 1 && pw == 1 && ID == 1 && OD == 1 &&
         IH == OH && IW == OW && (long)B * IH * IW * cin * 2 < ((long)1 << 31)) {
@@ -2280,7 +2297,26 @@ static int launch_halo(ConvArgs& a, const ConvPlan& pl, hipStream_t stream) {
 #else
     const size_t smem = (size_t)pl.h_slab_bytes + (size_t)HALO_NR * 8192 + 2048;
 #endif
+    a.h_xcg = 0; a.h_touch = 0;
     if (pl.h_v5) {
+        // XCD blocks + L2 warm-up of the weights (one tile per workgroup, a whole number of workgroups per XCD): the channel-group width cg that
+        // moves the fewest bytes into the eight L2s - weights x (row groups = 8 cg / NT) + input rows x (channel groups = NT / cg)
+        // (TRICOLO_HALO_XCG=0 keeps the linear tile order, TRICOLO_HALO_TOUCH=0 the cold start: A/B partners)
+        static int xcg_on = -1, touch_on = -1;
+        if (xcg_on < 0) { const char* e = getenv("TRICOLO_HALO_XCG"); xcg_on = e ? atoi(e) : -1; if (xcg_on < 0) xcg_on = 99; }
+        if (touch_on < 0) { const char* e = getenv("TRICOLO_HALO_TOUCH"); touch_on = (e && e[0] == '0') ? 0 : 1; }
+        const int NT = a.Cout / 64, G = pl.h_grid;
+        if (xcg_on && G == pl.h_mtiles * NT && G % 8 == 0 && a.Cin != 64) {
+            const double wb = (double)a.Cout * a.Kpad * 2, ib = (double)a.M * a.Cin * 2;
+            double best = 0;
+            for (int cg = 1; cg <= NT; ++cg) {
+                if (NT % cg || 8 % (NT / cg) || (G / 8) % cg) continue;
+                if (xcg_on != 99 && cg != xcg_on) continue;
+                const double bytes = wb * (8.0 * cg / NT) + ib * (NT / cg);
+                if (!a.h_xcg || bytes < best) { a.h_xcg = cg; best = bytes; }
+            }
+            a.h_touch = a.h_xcg ? touch_on : 0;
+        }
 #ifdef HALO_STAMPS
         a.h_dbg = g_halo_dbg;
         const size_t extra = 2048;
@@ -2461,16 +2497,6 @@ static int conv_dispatch(ConvArgs& a, int act_fmt, void* workspace, size_t works
         tri_internal_voxb_geometry(a.B, a.ID, a.IH, a.IW, a.Cin, a.OD, a.OH, a.OW, a.Cout, a.KD, a.KH, a.KW, a.stride, a.pd, a.ph, a.pw, &vb);
         return tri_internal_voxb_launch(vb, a.B, a.in, a.w_hi, a.out, a.row_mask, a.stats, act_fmt, stream);
     }
-    if (pl.vox1 && !a.transposed) {
-        if (a.row_count || a.bias || a.act != 0 || a.accumulate) {
-            tri_set_error("conv: this layer runs the brick kernel (tri_conv_kernel_family == 7): pass the site mask as row_mask, no row list, "
-                          "bias, activation or accumulate");
-            return TRI_ERR_ARG;
-        }
-        TriVox1Geom v1;
-        tri_internal_vox1_geometry(a.B, a.ID, a.IH, a.IW, a.Cin, a.OD, a.OH, a.OW, a.Cout, a.KD, a.KH, a.KW, a.stride, a.pd, a.ph, a.pw, &v1);
-        return tri_internal_vox1_launch(v1, a.B, a.in, a.w_hi, a.out, a.row_mask, a.stats, act_fmt, stream);
-    }
     if (pl.voxg) {
         if (a.row_count || a.bias || a.act != 0 || a.accumulate) {
             tri_set_error("conv: this layer runs conv_voxg_kernel (tri_conv_kernel_family == 13): pass the site mask as row_mask, no row list, "
@@ -2502,17 +2528,6 @@ static int conv_dispatch(ConvArgs& a, int act_fmt, void* workspace, size_t works
         TriS2gGeom g2;
         tri_internal_s2g_geometry(a.B, a.ID, a.IH, a.IW, a.Cin, a.OD, a.OH, a.OW, a.Cout, a.KD, a.KH, a.KW, a.stride, a.pd, a.ph, a.pw, &g2);
         return tri_internal_s2g_launch(g2, a.B, a.IH, a.IW, a.Cin, a.Cout, a.Kpad, a.in, a.w_hi, a.out, a.stats, act_fmt, stream);
-    }
-    if (pl.s2f && !a.transposed) {
-        if (!a.row_mask && !a.row_count && !a.bias && a.act == 0 && !a.accumulate) {
-            TriC64Geom sg;
-            tri_internal_s2f_geometry(a.B, a.ID, a.IH, a.IW, a.Cin, a.OD, a.OH, a.OW, a.Cout, a.KD, a.KH, a.KW, a.stride, a.pd, a.ph, a.pw, &sg);
-            return tri_internal_s2f_launch(sg, a.B, a.OH, a.in, a.w_hi, a.out, a.stats, act_fmt, stream);
-        }
-        if (a.stats) {                                                // (the record count of this layer is conv_s2f_kernel's)
-            tri_set_error("conv: this layer runs conv_s2f_kernel (tri_conv_kernel_family == 11): statistics only without row mask / bias / activation / accumulate");
-            return TRI_ERR_ARG;
-        }
     }
     if (pl.s2d && a.transposed && !bs && !a.row_mask && !a.row_count && !a.bias && a.act == 0 && !a.stats) {
         TriC64Geom sg;
@@ -2559,10 +2574,8 @@ extern "C" int tri_conv_num_records(const TriConvDesc* d, int split3, int row_li
     if (pl.stem) return pl.stem_grid;
     if (pl.vox0) return pl.vox0_grid;
     if (pl.voxb) return pl.voxb_grid;
-    if (pl.vox1) return pl.vox1_grid;
     if (pl.voxg) return pl.voxg_units;
     if (pl.c64) return pl.c64_grid;
-    if (pl.s2f) return pl.s2f_grid;
     if (pl.s2g) return pl.s2g_units;
     if (pl.halo) return pl.h_wgrec ? pl.h_grid / (d->Cout / 64) : pl.h_mtiles;
     return pl.ksplit > 1 ? (int)((M + 31) / 32) : (int)((M + 127) / 128);
@@ -2578,11 +2591,9 @@ extern "C" int tri_conv_kernel_family(const TriConvDesc* d, int transposed, int 
     if (pl.stem && !transposed) return 4 | (64 << 8);
     if (pl.vox0 && !transposed) return 6 | (32 << 8);
     if (pl.voxb && !transposed) return 14 | (64 << 8);
-    if (pl.vox1 && !transposed) return 7 | (64 << 8);
     if (pl.voxg) return 13 | (pl.voxg_ct << 8) | (pl.voxg_spu << 24);      // (bits 24..: samples per unit)
     if (pl.c64) return 9 | (64 << 8);
     if (pl.s2d && transposed) return 10 | (64 << 8);
-    if (pl.s2f && !transposed) return 11 | (128 << 8);
     if (pl.s2g && !transposed) return 15 | (64 << 8);
     if (pl.halo) return (pl.h_v5 ? 5 : 3) | (pl.halo << 8);
     if (pl.pw) return 12 | (pl.bn << 8);

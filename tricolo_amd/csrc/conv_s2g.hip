@@ -318,20 +318,18 @@ bool tri_internal_s2g_geometry(int B, int ID, int IH, int IW, int cin, int OD, i
     const int cus = tri_internal_num_cus(), nct = cout / 64;
     if (nct >= 8 ? nct % 8 : 8 % nct) return false;
     // Measured at the bench shape (profiles/r5/NOTES_voxel.md): layer4's opening layer (8x8 maps, units of 6 images = 96 rows) 27 -> 20 us against
-    // conv_dma_kernel; layer3's (16x16 maps, units of 3 images = 192 rows, the 12-fragment variant) 25 against 21 us - a chunk's MFMAs (0.8 us) are
-    // shorter than the latency of the next chunk's slab pieces, which one chunk of look-ahead cannot hide.  The plan therefore takes maps of
-    // at most 16 output positions and units of at most 96 rows (TRICOLO_S2G_ALL=1: every shape the kernel can run - tests, experiments).
-    static int all = -1;
-    if (all < 0) { const char* e = getenv("TRICOLO_S2G_ALL"); all = (e && e[0] == '1') ? 1 : 0; }
-    if (!all && opi > 16) return false;
-    // images per unit: up to 96 rows (192 with TRICOLO_S2G_ALL), halved while the launch would leave CUs without a workgroup
-    int ipu = (all ? 192 : 96) / opi;
+    // conv_dma_kernel; layer3's (16x16 maps, units of 3 images = 192 rows, a 12-fragment variant of this kernel) 25 against 21 us - a chunk's
+    // MFMAs (0.8 us) are shorter than the latency of the next chunk's slab pieces, which one chunk of look-ahead cannot hide.  The plan therefore
+    // takes maps of at most 16 output positions and units of at most 96 rows; the 12-fragment instantiation was dropped in round 6.
+    if (opi > 16) return false;
+    // images per unit: up to 96 rows, halved while the launch would leave CUs without a workgroup
+    int ipu = 96 / opi;
     if (ipu < 1) return false;
     if (ipu > B) ipu = B;
     while (ipu > 1 && (long)((B + ipu - 1) / ipu) * nct < cus) ipu = (ipu + 1) / 2;
     const int PW = OW + 1, PS = (OH + 1) * PW;
     const int NSP = (ipu * PS + 31) / 32 * 32;
-    g->ipu = ipu; g->nunits = (B + ipu - 1) / ipu; g->nrt = ipu * opi <= 96 ? 6 : 12;
+    g->ipu = ipu; g->nunits = (B + ipu - 1) / ipu; g->nrt = 6;
     g->PW = PW; g->PS = PS; g->NSP = NSP; g->HB = NSP * 32 + 128;          // (+128: the two halves of a site - lanes fq 0,1 / 2,3 of a fragment read - land on different banks)
     g->grid = nct >= 8 ? g->nunits * nct : 8 * ((g->nunits + 8 / nct - 1) / (8 / nct));
     size_t smem = (size_t)2 * 8 * g->HB;
@@ -360,6 +358,5 @@ int tri_internal_s2g_launch(const TriS2gGeom& g, int B, int IH, int IW, int cin,
     a.ipu = g.ipu; a.nunits = g.nunits; a.PW = g.PW; a.PS = g.PS; a.NSP = g.NSP; a.HB = g.HB;
     a.in_bytes = (unsigned)((size_t)B * IH * IW * cin * 2);
     a.w_bytes = (unsigned)((size_t)cout * kpad * 2);
-    if (g.nrt == 6) return act_fmt == TRI_FMT_F16 ? s2g_launch_t<f16_t, 6>(a, g, stream) : s2g_launch_t<bf16_t, 6>(a, g, stream);
-    return act_fmt == TRI_FMT_F16 ? s2g_launch_t<f16_t, 12>(a, g, stream) : s2g_launch_t<bf16_t, 12>(a, g, stream);
+    return act_fmt == TRI_FMT_F16 ? s2g_launch_t<f16_t, 6>(a, g, stream) : s2g_launch_t<bf16_t, 6>(a, g, stream);
 }

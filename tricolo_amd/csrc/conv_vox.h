@@ -17,14 +17,6 @@ int tri_internal_vox0_wgrad_grid(const TriVox0Geom& g);
 int tri_internal_vox0_wgrad_launch(const TriVox0Geom& g, int grid, int B, const void* in, const void* dout, const uint8_t* mask, float* slab,
                                    int act_fmt, hipStream_t stream);
 
-struct TriVox1Geom { int V, TY, nbricks, grid; };
-// level 1 of the voxel tower in a 16-bit storage mode (32 -> 64 channels, 3x3x3 / 1 / pad 1 on a 16^3 or 32^3 grid); g->grid = persistent
-// workgroups = BatchNorm records of the launch
-bool tri_internal_vox1_geometry(int B, int ID, int IH, int IW, int cin, int OD, int OH, int OW, int cout, int KD, int KH, int KW, int stride,
-                                int pd, int ph, int pw, TriVox1Geom* g);
-int tri_internal_vox1_launch(const TriVox1Geom& g, int B, const void* in, const void* w, void* out, const uint8_t* mask, float* stats, int act_fmt,
-                             hipStream_t stream);
-
 // the SubMConv3d layers on the coarse grids (2^3 / 4^3 / 8^3 sites per sample, 64 | cin, 16 | cout, 16-bit storage): conv_voxg_kernel
 // (conv_voxg.hip), forward and data gradient over the SITE MASK; spu samples per unit, nunits units = BatchNorm records, ct output
 // channels per workgroup
@@ -60,12 +52,6 @@ bool tri_internal_c64_geometry(int B, int ID, int IH, int IW, int cin, int OD, i
 bool tri_internal_s2d_geometry(int B, int ID, int IH, int IW, int cin, int OD, int OH, int OW, int cout, int KD, int KH, int KW, int stride,
                                int pd, int ph, int pw, TriC64Geom* g);
 int tri_internal_s2d_launch(const TriC64Geom& g, int B, int H, const void* in, const void* w, void* out, int accumulate, int act_fmt,
-                            hipStream_t stream);
-// forward of the same layer (64 -> 128 channels, 3x3 / 2 / pad 1, output rows of 16 / 32 pixels): conv_s2f_kernel (conv_c64.hip);
-// g->grid = persistent workgroups = BatchNorm records of the launch
-bool tri_internal_s2f_geometry(int B, int ID, int IH, int IW, int cin, int OD, int OH, int OW, int cout, int KD, int KH, int KW, int stride,
-                               int pd, int ph, int pw, TriC64Geom* g);
-int tri_internal_s2f_launch(const TriC64Geom& g, int B, int OH, const void* in, const void* w, void* out, float* stats, int act_fmt,
                             hipStream_t stream);
 struct TriConvBnSums;                                                         // include/tricolo_hip.h
 int tri_internal_c64_launch(const TriC64Geom& g, int B, int H, const void* in, const void* w, void* out, float* stats, int transposed,

@@ -472,196 +472,6 @@ __global__ __launch_bounds__(256, 3) void conv_vox0_wgrad_kernel(const Vox0Wgrad
     }
 }
 
-// ================================================================================================ level 1: 32 -> 64 channels
-// conv_vox1_kernel.  Level 1 through conv_igemm_kernel is a chain of exposed gather latencies (27 k-steps of one tap each, one
-// in flight): 23 us for 171 tiles at the bench shape, 93 us at 64^3 x 64.  Here the filter bank is STATIONARY IN REGISTERS: wave
-// w of a persistent workgroup holds the A fragments of output channels 16 w .. 16 w + 15 for all 27 taps (108 registers, loaded
-// once per workgroup), the workgroup walks its share of the grid's bricks (2 z-planes x TY rows x all columns = 16 runs of 16
-// sites), stages a brick + halo once in an LDS slab (64 B per site) and every wave forms the 27 taps of every active run from it:
-// one ds_read_b128 + one MFMA per tap and run, no address arithmetic (per-lane offset for kw = 0, 1, 2, immediates for kd, kh).
-//   * slab layout: site s of a row at byte s * 64, its 16-byte chunk q (8 channels) at position q ^ (2 * bit 2 of s).  For ANY 16
-//     consecutive sites the 16 lanes that one LDS cycle of a ds_read_b128 serves (k-groups a, a + 1 over four site quads) then hit
-//     16 distinct 16-byte bank slots - conflict-free for all three kw shifts (derivation in DESIGN.md section 5);
-//   * workgroup w takes bricks w, w + G, ... (order rotated by the sample number, see conv_vox0_kernel): their masks are fetched with
-//     one load per thread at the start, an empty brick then costs a 16-lane LDS read.  (Handing bricks out dynamically - an atomic
-//     counter + a memset node per launch - was measured and is slower at both sizes: 22.9 against 15.5 us at 32^3 x 32, 103 against
-//     119 us at 64^3 x 64, where conv_igemm_kernel takes 93: the kernel is planned for 16^3 level-1 grids only, i.e. 32^3 inputs);
-//   * two workgroups per CU (63 KB of LDS, < 256 registers): one fills its slab while the other one multiplies;
-//   * a lane ends up with 4 consecutive channels of a site (8-byte stores, 32-byte segments per wave, full 128-byte rows per
-//     workgroup); BatchNorm sums in registers across all bricks: one record per workgroup.
-struct Vox1Args {
-    const void* in;            // [B, V1, V1, V1, 32] 16-bit, zeros at inactive sites
-    const void* w;             // packed operand rows [64][864] (k = tap * 32 + channel)
-    void* out;                 // [B, V1, V1, V1, 64]; rows of inactive sites are not written
-    const uint8_t* mask;       // [B * V1^3] site mask, or NULL
-    float* stats;              // [grid][2][64] or NULL
-    int B, nbricks;
-    unsigned in_bytes;
-};
-
-template <int V1, int TY>
-struct Vox1Cfg {
-    static constexpr int XOFF = 4;                                             // zero / pad sites left of a row (multiple of 4)
-    static constexpr int PITCH = (V1 + 8) * 64;
-    static constexpr int PLANE = (TY + 2) * PITCH;
-    static constexpr int SLAB = 4 * PLANE;
-    static constexpr int RPR = V1 / 16;
-    static constexpr int HALF = TY * RPR;                                      // runs per z-plane of a brick
-    static constexpr int RUNS = 2 * HALF;
-    static constexpr int NYB = V1 / TY;
-    static constexpr int PS = (V1 / 2) * NYB;                                  // bricks per sample
-    static constexpr int CPR = V1 * 4;                                         // 16-byte chunks per row
-    static constexpr int ITEMS = (TY + 2) * CPR;                               // per plane
-    static constexpr int MAXC = (4 * ITEMS + 255) / 256;
-    static constexpr int NBMAX = 32;                                           // bricks whose masks a workgroup caches
-    static constexpr size_t SMEM = (size_t)SLAB + NBMAX * 256 + 4 * 16 * 2 * sizeof(float);
-    static_assert(RUNS == 16, "a brick is 16 runs (one 256-byte mask record)");
-    static_assert(2 * PLANE + 2 * PITCH + 4096 < 65536, "fragment-read immediates");
-};
-
-template <typename AT, int V1, int TY>
-__global__ __launch_bounds__(256, 2) void conv_vox1_kernel(const Vox1Args p) {
-    typedef Vox1Cfg<V1, TY> C;
-    typedef typename OpOf<AT>::E E;
-    typedef Mma<E> MM;
-    typedef typename MM::v8 v8;
-    constexpr int KPAD = 27 * 32;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int t = threadIdx.x, lane = t & 63, ct = __builtin_amdgcn_readfirstlane(t >> 6), fr = lane & 15, fq = lane >> 4;
-    char* const slab = smem;
-    uint8_t* const lmask = (uint8_t*)(smem + C::SLAB);                         // [NBMAX][16 runs][16 sites]
-    float* const red = (float*)(lmask + C::NBMAX * 256);                       // [4 waves][16][2]
-    const int G = gridDim.x, wg = blockIdx.x;
-    const int nmine = (p.nbricks - wg + G - 1) / G;                            // bricks wg, wg + G, ... (the launcher keeps this <= NBMAX)
-
-    // ---- filter bank of this wave's 16 output channels: 27 A fragments (row fr = channel 16 ct + fr, k = 8 fq .. 8 fq + 7 of the tap)
-    v8 wf[27];
-    {
-        const char* wrow = (const char*)p.w + ((size_t)(16 * ct + fr) * KPAD + fq * 8) * 2;
-#pragma unroll
-        for (int tap = 0; tap < 27; ++tap) wf[tap] = __builtin_bit_cast(v8, *(const uint4*)(wrow + tap * 64));
-    }
-    auto brick_of = [&](int k, int& b, int& z0, int& y0) {
-        const int j = wg + k * G;
-        b = j / C::PS;
-        const int sp = (j % C::PS + b * (C::PS / 2 + 1)) % C::PS;
-        z0 = (sp / C::NYB) * 2;
-        y0 = (sp % C::NYB) * TY;
-    };
-    // per-lane slab offsets for kw = 0, 1, 2: site XOFF + fr + kw - 1 (+ the run's x0, a multiple of 16 sites: bit 2 unchanged)
-    int lofs[3];
-#pragma unroll
-    for (int kw = 0; kw < 3; ++kw) {
-        const int sx = C::XOFF + fr + kw - 1;
-        lofs[kw] = sx * 64 + ((fq ^ (((sx >> 2) & 1) << 1)) << 4);
-    }
-    const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
-    f32x4 cs = {0.f, 0.f, 0.f, 0.f}, cq = cs;
-
-    // ---- site masks of all bricks of this workgroup: run r of a brick = 16 contiguous mask bytes
-    for (int i = t; i < nmine * 16; i += 256) {
-        const int k = i >> 4, r = i & 15;
-        int b, z0, y0;
-        brick_of(k, b, z0, y0);
-        const int zl = r / C::HALF, idx = r % C::HALF, yl = idx / C::RPR, xr = idx % C::RPR;
-        uint4 mv = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
-        if (p.mask) mv = *(const uint4*)(p.mask + ((size_t)(b * V1 + z0 + zl) * V1 + y0 + yl) * V1 + xr * 16);
-        *(uint4*)(lmask + k * 256 + r * 16) = mv;
-    }
-    __syncthreads();
-#pragma unroll 1
-    for (int k = 0; k < nmine; ++k) {
-        unsigned rm;
-        {
-            const uint4 mv = *(const uint4*)(lmask + k * 256 + (lane & 15) * 16);
-            rm = (unsigned)(__ballot((mv.x | mv.y | mv.z | mv.w) != 0u) & 0xffffull);
-        }
-        if (rm == 0u) continue;                                                // empty brick: the same answer in every wave
-        int b, z0, y0;
-        brick_of(k, b, z0, y0);
-        __syncthreads();                                                       // every wave is done with the previous slab
-        {
-            uint4 pre[C::MAXC];
-            int dst[C::MAXC];
-#pragma unroll
-            for (int u = 0; u < C::MAXC; ++u) {
-                const int c = t + u * 256;
-                const int zz = (c >= C::ITEMS) + (c >= 2 * C::ITEMS) + (c >= 3 * C::ITEMS);
-                const int i = c - zz * C::ITEMS;
-                const int yy = i / C::CPR, cc = i % C::CPR;
-                const int sx = C::XOFF + (cc >> 2), q = cc & 3;
-                const int gz = z0 - 1 + zz, gy = y0 - 1 + yy;
-                const bool inside = c < 4 * C::ITEMS;
-                dst[u] = inside ? zz * C::PLANE + yy * C::PITCH + sx * 64 + ((q ^ (((sx >> 2) & 1) << 1)) << 4) : -1;
-                const bool ok = inside && (unsigned)gz < (unsigned)V1 && (unsigned)gy < (unsigned)V1;
-                const unsigned voff = ok ? (unsigned)((((b * V1 + gz) * V1 + gy) * V1) * 64 + cc * 16) : 0x80000000u;
-                pre[u] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(irs, voff, 0, 0));
-            }
-            // the zero site left and right of every row (4 chunks each)
-            for (int i = t; i < 4 * (TY + 2) * 8; i += 256) {
-                const int row = i >> 3, side = (i >> 2) & 1, q = i & 3;
-                const int zz = row / (TY + 2), yy = row - zz * (TY + 2);
-                const int sx = side ? C::XOFF + V1 : C::XOFF - 1;
-                *(uint4*)(slab + zz * C::PLANE + yy * C::PITCH + sx * 64 + q * 16) = make_uint4(0u, 0u, 0u, 0u);
-            }
-#pragma unroll
-            for (int u = 0; u < C::MAXC; ++u)
-                if (dst[u] >= 0) *(uint4*)(slab + dst[u]) = pre[u];
-        }
-        __syncthreads();
-
-#pragma unroll 1
-        while (rm) {
-            const int r = __builtin_ctz(rm);
-            rm &= rm - 1;
-            const int zl = r / C::HALF, idx = r % C::HALF, yl = idx / C::RPR, xr = idx % C::RPR;
-            const char* sb = slab + zl * C::PLANE + yl * C::PITCH + xr * 1024;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            // the nine fragments of a kd plane are read as one batch, the next plane's batch is issued before this plane's MFMAs: with
-            // reads only two taps ahead (the compiler's own schedule) every MFMA pair waited out an LDS latency
-            v8 bf[2][9];
-#pragma unroll
-            for (int j = 0; j < 9; ++j) bf[0][j] = *(const v8*)(sb + lofs[j % 3] + (j / 3) * C::PITCH);
-#pragma unroll
-            for (int kd = 0; kd < 3; ++kd) {
-                if (kd < 2) {
-#pragma unroll
-                    for (int j = 0; j < 9; ++j) bf[(kd + 1) & 1][j] = *(const v8*)(sb + lofs[j % 3] + (kd + 1) * C::PLANE + (j / 3) * C::PITCH);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < 9; ++j) acc = MM::mma(wf[kd * 9 + j], bf[kd & 1][j], acc);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            const int live = lmask[k * 256 + r * 16 + fr];
-            if (live) {
-                typedef E e4 __attribute__((ext_vector_type(4)));
-                const e4 h = __builtin_convertvector(acc, e4);
-                const size_t site = ((size_t)(b * V1 + z0 + zl) * V1 + y0 + yl) * V1 + xr * 16 + fr;
-                *(e4*)((AT*)p.out + site * 64 + ct * 16 + fq * 4) = h;
-                const f32x4 rv = {(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
-                cs += rv;
-                cq += rv * rv;
-            }
-        }
-    }
-
-    if (p.stats) {                                                             // one record per workgroup: wave ct owns channels 16 ct ..
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float s_ = cs[r], q_ = cq[r];
-            s_ += vox_row_ror<8>(s_); q_ += vox_row_ror<8>(q_);
-            s_ += vox_row_ror<4>(s_); q_ += vox_row_ror<4>(q_);
-            s_ += vox_row_ror<2>(s_); q_ += vox_row_ror<2>(q_);
-            s_ += vox_row_ror<1>(s_); q_ += vox_row_ror<1>(q_);
-            if (fr == 0) {
-                p.stats[(size_t)blockIdx.x * 128 + ct * 16 + fq * 4 + r] = s_;
-                p.stats[(size_t)blockIdx.x * 128 + 64 + ct * 16 + fq * 4 + r] = q_;
-            }
-        }
-    }
-}
-
 static bool vox_disabled(const char* name) {
     const char* e = getenv(name);
     return e && e[0] == '1';
@@ -760,47 +570,4 @@ int tri_internal_vox0_wgrad_launch(const TriVox0Geom& g, int grid, int B, const 
 #undef TRI_VOX0W
     tri_set_error("conv_wgrad(vox0): brick shape not instantiated");
     return TRI_ERR_UNSUPPORTED;
-}
-
-bool tri_internal_vox1_geometry(int B, int ID, int IH, int IW, int cin, int OD, int OH, int OW, int cout, int KD, int KH, int KW, int stride,
-                                int pd, int ph, int pw, TriVox1Geom* g) {
-    static int off = -1;
-    if (off < 0) off = vox_disabled("TRICOLO_NO_VOX1") ? 1 : 0;               // A/B switch: level 1 stays on conv_igemm_kernel
-    if (off) return false;
-    const int V = ID;
-    static int big = -1;                                                      // TRICOLO_VOX1_32=1: also 32^3 level-1 grids (64^3 inputs; slower than conv_igemm_kernel there)
-    if (big < 0) big = vox_disabled("TRICOLO_VOX1_32") ? 1 : 0;
-    if (IH != V || IW != V || OD != V || OH != V || OW != V || (V != 16 && !(V == 32 && big))) return false;
-    if (cin != 32 || cout != 64 || KD != 3 || KH != 3 || KW != 3 || stride != 1 || pd != 1 || ph != 1 || pw != 1) return false;
-    if ((long)B * V * V * V * 64 >= (1L << 31)) return false;                 // 32-bit buffer offsets
-    g->V = V;
-    g->TY = V == 16 ? 8 : 4;
-    g->nbricks = B * (V / 2) * (V / g->TY);
-    int grid = 2 * tri_internal_num_cus();                                    // persistent: two workgroups per CU
-    if (grid > g->nbricks) grid = g->nbricks;
-    if ((long)grid * 32 < g->nbricks) grid = (g->nbricks + 31) / 32;          // a workgroup caches the masks of <= 32 bricks
-    g->grid = grid;
-    return true;
-}
-
-template <typename AT, int V1, int TY>
-static int vox1_launch_t(const Vox1Args& a, int grid, hipStream_t stream) {
-    typedef Vox1Cfg<V1, TY> C;
-    static bool attr = false;
-    if (!attr) {
-        hipFuncSetAttribute((const void*)conv_vox1_kernel<AT, V1, TY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::SMEM);
-        attr = true;
-    }
-    conv_vox1_kernel<AT, V1, TY><<<grid, 256, C::SMEM, stream>>>(a);
-    return tri_check_launch("tri_conv(vox1)");
-}
-
-int tri_internal_vox1_launch(const TriVox1Geom& g, int B, const void* in, const void* w, void* out, const uint8_t* mask, float* stats, int act_fmt,
-                             hipStream_t stream) {
-    Vox1Args a{};
-    a.in = in; a.w = w; a.out = out; a.mask = mask; a.stats = stats;
-    a.B = B; a.nbricks = g.nbricks;
-    a.in_bytes = (unsigned)((size_t)B * g.V * g.V * g.V * 64);
-    if (g.V == 16) return act_fmt == TRI_FMT_F16 ? vox1_launch_t<f16_t, 16, 8>(a, g.grid, stream) : vox1_launch_t<bf16_t, 16, 8>(a, g.grid, stream);
-    return act_fmt == TRI_FMT_F16 ? vox1_launch_t<f16_t, 32, 4>(a, g.grid, stream) : vox1_launch_t<bf16_t, 32, 4>(a, g.grid, stream);
 }

@@ -770,7 +770,7 @@ __global__ __launch_bounds__(256, 2) void conv_voxb_kernel(const VoxbArgs p) {
 
 static bool voxb_disabled() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("TRICOLO_NO_VOXB"); v = (e && e[0] == '1') ? 1 : 0; }      // A/B switch: level 1 stays on conv_vox1_kernel / conv_igemm_kernel
+    if (v < 0) { const char* e = getenv("TRICOLO_NO_VOXB"); v = (e && e[0] == '1') ? 1 : 0; }      // A/B switch: level 1 stays on conv_igemm_kernel
     return v == 1;
 }
 

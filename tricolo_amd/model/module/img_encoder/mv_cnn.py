@@ -23,6 +23,9 @@ from .... import ops
 from ....layers import SideStream, TriModule, linear_bwd, linear_fwd, require_gpu
 
 
+_DS_LATE = int(os.environ.get("TRICOLO_DS_LATE", "2"))         # A/B switch (round 6): 0 = shortcut branch forked at the start of the block
+
+
 class _BasicBlockParams(nn.Module):
     def __init__(self, inplanes, planes, stride):
         super().__init__()
@@ -136,12 +139,14 @@ class MVCNNEncoder(TriModule):
             self._side_prep.join(*pend)
             self.__dict__["_prep_pending"] = None
 
-    def _conv_bn(self, x, conv, bn, prec, train):
+    def _conv_bn(self, x, conv, bn, prec, train, after_conv=None):
         N, _, H, W, _ = x.shape
         g = self._geom2d(N, H, W, conv)
         packed = self._packed[(id(conv), False)]
         if train:
             y, stats = ops.conv_fwd(x, g, packed, want_stats=True)
+            if after_conv is not None:
+                after_conv()                                      # (issued between the conv launch and its BatchNorm finalize)
             co = ops.bn_finalize(stats, g.cout, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
                                  count_host=g.M, momentum=bn.momentum, eps=bn.eps)
         else:
@@ -164,11 +169,22 @@ class MVCNNEncoder(TriModule):
 
     def _run_block(self, blk, x, prec, train, save, store):
         ds = blk.downsample is not None
-        if ds:                                                 # 1x1/2 conv + BN of the shortcut: independent of conv1 / conv2
+        late = ds and train and _DS_LATE
+        shortcut = []
+
+        def run_shortcut():                                    # 1x1/2 conv + BN of the shortcut: independent of conv1 / conv2
             with torch.cuda.stream(self._side_ds.fork(x)):
-                yd, cod, gd = self._conv_bn(x, blk.downsample[0], blk.downsample[1], prec, train)
+                shortcut.extend(self._conv_bn(x, blk.downsample[0], blk.downsample[1], prec, train))
+        # Round 6: the shortcut's side stream is forked BEHIND conv1's launch - it then runs beside conv1's BatchNorm finalize / apply
+        # passes (short kernels) instead of beside conv1 itself: every conv kernel of the trunk wants whole CUs (LDS, registers), and a
+        # second kernel's workgroups on some CUs push part of the conv's workgroups into a second round (in-graph trace: conv1 31.7 / 38.5 us
+        # beside the shortcut conv against 19-23 us alone)
+        if ds and not late:
+            run_shortcut()
         fine = ops.TIMELINE is not None and ops.TIMELINE.get("fine")
-        y1, co1, g1 = self._conv_bn(x, blk.conv1, blk.bn1, prec, train)
+        y1, co1, g1 = self._conv_bn(x, blk.conv1, blk.bn1, prec, train, after_conv=run_shortcut if late else None)
+        if ds:
+            yd, cod, gd = shortcut
         if fine:
             ops.stamp(f"image.fwd.c{y1.shape[-1]}.conv1+fin")
         a1 = ops.bn_act(y1, co1, relu=True)
@@ -256,14 +272,23 @@ class MVCNNEncoder(TriModule):
             x, y1, co1, g1, a1, y2, co2, g2, yd, cod, gd, out = sv
             # relu(bn2(y2) + residual) backward inside the BN passes; g = dout * (out > 0) (gradient of the pre-activation sum,
             # also the residual branch's gradient) is written by the apply pass in place of dout
+            # shortcut blocks, round 6 (_DS_LATE): 1 = the shortcut's backward forked behind conv2's data gradient; 2 = its BatchNorm passes
+            # forked at the START of the block (they take the ReLU mask from the saved output themselves: nothing waits for bn2's apply
+            # pass, which then has no masked gradient to write), its 1x1 / 2 data gradient behind conv2's data gradient
+            late = _DS_LATE if (blk.downsample is not None and batch is not None) else 0
+            if late == 2:
+                with torch.cuda.stream(self._side_ds.fork(dout, yd)):
+                    dyd, gr[blk.downsample[1].weight], gr[blk.downsample[1].bias] = ops.bn_bwd(
+                        yd, dout, cod, blk.downsample[1].weight, count_host=gd.M, inplace=False, relu_out=out, out_scale=ugs)
             dy2, gr[blk.bn2.weight], gr[blk.bn2.bias] = ops.bn_bwd(y2, dout, co2, blk.bn2.weight, count_host=g2.M, inplace=False,
-                                                                   relu_out=out, g_masked=dout, out_scale=ugs, partial=dout_sums)
+                                                                   relu_out=out, g_masked=None if late == 2 else dout, out_scale=ugs,
+                                                                   partial=dout_sums)
             g = dout
             fine = ops.TIMELINE is not None and ops.TIMELINE.get("fine")
             tag = f"image.bwd.c{y2.shape[-1]}.b{bi}"
             if fine:
                 ops.stamp(tag + ".bn2")
-            if blk.downsample is not None:                         # shortcut branch next to the conv2 / conv1 chain
+            if blk.downsample is not None and not late:            # shortcut branch next to the conv2 / conv1 chain
                 with torch.cuda.stream(self._side_ds.fork(g, yd)):
                     dyd, gr[blk.downsample[1].weight], gr[blk.downsample[1].bias] = ops.bn_bwd(
                         yd, g, cod, blk.downsample[1].weight, count_host=gd.M, inplace=False, out_scale=ugs)
@@ -274,6 +299,15 @@ class MVCNNEncoder(TriModule):
             # relu(bn1(y1)) backward: the ReLU mask is recomputed from y1 inside the BN passes (no relu_bwd pass over a1); where conv2's
             # data-gradient kernel can, it takes bn1's sums in its epilogue (no reduce pass over da1 / y1)
             da1, sums1 = ops.conv_dgrad(dy2, g2, self._packed[(id(blk.conv2), True)], bn_sums=(y1, co1, None))
+            if late:
+                # the shortcut's data gradient (1: its whole backward) runs beside bn1's backward passes - short kernels - instead of beside
+                # the row-unit conv kernel, whose one-workgroup-per-CU launch took 49 us instead of 23 when the shortcut's workgroups
+                # sat on its CUs (in-graph trace, layer4)
+                with torch.cuda.stream(self._side_ds.fork(g, yd)):
+                    if late == 1:
+                        dyd, gr[blk.downsample[1].weight], gr[blk.downsample[1].bias] = ops.bn_bwd(
+                            yd, g, cod, blk.downsample[1].weight, count_host=gd.M, inplace=False, out_scale=ugs)
+                    dx = ops.conv_dgrad(dyd, gd, self._packed[(id(blk.downsample[0]), True)])
             if fine:
                 ops.stamp(tag + ".dgrad2")
             dy1, gr[blk.bn1.weight], gr[blk.bn1.bias] = ops.bn_bwd(y1, da1, co1, blk.bn1.weight, count_host=g1.M, relu=True, out_scale=ugs,

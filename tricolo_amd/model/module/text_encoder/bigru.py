@@ -61,7 +61,6 @@ class _BiGRUFn(torch.autograd.Function):
         hp = ops.head_precision(prec)
         g_ih, g_hh = linear_geom(L * B, I, 768), linear_geom(L * B, 128, 384)
         dgi = dgi.contiguous()
-        assert L * B > 64                                      # (the one-launch small-linear path is for the <= 64-row heads, never the projection)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.conv_dgrad(dgi, g_ih, ops.pack_weight(w_ih, g_ih, hp, transposed=True)).view(x2d.shape)

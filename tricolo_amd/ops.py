@@ -137,8 +137,6 @@ def _igemm_symbol(g, transposed, split, t):
     fam, bn = code & 255, (code >> 8) & 255
     if fam == 6:
         return f"conv_vox0_kernel<{_TNAME[t.dtype]}>"
-    if fam == 7:
-        return f"conv_vox1_kernel<{_TNAME[t.dtype]}>"
     if fam == 14:
         return f"conv_voxb_kernel<{_TNAME[t.dtype]}>"
     if fam == 13:
@@ -147,8 +145,6 @@ def _igemm_symbol(g, transposed, split, t):
         return f"conv_c64_kernel<{_TNAME[t.dtype]}>"                 # (forward / data gradient (+ accumulate) under one name)
     if fam == 10:
         return f"conv_s2d_kernel<{_TNAME[t.dtype]}>"
-    if fam == 11:
-        return f"conv_s2f_kernel<{_TNAME[t.dtype]}>"
     if fam == 15:
         return f"conv_s2g_kernel<{_TNAME[t.dtype]}>"
     if fam == 12:
@@ -816,8 +812,10 @@ def pool3d_bn_bwd(y, co: BNCoeffs, mask, pooled, dpooled, B, D, C, gamma, count_
     # routing pass then walks the active pooled sites, and - where dy may stay unwritten at inactive sites (keep_inactive) - the whole
     # BatchNorm backward walks this level's list
     big = y.numel() // C > 16384
-    if _VOX_ROWS and _ROUTE_RED and big and C % 4 == 0 and 256 % (C // 4) == 0 and rows_out is not None:
+    if _VOX_ROWS and _ROUTE_RED and fused and big and C % 4 == 0 and 256 % (C // 4) == 0 and rows_out is not None:
         # (round 5) the routing walk over the active pooled sites also leaves the BatchNorm-backward sums: route + finalize + apply
+        # (fused=False / TRICOLO_POOL_REDUCE=0 select the separate route and reduce passes here too)
+        assert dpooled.dtype == y.dtype and pooled.dtype == y.dtype
         g = torch.empty_like(y)
         nblk = lib().tri_pool3d_bwd_route_rows_num_blocks(B, D, C)
         partial = torch.empty((nblk, 2, C), dtype=torch.float32, device=y.device)

@@ -47,6 +47,7 @@ def fit(net, cfg, train_batches, val_batches=None, device="cuda", ckpt_path: str
         start_epoch, step = int(doc.get("epoch", -1)) + 1, int(doc.get("global_step", 0))
     best, history = None, []
     every = int(cfg.trainer.get("check_val_every_n_epoch", 1) or 1)
+    epoch_start_step = step                                           # global step the first epoch of THIS run starts from (resume: the checkpoint's)
     for epoch in range(start_epoch, int(cfg.trainer.max_epochs)):
         net.train()
         last = None
@@ -64,8 +65,10 @@ def fit(net, cfg, train_batches, val_batches=None, device="cuda", ckpt_path: str
             if rec["skipped_steps"] + rec["skipped_elements"] > seen:
                 log(f"[tricolo_amd.train] WARNING: {rec['skipped_steps']} optimizer step(s) / {rec['skipped_elements']} gradient element(s) skipped so far "
                     "because of inf / NaN gradients (f16 activation-gradient overflow?): lower ops.F16_GRAD_SCALE or train in bf16x3")
-            prev_sk, prev_step = (history[-1].get("skipped_steps", 0), history[-1]["global_step"]) if history else (0, 0)
-            if step > prev_step and rec["skipped_steps"] - prev_sk >= step - prev_step:
+            # (a resumed run starts with an empty history: its first epoch counts from the checkpoint's global step - FusedAdam.load_state_dict
+            #  zeroes the skip record -, and one skipped step of a one-step epoch is a transient, not a frozen run: ADVICE r5)
+            prev_sk, prev_step = (history[-1].get("skipped_steps", 0), history[-1]["global_step"]) if history else (0, epoch_start_step)
+            if step - prev_step >= 2 and rec["skipped_steps"] - prev_sk >= step - prev_step:
                 # the static scale does not back off like GradScaler: a persistent overflow would freeze the weights silently
                 raise RuntimeError(f"every optimizer step of epoch {epoch} was skipped for non-finite gradients: lower TRICOLO_F16_GRAD_SCALE "
                                    "(a power of two) or train in bf16x3")
