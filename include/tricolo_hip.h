@@ -315,6 +315,9 @@ int tri_voxel_from_rgba_u8(const uint8_t* rgba, int B, int V, void* dense, uint8
 int tri_mask_count(const uint8_t* mask, long n, int* count, void* stream);
 /* instrumentation: *slot = wall_clock64() (100 MHz) at this point of the stream; tools/step_timeline.py */
 int tri_debug_stamp(unsigned long long* slot, void* stream);
+/* toolchain regression probe: copies n16 16-byte elements src -> dst through the raw-buffer builtins (form 0 load with a per-lane offset -
+ * what the conv kernels use -, 1 load with an SGPR scalar offset, 2 / 3 the same for stores; csrc/misc.hip buffer_b128_probe_kernel) */
+int tri_debug_buffer_b128_probe(const void* src, void* dst, long n16, int form, void* stream);
 /* active-site list of a submanifold level: row_pos[0 .. *count) = positions with mask != 0, ascending; *count = how many.
  * Hand row_pos + count to tri_conv_fwd / tri_conv_dgrad: they then compute (and write) ONLY those rows - executed work =
  * active work (spconv's rulebook idea on a dense index space).  Split-K layers take the list too (slab row = list row).  scratch: tri_mask_compact_scratch(n) bytes. */

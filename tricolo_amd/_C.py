@@ -113,6 +113,7 @@ SIGNATURES = {
     "tri_nchw3_u8_to_nhwc4": (I, [P, I, I, I, P, P, P, I, P]),
     "tri_mask_count": (I, [P, L, P, P]),
     "tri_debug_stamp": (I, [P, P]),
+    "tri_debug_buffer_b128_probe": (I, [P, P, L, I, P]),
     "tri_mask_compact_scratch": (Z, [L]),
     "tri_mask_compact": (I, [P, L, P, P, P, P]),
     "tri_mask_pyramid": (I, [P, I, I, P, P]),

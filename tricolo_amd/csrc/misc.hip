@@ -81,6 +81,40 @@ extern "C" int tri_debug_stamp(unsigned long long* slot, void* stream) {
     return tri_check_launch("tri_debug_stamp");
 }
 
+// Toolchain regression probe (round 6): the 16-byte raw-buffer builtins in the forms the conv kernels use them
+// (form 0: load with a per-lane offset, scalar offset 0 - the 16 load sites of conv_igemm / conv_vox / conv_voxg / conv_c64 / conv_s2g /
+// conv_wgrad) and in the forms that MISCOMPILED on ROCm 7.2 when gru.hip tried them (profiles/r5/NOTES_voxel.md: store with an SGPR scalar
+// offset - data registers rewritten 0-3 instructions behind the store; load with a scalar offset the compiler did not see as uniform -
+// split into four dword loads, the fourth returning the first's value).  Every form copies src to dst, 16 bytes per lane, four
+// back-to-back elements per thread so that the data registers are reused right behind each access; tests/test_gpu_ops.py compares.
+//   form 0  load (voffset) -> plain store        form 1  load (voffset + SGPR soffset) -> plain store
+//   form 2  plain load -> store (voffset)        form 3  plain load -> store (voffset + SGPR soffset)
+__global__ __launch_bounds__(256) void buffer_b128_probe_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, long n16, int form) {
+    typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (int)(n16 * 16), 0x00020000);
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc((void*)dst, 0, (int)(n16 * 16), 0x00020000);
+    const long tile = (long)blockIdx.x * 1024;                       // 1024 elements per workgroup: 4 per thread, 256 apart
+    const unsigned sbase = (unsigned)__builtin_amdgcn_readfirstlane((int)(tile * 16));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const long i = tile + u * 256 + threadIdx.x;
+        if (i >= n16) continue;
+        const unsigned lane_off = (unsigned)((u * 256 + threadIdx.x) * 16);
+        uint4 v;
+        if (form == 0) v = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(srs, (unsigned)(i * 16), 0, 0));
+        else if (form == 1) v = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(srs, lane_off, sbase, 0));
+        else v = src[i];
+        if (form == 2) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_t, v), drs, (unsigned)(i * 16), 0, 0);
+        else if (form == 3) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_t, v), drs, lane_off, sbase, 0);
+        else dst[i] = v;
+    }
+}
+extern "C" int tri_debug_buffer_b128_probe(const void* src, void* dst, long n16, int form, void* stream) {
+    if (form < 0 || form > 3 || n16 <= 0 || n16 * 16 >= ((long)1 << 31)) { tri_set_error("tri_debug_buffer_b128_probe: form 0..3, 0 < n16 * 16 < 2^31"); return TRI_ERR_ARG; }
+    buffer_b128_probe_kernel<<<(unsigned)((n16 + 1023) / 1024), 256, 0, (hipStream_t)stream>>>((const uint4*)src, (uint4*)dst, n16, form);
+    return tri_check_launch("tri_debug_buffer_b128_probe");
+}
+
 // count of non-zero mask bytes -> *count (device int)
 __global__ void mask_count_kernel(const uint8_t* __restrict__ mask, long n, int* __restrict__ count) {
     int local = 0;

@@ -139,13 +139,17 @@ class SideStream:
         self.stream = None
         self.enabled = tag not in os.environ.get("TRICOLO_NO_SIDE", "").split(",")
 
-    def fork(self, *tensors):
-        """Make the side stream wait for everything issued so far on the current stream; returns the side stream."""
+    def fork(self, *tensors, event=None):
+        """Make the side stream wait for everything issued so far on the current stream (or, with `event`, for what had been issued when
+        that event was recorded: the branch is then ISSUED here but depends on less); returns the side stream."""
         if not self.enabled:
             return torch.cuda.current_stream()
         if self.stream is None:
             self.stream = torch.cuda.Stream()
-        self.stream.wait_stream(torch.cuda.current_stream())
+        if event is not None:
+            self.stream.wait_event(event)
+        else:
+            self.stream.wait_stream(torch.cuda.current_stream())
         if not torch.cuda.is_current_stream_capturing():   # (under capture the graph's private pool defers every free)
             for t in tensors:
                 if t is not None:

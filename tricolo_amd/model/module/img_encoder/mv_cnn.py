@@ -23,7 +23,10 @@ from .... import ops
 from ....layers import SideStream, TriModule, linear_bwd, linear_fwd, require_gpu
 
 
-_DS_LATE = int(os.environ.get("TRICOLO_DS_LATE", "2"))         # A/B switch (round 6): 0 = shortcut branch forked at the start of the block
+_DS_FWD = int(os.environ.get("TRICOLO_DS_FWD", "2"))           # where the shortcut branch of layer2-4's first block is issued (round 6; see _run_block)
+_DS_BWD = int(os.environ.get("TRICOLO_DS_BWD", "2"))
+_PREP_DGRAD_LATE = os.environ.get("TRICOLO_PREP_DGRAD_LATE", "1") != "0"   # trunk data-gradient operands packed behind layer4 (0: with the forward operands)
+_PREP_ISSUE = int(os.environ.get("TRICOLO_PREP_ISSUE", "1"))    # where the trunk's operand packing is issued: 0 first thing, 1 behind the stem conv, 2 behind the max-pool
 
 
 class _BasicBlockParams(nn.Module):
@@ -106,7 +109,7 @@ class MVCNNEncoder(TriModule):
         key = (N, H, W, train)
         packer = self._packers.get(key)
         if packer is None:
-            packer = (ops.WeightPacker(), ops.WeightPacker())
+            packer = (ops.WeightPacker(), ops.WeightPacker(), ops.WeightPacker())     # stem | trunk forward | trunk data-gradient operands
             stem_g = self._geom2d(N, H, W, self.net_1[0])
             packer[0].add((id(self.net_1[0]), False), self.net_1[0].weight, stem_g)
             convs = []
@@ -123,14 +126,58 @@ class MVCNNEncoder(TriModule):
                 g = self._geom2d(N, ch, cw, conv)
                 packer[1].add((id(conv), False), conv.weight, g)
                 if train:
-                    packer[1].add((id(conv), True), conv.weight, g, transposed=True)
+                    packer[2 if _PREP_DGRAD_LATE else 1].add((id(conv), True), conv.weight, g, transposed=True)
             self._packers[key] = packer
         packed = dict(packer[0].run(prec, device))
-        with torch.cuda.stream(self._side_prep.fork()):
-            rest = packer[1].run(prec, device)
-        packed.update(rest)
-        self.__dict__["_prep_pending"] = [t for pair in rest.values() for t in pair if t is not None]
+        ev = None
+        if _PREP_ISSUE:                                        # (the trunk's packing depends on nothing issued in this step ...)
+            ev = torch.cuda.Event()
+            ev.record()
+
+        def pack_rest():
+            with torch.cuda.stream(self._side_prep.fork(event=ev)):
+                rest = packer[1].run(prec, device)
+            self._packed.update(rest)
+            self.__dict__["_prep_pending"] = [t for pair in rest.values() for t in pair if t is not None]
+
+        def pack_dgrad():
+            # Round 6 (_PREP_DGRAD_LATE): the data-gradient operands (half of the trunk's packing traffic) are not needed before the
+            # backward: they are packed behind layer4's last launch, in the shadow of the heads / loss section (a chain of tiny kernels with
+            # the GPU nearly idle), instead of beside the stem conv, which is HBM-bound like the packing itself (83 us in-graph against 48 alone)
+            with torch.cuda.stream(self._side_prep.fork(event=ev)):
+                rest = packer[2].run(prec, device)
+            self._packed.update(rest)
+            self.__dict__["_prep_pending_dgrad"] = [t for pair in rest.values() for t in pair if t is not None]
+        self.__dict__["_pack_dgrad"] = pack_dgrad if (train and _PREP_DGRAD_LATE and packer[2].entries) else None
+        if ev is None and self.__dict__["_pack_dgrad"] is not None:
+            ev = torch.cuda.Event()
+            ev.record()
+        # Round 6 (_PREP_ISSUE = 1): ... but is ISSUED behind the stem conv's launch: a replayed graph releases nodes in capture order, and the
+        # 67 us packing launch captured first took the CUs the stem conv wanted (79 us in-graph against 48 alone)
+        self.__dict__["_pack_rest"] = pack_rest
+        self._packed = packed
+        if not _PREP_ISSUE:
+            self._run_pack_rest()
         return packed
+
+    def _run_pack_rest(self):
+        fn = self.__dict__.get("_pack_rest")
+        if fn is not None:
+            self.__dict__["_pack_rest"] = None
+            fn()
+
+    def _run_pack_dgrad(self):
+        fn = self.__dict__.get("_pack_dgrad")
+        if fn is not None:
+            self.__dict__["_pack_dgrad"] = None
+            fn()
+
+    def _join_packing_dgrad(self):
+        self._run_pack_dgrad()                                  # (a backward without the upper half's forward in between: never skipped)
+        pend = self.__dict__.get("_prep_pending_dgrad")
+        if pend:
+            self._side_prep.join(*pend)
+            self.__dict__["_prep_pending_dgrad"] = None
 
     def _join_packing(self):
         """The trunk's operand rows (packed on the side stream by _pack_all) are needed from here on."""
@@ -169,20 +216,25 @@ class MVCNNEncoder(TriModule):
 
     def _run_block(self, blk, x, prec, train, save, store):
         ds = blk.downsample is not None
-        late = ds and train and _DS_LATE
+        mode = _DS_FWD if (ds and train) else 0
         shortcut = []
+        ev = None
+        if mode == 2:                                          # (the shortcut depends on the block input only ...)
+            ev = torch.cuda.Event()
+            ev.record()
 
         def run_shortcut():                                    # 1x1/2 conv + BN of the shortcut: independent of conv1 / conv2
-            with torch.cuda.stream(self._side_ds.fork(x)):
+            with torch.cuda.stream(self._side_ds.fork(x, event=ev)):
                 shortcut.extend(self._conv_bn(x, blk.downsample[0], blk.downsample[1], prec, train))
-        # Round 6: the shortcut's side stream is forked BEHIND conv1's launch - it then runs beside conv1's BatchNorm finalize / apply
-        # passes (short kernels) instead of beside conv1 itself: every conv kernel of the trunk wants whole CUs (LDS, registers), and a
-        # second kernel's workgroups on some CUs push part of the conv's workgroups into a second round (in-graph trace: conv1 31.7 / 38.5 us
-        # beside the shortcut conv against 19-23 us alone)
-        if ds and not late:
+        # Round 6: where the shortcut's side branch is ISSUED matters under HIP-graph replay - nodes are released in capture order, so a branch
+        # captured first gets the CUs first and conv1, whose launch wants whole CUs (LDS, registers), runs part of its workgroups in a second
+        # round (in-graph trace: conv1 31.7 / 38.5 us beside the shortcut conv against 19-23 us alone).  _DS_FWD: 0 = forked and issued at the
+        # start of the block; 1 = forked BEHIND conv1's launch (it waits for conv1 and runs beside conv1's BatchNorm passes); 2 = issued
+        # behind conv1's launch but depending only on the block input (... and is released after conv1, taking the CUs conv1 leaves)
+        if ds and not mode:
             run_shortcut()
         fine = ops.TIMELINE is not None and ops.TIMELINE.get("fine")
-        y1, co1, g1 = self._conv_bn(x, blk.conv1, blk.bn1, prec, train, after_conv=run_shortcut if late else None)
+        y1, co1, g1 = self._conv_bn(x, blk.conv1, blk.bn1, prec, train, after_conv=run_shortcut if mode else None)
         if ds:
             yd, cod, gd = shortcut
         if fine:
@@ -215,8 +267,12 @@ class MVCNNEncoder(TriModule):
             x0 = ops.nchw3_u8_to_nhwc4(images, dtype=ops.act_dtype(prec))
         else:
             x0 = ops.nchw3_to_nhwc4(images, dtype=ops.act_dtype(prec))
-        y, co, g = self._conv_bn(x0, self.net_1[0], self.net_1[1], prec, train)
+        def after_stem_conv():
+            if _PREP_ISSUE == 1:
+                self._run_pack_rest()
+        y, co, g = self._conv_bn(x0, self.net_1[0], self.net_1[1], prec, train, after_conv=after_stem_conv)
         x, parg = ops.maxpool2d_fwd(y, want_arg=save, bn=co)            # BN + ReLU + 3x3/2 max-pool: relu(bn(y)) is never stored
+        self._run_pack_rest()                                          # (_PREP_ISSUE = 2, or an eval-mode forward: after_conv is a training hook)
         ops.stamp("image.fwd.stem.end")
         saved = {"stem": (x0, y, co, g, parg), "blocks": [], "N": N}
         self._join_packing()
@@ -233,12 +289,15 @@ class MVCNNEncoder(TriModule):
         for blk in self._blocks()[self.N_LOWER_BLOCKS:]:
             x = self._run_block(blk, x, prec, train, save, saved["blocks"])
         ops.stamp("image.fwd.layer4.end")
+        if save:
+            self._run_pack_dgrad()
         pooled, arg = ops.avgpool_viewmax_fwd(x, B, self.num_views)
         f = linear_fwd(pooled, self.net_2.weight, self.net_2.bias, 0, prec)
         h = linear_fwd(f, self.mlp[0].weight, self.mlp[0].bias, 1, prec)
         o = linear_fwd(h, self.mlp[2].weight, self.mlp[2].bias, 0, prec)
         zz, norm = ops.l2norm_fwd(o)
         if save:
+            self._join_packing_dgrad()      # (behind the heads' launches: a forward captured on its own - parallel.GraphedDPStep - must end joined)
             saved.update(feat_shape=tuple(x.shape), pooled=pooled, arg=arg, f=f, h=h, o=o, z=zz, norm=norm)
         return zz, saved
 
@@ -272,42 +331,37 @@ class MVCNNEncoder(TriModule):
             x, y1, co1, g1, a1, y2, co2, g2, yd, cod, gd, out = sv
             # relu(bn2(y2) + residual) backward inside the BN passes; g = dout * (out > 0) (gradient of the pre-activation sum,
             # also the residual branch's gradient) is written by the apply pass in place of dout
-            # shortcut blocks, round 6 (_DS_LATE): 1 = the shortcut's backward forked behind conv2's data gradient; 2 = its BatchNorm passes
-            # forked at the START of the block (they take the ReLU mask from the saved output themselves: nothing waits for bn2's apply
-            # pass, which then has no masked gradient to write), its 1x1 / 2 data gradient behind conv2's data gradient
-            late = _DS_LATE if (blk.downsample is not None and batch is not None) else 0
-            if late == 2:
-                with torch.cuda.stream(self._side_ds.fork(dout, yd)):
-                    dyd, gr[blk.downsample[1].weight], gr[blk.downsample[1].bias] = ops.bn_bwd(
-                        yd, dout, cod, blk.downsample[1].weight, count_host=gd.M, inplace=False, relu_out=out, out_scale=ugs)
             dy2, gr[blk.bn2.weight], gr[blk.bn2.bias] = ops.bn_bwd(y2, dout, co2, blk.bn2.weight, count_host=g2.M, inplace=False,
-                                                                   relu_out=out, g_masked=None if late == 2 else dout, out_scale=ugs,
-                                                                   partial=dout_sums)
+                                                                   relu_out=out, g_masked=dout, out_scale=ugs, partial=dout_sums)
             g = dout
             fine = ops.TIMELINE is not None and ops.TIMELINE.get("fine")
             tag = f"image.bwd.c{y2.shape[-1]}.b{bi}"
             if fine:
                 ops.stamp(tag + ".bn2")
-            if blk.downsample is not None and not late:            # shortcut branch next to the conv2 / conv1 chain
-                with torch.cuda.stream(self._side_ds.fork(g, yd)):
-                    dyd, gr[blk.downsample[1].weight], gr[blk.downsample[1].bias] = ops.bn_bwd(
+            # shortcut branch (three BatchNorm passes + the 1x1 / 2 data gradient) next to the conv2 / conv1 chain; _DS_BWD as _DS_FWD in
+            # _run_block: 0 = forked and issued here, 1 = forked behind conv2's data gradient (runs beside bn1's passes), 2 = issued behind
+            # conv2's data gradient, depending on bn2's backward only
+            mode = _DS_BWD if (blk.downsample is not None and batch is not None) else 0
+            ev = None
+            if mode == 2:
+                ev = torch.cuda.Event()
+                ev.record()
+
+            def shortcut_bwd():
+                with torch.cuda.stream(self._side_ds.fork(g, yd, event=ev)):
+                    dyd_, gr[blk.downsample[1].weight], gr[blk.downsample[1].bias] = ops.bn_bwd(
                         yd, g, cod, blk.downsample[1].weight, count_host=gd.M, inplace=False, out_scale=ugs)
                     if batch is None:
-                        gr[blk.downsample[0].weight] = ops.conv_wgrad(x, dyd, gd, blk.downsample[0].weight, prec, out_scale=ugs)
-                    dx = ops.conv_dgrad(dyd, gd, self._packed[(id(blk.downsample[0]), True)])
+                        gr[blk.downsample[0].weight] = ops.conv_wgrad(x, dyd_, gd, blk.downsample[0].weight, prec, out_scale=ugs)
+                    return dyd_, ops.conv_dgrad(dyd_, gd, self._packed[(id(blk.downsample[0]), True)])
+            if blk.downsample is not None and not mode:
+                dyd, dx = shortcut_bwd()
             wgrad_async(a1, dy2, g2, blk.conv2.weight)
             # relu(bn1(y1)) backward: the ReLU mask is recomputed from y1 inside the BN passes (no relu_bwd pass over a1); where conv2's
             # data-gradient kernel can, it takes bn1's sums in its epilogue (no reduce pass over da1 / y1)
             da1, sums1 = ops.conv_dgrad(dy2, g2, self._packed[(id(blk.conv2), True)], bn_sums=(y1, co1, None))
-            if late:
-                # the shortcut's data gradient (1: its whole backward) runs beside bn1's backward passes - short kernels - instead of beside
-                # the row-unit conv kernel, whose one-workgroup-per-CU launch took 49 us instead of 23 when the shortcut's workgroups
-                # sat on its CUs (in-graph trace, layer4)
-                with torch.cuda.stream(self._side_ds.fork(g, yd)):
-                    if late == 1:
-                        dyd, gr[blk.downsample[1].weight], gr[blk.downsample[1].bias] = ops.bn_bwd(
-                            yd, g, cod, blk.downsample[1].weight, count_host=gd.M, inplace=False, out_scale=ugs)
-                    dx = ops.conv_dgrad(dyd, gd, self._packed[(id(blk.downsample[0]), True)])
+            if mode:
+                dyd, dx = shortcut_bwd()
             if fine:
                 ops.stamp(tag + ".dgrad2")
             dy1, gr[blk.bn1.weight], gr[blk.bn1.bias] = ops.bn_bwd(y1, da1, co1, blk.bn1.weight, count_host=g1.M, relu=True, out_scale=ugs,
@@ -342,6 +396,7 @@ class MVCNNEncoder(TriModule):
         prec, B = self._prec(), saved["B"]
         gr = {}
         ops.stamp("image.bwd.start")
+        self._join_packing_dgrad()
         own = batch is None
         if own:
             batch = ops.wgrad_batch(dz.device)
@@ -363,6 +418,7 @@ class MVCNNEncoder(TriModule):
         prec = self._prec()
         ugs = 1.0 / ops.grad_scale(prec)
         gr = {}
+        self._join_packing_dgrad()
         own = batch is None
         if own:
             batch = ops.wgrad_batch(dout.device)

@@ -33,6 +33,17 @@ class FusedAdam(torch.optim.Optimizer):
         self._params = None
         self._pending_state = None
         self._captures = 0
+        self._zg_event = None
+        self._seg_side = None
+
+    def zero_grad(self, set_to_none: bool = True):
+        """torch.optim.Optimizer.zero_grad; inside a HIP-graph capture it also marks the point the step's gradient-pointer table may be
+        uploaded from (see _update_from_segments)."""
+        super().zero_grad(set_to_none=set_to_none)
+        self._zg_event = None
+        if self._step_dev is not None and torch.cuda.is_current_stream_capturing():
+            self._zg_event = torch.cuda.Event()
+            self._zg_event.record()
 
     # ------------------------------------------------------------------ state
     def prepare(self, captures: int = 0):
@@ -228,12 +239,27 @@ class FusedAdam(torch.optim.Optimizer):
             host = slot[0]
             host.copy_(torch.tensor(ptrs, dtype=torch.int64))
         self._seg_keep = grads                                       # keep temporaries alive until the next step
-        self._seg_ptr.copy_(host, non_blocking=True)
+        ev, self._zg_event = getattr(self, "_zg_event", None), None
+        if capturing and ev is not None:
+            # (round 6) captured step: the pointer table's copy node depends on nothing the step computes - it is issued here but hangs on
+            # the event zero_grad() recorded (same capture), so it runs long before the backward ends instead of sitting, with its
+            # dependent-node gap, between the last gradient kernel and the guard on the serial tail of the step
+            if self._seg_side is None:
+                self._seg_side = torch.cuda.Stream()
+            main = torch.cuda.current_stream()
+            self._seg_side.wait_event(ev)
+            with torch.cuda.stream(self._seg_side):
+                self._seg_ptr.copy_(host, non_blocking=True)
+            main.wait_stream(self._seg_side)
+        else:
+            self._seg_ptr.copy_(host, non_blocking=True)
         if not capturing:
             slot[1] = torch.cuda.Event()
             slot[1].record()
         if self._guard:
             ops.adam_guard_segments(self._seg_ptr, self._seg_start, self._flat_p.numel(), self._step_dev)
+        # (round 6: the tick folded into the guard launch's last workgroup - one node less - was built and measured: 4,096 workgroups taking a
+        #  ticket on one address cost 110 us; the kernel-argument form of the pointer table was dropped with it)
         ops.adam_tick(self._step_dev)                       # step += 1 on the device (or skipped += 1), once per optimizer step
         ops.adam_step_segments(self._flat_p, self._seg_ptr, self._seg_start, self._flat_m, self._flat_v, self._step_dev, group["lr"],
                                b1, b2, group["eps"], group["weight_decay"], grad_scale, lr_dev=self._lr_dev)
