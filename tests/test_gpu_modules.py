@@ -838,6 +838,54 @@ def test_f16_overflow_guard_never_fires_on_the_bench_workload():
     _report("f16_guard_2000_steps", {"first_loss": first, "last_loss": last, "skipped_steps": 0})
 
 
+def test_replayed_bench_steps_are_bit_reproducible():
+    """Round 6: the bench workload's step captured into a HIP graph and replayed, THREE independent runs from the same initial weights:
+    every loss of the trajectory must agree bit for bit.  A kernel that clobbers a register behind an un-waited asynchronous load, or a
+    side branch racing the chain it was forked from, shows up as a run whose trajectory leaves the others' after a few dozen steps (this
+    caught conv_halo_rows_kernel's first L2 warm-up, whose loads had register destinations: 5-10 % of bench runs ended on another loss)."""
+    ops.set_default_precision("f16")
+    from tricolo_amd import parallel
+    batches = [syn.batch_to_device(syn.make_batch(32, voxel_size=32, num_views=6, image_size=128, seed=syn.BASE_SEED + 4 + i), DEV) for i in range(4)]
+    runs = []
+    for rep in range(3):
+        net, cfg = _build_net("BiGRUEncoder", "MVCNNEncoder", "SparseCNNEncoder", 32, 6, 128)
+        opt = net.configure_optimizers()
+        opt.prepare(captures=len(batches))
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):                                # eager warm-up on a side stream (lazy buffers), then back to the initial state
+            snap = [p.detach().clone() for p in net.parameters()]
+            bufs = [b.detach().clone() for b in net.buffers()]
+            parallel.dp_training_step(net, batches[0], opt)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            for p_, q in zip(net.parameters(), snap):
+                p_.copy_(q)
+            for b_, q in zip(net.buffers(), bufs):
+                b_.copy_(q)
+            opt._flat_m.zero_(); opt._flat_v.zero_(); opt._step_dev.zero_()
+        graphs, outs = [], []
+        pool = None
+        for b in batches:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                outs.append(parallel.dp_training_step(net, b, opt)["train_loss/total_loss"])
+            pool = pool or g.pool()
+            graphs.append(g)
+        losses = []
+        for step in range(60):
+            graphs[step % len(graphs)].replay()
+            losses.append(outs[step % len(graphs)].clone())
+        torch.cuda.synchronize()
+        runs.append(torch.stack(losses).cpu())
+        del graphs, outs, net, opt
+        torch.cuda.empty_cache()
+    assert torch.isfinite(runs[0]).all()
+    for r in runs[1:]:
+        assert torch.equal(r, runs[0]), f"trajectories differ from step {int((r != runs[0]).nonzero()[0])}: {r[-1].item()} vs {runs[0][-1].item()}"
+
+
 @pytest.mark.parametrize("tag,text,image,voxel,V,nv,S,B", [
     ("config2", "BiGRUEncoder", None, "SparseCNNEncoder", 32, 6, 128, 64),
     ("config3", "BiGRUEncoder", "MVCNNEncoder", None, 32, 6, 128, 64),

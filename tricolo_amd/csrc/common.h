@@ -161,15 +161,6 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 // lds_dst must be wave-uniform (the hardware adds lane * 16).  M0 is named in the clobber list; clang treats it as a
 // reserved register and only warns (-Wno-inline-asm in the Makefile) - the kernels that use this helper have no other
 // M0 consumer (no movrel indexing, no compiler-issued LDS-DMA), and tests/test_gpu_ops.py checks them bit-exactly.
-// One dword of a 128-byte line requested and never used: pulls the line into this XCD's L2 ahead of the LDS-DMA pieces that need it.
-// The destination register must stay allocated until a vmcnt wait has covered the load (keep the returned value alive with an empty asm).
-__device__ __forceinline__ int touch_line(v4i rsrc, int voff) {
-    int d = 0;
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(d) : "v"(voff), "s"(rsrc) : "memory");
-#endif
-    return d;
-}
 __device__ __forceinline__ void dma16_async(v4i rsrc, unsigned lds_dst, int voff) {
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"

@@ -1094,21 +1094,26 @@ __global__ __launch_bounds__(PROD ? 512 : 256, 1) void conv_halo_rows_kernel(con
     // activations ago) and the ring runs one kernel row ahead - far less than a trip to HBM.  The workgroups of an XCD share the weight rows
     // of the XCD's channel tiles: each touches its 1 / n of them (one dword per 128-byte line and lane, right behind the first pieces), so
     // the XCD's L2 holds the whole slice by the time the prologue (~3 us) is over.  Waited for with the first pieces (vmcnt(0) below).
-    int touch0 = 0, touch1 = 0, touch2 = 0, touch3 = 0, touch4 = 0;
+    // The touches are LDS-DMA loads into a dummy kilobyte per wave of `red` (unused until the epilogue): a load with a register destination
+    // that nothing waits for would leave the compiler free to hand that register to another value before the data lands in it.
+    int touch4 = 0;
     if (p.h_xcg > 0 && p.h_touch && (!PROD || producer)) {
+        const unsigned dummy = lds_addr(red) + wave * 1024;
         const int cg = p.h_xcg, n = G >> 3, s = (int)blockIdx.x >> 3;
         const int lines = cg * BN * p.Kpad / 64, per = (lines + n - 1) / n;      // 128-byte lines of the XCD's cg channel tiles; this workgroup's share
         const int l0 = (bid % NT / cg * cg) * BN * p.Kpad / 64 + s * per;
-        if (t < per) touch0 = touch_line(w_rsrc, (l0 + t) * 128);
-        if (t + 256 < per) touch1 = touch_line(w_rsrc, (l0 + t + 256) * 128);
+        // (lanes past the share read out of range: zeros, no traffic; the branch is uniform per wave only up to the share's last wave)
+        if (wave * 64 < per) dma16_async(w_rsrc, dummy, t < per ? (l0 + t) * 128 : (int)0x80000000);
+        if (wave * 64 + 256 < per) dma16_async(w_rsrc, dummy, t + 256 < per ? (l0 + t + 256) * 128 : (int)0x80000000);
         // ... and the tile's input rows (written by the previous kernel of the chain: in another XCD's L2 or in memory by now), split over
         // the cg workgroups of this XCD that share the row tile; the accumulating data gradient also warms the output tile its epilogue
         // reads (those loads sit at the very end of the kernel, with nothing left to hide them)
         const int g0t = (bid / NT) * TR;
         const int ilines = min(TR, NH - g0t) * W * p.Cin / 64, ishare = (ilines + cg - 1) / cg, il0 = (bid % NT % cg) * ishare;
         const int ibase = g0t * W * p.Cin * 2;
-        if (t < ishare && il0 + t < ilines) touch2 = touch_line(in_rsrc, ibase + (il0 + t) * 128);
-        if (t + 256 < ishare && il0 + t + 256 < ilines) touch3 = touch_line(in_rsrc, ibase + (il0 + t + 256) * 128);
+        if (wave * 64 < ishare) dma16_async(in_rsrc, dummy, (t < ishare && il0 + t < ilines) ? ibase + (il0 + t) * 128 : (int)0x80000000);
+        if (wave * 64 + 256 < ishare)
+            dma16_async(in_rsrc, dummy, (t + 256 < ishare && il0 + t + 256 < ilines) ? ibase + (il0 + t + 256) * 128 : (int)0x80000000);
         if (ACCUM && t < min(TR, NH - g0t) * W) touch4 = *(const volatile int*)((const char*)p.out + ((size_t)(g0t * W + t) * p.Cout + (bid % NT) * BN) * sizeof(AT));
     }
 
@@ -1188,7 +1193,7 @@ __global__ __launch_bounds__(PROD ? 512 : 256, 1) void conv_halo_rows_kernel(con
     if (PROD && producer) {
         // ---- producer waves: the DMA side of the row schedule below, one barrier per kernel row -----------------------------------
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("" :: "v"(touch0), "v"(touch1), "v"(touch2), "v"(touch3), "v"(touch4));   // (the warm-up loads' destination registers are free from here)
+        asm volatile("" :: "v"(touch4));
         __builtin_amdgcn_s_barrier();                                   // (the consumers' prologue barrier)
         asm volatile("" ::: "memory");
         int c_g = 0, c_chunk = 0;
@@ -1458,7 +1463,7 @@ __global__ __launch_bounds__(PROD ? 512 : 256, 1) void conv_halo_rows_kernel(con
     HSTAMP(2);
     // ---- prologue: the first slab and weights have been issued; fragments of k-steps 0 and 1 --------------------------------
     if constexpr (!PROD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if constexpr (!PROD) asm volatile("" :: "v"(touch0), "v"(touch1), "v"(touch2), "v"(touch3), "v"(touch4));
+    if constexpr (!PROD) asm volatile("" :: "v"(touch4));
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     HR_FIRST_READS(0u)
