@@ -15,7 +15,7 @@ def main():
     filt = sys.argv[2] if len(sys.argv) > 2 else "."
     with tempfile.TemporaryDirectory() as d:
         co = os.path.join(d, "k.co")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "--no-gpu-bundle-output",
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "--offload-arch=gfx950", "--cuda-device-only", "--no-gpu-bundle-output",
                                "-w", "-c", src, "-o", co] + sys.argv[3:])
         notes = subprocess.run([LLVM + "/llvm-readelf", "--notes", co], capture_output=True, text=True, check=True).stdout
     for blk in notes.split("- .agpr_count")[1:]:

@@ -243,7 +243,6 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
                 float* gh = dgh + o * 384 + unit;
                 gh[0] = dr_pre; gh[128] = dz_pre; gh[256] = dgn;
                 hprev[o * GRU_H + unit] = hp;
-                sb[0] += dr_pre; sb[1] += dz_pre; sb[2] += dn_pre; sb[3] += dgn;
             }
             float vals[3] = {dr_pre * GS, dz_pre * GS, dgn * GS};
 #pragma unroll
@@ -254,6 +253,12 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
                 *(E*)(gb + off) = hh;
                 if (NSPLIT == 2) *(E*)(gb + 16 * 768 + off) = (E)(vals[g] - (float)hh);
             }
+            // (round 6) the bias sums are taken AFTER the scaled copies: the stored gradients stay live past `vals`, so the compiler cannot
+            // form dgn * GS etc. in place - it had put `v_pk_mul_f32 v[74:75], v[74:75], GS` two instructions behind
+            // `global_store_dword ..., v74` / `v75`, and about one replay of the training step in 300 stored the scaled value in the lanes
+            // 48..63 of one wave (tools/r6/determinism.py: one row, 16 units, |diff| = 4095 x the value)
+            __builtin_amdgcn_sched_barrier(0);
+            if (b < B) { sb[0] += dr_pre; sb[1] += dz_pre; sb[2] += dn_pre; sb[3] += dgn; }
         }
         __syncthreads();
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};

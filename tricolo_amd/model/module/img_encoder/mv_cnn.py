@@ -455,7 +455,7 @@ class MVCNNEncoder(TriModule):
         #  kernel-row kernel's workgroups fill every CU's registers and the chain's kernels wait for them either way)
         lo = self._backward_lower(saved["lower"], dx2, batch)
         if batch is not None:
-            batch.flush()
+            batch.flush(side=self._side)
         ops.stamp("image.bwd.end")
         return lo + up
 

@@ -70,6 +70,9 @@ class _BiGRUFn(torch.autograd.Function):
         if batch is not None:
             batch.flush()
         db_ih_f, db_hh_f, db_ih_r, db_hh_r = ops.gru_bias_grads(dbias)     # per-chunk (dr, dz, dn_input, dn_hidden) sums -> nn.GRU biases
+        if ops.DEBUG_KEEP is not None:                                     # (tools/r6/determinism.py: which tensor stops being reproducible)
+            ops.DEBUG_KEEP.update(gru_dhfinal=dhfinal, gru_hs=hs, gru_gates=gates, gru_dgi=dgi, gru_dgh=dgh, gru_hprev=hprev, gru_dbias=dbias,
+                                  gru_dx=dx, gru_dw_ih=dw_ih, gru_dw_hh0=dw_hh[0], gru_dw_hh1=dw_hh[1], gru_x2d=x2d)
         demb = dx.view(L, B, I) if dx is not None else None
         return (demb, dw_ih[:384], dw_hh[0], db_ih_f, db_hh_f, dw_ih[384:], dw_hh[1], db_ih_r, db_hh_r, None)
 

@@ -180,6 +180,24 @@ class TriCoLoNet(TriModule):
             output_dict["voxel_features"] = vox
         return output_dict
 
+    def join_side_streams(self):
+        """The current stream waits for everything issued on the towers' side streams.  Call between backward() and the optimizer step
+        (parallel.dp_training_step does): autograd's own end-of-backward synchronisation covers the streams its AccumulateGrad nodes ran
+        on, which need not be the streams the towers' backward kernels ran on once those nodes outlive an iteration (torch warns about
+        exactly that) - round 6 found the text tower's parameters ending a replayed step on other bits once in ~300 replays."""
+        if not torch.cuda.is_available():
+            return
+        cur = torch.cuda.current_stream()
+        streams = list(self._side_streams or ())
+        for enc in (self.image_encoder, self.voxel_encoder, self.text_encoder):
+            for name in ("_side", "_side_ds", "_side_prep"):
+                side = getattr(enc, name, None) if enc is not None else None
+                if side is not None and getattr(side, "stream", None) is not None:
+                    streams.append(side.stream)
+        for st in streams:
+            if st is not None and st != cur:
+                cur.wait_stream(st)
+
     def _gate(self, z):
         return self.dp_split.gate(z) if (self.dp_split is not None and torch.is_grad_enabled() and z.requires_grad) else z
 

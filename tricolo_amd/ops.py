@@ -479,6 +479,9 @@ _WGRAD_JOBS = os.environ.get("TRICOLO_WGRAD_JOBS", "1") != "0"           # A/B s
 _WGRAD_JOB_TILES = dict(zip(range(1, 8), [int(v) for v in os.environ.get("TRICOLO_WGRAD_JOB_TILES", "512,448,256,512,512,512,512").split(",")] + [512] * 7))   # (6, 7: stride-2 krow)
 
 
+_WGRAD_REDUCE_OVERLAP = os.environ.get("TRICOLO_WGRAD_REDUCE_OVERLAP", "1") != "0"   # A/B switch (round 6): WgradBatch.flush(side=...)
+
+
 class WgradBatch:
     """Deferred weight-gradient reduces of one tower backward (tri_conv_wgrad_partial / tri_wgrad_reduce_grouped).
 
@@ -557,12 +560,38 @@ class WgradBatch:
         """Drop every arena (between runs / modes: the chunks are plain torch allocations)."""
         WgradBatch._arenas.clear()
 
-    def flush(self):
-        self.launch_jobs()
-        n = len(self.descs)
+    def _reduce(self, descs):
+        n = len(descs)
         if n:
-            arr = (_C.TriWgradReduce * n)(*self.descs)
+            arr = (_C.TriWgradReduce * n)(*descs)
             check(lib().tri_wgrad_reduce_grouped(arr, n, stream()), "tri_wgrad_reduce_grouped")
+
+    def flush(self, side=None):
+        """Launch what is pending and sum every slab into its parameter gradient.  side (a layers.SideStream forked from the CAPTURE'S ORIGIN
+        stream - the image tower's; round 6): the pending families go smallest first with the two largest swapped, and the reduce of everything
+        launched before the LAST partial kernel runs on the side stream beside that kernel (the image tower's tail: 80 % of the slab bytes
+        belong to the 128-channel kernel-row launch, whose reduce - HBM-bound - then hides under the 64-channel launch - MFMA-bound)."""
+        fams = [f for f in sorted(self.queues) if self.queues[f][0]]
+        if side is None or not _WGRAD_REDUCE_OVERLAP or len(fams) < 2:
+            self.launch_jobs()
+            self._reduce(self.descs)
+            self.ci, self.off, self.descs = 0, 0, []
+            return
+        def work(f):                                              # dense layers carry their FLOPs as numbers (row-list layers: callables)
+            fl = [j[2] for j in self.queues[f][0]]
+            return sum(v for v in fl if not callable(v)) + 1e9 * self.queues[f][1] * any(callable(v) for v in fl)
+        fams.sort(key=work)
+        fams[-1], fams[-2] = fams[-2], fams[-1]
+        for f in fams[:-1]:
+            self.launch_jobs(f)
+        early, self.descs = self.descs, []
+        ev = torch.cuda.Event()
+        ev.record()                                               # (the early reduce depends on the partial kernels issued so far ...)
+        self.launch_jobs(fams[-1])                                # (... and is issued behind the last one: released after it under graph replay)
+        with torch.cuda.stream(side.fork(event=ev)):
+            self._reduce(early)
+        self._reduce(self.descs)
+        side.join()
         self.ci, self.off, self.descs = 0, 0, []
 
 
@@ -1251,6 +1280,7 @@ def stamp(name: str):
     check(lib().tri_debug_stamp(tl["buf"].data_ptr() + 8 * idx, stream()), "tri_debug_stamp")
 
 
+DEBUG_KEEP = None            # dict: debugging tools park intermediate tensors here (tools/r6/determinism.py)
 _ONES = {}
 
 

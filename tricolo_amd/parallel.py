@@ -255,6 +255,8 @@ def dp_training_step(net, batch, optimizer=None, split: BackwardSplit | None = N
         optimizer.apply_flat(flat)
         return losses
     losses["train_loss/total_loss"].backward(gradient=ops.one(losses["train_loss/total_loss"].device))
+    if hasattr(net, "join_side_streams"):
+        net.join_side_streams()                                              # (every tower's gradient kernels are ordered before the optimizer's)
     if optimizer is not None and getattr(optimizer, "_flatten", False):
         optimizer.step(reduce_fn=allreduce_flat if is_dist() else None)    # one bucket: pack -> all-reduce -> fused update
         return losses
