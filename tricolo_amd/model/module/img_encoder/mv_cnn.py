@@ -26,6 +26,7 @@ from ....layers import SideStream, TriModule, linear_bwd, linear_fwd, require_gp
 _DS_FWD = int(os.environ.get("TRICOLO_DS_FWD", "2"))           # where the shortcut branch of layer2-4's first block is issued (round 6; see _run_block)
 _DS_BWD = int(os.environ.get("TRICOLO_DS_BWD", "2"))
 _PREP_DGRAD_LATE = os.environ.get("TRICOLO_PREP_DGRAD_LATE", "1") != "0"   # trunk data-gradient operands packed behind layer4 (0: with the forward operands)
+_STEM_BESIDE_WGRAD = os.environ.get("TRICOLO_STEM_BESIDE_WGRAD", "1") != "0"   # the stem's backward beside the tower's weight-gradient launches (0: in front of them)
 _PREP_ISSUE = int(os.environ.get("TRICOLO_PREP_ISSUE", "1"))    # where the trunk's operand packing is issued: 0 first thing, 1 behind the stem conv, 2 behind the max-pool
 
 
@@ -414,7 +415,7 @@ class MVCNNEncoder(TriModule):
             batch.flush()
         return dx2, [gr[p] for p in self._upper_params()]
 
-    def _backward_lower(self, saved, dout, batch=None):
+    def _backward_lower(self, saved, dout, batch=None, stem_side=None):
         prec = self._prec()
         ugs = 1.0 / ops.grad_scale(prec)
         gr = {}
@@ -428,9 +429,23 @@ class MVCNNEncoder(TriModule):
         stem_mode = os.environ.get("TRICOLO_STEM_FUSED", "2")          # A/B: 0 three passes + max-pool backward, 1 BN passes from the pooled gradient
         if y.shape[2] % 2 == 0 and y.shape[3] % 2 == 0 and stem_mode == "2":
             # ... and the BatchNorm-backward apply pass inside the weight-gradient kernel's staging: the stem's dy is never stored
-            gr[self.net_1[0].weight], gr[self.net_1[1].weight], gr[self.net_1[1].bias] = ops.maxpool_bn_bwd_wgrad(
-                x0, y, parg, dout, co, self.net_1[1].weight, g0, self.net_1[0].weight, prec, out_scale=ugs, batch=batch,
-                pooled=saved["blocks"][0][0])                      # (the max-pool output = the first block's saved input)
+            # Round 6 (stem_side, _STEM_BESIDE_WGRAD): the stem's backward - three HBM-bound launches, ~85 us - has nothing behind it but the
+            # tower's weight-gradient launches, which are MFMA-bound and need nothing from it: those are issued first (WgradBatch.prelaunch)
+            # and the stem chain runs on the side stream beside them, hanging on the event recorded here
+            cm = None
+            if stem_side is not None and _STEM_BESIDE_WGRAD and batch is not None:
+                ev = torch.cuda.Event()
+                ev.record()
+                if batch.prelaunch():
+                    cm = torch.cuda.stream(stem_side.fork(dout, event=ev))
+            import contextlib
+            with (cm if cm is not None else contextlib.nullcontext()):
+                gr[self.net_1[0].weight], gr[self.net_1[1].weight], gr[self.net_1[1].bias] = ops.maxpool_bn_bwd_wgrad(
+                    x0, y, parg, dout, co, self.net_1[1].weight, g0, self.net_1[0].weight, prec, out_scale=ugs, batch=batch,
+                    pooled=saved["blocks"][0][0])                  # (the max-pool output = the first block's saved input)
+            if cm is not None and not torch.cuda.is_current_stream_capturing():
+                for t_ in (gr[self.net_1[0].weight], gr[self.net_1[1].weight], gr[self.net_1[1].bias]):
+                    t_.record_stream(torch.cuda.current_stream())   # (allocated on the side stream, read by the optimizer on this one)
             if own and batch is not None:
                 batch.flush()
             return [gr[p] for p in self._lower_params()]
@@ -453,7 +468,7 @@ class MVCNNEncoder(TriModule):
         # (round 4: launching layer3 / layer4's weight-gradient jobs here on a side stream, beside the lower half's data-gradient /
         #  BatchNorm chain instead of behind it, does not shorten the step - 2.766 against 2.747 ms, three alternating pairs: the
         #  kernel-row kernel's workgroups fill every CU's registers and the chain's kernels wait for them either way)
-        lo = self._backward_lower(saved["lower"], dx2, batch)
+        lo = self._backward_lower(saved["lower"], dx2, batch, stem_side=self._side)
         if batch is not None:
             batch.flush(side=self._side)
         ops.stamp("image.bwd.end")

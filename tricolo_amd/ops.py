@@ -504,6 +504,7 @@ class WgradBatch:
         self.chunks = WgradBatch._arenas.setdefault((device, torch.cuda.current_stream().cuda_stream, torch.cuda.is_current_stream_capturing()), [])
         self.ci, self.off, self.descs = 0, 0, []
         self.queues = {}                                          # kernel family -> [pending jobs, their output tiles]
+        self._pre = None                                          # prelaunch() state: (descs to reduce early, event, family left for flush)
 
     @property
     def jobs(self):
@@ -566,17 +567,15 @@ class WgradBatch:
             arr = (_C.TriWgradReduce * n)(*descs)
             check(lib().tri_wgrad_reduce_grouped(arr, n, stream()), "tri_wgrad_reduce_grouped")
 
-    def flush(self, side=None):
-        """Launch what is pending and sum every slab into its parameter gradient.  side (a layers.SideStream forked from the CAPTURE'S ORIGIN
-        stream - the image tower's; round 6): the pending families go smallest first with the two largest swapped, and the reduce of everything
-        launched before the LAST partial kernel runs on the side stream beside that kernel (the image tower's tail: 80 % of the slab bytes
-        belong to the 128-channel kernel-row launch, whose reduce - HBM-bound - then hides under the 64-channel launch - MFMA-bound)."""
+    def prelaunch(self):
+        """First half of flush(side=...): every pending family but the last is launched now (smallest first, the two largest swapped - see
+        flush).  The caller may issue other work between this and flush(); -> True when something is left for flush() to overlap."""
+        if self._pre is not None:
+            return True
         fams = [f for f in sorted(self.queues) if self.queues[f][0]]
-        if side is None or not _WGRAD_REDUCE_OVERLAP or len(fams) < 2:
-            self.launch_jobs()
-            self._reduce(self.descs)
-            self.ci, self.off, self.descs = 0, 0, []
-            return
+        if not _WGRAD_REDUCE_OVERLAP or len(fams) < 2:
+            return False
+
         def work(f):                                              # dense layers carry their FLOPs as numbers (row-list layers: callables)
             fl = [j[2] for j in self.queues[f][0]]
             return sum(v for v in fl if not callable(v)) + 1e9 * self.queues[f][1] * any(callable(v) for v in fl)
@@ -587,11 +586,27 @@ class WgradBatch:
         early, self.descs = self.descs, []
         ev = torch.cuda.Event()
         ev.record()                                               # (the early reduce depends on the partial kernels issued so far ...)
-        self.launch_jobs(fams[-1])                                # (... and is issued behind the last one: released after it under graph replay)
+        self._pre = (early, ev, fams[-1])
+        return True
+
+    def flush(self, side=None):
+        """Launch what is pending and sum every slab into its parameter gradient.  side (a layers.SideStream forked from the CAPTURE'S ORIGIN
+        stream - the image tower's; round 6): the pending families go smallest first with the two largest swapped, and the reduce of everything
+        launched before the LAST partial kernel runs on the side stream beside that kernel (the image tower's tail: 80 % of the slab bytes
+        belong to the 128-channel kernel-row launch, whose reduce - HBM-bound - then hides under the 64-channel launch - MFMA-bound)."""
+        if side is None or not self.prelaunch():
+            self.launch_jobs()
+            self._reduce(self.descs)
+            self.ci, self.off, self.descs = 0, 0, []
+            return
+        early, ev, last = self._pre
+        self._pre = None
+        late, self.descs = self.descs, []                         # (partial kernels issued between prelaunch() and here - the stem's)
+        self.launch_jobs(last)                                    # (... and is issued behind the last one: released after it under graph replay)
         with torch.cuda.stream(side.fork(event=ev)):
             self._reduce(early)
-        self._reduce(self.descs)
         side.join()
+        self._reduce(late + self.descs)
         self.ci, self.off, self.descs = 0, 0, []
 
 
