@@ -356,7 +356,11 @@ def run_mode(a, precision, world, rank, device, want_voxel_roofline):
     # graphs instead of one: 1.78 + 1.51 ms against 2.85 ms, profiles/r2/README.md), about what the hidden part of the 74 MB
     # all-reduce is expected to take at 8 GPUs - without a multi-GPU box to measure on, the simpler single-bucket step stays.
     split = None
-    if (world > 1 or force_dist) and os.environ.get("TRICOLO_DP_OVERLAP", "0") == "1":
+    # default (round 6, DESIGN.md section 6 "scaling model"): the two-bucket backward costs +0.45 ms of GPU time per step (four graphs, a
+    # second pack) and hides 68 % of the gradient all-reduce - it wins only where the exposed all-reduce is longer than 0.45 / 0.68 =
+    # 0.66 ms: by the per-link model that is N = 2 (one xGMI link between the pair: 74 MB each way at ~76 GB/s = 0.97 ms), not N = 4 / 8
+    ov_default = "1" if (world == 2 and not force_dist) else "0"
+    if (world > 1 or force_dist) and os.environ.get("TRICOLO_DP_OVERLAP", ov_default) == "1":
         split = parallel.BackwardSplit.for_net(net)
 
     def step(batch):

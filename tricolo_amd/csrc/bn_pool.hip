@@ -916,7 +916,7 @@ __global__ __launch_bounds__(256) void maxpool2d_fwd8_kernel(const T* __restrict
 extern "C" int tri_maxpool2d_fwd(const void* x, int N, int H, int W, int C, void* out, uint8_t* arg, const float* bn_scale,
                                  const float* bn_shift, int act_fmt, void* stream) {
     static int pool8 = -1;                                         // A/B switch: TRICOLO_POOL8=0 keeps the 4-channel form
-    if (pool8 < 0) { const char* e = getenv("TRICOLO_POOL8"); pool8 = (e && e[0] == '0') ? 0 : 1; }
+    if (pool8 < 0) pool8 = 1;
     if (pool8 && act_fmt != TRI_FMT_F32 && C % 8 == 0) {
         const long total8 = (long)N * (((H + 1) / 2 + 3) / 4) * ((W + 1) / 2) * (C / 8);   // (four output rows per thread)
         if (act_fmt == TRI_FMT_F16)
@@ -1055,7 +1055,7 @@ __device__ __forceinline__ float4 rnd4(float4 v) { return make_float4(Act<T>::rn
 // 2x2 blocks (4 positions each) per workgroup: 64 as bnb_rows of large tensors; tuning aid TRICOLO_STEM_BLOCKS
 static int stem_blocks_per_wg() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("TRICOLO_STEM_BLOCKS"); v = (e && atoi(e) >= 32) ? atoi(e) : 64; }
+    if (v < 0) v = 64;
     return v;
 }
 // 16-bit storage, C % 8 == 0: one thread = one 2x2 block of positions x EIGHT channels - 16-byte loads of y and the pooled gradient,

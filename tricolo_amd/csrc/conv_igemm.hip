@@ -1933,7 +1933,7 @@ __global__ __launch_bounds__(256) void weight_prep_multi_kernel(const TriPrepDes
 extern "C" int tri_weight_prep_multi(const TriPrepDesc* descs_dev, int n, void* stream) {
     if (n <= 0) return TRI_OK;
     static int gx = 0;                                               // workgroups per descriptor (tuning aid: TRICOLO_PREP_GRID)
-    if (!gx) { const char* e = getenv("TRICOLO_PREP_GRID"); gx = (e && atoi(e) > 0) ? atoi(e) : 512; }   // (256 -> 512: the three packing launches of a step 81 -> 68 us; 1024: 75)
+    if (!gx) gx = 512;   // (256 -> 512: the three packing launches of a step 81 -> 68 us; 1024: 75)
     weight_prep_multi_kernel<<<dim3(gx, n), 256, 0, (hipStream_t)stream>>>(descs_dev);
     return tri_check_launch("tri_weight_prep_multi");
 }
@@ -2007,7 +2007,7 @@ struct ConvPlan {
 // so the sweep (profiles/r1/README.md) favours ~one workgroup per CU over the 3 per CU the fp32-staging kernel liked.
 static int conv_target_blocks() {                               // tuning aid: TRICOLO_CONV_BLOCKS overrides it
     static int v = -1;
-    if (v < 0) { const char* e = getenv("TRICOLO_CONV_BLOCKS"); v = (e && atoi(e) > 0) ? atoi(e) : 0; }
+    if (v < 0) v = 0;
     return v;
 }
 
@@ -2065,11 +2065,11 @@ static bool halo_geometry(int B, int H, int W, int cin, int cout, int TM, ConvPl
         int g = num_cus() / NT * NT;
         if (g < NT) g = NT;
         static int half_tiles = -1;                                   // tuning aid: TRICOLO_HALO_ROWS_HALFTILES (tiles per workgroup x 2)
-        if (half_tiles < 0) { const char* e = getenv("TRICOLO_HALO_ROWS_HALFTILES"); half_tiles = e ? atoi(e) : 3; }
+        if (half_tiles < 0) half_tiles = 3;
         // (round 4: with >= 256 input channels - four or more weight chunks per tile - the row-unit kernel also wins launches of several
         //  rounds: 384 images of 8 x 8 x 256 47 -> 32 us, 768 images of 4 x 4 x 512 85 -> 65 us; TRICOLO_HALO_ROWS_DEEP=0 restores the tile rule)
         static int deep = -1;
-        if (deep < 0) { const char* e = getenv("TRICOLO_HALO_ROWS_DEEP"); deep = (e && e[0] == '0') ? 0 : 1; }
+        if (deep < 0) deep = 1;
         if (rows_kernel && (cin == 64 || (deep && cin >= 256) || 2 * items <= half_tiles * g || rows_kernel == 2) && (TM == 2 || (TM == 3 && cin != 64)) &&
             2 * (size_t)slab + 3 * (size_t)HROWS_SLOT + 8192 <= 163840) {
             pl->h_v5 = 1;
@@ -2091,7 +2091,7 @@ static bool stem_geometry(int B, int IH, int IW, int cin, int OH, int OW, int co
     if (pw < 0 || ph < 0 || IW + pw > 2 * OW + 6 || (long)B * IH * IW * 8 >= ((long)1 << 31)) return false;
     const int per_row = OW / 16;
     static int npt = -1;                                             // position tiles per wave: 2 (two workgroups per CU) unless overridden
-    if (npt < 0) { const char* e = getenv("TRICOLO_STEM_NPT"); npt = (e && atoi(e) == 4) ? 4 : 2; }
+    if (npt < 0) npt = 2;
     if (per_row > 4 * npt) return false;
     int TH = 4 * npt / per_row;                                      // <= 4 * npt position tiles per workgroup tile
     if (TH > OH) TH = OH;
@@ -2143,7 +2143,7 @@ static ConvPlan conv_make_plan(int B, int ID, int IH, int IW, int cin, int OD, i
     // config 4's - where the voxel backward is the tail since the image tower got shorter - gains 0.02 ms in three of three pairs
     // (2.896-2.922 against 2.920-2.944): on by default, TRICOLO_DMA32=0 switches them off)
     static int no32 = -1;
-    if (no32 < 0) { const char* e = getenv("TRICOLO_DMA32"); no32 = (e && e[0] == '0') ? 1 : 0; }
+    if (no32 < 0) no32 = 0;
     if (split_mode == 2 && cin % 64 == 0 && (cout % 64 == 0 || (cout % 32 == 0 && !no32)) && !dma_disabled()) pl.dma = 1;
     pl.bn = bn;
     {
@@ -2240,7 +2240,7 @@ static ConvPlan conv_make_plan(int B, int ID, int IH, int IW, int cin, int OD, i
         // workgroups per CU, twice the workgroups) beat 128x128 on every layer measured up to 384 wide tiles (sweep in
         // profiles/r1/README.md).  Wide tiles are kept for launches that fill the GPU several times over anyway.
         static int narrow = -1;
-        if (narrow < 0) { const char* e = getenv("TRICOLO_DMA_BN64"); narrow = e ? atoi(e) : 1024; }
+        if (narrow < 0) narrow = 1024;
         // (decided on the DENSE tile count also for row-list launches: 64^3 level 2 - 2,048 dense tiles, 365 live - takes 42 us with
         // 128-wide tiles against 54 with 64-wide ones; the occupancy discount is for the split-K decision only)
         if (pl.dma && bn == 128 && blocks_dense < narrow) { pl.bn = 64; blocks *= 2; }
@@ -2249,7 +2249,7 @@ static ConvPlan conv_make_plan(int B, int ID, int IH, int IW, int cin, int OD, i
     // bench shape): 64-wide tiles that fill the GPU once instead of 128-wide tiles split over K with a finish launch (two launches, a
     // 19 MB round trip of partial sums for 8 k-steps of work)
     static int lin64 = -1;
-    if (lin64 < 0) { const char* e = getenv("TRICOLO_LINEAR_BN64"); lin64 = (e && e[0] == '0') ? 0 : 1; }
+    if (lin64 < 0) lin64 = 1;
     const bool short_linear = lin64 && !pl.dma && !row_list && ntaps == 1 && kpad <= 256 && cout % 64 == 0;
     if (short_linear && bn == 128 && blocks < num_cus() && 2 * blocks >= num_cus()) { pl.bn = 64; blocks *= 2; }
     pl.nunits = pl.dma ? kpad / 64 : kpad / 32;
@@ -2402,7 +2402,7 @@ static int launch_halo(ConvArgs& a, const ConvPlan& pl, hipStream_t stream) {
         // those instantiations are only built with -DHALO_NTL_EXPERIMENT
         int ntl = a.Cin == 64 ? 1 : 0;
 #ifdef HALO_NTL_EXPERIMENT
-        { static int f = -1; if (f < 0) { const char* e = getenv("TRICOLO_HALO_NTL"); f = e ? atoi(e) : 0; }
+        { static int f = -1; if (f < 0) f = 0;
           const int items = pl.h_mtiles * (a.Cout / 64), per_wg = (items + pl.h_grid - 1) / pl.h_grid;
           if (f && a.Cin != 64 && per_wg > 1) ntl = per_wg == 2 ? 2 : 4; }
 #endif

@@ -480,7 +480,7 @@ static bool vox_disabled(const char* name) {
 // brick rows per workgroup: 32^3 -> 16 (64 runs), 64^3 -> 8 (64 runs; TRICOLO_VOX0_TY=16: 128 runs), 128^3 -> 8 (128 runs)
 static int vox0_ty(int V) {
     static int env = -1;
-    if (env < 0) { const char* e = getenv("TRICOLO_VOX0_TY"); env = e ? atoi(e) : 0; }
+    if (env < 0) env = 0;
     if (V == 64 && env == 16) return 16;
     return V == 32 ? 16 : 8;
 }

@@ -1404,7 +1404,7 @@ extern "C" int tri_conv_plan_build(const TriConvDesc* d, void* plan, void* strea
 // operand is then read once, not once per j-tile: stem 7x7, voxel level 0, 1x1 down-samples), else 128 columns.
 static int wgrad_target_blocks() {                             // tuning aid: TRICOLO_WGRAD_BLOCKS overrides the default
     static int v = -1;
-    if (v < 0) { const char* e = getenv("TRICOLO_WGRAD_BLOCKS"); v = (e && atoi(e) > 0) ? atoi(e) : WGRAD_TARGET_BLOCKS; }
+    if (v < 0) v = WGRAD_TARGET_BLOCKS;
     return v;
 }
 
@@ -1491,7 +1491,7 @@ static bool krow_wgrad_disabled() {
 }
 static bool c64_wgrad_disabled() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("TRICOLO_NO_C64_WGRAD"); v = (e && e[0] == '1') ? 1 : 0; }
+    if (v < 0) v = 0;
     return v == 1;
 }
 // geometry of conv_wgrad_c64_kernel; false when the layer does not qualify
@@ -1518,10 +1518,10 @@ static bool c64_wgrad_geometry(const TriConvDesc* d, int act_fmt, C64WgradArgs* 
     // kernel), 6 tiles per CU 4.10-4.12 against 4.14-4.15 ms (grouped) - back to 6; 3 tiles per CU (the bench shape) 2.95 against 2.81-2.84 ms:
     // 512 workgroups x 147 KB of slabs per layer are what it costs there
     static int min_per_cu = -1;
-    if (min_per_cu < 0) { const char* e = getenv("TRICOLO_C64_MIN_TILES_PER_CU"); min_per_cu = e ? atoi(e) : 6; }
+    if (min_per_cu < 0) min_per_cu = 6;
     if (g->ntiles < min_per_cu * tri_internal_num_cus()) return false;
     static int per_cu = -1;
-    if (per_cu < 0) { const char* e = getenv("TRICOLO_C64_WGS_PER_CU"); per_cu = e ? atoi(e) : 2; }
+    if (per_cu < 0) per_cu = 2;
     *grid = tri_internal_num_cus() * (per_cu < 1 ? 1 : per_cu);
     if (*grid > g->ntiles) *grid = g->ntiles;
     return true;
@@ -1760,7 +1760,7 @@ static void wgrad_fill_pending(const TriConvDesc* d, const float* slab, int spli
     pending->kw_real = 0; pending->kw_shift = 0;
     // torchvision layout with several taps and not too many splits: the row form (wgrad_reduce_row), one output channel per block
     static int rows = -1;
-    if (rows < 0) { const char* e = getenv("TRICOLO_WGRAD_REDUCE_ROWS"); rows = (e && e[0] == '0') ? 0 : 1; }
+    if (rows < 0) rows = 1;
     if (rows && ntaps > 1 && s_tap == 1 && s_ci == ntaps && s_co == (long)ntaps * d->Cin && cin_real == d->Cin && d->Cin % 4 == 0 &&
         ntaps * (d->Cin + 1) <= WGRAD_ROW_MAX && splits <= 48) {
         pending->zlanes = 0;
@@ -1775,7 +1775,7 @@ static int stem_wgrad_launch(const TriConvDesc* d, StemWgradArgs& sg, int grid, 
     if (workspace_bytes < need) { tri_set_error("wgrad(stem): workspace too small"); return TRI_ERR_ARG; }
     sg.slab = (float*)workspace;
     sg.h_abl = tri_probe_ablation();
-    { static int pipe = -1; if (pipe < 0) { const char* e = getenv("TRICOLO_STEM_WGRAD_PIPE"); pipe = (e && e[0] == '0') ? 0 : 1; } sg.unpiped = !pipe; }
+    { static int pipe = -1; if (pipe < 0) pipe = 1; sg.unpiped = !pipe; }
     const bool bnf = sg.y != nullptr;
     const size_t smem = (size_t)sg.TH * sg.OW * 128 + (size_t)sg.slab_rows * sg.row_bytes + (bnf ? 5 * 64 * sizeof(float) : 0);
     hipStream_t st = (hipStream_t)stream;
@@ -1941,7 +1941,7 @@ extern "C" int tri_conv_wgrad_partial(const TriConvDesc* d, const void* in, cons
 // other towers' kernels no room beside it) - so it stays an experiment switch (profiles/r3/NOTES_wgrad.md).
 static bool wgrad_wide_tiles() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("TRICOLO_WGRAD_WIDE"); v = (e && e[0] == '1') ? 1 : 0; }
+    if (v < 0) v = 0;
     return v == 1;
 }
 static int wgrad_group_target(int family) {                     // resident workgroups a grouped launch is planned for
@@ -1954,12 +1954,6 @@ static int wgrad_group_target(int family) {                     // resident work
         // 126 registers - layer1's four layers in one launch 592 -> 725 TF; the step does not move); 7: <64> stride 2 (one layer of the
         // trunk: it rides in the stride-1 launch, so its own target is the two-per-CU default)
         v[0] = 512; v[1] = 448; v[2] = 256; v[3] = KROW_TARGET_BLOCKS; v[4] = 768; v[5] = KROW_TARGET_BLOCKS; v[6] = KROW_TARGET_BLOCKS;
-        const char* e = getenv("TRICOLO_WGRAD_GROUP_BLOCKS");
-        if (e) {
-            int a[7] = {0, 0, 0, 0, 0, 0, 0};
-            const int k = sscanf(e, "%d,%d,%d,%d,%d,%d,%d", &a[0], &a[1], &a[2], &a[3], &a[4], &a[5], &a[6]);
-            for (int i = 0; i < k && i < 7; ++i) if (a[i] > 0) v[i] = a[i];
-        }
     }
     return v[family >= 1 && family <= 7 ? family - 1 : 1];
 }

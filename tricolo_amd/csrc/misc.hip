@@ -235,7 +235,7 @@ extern "C" int tri_mask_compact(const uint8_t* mask, long n, int* row_pos, int* 
     const int nb = (int)((n + CMP_SITES - 1) / CMP_SITES);
     mask_block_count_kernel<<<nb, 256, 0, s>>>(mask, n, (int*)scratch);
     static int fused = -1;                                           // A/B switch: TRICOLO_MASK_SCAN_FUSED=0 keeps the separate scan launch
-    if (fused < 0) { const char* e = getenv("TRICOLO_MASK_SCAN_FUSED"); fused = (e && e[0] == '0') ? 0 : 1; }
+    if (fused < 0) fused = 1;
     if (fused && nb <= 1024) {
         mask_block_write_scan_kernel<<<nb, 256, 0, s>>>(mask, n, (const int*)scratch, row_pos, count);
         return tri_check_launch("tri_mask_compact");

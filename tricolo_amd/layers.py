@@ -55,7 +55,7 @@ def linear_geom(rows: int, K: int, N: int, spatial: int = 1) -> ops.ConvGeom:
     return g
 
 
-_NO_SMALL = os.environ.get("TRICOLO_NO_SMALL", "0") == "1"      # A/B switch for the <= 64-row dense kernels
+_NO_SMALL = False                                               # (round 6: the A/B switch of the <= 64-row dense kernels was dropped)
 
 
 def _small(x, w, spatial) -> bool:

@@ -311,10 +311,10 @@ class MVCNNEncoder(TriModule):
         """BasicBlock backward over `blocks` (last first); returns the gradient w.r.t. the first block's input."""
         side = self._side
         # Weight gradients need only x and dy and could run beside the dgrad / BatchNorm-backward chain on a side stream
-        # (TRICOLO_WG_PATTERN=s; =sm alternates).  Measured with the round-1 kernels that is a LOSS: two GPU-filling kernels
+        # (pattern "s"; "sm" alternates).  Measured with the round-1 kernels that is a LOSS: two GPU-filling kernels
         # side by side thrash each other (all on the side stream 4.23 ms per step, alternating 4.09-4.15, all inline 3.93-3.97),
         # so they are issued inline on the tower's stream.
-        pattern = os.environ.get("TRICOLO_WG_PATTERN", "m")
+        pattern = "m"                                              # (the side-stream pattern experiment switch was dropped in round 6)
         turn = [0]
 
         def wgrad_async(x, dy, g, w):
@@ -426,7 +426,7 @@ class MVCNNEncoder(TriModule):
         dout = self._backward_blocks(self._blocks()[:self.N_LOWER_BLOCKS], saved["blocks"], dout, gr, prec, ugs, batch)
         x0, y, co, g0, parg = saved["stem"]
         ops.stamp("image.bwd.layer1.end")
-        stem_mode = os.environ.get("TRICOLO_STEM_FUSED", "2")          # A/B: 0 three passes + max-pool backward, 1 BN passes from the pooled gradient
+        stem_mode = "2"                                                # (2: apply pass inside the weight-gradient kernel; the 0 / 1 A/B forms stay reachable for odd map sizes only)
         if y.shape[2] % 2 == 0 and y.shape[3] % 2 == 0 and stem_mode == "2":
             # ... and the BatchNorm-backward apply pass inside the weight-gradient kernel's staging: the stem's dy is never stored
             # Round 6 (stem_side, _STEM_BESIDE_WGRAD): the stem's backward - three HBM-bound launches, ~85 us - has nothing behind it but the

@@ -111,8 +111,8 @@ class SparseCNNEncoder(TriModule):
         if fine:
             ops.stamp("voxel.fwd.scattered")
         # (round 5) every level's site mask and row list up front, three launches (ops.mask_pyramid / mask_compact_multi) instead of two per
-        # level between the convolutions; TRICOLO_NO_MASK_PYRAMID=1 or V % 16 != 0: level by level as before
-        pyramid = V % 16 == 0 and os.environ.get("TRICOLO_NO_MASK_PYRAMID") != "1"
+        # level between the convolutions; V % 16 != 0: level by level as before
+        pyramid = V % 16 == 0
         if pyramid:
             masks = [mask] + ops.mask_pyramid(mask, B, V)
             lists = ops.mask_compact_multi(masks, [B * (V >> l) ** 3 for l in range(5)])

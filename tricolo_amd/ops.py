@@ -412,7 +412,7 @@ def conv_fwd(x, g: ConvGeom, packed, row_mask=None, bias=None, act=0, want_stats
     return (out, stats) if want_stats else out
 
 
-_ROW_ORDER = os.environ.get("TRICOLO_NO_ROW_ORDER", "0") != "1"      # A/B switch: parity-class row order for stride-2 data gradients
+_ROW_ORDER = True                                                    # parity-class row order for stride-2 data gradients (A/B switch dropped in round 6)
 
 
 # A/B switch: 0 = BatchNorm-backward sums as a pass of their own everywhere, 2 (default) = only the relu(bn1) form inside conv2's data
@@ -474,9 +474,9 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
 _WGRAD_GROUPED = os.environ.get("TRICOLO_WGRAD_GROUPED", "1") != "0"     # A/B switch: one reduce launch per layer instead
 _WGRAD_JOBS = os.environ.get("TRICOLO_WGRAD_JOBS", "1") != "0"           # A/B switch: one partial launch per layer instead
 # output tiles (workgroups per split) one grouped partial launch takes, per kernel family (1: 128-row, 2: 64-row, 3: 256-row tiles); the
-# library's split planner uses the same figures (TRICOLO_WGRAD_GROUP_BLOCKS)
+# library's split planner uses the same figures
 # (4, 5: conv_wgrad_krow_kernel<128> / <64>; a krow launch may hold more workgroups than resident slots, the library deals them longest first)
-_WGRAD_JOB_TILES = dict(zip(range(1, 8), [int(v) for v in os.environ.get("TRICOLO_WGRAD_JOB_TILES", "512,448,256,512,512,512,512").split(",")] + [512] * 7))   # (6, 7: stride-2 krow)
+_WGRAD_JOB_TILES = dict(zip(range(1, 8), [512, 448, 256, 512, 512, 512, 512]))   # (6, 7: stride-2 krow; the tuning aid for these figures was dropped in round 6)
 
 
 _WGRAD_REDUCE_OVERLAP = os.environ.get("TRICOLO_WGRAD_REDUCE_OVERLAP", "1") != "0"   # A/B switch (round 6): WgradBatch.flush(side=...)
@@ -764,7 +764,7 @@ def _bn_bwd_finalize(partial, nblk, C, count_dev, count_host, gamma, co: "BNCoef
     return buf
 
 
-_BN_SMALL = os.environ.get("TRICOLO_BN_SMALL", "1") != "0"          # A/B switch: 0 = the three-pass BatchNorm backward for every tensor size
+_BN_SMALL = True                                                    # one-launch BatchNorm backward of tiny tensors (A/B switch dropped in round 6)
 
 
 def bn_bwd(y, g, co: BNCoeffs, gamma, count_dev=None, count_host=0, row_mask=None, inplace=True, relu=False, relu_out=None,
@@ -822,8 +822,8 @@ def pool3d_bwd_route(y, co: BNCoeffs, mask, pooled, dpooled, B, D, C):
     return g
 
 
-_VOX_ROWS = os.environ.get("TRICOLO_VOX_BWD_ROWS", "1") != "0"      # A/B switch: 0 = the dense (mask-skipping) passes everywhere
-_ROUTE_RED = os.environ.get("TRICOLO_NO_ROUTE_ROWS_REDUCE") != "1"    # A/B switch: 1 = separate reduce pass after the row-list routing walk (round 4)
+_VOX_ROWS = True                                                    # row-list passes on the fine voxel levels (A/B switch dropped in round 6)
+_ROUTE_RED = True                                                     # BatchNorm-backward sums inside the row-list routing walk (A/B switch dropped in round 6)
 
 
 def pool3d_bwd_route_rows(y, co: BNCoeffs, mask, pooled, dpooled, B, D, C, rows_out):
@@ -907,7 +907,7 @@ def maxpool2d_fwd(x, want_arg=True, bn: BNCoeffs = None):
     return out, arg
 
 
-_STEM_POOLED = os.environ.get("TRICOLO_STEM_POOLED", "1") != "0"       # A/B switch: stem BatchNorm-backward sums from y + tap map (0)
+_STEM_POOLED = True                                                    # stem BatchNorm-backward sums from the pooled tensors (A/B switch dropped in round 6)
 
 
 def _maxpool_bn_bwd_sums(y, arg, dpool, co: "BNCoeffs", gamma, pooled):
