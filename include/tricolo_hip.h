@@ -178,6 +178,10 @@ int tri_conv_wgrad_partial(const TriConvDesc* d, const void* in, const void* dou
                            int act_fmt, float out_scale, const int* row_pos, const int* row_count, TriWgradReduce* pending /* HOST, out */,
                            void* stream);
 int tri_wgrad_reduce_grouped(const TriWgradReduce* pending /* HOST array */, int n, void* stream);
+/* Same, and every workgroup that STORED an inf / NaN gradient element flags the optimizer's current attempt in `note` (the int32[4]
+ * device record of tri_adam_guard / tri_adam_tick: note[2] = max(note[2], note[0] + note[3] + 1)) - the overflow scan of these tensors
+ * (torch.cuda.amp.GradScaler's found_inf; tricolo_amd/optim.py) then needs no pass of its own.  note may be NULL. */
+int tri_wgrad_reduce_grouped_noted(const TriWgradReduce* pending /* HOST array */, int n, int* note, void* stream);
 /* Several layers' partial kernels in ONE launch (16-bit activation storage).  The launch's resident
  * workgroups are shared by the jobs, so each layer is cut into fewer, longer splits than alone: the fp32 slab traffic of the step
  * (splits x Cout x K per layer, written here and re-read by the reduce) shrinks by about the number of jobs.

@@ -1332,6 +1332,74 @@ def test_wgrad_jobs_share_one_partial_launch(group, store, prec):
         assert torch.equal(o.cpu(), r * (0.5 if i % 2 else 1.0)), f"job {i}: max abs diff {(o.cpu() - r).abs().max().item()}"
 
 
+@pytest.mark.parametrize("store,prec", STORE16[:1], ids=STORE16_IDS[:1])
+def test_overflow_noted_by_the_grouped_weight_gradient_reduce(store, prec):
+    """Round 6: the grouped reduce flags an inf / NaN it STORES in the optimizer's record (tri_wgrad_reduce_grouped_noted) and FusedAdam leaves
+    the tensors it vouched for out of its own scan.  A conv-weight gradient that overflows inside the backward skips the whole step although
+    nobody scans it; a healthy one applies (against torch.optim.Adam); a vouched-for gradient somebody modifies AFTER the reduce (its version
+    counter moved) is scanned again; and a gradient that never went through the reduce is scanned as before."""
+    from tricolo_amd.optim import FusedAdam
+    cases = WGRAD_JOB_CASES["mixed"][:3]
+    made = [make_case(c, integer=True, seed=410 + i) for i, c in enumerate(cases)]
+    gen = torch.Generator().manual_seed(77)
+    ws = [torch.nn.Parameter((0.01 * torch.randn(m[2].shape, generator=gen)).to(DEV)) for m in made]     # parameters in the packed layout's shape
+    other = torch.nn.Parameter(torch.randn(128, generator=gen).to(DEV))
+    rws = [torch.nn.Parameter(w.detach().cpu().clone()) for w in ws]
+    rother = torch.nn.Parameter(other.detach().cpu().clone())
+    opt = FusedAdam(ws + [other], lr=1e-2)
+    ropt = torch.optim.Adam(rws + [rother], lr=1e-2)
+    opt.prepare()
+
+    def backward(poison=None):
+        opt.zero_grad(set_to_none=True)
+        batch = ops.WgradBatch(torch.device(DEV), group_jobs=True)
+        outs = []
+        for i, (case, (x, w, wp, xcl, g)) in enumerate(zip(cases, made)):
+            dy = ints((g.B, *g.out_grid, g.cout), -2, 2, 900 + i).to(store)
+            if poison == i:
+                dy.view(-1)[11] = float("inf")
+            outs.append(ops.conv_wgrad(xcl.to(DEV).to(store), dy.to(DEV), g, ws[i], prec, batch=batch))
+        batch.flush()
+        for w, o in zip(ws, outs):
+            w.grad = o
+        other.grad = torch.randn(128, generator=gen).to(DEV)
+        return outs
+
+    def step_applied():
+        before = [p.detach().clone() for p in ws + [other]]
+        opt.step()
+        torch.cuda.synchronize()
+        same = [torch.equal(p.detach(), b_) for p, b_ in zip(ws + [other], before)]
+        assert all(same) or not any(same)
+        return not same[0]
+
+    # 1. healthy step: every conv gradient is vouched for, the scan list is just `other`; the update is torch's
+    outs = backward()
+    assert all(getattr(o, "_tri_noted", None) == (opt._step_dev.data_ptr(), o._version) for o in outs) and not hasattr(other.grad, "_tri_noted")
+    for r, p in zip(rws + [rother], ws + [other]):
+        r.grad = p.grad.detach().cpu().clone()
+    assert step_applied()
+    ropt.step()
+    for p, r in zip(ws + [other], rws + [rother]):
+        np.testing.assert_allclose(p.detach().cpu().numpy(), r.detach().numpy(), atol=3e-7)
+    assert opt.skipped_steps() == 0
+    # 2. an inf born inside the backward of layer 1: noted by the reduce, step skipped whole
+    outs = backward(poison=1)
+    assert not torch.isfinite(outs[1]).all() and torch.isfinite(outs[0]).all()
+    assert not step_applied() and opt.skipped_steps() == 1 and opt.nonfinite_skipped() == 0
+    # 3. a vouched-for gradient poked afterwards: its version moved, so it is scanned
+    outs = backward()
+    outs[2].view(-1)[5] = float("nan")
+    assert not step_applied() and opt.skipped_steps() == 2
+    # 4. a gradient the reduce never saw
+    backward()
+    other.grad.view(-1)[3] = float("inf")
+    assert not step_applied() and opt.skipped_steps() == 3
+    # 5. and the next healthy step applies
+    backward()
+    assert step_applied() and opt.skipped_steps() == 3 and opt.nonfinite_skipped() == 0
+
+
 KROW_CASES = [
     # name, images, (1, H, W), cin, cout: every image width the kernel-row slab kernel takes, both tile heights (Cout % 128), several
     # input-channel chunks, a last step that runs past the tensor, image heights that do not divide the rows of a step

@@ -5,7 +5,7 @@
 // per kernel row 4 k-steps 0-3, 5 DMA wait, 6 barrier, 8 k-steps 4-5 + DMA issue, 10 epilogue, 11 statistics written.
 // Build (cross-compiles here, runs on the GPU box):
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DHALO_STAMPS -Iinclude -o tools/probes/build/halo_probe tools/probes/halo_probe.hip \
-//         tricolo_amd/csrc/{misc,conv_c64,conv_vox,conv_pw}.hip          (usage: halo_probe [images = 192] [first layer 0..3])
+//         tricolo_amd/csrc/{misc,conv_c64,conv_vox,conv_pw,conv_s2g}.hip  (usage: halo_probe [images = 192] [first layer 0..3])
 // Prints, per layer: kernel time, and for a few workgroups the cycles between consecutive stamps summed by phase.
 #include "../../tricolo_amd/csrc/conv_igemm.hip"
 #include <vector>

@@ -77,6 +77,7 @@ SIGNATURES = {
     "tri_conv_wgrad": (I, [DP, P, P, P, P, P, Z, P, L, L, L, I, I, I, F, P, P, P]),
     "tri_conv_wgrad_partial": (I, [DP, P, P, P, P, P, Z, P, L, L, L, I, I, I, F, P, P, P, P]),
     "tri_wgrad_reduce_grouped": (I, [P, I, P]),
+    "tri_wgrad_reduce_grouped_noted": (I, [P, I, P, P]),
     "tri_conv_stem_wgrad_bn": (I, [DP, P, P, P, P, P, P, P, P, P, P, Z, P, L, L, L, I, I, F, P, P]),
     "tri_conv_wgrad_group_info": (I, [DP, I, P, P, P]),
     "tri_conv_wgrad_partial_group": (I, [P, I, I, P, P]),

@@ -1249,6 +1249,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_krow_kernel(const KrowJobs 
         }
 }
 
+// Overflow note of the reduces (round 6): the reduce holds every FINAL gradient element in a register right before its only store, so the
+// optimizer's non-finite scan of these tensors (adam_guard_seg_kernel: one more read of 64 of the step's 74 MB of gradients, on the serial
+// tail of the step) is free here.  `note` = the optimizer's device record (misc.hip: [0] applied steps, [2] attempt flagged, [3] steps
+// skipped whole); a workgroup that stored an inf / NaN flags the current attempt exactly as the guard kernel does.
+__device__ __forceinline__ unsigned wgrad_nonfinite(float x) { return (__float_as_uint(x) & 0x7f800000u) == 0x7f800000u ? 1u : 0u; }
+__device__ __forceinline__ void wgrad_note_bad(unsigned bad, int* note) {
+    if (note && __any(bad) && (threadIdx.x & 63) == 0) atomicMax(note + 2, note[0] + note[3] + 1);
+}
 // dw[co*s_co + tap*s_tap + ci*s_ci] = sum_split slab[split][co][tap*cin_stored + ci]   (ci < cin_real)
 // Each thread owns 4 consecutive k (one 16-byte load per split) of one co; a block is (256 / zlanes) such quads x zlanes
 // split lanes: lane z sums splits z, z + zlanes, ... and lane 0 adds the partials in a fixed order (bitwise
@@ -1256,7 +1264,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_krow_kernel(const KrowJobs 
 // and a tiny dW (stem, voxel level 0) still put a few hundred thousand loads in flight.
 __device__ __forceinline__ void wgrad_reduce_block(const float* __restrict__ slab, int splits, int Cout, int Kpad, int ntaps, int cin_stored,
                                                    int cin_real, float* __restrict__ dw, long s_co, long s_tap, long s_ci, int zlanes,
-                                                   float out_scale, unsigned block, float4* part, int kw_real = 0, int kw_shift = 3) {
+                                                   float out_scale, unsigned block, float4* part, unsigned& bad, int kw_real = 0,
+                                                   int kw_shift = 3) {
     const int kq = 256 / zlanes;                                 // quads per block
     const int ql = threadIdx.x % kq, zl = threadIdx.x / kq;
     const int K4 = (ntaps * cin_stored) >> 2;
@@ -1289,12 +1298,14 @@ __device__ __forceinline__ void wgrad_reduce_block(const float* __restrict__ sla
             tap = kh * kw_real + kw;
         }
         float* d = dw + co * s_co + tap * s_tap + ci * s_ci;
-        if (s_ci == 1 && cin_real == cin_stored && (((uintptr_t)d) & 15) == 0) *(float4*)d = s;
-        else {
-            if (ci + 0 < cin_real) d[0] = s.x;
-            if (ci + 1 < cin_real) d[s_ci] = s.y;
-            if (ci + 2 < cin_real) d[2 * s_ci] = s.z;
-            if (ci + 3 < cin_real) d[3 * s_ci] = s.w;
+        if (s_ci == 1 && cin_real == cin_stored && (((uintptr_t)d) & 15) == 0) {
+            *(float4*)d = s;
+            bad |= wgrad_nonfinite(s.x) | wgrad_nonfinite(s.y) | wgrad_nonfinite(s.z) | wgrad_nonfinite(s.w);
+        } else {
+            if (ci + 0 < cin_real) { d[0] = s.x; bad |= wgrad_nonfinite(s.x); }
+            if (ci + 1 < cin_real) { d[s_ci] = s.y; bad |= wgrad_nonfinite(s.y); }
+            if (ci + 2 < cin_real) { d[2 * s_ci] = s.z; bad |= wgrad_nonfinite(s.z); }
+            if (ci + 3 < cin_real) { d[3 * s_ci] = s.w; bad |= wgrad_nonfinite(s.w); }
         }
     }
 }
@@ -1305,7 +1316,7 @@ __device__ __forceinline__ void wgrad_reduce_block(const float* __restrict__ sla
 // floats: bank = (tap + ci) mod 32) and leaves as ONE contiguous run of K floats.  Splits are summed in order 0, 1, ...
 #define WGRAD_ROW_MAX 4640                                         // floats: 9 taps x (512 + 1)
 __device__ __forceinline__ void wgrad_reduce_row(const float* __restrict__ slab, int splits, int Cout, int Kpad, int ntaps, int cin,
-                                                 float* __restrict__ dw, long s_co, float out_scale, unsigned co, float* rowbuf) {
+                                                 float* __restrict__ dw, long s_co, float out_scale, unsigned co, float* rowbuf, unsigned& bad) {
     const int K = ntaps * cin, K4 = K >> 2;
     const size_t zs = (size_t)Cout * Kpad;
     const float* src = slab + (size_t)co * Kpad;
@@ -1318,7 +1329,9 @@ __device__ __forceinline__ void wgrad_reduce_row(const float* __restrict__ slab,
         }
         const int k = q * 4, tap = k / cin, ci = k - tap * cin;     // cin % 4 == 0: the quad stays inside one tap
         float* d = rowbuf + tap * (cin + 1) + ci;
-        d[0] = s.x * out_scale; d[1] = s.y * out_scale; d[2] = s.z * out_scale; d[3] = s.w * out_scale;
+        s.x *= out_scale; s.y *= out_scale; s.z *= out_scale; s.w *= out_scale;
+        d[0] = s.x; d[1] = s.y; d[2] = s.z; d[3] = s.w;
+        bad |= wgrad_nonfinite(s.x) | wgrad_nonfinite(s.y) | wgrad_nonfinite(s.z) | wgrad_nonfinite(s.w);
     }
     __syncthreads();
     float* out = dw + (size_t)co * s_co;
@@ -1331,8 +1344,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
                                                            int cin_stored, int cin_real, float* __restrict__ dw, long s_co, long s_tap,
                                                            long s_ci, int zlanes, float out_scale) {
     __shared__ float4 part[WGRAD_ROW_MAX / 4];
-    if (zlanes == 0) { wgrad_reduce_row(slab, splits, Cout, Kpad, ntaps, cin_stored, dw, s_co, out_scale, blockIdx.x, (float*)part); return; }
-    wgrad_reduce_block(slab, splits, Cout, Kpad, ntaps, cin_stored, cin_real, dw, s_co, s_tap, s_ci, zlanes, out_scale, blockIdx.x, part);
+    unsigned bad = 0;                                              // (this single-layer form carries no note: the optimizer scans its tensor)
+    if (zlanes == 0) { wgrad_reduce_row(slab, splits, Cout, Kpad, ntaps, cin_stored, dw, s_co, out_scale, blockIdx.x, (float*)part, bad); return; }
+    wgrad_reduce_block(slab, splits, Cout, Kpad, ntaps, cin_stored, cin_real, dw, s_co, s_tap, s_ci, zlanes, out_scale, blockIdx.x, part, bad);
 }
 // Grouped form: the reduces of up to TRI_WGRAD_GROUP_MAX layers in ONE launch (their partial kernels ran earlier into per-layer
 // slabs - tri_conv_wgrad_partial).  A tower's backward then pays one reduce launch instead of one per layer (28 launches of
@@ -1340,18 +1354,20 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 struct WgradGroup {
     TriWgradReduce d[TRI_WGRAD_GROUP_MAX];
     int first_block[TRI_WGRAD_GROUP_MAX + 1];
+    int* note;                                                     // optional: the optimizer's overflow record (wgrad_note_bad)
 };
 __global__ __launch_bounds__(256) void wgrad_reduce_grouped_kernel(const WgradGroup g, int n) {
     __shared__ float4 part[WGRAD_ROW_MAX / 4];
     int i = 0;
     while (i + 1 < n && (int)blockIdx.x >= g.first_block[i + 1]) ++i;
     const TriWgradReduce& r = g.d[i];
-    if (r.zlanes == 0) {
-        wgrad_reduce_row(r.slab, r.splits, r.Cout, r.Kpad, r.ntaps, r.cin_stored, r.dw, r.s_co, r.out_scale, blockIdx.x - g.first_block[i], (float*)part);
-        return;
-    }
-    wgrad_reduce_block(r.slab, r.splits, r.Cout, r.Kpad, r.ntaps, r.cin_stored, r.cin_real, r.dw, r.s_co, r.s_tap, r.s_ci, r.zlanes,
-                       r.out_scale, blockIdx.x - g.first_block[i], part, r.kw_real, r.kw_shift);
+    unsigned bad = 0;
+    if (r.zlanes == 0)
+        wgrad_reduce_row(r.slab, r.splits, r.Cout, r.Kpad, r.ntaps, r.cin_stored, r.dw, r.s_co, r.out_scale, blockIdx.x - g.first_block[i], (float*)part, bad);
+    else
+        wgrad_reduce_block(r.slab, r.splits, r.Cout, r.Kpad, r.ntaps, r.cin_stored, r.cin_real, r.dw, r.s_co, r.s_tap, r.s_ci, r.zlanes,
+                           r.out_scale, blockIdx.x - g.first_block[i], part, bad, r.kw_real, r.kw_shift);
+    wgrad_note_bad(bad, g.note);
 }
 
 static int ilog2_exact(int v) {
@@ -2076,6 +2092,9 @@ extern "C" int tri_conv_wgrad_partial_group(const TriWgradJob* jobs, int n, int 
 }
 
 extern "C" int tri_wgrad_reduce_grouped(const TriWgradReduce* pending, int n, void* stream) {
+    return tri_wgrad_reduce_grouped_noted(pending, n, nullptr, stream);
+}
+extern "C" int tri_wgrad_reduce_grouped_noted(const TriWgradReduce* pending, int n, int* note, void* stream) {
     if (n < 0 || (n > 0 && !pending)) { tri_set_error("wgrad reduce: bad descriptor list"); return TRI_ERR_ARG; }
     for (int base = 0; base < n; base += TRI_WGRAD_GROUP_MAX) {
         const int m = n - base < TRI_WGRAD_GROUP_MAX ? n - base : TRI_WGRAD_GROUP_MAX;
@@ -2088,6 +2107,7 @@ extern "C" int tri_wgrad_reduce_grouped(const TriWgradReduce* pending, int n, vo
             blocks += g.d[i].nblocks;
         }
         g.first_block[m] = blocks;
+        g.note = note;
         wgrad_reduce_grouped_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(g, m);
         int rc = tri_check_launch("tri_wgrad_reduce_grouped");
         if (rc) return rc;

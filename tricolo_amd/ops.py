@@ -482,6 +482,28 @@ _WGRAD_JOB_TILES = dict(zip(range(1, 8), [512, 448, 256, 512, 512, 512, 512]))  
 _WGRAD_REDUCE_OVERLAP = os.environ.get("TRICOLO_WGRAD_REDUCE_OVERLAP", "1") != "0"   # A/B switch (round 6): WgradBatch.flush(side=...)
 
 
+# Overflow note (round 6): the optimizer whose zero_grad() ran last lends the grouped weight-gradient reduce its device record; the reduce flags
+# a step that STORED an inf / NaN exactly as the optimizer's own scan would, and tags every gradient tensor it vouched for (`_tri_noted` =
+# (address of the record, the tensor's version counter)) - FusedAdam leaves those out of its scan (64 of the default step's 74 MB of
+# gradients).  The tag travels with the tensor OBJECT: a gradient that reaches the optimizer as another tensor (accumulated over several
+# backward passes, cloned by AccumulateGrad, made contiguous) has no tag, one that was modified in place no longer matches its version -
+# both are scanned as before.  (No table of addresses, and no reference to the tensors is kept here: a second owner makes autograd's
+# AccumulateGrad CLONE every gradient it is handed - measured: +120 us per step.)
+_GUARD_NOTE = None           # int32[4] device tensor (kept alive here) or None
+
+
+def set_guard_note(note):
+    global _GUARD_NOTE
+    _GUARD_NOTE = note
+
+
+def guard_noted(g, note) -> bool:
+    """True when g's writer already noted its inf / NaN in `note` and nobody touched g since.  Consumes the tag: a second optimizer step on
+    the same tensor scans it."""
+    tag = g.__dict__.pop("_tri_noted", None)
+    return tag is not None and tag == (note.data_ptr(), g._version)
+
+
 class WgradBatch:
     """Deferred weight-gradient reduces of one tower backward (tri_conv_wgrad_partial / tri_wgrad_reduce_grouped).
 
@@ -505,6 +527,7 @@ class WgradBatch:
         self.ci, self.off, self.descs = 0, 0, []
         self.queues = {}                                          # kernel family -> [pending jobs, their output tiles]
         self._pre = None                                          # prelaunch() state: (descs to reduce early, event, family left for flush)
+        self.dws = {}                                             # data_ptr -> gradient tensor of every layer queued here (overflow note)
 
     @property
     def jobs(self):
@@ -565,7 +588,15 @@ class WgradBatch:
         n = len(descs)
         if n:
             arr = (_C.TriWgradReduce * n)(*descs)
-            check(lib().tri_wgrad_reduce_grouped(arr, n, stream()), "tri_wgrad_reduce_grouped")
+            note = _GUARD_NOTE
+            if note is not None and self.device.index is not None and note.device.index != self.device.index:
+                note = None
+            check(lib().tri_wgrad_reduce_grouped_noted(arr, n, ptr(note), stream()), "tri_wgrad_reduce_grouped")
+            if note is not None:
+                for d in descs:
+                    t = self.dws.pop(int(d.dw or 0), None)
+                    if t is not None:
+                        t._tri_noted = (note.data_ptr(), t._version)
 
     def prelaunch(self):
         """First half of flush(side=...): every pending family but the last is launched now (smallest first, the two largest swapped - see
@@ -598,6 +629,7 @@ class WgradBatch:
             self.launch_jobs()
             self._reduce(self.descs)
             self.ci, self.off, self.descs = 0, 0, []
+            self.dws.clear()
             return
         early, ev, last = self._pre
         self._pre = None
@@ -608,6 +640,7 @@ class WgradBatch:
         side.join()
         self._reduce(late + self.descs)
         self.ci, self.off, self.descs = 0, 0, []
+        self.dws.clear()
 
 
 def wgrad_batch(device):
@@ -644,8 +677,10 @@ def conv_wgrad(x, dout, g: ConvGeom, like: torch.Tensor, precision: str, row_mas
             job = _C.TriWgradJob(_C.C.pointer(g.desc), ptr(xa), ptr(da), ptr(plan), ptr(ws), ws.numel(), ptr(dw), s_co, s_tap, s_ci, g.cin,
                                  float(out_scale), ptr(rows[0]) if rows else None, ptr(rows[1]) if rows else None)
             batch.add_job(fam, tiles, job, (xa, da, ws, dw, plan, rows), _flops(g, rows), sym)
+            batch.dws[dw.data_ptr()] = dw
             return dw
     if batch is not None:
+        batch.dws[dw.data_ptr()] = dw
         desc = _C.TriWgradReduce()
         check(_timed(sym, _flops(g, rows, row_mask),
                      lambda: lib().tri_conv_wgrad_partial(_C.C.byref(g.desc), ptr(_act(x)), ptr(_act(dout)), ptr(row_mask), ptr(plan),
@@ -974,6 +1009,7 @@ def maxpool_bn_bwd_wgrad(x0, y, arg, dpool, co: "BNCoeffs", gamma, g: "ConvGeom"
     check(rc, "tri_conv_stem_wgrad_bn")
     if batch is not None:
         batch.descs.append(desc)
+        batch.dws[dw.data_ptr()] = dw
     else:
         check(lib().tri_wgrad_reduce_grouped(_C.C.byref(desc), 1, stream()), "tri_wgrad_reduce_grouped")
     return dw, buf[0], buf[1]

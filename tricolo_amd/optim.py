@@ -13,9 +13,14 @@ change ``param_groups[0]["lr"]`` as usual; eager steps pick it up by themselves,
 ``state_dict()`` / ``load_state_dict()`` speak torch.optim.Adam's format (per-parameter ``step``, ``exp_avg``,
 ``exp_avg_sq``), so Lightning's ``optimizer_states`` checkpoints resume in either optimizer.
 """
+import os
+
 import torch
 
 from . import ops
+
+
+_GUARD_NOTE = os.environ.get("TRICOLO_GUARD_NOTE", "1") != "0"     # A/B switch (round 6): 0 = the guard scans every gradient itself
 
 
 class FusedAdam(torch.optim.Optimizer):
@@ -41,6 +46,8 @@ class FusedAdam(torch.optim.Optimizer):
         uploaded from (see _update_from_segments)."""
         super().zero_grad(set_to_none=set_to_none)
         self._zg_event = None
+        # lend the gradient writers this optimizer's overflow record (ops.set_guard_note): what they vouch for is left out of the scan below
+        ops.set_guard_note(self._step_dev if (_GUARD_NOTE and self._guard and self._step_dev is not None and getattr(self, "_seg_ok", False)) else None)
         if self._step_dev is not None and torch.cuda.is_current_stream_capturing():
             self._zg_event = torch.cuda.Event()
             self._zg_event.record()
@@ -52,7 +59,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._captures = max(int(captures), getattr(self, "_captures", 0))
         if self._step_dev is not None:
             while hasattr(self, "_seg_capture_pool") and len(self._seg_capture_pool) + len(self._seg_captured) < self._captures:
-                self._seg_capture_pool.append(torch.zeros((len(self._params),), dtype=torch.int64).pin_memory())
+                self._seg_capture_pool.append(torch.zeros((3 * len(self._params),), dtype=torch.int64).pin_memory())
             return
         params = [p for g in self.param_groups for p in g["params"] if p.requires_grad]
         if not params:
@@ -92,13 +99,16 @@ class FusedAdam(torch.optim.Optimizer):
                 # eager steps: a small ring of pinned staging buffers, each guarded by an event (the stream may lag the host by
                 # many kernels, so a buffer is only refilled after its previous copy ran); a HIP-graph capture gets a staging
                 # buffer of its own that is never written again (the captured copy re-reads it on every replay)
-                self._seg_ring = [[torch.zeros((len(sizes),), dtype=torch.int64).pin_memory(), None] for _ in range(4)]
+                # (table layout, 3 n entries: gradient pointers | pointers of the segments the guard scans | their starts in the scan's order)
+                self._seg_sizes = sizes
+                self._seg_ring = [[torch.zeros((3 * len(sizes),), dtype=torch.int64).pin_memory(), None] for _ in range(4)]
                 self._seg_ring_i = 0
                 # (bench.py captures one graph per resident batch - 8 by default -, tests and re-captures add more: 32 tables of a few KB;
                 #  prepare(captures=n) sizes it for a caller that knows better; an exhausted pool is reported, never silent)
-                self._seg_capture_pool = [torch.zeros((len(sizes),), dtype=torch.int64).pin_memory() for _ in range(max(32, self._captures))]
+                self._seg_capture_pool = [torch.zeros((3 * len(sizes),), dtype=torch.int64).pin_memory() for _ in range(max(32, self._captures))]
                 self._seg_captured = []
-                self._seg_ptr = torch.zeros((len(sizes),), dtype=torch.int64, device=dev)
+                self._seg_tab = torch.zeros((3 * len(sizes),), dtype=torch.int64, device=dev)
+                self._seg_ptr = self._seg_tab[:len(sizes)]
                 self._seg_keep = None
             off = 0
             for p, n in zip(params, sizes):                          # torch-compatible per-parameter state views
@@ -218,6 +228,16 @@ class FusedAdam(torch.optim.Optimizer):
                     return False
             grads.append(g)
             ptrs.append(g.data_ptr() if g is not None else 0)
+        n = len(ptrs)
+        # the guard's scan list: every gradient no writer vouched for (ops.guard_noted: the grouped weight-gradient reduce notes the
+        # inf / NaN it stores itself), compacted - the scan's grid and its binary search then cover those elements only
+        gptrs, gstarts, gtotal = [], [], 0
+        for a, size, g in zip(ptrs, self._seg_sizes, grads):
+            if a and not ops.guard_noted(g, self._step_dev):
+                gptrs.append(a)
+                gstarts.append(gtotal)
+                gtotal += size
+        table = ptrs + gptrs + [0] * (n - len(gptrs)) + gstarts + [0] * (n - len(gstarts))
         capturing = torch.cuda.is_current_stream_capturing()
         if capturing:
             if not self._seg_capture_pool:                           # (pinned memory cannot be allocated inside a capture)
@@ -229,7 +249,7 @@ class FusedAdam(torch.optim.Optimizer):
                     self._pool_warned = True
                 return False
             host = self._seg_capture_pool.pop()
-            host.copy_(torch.tensor(ptrs, dtype=torch.int64))
+            host.copy_(torch.tensor(table, dtype=torch.int64))
             self._seg_captured.append(host)                          # owned by the graph from now on
         else:
             slot = self._seg_ring[self._seg_ring_i]
@@ -237,7 +257,7 @@ class FusedAdam(torch.optim.Optimizer):
             if slot[1] is not None:
                 slot[1].synchronize()
             host = slot[0]
-            host.copy_(torch.tensor(ptrs, dtype=torch.int64))
+            host.copy_(torch.tensor(table, dtype=torch.int64))
         self._seg_keep = grads                                       # keep temporaries alive until the next step
         ev, self._zg_event = getattr(self, "_zg_event", None), None
         if capturing and ev is not None:
@@ -249,15 +269,15 @@ class FusedAdam(torch.optim.Optimizer):
             main = torch.cuda.current_stream()
             self._seg_side.wait_event(ev)
             with torch.cuda.stream(self._seg_side):
-                self._seg_ptr.copy_(host, non_blocking=True)
+                self._seg_tab.copy_(host, non_blocking=True)
             main.wait_stream(self._seg_side)
         else:
-            self._seg_ptr.copy_(host, non_blocking=True)
+            self._seg_tab.copy_(host, non_blocking=True)
         if not capturing:
             slot[1] = torch.cuda.Event()
             slot[1].record()
-        if self._guard:
-            ops.adam_guard_segments(self._seg_ptr, self._seg_start, self._flat_p.numel(), self._step_dev)
+        if self._guard and gptrs:
+            ops.adam_guard_segments(self._seg_tab[n:n + len(gptrs)], self._seg_tab[2 * n:2 * n + len(gptrs)], gtotal, self._step_dev)
         # (round 6: the tick folded into the guard launch's last workgroup - one node less - was built and measured: 4,096 workgroups taking a
         #  ticket on one address cost 110 us; the kernel-argument form of the pointer table was dropped with it)
         ops.adam_tick(self._step_dev)                       # step += 1 on the device (or skipped += 1), once per optimizer step
