@@ -1,0 +1,21 @@
+#!/bin/bash
+O=gpurun_out/r6ac; mkdir -p $O; rm -f $O/*
+run() { env $1 timeout 600 python bench.py --modes "" --no-cpu-baseline --no-voxel-config5 > $O/bench_$2.$3.json 2>> $O/bench.err; }
+for rep in 1 2; do
+run "X=1" base $rep
+run "TRICOLO_WGRAD_EARLY=1" early $rep
+run "TRICOLO_WGRAD_EARLY=1 TRICOLO_KROW_LDS_PAD=32768" early_pad32 $rep
+run "TRICOLO_WGRAD_EARLY=1 TRICOLO_KROW_LDS_PAD=98304" early_pad96 $rep
+done
+python - <<'P'
+import glob, json, collections
+res = collections.defaultdict(list)
+for f in sorted(glob.glob('gpurun_out/r6ac/bench_*.json')):
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        res[f.split('/')[-1].split('.')[0]].append((d['ms_per_step'], d['config']['final_loss']))
+    except Exception as ex:
+        print(f, 'ERR', ex)
+for k, v in sorted(res.items()): print(k, v)
+P
+TRICOLO_WGRAD_EARLY=1 TRICOLO_KROW_LDS_PAD=32768 timeout 300 python tools/step_timeline.py 2>/dev/null | grep -E "image.bwd|adam|step.end" | sed "s/^/pad32 /"
