@@ -329,8 +329,8 @@ def voxel_fwd_roofline(net, batch, B, nrep=3):
             "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tot_exec / tot_raw / 1e9 / MFMA_PEAK_TFLOPS, 4),
             "frac_dense_equivalent": round(tot_dense / tot_raw / 1e9 / MFMA_PEAK_TFLOPS, 4),
             "frac_minus_event_overhead": round(tot_exec / tot_ms / 1e9 / MFMA_PEAK_TFLOPS, 4),
-            "rocprof": "kernel durations of the same five launches: newest profiles/r*/kernel_stats_<mode>.csv (conv_vox0_kernel, conv_vox1_kernel, "
-                       "conv_voxg_kernel / conv_dma_kernel / conv_igemm_kernel rows), profiles/r5/kernel_stats_voxel_fwd.csv and profiles/r5/voxel_fwd.txt",
+            "rocprof": "kernel durations of the same five launches: newest profiles/r*/kernel_stats_<mode>.csv (conv_vox0_kernel, conv_voxb_kernel, "
+                       "conv_voxg_kernel / conv_dma_kernel / conv_igemm_kernel rows), and that round's kernel_stats_voxel_fwd.csv / voxel_fwd.txt",
             "level0_hbm": {"bound": "hbm", "achieved": l0["algorithmic_hbm_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(l0["algorithmic_hbm_gbs"] / HBM_PEAK_GBS, 4),
                            "note": "level 0 (3 -> 32 channels, 74 FLOP/B) is HBM-bound: bytes = needed input rows once + written output "
