@@ -481,7 +481,7 @@ def run_mode(a, precision, world, rank, device, want_voxel_roofline):
     roof, vox_roof = None, None
     if rank == 0:
         ops.TIMER = ops.KernelTimer()
-    nprof = 3
+    nprof = 6                          # (eager steps of the leg: 72 launches of the graded family instead of 36 - the run-to-run spread of `frac` was +-3 %)
     # serialise the streams for this leg: a kernel's HIP-event duration must not include the other towers' kernels
     # sharing the GPU with it (the timed region above keeps towers on parallel streams)
     net.overlap_towers = False
