@@ -72,72 +72,94 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
     // Input projections are prefetched THREE steps ahead: a step is ~600 cycles of MFMAs and gate math, a global load ~1-2 us.
     // (Loaded at the top of the step that uses them, every one of the 96 steps waited a full load latency: 2.2 us per step,
     // 214 us for the kernel - on the text tower's forward, which the loss of the whole step waits for.)
+    //
+    // Round 6: the step is VALU-ISSUE bound, not a latency chain - four CUs run the whole recurrence, two waves per SIMD, and the ISA of the
+    // rolled loop was 289 instructions per step of which ~50 were register moves (rotating the prefetch buffers) and ~45 64-bit address
+    // arithmetic for 12 loads and 8 stores; at 4 cycles per wave64 VALU instruction (16 for the 24 exp / rcp) that is the 1.1 us a step
+    // took.  Here six steps are unrolled: the prefetch buffer of a step and the LDS image it reads / writes are compile-time choices (no
+    // moves, no toggling), and every global access is (a scalar base that moves with the step) + (a per-lane 32-bit offset computed once).
+    // Same arithmetic in the same order: the results are bit-identical.
     constexpr int PF = 3;
     float xq[PF][12];
+    unsigned xoff[4], hoff[4], loff[4];
+    bool rowok[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = fq * 4 + r, b = b0 + row;
+        rowok[r] = b < B;
+        xoff[r] = (unsigned)((b < B ? b : 0) * 768 + dir * 384 + unit);
+        hoff[r] = (unsigned)((b < B ? b : 0) * GRU_H + unit);
+        loff[r] = (unsigned)(himg_off(row, unit >> 3, 256) + (unit & 7) * 2);
+    }
+    const size_t xstride = (size_t)B * 768, hstride = (size_t)B * GRU_H;
     auto load_x = [&](int s_, float* dst) {
         const int t_ = dir == 0 ? s_ : L - 1 - s_;
+        const float* xs = xproj + (size_t)(s_ < L ? t_ : 0) * xstride;      // (uniform; past the end: a harmless re-read of step 0's row)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            int b = b0 + fq * 4 + r;
-            const float* xp = xproj + ((size_t)(s_ < L ? t_ : 0) * B + (b < B ? b : 0)) * 768 + dir * 384 + unit;
+            const float* xp = xs + xoff[r];
             dst[r] = xp[0]; dst[4 + r] = xp[128]; dst[8 + r] = xp[256];
         }
     };
 #pragma unroll
     for (int d = 0; d < PF; ++d) load_x(d, xq[d]);
-    int cur = 0;
-    for (int s = 0; s < L; ++s) {
-        const int tt = dir == 0 ? s : L - 1 - s;
-        float xr[4], xz[4], xn[4];
+    float* const hs_d = hs + (size_t)dir * L * hstride;
+    float* const gates_d = gates + (size_t)dir * L * hstride * 4;
+#pragma unroll 1
+    for (int s0 = 0; s0 < L; s0 += 6) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { xr[r] = xq[0][r]; xz[r] = xq[0][4 + r]; xn[r] = xq[0][8 + r]; }
+        for (int u = 0; u < 6; ++u) {
+            const int s = s0 + u;
+            if (s < L) {                                                // (uniform)
+                constexpr int NS = NSPLIT * 16 * 256;
+                const int tt = dir == 0 ? s : L - 1 - s;
+                float* const xb = xq[u % PF];
+                float xr[4], xz[4], xn[4];
 #pragma unroll
-        for (int d = 0; d + 1 < PF; ++d)
+                for (int r = 0; r < 4; ++r) { xr[r] = xb[r]; xz[r] = xb[4 + r]; xn[r] = xb[8 + r]; }
+                load_x(s + PF, xb);
+                const char* hb = lds + (u & 1) * NS;
+                f32x4 acc[3];
 #pragma unroll
-            for (int k = 0; k < 12; ++k) xq[d][k] = xq[d + 1][k];
-        load_x(s + PF, xq[PF - 1]);                                 // (past the end: a harmless re-read of step 0's row)
-        const char* hb = lds + cur * (NSPLIT * 16 * 256);
-        f32x4 acc[3];
+                for (int g = 0; g < 3; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int g = 0; g < 3; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int ks = 0; ks < 4; ++ks) {
+                    int off = himg_off(fr, ks * 4 + fq, 256);
+                    v8 ah = *(const v8*)(hb + off);
+                    v8 al;
+                    if (NSPLIT == 2) al = *(const v8*)(hb + 16 * 256 + off);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            int off = himg_off(fr, ks * 4 + fq, 256);
-            v8 ah = *(const v8*)(hb + off);
-            v8 al;
-            if (NSPLIT == 2) al = *(const v8*)(hb + 16 * 256 + off);
-#pragma unroll
-            for (int g = 0; g < 3; ++g) {
-                if (NSPLIT == 2) {
-                    acc[g] = MM::mma(al, wh[g][ks], acc[g]);
-                    acc[g] = MM::mma(ah, wl[g][ks], acc[g]);
+                    for (int g = 0; g < 3; ++g) {
+                        if (NSPLIT == 2) {
+                            acc[g] = MM::mma(al, wh[g][ks], acc[g]);
+                            acc[g] = MM::mma(ah, wl[g][ks], acc[g]);
+                        }
+                        acc[g] = MM::mma(ah, wh[g][ks], acc[g]);
+                    }
                 }
-                acc[g] = MM::mma(ah, wh[g][ks], acc[g]);
-            }
-        }
-        char* hn_buf = lds + (cur ^ 1) * (NSPLIT * 16 * 256);
+                char* hn_buf = lds + ((u & 1) ^ 1) * NS;
+                float* const hs_s = hs_d + (size_t)tt * hstride;        // (uniform bases of this step's rows)
+                float* const gates_s = gates_d + (size_t)tt * hstride * 4;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            int row = fq * 4 + r, b = b0 + row;
-            float rg = sigmoidf_(xr[r] + acc[0][r] + bhr);
-            float zg = sigmoidf_(xz[r] + acc[1][r] + bhz);
-            float ghn = acc[2][r] + bhn;
-            float ng = tanhf_(xn[r] + rg * ghn);
-            float hnew = (1.f - zg) * ng + zg * h[r];
-            h[r] = hnew;
-            if (b < B) {
-                size_t o = ((size_t)dir * L + tt) * B + b;
-                hs[o * GRU_H + unit] = hnew;
-                *(float4*)(gates + (o * GRU_H + unit) * 4) = make_float4(rg, zg, ng, ghn);      // one 16-byte store per (row, unit)
+                for (int r = 0; r < 4; ++r) {
+                    float rg = sigmoidf_(xr[r] + acc[0][r] + bhr);
+                    float zg = sigmoidf_(xz[r] + acc[1][r] + bhz);
+                    float ghn = acc[2][r] + bhn;
+                    float ng = tanhf_(xn[r] + rg * ghn);
+                    float hnew = (1.f - zg) * ng + zg * h[r];
+                    h[r] = hnew;
+                    if (rowok[r]) {
+                        hs_s[hoff[r]] = hnew;
+                        *(float4*)(gates_s + (size_t)hoff[r] * 4) = make_float4(rg, zg, ng, ghn);   // one 16-byte store per (row, unit)
+                    }
+                    // re-publish as 16-bit (hi, lo): element (row, unit) -> chunk unit/8, byte (unit%8)*2
+                    E hh = (E)hnew;
+                    *(E*)(hn_buf + loff[r]) = hh;
+                    if (NSPLIT == 2) *(E*)(hn_buf + 16 * 256 + loff[r]) = (E)(hnew - (float)hh);
+                }
+                __syncthreads();
             }
-            // re-publish as 16-bit (hi, lo): element (row, unit) -> chunk unit/8, byte (unit%8)*2
-            E hh = (E)hnew;
-            int off = himg_off(row, unit >> 3, 256) + (unit & 7) * 2;
-            *(E*)(hn_buf + off) = hh;
-            if (NSPLIT == 2) *(E*)(hn_buf + 16 * 256 + off) = (E)(hnew - (float)hh);
         }
-        cur ^= 1;
-        __syncthreads();
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
