@@ -251,6 +251,17 @@ int tri_bn_bwd_apply(const void* y, const void* g, const float* c1, const float*
                      int keep_inactive /* 0: rows with row_mask == 0 come out as zeros (a data gradient gathers them); 1: they are left
                                           untouched - for layers whose dy only feeds a weight gradient over the same mask (voxel level 0) */,
                      int act_fmt, void* stream);
+/* BatchNorm backward of TWO tensors of one shape that share their upstream gradient - bn2 and the shortcut's BatchNorm of a down-sampling
+ * BasicBlock (mv_cnn.py:20; out = relu(bn_a(ya) + bn_b(yb)), g = gradient of out, relu_out = out): the three passes serve both, g and
+ * relu_out are read once.  partial_* [tri_bn_bwd_num_blocks(M)][2][C]; buf_* [5][C] = dgamma, dbeta, c1, c2, c3; g_masked (may alias g)
+ * receives g * (out > 0). */
+int tri_bn_bwd_pair_reduce(const void* ya, const void* yb, const void* g, const void* relu_out, long M, int C, float* partial_a,
+                           float* partial_b, int act_fmt, void* stream);
+int tri_bn_bwd_pair_finalize(const float* partial_a, const float* partial_b, int nblk, int C, int count_host, const float* gamma_a,
+                             const float* mean_a, const float* invstd_a, float* buf_a, const float* gamma_b, const float* mean_b,
+                             const float* invstd_b, float* buf_b, float out_scale, void* stream);
+int tri_bn_bwd_pair_apply(const void* ya, const void* yb, const void* g, const void* relu_out, const float* buf_a, const float* buf_b,
+                          void* dya, void* dyb, void* g_masked, long M, int C, int act_fmt, void* stream);
 
 /* ---- pooling -------------------------------------------------------------------------------------------------
  * BN + ReLU + mask + spconv.SparseMaxPool3d(2,2) fused (sparse_cnn.py:13-15 ...), its backward routing;

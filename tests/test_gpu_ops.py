@@ -298,6 +298,44 @@ def test_linear_small_matches_torch(M, K, N, act):
         assert torch.equal(dw1, dw) and torch.equal(db1, db)
 
 
+@pytest.mark.parametrize("M,C,store", [(3072, 512, torch.float16), (12288, 256, torch.float16), (49152, 128, torch.float16), (49152, 128, torch.bfloat16),
+                                       (100, 64, torch.float32)])
+def test_bn_bwd_pair_is_two_single_backward_passes_bit_for_bit(M, C, store):
+    """Round 6: bn2 and the shortcut's BatchNorm of a down-sampling BasicBlock receive the same gradient g = dout * (out > 0); ops.bn_bwd_pair
+    runs ONE reduce / finalize / apply for both.  Every output must EQUAL what bn_bwd(y2, ..., relu_out=out, g_masked=...) followed by
+    bn_bwd(yd, g_masked, ...) produce - down to the compiler's choice of folding the last FMA into the f16 conversion or not, which differs
+    between the two single passes and which the pair kernel reproduces (a toolchain that changes either shows up here) - at the layer shapes
+    of the bench step and a ragged one in fp32 storage; plus a float64 anchor."""
+    gen = torch.Generator().manual_seed(97)
+    ya, yb = torch.randn(M, C, generator=gen).to(DEV).to(store), (torch.randn(M, C, generator=gen) * 0.5 + 0.2).to(DEV).to(store)
+    out = torch.relu(torch.randn(M, C, generator=gen)).to(DEV).to(store)
+    dout = (torch.randn(M, C, generator=gen) * 64).to(DEV).to(store)
+    ga, gb = (torch.rand(C, generator=gen) + 0.5).to(DEV), (torch.rand(C, generator=gen) + 0.5).to(DEV)
+    coa, cob = ops.BNCoeffs(C, DEV), ops.BNCoeffs(C, DEV)
+    for co, y in ((coa, ya), (cob, yb)):
+        yf = y.float()
+        co.mean.copy_(yf.mean(0))
+        co.invstd.copy_(1.0 / torch.sqrt(yf.var(0, unbiased=False) + 1e-5))
+    scale = 1.0 / 4096
+    d1 = dout.clone()
+    dya, dga, dba = ops.bn_bwd(ya, d1, coa, ga, count_host=M, inplace=False, relu_out=out, g_masked=d1, out_scale=scale)
+    dyb, dgb, dbb = ops.bn_bwd(yb, d1, cob, gb, count_host=M, inplace=False, out_scale=scale)
+    d2 = dout.clone()
+    pa, pga, pba, pb, pgb, pbb = ops.bn_bwd_pair(ya, coa, ga, yb, cob, gb, d2, out, M, g_masked=d2, out_scale=scale)
+    torch.cuda.synchronize()
+    for a_, b_, name in ((pa, dya, "dya"), (pga, dga, "dgamma_a"), (pba, dba, "dbeta_a"), (pb, dyb, "dyb"), (pgb, dgb, "dgamma_b"), (pbb, dbb, "dbeta_b"),
+                         (d2, d1, "g_masked")):
+        if store == torch.float32:                          # (fp32 storage: no conversion to fold, but the FMA contraction of the two forms may differ by an ulp)
+            np.testing.assert_allclose(a_.cpu().numpy(), b_.cpu().numpy(), rtol=1e-5, atol=1e-4, err_msg=name)
+        else:
+            assert torch.equal(a_, b_), (name, float((a_.float() - b_.float()).abs().max()))
+    # float64 anchor for tensor b (the single form has its own torch parity test)
+    g64 = (dout.double() * (out > 0)).cpu()
+    xh = ((yb.double() - cob.mean.double()) * cob.invstd.double()).cpu()
+    np.testing.assert_allclose(pgb.cpu().numpy(), ((g64 * xh).sum(0) * scale).numpy(), rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(pbb.cpu().numpy(), (g64.sum(0) * scale).numpy(), rtol=2e-3, atol=2e-3)
+
+
 def test_embedding_kernels_match_torch():
     """Token lookup into time-major order and the deterministic dense weight gradient (duplicates, padding row)."""
     g = torch.Generator().manual_seed(23)

@@ -90,6 +90,9 @@ SIGNATURES = {
     "tri_bn_bwd_finalize": (I, [P, I, I, P, I, P, P, P, P, P, P, P, P, F, P]),
     "tri_bn_bwd_small": (I, [P, P, L, I, P, I, P, P, P, P, P, P, P, P, I, P, P, P, F, I, P]),
     "tri_bn_bwd_apply": (I, [P, P, P, P, P, P, P, L, I, P, P, P, P, I, I, P]),
+    "tri_bn_bwd_pair_reduce": (I, [P, P, P, P, L, I, P, P, I, P]),
+    "tri_bn_bwd_pair_finalize": (I, [P, P, I, I, I, P, P, P, P, P, P, P, P, F, P]),
+    "tri_bn_bwd_pair_apply": (I, [P, P, P, P, P, P, P, P, P, L, I, I, P]),
     "tri_bn_relu_pool3d_fwd": (I, [P, P, P, P, I, I, I, P, P, I, P]),
     "tri_pool3d_bwd_route": (I, [P, P, P, P, P, P, I, I, I, P, I, P]),
     "tri_pool3d_bwd_route_rows": (I, [P, P, P, P, P, P, I, I, I, P, P, P, I, P]),

@@ -236,12 +236,12 @@ extern "C" int tri_bn_bwd_reduce(const void* y, const void* g, long M, int C, fl
     return tri_check_launch("tri_bn_bwd_reduce");
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, const int* __restrict__ count_dev,
-                                       int count_host, const float* __restrict__ gamma, const float* __restrict__ mean,
-                                       const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                       float* __restrict__ c1, float* __restrict__ c2, float* __restrict__ c3, float out_scale) {
+__device__ __forceinline__ void bn_bwd_finalize_body(const float* __restrict__ partial, int nblk, int C, const int* __restrict__ count_dev,
+                                                     int count_host, const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     float* __restrict__ c1, float* __restrict__ c2, float* __restrict__ c3, float out_scale,
+                                                     int c) {
     __shared__ double ssum[4], ssq[4];                              // one channel per block, see bn_finalize_kernel
-    const int c = blockIdx.x;
     float pmu = 0.f, pis = 0.f, pga = 0.f;
     int pcount = count_host;
     if (threadIdx.x == 0) {                                         // requested up front, see bn_finalize_kernel
@@ -273,6 +273,23 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nb
         double k2 = -k1 * dbe / n - k3 * mu;
         c1[c] = (float)k1; c2[c] = (float)k2; c3[c] = (float)k3;
     }
+}
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, const int* __restrict__ count_dev,
+                                       int count_host, const float* __restrict__ gamma, const float* __restrict__ mean,
+                                       const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                       float* __restrict__ c1, float* __restrict__ c2, float* __restrict__ c3, float out_scale) {
+    bn_bwd_finalize_body(partial, nblk, C, count_dev, count_host, gamma, mean, invstd, dgamma, dbeta, c1, c2, c3, out_scale, blockIdx.x);
+}
+// two BatchNorms of one shape in one launch (blocks [0, C): set a, [C, 2 C): set b); buf_* = [5][C] (dgamma, dbeta, c1, c2, c3)
+__global__ void bn_bwd_finalize_pair_kernel(const float* __restrict__ pa, const float* __restrict__ pb, int nblk, int C, int count_host,
+                                            const float* __restrict__ ga, const float* __restrict__ ma, const float* __restrict__ ia,
+                                            float* __restrict__ buf_a, const float* __restrict__ gb, const float* __restrict__ mb,
+                                            const float* __restrict__ ib, float* __restrict__ buf_b, float out_scale) {
+    const bool second = (int)blockIdx.x >= C;
+    const int c = second ? blockIdx.x - C : blockIdx.x;
+    float* buf = second ? buf_b : buf_a;
+    bn_bwd_finalize_body(second ? pb : pa, nblk, C, nullptr, count_host, second ? gb : ga, second ? mb : ma, second ? ib : ia, buf, buf + C,
+                         buf + 2 * C, buf + 3 * C, buf + 4 * C, out_scale, c);
 }
 extern "C" int tri_bn_bwd_finalize(const float* partial, int nblk, int C, const int* count_dev, int count_host, const float* gamma,
                                    const float* mean, const float* invstd, float* dgamma, float* dbeta, float* c1, float* c2,
@@ -324,6 +341,111 @@ extern "C" int tri_bn_bwd_apply(const void* y, const void* g, const float* c1, c
     else TRI_BNA(0);
 #undef TRI_BNA
     return tri_check_launch("tri_bn_bwd_apply");
+}
+
+// ---- BatchNorm backward of TWO tensors that share their upstream gradient (round 6): the last BatchNorm of a down-sampling
+// BasicBlock (bn2 of y2) and the shortcut's BatchNorm (of yd) both receive g = dout * (out > 0) (mv_cnn.py:20: torchvision BasicBlock,
+// out = relu(bn2(y2) + bn_d(yd))).  The three passes serve both tensors: g and the saved output are read once, the sums of g are shared,
+// and the shortcut branch is left with its 1x1 / 2 data gradient alone.  Same per-thread summation order and expressions as the single forms.
+template <typename T>
+__global__ void bn_bwd_reduce_pair_kernel(const T* __restrict__ ya, const T* __restrict__ yb, const T* __restrict__ g, long M, int C,
+                                          float* __restrict__ partial_a, float* __restrict__ partial_b, int BNB_ROWS,
+                                          const T* __restrict__ ro) {
+    extern __shared__ float sh[];                      // [rows_per_pass][C4][12]
+    const int C4 = C >> 2;
+    const int tpr = C4 < 256 ? C4 : 256;
+    const int rpp = 256 / tpr;
+    const int cpt = (C4 + tpr - 1) / tpr;
+    const int tc = threadIdx.x % tpr, tr = threadIdx.x / tpr;
+    const long r0 = (long)blockIdx.x * BNB_ROWS;
+    const long r1 = r0 + BNB_ROWS < M ? r0 + BNB_ROWS : M;
+    for (int cc = 0; cc < cpt; ++cc) {
+        int c4 = tc + cc * tpr;
+        float4 sg = make_float4(0, 0, 0, 0), sga = make_float4(0, 0, 0, 0), sgb = make_float4(0, 0, 0, 0);
+        if (c4 < C4 && tr < rpp)
+#pragma unroll 4
+            for (long r = r0 + tr; r < r1; r += rpp) {
+                float4 gv = Act<T>::ld4(g + r * C + c4 * 4);
+                const float4 av = Act<T>::ld4(ya + r * C + c4 * 4), bv = Act<T>::ld4(yb + r * C + c4 * 4), ov = Act<T>::ld4(ro + r * C + c4 * 4);
+                gv.x = ov.x > 0.f ? gv.x : 0.f; gv.y = ov.y > 0.f ? gv.y : 0.f; gv.z = ov.z > 0.f ? gv.z : 0.f; gv.w = ov.w > 0.f ? gv.w : 0.f;
+                sg.x += gv.x; sg.y += gv.y; sg.z += gv.z; sg.w += gv.w;
+                sga.x += gv.x * av.x; sga.y += gv.y * av.y; sga.z += gv.z * av.z; sga.w += gv.w * av.w;
+                sgb.x += gv.x * bv.x; sgb.y += gv.y * bv.y; sgb.z += gv.z * bv.z; sgb.w += gv.w * bv.w;
+            }
+        __syncthreads();
+        if (c4 < C4 && tr < rpp) {
+            float* p = sh + ((size_t)tr * tpr + tc) * 12;
+            p[0] = sg.x; p[1] = sg.y; p[2] = sg.z; p[3] = sg.w; p[4] = sga.x; p[5] = sga.y; p[6] = sga.z; p[7] = sga.w;
+            p[8] = sgb.x; p[9] = sgb.y; p[10] = sgb.z; p[11] = sgb.w;
+        }
+        __syncthreads();
+        if (tr == 0 && c4 < C4) {
+            float a[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (int rr = 0; rr < rpp; ++rr) {
+                const float* p = sh + ((size_t)rr * tpr + tc) * 12;
+#pragma unroll
+                for (int k = 0; k < 12; ++k) a[k] += p[k];
+            }
+            float* oa = partial_a + (size_t)blockIdx.x * 2 * C;
+            float* ob = partial_b + (size_t)blockIdx.x * 2 * C;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { oa[c4 * 4 + k] = a[k]; oa[C + c4 * 4 + k] = a[4 + k]; ob[c4 * 4 + k] = a[k]; ob[C + c4 * 4 + k] = a[8 + k]; }
+        }
+    }
+}
+template <typename T>
+__global__ void bn_bwd_apply_pair_kernel(const T* __restrict__ ya, const T* __restrict__ yb, const T* g, const float4* __restrict__ ca,
+                                         const float4* __restrict__ cb, T* dya, T* dyb, long total4, int C4, const T* __restrict__ ro, T* gm) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        float4 gv = Act<T>::ld4(g + i * 4);
+        const float4 av = Act<T>::ld4(ya + i * 4), bv = Act<T>::ld4(yb + i * 4), ov = Act<T>::ld4(ro + i * 4);
+        gv.x = ov.x > 0.f ? gv.x : 0.f; gv.y = ov.y > 0.f ? gv.y : 0.f; gv.z = ov.z > 0.f ? gv.z : 0.f; gv.w = ov.w > 0.f ? gv.w : 0.f;
+        if (gm) Act<T>::st4(gm + i * 4, gv);
+        {
+            const float4 a = ca[c], b = ca[C4 + c], d = ca[2 * C4 + c];
+            float4 o;
+            o.x = a.x * gv.x + b.x + d.x * av.x; o.y = a.y * gv.y + b.y + d.y * av.y;
+            o.z = a.z * gv.z + b.z + d.z * av.z; o.w = a.w * gv.w + b.w + d.w * av.w;
+            asm volatile("" : "+v"(o.x), "+v"(o.y), "+v"(o.z), "+v"(o.w));      // (keeps the storage conversion a rounding of its own, as in bn_bwd_apply_kernel)
+            Act<T>::st4(dya + i * 4, o);
+        }
+        {
+            const float4 a = cb[c], b = cb[C4 + c], d = cb[2 * C4 + c];
+            float4 o;
+            o.x = a.x * gv.x + b.x + d.x * bv.x; o.y = a.y * gv.y + b.y + d.y * bv.y;
+            o.z = a.z * gv.z + b.z + d.z * bv.z; o.w = a.w * gv.w + b.w + d.w * bv.w;
+            // (no barrier here: the shortcut's single pass - bn_bwd_apply_kernel<T, 0> - lets the compiler fold its last FMA and the f16 conversion
+            //  into v_fma_mixlo_f16, the <T, 2> form above does not; the bit-equality test of the two paths watches over both choices)
+            Act<T>::st4(dyb + i * 4, o);
+        }
+    }
+}
+extern "C" int tri_bn_bwd_pair_reduce(const void* ya, const void* yb, const void* g, const void* relu_out, long M, int C, float* partial_a,
+                                      float* partial_b, int act_fmt, void* stream) {
+    if (C % 4 || !relu_out) { tri_set_error("tri_bn_bwd_pair_reduce: C % 4 == 0 and the saved output are required"); return TRI_ERR_ARG; }
+    const int rows = bnb_rows(M), nblk = (int)((M + rows - 1) / rows);
+    const int C4 = C / 4, tpr = C4 < 256 ? C4 : 256, rpp = 256 / tpr;
+    const size_t smem = (size_t)rpp * tpr * 12 * sizeof(float);
+    TRI_ACT_DISPATCH(act_fmt, bn_bwd_reduce_pair_kernel<T><<<nblk, 256, smem, (hipStream_t)stream>>>(
+        (const T*)ya, (const T*)yb, (const T*)g, M, C, partial_a, partial_b, rows, (const T*)relu_out));
+    return tri_check_launch("tri_bn_bwd_pair_reduce");
+}
+extern "C" int tri_bn_bwd_pair_finalize(const float* partial_a, const float* partial_b, int nblk, int C, int count_host, const float* gamma_a,
+                                        const float* mean_a, const float* invstd_a, float* buf_a, const float* gamma_b, const float* mean_b,
+                                        const float* invstd_b, float* buf_b, float out_scale, void* stream) {
+    bn_bwd_finalize_pair_kernel<<<2 * C, 256, 0, (hipStream_t)stream>>>(partial_a, partial_b, nblk, C, count_host, gamma_a, mean_a, invstd_a, buf_a,
+                                                                       gamma_b, mean_b, invstd_b, buf_b, out_scale);
+    return tri_check_launch("tri_bn_bwd_pair_finalize");
+}
+extern "C" int tri_bn_bwd_pair_apply(const void* ya, const void* yb, const void* g, const void* relu_out, const float* buf_a, const float* buf_b,
+                                     void* dya, void* dyb, void* g_masked, long M, int C, int act_fmt, void* stream) {
+    if (C % 4) { tri_set_error("tri_bn_bwd_pair_apply: C must be a multiple of 4"); return TRI_ERR_ARG; }
+    const long total4 = M * (C / 4);
+    TRI_ACT_DISPATCH(act_fmt, bn_bwd_apply_pair_kernel<T><<<ew_grid(total4), 256, 0, (hipStream_t)stream>>>(
+        (const T*)ya, (const T*)yb, (const T*)g, (const float4*)(buf_a + 2 * C), (const float4*)(buf_b + 2 * C), (T*)dya, (T*)dyb, total4, C / 4,
+        (const T*)relu_out, (T*)g_masked));
+    return tri_check_launch("tri_bn_bwd_pair_apply");
 }
 
 // ---- BatchNorm backward of a TINY tensor in one launch (tri_bn_bwd_small)

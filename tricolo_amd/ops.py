@@ -838,6 +838,27 @@ def bn_bwd(y, g, co: BNCoeffs, gamma, count_dev=None, count_host=0, row_mask=Non
     return dy, buf[0], buf[1]
 
 
+def bn_bwd_pair(ya, coa: BNCoeffs, gamma_a, yb, cob: BNCoeffs, gamma_b, g, relu_out, count_host, g_masked=None, out_scale: float = 1.0):
+    """BatchNorm backward of bn_a(ya) and bn_b(yb) under out = relu(bn_a(ya) + bn_b(yb)) (bn2 and the shortcut's BatchNorm of a
+    down-sampling BasicBlock): -> (dya, dgamma_a, dbeta_a, dyb, dgamma_b, dbeta_b); g_masked (may alias g) receives g * (out > 0).
+    Three launches for both tensors; the values of bn_bwd(ya, g, ..., relu_out=out, g_masked=...) followed by bn_bwd(yb, g_masked, ...)."""
+    C = ya.shape[-1]
+    M = ya.numel() // C
+    assert ya.dtype == g.dtype == yb.dtype == relu_out.dtype and ya.shape == yb.shape and _sync_world() == 1
+    nblk = lib().tri_bn_bwd_num_blocks(M)
+    partial = torch.empty((2, nblk, 2, C), dtype=torch.float32, device=ya.device)
+    check(lib().tri_bn_bwd_pair_reduce(ptr(_act(ya)), ptr(_act(yb)), ptr(_act(g)), ptr(relu_out), M, C, ptr(partial[0]), ptr(partial[1]), _abf(ya),
+                                       stream()), "tri_bn_bwd_pair_reduce")
+    buf = torch.empty((2, 5, C), dtype=torch.float32, device=ya.device)
+    check(lib().tri_bn_bwd_pair_finalize(ptr(partial[0]), ptr(partial[1]), nblk, C, int(count_host), ptr(gamma_a), ptr(coa.mean), ptr(coa.invstd),
+                                         ptr(buf[0]), ptr(gamma_b), ptr(cob.mean), ptr(cob.invstd), ptr(buf[1]), float(out_scale), stream()),
+          "tri_bn_bwd_pair_finalize")
+    dya, dyb = torch.empty_like(ya), torch.empty_like(yb)
+    check(lib().tri_bn_bwd_pair_apply(ptr(ya), ptr(yb), ptr(g), ptr(relu_out), ptr(buf[0]), ptr(buf[1]), ptr(dya), ptr(dyb), ptr(g_masked), M, C,
+                                      _abf(ya), stream()), "tri_bn_bwd_pair_apply")
+    return dya, buf[0, 0], buf[0, 1], dyb, buf[1, 0], buf[1, 1]
+
+
 # ------------------------------------------------------------------------------------------------ pooling
 def bn_relu_pool3d_fwd(y, co: BNCoeffs, mask, B, D, C, want_mask: bool = True):
     """want_mask=False: the pooled level's site mask is not written (the caller has it from mask_pyramid); returns (pooled, None)."""
