@@ -955,7 +955,7 @@ def test_ntxent_large_batch_against_float64():
 
 
 @pytest.mark.parametrize("precision,tol", [("bf16x3", 2e-5), ("bf16", 2e-2), ("f16", 2e-3)])      # f16: single f16 products (ops.gru_mode)
-@pytest.mark.parametrize("B,L", [(8, 96), (19, 7)])
+@pytest.mark.parametrize("B,L", [(8, 96), (19, 7), (3, 2), (33, 13)])      # (round 6: six unrolled steps - lengths that are not multiples of 6, shorter than the prefetch depth)
 def test_gru_recurrence_matches_explicit_equations(precision, tol, B, L):
     from oracle.modules import gru_explicit
     g = torch.Generator().manual_seed(3)
